@@ -1,0 +1,119 @@
+"""Deterministic synthetic inputs for tests and bench.py.
+
+The licensed SMPL-H pickle, ``smpl_faces.npy`` and the generator checkpoint are not distributable, so every
+measurement uses: the T-pose template ``v`` of ``mapper_uv.txt`` as ``v_template``, random SMPL-H blend
+tensors of the documented scales, seeded poses around the upright canonical view (global rotation pi about
+x, reference ``services/base_runner.py:26``), and seeded generator weights.  Everything derives from
+``numpy.random.RandomState`` keyed by (seed, name) so the reference-side golden script, the oracle and the
+HIP path all see bit-identical inputs without storing them.
+"""
+import os
+import pickle
+import zlib
+
+import numpy as np
+
+from .geometry import mesh
+
+NUM_VERTS = 6890
+NUM_FACES = 13776
+NUM_JOINTS_SMPLH = 52
+
+
+def _rs(seed, name):
+    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def _softmax(x, axis):
+    x = x - x.max(axis=axis, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def smplh_model_dict(seed=0, topo=None):
+    """A synthetic SMPL-H parameter dict with the pickle schema the reference reads
+    (smplx/body_models.py:200-296, bodynets/batch_smplh.py:105-131)."""
+    topo = topo or mesh.load_topology()
+    nj = NUM_JOINTS_SMPLH
+    parents = np.zeros(nj, dtype=np.int64)
+    r = _rs(seed, "parents")
+    for j in range(1, nj):
+        parents[j] = r.randint(max(0, j - 4), j)          # topologically sorted: parents[j] < j
+    kintree = np.stack([parents, np.arange(nj, dtype=np.int64)], axis=0)
+    kintree[0, 0] = 4294967295 % (2 ** 31)                # root marker (overwritten by -1 in the loader)
+    return {
+        "v_template": topo["v"].astype(np.float64),
+        "shapedirs": (0.01 * _rs(seed, "shapedirs").standard_normal((NUM_VERTS, 3, 10))),
+        "posedirs": (0.001 * _rs(seed, "posedirs").standard_normal((NUM_VERTS, 3, (nj - 1) * 9))),
+        "J_regressor": _softmax(_rs(seed, "J_regressor").standard_normal((nj, NUM_VERTS)), axis=1),
+        "weights": _softmax(_rs(seed, "weights").standard_normal((NUM_VERTS, nj)), axis=1),
+        "kintree_table": kintree,
+        "f": topo["faces_uv"].astype(np.uint32),
+        "hands_meanl": np.zeros(45), "hands_meanr": np.zeros(45),
+        "hands_componentsl": np.eye(45), "hands_componentsr": np.eye(45),
+    }
+
+
+def write_smplh_pickle(path, seed=0):
+    with open(path, "wb") as fp:
+        pickle.dump(smplh_model_dict(seed), fp, protocol=2)
+    return path
+
+
+def write_smpl_faces_npy(path, topo=None):
+    """``smpl_faces.npy`` stand-in: the faces of mapper_uv.txt (SMPL winding), SURVEY section 0.9."""
+    topo = topo or mesh.load_topology()
+    np.save(path, topo["faces_uv"].astype(np.int32))
+    return path
+
+
+def _rotvec_compose_x_pi(extra):
+    """Rotation vector of R_x(pi) * R(extra) (small extra), via quaternions; returns (3,) float64."""
+    qa = np.array([0.0, 1.0, 0.0, 0.0])                                # pi about x
+    ang = np.linalg.norm(extra)
+    qb = np.array([1.0, 0, 0, 0]) if ang < 1e-12 else np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * extra / ang])
+    w = qa[0] * qb[0] - qa[1:] @ qb[1:]
+    v = qa[0] * qb[1:] + qb[0] * qa[1:] + np.cross(qa[1:], qb[1:])
+    n = np.linalg.norm(v)
+    theta = 2 * np.arctan2(n, w)
+    return v / n * theta
+
+
+def smpl_sequence(n_frames, seed=0, pose_dim=72, pose_scale=0.2):
+    """(n,3+pose_dim+10) fp32 SMPL params: cam jitter, pi-about-x global rotation, small joint rotations."""
+    r = _rs(seed, f"smpls{pose_dim}")
+    out = np.zeros((n_frames, 3 + pose_dim + 10), dtype=np.float32)
+    for t in range(n_frames):
+        out[t, 0] = r.uniform(0.7, 0.9)
+        out[t, 1] = r.uniform(-0.1, 0.1)
+        out[t, 2] = r.uniform(-0.35, -0.25)
+        pose = pose_scale * r.standard_normal(pose_dim)
+        pose[0:3] = _rotvec_compose_x_pi(0.3 * pose[0:3])
+        out[t, 3:3 + pose_dim] = pose
+        out[t, -10:] = 0.5 * r.standard_normal(10)
+    return out
+
+
+def param_array(name, shape, seed=0):
+    """Seeded value for one generator tensor: N(0,1)/sqrt(fan_in) for kernels, 0.1*N(0,1) for biases."""
+    r = _rs(seed, "param:" + name)
+    shape = tuple(int(s) for s in shape)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return (r.standard_normal(shape) / np.sqrt(max(fan_in, 1))).astype(np.float32)
+    return (0.1 * r.standard_normal(shape)).astype(np.float32)
+
+
+def fill_state_dict(shapes, seed=0):
+    """{name: shape} -> {name: fp32 ndarray}, independent of torch's RNG and of construction order."""
+    return {k: param_array(k, shapes[k], seed) for k in sorted(shapes)}
+
+
+def uniform_image(shape, seed, name):
+    return _rs(seed, name).uniform(-1.0, 1.0, size=shape).astype(np.float32)
+
+
+def tmp_asset_dir():
+    d = os.environ.get("LWG_TMPDIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "lwg_synth")
+    os.makedirs(d, exist_ok=True)
+    return d

@@ -1,0 +1,386 @@
+"""TEST INFRASTRUCTURE ONLY - CPU oracle for the per-frame synthesis path of iPERCore's Liquid Warping GAN.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module,
+and only as the checker.  Nothing under ``ipercore_amd/`` imports it; the product path has no CPU fallback.
+
+Each function is a plain fp32 (torch-CPU / numpy) restatement of one reference function and cites the
+file:line (relative to the iPERCore checkout) it follows.  Pinning status:
+
+* everything except the rasterizer is pinned against outputs of the reference's own Python, imported in the
+  authoring container by ``tests/golden/make_golden.py`` (fixtures in ``tests/golden/*.npz``; checked by
+  ``tests/test_oracle_golden.py``);
+* ``rasterize_fim_wim`` (``oracle/raster_oracle.c``) is **parity unpinned**: the reference delegates it to
+  the third-party CUDA package ``neural_renderer`` (iPERDance/neural_renderer@e5f54f7, requirements/build.txt:3)
+  whose source is absent; it restates the published upstream algorithm and is anchored on the reference's
+  call sites and on the identity-warp property (see the C file's header).
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liblwg_oracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE, "liblwg_oracle.so"])
+        _LIB = ctypes.CDLL(path)
+        _LIB.lwg_oracle_rasterize_fim_wim.restype = None
+        _LIB.lwg_oracle_rasterize_fim_wim.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+            ctypes.c_void_p, ctypes.c_void_p]
+    return _LIB
+
+
+# --------------------------------------------------------------------------------------------------
+# a2: SMPL-H linear blend skinning
+# --------------------------------------------------------------------------------------------------
+def quat_to_rotmat(q):
+    """(N,4) wxyz -> (N,3,3), renormalising first (tools/utils/geometry/rotations.py:355-375)."""
+    q = q / q.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz = w * x, w * y, w * z
+    xy, xz, yz = x * y, x * z, y * z
+    m = torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                     2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                     2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1)
+    return m.view(-1, 3, 3)
+
+
+def rotvec_to_rotmat(rv):
+    """(N,3) axis-angle -> (N,3,3) through a quaternion; angle = ||rv + 1e-8|| (rotations.py:318-332)."""
+    ang = torch.norm(rv + 1e-8, p=2, dim=1).unsqueeze(-1)
+    axis = rv / ang
+    half = ang * 0.5
+    return quat_to_rotmat(torch.cat([torch.cos(half), torch.sin(half) * axis], dim=1))
+
+
+def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    """smplx/lbs.py:137-227 (pose2rot=True).  Returns verts (B,V,3), posed joints (B,J,3)."""
+    B = max(betas.shape[0], pose.shape[0])
+    nj = J_regressor.shape[0]
+    v_shaped = v_template + torch.einsum("bl,mkl->bmk", betas, shapedirs)          # lbs.py:185, :250-271
+    J = torch.einsum("bik,ji->bjk", v_shaped, J_regressor)                          # lbs.py:190, :230-247
+    R = rotvec_to_rotmat(pose.reshape(-1, 3)).view(B, nj, 3, 3)                     # lbs.py:201, :378-406
+    pose_feature = (R[:, 1:] - torch.eye(3)).reshape(B, -1)
+    v_posed = torch.matmul(pose_feature, posedirs).view(B, -1, 3) + v_shaped        # lbs.py:203-215
+    # batch_rigid_transform, lbs.py:321-375
+    rel = J.clone()
+    rel[:, 1:] = rel[:, 1:] - J[:, parents[1:]]
+    T = torch.zeros(B, nj, 4, 4)
+    T[:, :, :3, :3] = R
+    T[:, :, :3, 3] = rel
+    T[:, :, 3, 3] = 1.0
+    chain = [T[:, 0]]
+    for j in range(1, nj):
+        chain.append(torch.matmul(chain[int(parents[j])], T[:, j]))
+    G = torch.stack(chain, dim=1)
+    posed_joints = G[:, :, :3, 3]
+    Jh = F.pad(J.unsqueeze(-1), [0, 0, 0, 1])
+    A = G - F.pad(torch.matmul(G, Jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    Tv = torch.matmul(lbs_weights.unsqueeze(0).expand(B, -1, -1), A.view(B, nj, 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1)], dim=2)
+    verts = torch.matmul(Tv, vh.unsqueeze(-1))[:, :, :3, 0]
+    return verts, posed_joints
+
+
+class SMPLHModel:
+    """Buffers of bodynets/batch_smplh.py:36-131 + smplx/body_models.py:200-296, from the pickle dict."""
+
+    def __init__(self, data):
+        f32 = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))                # noqa: E731
+        self.v_template = f32(data["v_template"])
+        self.shapedirs = f32(data["shapedirs"])
+        pd = np.asarray(data["posedirs"])
+        self.posedirs = f32(np.reshape(pd, [-1, pd.shape[-1]]).T)
+        self.J_regressor = f32(data["J_regressor"])
+        parents = torch.tensor(np.asarray(data["kintree_table"][0]).astype(np.int64))
+        parents[0] = -1
+        self.parents = parents
+        self.lbs_weights = f32(data["weights"])
+        self.hands_mean = f32(np.concatenate([data["hands_meanl"], data["hands_meanr"]]))
+
+
+def link(verts, linked_ids):
+    """bodynets/base_smpl.py:28-50."""
+    out = verts.clone()
+    ids = torch.as_tensor(linked_ids).long()
+    if ids.dim() == 2:
+        out[:, ids[:, 0]] = verts[:, ids[:, 1]]
+    else:
+        for i in range(verts.shape[0]):
+            on = ids[i, :, 2] == 1
+            out[i, ids[i, on, 0]] = verts[i, ids[i, on, 1]]
+    return out
+
+
+def smplh_get_details(model, theta, offsets=0, links_ids=None):
+    """bodynets/base_smpl.py:107-142 over bodynets/batch_smplh.py:137-180."""
+    theta = torch.as_tensor(theta, dtype=torch.float32)
+    cam, pose, shape = theta[:, 0:3], theta[:, 3:-10].contiguous(), theta[:, -10:].contiguous()
+    if pose.shape[1] == 72:
+        pose = torch.cat([pose[:, 0:66], model.hands_mean.repeat(pose.shape[0], 1)], dim=1)
+    verts, j3d = lbs(shape, pose, model.v_template + torch.as_tensor(offsets, dtype=torch.float32),
+                     model.shapedirs, model.posedirs, model.J_regressor, model.parents, model.lbs_weights)
+    if links_ids is not None:
+        verts = link(verts, links_ids)
+    j2d = cam[:, None, 0:1] * (j3d[:, :, :2] + cam[:, None, 1:])                    # base_smpl.py:7-18
+    return {"theta": theta, "cam": cam, "pose": theta[:, 3:-10].contiguous(), "shape": shape,
+            "verts": verts, "j2d": j2d, "j3d": j3d}
+
+
+def cam_swap(src_cam, ref_cam, first_cam, strategy="smooth"):
+    """tools/utils/geometry/cam_pose_utils.py:17-50."""
+    if strategy == "smooth":
+        cam = src_cam.clone()
+        cam[:, 1:] += ref_cam[:, 1:] - first_cam[:, 1:]
+        cam[:, 0] = cam[:, 0] * ref_cam[:, 0] / first_cam[:, 0]
+        return cam
+    if strategy == "ref_txty":
+        cam = src_cam.clone()
+        cam[:, 1:] = ref_cam[:, 1:]
+        return cam
+    return src_cam if strategy == "source" else ref_cam
+
+
+# --------------------------------------------------------------------------------------------------
+# a3/a4: projection + rasterizer
+# --------------------------------------------------------------------------------------------------
+EYE_Z = -(1.0 / np.tan(np.radians(30.0)) + 1.0)                                       # renders/nmr.py:225
+
+
+def look_at(vertices, eye):
+    """Upstream neural_renderer.look_at (at = 0, up = +y): rotate/translate into the eye frame."""
+    eye = torch.tensor(eye, dtype=torch.float32)
+    up = torch.tensor([0.0, 1.0, 0.0])
+    z = F.normalize(-eye, dim=0, eps=1e-5)
+    x = F.normalize(torch.cross(up, z, dim=0), dim=0, eps=1e-5)
+    y = F.normalize(torch.cross(z, x, dim=0), dim=0, eps=1e-5)
+    r = torch.stack([x, y, z], dim=0)
+    return torch.matmul(vertices - eye, r.t())
+
+
+def project_faces(cam, verts, faces):
+    """renders/nmr.py:34-52,:326-336: s(xy+t) keeping z, flip y, look_at, gather -> (B,nf,3,3)."""
+    s = cam[:, 0].view(-1, 1, 1)
+    t = cam[:, 1:3].view(cam.shape[0], 1, -1)
+    proj = torch.cat([s * (verts[:, :, :2] + t), verts[:, :, 2:3]], dim=2).clone()
+    proj[:, :, 1] *= -1
+    v = look_at(proj, [0.0, 0.0, float(EYE_Z)])
+    return v[:, torch.as_tensor(faces).long()]                                         # nr.vertices_to_faces
+
+
+def rasterize_fim_wim(faces_v, image_size, near=0.1, far=100.0):
+    """(B,nf,3,3) -> fim (B,S,S) int32, wim (B,S,S,3) fp32 via oracle/raster_oracle.c."""
+    fv = np.ascontiguousarray(np.asarray(faces_v, dtype=np.float32))
+    B, nf = fv.shape[0], fv.shape[1]
+    S = int(image_size)
+    fim = np.empty((B, S, S), dtype=np.int32)
+    wim = np.empty((B, S, S, 3), dtype=np.float32)
+    _lib().lwg_oracle_rasterize_fim_wim(fv.ctypes.data, B, nf, S, ctypes.c_float(near), ctypes.c_float(far),
+                                        fim.ctypes.data, wim.ctypes.data)
+    return torch.from_numpy(fim), torch.from_numpy(wim)
+
+
+def render_fim_wim(cam, verts, faces, image_size):
+    """renders/nmr.py:319-342 -> f2pts (B,nf,3,2) (y un-flipped), fim, wim."""
+    fv = project_faces(cam, verts, faces)
+    fim, wim = rasterize_fim_wim(fv.numpy(), image_size)
+    f2pts = fv[:, :, :, 0:2].clone()
+    f2pts[:, :, :, 1] *= -1
+    return f2pts, fim, wim
+
+
+def render_uv_fim_wim(f_img2uvs, bs, image_size):
+    """renders/nmr.py:344-358."""
+    f = torch.as_tensor(f_img2uvs, dtype=torch.float32).repeat(bs, 1, 1, 1).clone()
+    f[:, :, :, 1] *= -1
+    return rasterize_fim_wim(f.numpy(), image_size)
+
+
+# --------------------------------------------------------------------------------------------------
+# a5/a7/a8/a9: codes and flows
+# --------------------------------------------------------------------------------------------------
+def encode_fim(map_fn, fim, transpose=True):
+    """renders/nmr.py:390-401 - fim == -1 picks the LAST row by negative indexing."""
+    enc = torch.as_tensor(map_fn)[fim.long()]
+    return enc.permute(0, 3, 1, 2) if transpose else enc
+
+
+def cal_bc_transform(src_f2pts, dst_fims, dst_wims):
+    """renders/nmr.py:713-757: T[p] = sum_k wim[p,k] * src_f2pts[fim[p],k,:], background -> (-2,-2)."""
+    B, S = dst_fims.shape[0], dst_fims.shape[1]
+    T = -2 * torch.ones((B, S * S, 2), dtype=torch.float32)
+    for i in range(B):
+        idx = dst_fims[i].long().reshape(-1)
+        w = dst_wims[i].reshape(-1, 3)
+        on = idx != -1
+        T[i, on] = (src_f2pts[i][idx[on]] * w[on][:, :, None]).sum(dim=1)
+    return T.view(B, S, S, 2)
+
+
+def make_tsf_inputs(uv_img, f_uvs2img, cond, fim, wim):
+    """models/flowcomposition.py:206-248 for nt == 1: cat[grid_sample(uv_img, Tuv2t), cond] -> (bs,6,h,w)."""
+    bs = cond.shape[0]
+    Tuv2t = cal_bc_transform(torch.as_tensor(f_uvs2img).repeat(bs, 1, 1, 1), fim, wim)
+    syn = F.grid_sample(uv_img.expand(bs, -1, -1, -1), Tuv2t, mode="bilinear", padding_mode="zeros",
+                        align_corners=False)
+    return torch.cat([syn, cond], dim=1), Tuv2t
+
+
+def make_trans_flow(src_f2pts, ref_fim, ref_wim):
+    """models/flowcomposition.py:514-567 (bs=1, temporal=False): Tst (1,ns,h,w,2)."""
+    ns = src_f2pts.shape[0]
+    T = cal_bc_transform(src_f2pts, ref_fim.repeat(ns, 1, 1), ref_wim.repeat(ns, 1, 1, 1))
+    return T.view(1, ns, T.shape[1], T.shape[2], 2)
+
+
+# --------------------------------------------------------------------------------------------------
+# a10/a11/a12/a15: AttLWB-SPADE generator, functional over a state_dict
+# --------------------------------------------------------------------------------------------------
+def _conv(sd, name, x, stride=1, pad=1):
+    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=pad)
+
+
+def _convT(sd, name, x):
+    return F.conv_transpose2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=2, padding=1)
+
+
+def lwb_transform(x, T):
+    """generators/attlwb_spade_resunet.py:175-191: flow resize (align_corners=True) then grid_sample."""
+    h, w = x.shape[-2:]
+    if T.shape[1] != h or T.shape[2] != w:
+        T = F.interpolate(T.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    return F.grid_sample(x, T, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def attention_lwb(sd, p, tsf_x, src_x, Tst):
+    """SelfAttentionLWB.forward :208-252 + SelfAttentionBlock :106-139 + SPADE :80-93 (temporal=False)."""
+    bs, ns, H, W, _ = Tst.shape
+    h, w = tsf_x.shape[-2:]
+    warp = lwb_transform(src_x, Tst.reshape(bs * ns, H, W, 2))
+    K = _conv(sd, p + ".fk", warp, pad=0).view(bs, ns, -1, h, w)
+    V = _conv(sd, p + ".fv", warp, pad=0).view(bs, ns, -1, h, w)
+    q = _conv(sd, p + ".fq", tsf_x, pad=0)
+    logits = (K * q.unsqueeze(1)).sum(dim=2, keepdim=True) / math.sqrt(K.shape[2])
+    alpha = torch.softmax(logits, dim=1)
+    x = (alpha * V).sum(dim=1)
+    normalized = F.instance_norm(tsf_x, eps=1e-5)
+    actv = F.relu(_conv(sd, p + ".spade.mlp_shared.0", x))
+    gamma = _conv(sd, p + ".spade.mlp_gamma", actv)
+    beta = _conv(sd, p + ".spade.mlp_beta", actv)
+    return normalized * (1 + gamma) + beta
+
+
+def _res_block(sd, p, x):
+    """ResidualBlock :14-25."""
+    return x + _conv(sd, p + ".main.2", F.relu(_conv(sd, p + ".main.0", x)))
+
+
+def gen_forward_src(sd, src_inputs, n_down=3, n_res=6):
+    """BaseAttentionLWBGenerator.forward_src(only_enc=True) :450-478."""
+    bs, ns, _, h, w = src_inputs.shape
+    x = src_inputs.view(bs * ns, -1, h, w)
+    enc = []
+    for i in range(n_down):
+        x = F.relu(_conv(sd, f"src_net.encoders.layers.{i}.0", x, stride=2))
+        enc.append(x)
+    res = []
+    for i in range(n_res):
+        x = _res_block(sd, f"src_net.res_blocks.{i}", x)
+        res.append(x)
+    return enc, res
+
+
+def gen_forward_tsf(sd, tsf_inputs, src_enc_outs, src_res_outs, Tst, n_down=3, n_res=6):
+    """BaseAttentionLWBGenerator.forward_tsf :480-535 (temporal=False) -> (tsf_img, tsf_mask)."""
+    x = tsf_inputs
+    enc = []
+    for i in range(n_down):
+        x = F.relu(_conv(sd, f"tsf_net_enc.layers.{i}.0", x, stride=2))
+        x = attention_lwb(sd, f"enc_attlwbs.{i}", x, src_enc_outs[i], Tst)
+        enc.append(x)
+    for i in range(n_res):
+        x = _res_block(sd, f"res_blocks.{i}", x)
+        x = attention_lwb(sd, f"res_attlwbs.{i}", x, src_res_outs[i], Tst)
+    for i in range(n_down):                                                      # SkipDecoder :316-357
+        x = F.relu(_convT(sd, f"tsf_net_dec.upconvs.{i}.0", x))
+        if i != n_down - 1:
+            x = F.relu(_conv(sd, f"tsf_net_dec.skippers.{i}.0", torch.cat([enc[n_down - 2 - i], x], dim=1)))
+    img = torch.tanh(_conv(sd, "tsf_img_reg.0", x, pad=2))
+    mask = torch.sigmoid(_conv(sd, "tsf_att_reg.0", x, pad=2))
+    return img, mask
+
+
+def gen_forward_bg(sd, bg_inputs, n_down=4, n_res=6):
+    """AttentionLWBGenerator.forward_bg :615-631 over ResNetInpaintor (generators/bg_inpaintor.py:24-60).
+
+    n_down = len(num_filters); Sequential indices follow the construction order of bg_inpaintor.py:31-57.
+    """
+    bs, ns, _, h, w = bg_inputs.shape
+    x = bg_inputs.view(bs * ns, -1, h, w)
+
+    def cv(name, t, stride, pad):
+        return F.conv2d(t, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=pad)
+
+    i = 0
+    x = F.relu(F.instance_norm(cv(f"bg_net.main.{i}", x, 1, 3), eps=1e-5))
+    i += 3
+    for _ in range(n_down - 1):
+        x = F.relu(F.instance_norm(cv(f"bg_net.main.{i}", x, 2, 1), eps=1e-5))
+        i += 3
+    for _ in range(n_res):
+        y = F.relu(F.instance_norm(cv(f"bg_net.main.{i}.main.0", x, 1, 1), eps=1e-5))
+        x = x + F.instance_norm(cv(f"bg_net.main.{i}.main.3", y, 1, 1), eps=1e-5)
+        i += 1
+    for _ in range(n_down - 1):
+        x = F.conv_transpose2d(x, sd[f"bg_net.main.{i}.weight"], sd.get(f"bg_net.main.{i}.bias"), stride=2, padding=1)
+        x = F.relu(F.instance_norm(x, eps=1e-5))
+        i += 3
+    x = torch.tanh(cv(f"bg_net.main.{i}", x, 1, 3))
+    return x.view(bs, ns, 3, h, w)
+
+
+def compose(tsf_img, tsf_mask, bg_img):
+    """models/imitator.py:393."""
+    return tsf_mask * bg_img + (1 - tsf_mask) * tsf_img
+
+
+def to_uint8_bgr(pred_chw):
+    """tools/utils/filesio/cv_utils.py:100-116 (normalize=True): CHW RGB [-1,1] -> HWC BGR uint8, truncation."""
+    img = np.transpose(np.asarray(pred_chw), (1, 2, 0))[:, :, ::-1]
+    return ((img + 1) / 2.0 * 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------------------
+# whole frame (a1..a13), used by parity tests and bench.py's cpu_baseline
+# --------------------------------------------------------------------------------------------------
+def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size):
+    """One iteration of Imitator.inference (models/imitator.py:341-395, temporal=False, cam "smooth").
+
+    tables: dict(smpl_faces, map_fn, f_uvs2img).  src_info: dict(cam, shape, offsets, links_ids, uv_img, bg,
+    f2pts (ns,nf,3,2), feats=(enc list, res list)).  Returns dict with pred and every intermediate.
+    """
+    tgt = torch.as_tensor(tgt_smpl, dtype=torch.float32).view(1, -1)
+    cam = cam_swap(src_info["cam"][0:1], tgt[:, 0:3], first_cam, "smooth")
+    ref_smpl = torch.cat([cam, tgt[:, 3:-10], src_info["shape"][0:1]], dim=1)
+    ref = smplh_get_details(model, ref_smpl, src_info.get("offsets", 0), src_info.get("links_ids"))
+    f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
+    cond = encode_fim(tables["map_fn"], fim)
+    tsf_inputs, Tuv2t = make_tsf_inputs(src_info["uv_img"], tables["f_uvs2img"], cond, fim, wim)
+    Tst = make_trans_flow(src_info["f2pts"], fim, wim)
+    enc, res = src_info["feats"]
+    img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(enc), n_res=len(res))
+    pred = compose(img, mask, src_info["bg"])
+    return {"pred": pred, "mask": mask, "img": img, "tsf_inputs": tsf_inputs, "Tst": Tst, "fim": fim, "wim": wim,
+            "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t}

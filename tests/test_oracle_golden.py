@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the reference's own Python
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from ipercore_amd import synthetic
+from ipercore_amd.geometry import mesh
+from oracle import lwg_oracle as orc
+
+S = 64
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _smplh():
+    return orc.SMPLHModel(synthetic.smplh_model_dict(seed=0))
+
+
+def _tables(topo):
+    uv, fim = mesh.obj_from_topology(topo, "uv"), mesh.obj_from_topology(topo, "fim")
+    return {
+        "smpl_faces": topo["faces_uv"].astype(np.int32),
+        "map_fn": mesh.create_mapping("uv_seg", fim, contain_bg=True).astype(np.float32),
+        "f_uvs2img": mesh.get_f2vts(uv, z=1)[:, :, 0:2].astype(np.float32),
+        "f_img2uvs": mesh.get_f2vts(fim, z=1).astype(np.float32),
+    }
+
+
+def _details72():
+    smpls72 = synthetic.smpl_sequence(3, seed=1, pose_dim=72)
+    offsets = (0.005 * synthetic._rs(3, "offsets").standard_normal((6890, 3))).astype(np.float32)
+    r = synthetic._rs(4, "links")
+    links = np.stack([r.randint(0, 6890, size=40), r.randint(0, 6890, size=40)], axis=1).astype(np.int64)
+    return orc.smplh_get_details(_smplh(), smpls72, torch.tensor(offsets), links)
+
+
+def test_smplh_matches_reference(golden):
+    d = _details72()
+    assert np.abs(d["verts"].numpy() - golden["smplh72/verts"]).max() <= 1e-5
+    assert np.abs(d["j3d"].numpy() - golden["smplh72/j3d"]).max() <= 1e-5
+    assert np.abs(d["j2d"].numpy() - golden["smplh72/j2d"]).max() <= 1e-5
+    d2 = orc.smplh_get_details(_smplh(), synthetic.smpl_sequence(2, seed=2, pose_dim=156), 0, None)
+    assert np.abs(d2["verts"].numpy()[:, ::5] - golden["smplh156/verts_sub"]).max() <= 1e-5
+    assert np.abs(d2["j3d"].numpy() - golden["smplh156/j3d"]).max() <= 1e-5
+
+
+def test_cam_swap(golden):
+    cams = synthetic._rs(5, "cams").uniform(0.5, 1.0, size=(3, 1, 3)).astype(np.float32)
+    got = orc.cam_swap(torch.tensor(cams[0]), torch.tensor(cams[1]), torch.tensor(cams[2]), "smooth")
+    assert np.array_equal(got.numpy(), golden["cam_swap/smooth"])
+
+
+def test_render_wrapper_and_flows(golden, topo):
+    t = _tables(topo)
+    d = _details72()
+    f2pts, fim, wim = orc.render_fim_wim(d["cam"][0:1], d["verts"][0:1], t["smpl_faces"], S)
+    # the wrapper (projection, y flips, look_at) is bit-exact; fim/wim come from the same C oracle
+    assert sha(f2pts.numpy()) == str(golden["render/f2pts_sha"])
+    assert np.array_equal(fim.numpy(), golden["render/fim"])
+    assert np.array_equal(wim.numpy(), golden["render/wim"])
+    cond = orc.encode_fim(t["map_fn"], fim)
+    assert sha(cond.numpy()) == str(golden["render/cond_sha"])
+    uv_fim, _ = orc.render_uv_fim_wim(t["f_img2uvs"], 1, S)
+    assert sha(uv_fim.numpy()) == str(golden["render/uv_fim_sha"])
+    uv_img = torch.tensor(synthetic.uniform_image((1, 3, S, S), 6, "uv_img"))
+    tsf_inputs, Tuv2t = orc.make_tsf_inputs(uv_img, t["f_uvs2img"], cond, fim, wim)
+    assert np.abs(Tuv2t.numpy() - golden["render/Tuv2t"]).max() <= 1e-6
+    assert np.abs(tsf_inputs[:, 0:3].numpy() - golden["render/syn"]).max() <= 1e-5
+    src_f2pts, _, _ = orc.render_fim_wim(d["cam"][1:3], d["verts"][1:3], t["smpl_faces"], S)
+    Tst = orc.make_trans_flow(src_f2pts, fim, wim)
+    assert np.abs(Tst[0].numpy() - golden["render/Tst"]).max() <= 1e-6
+
+
+def _gen_case(golden, tag, nf, nres, bgf):
+    from ipercore_amd.networks import generator_param_shapes
+    shapes = generator_param_shapes(nf, nres, bgf)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(golden[f"gen_{tag}/nparams"])
+    keys = hashlib.sha256("\n".join(f"{k}:{tuple(shapes[k])}" for k in sorted(shapes)).encode()).hexdigest()
+    assert keys == str(golden[f"gen_{tag}/keys_sha"])
+    sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=7).items()}
+    ns = 2
+    src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    bg_inputs = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"))
+    Tst = torch.tensor(golden["render/Tst"]).view(1, ns, S, S, 2)
+    with torch.no_grad():
+        enc, res = orc.gen_forward_src(sd, src_inputs, n_down=len(nf), n_res=nres)
+        img, mask = orc.gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(nf), n_res=nres)
+        bg = orc.gen_forward_bg(sd, bg_inputs, n_down=len(bgf), n_res=nres)
+    assert np.abs(enc[-1].numpy()[:, ::8] - golden[f"gen_{tag}/enc2_sub"]).max() <= 1e-5
+    assert np.abs(res[-1].numpy()[:, ::8] - golden[f"gen_{tag}/res_last_sub"]).max() <= 1e-4
+    assert np.abs(img.numpy() - golden[f"gen_{tag}/img"]).max() <= 1e-4
+    assert np.abs(mask.numpy() - golden[f"gen_{tag}/mask"]).max() <= 1e-4
+    assert np.abs(bg.numpy() - golden[f"gen_{tag}/bg"]).max() <= 1e-4
+
+
+def test_generator_tiny(golden):
+    _gen_case(golden, "tiny", [32, 64, 64], 2, [32, 64, 64])
+
+
+def test_generator_full(golden):
+    _gen_case(golden, "full", [64, 128, 256], 6, [64, 128, 128, 256])
+
+
+def test_identity_warp_property(topo):
+    """T = cal_bc_transform(f2pts, fim, wim) reproduces the grid_sample coordinate of each
+    covered pixel - the property the reference relies on when it uses T as a sampling grid."""
+    t = _tables(topo)
+    d = _details72()
+    for size in (64, 128):
+        f2pts, fim, wim = orc.render_fim_wim(d["cam"][0:1], d["verts"][0:1], t["smpl_faces"], size)
+        T = orc.cal_bc_transform(f2pts, fim, wim)[0].numpy()
+        on = fim[0].numpy() >= 0
+        assert 0.05 < on.mean() < 0.6
+        rr, cc = np.nonzero(on)
+        want = np.stack([(2 * cc + 1) / size - 1, (2 * rr + 1) / size - 1], axis=1)
+        err = np.abs(T[on] - want)
+        # interior pixels are exact to rounding; silhouette pixels have clamped weights (<= 1 pixel)
+        assert np.median(err) < 1e-5
+        assert err.max() < 2.0 / size
+
+
+def test_uv_atlas_front_facing(topo):
+    """All 13776 UV-atlas triangles of mapper_fim_enc.txt survive back-face culling."""
+    t = _tables(topo)
+    f = t["f_img2uvs"].copy()
+    f[:, :, 1] *= -1
+    keep = (f[:, 2, 1] - f[:, 0, 1]) * (f[:, 1, 0] - f[:, 0, 0]) >= (f[:, 1, 1] - f[:, 0, 1]) * (f[:, 2, 0] - f[:, 0, 0])
+    assert keep.all()
+    uv_fim, uv_wim = orc.render_uv_fim_wim(t["f_img2uvs"], 1, 128)
+    assert (uv_fim >= 0).float().mean() > 0.3
+    assert torch.allclose(uv_wim.sum(-1)[uv_fim >= 0], torch.ones(1), atol=1e-5)
