@@ -1,0 +1,159 @@
+/*
+ * lwg_hip.h - C ABI of liblwg_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the per-frame
+ * synthesis path of iPERCore's Liquid Warping GAN (Imitator.inference, models/imitator.py:327-395).
+ *
+ * The reference has no FFI: its boundary for this path is Python calling (a) torch ATen ops and (b) the
+ * third-party CUDA extension `neural_renderer` (requirements/build.txt:3).  Each entry point below names the
+ * reference call it replaces (file:line relative to the iPERCore checkout).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions (every function):
+ *   - all pointers are DEVICE pointers into buffers owned by the caller (PyTorch-ROCm allocations);
+ *     kernels never allocate, never synchronise, and are enqueued on `stream` (a hipStream_t passed as void*);
+ *   - tensors are contiguous; activations are NHWC fp32; face/vertex/pixel indices are int32;
+ *   - the return value is a hipError_t cast to int (0 = hipSuccess; 1 = hipErrorInvalidValue is also used
+ *     for contract violations detected on the host side before any launch).
+ */
+#ifndef LWG_HIP_H
+#define LWG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lwg_stream_t; /* hipStream_t */
+
+#define LWG_ABI_VERSION 1
+int lwg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense convolution on the matrix cores (fp32 MFMA implicit GEMM), NHWC.
+ * Replaces F.conv2d / F.conv_transpose2d as called by
+ *   generators/attlwb_spade_resunet.py:18-22 (ResidualBlock), :73-78,:87-92 (SPADE), :202-204 (fq/fk/fv),
+ *   :268-271 (Encoder), :331-340,:353-355 (SkipDecoder), generators/bg_inpaintor.py:31-57.
+ * ------------------------------------------------------------------------------------------------ */
+#define LWG_MAX_TAPS 52
+enum { LWG_EPI_NONE = 0, LWG_EPI_RESIDUAL = 1, LWG_EPI_SPADE = 2 };
+enum { LWG_ACTIVATION_NONE = 0, LWG_ACTIVATION_RELU = 1, LWG_ACTIVATION_TANH = 2, LWG_ACTIVATION_SIGMOID = 3 };
+
+typedef struct LwgConvArgs {
+    const float* x0;   /* input, NHWC (B,H,W,C0) */
+    const float* x1;   /* optional second input concatenated along C (skip connection), (B,H,W,C1), or NULL */
+    int C0, C1;        /* Cin = C0 + C1; Cin % 32 == 0 (C0 % 32 == 0 when C1 > 0) or Cin in {4,8,16} with C1 == 0 */
+    int B, H, W;       /* input dims */
+    int OH, OW;        /* GEMM row grid: rows are (b, oy, ox), oy < OH, ox < OW */
+    int M;             /* B*OH*OW */
+    int stride;        /* input sample position = (oy*stride + dy[tap], ox*stride + dx[tap]); zero outside */
+    int ntaps;         /* number of kernel taps (<= LWG_MAX_TAPS) */
+    int cshift;        /* log2(Cin/4) when Cin < 32, else unused */
+    const float* w;    /* packed weights [ceil(ntaps*Cin/32)*8][N][4]: k = tap*Cin + c -> w[k/4][n][k%4] */
+    int N;             /* GEMM columns (Cout, or 2*Cout gamma|beta interleaved by 32 for LWG_EPI_SPADE) */
+    const float* bias; /* [N] or NULL */
+    float* y;          /* output NHWC (B,YH,YW,YC); row (b,oy,ox) -> pixel (oy*omul+ooy, ox*omul+oox) */
+    int YH, YW, YC, ycoff; /* channel n is written at ycoff + n */
+    int omul, ooy, oox;
+    int epi;           /* LWG_EPI_* */
+    int act;           /* LWG_ACTIVATION_* applied last */
+    const float* res;  /* LWG_EPI_RESIDUAL: tensor shaped like y, added before the activation */
+    const float* xn;   /* LWG_EPI_SPADE: tensor to normalise (B,YH,YW,YC) */
+    const float* mean; /* LWG_EPI_SPADE: (B,YC) instance mean   */
+    const float* rstd; /* LWG_EPI_SPADE: (B,YC) 1/sqrt(var+eps) */
+    signed char dy[LWG_MAX_TAPS];
+    signed char dx[LWG_MAX_TAPS];
+} LwgConvArgs;
+
+int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.
+ * Replaces nn.InstanceNorm2d at attlwb_spade_resunet.py:62,:83 and bg_inpaintor.py:14,17,33,40,51.
+ *   x (B,HW,C) -> mean (B,C), rstd (B,C) = 1/sqrt(var + eps).   ws: >= B*C*nsplit*3 floats of scratch.
+ * lwg_instnorm_apply_nhwc_f32: y = act((x - mean) * rstd) (+ res), used by the background network.
+ * ------------------------------------------------------------------------------------------------ */
+int lwg_instnorm_stats_nhwc_f32(const float* x, int B, int HW, int C, float eps, float* mean, float* rstd,
+                                float* ws, int nsplit, lwg_stream_t stream);
+int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* res,
+                                float* y, int B, int HW, int C, int act, lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Liquid Warping Block, attention form (one of 9 sites per frame).
+ * Replaces LWB.resize_trans + LWB.transform (attlwb_spade_resunet.py:175-191), the fk/fv 1x1 convs on the
+ * warped features (:226-227) and SelfAttentionBlock (:106-139).  Ks/Vs are Wk*x_src / Wv*x_src (no bias),
+ * computed once per source with lwg_conv2d_nhwc_f32; the biases are added after the warp, as the reference
+ * does.  q (B,h,w,C), Ks/Vs (ns,h,w,C) shared by all frames (src_batched = 0) or (B*ns,h,w,C) (= 1),
+ * T (B,ns,S,S,2), out (B,h,w,C); C in {32,64,128,256}.
+ * ------------------------------------------------------------------------------------------------ */
+int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
+                          const float* T, float* out, int B, int ns, int h, int w, int C, int S,
+                          int src_batched, lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Renderer (replaces the `neural_renderer` CUDA package as used by renders/nmr.py).
+ * lwg_project_faces_f32:   nmr.py:34-52 orthographic_proj_withz_idrot + :331 y flip + :333 nr.look_at
+ *                          (eye (0,0,-eye_dist): identity rotation) + :336 nr.vertices_to_faces, and the
+ *                          f2pts of :339-340.  verts (B,nv,3), cam (B,3), faces (nf,3) int32 ->
+ *                          faces_v (B,nf,3,3) and/or f2pts (B,nf,3,2).
+ * lwg_rasterize_fim_wim_f32: nmr.py:337,356 nr.rasterize_face_index_map_and_weight_map(faces, S, False):
+ *                          faces_v (B,nf,3,3) -> fim (B,S,S) int32 (-1 = background), wim (B,S,S,3).
+ *                          ws: lwg_rasterize_ws_bytes(B,nf) bytes of scratch.
+ * ------------------------------------------------------------------------------------------------ */
+size_t lwg_rasterize_ws_bytes(int B, int nf);
+int lwg_project_faces_f32(const float* verts, const float* cam, const int32_t* faces, int B, int nv, int nf,
+                          float eye_dist, float* faces_v, float* f2pts, lwg_stream_t stream);
+int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, int S, float near, float far, int32_t* fim,
+                              float* wim, void* ws, lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow composition from (fim, wim).
+ * lwg_flow_compose_f32 fuses, for B target frames: encode_fim (nmr.py:390-401), cal_bc_transform with the UV
+ *   table (nmr.py:713-757 as called at flowcomposition.py:240), the UV grid_sample (:242), the tsf_inputs
+ *   concat (:244) and make_trans_flow (:551-567).  map_fn (nf+1,3); f_uvs2img (nf,3,2); uv_img4 (Hu,Wu,4)
+ *   NHWC (4th channel ignored); src_f2pts (ns,nf,3,2).  Outputs: tsf_inputs (B,S,S,8) NHWC [syn3|cond3|0|0],
+ *   Tst (B,ns,S,S,2); optional cond_nchw (B,3,S,S) and Tuv (B,S,S,2) (NULL to skip).
+ * lwg_bc_transform_f32: cal_bc_transform for arbitrary per-batch tables f2pts (B,nf,3,2) -> T (B,S,S,2).
+ * lwg_encode_fim_f32:   map_fn[fim] for any (nf+1,D) table -> (B,D,S,S).
+ * ------------------------------------------------------------------------------------------------ */
+int lwg_flow_compose_f32(const int32_t* fim, const float* wim, int B, int S, const float* map_fn, int nf,
+                         const float* f_uvs2img, const float* uv_img4, int Hu, int Wu, const float* src_f2pts,
+                         int ns, float* tsf_inputs, float* Tst, float* cond_nchw, float* Tuv, lwg_stream_t stream);
+int lwg_bc_transform_f32(const float* f2pts, const int32_t* fim, const float* wim, int B, int S, int nf, float* T,
+                         lwg_stream_t stream);
+int lwg_encode_fim_f32(const int32_t* fim, const float* map_fn, int B, int S, int nf, int D, float* out,
+                       lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SMPL / SMPL-H linear blend skinning for B frames.
+ * Replaces smplx/lbs.py:137-227 (lbs) incl. rotations.py:318-375, lbs.py:321-375 and base_smpl.py:28-50
+ * (link, 2-D ids) and :7-18 (j2d).  pose rows are 3*nj axis-angle floats (row stride pose_stride);
+ * shapedirs (nv,3,nbeta); posedirs ((nj-1)*9, nv*3); J_regressor (nj,nv); parents (nj) int32;
+ * lbs_weights (nv,nj); offsets NULL | (nv,3) | (B,nv,3); links NULL | (nlinks,2) int32 (to, from).
+ * ws: lwg_smpl_lbs_ws_floats(B,nv,nj) floats.
+ * ------------------------------------------------------------------------------------------------ */
+size_t lwg_smpl_lbs_ws_floats(int B, int nv, int nj);
+int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float* beta, int beta_stride, int nbeta,
+                     const float* cam, int cam_stride, const float* v_template, const float* offsets, int off_batched,
+                     const float* shapedirs, const float* posedirs, const float* J_regressor, const int32_t* parents,
+                     const float* lbs_weights, const int32_t* links, int nlinks, int B, int nv, int nj, float* verts,
+                     float* j3d, float* j2d, float* ws, lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Output head + compositing: tsf_img_reg / tsf_att_reg (attlwb_spade_resunet.py:605-613, called :533) and
+ * Imitator.forward's pred = mask*bg + (1-mask)*img (models/imitator.py:393).
+ * x (B,S,S,C) NHWC; wpk [25][C][4] (outputs 0..2 image, 3 mask); bg (.,3,S,S) NCHW, batch stride bg_bstride
+ * floats (0 = one shared background).  pred (B,3,S,S), mask (B,1,S,S), img (B,3,S,S), each optional.
+ * lwg_nchw_to_nhwc_f32 / lwg_nhwc_to_nchw_f32: layout changes at the API edge ((B,C,P) <-> (B,P,Cp)).
+ * ------------------------------------------------------------------------------------------------ */
+int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
+                         float* pred, float* mask, float* img, lwg_stream_t stream);
+int lwg_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int Cp, int P, lwg_stream_t stream);
+int lwg_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int Cs, int P, lwg_stream_t stream);
+
+int lwg_device_cu_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWG_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of liblwg_hip.so (C ABI: include/lwg_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C ipercore_amd/csrc`` and travels with
+the source tree.  There is NO fallback: if the shared object is missing or a symbol is absent, importing the
+binding raises, and every op raises on non-CUDA tensors.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblwg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg_hip.h")
+
+LWG_MAX_TAPS = 52
+EPI_NONE, EPI_RESIDUAL, EPI_SPADE = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+c_f = ctypes.c_void_p  # device pointers travel as void*
+c_i = ctypes.c_int
+
+
+class LwgConvArgs(ctypes.Structure):
+    """Mirror of ``struct LwgConvArgs`` (include/lwg_hip.h) - field order and types must match."""
+    _fields_ = [
+        ("x0", c_f), ("x1", c_f),
+        ("C0", c_i), ("C1", c_i),
+        ("B", c_i), ("H", c_i), ("W", c_i),
+        ("OH", c_i), ("OW", c_i),
+        ("M", c_i), ("stride", c_i), ("ntaps", c_i), ("cshift", c_i),
+        ("w", c_f), ("N", c_i), ("bias", c_f),
+        ("y", c_f), ("YH", c_i), ("YW", c_i), ("YC", c_i), ("ycoff", c_i),
+        ("omul", c_i), ("ooy", c_i), ("oox", c_i),
+        ("epi", c_i), ("act", c_i),
+        ("res", c_f), ("xn", c_f), ("mean", c_f), ("rstd", c_f),
+        ("dy", ctypes.c_byte * LWG_MAX_TAPS), ("dx", ctypes.c_byte * LWG_MAX_TAPS),
+    ]
+
+
+_SIGS = {
+    "lwg_abi_version": (c_i, []),
+    "lwg_device_cu_count": (c_i, []),
+    "lwg_conv2d_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_instnorm_stats_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
+    "lwg_instnorm_apply_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_lwb_attention_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_rasterize_ws_bytes": (ctypes.c_size_t, [c_i, c_i]),
+    "lwg_project_faces_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f]),
+    "lwg_rasterize_fim_wim_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_f, c_f]),
+    "lwg_flow_compose_f32": (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "lwg_bc_transform_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_encode_fim_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_smpl_lbs_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "lwg_smpl_lbs_f32": (c_i, [c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i,
+                               c_i, c_f, c_f, c_f, c_f, c_f]),
+    "lwg_head_compose_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "lwg_nchw_to_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_nhwc_to_nchw_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/lwg_hip.h (used by the CPU test that checks the exports)."""
+    with open(HEADER_PATH) as fp:
+        src = re.sub(r"/\*.*?\*/", "", fp.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(lwg_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP kernels are not built (run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C ipercore_amd/csrc`).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.lwg_abi_version() != 1:
+            raise RuntimeError("liblwg_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what} failed with hipError_t {err}")

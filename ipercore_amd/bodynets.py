@@ -1,0 +1,123 @@
+"""SMPL-H body model behind the reference's ``SMPLH`` API, skinning on the MI355X (csrc/lbs.hip).
+
+Drop-in for ``iPERCore.tools.human_digitalizer.bodynets.SMPLH`` (batch_smplh.py:15-180) with the ``BaseSMPL``
+helpers (base_smpl.py:21-142): same constructor ``SMPLH(model_path)``, same pickle schema
+(smplx/body_models.py:200-296: v_template, shapedirs, posedirs, J_regressor, kintree_table, weights, f,
+hands_meanl/r, hands_componentsl/r), same methods ``forward`` / ``get_details`` / ``skinning`` / ``split`` /
+``link`` and the ``np_hands_mean`` property used by ``base_runner.add_hands_params_to_smpl``.
+The whole frame batch is skinned by one C-ABI call (``lwg_smpl_lbs_f32``); there is no CPU path.
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _dense(a):
+    if hasattr(a, "todense"):
+        a = a.todense()
+    return np.asarray(a)
+
+
+class SMPLH(nn.Module):
+    NUM_BODY_JOINTS = 21
+    NUM_HAND_JOINTS = 15
+    NUM_JOINTS = NUM_BODY_JOINTS + 2 * NUM_HAND_JOINTS      # 51 + root = 52 rotations
+
+    def __init__(self, model_path, use_pca=False, num_pca_comps=6, dtype=torch.float32, **kwargs):
+        super().__init__()
+        if isinstance(model_path, dict):
+            data = model_path
+        else:
+            with open(model_path, "rb") as fp:
+                data = pickle.load(fp, encoding="latin1")
+        self.use_pca = use_pca
+        self.num_pca_comps = num_pca_comps
+        f32 = lambda a: torch.tensor(np.ascontiguousarray(_dense(a), dtype=np.float32))    # noqa: E731
+        self.faces = _dense(data["f"])
+        self.register_buffer("faces_tensor", torch.tensor(self.faces.astype(np.int64)))
+        self.register_buffer("v_template", f32(data["v_template"]))
+        self.register_buffer("shapedirs", f32(data["shapedirs"])[:, :, :10].contiguous())
+        pd = _dense(data["posedirs"])
+        self.register_buffer("posedirs", f32(np.reshape(pd, [-1, pd.shape[-1]]).T))       # (P, V*3)
+        self.register_buffer("J_regressor", f32(data["J_regressor"]))
+        parents = torch.tensor(_dense(data["kintree_table"])[0].astype(np.int64))
+        parents[0] = -1
+        self.register_buffer("parents", parents)
+        self.register_buffer("parents_i32", parents.to(torch.int32))
+        self.register_buffer("lbs_weights", f32(data["weights"]))
+        self.np_hands_meanl = _dense(data["hands_meanl"]).astype(np.float32)
+        self.np_hands_meanr = _dense(data["hands_meanr"]).astype(np.float32)
+        self.register_buffer("hands_meanl", torch.tensor(self.np_hands_meanl))
+        self.register_buffer("hands_meanr", torch.tensor(self.np_hands_meanr))
+        self.register_buffer("hands_mean", torch.tensor(self.np_hands_mean))
+        self.register_buffer("left_hand_components", f32(_dense(data["hands_componentsl"])[:num_pca_comps]))
+        self.register_buffer("right_hand_components", f32(_dense(data["hands_componentsr"])[:num_pca_comps]))
+
+    @property
+    def np_hands_mean(self):
+        return np.concatenate([self.np_hands_meanl, self.np_hands_meanr], axis=0)
+
+    # ---- BaseSMPL helpers -------------------------------------------------------------------------
+    def _device_model(self):
+        return {"v_template": self.v_template, "shapedirs": self.shapedirs, "posedirs": self.posedirs,
+                "J_regressor": self.J_regressor, "parents": self.parents_i32, "lbs_weights": self.lbs_weights}
+
+    def _full_pose(self, theta):
+        bs = theta.shape[0]
+        if theta.shape[1] == 72:                                            # batch_smplh.py:156-158
+            theta = torch.cat([theta[:, 0:66], self.hands_mean.repeat(bs, 1)], dim=1)
+        if self.use_pca:                                                    # batch_smplh.py:160-169
+            lh = torch.matmul(theta[:, -12:-6], self.left_hand_components)
+            rh = torch.matmul(theta[:, -6:], self.right_hand_components)
+            theta = torch.cat([theta[:, :-12], lh, rh], dim=1)
+        return theta.contiguous()
+
+    def _links_2d(self, links_ids, device):
+        ids = torch.as_tensor(links_ids)
+        if ids.dim() != 2:
+            raise NotImplementedError("per-batch (bs, nv, 3) links_ids are not handled on the device yet")
+        return ids[:, 0:2].to(device=device, dtype=torch.int32).contiguous()
+
+    @torch.no_grad()
+    def forward(self, beta, theta, offsets=0, links_ids=None, get_skin=False, cam=None):
+        """batch_smplh.py:137-180 -> (vertices (B,6890,3), joints (B,52,3), full_pose)."""
+        full_pose = self._full_pose(theta.float())
+        off = None
+        if torch.is_tensor(offsets):
+            if offsets.numel() > 1:
+                off = offsets.to(device=full_pose.device, dtype=torch.float32).contiguous()
+        elif isinstance(offsets, np.ndarray) and offsets.size > 1:
+            off = torch.tensor(offsets, device=full_pose.device, dtype=torch.float32)
+        links = None if links_ids is None else self._links_2d(links_ids, full_pose.device)
+        verts, j3d, j2d = ops.smpl_lbs(self._device_model(), full_pose, beta.float().contiguous(),
+                                       None if cam is None else cam.float().contiguous(), off, links)
+        self._last_j2d = j2d
+        return verts, j3d, full_pose
+
+    def link(self, verts, linked_ids):
+        """base_smpl.py:28-50 (2-D ids)."""
+        ids = self._links_2d(linked_ids, verts.device).long()
+        out = verts.clone()
+        out[:, ids[:, 0]] = verts[:, ids[:, 1]]
+        return out
+
+    def split(self, theta):
+        return {"cam": theta[:, 0:3], "pose": theta[:, 3:-10].contiguous(), "shape": theta[:, -10:].contiguous(),
+                "theta": theta}
+
+    def skinning(self, theta, offsets=0, links_ids=None):
+        cam, pose, shape = theta[:, 0:3], theta[:, 3:-10].contiguous(), theta[:, -10:].contiguous()
+        verts, _, _ = self.forward(beta=shape, theta=pose, offsets=offsets, links_ids=links_ids, get_skin=True)
+        return {"cam": cam, "pose": pose, "shape": shape, "verts": verts, "theta": theta}
+
+    def get_details(self, theta, offsets=0, links_ids=None):
+        """base_smpl.py:107-142: verts, posed joints and their weak-perspective projection."""
+        cam, pose, shape = theta[:, 0:3], theta[:, 3:-10].contiguous(), theta[:, -10:].contiguous()
+        verts, j3d, _ = self.forward(beta=shape, theta=pose, offsets=offsets, links_ids=links_ids, get_skin=True,
+                                     cam=cam.contiguous())
+        return {"theta": theta, "cam": cam, "pose": pose, "shape": shape, "verts": verts, "j2d": self._last_j2d,
+                "j3d": j3d}

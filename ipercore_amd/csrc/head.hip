@@ -1,0 +1,155 @@
+// Output head of TSFNet fused with the final compositing, plus NCHW <-> NHWC layout changes for the API edge.
+// Replaces reference generators/attlwb_spade_resunet.py:605-613 (tsf_img_reg: conv5x5 64->3 + tanh,
+// tsf_att_reg: conv5x5 64->1 + sigmoid; both bias-free) as called at :533, and models/imitator.py:393
+// (pred = mask * bg + (1 - mask) * img).
+//
+// Cout = 4 is too narrow for the 32-wide MFMA tiles (12.5 % utilisation), and the fp32 MFMA rate equals the
+// fp32 VALU rate on gfx950, so this is a register-blocked VALU direct convolution: a workgroup owns a 32x32
+// pixel tile, each thread 4 pixels x 4 outputs; the input halo tile is staged through LDS 8 channels at a
+// time as channel-quads ([cq][row][col] float4: a wave reads 512 contiguous bytes per ds_read_b128), weights
+// are LDS broadcasts.  Outputs are written NCHW (what Imitator.inference hands to the host), coalesced in x.
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define HT 32          // tile edge
+#define HH (HT + 4)    // halo edge (5x5, pad 2)
+#define HCH 8          // channels per stage
+
+__global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bg, size_t bg_bstride, int S, int C,
+                                                              float* __restrict__ pred, float* __restrict__ mask_out,
+                                                              float* __restrict__ img_out) {
+    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HH][HH][4];
+    __shared__ __attribute__((aligned(16))) float sw[25][HCH][4];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int b = blockIdx.z, x0 = blockIdx.x * HT, y0 = blockIdx.y * HT;
+    const float* xb = x + (size_t)b * S * S * C;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
+
+    for (int c0 = 0; c0 < C; c0 += HCH) {
+        // stage input halo: HH*HH pixels x 2 channel quads
+        for (int i = tid; i < HH * HH * (HCH / 4); i += 256) {
+            const int cq = i & 1, p = i >> 1;
+            const int py = p / HH, px = p - py * HH;
+            const int gy = y0 + py - 2, gx = x0 + px - 2;
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < S && gx >= 0 && gx < S)
+                v = *reinterpret_cast<const floatx4*>(xb + ((size_t)gy * S + gx) * C + c0 + cq * 4);
+            *reinterpret_cast<floatx4*>(&sx[cq][py][px][0]) = v;
+        }
+        // stage weights: wpk is [25][C][4]
+        for (int i = tid; i < 25 * HCH; i += 256) {
+            const int tap = i / HCH, c = i - tap * HCH;
+            *reinterpret_cast<floatx4*>(&sw[tap][c][0]) =
+                *reinterpret_cast<const floatx4*>(wpk + ((size_t)tap * C + c0 + c) * 4);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+#pragma unroll
+                for (int cq = 0; cq < HCH / 4; ++cq) {
+                    floatx4 w4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w4[c] = *reinterpret_cast<const floatx4*>(&sw[ky * 5 + kx][cq * 4 + c][0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const floatx4 xv = *reinterpret_cast<const floatx4*>(&sx[cq][ty + 8 * j + ky][tx + kx][0]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[j][o] += xv[c] * w4[c][o];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int gx = x0 + tx;
+    if (gx >= S) return;
+    const size_t plane = (size_t)S * S;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gy = y0 + ty + 8 * j;
+        if (gy >= S) continue;
+        const size_t pix = (size_t)gy * S + gx;
+        const float m = 1.f / (1.f + expf(-acc[j][3]));
+        if (mask_out) mask_out[(size_t)b * plane + pix] = m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float im = tanhf(acc[j][c]);
+            if (img_out) img_out[((size_t)b * 3 + c) * plane + pix] = im;
+            if (pred) {
+                const float bgv = bg[(size_t)b * bg_bstride + c * plane + pix];
+                pred[((size_t)b * 3 + c) * plane + pix] = m * bgv + (1.f - m) * im;
+            }
+        }
+    }
+}
+
+// (B,C,P) -> (B,P,Cp), channels >= C zero-filled.  32x32 LDS tile transpose.
+__global__ __launch_bounds__(256) void lwg_nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                              int Cp, int P) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + lx;
+        t[r][lx] = (c < C && p < P) ? src[((size_t)b * C + c) * P + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + lx;
+        if (p < P && c < Cp) dst[((size_t)b * P + p) * Cp + c] = t[lx][r];
+    }
+}
+
+// (B,P,Cs) -> (B,C,P) taking the first C channels.
+__global__ __launch_bounds__(256) void lwg_nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                              int Cs, int P) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + lx;
+        t[r][lx] = (p < P && c < C) ? src[((size_t)b * P + p) * Cs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + lx;
+        if (c < C && p < P) dst[((size_t)b * C + c) * P + p] = t[lx][r];
+    }
+}
+
+// x (B,S,S,C) NHWC, C % 8 == 0; wpk [25][C][4] (out 0..2 = img_reg, out 3 = att_reg; tap = ky*5+kx);
+// bg (Bbg,3,S,S) NCHW with batch stride bg_bstride floats (0 = shared); pred (B,3,S,S), mask (B,1,S,S),
+// img (B,3,S,S): any of the three outputs may be NULL (bg may be NULL when pred is NULL).
+extern "C" int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
+                                    float* pred, float* mask, float* img, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !wpk || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C <= 0 || (C % HCH) != 0 || B > 65535)
+        return (int)hipErrorInvalidValue;
+    const int tiles = (S + HT - 1) / HT;
+    hipLaunchKernelGGL(lwg_head_compose_kernel, dim3(tiles, tiles, B), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred,
+                       mask, img);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int Cp, int P, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!src || !dst || B <= 0 || C <= 0 || Cp < C || P <= 0 || B > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_nchw_to_nhwc_kernel, dim3((P + 31) / 32, (Cp + 31) / 32, B), dim3(256), 0, stream, src, dst, C, Cp, P);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int Cs, int P, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!src || !dst || B <= 0 || C <= 0 || Cs < C || P <= 0 || B > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_nhwc_to_nchw_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, dst, C, Cs, P);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,131 @@
+// Liquid Warping Block, attention form: flow resize + feature warp + per-pixel softmax over the sources.
+// Replaces, per AttLWB site (9 per frame), the chain of reference
+//   generators/attlwb_spade_resunet.py:175-182  LWB.resize_trans  (F.interpolate bilinear, align_corners=True)
+//   :190                                        LWB.transform     (F.grid_sample bilinear/zeros/align_corners=False)
+//   :226-227                                    fk / fv 1x1 convs on the warped source features
+//   :121-139, :116-117                          SelfAttentionBlock.query + weighted sum
+// A 1x1 conv commutes with the (linear, zero-padded) warp:  fk(warp(x)) = warp(Wk x) + bk  at every pixel,
+// including out-of-range ones where the warp is 0.  Ks = Wk x and Vs = Wv x are therefore computed ONCE per
+// source (they only depend on the cached source features) and this kernel gathers them: an HBM/L2-bound
+// gather with 16-byte loads, one pixel per LPP = C/4 lanes, online softmax over the ns sources.
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+template <int LPP>
+__global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restrict__ q, const float* __restrict__ Ks,
+                                                          const float* __restrict__ Vs, const float* __restrict__ bk,
+                                                          const float* __restrict__ bv, const float* __restrict__ T,
+                                                          float* __restrict__ out, int B, int ns, int h, int w, int S, int src_batched) {
+    constexpr int C = 4 * LPP;
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cl = lane % LPP;
+    const long total = (long)B * h * w;
+    long gp = ((long)blockIdx.x * 4 + wid) * PPW + lane / LPP;
+    const bool live = gp < total;
+    if (!live) gp = total - 1;  // keep all lanes in the shuffles
+    const int hw = h * w;
+    const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
+    const int y = rem / w, x = rem - y * w;
+
+    const floatx4 q4 = *reinterpret_cast<const floatx4*>(q + gp * C + 4 * cl);
+    const floatx4 bk4 = *reinterpret_cast<const floatx4*>(bk + 4 * cl);
+    const floatx4 bv4 = *reinterpret_cast<const floatx4*>(bv + 4 * cl);
+
+    // flow resize S x S -> h x w, bilinear, align_corners=True (ATen area_pixel_compute_source_index)
+    const float sc_y = h > 1 ? (float)(S - 1) / (float)(h - 1) : 0.f;
+    const float sc_x = w > 1 ? (float)(S - 1) / (float)(w - 1) : 0.f;
+    const float sy = sc_y * (float)y, sx = sc_x * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const bool same = (h == S) && (w == S);
+
+    const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    float mrun = -INFINITY, lrun = 0.f;
+    floatx4 o = {0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < ns; ++s) {
+        const float2* Tp = reinterpret_cast<const float2*>(T) + ((size_t)b * ns + s) * S * S;
+        float gx, gy;
+        if (same) {
+            const float2 t = Tp[(size_t)y * S + x];
+            gx = t.x; gy = t.y;
+        } else {
+            const float2 t00 = Tp[(size_t)y0 * S + x0], t01 = Tp[(size_t)y0 * S + x1];
+            const float2 t10 = Tp[(size_t)y1 * S + x0], t11 = Tp[(size_t)y1 * S + x1];
+            gx = ly0 * (lx0 * t00.x + lx1 * t01.x) + ly1 * (lx0 * t10.x + lx1 * t11.x);
+            gy = ly0 * (lx0 * t00.y + lx1 * t01.y) + ly1 * (lx0 * t10.y + lx1 * t11.y);
+        }
+        // grid_sample, align_corners=False: pixel = ((g + 1) * size - 1) / 2
+        const float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+        // clamp before the int conversion so wild flows cannot overflow; out-of-range taps are skipped anyway
+        const int tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+        const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
+        const float* Kb = Ks + sidx * hw * C + 4 * cl;
+        const float* Vb = Vs + sidx * hw * C + 4 * cl;
+        floatx4 ka = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+            const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                const size_t off = ((size_t)ty * w + tx) * C;
+                const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
+                const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ka[k] += k4[k] * wt; va[k] += v4[k] * wt; }
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dot += (ka[k] + bk4[k]) * q4[k];
+#pragma unroll
+        for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const float logit = dot * inv_sqrt_c;
+        const float mnew = fmaxf(mrun, logit);
+        const float corr = __expf(mrun - mnew);  // exp(-inf) = 0 on the first source
+        const float p = __expf(logit - mnew);
+        lrun = lrun * corr + p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = o[k] * corr + p * (va[k] + bv4[k]);
+        mrun = mnew;
+    }
+    if (live) {
+        const float invl = 1.f / lrun;
+        floatx4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = o[k] * invl;
+        *reinterpret_cast<floatx4*>(out + gp * C + 4 * cl) = r;
+    }
+}
+
+// src_batched = 0: Ks/Vs (ns,h,w,C) shared by all B frames; 1: (B*ns,h,w,C), frame b uses rows b*ns+s.
+// q (B,h,w,C) = fq(tsf_x) incl. bias; Ks/Vs (ns,h,w,C) = Wk x_src / Wv x_src WITHOUT bias; bk/bv (C);
+// T (B,ns,S,S,2) flows in grid_sample coordinates (-2 = background); out (B,h,w,C).
+extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
+                                     const float* T, float* out, int B, int ns, int h, int w, int C, int S,
+                                     int src_batched, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!q || !Ks || !Vs || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0)
+        return (int)hipErrorInvalidValue;
+    const long total = (long)B * h * w;
+#define LWG_ATTN_LAUNCH(LPP)                                                                                      \
+    {                                                                                                             \
+        const long per_block = 4 * (64 / LPP);                                                                    \
+        hipLaunchKernelGGL(lwg_lwb_attn_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
+                           stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);                                   \
+    }
+    switch (C) {
+        case 32: LWG_ATTN_LAUNCH(8) break;
+        case 64: LWG_ATTN_LAUNCH(16) break;
+        case 128: LWG_ATTN_LAUNCH(32) break;
+        case 256: LWG_ATTN_LAUNCH(64) break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LWG_ATTN_LAUNCH
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,107 @@
+// InstanceNorm2d(affine=False, eps) statistics and application on NHWC fp32 - HBM-bound streaming kernels.
+// Replaces nn.InstanceNorm2d at reference generators/attlwb_spade_resunet.py:62,:83 (SPADE's parameter-free
+// norm; the normalisation itself is fused into the gamma/beta conv epilogue) and bg_inpaintor.py:14-51.
+//
+// Layout: x is (B, HW, C); a wave reads 64 consecutive channels of one pixel (256 contiguous bytes).
+// Pass 1: grid (C/64, nsplit, B), 4 waves stride over the pixels of one split, shifted sums (shift = first
+//         pixel of the split) to avoid E[x^2]-E[x]^2 cancellation; per-split (n, mean, M2) to scratch.
+// Pass 2: Chan combination of the nsplit partials -> mean, rstd = 1/sqrt(M2/n + eps) (biased variance).
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+__global__ __launch_bounds__(256) void lwg_in_stats_partial(const float* __restrict__ x, int HW, int C, int nsplit,
+                                                           float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, split = blockIdx.y, b = blockIdx.z;
+    const bool cok = c < C;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    const float* xb = x + (size_t)b * HW * C;
+    float shift = 0.f, s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    if (cok && p0 < p1) shift = xb[(size_t)p0 * C + c];
+    if (cok) {
+        for (int p = p0 + wid; p < p1; p += 4) {
+            const float d = xb[(size_t)p * C + c] - shift;
+            s1 += d;
+            s2 += d * d;
+            ++n;
+        }
+    }
+    __shared__ float sh[3][4][64];
+    sh[0][wid][lane] = s1;
+    sh[1][wid][lane] = s2;
+    sh[2][wid][lane] = (float)n;
+    __syncthreads();
+    if (wid == 0 && cok) {
+        float t1 = 0.f, t2 = 0.f, tn = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { t1 += sh[0][w][lane]; t2 += sh[1][w][lane]; tn += sh[2][w][lane]; }
+        float mean = shift, m2 = 0.f;
+        if (tn > 0.f) { mean = shift + t1 / tn; m2 = t2 - t1 * t1 / tn; }
+        float* o = ws + (((size_t)b * nsplit + split) * C + c) * 3;
+        o[0] = tn; o[1] = mean; o[2] = m2 > 0.f ? m2 : 0.f;
+    }
+}
+
+__global__ void lwg_in_stats_final(const float* __restrict__ ws, int BC, int C, int nsplit, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i - b * C;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 3;
+        const float nb = o[0];
+        if (nb <= 0.f) continue;
+        const float tot = n + nb, delta = o[1] - mu;
+        mu += delta * (nb / tot);
+        m2 += o[2] + delta * delta * (n * nb / tot);
+        n = tot;
+    }
+    mean[i] = mu;
+    rstd[i] = 1.0f / sqrtf(m2 / n + eps);
+}
+
+__global__ __launch_bounds__(256) void lwg_in_apply(const floatx4* __restrict__ x, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, const floatx4* __restrict__ res,
+                                                   floatx4* __restrict__ y, int HW, int C4, size_t total4, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int b = (int)(i / ((size_t)HW * C4));
+        const floatx4 v = x[i];
+        const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + (size_t)b * C4 * 4 + c4 * 4);
+        const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + (size_t)b * C4 * 4 + c4 * 4);
+        floatx4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = lwg_act((v[k] - mu[k]) * rs[k], act);
+        if (res) {
+            const floatx4 r = res[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += r[k];
+        }
+        y[i] = o;
+    }
+}
+
+extern "C" int lwg_instnorm_stats_nhwc_f32(const float* x, int B, int HW, int C, float eps, float* mean, float* rstd,
+                                           float* ws, int nsplit, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !mean || !rstd || !ws || B <= 0 || HW <= 0 || C <= 0 || nsplit <= 0 || nsplit > 65535)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_in_stats_partial, dim3((C + 63) / 64, nsplit, B), dim3(256), 0, stream, x, HW, C, nsplit, ws);
+    const int BC = B * C;
+    hipLaunchKernelGGL(lwg_in_stats_final, dim3((BC + 255) / 256), dim3(256), 0, stream, ws, BC, C, nsplit, eps, mean, rstd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* res,
+                                           float* y, int B, int HW, int C, int act, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !mean || !rstd || !y || (C & 3) || B <= 0) return (int)hipErrorInvalidValue;
+    const size_t total4 = (size_t)B * HW * (C / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lwg_in_apply, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(x), mean, rstd,
+                       reinterpret_cast<const floatx4*>(res), reinterpret_cast<floatx4*>(y), HW, C / 4, total4, act);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,127 @@
+"""Flow composition of the runner (reference iPERCore/models/flowcomposition.py:21-744), per-frame part.
+
+Built in this round (the per-frame path of ``Imitator.inference``):
+  ``add_rendered_f2verts_fim_wim`` (:139-204, without the source-only ``use_morph`` branch),
+  ``make_tsf_inputs`` (:206-248), ``make_trans_flow`` (:514-582, temporal=False), ``make_uv_setup`` (:78-85),
+  ``make_src_inputs`` (:262-265), and the fused ``frame_inputs`` that the MI355X runner actually calls: ONE
+  pass over (fim, wim) producing cond, the UV flow + UV sample, the generator input and all source flows
+  (``csrc/flow.hip``) instead of 2 + ns boolean-mask gathers with host syncs.
+Not built yet (source_setup): ``process_source`` / ``make_uv_img`` / ``make_morph_image`` /
+``make_bg_inputs`` (morphology, Canny, O(n1 n2) nearest-boundary fill) - they raise.
+"""
+import torch
+
+from . import ops
+from .renders import SMPLRenderer
+
+
+class FlowComposition(torch.nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self._opt = opt
+        self._name = "FlowComposition"
+        g = lambda k, d=None: getattr(opt, k, d) if not isinstance(opt, dict) else opt.get(k, d)    # noqa: E731
+        self.image_size = int(g("image_size", 512))
+        self.only_vis = bool(g("only_vis", False))
+        self.render = SMPLRenderer(
+            face_path=g("face_path"), fim_enc_path=g("fim_enc_path"), uv_map_path=g("uv_map_path"),
+            part_path=g("part_path"), front_path=g("front_path"), head_path=g("head_path"), facial_path=g("facial_path"),
+            map_name=g("map_name", "uv_seg"), image_size=self.image_size, fill_back=False, anti_aliasing=True,
+            background_color=(0, 0, 0), has_front=True, top_k=3)
+        self.register_buffer("grid", self.render.create_meshgrid(image_size=self.image_size))
+        self.f2uvs = None
+        self.uv_fim = None
+        self.uv_wim = None
+        self.one_map = None
+
+    # ------------------------------------------------------------------ reference-shaped methods
+    def make_uv_setup(self, bs, ns, nt, device):
+        if self.f2uvs is None:
+            n = bs * max(ns, nt)
+            self.uv_fim, self.uv_wim = self.render.render_uv_fim_wim(n)
+            self.f2uvs = self.render.get_f_uvs2img(n)
+            self.one_map = torch.ones(bs * ns, 1, self.image_size, self.image_size, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def add_rendered_f2verts_fim_wim(self, smpl_info, use_morph=False, get_uv_info=True):
+        """flowcomposition.py:139-204."""
+        if use_morph:
+            raise NotImplementedError("use_morph=True (source_setup silhouette morphology) is a 'next' row (SURVEY 8f-1)")
+        f2pts, fim, wim = self.render.render_fim_wim(cam=smpl_info["cam"], vertices=smpl_info["verts"], smpl_faces=True)
+        cond, _ = self.render.encode_fim(fim=fim, transpose=True)
+        smpl_info["f2pts"] = f2pts
+        smpl_info["only_vis_f2pts"] = _Lazy(lambda: self.render.get_vis_f2pts(f2pts, fim))   # consumed only if only_vis
+        smpl_info["cond"], smpl_info["fim"], smpl_info["wim"] = cond, fim, wim
+        if get_uv_info:
+            obj_f2pts, obj_fim, obj_wim = self.render.render_fim_wim(cam=smpl_info["cam"], vertices=smpl_info["verts"],
+                                                                     smpl_faces=False)
+            smpl_info["obj_f2pts"] = obj_f2pts
+            smpl_info["only_vis_obj_f2pts"] = self.render.get_vis_f2pts(obj_f2pts, obj_fim)
+            smpl_info["obj_fim"], smpl_info["obj_wim"] = obj_fim, obj_wim
+        return smpl_info
+
+    @torch.no_grad()
+    def make_tsf_inputs(self, uv_img, ref_info):
+        """flowcomposition.py:206-248 -> (bs, nt, 6, h, w) NCHW."""
+        fim, wim = ref_info["fim"], ref_info["wim"]
+        bs, _, h, w = uv_img.shape
+        nt = fim.shape[0] // bs
+        uv4 = ops.nchw_to_nhwc(uv_img.contiguous().float(), c_pad=4)
+        outs = []
+        for b in range(bs):
+            sl = slice(b * nt, (b + 1) * nt)
+            tsf8, _, _, _ = ops.flow_compose(fim[sl].contiguous(), wim[sl].contiguous(), self.render.map_fn,
+                                             self.render.f_uvs2img, uv4[b],
+                                             torch.empty(0, self.render.nf, 3, 2, device=fim.device))
+            outs.append(ops.nhwc_to_nchw(tsf8, channels=6))
+        return torch.cat(outs, dim=0).view(bs, nt, 6, h, w)
+
+    @torch.no_grad()
+    def make_trans_flow(self, bs, ns, nt, src_info, temp_info, ref_info, temporal=True, use_selected_f2pts=False):
+        """flowcomposition.py:514-582 -> (Tst (bs,ns,h,w,2), Ttt)."""
+        if temporal:
+            raise NotImplementedError("temporal flows (Ttt) are a 'next' row (SURVEY 8f-4)")
+        h = w = self.image_size
+        key = "selected_f2pts" if use_selected_f2pts else ("only_vis_f2pts" if self.only_vis else "f2pts")
+        src_f2pts = _force(src_info[key])
+        n = ns * bs
+        Tst = self.render.cal_bc_transform(src_f2pts, ref_info["fim"].repeat(max(ns, nt), 1, 1)[0:n],
+                                           ref_info["wim"].repeat(max(ns, nt), 1, 1, 1)[0:n])
+        return Tst.view(bs, ns, h, w, 2), None
+
+    def make_src_inputs(self, src_img, src_info):
+        return torch.cat([src_img, src_info["cond"]], dim=1)
+
+    def process_source(self, *a, **k):
+        raise NotImplementedError("process_source (morph / Canny / UV merge) is a 'next' row (SURVEY 8f-1); "
+                                  "use Imitator.set_source() with a prepared uv_img")
+
+    make_uv_img = make_morph_image = make_bg_inputs = process_source
+
+    # ------------------------------------------------------------------ fused MI355X per-frame entry
+    @torch.no_grad()
+    def frame_inputs(self, cam, verts, uv_img4, src_f2pts, want_aux=False):
+        """B target frames -> (tsf8 (B,S,S,8) NHWC, Tst (B,ns,S,S,2), aux dict).  Equivalent to
+        add_rendered_f2verts_fim_wim(get_uv_info=False) + make_tsf_inputs + make_trans_flow (temporal=False)."""
+        fv, f2pts = ops.project_faces(verts, cam, self.render.smpl_faces, want_f2pts=want_aux)
+        fim, wim = ops.rasterize_fim_wim(fv, self.image_size)
+        tsf8, Tst, cond, tuv = ops.flow_compose(fim, wim, self.render.map_fn, self.render.f_uvs2img, uv_img4, src_f2pts,
+                                                want_cond=want_aux, want_tuv=want_aux)
+        aux = {"fim": fim, "wim": wim, "f2pts": f2pts, "cond": cond, "Tuv2t": tuv} if want_aux else None
+        return tsf8, Tst, aux
+
+
+class _Lazy:
+    """Defers a value nobody may ask for (the reference computes only_vis_f2pts eagerly, with two host syncs)."""
+
+    def __init__(self, fn):
+        self.fn, self.val = fn, None
+
+    def get(self):
+        if self.val is None:
+            self.val = self.fn()
+        return self.val
+
+
+def _force(v):
+    return v.get() if isinstance(v, _Lazy) else v

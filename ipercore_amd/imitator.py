@@ -1,0 +1,186 @@
+"""The Imitator runner (reference iPERCore/models/imitator.py:130-401) on the MI355X.
+
+Same public surface as the reference for the per-frame path: ``Imitator(opt, device)``, ``swap_params``
+(:248-256), ``make_inputs_for_tsf`` (:258-325), ``inference(tgt_smpls, cam_strategy, output_dir, prefix, ...)``
+(:327-382), ``forward`` (:384-395).  ``inference`` returns what the reference returns: a list of file paths
+(``"{prefix}{t:0>8}.png"``) when ``output_dir`` is given, else a list of ``(3, S, S)`` float arrays in [-1, 1].
+
+MI355X-first structure: with ``temporal=False`` (deploy.toml:40) a frame depends only on the cached source
+state, its own SMPL parameters and ``first_cam`` (:298-299), so ``inference`` walks the clip in batches of
+``frame_batch`` frames; every batch is: one batched skinning call, one projection + rasterization, one fused
+flow pass, the generator (MFMA convs at batch B), one head + compositing kernel.  No host sync inside a batch.
+Frames of one clip shard over ranks with ``ipercore_amd.sharding`` (one all-gather of the output tensor).
+
+``source_setup`` (:177-246) needs the source-image morphology / UV-merge stage that is a "next" row
+(SURVEY 8f-1); until then sources enter through ``set_source`` with an already prepared UV image.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .bodynets import SMPLH
+from .flowcomposition import FlowComposition
+from .geometry import cam_pose_utils
+from .networks import NetworksFactory
+
+
+def _opt_get(opt, key, default=None):
+    if isinstance(opt, dict):
+        return opt.get(key, default)
+    return getattr(opt, key, default)
+
+
+class Imitator(object):
+    def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8):
+        self._opt = opt
+        self._name = "Imitator"
+        self.device = torch.device(device)
+        self.frame_batch = int(frame_batch)
+        self.src_info = None
+        self.first_cam = None
+        self.image_size = int(_opt_get(opt, "image_size", 512))
+        self.temporal = bool(_opt_get(opt, "temporal", False))
+        if self.temporal:
+            raise NotImplementedError("temporal=True (TemporalFIFO) is a 'next' row (SURVEY 8f-4)")
+        self._create_networks()
+
+    def _create_networks(self):
+        self.body_rec = SMPLH(model_path=_opt_get(self._opt, "smpl_model_hand")).to(self.device)
+        self.weak_cam_swapper = cam_pose_utils.WeakPerspectiveCamera(self.body_rec)
+        self.flow_comp = FlowComposition(opt=self._opt).to(self.device)
+        self.generator = self._create_generator(_opt_get(_opt_get(self._opt, "neural_render_cfg"), "Generator"))
+        self.generator = self.generator.to(self.device)
+
+    def _create_generator(self, cfg):
+        net = NetworksFactory.get_by_name(_opt_get(self._opt, "gen_name", "AttLWB-SPADE"), cfg=cfg, temporal=self.temporal)
+        meta = _opt_get(self._opt, "meta_data")
+        load_path = _opt_get(meta, "personalized_ckpt_path", "") if meta is not None else ""
+        if not (load_path and os.path.exists(load_path)):
+            load_path = _opt_get(self._opt, "load_path_G", "")
+        if load_path and os.path.exists(load_path):
+            ckpt = torch.load(load_path, map_location="cpu")
+            ckpt = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ckpt.items()}
+            missing = net.load_state_dict(ckpt, strict=False)
+            if missing.missing_keys or missing.unexpected_keys:
+                # the reference loads with strict=False silently (imitator.py:167-168); we say what did not match
+                print(f"[ipercore_amd] checkpoint {load_path}: missing {len(missing.missing_keys)} keys, "
+                      f"unexpected {len(missing.unexpected_keys)} keys")
+        net.eval()
+        return net
+
+    # ------------------------------------------------------------------ source state
+    def source_setup(self, *args, **kwargs):
+        raise NotImplementedError("Imitator.source_setup needs process_source (morph / Canny / UV merge): 'next' row "
+                                  "(SURVEY 8f-1).  Use set_source(src_smpl, uv_img, bg_img, src_inputs=...)")
+
+    @torch.no_grad()
+    def set_source(self, src_smpl, uv_img, bg_img, src_img=None, offsets=0, links_ids=None):
+        """Build ``src_info`` from prepared tensors: what source_setup (:177-246) caches after process_source.
+
+        src_smpl (ns,85); uv_img (1,3,S,S); bg_img (1,3,S,S); src_img (1,ns,3,S,S) source images (already morphed).
+        Runs the source renders (f2pts, cond), SIDNet (forward_src) and the K/V projections on the device.
+        """
+        dev = self.device
+        src_smpl = torch.as_tensor(src_smpl, dtype=torch.float32, device=dev)
+        off = offsets if not isinstance(offsets, np.ndarray) else torch.tensor(offsets, dtype=torch.float32, device=dev)
+        src_info = self.body_rec.get_details(src_smpl, off, links_ids=links_ids)
+        ns = src_smpl.shape[0]
+        src_info["num_source"] = ns
+        self.flow_comp.add_rendered_f2verts_fim_wim(src_info, use_morph=False, get_uv_info=False)
+        src_info["offsets"], src_info["links_ids"] = off, links_ids
+        src_info["uv_img"] = torch.as_tensor(uv_img, dtype=torch.float32, device=dev).contiguous()
+        src_info["uv_img4"] = ops.nchw_to_nhwc(src_info["uv_img"], c_pad=4)[0].contiguous()
+        src_info["bg"] = torch.as_tensor(bg_img, dtype=torch.float32, device=dev).contiguous()
+        if src_img is None:
+            raise ValueError("src_img (1, ns, 3, S, S) is required")
+        src_img = torch.as_tensor(src_img, dtype=torch.float32, device=dev)
+        src_info["img"] = src_img
+        S = self.image_size
+        input_G_src = self.flow_comp.make_src_inputs(src_img.view(ns, 3, S, S), src_info).view(1, ns, 6, S, S)
+        enc, res = self.generator.forward_src(input_G_src, only_enc=True)
+        src_info["feats"] = (enc, res)
+        src_info["feats_nhwc"] = enc.lwg_cache
+        self.src_info = src_info
+        return src_info
+
+    # ------------------------------------------------------------------ per-frame path
+    def swap_params(self, src_cam, src_shape, tgt_smpl, cam_strategy="smooth"):
+        """imitator.py:248-256, for a batch of target frames."""
+        cam = self.weak_cam_swapper.cam_swap(src_cam, tgt_smpl[:, 0:3], self.first_cam, cam_strategy)
+        return torch.cat([cam, tgt_smpl[:, 3:-10], src_shape.expand(tgt_smpl.shape[0], -1)], dim=1)
+
+    @torch.no_grad()
+    def make_inputs_for_tsf(self, src_info, tgt_smpl, cam_strategy="smooth", t=0, primary_ids=0, use_selected_f2pts=False,
+                            want_aux=False):
+        """imitator.py:258-325 for B frames at once -> (tsf8 NHWC, Tst, ref_info)."""
+        if t == 0 and cam_strategy == "smooth" and self.first_cam is None:
+            self.first_cam = tgt_smpl[0:1, 0:3].clone()
+        ref_smpl = self.swap_params(src_info["cam"][primary_ids:primary_ids + 1],
+                                    src_info["shape"][primary_ids:primary_ids + 1], tgt_smpl, cam_strategy)
+        ref_info = self.body_rec.get_details(ref_smpl.contiguous(), src_info["offsets"], links_ids=src_info["links_ids"])
+        key = "selected_f2pts" if use_selected_f2pts else "f2pts"
+        tsf8, Tst, aux = self.flow_comp.frame_inputs(ref_info["cam"].contiguous(), ref_info["verts"], src_info["uv_img4"],
+                                                     src_info[key].contiguous(), want_aux=want_aux)
+        if aux is not None:
+            ref_info.update(aux)
+        return tsf8, Tst, ref_info
+
+    @torch.no_grad()
+    def forward(self, tsf8, Tst):
+        """imitator.py:384-395 on the engine's NHWC input -> (pred (B,3,S,S), mask (B,1,S,S))."""
+        pred, mask, _ = self.generator.run_tsf(tsf8, self.src_info["feats_nhwc"], Tst, bg=self.src_info["bg"],
+                                               want_pred=True, want_mask=True)
+        return pred, mask
+
+    @torch.no_grad()
+    def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0):
+        """Frames [t0, t0+n) of an (already stabilised) device tensor (n,85) -> pred (n,3,S,S) on the device."""
+        outs = []
+        for s in range(0, tgt_smpls.shape[0], self.frame_batch):
+            chunk = tgt_smpls[s:s + self.frame_batch]
+            tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s)
+            outs.append(self.forward(tsf8, Tst)[0])
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def prepare_sequence(self, tgt_smpls, cam_strategy="smooth"):
+        """The sequence-global pre-pass of inference (imitator.py:335-339): to device, stabilise, fix first_cam."""
+        self.first_cam = None
+        tgt = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).to(self.device)
+        if cam_strategy == "smooth":
+            tgt = self.weak_cam_swapper.stabilize(tgt)
+            self.first_cam = tgt[0:1, 0:3].clone()
+        return tgt
+
+    @torch.no_grad()
+    def inference(self, tgt_smpls, cam_strategy="smooth", output_dir="", prefix="pred_", use_selected_f2pts=False,
+                  visualizer=None, verbose=True):
+        """imitator.py:327-382."""
+        tgt = self.prepare_sequence(tgt_smpls, cam_strategy)
+        outputs = []
+        for s in range(0, tgt.shape[0], self.frame_batch):
+            preds = self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s).cpu().numpy()
+            for i in range(preds.shape[0]):
+                if output_dir:
+                    path = os.path.join(output_dir, prefix + "{:0>8}.png".format(s + i))
+                    save_image(preds[i], path)
+                    outputs.append(path)
+                else:
+                    outputs.append(preds[i])
+        return outputs
+
+
+def to_uint8_hwc(pred_chw):
+    """cv_utils.save_cv2_img(normalize=True) numerics (cv_utils.py:100-116): (x+1)/2*255, truncated to uint8."""
+    img = np.transpose(pred_chw, (1, 2, 0))
+    return ((img + 1) / 2.0 * 255).astype(np.uint8)
+
+
+def save_image(pred_chw, path):
+    """Write one frame as PNG.  The reference converts RGB->BGR and calls cv2.imwrite, which stores RGB on disk; cv2
+    is not a dependency here, PIL writes the same RGB pixels."""
+    from PIL import Image
+    Image.fromarray(to_uint8_hwc(pred_chw), mode="RGB").save(path)
+    return path

@@ -1,0 +1,398 @@
+"""AttLWB-SPADE generator behind the reference's generator API, executed by hand-written HIP kernels.
+
+Drop-in for ``iPERCore.models.networks.generators.AttentionLWBGenerator``
+(attlwb_spade_resunet.py:538-699) / ``AttentionLWBFrontGenerator`` (:702-834):
+
+* same constructor ``(cfg, temporal=False)``, same ``state_dict`` keys (checkpoint-compatible), still an
+  ``nn.Module`` (``.parameters()``, ``.to()``, ``.eval()``);
+* same methods and tensor conventions: ``forward_bg`` (:615-631), ``forward_src`` (:450-478),
+  ``forward_tsf`` (:480-535), ``forward`` (:633-699) - NCHW fp32 in / out.
+
+MI355X design (not a translation of the reference's layer objects):
+  - the module is a parameter tree; kernels read re-packed weight panels (``packing.py``) cached per weight
+    version;
+  - activations are NHWC fp32 end to end; every conv is one launch of the MFMA implicit-GEMM kernel with its
+    bias / ReLU / residual / SPADE epilogue fused; a transposed conv is 4 parity launches, the skip concat is
+    read in place (two input pointers), the output head + compositing is one kernel;
+  - the 1x1 ``fk``/``fv`` convs are hoisted out of the frame loop: ``Wk x_src`` / ``Wv x_src`` depend only on
+    the cached source features, and a 1x1 conv commutes with the zero-padded bilinear warp (bias added after
+    the warp, as the reference does) - see ``csrc/lwb_attn.hip``;
+  - frames are independent when ``temporal=False`` so the engine takes a batch of frames per call.
+
+Inference only in this round: the methods run under ``torch.no_grad()`` on CUDA tensors and raise on CPU
+tensors (no fallback).  The backward pass for personalization is a "next" row.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import packing
+from .params import generator_param_shapes
+
+
+class _Node(nn.Module):
+    """A bare container: parameters live at the leaves of a tree of these, named like the reference's modules."""
+
+    def __init__(self):
+        super().__init__()
+
+
+class ParamTree(nn.Module):
+    def __init__(self, shapes):
+        super().__init__()
+        self._shapes = dict(shapes)
+        for name, shape in shapes.items():
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            node.register_parameter(parts[-1], nn.Parameter(torch.empty(*shape)))
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """PyTorch's default Conv2d/ConvTranspose2d init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), ..)."""
+        named = dict(self.named_parameters())
+        for name, p in named.items():
+            if name.endswith(".weight"):
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                bound = 1.0 / math.sqrt(fan_in)
+                p.uniform_(-bound, bound)
+                b = named.get(name[:-len("weight")] + "bias")
+                if b is not None:
+                    b.uniform_(-bound, bound)
+
+
+class _Packed:
+    """Packed weight panels of one generator, rebuilt when a parameter changes (version counters)."""
+
+    def __init__(self, gen):
+        sd = {k: v for k, v in gen.named_parameters()}
+        dev = next(gen.parameters()).device
+        self.device = dev
+        self.version = _param_version(gen)
+        nf, n_res, n_down = gen.num_filters, gen.n_res_block, len(gen.num_filters)
+        P = packing
+
+        def conv(name, stride=1, pad=None, cin_pad=None, n_pad=None):
+            return P.spec_to(P.pack_conv(sd[name + ".weight"], sd.get(name + ".bias"), stride, pad, cin_pad, n_pad), dev)
+
+        def convT(name, n_pad=None):
+            return [P.spec_to(s, dev) for s in P.pack_conv_transpose(sd[name + ".weight"], sd.get(name + ".bias"), n_pad)]
+
+        def site(p):
+            d = {
+                "fq": conv(p + ".fq", pad=0),
+                "fk": P.spec_to(P.pack_conv(sd[p + ".fk.weight"], None, 1, 0), dev),     # bias added after the warp
+                "fv": P.spec_to(P.pack_conv(sd[p + ".fv.weight"], None, 1, 0), dev),
+                "bk": sd[p + ".fk.bias"].detach().float().contiguous(),
+                "bv": sd[p + ".fv.bias"].detach().float().contiguous(),
+                "shared": conv(p + ".spade.mlp_shared.0"),
+                "gb": P.spec_to(P.pack_spade_gamma_beta(sd[p + ".spade.mlp_gamma.weight"], sd[p + ".spade.mlp_gamma.bias"],
+                                                        sd[p + ".spade.mlp_beta.weight"], sd[p + ".spade.mlp_beta.bias"]), dev),
+            }
+            return d
+
+        cin_pad = 8
+        self.tsf_enc = [conv(f"tsf_net_enc.layers.{i}.0", stride=2, cin_pad=cin_pad if i == 0 else None) for i in range(n_down)]
+        self.src_enc = [conv(f"src_net.encoders.layers.{i}.0", stride=2, cin_pad=cin_pad if i == 0 else None) for i in range(n_down)]
+        self.src_res = [(conv(f"src_net.res_blocks.{i}.main.0"), conv(f"src_net.res_blocks.{i}.main.2")) for i in range(n_res)]
+        self.src_dec = [convT(f"src_net.decoders.layers.{i}.0") for i in range(n_down)]
+        self.src_head = P.pack_head(sd["src_net.img_reg.0.weight"], sd["src_net.att_reg.0.weight"]).to(dev)
+        self.res = [(conv(f"res_blocks.{i}.main.0"), conv(f"res_blocks.{i}.main.2")) for i in range(n_res)]
+        self.enc_sites = [site(f"enc_attlwbs.{i}") for i in range(n_down)]
+        self.res_sites = [site(f"res_attlwbs.{i}") for i in range(n_res)]
+        self.upconvs = [convT(f"tsf_net_dec.upconvs.{i}.0") for i in range(n_down)]
+        self.skippers = [conv(f"tsf_net_dec.skippers.{i}.0") for i in range(n_down - 1)]
+        self.head = P.pack_head(sd["tsf_img_reg.0.weight"], sd["tsf_att_reg.0.weight"]).to(dev)
+        self.bg = None
+        if gen.has_bg:
+            bgf = gen.bg_filters
+            i = 0
+            layers = [("conv", conv(f"bg_net.main.{i}", stride=1, pad=3, cin_pad=4))]
+            i += 3
+            for d in range(1, len(bgf)):
+                layers.append(("conv", conv(f"bg_net.main.{i}", stride=2)))
+                i += 3
+            for _ in range(n_res):
+                layers.append(("res", (conv(f"bg_net.main.{i}.main.0"), conv(f"bg_net.main.{i}.main.3"))))
+                i += 1
+            for d in range(len(bgf) - 1, 0, -1):
+                layers.append(("convT", convT(f"bg_net.main.{i}")))
+                i += 3
+            layers.append(("out", conv(f"bg_net.main.{i}", stride=1, pad=3, n_pad=64)))
+            self.bg = layers
+
+
+def _param_version(gen):
+    return tuple((p.data_ptr(), p._version) for p in gen.parameters())
+
+
+class SourceFeatures:
+    """Per-source cache (NHWC): encoder / res-block features and their hoisted K/V projections per AttLWB site."""
+
+    def __init__(self, enc, res, kv, ns, batched=False):
+        self.enc, self.res, self.kv, self.ns, self.batched = enc, res, kv, ns, batched
+
+
+class AttentionLWBGenerator(nn.Module):
+    has_bg = True
+
+    def __init__(self, cfg, temporal=False):
+        super().__init__()
+        self._name = _get(cfg, "name", "AttLWB-SPADE")
+        tsf = _get(cfg, "TSFNet")
+        sid = _get(cfg, "SIDNet")
+        self.num_filters = [int(c) for c in _get(tsf, "num_filters")]
+        self.n_res_block = int(_get(tsf, "n_res_block"))
+        if [int(c) for c in _get(sid, "num_filters")] != self.num_filters or int(_get(sid, "n_res_block")) != self.n_res_block:
+            raise ValueError("SIDNet and TSFNet must share num_filters / n_res_block (the LWB sites pair them up)")
+        for c in self.num_filters:
+            if c not in (64, 128, 256):
+                raise ValueError(f"num_filters entries must be in {{64,128,256}} for the HIP kernels, got {c}")
+        self.cond_nc = int(_get(tsf, "cond_nc"))
+        self.temporal = temporal
+        self.bg_filters, bg_cond = None, 4
+        if self.has_bg:
+            bgc = _get(cfg, "BGNet")
+            self.bg_filters = [int(c) for c in _get(bgc, "num_filters")]
+            bg_cond = int(_get(bgc, "cond_nc"))
+        shapes = generator_param_shapes(self.num_filters, self.n_res_block, self.bg_filters or (), cond_nc=self.cond_nc,
+                                        bg_cond_nc=bg_cond, with_bg=self.has_bg)
+        tree = ParamTree(shapes)
+        for name, child in tree.named_children():     # graft the tree's top-level nodes onto this module
+            self.add_module(name, child)
+        self._packed = None
+
+    # ------------------------------------------------------------------ plumbing
+    def packed(self):
+        if self._packed is None or self._packed.version != _param_version(self):
+            self._packed = _Packed(self)
+        return self._packed
+
+    def _check(self, *tensors):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("training (autograd) through the HIP generator is not built yet (SURVEY 8f-3); "
+                                      "call under torch.no_grad() / .eval()")
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("ipercore_amd generator runs on the MI355X only: got a CPU tensor (no fallback)")
+
+    # ------------------------------------------------------------------ NHWC engine
+    @torch.no_grad()
+    def encode_sources(self, src8, batched=False, ns=None):
+        """src8: (n, S, S, 8) NHWC (6 used) -> SourceFeatures with K/V panels for the 9 AttLWB sites."""
+        pk = self.packed()
+        x = src8
+        enc, res = [], []
+        for i, spec in enumerate(pk.src_enc):
+            n, H, W, _ = x.shape
+            y = x.new_empty(n, H // 2, W // 2, spec.N)
+            x = ops.conv2d(x, spec, y, act=ops.ACT_RELU)
+            enc.append(x)
+        for c0, c1 in pk.src_res:
+            h = ops.conv2d(x, c0, torch.empty_like(x), act=ops.ACT_RELU)
+            x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
+            res.append(x)
+        kv = []
+        for feats, sites in ((enc, pk.enc_sites), (res, pk.res_sites)):
+            for f, st in zip(feats, sites):
+                kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
+        return SourceFeatures(enc, res, kv, ns if ns is not None else src8.shape[0], batched)
+
+    def _attlwb(self, st, tsf_x, kv, Tst, batched, scratch):
+        B, h, w, C = tsf_x.shape
+        q = ops.conv2d(tsf_x, st["fq"], torch.empty_like(tsf_x))
+        att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], Tst, torch.empty_like(tsf_x), src_batched=batched)
+        mean = tsf_x.new_empty(B, C)
+        rstd = tsf_x.new_empty(B, C)
+        nsplit = max(1, min(64, (h * w) // 256))
+        ws = scratch.get(B * C * nsplit * 3, tsf_x.device)
+        ops.instnorm_stats(tsf_x, mean, rstd, ws, eps=1e-5, nsplit=nsplit)
+        actv = ops.conv2d(att, st["shared"], tsf_x.new_empty(B, h, w, st["shared"].N), act=ops.ACT_RELU)
+        return ops.conv2d(actv, st["gb"], torch.empty_like(tsf_x), epi=ops.EPI_SPADE, xn=tsf_x, mean=mean, rstd=rstd)
+
+    @staticmethod
+    def _upconv(x, specs, act):
+        B, H, W, _ = x.shape
+        y = x.new_empty(B, 2 * H, 2 * W, specs[0].N)
+        for s in specs:
+            ops.conv2d(x, s, y, act=act)
+        return y
+
+    @torch.no_grad()
+    def run_tsf(self, tsf8, feats, Tst, bg=None, want_pred=True, want_mask=True, want_img=False):
+        """tsf8 (B,S,S,8) NHWC; feats: SourceFeatures; Tst (B,ns,S,S,2) -> (pred, mask, img) NCHW (None if not asked)."""
+        pk = self.packed()
+        scratch = _Scratch()
+        n_down = len(pk.tsf_enc)
+        x = tsf8
+        enc = []
+        site = 0
+        for i, spec in enumerate(pk.tsf_enc):
+            B, H, W, _ = x.shape
+            x = ops.conv2d(x, spec, x.new_empty(B, H // 2, W // 2, spec.N), act=ops.ACT_RELU)
+            x = self._attlwb(pk.enc_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
+            site += 1
+            enc.append(x)
+        for i, (c0, c1) in enumerate(pk.res):
+            h = ops.conv2d(x, c0, torch.empty_like(x), act=ops.ACT_RELU)
+            x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
+            x = self._attlwb(pk.res_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
+            site += 1
+        for i in range(n_down):
+            x = self._upconv(x, pk.upconvs[i], ops.ACT_RELU)
+            if i != n_down - 1:
+                skip = enc[n_down - 2 - i]
+                sp = pk.skippers[i]
+                x = ops.conv2d(skip, sp, x.new_empty(x.shape[0], x.shape[1], x.shape[2], sp.N), x1=x, act=ops.ACT_RELU)
+        return ops.head_compose(x, pk.head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img)
+
+    @torch.no_grad()
+    def run_bg(self, bg4):
+        """bg4 (n,S,S,4) NHWC -> (n,3,S,S) NCHW."""
+        pk = self.packed()
+        scratch = _Scratch()
+        x = bg4
+
+        def norm(t, act, res=None):
+            B, h, w, C = t.shape
+            mean, rstd = t.new_empty(B, C), t.new_empty(B, C)
+            nsplit = max(1, min(64, (h * w) // 256))
+            ops.instnorm_stats(t, mean, rstd, scratch.get(B * C * nsplit * 3, t.device), eps=1e-5, nsplit=nsplit)
+            return ops.instnorm_apply(t, mean, rstd, torch.empty_like(t), act=act, res=res)
+
+        for kind, spec in pk.bg:
+            B, H, W, _ = x.shape
+            if kind == "conv":
+                y = ops.conv2d(x, spec, x.new_empty(B, H // spec.stride, W // spec.stride, spec.N))
+                x = norm(y, ops.ACT_RELU)
+            elif kind == "res":
+                h = norm(ops.conv2d(x, spec[0], torch.empty_like(x)), ops.ACT_RELU)
+                x = norm(ops.conv2d(h, spec[1], torch.empty_like(x)), ops.ACT_NONE, res=x)
+            elif kind == "convT":
+                x = norm(self._upconv(x, spec, ops.ACT_NONE), ops.ACT_RELU)
+            else:
+                y = ops.conv2d(x, spec, x.new_empty(B, H, W, spec.N), act=ops.ACT_TANH)
+                return ops.nhwc_to_nchw(y, channels=3)
+
+    @torch.no_grad()
+    def run_src_decode(self, x):
+        """SIDNet decoder + regressors on the last res-block feature (forward_src(only_enc=False))."""
+        pk = self.packed()
+        for specs in pk.src_dec:
+            x = self._upconv(x, specs, ops.ACT_RELU)
+        _, mask, img = ops.head_compose(x, pk.src_head, None, want_pred=False, want_mask=True, want_img=True)
+        return img, mask
+
+    # ------------------------------------------------------------------ reference API (NCHW)
+    @torch.no_grad()
+    def forward_bg(self, bg_inputs):
+        """(bs, ns, 4, h, w) -> (bs, ns, 3, h, w)  (attlwb_spade_resunet.py:615-631)."""
+        if not self.has_bg:
+            raise AttributeError("this generator has no background network")
+        self._check(bg_inputs)
+        bs, ns, c, h, w = bg_inputs.shape
+        x = ops.nchw_to_nhwc(bg_inputs.reshape(bs * ns, c, h, w).contiguous().float(), c_pad=4)
+        return self.run_bg(x).view(bs, ns, 3, h, w)
+
+    @torch.no_grad()
+    def forward_src(self, src_inputs, only_enc=True):
+        """(bs, ns, 6, h, w) -> (enc_outs, res_outs[, img, mask]) as NCHW lists (:450-478).  The returned lists carry
+        the NHWC/KV cache so a following ``forward_tsf`` does not recompute it."""
+        self._check(src_inputs)
+        bs, ns, c, h, w = src_inputs.shape
+        src8 = ops.nchw_to_nhwc(src_inputs.reshape(bs * ns, c, h, w).contiguous().float(), c_pad=8)
+        feats = self.encode_sources(src8, batched=bs > 1, ns=ns)
+        enc = _FeatList(ops.nhwc_to_nchw(t) for t in feats.enc)
+        res = _FeatList(ops.nhwc_to_nchw(t) for t in feats.res)
+        enc.lwg_cache = res.lwg_cache = feats
+        if only_enc:
+            return enc, res
+        img, mask = self.run_src_decode(feats.res[-1])
+        return enc, res, img.view(bs, ns, 3, h, w), mask.view(bs, ns, 1, h, w)
+
+    def _features_from_api(self, src_enc_outs, src_res_outs, bs):
+        cache = getattr(src_enc_outs, "lwg_cache", None)
+        if cache is not None and getattr(src_res_outs, "lwg_cache", None) is cache:
+            return cache
+        pk = self.packed()
+        enc = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_enc_outs]
+        res = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_res_outs]
+        kv = []
+        for fl, sites in ((enc, pk.enc_sites), (res, pk.res_sites)):
+            for f, st in zip(fl, sites):
+                kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
+        n = enc[0].shape[0]
+        return SourceFeatures(enc, res, kv, n // bs, batched=bs > 1)
+
+    @torch.no_grad()
+    def forward_tsf(self, tsf_inputs, src_enc_outs, src_res_outs, Tst, temp_enc_outs=None, temp_res_outs=None, Ttt=None):
+        """(bs,6,h,w), src feats, Tst (bs,ns,h,w,2) -> (tsf_img (bs,3,h,w), tsf_mask (bs,1,h,w))  (:480-535)."""
+        if temp_enc_outs is not None or Ttt is not None:
+            raise NotImplementedError("temporal attention (Ttt / TemporalFIFO) is a 'next' row (SURVEY 8f-4)")
+        self._check(tsf_inputs, Tst)
+        bs = tsf_inputs.shape[0]
+        feats = self._features_from_api(src_enc_outs, src_res_outs, bs)
+        tsf8 = ops.nchw_to_nhwc(tsf_inputs.contiguous().float(), c_pad=8)
+        _, mask, img = self.run_tsf(tsf8, feats, Tst.contiguous().float(), bg=None, want_pred=False, want_mask=True, want_img=True)
+        return img, mask
+
+    @torch.no_grad()
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
+        """:633-699 with temporal=False: Tst (bs, nt, ns, h, w, 2), tsf_inputs (bs, nt, 6, h, w)."""
+        bs, nt = Tst.shape[0], Tst.shape[1]
+        bg_img = self.forward_bg(bg_inputs)
+        if only_tsf:
+            enc, res = self.forward_src(src_inputs, only_enc=True)
+            src_imgs = src_masks = None
+        else:
+            enc, res, src_imgs, src_masks = self.forward_src(src_inputs, only_enc=False)
+        imgs, masks = [], []
+        for t in range(nt):
+            if t != 0 and self.temporal:
+                raise NotImplementedError("temporal attention is a 'next' row (SURVEY 8f-4)")
+            img, mask = self.forward_tsf(tsf_inputs[:, t], enc, res, Tst[:, t].contiguous())
+            imgs.append(img)
+            masks.append(mask)
+        imgs, masks = torch.stack(imgs, dim=1), torch.stack(masks, dim=1)
+        if only_tsf:
+            return bg_img, imgs, masks
+        return bg_img, src_imgs, src_masks, imgs, masks
+
+
+class AttentionLWBFrontGenerator(AttentionLWBGenerator):
+    """attlwb_spade_resunet.py:702-834: same network without the background branch."""
+    has_bg = False
+
+    def forward(self, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
+        raise NotImplementedError("AttLWB-Front-SPADE.forward is used by LWGFrontTrainer only (training: next row)")
+
+
+class _FeatList(list):
+    """A list that can carry the engine's cache as an attribute (plain lists cannot)."""
+
+
+class _Scratch:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, n, device):
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf = torch.empty(max(n, 1 << 16), device=device, dtype=torch.float32)
+        return self.buf
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        if key in cfg:
+            return cfg[key]
+    elif hasattr(cfg, key):
+        return getattr(cfg, key)
+    if default is not None:
+        return default
+    raise KeyError(key)

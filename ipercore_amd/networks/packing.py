@@ -1,0 +1,94 @@
+"""Weight re-layout for the HIP kernels (done once per weight load, on whatever device the weights live).
+
+The implicit-GEMM kernel (csrc/conv_igemm.hip) wants the GEMM B panel as ``[K/4][N][4]`` fp32 with
+``k = tap * Cin + c`` and K padded to a multiple of 32, so one lane's 16-byte load is four consecutive k of
+one output channel.  ``state_dict`` tensors keep PyTorch's OIHW / IOHW layouts (checkpoint compatibility);
+only these packed copies are what the kernels read.
+"""
+import torch
+
+from ..ops import ConvSpec
+
+
+def _panel(wk):
+    """(K, N) -> contiguous (ceil32(K)/4, N, 4)."""
+    K, N = wk.shape
+    Kp = (K + 31) // 32 * 32
+    if Kp != K:
+        wk = torch.cat([wk, wk.new_zeros(Kp - K, N)], dim=0)
+    return wk.view(Kp // 4, 4, N).permute(0, 2, 1).contiguous()
+
+
+def _pad_vec(b, n):
+    if b is None:
+        return None
+    b = b.detach().float()
+    if b.numel() == n:
+        return b.contiguous()
+    return torch.cat([b, b.new_zeros(n - b.numel())]).contiguous()
+
+
+def pack_conv(weight, bias=None, stride=1, pad=None, cin_pad=None, n_pad=None):
+    """nn.Conv2d weight (N, Cin, kh, kw) -> ConvSpec.  ``cin_pad``: zero-extend input channels (6 -> 8);
+    ``n_pad``: zero-extend output channels to the kernel's 64-column granularity."""
+    weight = weight.detach().float()
+    N, Cin, kh, kw = weight.shape
+    pad = kh // 2 if pad is None else pad
+    Cp = Cin if cin_pad is None else cin_pad
+    Np = N if n_pad is None else n_pad
+    w = weight.new_zeros(kh * kw, Cp, Np)
+    w[:, :Cin, :N] = weight.permute(2, 3, 1, 0).reshape(kh * kw, Cin, N)
+    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+    return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np)), _pad_vec(bias, Np), Np, Cp, taps, stride=stride)
+
+
+# output parity -> [(kernel index, input offset)] for ConvTranspose2d(kernel 4, stride 2, padding 1):
+# out[2a]   = x[a] * w[1] + x[a-1] * w[3];   out[2a+1] = x[a+1] * w[0] + x[a] * w[2]
+_CT_TAPS = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}
+
+
+def pack_conv_transpose(weight, bias=None, n_pad=None):
+    """nn.ConvTranspose2d(k=4, s=2, p=1) weight (Cin, Cout, 4, 4) -> four ConvSpecs, one per output parity."""
+    weight = weight.detach().float()
+    Cin, N, kh, kw = weight.shape
+    assert kh == 4 and kw == 4
+    Np = N if n_pad is None else n_pad
+    specs = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps, mats = [], []
+            for ky, dy in _CT_TAPS[py]:
+                for kx, dx in _CT_TAPS[px]:
+                    taps.append((dy, dx))
+                    m = weight.new_zeros(Cin, Np)
+                    m[:, :N] = weight[:, :, ky, kx]
+                    mats.append(m)
+            wk = torch.stack(mats, dim=0).reshape(len(taps) * Cin, Np)
+            specs.append(ConvSpec(_panel(wk), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px))
+    return specs
+
+
+def pack_spade_gamma_beta(w_gamma, b_gamma, w_beta, b_beta):
+    """mlp_gamma / mlp_beta (C, 128, 3, 3) each -> one ConvSpec with N = 2C whose columns alternate in blocks of
+    32: [gamma c0..c31 | beta c0..c31 | gamma c32..c63 | ...] so one wave holds gamma and beta of the same
+    channels (SPADE epilogue of the conv kernel)."""
+    C = w_gamma.shape[0]
+    assert C % 32 == 0
+    wg = w_gamma.detach().float().view(C // 32, 32, *w_gamma.shape[1:])
+    wb = w_beta.detach().float().view(C // 32, 32, *w_beta.shape[1:])
+    w = torch.stack([wg, wb], dim=1).reshape(2 * C, *w_gamma.shape[1:])
+    b = torch.stack([b_gamma.detach().float().view(C // 32, 32), b_beta.detach().float().view(C // 32, 32)], dim=1).reshape(2 * C)
+    return pack_conv(w, b, stride=1)
+
+
+def pack_head(w_img, w_att):
+    """tsf_img_reg (3,C,5,5) + tsf_att_reg (1,C,5,5) -> (25, C, 4) fp32 for csrc/head.hip."""
+    w = torch.cat([w_img.detach().float(), w_att.detach().float()], dim=0)       # (4, C, 5, 5)
+    return w.permute(2, 3, 1, 0).reshape(25, w.shape[1], 4).contiguous()
+
+
+def spec_to(spec, device):
+    spec.w = spec.w.to(device)
+    if spec.bias is not None:
+        spec.bias = spec.bias.to(device)
+    return spec

@@ -1,0 +1,217 @@
+"""Thin tensor-level wrappers over the C ABI (include/lwg_hip.h).
+
+PyTorch-ROCm is plumbing here: it owns device memory and the stream; every compute call goes through
+``liblwg_hip.so``.  All wrappers require contiguous CUDA tensors and raise otherwise - there is no eager /
+CPU fallback on the product path.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EPI_NONE, EPI_RESIDUAL, EPI_SPADE  # noqa: F401
+
+EYE_DIST = 2.7320508075688776   # 1/tan(30 deg) + 1 (reference renders/nmr.py:225)
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("ipercore_amd ops need CUDA (HIP) tensors: the MI355X path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ConvSpec:
+    """Host description of one packed convolution (weights already in the kernel's layout)."""
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox")
+
+    def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0):
+        self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
+        self.ntaps = len(taps)
+        self.dy = [int(t[0]) for t in taps]
+        self.dx = [int(t[1]) for t in taps]
+        self.stride, self.omul, self.ooy, self.oox = stride, omul, ooy, oox
+        self.cshift = 0
+        if self.Cin % 32 != 0:
+            q = self.Cin // 4
+            assert q in (1, 2, 4), "small-Cin path handles Cin in {4, 8, 16}"
+            self.cshift = q.bit_length() - 1
+
+
+def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
+           out_hw=None, ycoff=0):
+    """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place)."""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    assert C0 + C1 == spec.Cin, (C0, C1, spec.Cin)
+    YB, YH, YW, YC = y.shape
+    if out_hw is None:
+        OH, OW = (YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul)
+    else:
+        OH, OW = out_hw
+    a = _lib.LwgConvArgs()
+    a.x0, a.x1 = _ptr(x0), _ptr(x1)
+    a.C0, a.C1 = C0, C1
+    a.B, a.H, a.W = B, H, W
+    a.OH, a.OW, a.M = OH, OW, B * OH * OW
+    a.stride, a.ntaps, a.cshift = spec.stride, spec.ntaps, spec.cshift
+    a.w, a.N, a.bias = _ptr(spec.w), spec.N, _ptr(spec.bias)
+    a.y, a.YH, a.YW, a.YC, a.ycoff = _ptr(y), YH, YW, YC, ycoff
+    a.omul, a.ooy, a.oox = spec.omul, spec.ooy, spec.oox
+    a.epi, a.act = epi, act
+    a.res, a.xn, a.mean, a.rstd = _ptr(res), _ptr(xn), _ptr(mean), _ptr(rstd)
+    for i in range(spec.ntaps):
+        a.dy[i] = spec.dy[i]
+        a.dx[i] = spec.dx[i]
+    _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+    return y
+
+
+def instnorm_stats(x, mean, rstd, ws, eps=1e-5, nsplit=None):
+    B, H, W, C = x.shape
+    HW = H * W
+    if nsplit is None:
+        nsplit = max(1, min(64, HW // 256))
+    assert ws.numel() >= B * C * nsplit * 3
+    _lib.check(_lib.lib().lwg_instnorm_stats_nhwc_f32(_ptr(x), B, HW, C, eps, _ptr(mean), _ptr(rstd), _ptr(ws), nsplit,
+                                                       _stream()), "lwg_instnorm_stats_nhwc_f32")
+
+
+def instnorm_apply(x, mean, rstd, y, act=ACT_NONE, res=None):
+    B, H, W, C = x.shape
+    _lib.check(_lib.lib().lwg_instnorm_apply_nhwc_f32(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(res), _ptr(y), B, H * W, C, act,
+                                                       _stream()), "lwg_instnorm_apply_nhwc_f32")
+    return y
+
+
+def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
+    B, h, w, C = q.shape
+    ns = T.shape[1]
+    S = T.shape[2]
+    assert T.shape[0] == B and Ks.shape[0] == (B * ns if src_batched else ns) and tuple(Ks.shape[1:]) == (h, w, C)
+    _lib.check(_lib.lib().lwg_lwb_attention_f32(_ptr(q), _ptr(Ks), _ptr(Vs), _ptr(bk), _ptr(bv), _ptr(T), _ptr(out), B, ns, h,
+                                                 w, C, S, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_f32")
+    return out
+
+
+def project_faces(verts, cam, faces, want_faces_v=True, want_f2pts=True):
+    B, nv, _ = verts.shape
+    nf = faces.shape[0]
+    fv = torch.empty(B, nf, 3, 3, device=verts.device, dtype=torch.float32) if want_faces_v else None
+    f2 = torch.empty(B, nf, 3, 2, device=verts.device, dtype=torch.float32) if want_f2pts else None
+    cam = cam.contiguous()
+    _lib.check(_lib.lib().lwg_project_faces_f32(_ptr(verts), _ptr(cam), _ptr(faces, torch.int32), B, nv, nf, EYE_DIST, _ptr(fv),
+                                                 _ptr(f2), _stream()), "lwg_project_faces_f32")
+    return fv, f2
+
+
+def rasterize_fim_wim(faces_v, image_size, near=0.1, far=100.0):
+    B, nf = faces_v.shape[0], faces_v.shape[1]
+    S = int(image_size)
+    dev = faces_v.device
+    fim = torch.empty(B, S, S, device=dev, dtype=torch.int32)
+    wim = torch.empty(B, S, S, 3, device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().lwg_rasterize_ws_bytes(B, nf), device=dev, dtype=torch.uint8)
+    _lib.check(_lib.lib().lwg_rasterize_fim_wim_f32(_ptr(faces_v), B, nf, S, near, far, _ptr(fim, torch.int32), _ptr(wim),
+                                                     ws.data_ptr(), _stream()), "lwg_rasterize_fim_wim_f32")
+    return fim, wim
+
+
+def flow_compose(fim, wim, map_fn, f_uvs2img, uv_img4, src_f2pts, want_cond=False, want_tuv=False):
+    B, S, _ = fim.shape
+    nf = f_uvs2img.shape[0]
+    ns = src_f2pts.shape[0]
+    dev = fim.device
+    tsf = torch.empty(B, S, S, 8, device=dev, dtype=torch.float32)
+    Tst = torch.empty(B, ns, S, S, 2, device=dev, dtype=torch.float32)
+    cond = torch.empty(B, 3, S, S, device=dev, dtype=torch.float32) if want_cond else None
+    tuv = torch.empty(B, S, S, 2, device=dev, dtype=torch.float32) if want_tuv else None
+    Hu, Wu = uv_img4.shape[0], uv_img4.shape[1]
+    _lib.check(_lib.lib().lwg_flow_compose_f32(_ptr(fim, torch.int32), _ptr(wim), B, S, _ptr(map_fn), nf, _ptr(f_uvs2img),
+                                                _ptr(uv_img4), Hu, Wu, _ptr(src_f2pts), ns, _ptr(tsf), _ptr(Tst), _ptr(cond),
+                                                _ptr(tuv), _stream()), "lwg_flow_compose_f32")
+    return tsf, Tst, cond, tuv
+
+
+def bc_transform(f2pts, fim, wim):
+    B, S, _ = fim.shape
+    nf = f2pts.shape[1]
+    T = torch.empty(B, S, S, 2, device=fim.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_bc_transform_f32(_ptr(f2pts), _ptr(fim, torch.int32), _ptr(wim), B, S, nf, _ptr(T), _stream()),
+               "lwg_bc_transform_f32")
+    return T
+
+
+def encode_fim(fim, map_fn):
+    B, S, _ = fim.shape
+    D = map_fn.shape[1]
+    out = torch.empty(B, D, S, S, device=fim.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_encode_fim_f32(_ptr(fim, torch.int32), _ptr(map_fn), B, S, map_fn.shape[0] - 1, D, _ptr(out),
+                                              _stream()), "lwg_encode_fim_f32")
+    return out
+
+
+def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
+    B, S, _, C = x.shape
+    dev = x.device
+    pred = torch.empty(B, 3, S, S, device=dev, dtype=torch.float32) if want_pred else None
+    mask = torch.empty(B, 1, S, S, device=dev, dtype=torch.float32) if want_mask else None
+    img = torch.empty(B, 3, S, S, device=dev, dtype=torch.float32) if want_img else None
+    bstride = 0
+    if bg is not None and bg.shape[0] != 1:
+        assert bg.shape[0] == B
+        bstride = 3 * S * S
+    _lib.check(_lib.lib().lwg_head_compose_f32(_ptr(x), _ptr(wpk), _ptr(bg), bstride, B, S, C, _ptr(pred), _ptr(mask), _ptr(img),
+                                                _stream()), "lwg_head_compose_f32")
+    return pred, mask, img
+
+
+def nchw_to_nhwc(x, c_pad=None):
+    B, C = x.shape[0], x.shape[1]
+    H, W = x.shape[2], x.shape[3]
+    Cp = C if c_pad is None else c_pad
+    y = torch.empty(B, H, W, Cp, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_nchw_to_nhwc_f32(_ptr(x), _ptr(y), B, C, Cp, H * W, _stream()), "lwg_nchw_to_nhwc_f32")
+    return y
+
+
+def nhwc_to_nchw(x, channels=None):
+    B, H, W, Cs = x.shape
+    C = Cs if channels is None else channels
+    y = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_nhwc_to_nchw_f32(_ptr(x), _ptr(y), B, C, Cs, H * W, _stream()), "lwg_nhwc_to_nchw_f32")
+    return y
+
+
+def smpl_lbs(model, pose, beta, cam, offsets=None, links=None):
+    """model: dict of device buffers (v_template, shapedirs, posedirs, J_regressor, parents int32, lbs_weights)."""
+    B = pose.shape[0]
+    nv = model["v_template"].shape[0]
+    nj = model["J_regressor"].shape[0]
+    dev = pose.device
+    assert pose.shape[1] == 3 * nj, (pose.shape, nj)
+    verts = torch.empty(B, nv, 3, device=dev, dtype=torch.float32)
+    j3d = torch.empty(B, nj, 3, device=dev, dtype=torch.float32)
+    j2d = torch.empty(B, nj, 2, device=dev, dtype=torch.float32) if cam is not None else None
+    ws = torch.empty(_lib.lib().lwg_smpl_lbs_ws_floats(B, nv, nj), device=dev, dtype=torch.float32)
+    off_batched = 0
+    if offsets is not None:
+        off_batched = 1 if offsets.dim() == 3 else 0
+        if off_batched:
+            assert offsets.shape[0] == B
+    nlinks = 0 if links is None else links.shape[0]
+    nbeta = beta.shape[1]
+    _lib.check(_lib.lib().lwg_smpl_lbs_f32(
+        _ptr(pose), pose.shape[1], _ptr(beta), nbeta, nbeta, _ptr(cam), 0 if cam is None else cam.shape[1],
+        _ptr(model["v_template"]), _ptr(offsets), off_batched, _ptr(model["shapedirs"]), _ptr(model["posedirs"]),
+        _ptr(model["J_regressor"]), _ptr(model["parents"], torch.int32), _ptr(model["lbs_weights"]),
+        _ptr(links, torch.int32), nlinks, B, nv, nj, _ptr(verts), _ptr(j3d), _ptr(j2d), _ptr(ws), _stream()),
+        "lwg_smpl_lbs_f32")
+    return verts, j3d, j2d

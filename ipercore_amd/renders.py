@@ -1,0 +1,176 @@
+"""SMPL mesh renderer behind the reference's ``SMPLRenderer`` API, rasterizing on the MI355X.
+
+Drop-in for ``iPERCore.tools.human_digitalizer.renders.SMPLRenderer`` (renders/nmr.py:128-225 buffers,
+:298-358 render_fim / render_fim_wim / render_uv_fim_wim, :390-408 encode_fim / encode_front_fim,
+:597-681 get_f_uvs2img / get_selected_f2pts / get_vis_f2pts, :713-757 cal_bc_transform, :579-595
+create_meshgrid), for the methods the per-frame path and ``source_setup`` use.  The third-party CUDA package
+``neural_renderer`` is replaced by ``csrc/raster.hip`` (see ``ipercore_amd/nr.py`` for the function-level
+drop-in).  Textured rendering (``render`` / ``forward``, nmr.py:243-296) is a "next" row and raises.
+
+Constructor arguments are the reference's; each ``*_path`` may also be ``None`` to use the packed topology
+asset (``ipercore_amd/assets/smpl_topology.npz``, same data as assets/configs/pose3d/*).  The reference's
+batch-of-3 workaround (nmr.py:814-943) is not needed: any batch size is rasterized in one launch.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .geometry import mesh
+
+
+class SMPLRenderer(nn.Module):
+    def __init__(self, face_path=None, fim_enc_path=None, uv_map_path=None, part_path=None, front_path=None,
+                 head_path=None, facial_path=None, map_name="uv_seg", tex_size=3, image_size=256,
+                 anti_aliasing=True, fill_back=False, background_color=(0, 0, 0), viewing_angle=30, near=0.1, far=25.0,
+                 has_front=False, top_k=5):
+        super().__init__()
+        if fill_back:
+            raise NotImplementedError("fill_back=True is not used by the Imitator path (flowcomposition.py:66)")
+        topo = None
+        if None in (face_path, fim_enc_path, uv_map_path, part_path, front_path, head_path, facial_path):
+            topo = mesh.load_topology()
+        self.background_color = background_color
+        self.anti_aliasing = anti_aliasing
+        self.image_size = image_size
+        self.fill_back = fill_back
+        self.map_name = map_name
+        self.tex_size = tex_size
+
+        fim_obj = mesh.load_obj(fim_enc_path) if fim_enc_path is not None else mesh.obj_from_topology(topo, "fim")
+        uv_obj = mesh.load_obj(uv_map_path) if uv_map_path is not None else mesh.obj_from_topology(topo, "uv")
+        self.obj_info = fim_obj
+        smpl_faces = np.load(face_path) if face_path is not None else topo["faces_uv"]
+        obj_faces = fim_obj["faces"]
+        self.base_nf = self.nf = smpl_faces.shape[0]
+        part_info = part_path if part_path is not None else {str(n): topo["part_" + str(n)] for n in topo["part_names"]}
+        head_info = head_path if head_path is not None else topo["head"]
+
+        self.register_buffer("smpl_faces", torch.tensor(smpl_faces.astype(np.int32)).int())
+        self.register_buffer("obj_faces", torch.tensor(obj_faces.astype(np.int32)).int())
+        self.register_buffer("map_fn", torch.tensor(mesh.create_mapping(map_name, fim_obj, part_path=part_info,
+                                                                        contain_bg=True)).float())
+        if has_front:
+            self.register_buffer("front_map_fn", torch.tensor(mesh.create_mapping(
+                "head", fim_obj, head_path=head_info, contain_bg=True)).float())
+        else:
+            self.front_map_fn = None
+        self.body_parts = mesh.get_part_ids(self.nf, part_info)
+        f_img2uvs = mesh.get_f2vts(fim_obj, z=1)
+        self.register_buffer("f_img2uvs", torch.tensor(f_img2uvs).float())
+        self.register_buffer("face_k_nearest", torch.tensor(
+            mesh.find_part_k_nearest_faces(f_img2uvs, self.body_parts, k=top_k)).long())
+        self.register_buffer("f_uvs2img", torch.tensor(mesh.get_f2vts(uv_obj, z=1)[:, :, 0:2]).float().contiguous())
+        self.register_buffer("coords", self.create_coords(tex_size))
+        self.register_buffer("img2uv_sampler", torch.tensor(mesh.create_uvsampler(uv_obj, tex_size=tex_size)).float())
+        self.near, self.far = near, far
+        self.viewing_angle = viewing_angle
+        self.eye = [0, 0, -(1. / np.tan(np.radians(self.viewing_angle)) + 1)]
+        if viewing_angle != 30:
+            raise NotImplementedError("the projection kernel folds look_at for viewing_angle=30 (reference default)")
+
+    def set_img_size(self, image_size):
+        self.image_size = image_size
+
+    # ------------------------------------------------------------------ rasterization
+    def _faces(self, smpl_faces):
+        return self.smpl_faces if smpl_faces else self.obj_faces
+
+    @torch.no_grad()
+    def render_fim_wim(self, cam, vertices, smpl_faces=True):
+        """nmr.py:319-342 -> f2pts (bs,nf,3,2), fim (bs,S,S) int32, wim (bs,S,S,3)."""
+        fv, f2pts = ops.project_faces(vertices.float().contiguous(), cam.float().contiguous(), self._faces(smpl_faces))
+        fim, wim = ops.rasterize_fim_wim(fv, self.image_size)          # the reference passes no near/far here
+        return f2pts, fim, wim
+
+    @torch.no_grad()
+    def render_fim(self, cam, vertices, smpl_faces=True):
+        """nmr.py:298-317."""
+        fv, _ = ops.project_faces(vertices.float().contiguous(), cam.float().contiguous(), self._faces(smpl_faces),
+                                  want_f2pts=False)
+        return ops.rasterize_fim_wim(fv, self.image_size)[0]
+
+    @torch.no_grad()
+    def render_uv_fim_wim(self, bs):
+        """nmr.py:344-358: the UV atlas itself rasterized (constant z = 1), identical for every batch item."""
+        f = self.f_img2uvs.clone()
+        f[:, :, 1] *= -1
+        fim, wim = ops.rasterize_fim_wim(f.unsqueeze(0).contiguous(), self.image_size)
+        return fim.repeat(bs, 1, 1), wim.repeat(bs, 1, 1, 1)
+
+    # ------------------------------------------------------------------ codes and flows
+    @torch.no_grad()
+    def encode_fim(self, cam=None, vertices=None, fim=None, transpose=True, map_fn=None):
+        """nmr.py:390-401 -> (fim_enc, fim)."""
+        assert (cam is not None and vertices is not None) or fim is not None
+        if fim is None:
+            fim = self.render_fim(cam, vertices)
+        table = self.map_fn if map_fn is None else map_fn
+        enc = ops.encode_fim(fim.contiguous(), table.float().contiguous())
+        if not transpose:
+            enc = enc.permute(0, 2, 3, 1)
+        return enc, fim
+
+    @torch.no_grad()
+    def encode_front_fim(self, fim, transpose=True):
+        enc = ops.encode_fim(fim.contiguous(), self.front_map_fn)
+        return enc if transpose else enc.permute(0, 2, 3, 1)
+
+    @torch.no_grad()
+    def cal_bc_transform(self, src_f2pts, dst_fims, dst_wims):
+        """nmr.py:713-757 -> T (bs,S,S,2); background = -2."""
+        return ops.bc_transform(src_f2pts[..., 0:2].float().contiguous(), dst_fims.contiguous(), dst_wims.contiguous())
+
+    def get_f_uvs2img(self, bs):
+        return self.f_uvs2img.repeat(bs, 1, 1, 1)
+
+    @torch.no_grad()
+    def get_vis_f2pts(self, f2pts, fims):
+        """nmr.py:639-681: keep visible faces and their k nearest same-part faces, others -> -2.  Off the hot path
+        (only consumed when ``only_vis`` is set, flowcomposition.py:559-562); done with index ops, host-sync free."""
+        single = f2pts.dim() == 3
+        if single:
+            f2pts, fims = f2pts.unsqueeze(0), fims.unsqueeze(0)
+        bs, nf = f2pts.shape[0], f2pts.shape[1]
+        out = torch.full_like(f2pts, -2.0)
+        for i in range(bs):
+            # the reference drops the smallest unique value assuming it is the background id -1 (nmr.py:660)
+            seen = torch.zeros(nf + 1, dtype=torch.bool, device=f2pts.device)
+            seen[(fims[i].reshape(-1).long() + 1)] = True
+            first = int(torch.nonzero(seen)[0])
+            seen[first] = False
+            vis = seen[1:]
+            keep = torch.zeros(nf, dtype=torch.bool, device=f2pts.device)
+            keep[self.face_k_nearest[vis].reshape(-1)] = True
+            out[i][keep] = f2pts[i][keep]
+        return out[0] if single else out
+
+    def get_selected_f2pts(self, f2pts, selected_fids):
+        """nmr.py:601-637."""
+        def sel(orig, ids):
+            o = torch.zeros_like(orig) - 2.0
+            o[ids] = orig[ids]
+            return o
+        if f2pts.dim() == 4:
+            return torch.stack([sel(f2pts[i], selected_fids[i]) for i in range(f2pts.shape[0])], dim=0)
+        return sel(f2pts, selected_fids)
+
+    # ------------------------------------------------------------------ small host helpers
+    @staticmethod
+    def create_coords(tex_size=3):
+        step = 1 if tex_size == 1 else 1 / (tex_size - 1)
+        ab = torch.arange(0, 1 + step, step, dtype=torch.float32)
+        xv, yv = torch.meshgrid([ab, ab], indexing="ij")
+        return torch.stack([xv.flatten(), yv.flatten()], dim=0)
+
+    @staticmethod
+    def create_meshgrid(image_size):
+        f = torch.arange(0, image_size, dtype=torch.float32) / (image_size - 1)
+        f = (f - 0.5) * 2
+        xv, yv = torch.meshgrid([f, f], indexing="ij")
+        return torch.stack([yv, xv], dim=-1)
+
+    def render(self, *args, **kwargs):
+        raise NotImplementedError("textured rendering (nr.rasterize + nr.lighting) is a 'next' row (SURVEY 8f-4)")
+
+    forward = render

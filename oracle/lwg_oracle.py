@@ -365,14 +365,14 @@ def to_uint8_bgr(pred_chw):
 # --------------------------------------------------------------------------------------------------
 # whole frame (a1..a13), used by parity tests and bench.py's cpu_baseline
 # --------------------------------------------------------------------------------------------------
-def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size):
+def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, cam_strategy="smooth"):
     """One iteration of Imitator.inference (models/imitator.py:341-395, temporal=False, cam "smooth").
 
     tables: dict(smpl_faces, map_fn, f_uvs2img).  src_info: dict(cam, shape, offsets, links_ids, uv_img, bg,
     f2pts (ns,nf,3,2), feats=(enc list, res list)).  Returns dict with pred and every intermediate.
     """
     tgt = torch.as_tensor(tgt_smpl, dtype=torch.float32).view(1, -1)
-    cam = cam_swap(src_info["cam"][0:1], tgt[:, 0:3], first_cam, "smooth")
+    cam = cam_swap(src_info["cam"][0:1], tgt[:, 0:3], first_cam, cam_strategy)
     ref_smpl = torch.cat([cam, tgt[:, 3:-10], src_info["shape"][0:1]], dim=1)
     ref = smplh_get_details(model, ref_smpl, src_info.get("offsets", 0), src_info.get("links_ids"))
     f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
@@ -384,3 +384,54 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size):
     pred = compose(img, mask, src_info["bg"])
     return {"pred": pred, "mask": mask, "img": img, "tsf_inputs": tsf_inputs, "Tst": Tst, "fim": fim, "wim": wim,
             "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t}
+
+
+# --------------------------------------------------------------------------------------------------
+# sequence-global pre-pass of Imitator.inference: WeakPerspectiveCamera.stabilize
+# --------------------------------------------------------------------------------------------------
+def _turning_points(y):
+    """cam_pose_utils.py:130-153."""
+    idx = [0] + [i for i in range(1, len(y) - 1) if (y[i] - y[i - 1]) * (y[i + 1] - y[i]) < 0]
+    return idx + [len(y) - 1]
+
+
+def jump_intervals(final_foot_y, up_thr=0.2, down_thr=0.1):
+    """cam_pose_utils.py:155-208 -> [(start, end), ...]."""
+    y = final_foot_y
+    ground = y[0]
+    pts = _turning_points(y)
+    out, start, in_jump = [], None, False
+    for a, b in zip(pts[:-1], pts[1:]):
+        rise = y[b] - y[a]
+        if rise < 0 and abs(rise) > up_thr:
+            in_jump = True
+            below = [f for f in range(a, b) if y[f] < ground]
+            start = below[0] if below else a
+        elif in_jump:
+            if y[b] < y[start] and abs(y[b] - y[start]) > down_thr:
+                continue
+            in_jump = False
+            out.append((start, b))
+            start = None
+    if in_jump:
+        out.append((start, len(y) - 1))
+    return out
+
+
+def stabilize(model, smpls):
+    """cam_pose_utils.py:52-99 (foot height via cam_pose_utils.py:101-128 = SMPLH.forward without offsets)."""
+    smpls = torch.as_tensor(smpls, dtype=torch.float32)
+    cam, pose, shape = smpls[:, 0:3], smpls[:, 3:-10], smpls[:, -10:]
+    shape = shape[0:1].repeat(pose.shape[0], 1)
+    full = pose if pose.shape[1] != 72 else torch.cat([pose[:, 0:66], model.hands_mean.repeat(pose.shape[0], 1)], dim=1)
+    verts, _ = lbs(shape, full, model.v_template, model.shapedirs, model.posedirs, model.J_regressor, model.parents,
+                   model.lbs_weights)
+    foot_y = verts[:, :, 1].max(dim=1)[0]
+    cam_y = cam[:, 2]
+    new_y = cam_y[0] + (-foot_y + foot_y[0])
+    for s, e in jump_intervals((foot_y + cam_y).numpy()):
+        new_y[s:e + 1] = torch.min(cam_y[s:e + 1], new_y[s:e + 1])
+    new_cam = torch.zeros_like(cam)
+    new_cam[:, 0] = 1
+    new_cam[:, 2] = new_y
+    return torch.cat([new_cam, pose, shape], dim=1)

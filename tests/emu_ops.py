@@ -1,0 +1,183 @@
+"""CPU emulation of the C-ABI ops' *contracts* (include/lwg_hip.h) - TEST INFRASTRUCTURE ONLY.
+
+Lets the `-m "not gpu"` suite exercise the host logic (weight packing, launch orchestration, layouts, the
+generator/renderer/runner classes) without a GPU by monkeypatching ``ipercore_amd.ops``.  It follows the
+kernels' documented semantics (packed panels, tap tables, epilogues), NOT the oracle, so a packing or
+orchestration bug shows up as a mismatch against the oracle.  Never imported by the product.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ipercore_amd import ops as real_ops
+
+ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
+
+
+def _unpanel(w):
+    K4, N, _ = w.shape
+    return w.permute(0, 2, 1).reshape(K4 * 4, N)
+
+
+def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0):
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    B, H, W, Cin = x.shape
+    assert Cin == spec.Cin
+    YB, YH, YW, YC = y.shape
+    if out_hw is None:
+        OH, OW = (YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul)
+    else:
+        OH, OW = out_hw
+    Wk = _unpanel(spec.w)
+    assert Wk.shape[0] >= spec.ntaps * Cin and Wk.shape[1] == spec.N
+    oy = torch.arange(OH) * spec.stride
+    ox = torch.arange(OW) * spec.stride
+    acc = torch.zeros(B, OH, OW, spec.N)
+    for t in range(spec.ntaps):
+        iy, ix = oy + spec.dy[t], ox + spec.dx[t]
+        vy, vx = (iy >= 0) & (iy < H), (ix >= 0) & (ix < W)
+        g = x[:, iy.clamp(0, H - 1)][:, :, ix.clamp(0, W - 1)]
+        g = g * (vy[:, None] & vx[None, :]).float()[None, :, :, None]
+        acc += g.reshape(-1, Cin) .matmul(Wk[t * Cin:(t + 1) * Cin]).view(B, OH, OW, spec.N)
+    ys = slice(spec.ooy, None, spec.omul) if spec.omul > 1 else slice(None)
+    xs = slice(spec.oox, None, spec.omul) if spec.omul > 1 else slice(None)
+    if epi == real_ops.EPI_SPADE:
+        C = spec.N // 2
+        assert YC == C and spec.omul == 1
+        v = (acc + spec.bias).view(B, OH, OW, C // 32, 2, 32)
+        gamma, beta = v[..., 0, :].reshape(B, OH, OW, C), v[..., 1, :].reshape(B, OH, OW, C)
+        out = (xn - mean[:, None, None, :]) * rstd[:, None, None, :] * (1 + gamma) + beta
+        y.copy_(ACT[act](out))
+        return y
+    if spec.bias is not None:
+        acc = acc + spec.bias
+    if epi == real_ops.EPI_RESIDUAL:
+        acc = acc + res[:, ys, xs, ycoff:ycoff + spec.N]
+    y[:, ys, xs, ycoff:ycoff + spec.N] = ACT[act](acc)
+    return y
+
+
+def instnorm_stats(x, mean, rstd, ws, eps=1e-5, nsplit=None):
+    B, H, W, C = x.shape
+    v = x.reshape(B, H * W, C)
+    mean.copy_(v.mean(dim=1))
+    rstd.copy_(1.0 / torch.sqrt(v.var(dim=1, unbiased=False) + eps))
+
+
+def instnorm_apply(x, mean, rstd, y, act=0, res=None):
+    out = ACT[act]((x - mean[:, None, None, :]) * rstd[:, None, None, :])
+    if res is not None:
+        out = out + res
+    y.copy_(out)
+    return y
+
+
+def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
+    B, h, w, C = q.shape
+    ns, S = T.shape[1], T.shape[2]
+    Tf = T.reshape(B * ns, S, S, 2)
+    if S != h:
+        Tf = F.interpolate(Tf.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    if src_batched:
+        Kn, Vn = Ks, Vs
+    else:
+        Kn, Vn = Ks.repeat(B, 1, 1, 1), Vs.repeat(B, 1, 1, 1)
+    Kw = F.grid_sample(Kn.permute(0, 3, 1, 2), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    Vw = F.grid_sample(Vn.permute(0, 3, 1, 2), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    Kw = Kw.view(B, ns, C, h, w) + bk.view(1, 1, C, 1, 1)
+    Vw = Vw.view(B, ns, C, h, w) + bv.view(1, 1, C, 1, 1)
+    logits = (Kw * q.permute(0, 3, 1, 2).unsqueeze(1)).sum(dim=2, keepdim=True) / math.sqrt(C)
+    a = torch.softmax(logits, dim=1)
+    out.copy_((a * Vw).sum(dim=1).permute(0, 2, 3, 1))
+    return out
+
+
+def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
+    B, S, _, C = x.shape
+    w = wpk.view(5, 5, C, 4).permute(3, 2, 0, 1)
+    o = F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=2)
+    img, mask = torch.tanh(o[:, 0:3]), torch.sigmoid(o[:, 3:4])
+    pred = mask * bg + (1 - mask) * img if (want_pred and bg is not None) else None
+    return pred, (mask if want_mask else None), (img if want_img else None)
+
+
+def nchw_to_nhwc(x, c_pad=None):
+    B, C, H, W = x.shape
+    Cp = C if c_pad is None else c_pad
+    y = torch.zeros(B, H, W, Cp)
+    y[..., :C] = x.permute(0, 2, 3, 1)
+    return y
+
+
+def nhwc_to_nchw(x, channels=None):
+    C = x.shape[3] if channels is None else channels
+    return x[..., :C].permute(0, 3, 1, 2).contiguous()
+
+
+# ---- renderer / flow / body ops follow the ABI text, implemented with the same formulas as the kernels ----
+def project_faces(verts, cam, faces, want_faces_v=True, want_f2pts=True):
+    s, t = cam[:, 0].view(-1, 1, 1), cam[:, 1:3].view(-1, 1, 2)
+    xy = s * (verts[:, :, :2] + t)
+    v = verts[:, faces.long()]
+    pxy = xy[:, faces.long()]
+    fv = torch.stack([pxy[..., 0], -pxy[..., 1], v[..., 2] + np.float32(real_ops.EYE_DIST)], dim=-1) if want_faces_v else None
+    return fv, (pxy.clone() if want_f2pts else None)
+
+
+def rasterize_fim_wim(faces_v, image_size, near=0.1, far=100.0):
+    from oracle import lwg_oracle as orc          # the emulator borrows the C rasterizer: same spec by construction
+    return orc.rasterize_fim_wim(faces_v.numpy(), image_size, near, far)
+
+
+def bc_transform(f2pts, fim, wim):
+    B, S, _ = fim.shape
+    T = torch.full((B, S, S, 2), -2.0)
+    for b in range(B):
+        on = fim[b] >= 0
+        idx = fim[b][on].long()
+        T[b][on] = (f2pts[b][idx] * wim[b][on][:, :, None]).sum(dim=1)
+    return T
+
+
+def encode_fim(fim, map_fn):
+    return map_fn[fim.long()].permute(0, 3, 1, 2).contiguous()
+
+
+def flow_compose(fim, wim, map_fn, f_uvs2img, uv_img4, src_f2pts, want_cond=False, want_tuv=False):
+    B, S, _ = fim.shape
+    ns = src_f2pts.shape[0]
+    cond = encode_fim(fim, map_fn)
+    tuv = bc_transform(f_uvs2img.unsqueeze(0).expand(B, -1, -1, -1), fim, wim)
+    uv = uv_img4[..., :3].permute(2, 0, 1).unsqueeze(0).expand(B, -1, -1, -1)
+    syn = F.grid_sample(uv, tuv, mode="bilinear", padding_mode="zeros", align_corners=False)
+    tsf = torch.zeros(B, S, S, 8)
+    tsf[..., 0:3] = syn.permute(0, 2, 3, 1)
+    tsf[..., 3:6] = cond.permute(0, 2, 3, 1)
+    Tst = torch.zeros(B, 0, S, S, 2) if ns == 0 else torch.stack(
+        [bc_transform(src_f2pts[s:s + 1].expand(B, -1, -1, -1), fim, wim) for s in range(ns)], dim=1)
+    return tsf, Tst, (cond if want_cond else None), (tuv if want_tuv else None)
+
+
+def smpl_lbs(model, pose, beta, cam, offsets=None, links=None):
+    from oracle import lwg_oracle as orc
+    vt = model["v_template"] if offsets is None else model["v_template"] + offsets
+    verts, j3d = orc.lbs(beta, pose, vt, model["shapedirs"], model["posedirs"], model["J_regressor"],
+                         model["parents"].long(), model["lbs_weights"])
+    if links is not None:
+        out = verts.clone()
+        out[:, links[:, 0].long()] = verts[:, links[:, 1].long()]
+        verts = out
+    j2d = cam[:, None, 0:1] * (j3d[:, :, :2] + cam[:, None, 1:3]) if cam is not None else None
+    return verts, j3d, j2d
+
+
+def install(monkeypatch):
+    """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
+    for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
+                 "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
+                 "smpl_lbs"):
+        monkeypatch.setattr(real_ops, name, globals()[name])
+    from ipercore_amd.networks import generator
+    monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -120,6 +120,15 @@ def main():
     out["cam_swap/smooth"] = WeakPerspectiveCamera.cam_swap(
         torch.tensor(cams[0]), torch.tensor(cams[1]), torch.tensor(cams[2]), "smooth").numpy()
 
+    # ---------------- 3b. stabilize (sequence-global pre-pass), with an injected jump ----------------
+    seq = synthetic.smpl_sequence(14, seed=13, pose_dim=72)
+    seq[4:9, 2] -= np.array([0.15, 0.45, 0.6, 0.4, 0.1], dtype=np.float32)
+    with torch.no_grad():
+        wcam = WeakPerspectiveCamera(smplh)
+        out["stabilize/out"] = wcam.stabilize(torch.tensor(seq)).numpy()
+        fy = wcam.infer_smpl_foot_y(torch.tensor(seq[:, 3:-10]), torch.tensor(seq[0:1, -10:]).repeat(14, 1))
+        out["stabilize/jumps"] = np.array(wcam.get_jump_mask((fy + torch.tensor(seq[:, 2])).numpy())[0]).reshape(-1, 2)
+
     # ---------------- 4. renderer wrapper + flow functions (S=64) ----------------
     with torch.no_grad():
         cam = d72["cam"][0:1].clone()
@@ -148,7 +157,7 @@ def main():
     out["render/vis_f2pts_sha"] = np.array(sha(vis.numpy()))
 
     # ---------------- 5. generator (tiny config stored fully; full config at S=64) ----------------
-    for tag, nf, nres, bgf in (("tiny", [32, 64, 64], 2, [32, 64, 64]), ("full", [64, 128, 256], 6, [64, 128, 128, 256])):
+    for tag, nf, nres, bgf in (("tiny", [64, 64, 128], 2, [64, 64, 128]), ("full", [64, 128, 256], 6, [64, 128, 128, 256])):
         cfg = gen_cfg(nf, nres, bgf)
         G = AttentionLWBGenerator(cfg, temporal=False).eval()
         shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}

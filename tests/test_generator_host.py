@@ -1,0 +1,85 @@
+"""Host logic of the generator (weight packing, launch orchestration, layouts, API) on CPU: the C-ABI ops are
+replaced by tests/emu_ops.py, the result is checked against the oracle and the reference-generated goldens."""
+import numpy as np
+import pytest
+import torch
+
+from ipercore_amd import synthetic
+from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+from oracle import lwg_oracle as orc
+from tests import emu_ops
+
+S = 64
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_cfg(nf, nres, bgf):
+    return AttrDict(name="AttLWB-SPADE",
+                    BGNet=AttrDict(norm_type="instance", cond_nc=4, n_res_block=nres, num_filters=bgf),
+                    SIDNet=AttrDict(norm_type="None", cond_nc=6, n_res_block=nres, num_filters=nf),
+                    TSFNet=AttrDict(norm_type="instance", cond_nc=6, n_res_block=nres, num_filters=nf))
+
+
+def build(nf, nres, bgf, seed=7):
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=make_cfg(nf, nres, bgf), temporal=False).eval()
+    shapes = generator_param_shapes(nf, nres, bgf)
+    sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=seed).items()}
+    missing = G.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return G, sd
+
+
+def test_state_dict_keys_match_reference(golden):
+    G, _ = build([64, 128, 256], 6, [64, 128, 128, 256])
+    keys = [ln.split(" ")[0] for ln in open("tests/golden/attlwb_spade_state_dict_keys.txt")]
+    assert sorted(G.state_dict().keys()) == sorted(keys)
+    assert sum(p.numel() for p in G.parameters()) == 36276992 == int(golden["gen_full/nparams"])
+
+
+@pytest.mark.parametrize("tag,nf,nres,bgf", [("tiny", [64, 64, 128], 2, [64, 64, 128]),
+                                              ("full", [64, 128, 256], 6, [64, 128, 128, 256])])
+def test_generator_api_through_emulated_abi(monkeypatch, golden, tag, nf, nres, bgf):
+    emu_ops.install(monkeypatch)
+    G, sd = build(nf, nres, bgf)
+    ns = 2
+    src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    bg_inputs = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"))
+    Tst = torch.tensor(golden["render/Tst"]).view(1, ns, S, S, 2)
+    enc, res = G.forward_src(src_inputs, only_enc=True)
+    img, mask = G.forward_tsf(tsf_inputs, enc, res, Tst)
+    bg = G.forward_bg(bg_inputs)
+    # vs the reference's own outputs
+    assert np.abs(enc[-1].numpy()[:, ::8] - golden[f"gen_{tag}/enc2_sub"]).max() <= 1e-4
+    assert np.abs(res[-1].numpy()[:, ::8] - golden[f"gen_{tag}/res_last_sub"]).max() <= 1e-4
+    assert np.abs(img.numpy() - golden[f"gen_{tag}/img"]).max() <= 2e-4
+    assert np.abs(mask.numpy() - golden[f"gen_{tag}/mask"]).max() <= 2e-4
+    assert np.abs(bg.numpy() - golden[f"gen_{tag}/bg"]).max() <= 2e-4
+    # plain-list API (no engine cache attached) must give the same answer
+    img2, mask2 = G.forward_tsf(tsf_inputs, list(enc), list(res), Tst)
+    assert torch.allclose(img, img2, atol=1e-6) and torch.allclose(mask, mask2, atol=1e-6)
+    # src decode branch + full forward
+    enc_o, res_o = orc.gen_forward_src(sd, src_inputs, n_down=len(nf), n_res=nres)
+    _, _, simg, smask = G.forward_src(src_inputs, only_enc=False)
+    x = res_o[-1]
+    for i in range(len(nf)):
+        x = torch.relu(orc._convT(sd, f"src_net.decoders.layers.{i}.0", x))
+    assert torch.allclose(simg[0], torch.tanh(orc._conv(sd, "src_net.img_reg.0", x, pad=2)), atol=2e-4)
+    assert torch.allclose(smask[0], torch.sigmoid(orc._conv(sd, "src_net.att_reg.0", x, pad=2)), atol=2e-4)
+    outs = G(bg_inputs, src_inputs, tsf_inputs.unsqueeze(1), Tst.unsqueeze(1), only_tsf=True)
+    assert outs[0].shape == (1, 1, 3, S, S) and outs[1].shape == (1, 1, 3, S, S) and outs[2].shape == (1, 1, 1, S, S)
+    assert torch.allclose(outs[1][:, 0], img, atol=1e-6)
+
+
+def test_cpu_tensors_fail_loudly():
+    G, _ = build([64, 64, 128], 2, [64, 64, 128])
+    with pytest.raises(RuntimeError):
+        G.forward_bg(torch.zeros(1, 1, 4, S, S))
+
+
+def test_unknown_network_name():
+    with pytest.raises(ValueError):
+        NetworksFactory.get_by_name("InputConcat", cfg=None)

@@ -1,0 +1,53 @@
+"""Host logic of the runner (Imitator / FlowComposition / SMPLRenderer / SMPLH wrappers, frame batching, camera
+pre-pass) on CPU with the C-ABI ops emulated (tests/emu_ops.py), against the oracle's frame-by-frame result."""
+import numpy as np
+import torch
+
+from tests import emu_ops
+from tests import parity_utils as pu
+
+
+def test_imitator_batched_equals_oracle_per_frame(monkeypatch):
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=5, ns=2)
+    im = pu.make_imitator(case, frame_batch=2, device="cpu")        # 5 frames in batches of 2,2,1
+    got = pu.run_hip(case, imitator=im)
+    want = pu.run_oracle(case)
+    assert got.shape == (5, 3, 64, 64)
+    assert (got - want).abs().max().item() <= 2e-4
+    # reference-shaped API: inference() returns a list of (3,S,S) arrays in [-1,1]
+    outs = im.inference(case.tgt_smpls, cam_strategy="smooth", output_dir="", verbose=False)
+    assert len(outs) == 5 and outs[0].shape == (3, 64, 64)
+    assert np.abs(np.stack(outs) - want.numpy()).max() <= 2e-4
+
+
+def test_inference_writes_reference_file_names(monkeypatch, tmp_path):
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=2, ns=1)
+    im = pu.make_imitator(case, frame_batch=8, device="cpu")
+    paths = im.inference(case.tgt_smpls, cam_strategy="copy", output_dir=str(tmp_path), prefix="pred_", verbose=False)
+    assert [p.split("/")[-1] for p in paths] == ["pred_00000000.png", "pred_00000001.png"]
+    from PIL import Image
+    from oracle import lwg_oracle as orc
+    want = pu.run_oracle(case, cam_strategy="copy")
+    img = np.asarray(Image.open(paths[1]))
+    assert np.array_equal(img[:, :, ::-1], orc.to_uint8_bgr(want[1].numpy())) or \
+        np.abs(img[:, :, ::-1].astype(int) - orc.to_uint8_bgr(want[1].numpy()).astype(int)).max() <= 1
+
+
+def test_reference_shaped_flow_methods(monkeypatch):
+    emu_ops.install(monkeypatch)
+    from oracle import lwg_oracle as orc
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=2, ns=2)
+    im = pu.make_imitator(case, frame_batch=2, device="cpu")
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    model, tables, sd, info = pu.oracle_source(case)
+    ref = im.body_rec.get_details(im.swap_params(im.src_info["cam"][0:1], im.src_info["shape"][0:1], tgt[0:1]), 0, None)
+    im.flow_comp.add_rendered_f2verts_fim_wim(ref, use_morph=False, get_uv_info=False)
+    im.flow_comp.make_uv_setup(1, 2, 1, "cpu")
+    tsf = im.flow_comp.make_tsf_inputs(im.src_info["uv_img"], ref)
+    Tst, Ttt = im.flow_comp.make_trans_flow(1, 2, 1, im.src_info, None, ref, temporal=False)
+    want, allr = pu.run_oracle(case, frames=[0], return_all=True)
+    assert Ttt is None and Tst.shape == (1, 2, 64, 64, 2)
+    assert (tsf[:, 0] - allr[0]["tsf_inputs"]).abs().max() <= 2e-4   # random-texture sampling amplifies 1e-7 flow rounding
+    assert (Tst - allr[0]["Tst"]).abs().max() <= 1e-6
