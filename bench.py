@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py - synthesized frames/s of the per-frame path (run_imitator, 512x512, AttLWB-SPADE fp32) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (camera swap, SMPL-H skinning, projection +
+rasterization, fused flows, AttLWB-SPADE forward_tsf, head + compositing) over one batch of ``--frame-batch``
+synthetic target frames of BASELINE.json configs[1] (512x512, one source/reference pair, ns = 2, random-init
+weights of the real architecture, synthetic SMPL-H + T-pose template geometry).  Inputs (SMPL parameters, cached
+source state) are resident in HBM before the timed region; source_setup and PNG writing are outside it.  With
+N > 1 the clip is frame-sharded (weak scaling: every rank renders K batches) and the timed region ends with the
+single RCCL all-gather of the output video tensor.
+
+Prints ONE JSON line on rank 0.  ``roofline`` is for the dominant kernel (the fp32 MFMA implicit-GEMM conv):
+algorithmic conv flops of all its launches in the timed region / their HIP-event time, against the 157.3
+TFLOP/s fp32 matrix peak of gfx950.  ``cpu_baseline`` times the CPU oracle ("port") on this host for a few
+frames of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+class ConvTimer:
+    """Brackets every conv launch with events on torch's current stream (the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.pairs, self.flops, self.enabled = [], 0.0, False
+        self._start = None
+
+    def __call__(self, begin, M, spec):
+        if not self.enabled:
+            return
+        if begin:
+            self._start = torch.cuda.Event(enable_timing=True)
+            self._start.record()
+        else:
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record()
+            self.pairs.append((self._start, stop))
+            self.flops += 2.0 * M * spec.algo_kn
+
+    def result(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return ms, self.flops, len(self.pairs)
+
+
+def cpu_baseline(case, n_frames):
+    """The oracle (CPU restatement of the reference algorithm) on the host cores, a bounded sample."""
+    from tests import parity_utils as pu
+    t0 = time.time()
+    pu.oracle_source(case)                       # source-side work is not part of the per-frame metric
+    t_src = time.time() - t0
+    t0 = time.time()
+    pu.run_oracle(case, frames=list(range(n_frames)))
+    dt = time.time() - t0 - t_src                # run_oracle rebuilds the source state once
+    return {"value": round(n_frames / max(dt, 1e-9), 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_frames} frames @{case.S}x{case.S} ns={case.ns} through oracle/lwg_oracle.py (torch-CPU fp32 + "
+                      f"OpenMP C rasterizer), {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--frame-batch", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-conv-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from ipercore_amd import ops, sharding
+    from tests import parity_utils as pu
+
+    FB, K, W, S = args.frame_batch, args.steps, args.warmup, args.size
+    per_rank = (K + W) * FB
+    case = pu.build_case(image_size=S, n_frames=per_rank * world, ns=2)
+    im = pu.make_imitator(case, frame_batch=FB, device=dev)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")          # sequence-global pre-pass, every rank identically
+    lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
+    mine = tgt[lo:hi].contiguous()
+
+    timer = ConvTimer()
+    ops.CONV_HOOK = None if args.no_conv_events else timer
+
+    def step(i):
+        chunk = mine[i * FB:(i + 1) * FB]
+        tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, chunk, "smooth", t=lo + i * FB)
+        return im.forward(tsf8, Tst)[0]
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    outs = []
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        outs.append(step(i))
+    local = torch.cat(outs, dim=0)
+    video = sharding.all_gather_frames(local, K * FB * world) if world > 1 else local
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    assert video.shape[0] == K * FB * world and torch.isfinite(local).all()
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        conv_ms, conv_flops, n_launch = timer.result()
+        frames = K * FB * world
+        line = {
+            "metric": "synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}",
+            "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])",
+                       "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
+                       "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
+                       "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},
+        }
+        if n_launch:
+            achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
+                                "launches": n_launch, "avg_launch_us": round(conv_ms * 1e3 / n_launch, 2),
+                                "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
+                                "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
+        if args.cpu_frames > 0:
+            small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
+            line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

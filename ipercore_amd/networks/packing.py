@@ -39,7 +39,8 @@ def pack_conv(weight, bias=None, stride=1, pad=None, cin_pad=None, n_pad=None):
     w = weight.new_zeros(kh * kw, Cp, Np)
     w[:, :Cin, :N] = weight.permute(2, 3, 1, 0).reshape(kh * kw, Cin, N)
     taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
-    return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np)), _pad_vec(bias, Np), Np, Cp, taps, stride=stride)
+    return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np)), _pad_vec(bias, Np), Np, Cp, taps, stride=stride,
+                    algo_kn=kh * kw * Cin * N)
 
 
 # output parity -> [(kernel index, input offset)] for ConvTranspose2d(kernel 4, stride 2, padding 1):
@@ -64,7 +65,8 @@ def pack_conv_transpose(weight, bias=None, n_pad=None):
                     m[:, :N] = weight[:, :, ky, kx]
                     mats.append(m)
             wk = torch.stack(mats, dim=0).reshape(len(taps) * Cin, Np)
-            specs.append(ConvSpec(_panel(wk), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px))
+            specs.append(ConvSpec(_panel(wk), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px,
+                                  algo_kn=len(taps) * Cin * N))
     return specs
 
 

@@ -24,16 +24,21 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
+CONV_HOOK = None     # bench.py installs a callable(begin, M, spec) to bracket conv launches with HIP events
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn")
 
-    def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0):
+    def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
+        # un-padded K*N of the convolution this panel implements: 2*M*algo_kn = its algorithmic flops
+        self.algo_kn = int(algo_kn) if algo_kn is not None else len(taps) * int(Cin) * int(N)
         self.ntaps = len(taps)
         self.dy = [int(t[0]) for t in taps]
         self.dx = [int(t[1]) for t in taps]
@@ -70,7 +75,11 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     for i in range(spec.ntaps):
         a.dy[i] = spec.dy[i]
         a.dx[i] = spec.dx[i]
+    if CONV_HOOK is not None:
+        CONV_HOOK(True, a.M, spec)
     _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+    if CONV_HOOK is not None:
+        CONV_HOOK(False, a.M, spec)
     return y
 
 

@@ -365,7 +365,7 @@ def to_uint8_bgr(pred_chw):
 # --------------------------------------------------------------------------------------------------
 # whole frame (a1..a13), used by parity tests and bench.py's cpu_baseline
 # --------------------------------------------------------------------------------------------------
-def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, cam_strategy="smooth"):
+def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, cam_strategy="smooth", ref_override=None):
     """One iteration of Imitator.inference (models/imitator.py:341-395, temporal=False, cam "smooth").
 
     tables: dict(smpl_faces, map_fn, f_uvs2img).  src_info: dict(cam, shape, offsets, links_ids, uv_img, bg,
@@ -375,6 +375,9 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     cam = cam_swap(src_info["cam"][0:1], tgt[:, 0:3], first_cam, cam_strategy)
     ref_smpl = torch.cat([cam, tgt[:, 3:-10], src_info["shape"][0:1]], dim=1)
     ref = smplh_get_details(model, ref_smpl, src_info.get("offsets", 0), src_info.get("links_ids"))
+    own_verts = ref["verts"]
+    if ref_override is not None:          # tests: rasterize the caller's (bit-identical) vertices, see parity_utils
+        ref["cam"], ref["verts"] = ref_override
     f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
     cond = encode_fim(tables["map_fn"], fim)
     tsf_inputs, Tuv2t = make_tsf_inputs(src_info["uv_img"], tables["f_uvs2img"], cond, fim, wim)
@@ -383,7 +386,8 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(enc), n_res=len(res))
     pred = compose(img, mask, src_info["bg"])
     return {"pred": pred, "mask": mask, "img": img, "tsf_inputs": tsf_inputs, "Tst": Tst, "fim": fim, "wim": wim,
-            "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t}
+            "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t, "own_verts": own_verts,
+            "src_own_verts": src_info.get("own_verts"), "src_fim": src_info.get("fim")}
 
 
 # --------------------------------------------------------------------------------------------------

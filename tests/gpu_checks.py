@@ -1,0 +1,347 @@
+"""GPU parity checks: every C-ABI entry point against the CPU emulation of its contract / the oracle, then the
+whole per-frame path against the oracle and the reference-generated golden fixtures.  Each check returns a
+dict of metrics and raises AssertionError on failure; ``tests/test_gpu_parity.py`` runs them under pytest
+(-m gpu) and ``tools/gpu_diag.py`` runs them all and dumps a JSON report (nothing here reads /root/reference).
+"""
+import hashlib
+import os
+import time
+
+import numpy as np
+import torch
+
+from ipercore_amd import ops, synthetic
+from ipercore_amd.geometry import mesh
+from ipercore_amd.networks import packing
+from tests import emu_ops
+from tests import parity_utils as pu
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.tensor(synthetic._rs(seed, "chk").standard_normal(shape).astype(np.float32) * scale)
+
+
+def _cmp(got, want, tol, name):
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs()
+    ref = max(want.abs().max().item(), 1e-6)
+    m = {"max_abs": err.max().item(), "mean_abs": err.mean().item(), "ref_max": ref}
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    assert m["max_abs"] <= tol * max(1.0, ref), f"{name}: max|d|={m['max_abs']:.3e} (ref max {ref:.3e}, tol {tol})"
+    return m
+
+
+def _spec_dev(spec):
+    return packing.spec_to(spec, DEV)
+
+
+def _conv_case(name, B, H, W, Cin, N, k, stride, pad, seed, cin_pad=None, C1=0, epi=0, act=0, bias=True):
+    w = _rand((N, Cin, k, k), seed, 1.0 / np.sqrt(Cin * k * k))
+    b = _rand((N,), seed + 1, 0.1) if bias else None
+    spec = packing.pack_conv(w, b, stride=stride, pad=pad, cin_pad=cin_pad)
+    Cp = spec.Cin
+    x = _rand((B, H, W, Cp), seed + 2)
+    if cin_pad:
+        x[..., Cin:] = 0
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _rand((B, OH, OW, N), seed + 3) if epi == ops.EPI_RESIDUAL else None
+    x0, x1 = (x, None) if C1 == 0 else (x[..., :Cp - C1].contiguous(), x[..., Cp - C1:].contiguous())
+    want = emu_ops.conv2d(x0, spec, torch.zeros(B, OH, OW, N), x1=x1, epi=epi, act=act, res=res)
+    sd = _spec_dev(packing.pack_conv(w, b, stride=stride, pad=pad, cin_pad=cin_pad))
+    got = ops.conv2d(x0.to(DEV), sd, torch.full((B, OH, OW, N), float("nan"), device=DEV), x1=None if x1 is None else x1.to(DEV),
+                     epi=epi, act=act, res=None if res is None else res.to(DEV))
+    torch.cuda.synchronize()
+    return _cmp(got, want, 2e-5, name)
+
+
+def check_conv_variants():
+    out = {}
+    out["3x3_s1_64_128"] = _conv_case("3x3 s1", 2, 16, 16, 64, 128, 3, 1, 1, 10, act=ops.ACT_RELU)
+    out["3x3_s2_64_128"] = _conv_case("3x3 s2", 2, 16, 16, 64, 128, 3, 2, 1, 20, act=ops.ACT_RELU)
+    out["3x3_s1_128_64_n64"] = _conv_case("3x3 N=64", 1, 12, 20, 128, 64, 3, 1, 1, 30)          # BN=64 config, M tail
+    out["1x1_256_256"] = _conv_case("1x1", 1, 8, 8, 256, 256, 1, 1, 0, 40)
+    out["3x3_s2_cin8"] = _conv_case("smallC 6->64", 2, 32, 32, 6, 64, 3, 2, 1, 50, cin_pad=8, bias=False, act=ops.ACT_RELU)
+    out["7x7_cin4"] = _conv_case("smallC 7x7 4->64", 1, 16, 16, 4, 64, 7, 1, 3, 60, cin_pad=4)
+    out["3x3_concat"] = _conv_case("concat 128+256", 1, 16, 16, 384, 256, 3, 1, 1, 70, C1=256, act=ops.ACT_RELU)
+    out["3x3_residual"] = _conv_case("residual", 2, 8, 8, 256, 256, 3, 1, 1, 80, epi=ops.EPI_RESIDUAL)
+    out["3x3_tail_m"] = _conv_case("M tail", 3, 9, 7, 64, 128, 3, 1, 1, 90)
+    out["3x3_tanh_sigmoid"] = _conv_case("tanh", 1, 8, 8, 64, 64, 3, 1, 1, 95, act=ops.ACT_TANH)
+    return out
+
+
+def check_conv_transpose():
+    B, H, W, Cin, N = 2, 8, 8, 128, 64
+    w = _rand((Cin, N, 4, 4), 100, 1.0 / np.sqrt(Cin * 4))
+    b = _rand((N,), 101, 0.1)
+    x = _rand((B, H, W, Cin), 102)
+    want = torch.nn.functional.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1).relu().permute(0, 2, 3, 1)
+    y = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+    for s in packing.pack_conv_transpose(w, b):
+        ops.conv2d(x.to(DEV), _spec_dev(s), y, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    return _cmp(y, want, 2e-5, "convT 4x4 s2")
+
+
+def check_spade_epilogue():
+    B, H, W, C = 2, 8, 8, 128
+    wg, bg = _rand((C, 128, 3, 3), 110, 0.03), _rand((C,), 111, 0.1)
+    wb, bb = _rand((C, 128, 3, 3), 112, 0.03), _rand((C,), 113, 0.1)
+    actv, xn = _rand((B, H, W, 128), 114), _rand((B, H, W, C), 115, 2.0) + 0.5
+    mean, rstd = xn.reshape(B, -1, C).mean(1), 1 / torch.sqrt(xn.reshape(B, -1, C).var(1, unbiased=False) + 1e-5)
+    g = torch.nn.functional.conv2d(actv.permute(0, 3, 1, 2), wg, bg, padding=1)
+    bt = torch.nn.functional.conv2d(actv.permute(0, 3, 1, 2), wb, bb, padding=1)
+    want = (torch.nn.functional.instance_norm(xn.permute(0, 3, 1, 2), eps=1e-5) * (1 + g) + bt).permute(0, 2, 3, 1)
+    spec = _spec_dev(packing.pack_spade_gamma_beta(wg, bg, wb, bb))
+    got = ops.conv2d(actv.to(DEV), spec, torch.full((B, H, W, C), float("nan"), device=DEV), epi=ops.EPI_SPADE,
+                     xn=xn.to(DEV), mean=mean.to(DEV), rstd=rstd.to(DEV))
+    torch.cuda.synchronize()
+    return _cmp(got, want, 5e-5, "SPADE epilogue")
+
+
+def check_instnorm():
+    out = {}
+    for (B, H, W, C) in ((2, 16, 16, 64), (1, 64, 64, 256), (3, 8, 8, 128)):
+        x = _rand((B, H, W, C), 120 + C, 1.5) + 3.0          # large mean: exercises the shifted sums
+        mean, rstd = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+        nsplit = max(1, min(64, H * W // 256))
+        ws = torch.empty(B * C * nsplit * 3 + 16, device=DEV)
+        ops.instnorm_stats(x.to(DEV), mean, rstd, ws, eps=1e-5, nsplit=nsplit)
+        v = x.reshape(B, -1, C).double()
+        out[f"mean_{C}"] = _cmp(mean, v.mean(1).float(), 1e-6, "IN mean")
+        out[f"rstd_{C}"] = _cmp(rstd, (1 / torch.sqrt(v.var(1, unbiased=False) + 1e-5)).float(), 1e-5, "IN rstd")
+        res = _rand((B, H, W, C), 130)
+        y = ops.instnorm_apply(x.to(DEV), mean, rstd, torch.empty(B, H, W, C, device=DEV), act=ops.ACT_RELU, res=res.to(DEV))
+        want = torch.relu(torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2), eps=1e-5)).permute(0, 2, 3, 1) + res
+        out[f"apply_{C}"] = _cmp(y, want, 2e-5, "IN apply")
+    return out
+
+
+def _flows(B, ns, S, seed):
+    r = synthetic._rs(seed, "flows")
+    T = torch.tensor(r.uniform(-1.1, 1.1, size=(B, ns, S, S, 2)).astype(np.float32))
+    bgm = torch.tensor(r.uniform(size=(B, ns, S, S)) < 0.3)
+    T[bgm] = -2.0
+    return T
+
+
+def check_lwb_attention():
+    out = {}
+    for (B, ns, h, C, S, batched) in ((2, 2, 16, 64, 64, False), (1, 3, 8, 256, 64, False), (2, 2, 16, 128, 16, False),
+                                       (2, 2, 8, 64, 32, True)):
+        q, bk, bv = _rand((B, h, h, C), 140), _rand((C,), 141, 0.1), _rand((C,), 142, 0.1)
+        n_src = B * ns if batched else ns
+        Ks, Vs = _rand((n_src, h, h, C), 143), _rand((n_src, h, h, C), 144)
+        T = _flows(B, ns, S, 145 + C)
+        want = emu_ops.lwb_attention(q, Ks, Vs, bk, bv, T, torch.zeros(B, h, h, C), src_batched=batched)
+        got = ops.lwb_attention(q.to(DEV), Ks.to(DEV), Vs.to(DEV), bk.to(DEV), bv.to(DEV), T.to(DEV),
+                                torch.full((B, h, h, C), float("nan"), device=DEV), src_batched=batched)
+        torch.cuda.synchronize()
+        out[f"C{C}_h{h}_S{S}_b{int(batched)}"] = _cmp(got, want, 5e-5, "lwb attention")
+    return out
+
+
+def check_head_and_layout():
+    out = {}
+    B, S, C = 2, 40, 64                                    # S not a multiple of the 32-pixel tile
+    x = _rand((B, S, S, C), 150)
+    wi, wa = _rand((3, C, 5, 5), 151, 0.03), _rand((1, C, 5, 5), 152, 0.03)
+    bg = _rand((1, 3, S, S), 153)
+    wpk = packing.pack_head(wi, wa)
+    wp, wm, wim_ = emu_ops.head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=True)
+    gp, gm, gi = ops.head_compose(x.to(DEV), wpk.to(DEV), bg.to(DEV), want_pred=True, want_mask=True, want_img=True)
+    torch.cuda.synchronize()
+    out["pred"], out["mask"], out["img"] = _cmp(gp, wp, 2e-5, "head pred"), _cmp(gm, wm, 2e-5, "head mask"), _cmp(gi, wim_, 2e-5, "head img")
+    t = _rand((3, 6, 20, 28), 154)
+    nh = ops.nchw_to_nhwc(t.to(DEV), c_pad=8)
+    assert torch.equal(nh.cpu(), emu_ops.nchw_to_nhwc(t, c_pad=8)), "nchw_to_nhwc"
+    assert torch.equal(ops.nhwc_to_nchw(nh, channels=6).cpu(), t), "nhwc_to_nchw"
+    t2 = _rand((2, 130, 9, 9), 155)
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(t2.to(DEV))).cpu(), t2), "layout round trip"
+    return out
+
+
+def _smplh_dev(model_dict):
+    from ipercore_amd.bodynets import SMPLH
+    return SMPLH(model_dict).to(DEV)
+
+
+def check_lbs():
+    from oracle import lwg_oracle as orc
+    md = synthetic.smplh_model_dict(seed=0)
+    body = _smplh_dev(md)
+    om = orc.SMPLHModel(md)
+    out = {}
+    smpls = synthetic.smpl_sequence(11, seed=1, pose_dim=72)                       # 11 frames: groups of 8 + 3
+    offsets = (0.005 * synthetic._rs(3, "offsets").standard_normal((6890, 3))).astype(np.float32)
+    r = synthetic._rs(4, "links")
+    links = np.stack([r.randint(0, 6890, size=40), r.randint(0, 6890, size=40)], axis=1).astype(np.int64)
+    got = body.get_details(torch.tensor(smpls, device=DEV), torch.tensor(offsets, device=DEV), links_ids=links)
+    want = orc.smplh_get_details(om, smpls, torch.tensor(offsets), links)
+    for k in ("verts", "j3d", "j2d"):
+        out[k] = _cmp(got[k], want[k], 1e-5, "smplh " + k)
+    # link indices must be exact gathers of the un-linked result
+    raw = body.get_details(torch.tensor(smpls, device=DEV), torch.tensor(offsets, device=DEV), links_ids=None)["verts"]
+    assert torch.equal(got["verts"][:, links[:, 0]], raw[:, links[:, 1]]), "link gather not exact"
+    s156 = synthetic.smpl_sequence(2, seed=2, pose_dim=156)
+    out["verts156"] = _cmp(body.get_details(torch.tensor(s156, device=DEV), 0, None)["verts"],
+                           orc.smplh_get_details(om, s156, 0, None)["verts"], 1e-5, "smplh 156")
+    return out
+
+
+def _posed(n_frames=2, seed=1):
+    from oracle import lwg_oracle as orc
+    om = orc.SMPLHModel(synthetic.smplh_model_dict(seed=0))
+    d = orc.smplh_get_details(om, synthetic.smpl_sequence(n_frames, seed=seed, pose_dim=72), 0, None)
+    return d["cam"].contiguous(), d["verts"].contiguous()
+
+
+def check_raster(sizes=(64, 128, 256)):
+    from oracle import lwg_oracle as orc
+    topo = mesh.load_topology()
+    faces = torch.tensor(topo["faces_uv"].astype(np.int32))
+    cam, verts = _posed(2)
+    out = {}
+    fv_want = orc.project_faces(cam, verts, faces.numpy())
+    fv, f2 = ops.project_faces(verts.to(DEV), cam.to(DEV), faces.to(DEV))
+    assert torch.equal(fv.cpu(), fv_want), "project_faces not bit-exact"
+    f2w = fv_want[..., 0:2].clone()
+    f2w[..., 1] *= -1
+    assert torch.equal(f2.cpu(), f2w), "f2pts not bit-exact"
+    for S in sizes:
+        t0 = time.time()
+        fim_w, wim_w = orc.rasterize_fim_wim(fv_want.numpy(), S)
+        t_cpu = time.time() - t0
+        fim, wim = ops.rasterize_fim_wim(fv, S)
+        torch.cuda.synchronize()
+        agree = (fim.cpu() == fim_w).float().mean().item()
+        cover = (fim_w >= 0).float().mean().item()
+        same = fim.cpu() == fim_w
+        werr = (wim.cpu() - wim_w).abs()[same].max().item()
+        out[f"S{S}"] = {"fim_agree": agree, "cover": cover, "wim_max_abs": werr, "oracle_s": t_cpu}
+        assert agree == 1.0, f"fim mismatch at S={S}: agreement {agree}"
+        assert werr == 0.0, f"wim mismatch at S={S}: {werr}"
+        assert 0.03 < cover < 0.7
+    # UV atlas (constant z): every triangle front-facing, renderer call of render_uv_fim_wim
+    f_img2uvs = torch.tensor(mesh.get_f2vts(mesh.obj_from_topology(topo, "fim"), z=1)).float()
+    f = f_img2uvs.clone()
+    f[:, :, 1] *= -1
+    fim_w, wim_w = orc.rasterize_fim_wim(f.unsqueeze(0).numpy(), 128)
+    fim, wim = ops.rasterize_fim_wim(f.unsqueeze(0).contiguous().to(DEV), 128)
+    assert torch.equal(fim.cpu(), fim_w) and torch.equal(wim.cpu(), wim_w), "UV atlas raster mismatch"
+    return out
+
+
+def check_flows():
+    from oracle import lwg_oracle as orc
+    topo = mesh.load_topology()
+    t = pu.oracle_tables(topo)
+    cam, verts = _posed(3)
+    S = 96
+    f2pts, fim, wim = orc.render_fim_wim(cam, verts, t["smpl_faces"], S)
+    uv_img = torch.tensor(synthetic.uniform_image((1, 3, S, S), 6, "uv_img"))
+    uv4 = emu_ops.nchw_to_nhwc(uv_img, c_pad=4)[0].contiguous()
+    map_fn, fu = torch.tensor(t["map_fn"]), torch.tensor(t["f_uvs2img"])
+    src = f2pts[1:3].contiguous()
+    w_tsf, w_T, w_cond, w_tuv = emu_ops.flow_compose(fim[0:2], wim[0:2], map_fn, fu, uv4, src, True, True)
+    g_tsf, g_T, g_cond, g_tuv = ops.flow_compose(fim[0:2].contiguous().to(DEV), wim[0:2].contiguous().to(DEV), map_fn.to(DEV),
+                                                 fu.to(DEV), uv4.to(DEV), src.to(DEV), True, True)
+    torch.cuda.synchronize()
+    out = {"Tst": _cmp(g_T, w_T, 1e-6, "Tst"), "Tuv": _cmp(g_tuv, w_tuv, 1e-6, "Tuv"),
+           "tsf": _cmp(g_tsf, w_tsf, 1e-4, "tsf_inputs")}
+    assert torch.equal(g_cond.cpu(), w_cond), "cond (encode_fim) must be an exact gather"
+    assert torch.equal(g_tsf[..., 3:6].cpu(), w_tsf[..., 3:6]) and (g_tsf[..., 6:] == 0).all()
+    assert torch.equal((g_T.cpu() == -2), (w_T == -2)), "background sentinel positions differ"
+    out["bc"] = _cmp(ops.bc_transform(f2pts.to(DEV), fim.to(DEV), wim.to(DEV)), emu_ops.bc_transform(f2pts, fim, wim), 1e-6, "bc")
+    assert torch.equal(ops.encode_fim(fim.to(DEV), map_fn.to(DEV)).cpu(), emu_ops.encode_fim(fim, map_fn))
+    return out
+
+
+def check_identity_warp_512():
+    """Size-independent property at BASELINE size: T_self reproduces pixel-centre coordinates."""
+    topo = mesh.load_topology()
+    cam, verts = _posed(2)
+    S = 512
+    faces = torch.tensor(topo["faces_uv"].astype(np.int32), device=DEV)
+    fv, f2 = ops.project_faces(verts.to(DEV), cam.to(DEV), faces)
+    fim, wim = ops.rasterize_fim_wim(fv, S)
+    T = ops.bc_transform(f2, fim, wim).cpu().numpy()
+    fimc = fim.cpu().numpy()
+    res = {}
+    for b in range(2):
+        on = fimc[b] >= 0
+        rr, cc = np.nonzero(on)
+        want = np.stack([(2 * cc + 1) / S - 1, (2 * rr + 1) / S - 1], axis=1)
+        err = np.abs(T[b][on] - want)
+        res[f"b{b}"] = {"cover": float(on.mean()), "median": float(np.median(err)), "max": float(err.max())}
+        assert 0.03 < on.mean() < 0.7 and np.median(err) < 1e-5 and err.max() < 2.0 / S
+        wsum = wim[b].cpu().numpy()[on].sum(-1)
+        assert np.abs(wsum - 1).max() < 1e-5
+    assert (fimc.max() < 13776) and (fimc.min() == -1)
+    return res
+
+
+def check_generator_golden():
+    """The generator API on the GPU against outputs of the REFERENCE's own module (tests/golden)."""
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    S, ns, out = 64, 2, {}
+    for tag, nf, nres, bgf in (("tiny", [64, 64, 128], 2, [64, 64, 128]), ("full", [64, 128, 256], 6, [64, 128, 128, 256])):
+        G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).eval()
+        sd = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+        G.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+        G.to(DEV)
+        src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"), device=DEV)
+        tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"), device=DEV)
+        bg_inputs = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"), device=DEV)
+        Tst = torch.tensor(g["render/Tst"], device=DEV).view(1, ns, S, S, 2)
+        enc, res = G.forward_src(src_inputs, only_enc=True)
+        img, mask = G.forward_tsf(tsf_inputs, enc, res, Tst)
+        bg = G.forward_bg(bg_inputs)
+        torch.cuda.synchronize()
+        out[tag] = {
+            "enc": _cmp(enc[-1][:, ::8], torch.tensor(g[f"gen_{tag}/enc2_sub"]), 1e-4, "enc"),
+            "res": _cmp(res[-1][:, ::8], torch.tensor(g[f"gen_{tag}/res_last_sub"]), 2e-4, "res"),
+            "img": _cmp(img, torch.tensor(g[f"gen_{tag}/img"]), 2e-3, "tsf_img"),      # SURVEY 8c tolerance
+            "mask": _cmp(mask, torch.tensor(g[f"gen_{tag}/mask"]), 2e-3, "tsf_mask"),
+            "bg": _cmp(bg, torch.tensor(g[f"gen_{tag}/bg"]), 2e-3, "bg"),
+        }
+        assert out[tag]["img"]["mean_abs"] <= 1e-4 and out[tag]["mask"]["mean_abs"] <= 1e-4
+    return out
+
+
+def _pipeline(S, nf, nres, bgf, n_frames, frame_batch, frames=None):
+    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=n_frames, ns=2)
+    t0 = time.time()
+    m, got, im = pu.staged_parity(case, frame_batch=frame_batch, frames=frames)
+    m["total_s"] = time.time() - t0
+    assert m["pred_finite"], "non-finite frames"
+    assert m["src_verts_max"] <= 1e-5 and m["verts_max"] <= 1e-5, m        # LBS verts |d| <= 1e-5
+    assert m["src_fim_equal"] and m["fim_equal"] and m["wim_max"] == 0.0, m  # index maps bit-exact on identical vertices
+    assert m["Tst_max"] <= 1e-5 and m["tsf_inputs_max"] <= 2e-4, m
+    assert m["pred_max"] <= 2e-3 and m["pred_mean"] <= 1e-4, m               # SURVEY 8c generator tolerance
+    # frames are independent: the batch composition must not change a frame (bitwise)
+    single = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=1)).cpu()
+    m["batch_vs_single_max"] = (single - got).abs().max().item()
+    assert m["batch_vs_single_max"] == 0.0, "batched and per-frame results differ"
+    return m
+
+
+def check_pipeline_tiny_64():
+    return _pipeline(64, [64, 64, 128], 2, [64, 64, 128], n_frames=5, frame_batch=2)
+
+
+def check_pipeline_full_256():
+    return _pipeline(256, [64, 128, 256], 6, [64, 128, 128, 256], n_frames=3, frame_batch=3)
+
+
+def check_pipeline_full_512():
+    return _pipeline(512, [64, 128, 256], 6, [64, 128, 128, 256], n_frames=3, frame_batch=3, frames=[2])
+
+
+ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
+       check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
+       check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512]

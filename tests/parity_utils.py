@@ -62,27 +62,35 @@ def oracle_tables(topo=None):
             "f_uvs2img": mesh.get_f2vts(uv, z=1)[:, :, 0:2].astype(np.float32)}
 
 
-def oracle_source(case, tables=None):
-    """The oracle's version of the cached source state (what source_setup leaves in src_info)."""
+def oracle_source(case, tables=None, src_override=None):
+    """The oracle's version of the cached source state (what source_setup leaves in src_info).
+
+    src_override = (cam, verts): use these posed source vertices instead of the oracle's own skinning, so that
+    the rasterizer sees bit-identical inputs on both sides (a 1e-7 vertex difference flips silhouette pixels,
+    which is a discontinuity of the algorithm, not an error of either implementation)."""
     from oracle import lwg_oracle as orc
     tables = tables or oracle_tables()
     model = orc.SMPLHModel(case.smplh)
     sd = {k: torch.tensor(v) for k, v in case.state.items()}
     src = orc.smplh_get_details(model, case.src_smpl, 0, None)
+    own_verts = src["verts"]
+    if src_override is not None:
+        src["cam"], src["verts"] = src_override
     f2pts, fim, wim = orc.render_fim_wim(src["cam"], src["verts"], tables["smpl_faces"], case.S)
     cond = orc.encode_fim(tables["map_fn"], fim)
     src_inputs = torch.cat([torch.tensor(case.src_img)[0], cond], dim=1).unsqueeze(0)
     with torch.no_grad():
         feats = orc.gen_forward_src(sd, src_inputs, n_down=len(case.num_filters), n_res=case.n_res)
     info = {"cam": src["cam"], "shape": src["shape"], "offsets": 0, "links_ids": None, "uv_img": torch.tensor(case.uv_img),
-            "bg": torch.tensor(case.bg_img), "f2pts": f2pts, "feats": feats}
+            "bg": torch.tensor(case.bg_img), "f2pts": f2pts, "feats": feats, "own_verts": own_verts, "fim": fim}
     return model, tables, sd, info
 
 
-def run_oracle(case, cam_strategy="smooth", frames=None, return_all=False):
-    """(n,3,S,S) CPU tensor: the reference algorithm for every frame (or the listed frame indices)."""
+def run_oracle(case, cam_strategy="smooth", frames=None, return_all=False, src_override=None, ref_override=None):
+    """(n,3,S,S) CPU tensor: the reference algorithm for every frame (or the listed frame indices).
+    ref_override: {t: (cam (1,3), verts (1,nv,3))} posed target vertices to rasterize instead of the oracle's."""
     from oracle import lwg_oracle as orc
-    model, tables, sd, info = oracle_source(case)
+    model, tables, sd, info = oracle_source(case, src_override=src_override)
     tgt = torch.tensor(case.tgt_smpls)
     if cam_strategy == "smooth":
         tgt = orc.stabilize(model, tgt)
@@ -90,8 +98,42 @@ def run_oracle(case, cam_strategy="smooth", frames=None, return_all=False):
     outs, extra = [], []
     for t in (range(tgt.shape[0]) if frames is None else frames):
         with torch.no_grad():
-            r = orc.imitate_frame(model, tables, sd, info, tgt[t], first_cam, case.S, cam_strategy)
+            r = orc.imitate_frame(model, tables, sd, info, tgt[t], first_cam, case.S, cam_strategy,
+                                  ref_override=None if ref_override is None else ref_override[t])
         outs.append(r["pred"])
         extra.append(r)
     pred = torch.cat(outs, dim=0)
     return (pred, extra) if return_all else pred
+
+
+def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, device="cuda:0", imitator=None):
+    """HIP path vs oracle, stage by stage (the end-to-end map is discontinuous at silhouette pixels, so each stage
+    is compared on identical inputs): (1) skinned vertices HIP vs oracle; (2) fim/wim exact given the HIP vertices;
+    (3) generator input / flows; (4) final frames.  Returns a metrics dict; the caller asserts."""
+    im = imitator or make_imitator(case, frame_batch, device=device)
+    tgt = im.prepare_sequence(case.tgt_smpls, cam_strategy)
+    preds, refs = [], {}
+    for s in range(0, tgt.shape[0], im.frame_batch):
+        tsf8, Tst, ref = im.make_inputs_for_tsf(im.src_info, tgt[s:s + im.frame_batch], cam_strategy, t=s, want_aux=True)
+        preds.append(im.forward(tsf8, Tst)[0])
+        for i in range(ref["verts"].shape[0]):
+            refs[s + i] = {"cam": ref["cam"][i:i + 1].cpu(), "verts": ref["verts"][i:i + 1].cpu(), "fim": ref["fim"][i].cpu(),
+                           "wim": ref["wim"][i].cpu(), "Tst": Tst[i].cpu(), "tsf8": tsf8[i].cpu()}
+    got = torch.cat(preds, dim=0).cpu()
+    idx = list(range(tgt.shape[0])) if frames is None else list(frames)
+    src_ov = (im.src_info["cam"].cpu(), im.src_info["verts"].cpu())
+    want, extra = run_oracle(case, cam_strategy, frames=idx, return_all=True, src_override=src_ov,
+                             ref_override={t: (refs[t]["cam"], refs[t]["verts"]) for t in idx})
+    m = {"frames": idx}
+    m["src_verts_max"] = (extra[0]["src_own_verts"] - src_ov[1]).abs().max().item()
+    m["src_fim_equal"] = bool(torch.equal(im.src_info["fim"].cpu(), extra[0]["src_fim"]))
+    m["verts_max"] = max((extra[k]["own_verts"] - refs[t]["verts"]).abs().max().item() for k, t in enumerate(idx))
+    m["fim_equal"] = all(bool(torch.equal(refs[t]["fim"], extra[k]["fim"][0])) for k, t in enumerate(idx))
+    m["wim_max"] = max((refs[t]["wim"] - extra[k]["wim"][0]).abs().max().item() for k, t in enumerate(idx))
+    m["Tst_max"] = max((refs[t]["Tst"] - extra[k]["Tst"][0]).abs().max().item() for k, t in enumerate(idx))
+    m["tsf_inputs_max"] = max((refs[t]["tsf8"][..., :6].permute(2, 0, 1) - extra[k]["tsf_inputs"][0]).abs().max().item()
+                              for k, t in enumerate(idx))
+    d = (got[idx] - want).abs()
+    m["pred_max"], m["pred_mean"] = d.max().item(), d.mean().item()
+    m["pred_finite"] = bool(torch.isfinite(got).all())
+    return m, got, im

@@ -50,4 +50,14 @@ def test_reference_shaped_flow_methods(monkeypatch):
     want, allr = pu.run_oracle(case, frames=[0], return_all=True)
     assert Ttt is None and Tst.shape == (1, 2, 64, 64, 2)
     assert (tsf[:, 0] - allr[0]["tsf_inputs"]).abs().max() <= 2e-4   # random-texture sampling amplifies 1e-7 flow rounding
-    assert (Tst - allr[0]["Tst"]).abs().max() <= 1e-6
+    assert (Tst - allr[0]["Tst"]).abs().max() <= 1e-5
+
+
+def test_staged_parity_harness_on_emulated_abi(monkeypatch):
+    """The staged comparison used by the GPU parity tests and smoke(), exercised on CPU."""
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=3, ns=2)
+    m, got, im = pu.staged_parity(case, frame_batch=2, device="cpu")
+    assert m["fim_equal"] and m["src_fim_equal"] and m["wim_max"] == 0.0
+    assert m["verts_max"] <= 1e-5 and m["src_verts_max"] <= 1e-5
+    assert m["pred_max"] <= 2e-4 and m["Tst_max"] <= 1e-5
