@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restri
         for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
         const float logit = dot * inv_sqrt_c;
         const float mnew = fmaxf(mrun, logit);
-        const float corr = __expf(mrun - mnew);  // exp(-inf) = 0 on the first source
-        const float p = __expf(logit - mnew);
+        const float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first source
+        const float p = expf(logit - mnew);
         lrun = lrun * corr + p;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = o[k] * corr + p * (va[k] + bv4[k]);
