@@ -36,7 +36,7 @@ class ConvTimer:
     """Brackets every conv launch with events on torch's current stream (the stream the kernels are launched on)."""
 
     def __init__(self):
-        self.pairs, self.flops, self.enabled = [], 0.0, False
+        self.pairs, self.flops, self.enabled, self.meta = [], 0.0, False, []
         self._start = None
 
     def __call__(self, begin, M, spec):
@@ -50,10 +50,24 @@ class ConvTimer:
             stop.record()
             self.pairs.append((self._start, stop))
             self.flops += 2.0 * M * spec.algo_kn
+            self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn))
 
     def result(self):
         ms = sum(a.elapsed_time(b) for a, b in self.pairs)
         return ms, self.flops, len(self.pairs)
+
+    def breakdown(self):
+        """Per distinct conv shape: launches, total ms, achieved TFLOP/s (algorithmic flops / event time)."""
+        agg = {}
+        for (a, b), m in zip(self.pairs, self.meta):
+            key = "M%d N%d Cin%d taps%d s%d up%d" % m[:6]
+            e = agg.setdefault(key, [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += a.elapsed_time(b)
+            e[2] += m[6]
+        rows = [{"shape": k, "launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r["ms"])
 
 
 def cpu_baseline(case, n_frames):
@@ -79,6 +93,7 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-conv-events", action="store_true")
+    ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +173,10 @@ def main():
                                 "launches": n_launch, "avg_launch_us": round(conv_ms * 1e3 / n_launch, 2),
                                 "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
+        if args.conv_breakdown and n_launch:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "conv_breakdown.json"), "w") as fp:
+                json.dump(timer.breakdown(), fp, indent=1)
         if args.cpu_frames > 0:
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)

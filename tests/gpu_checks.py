@@ -136,7 +136,10 @@ def check_lwb_attention():
         n_src = B * ns if batched else ns
         Ks, Vs = _rand((n_src, h, h, C), 143), _rand((n_src, h, h, C), 144)
         T = _flows(B, ns, S, 145 + C)
-        want = emu_ops.lwb_attention(q, Ks, Vs, bk, bv, T, torch.zeros(B, h, h, C), src_batched=batched)
+        # fp64 evaluation of the same formulas: the fp32 lambda = s*i - floor(s*i) of the align_corners=True resize has
+        # an absolute error of ~S*2^-24, which the -2 sentinel jumps amplify (torch-CPU fp32 itself is ~1e-5 mean off)
+        want = emu_ops.lwb_attention(q.double(), Ks.double(), Vs.double(), bk.double(), bv.double(), T.double(),
+                                     torch.zeros(B, h, h, C).double(), src_batched=batched).float()
         got = ops.lwb_attention(q.to(DEV), Ks.to(DEV), Vs.to(DEV), bk.to(DEV), bv.to(DEV), T.to(DEV),
                                 torch.full((B, h, h, C), float("nan"), device=DEV), src_batched=batched)
         torch.cuda.synchronize()
@@ -145,7 +148,7 @@ def check_lwb_attention():
         out[key] = {"max_abs": err.max().item(), "mean_abs": err.mean().item(), "n_gt_2e-5": int((err > 2e-5).sum()),
                     "numel": err.numel(), "ref_max": want.abs().max().item()}
     for key, m in out.items():
-        assert m["max_abs"] <= 1e-4 * max(1.0, m["ref_max"]) and m["mean_abs"] <= 2e-6, (key, m)
+        assert m["max_abs"] <= 5e-4 * max(1.0, m["ref_max"]) and m["mean_abs"] <= 2e-5, (key, m)
     return out
 
 
