@@ -87,8 +87,8 @@ def cpu_baseline(case, n_frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)   # the shader clock needs ~0.2 s of load to settle
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frame-batch", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")

@@ -40,7 +40,7 @@ enum { LWG_EPI_NONE = 0, LWG_EPI_RESIDUAL = 1, LWG_EPI_SPADE = 2 };
 enum { LWG_ACTIVATION_NONE = 0, LWG_ACTIVATION_RELU = 1, LWG_ACTIVATION_TANH = 2, LWG_ACTIVATION_SIGMOID = 3 };
 
 typedef struct LwgConvArgs {
-    const float* x0;   /* input, NHWC (B,H,W,C0) */
+    const float* x0;   /* input, NHWC (B,H,W,C0); each input tensor must be < 3 GiB (32-bit buffer offsets) */
     const float* x1;   /* optional second input concatenated along C (skip connection), (B,H,W,C1), or NULL */
     int C0, C1;        /* Cin = C0 + C1; Cin % 32 == 0 (C0 % 32 == 0 when C1 > 0) or Cin in {4,8,16} with C1 == 0 */
     int B, H, W;       /* input dims */
@@ -53,7 +53,7 @@ typedef struct LwgConvArgs {
     int N;             /* GEMM columns (Cout, or 2*Cout gamma|beta interleaved by 32 for LWG_EPI_SPADE) */
     const float* bias; /* [N] or NULL */
     float* y;          /* output NHWC (B,YH,YW,YC); row (b,oy,ox) -> pixel (oy*omul+ooy, ox*omul+oox) */
-    int YH, YW, YC, ycoff; /* channel n is written at ycoff + n */
+    int YH, YW, YC, ycoff; /* channel n is written at ycoff + n; YC % 4 == 0 and ycoff % 4 == 0 (16-byte stores) */
     int omul, ooy, oox;
     int epi;           /* LWG_EPI_* */
     int act;           /* LWG_ACTIVATION_* applied last */

@@ -50,9 +50,9 @@ class ConvSpec:
             self.cshift = q.bit_length() - 1
 
 
-def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
-           out_hw=None, ycoff=0):
-    """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place)."""
+def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
+              out_hw=None, ycoff=0):
+    """Fill the C-ABI argument block of one conv launch (see ``conv2d``)."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     assert C0 + C1 == spec.Cin, (C0, C1, spec.Cin)
@@ -75,6 +75,13 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     for i in range(spec.ntaps):
         a.dy[i] = spec.dy[i]
         a.dx[i] = spec.dx[i]
+    return a
+
+
+def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
+           out_hw=None, ycoff=0):
+    """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place)."""
+    a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec)
     _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")

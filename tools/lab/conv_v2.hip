@@ -18,17 +18,14 @@
 //   are issued before the MFMAs of phase g.  The global loads of step t+1 are issued between the first MFMAs
 //   of phase 0 with ZERO vector ALU work (per-pixel byte offsets are recomputed only when the tap or the
 //   concat source changes; the channel chunk rides in the scalar offset), their ds_writes go to the other LDS
-//   stage in the shadow of the first MFMAs of phase 3, then the single barrier of the step, then the fragment
-//   reads of step t+1 phase 0 - issued BEFORE the last 4 MFMAs of step t so their latency is covered.  The K
-//   loop is unrolled by two so every LDS address is a base register + immediate.
-// The MFMAs compute D^T (weight fragment as the row operand): a lane then owns one output pixel and 4x4
-// consecutive channels of each 32x32 tile, so the epilogue issues 16-byte NHWC stores and does the pixel
-// index math once per row tile.
+//   stage late in phase 3, then the single barrier of the step, then the fragment reads of step t+1 phase 0 -
+//   issued BEFORE the last 4 MFMAs of step t so their latency is covered.  The K loop is unrolled by two so
+//   every LDS address is a base register + immediate.
 // Epilogues fuse bias, ReLU/tanh/sigmoid, the residual add, or SPADE's IN(x)*(1+gamma)+beta.
 #include <type_traits>
 
-#include "lwg_common.h"
-#include "lwg_conv_args.h"
+#include "../../ipercore_amd/csrc/lwg_common.h"
+#include "../../ipercore_amd/csrc/lwg_conv_args.h"
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
@@ -86,11 +83,9 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         taptab[tid] = dy * a.W + dx;
         taptab[LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
     }
-    __syncthreads();  // taptab visible
     if (!SMALLC) {
         for (int tp = 0; tp < a.ntaps; ++tp) {
-            const int packed = taptab[LWG_MAX_TAPS + tp];
-            const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
+            const int dy = a.dy[tp], dx = a.dx[tp];
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int iy = piy[p] + dy, ix = pix[p] + dx;
@@ -99,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
             }
         }
     }
+    __syncthreads();  // taptab visible
 
     const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 4u;
     const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 4u;
@@ -177,19 +173,13 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
 
     const int st_a = kq * A_ROW + mrow * 4;  // + 128 * p
     const int st_b = tid * 4;                // + 1024 * p   ([kq][n] is linear in idx)
-    auto lstore_a = [&](int buf) {
+    auto lstore = [&](int buf) {
         float* Ab = As + buf * A_STAGE + st_a;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[p];
-    };
-    auto lstore_b = [&](int buf) {
         float* Bb = Bs + buf * B_STAGE + st_b;
 #pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[p];
+#pragma unroll
         for (int p = 0; p < PB; ++p) *reinterpret_cast<floatx4*>(Bb + 1024 * p) = rb[p];
-    };
-    auto lstore = [&](int buf) {
-        lstore_a(buf);
-        lstore_b(buf);
     };
 
     floatx16 acc[TM][TN];
@@ -217,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
     };
 
     // ---- prologue: stage 0 ----
@@ -263,18 +253,13 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         mfma_e(0, 2);
         mfma_e(0, 3);
         LWG_SB();
-        // phase 3: the stores of step t+1 ride in the shadow of MFMAs 1..8, the barrier sits before the last 4
+        // phase 3: the barrier sits between the 12th and the 13th MFMA
         mfma_e(1, 0);
-        LWG_SB();
-        if (NEXT) lstore_a(CUR ^ 1);
-        LWG_SB();
         mfma_e(1, 1);
-        LWG_SB();
-        if (NEXT) lstore_b(CUR ^ 1);
-        LWG_SB();
         mfma_e(1, 2);
         LWG_SB();
         if (NEXT) {
+            lstore(CUR ^ 1);
             __syncthreads();
             read_frags(CUR ^ 1, 0, 0);
         }
@@ -296,70 +281,45 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         step(c0{}, std::false_type{}, t);
     }
 
-    // ---- epilogue.  The MFMAs computed D^T (weights as the row operand), so a lane owns ONE output pixel
-    // m = lane&31 of each 32x32 tile and 16 channels n = 8*(r>>2) + 4*(lane>>5) + (r&3): four float4 per tile,
-    // channel-contiguous in NHWC -> 16-byte stores, pixel index math once per row tile.
+    // ---- epilogue: lane owns column n = lane&31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const bool direct = (a.omul == 1) && (a.YH == a.OH) && (a.YW == a.OW);
-    const int ncol0 = n_base + wn * TN * 32 + 4 * khalf;  // + 32*j + 8*g
-    floatx4 bias4[TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bias4[j][g] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias4[j][g] = *reinterpret_cast<const floatx4*>(a.bias + ncol0 + 32 * j + 8 * g);
-        }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m_base + wm * TM * 32 + i * 32 + (lane & 31);
-        if (m >= a.M) continue;
-        size_t opix = (size_t)m;
-        int bimg = 0;
-        if (!direct || EPI == LWG_EPI_SPADE) {
-            const int b = m / HW;
-            bimg = b;
-            if (!direct) {
-                const int rem = m - b * HW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (m >= a.M) continue;
+            size_t opix;
+            int bimg = 0;
+            if (direct) {
+                opix = (size_t)m;
+                if (EPI == LWG_EPI_SPADE) bimg = m / HW;
+            } else {
+                const int b = m / HW, rem = m - b * HW;
                 const int oy = rem / a.OW, ox = rem - oy * a.OW;
                 opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+                bimg = b;
             }
-        }
-        if (EPI == LWG_EPI_SPADE) {
-            // wave columns [0,32) = gamma, [32,64) = beta of the same 32 channels (host packs them so)
-            static_assert(EPI != LWG_EPI_SPADE || TN == 2, "SPADE epilogue needs gamma|beta in one wave");
-            const int ch0 = ((n_base + wn * TN * 32) >> 1) + 4 * khalf;
-            const float* xr = a.xn + opix * a.YC + ch0;
-            const float* mr = a.mean + (size_t)bimg * a.YC + ch0;
-            const float* rr = a.rstd + (size_t)bimg * a.YC + ch0;
-            float* yr = a.y + opix * a.YC + ch0;
+            if (EPI == LWG_EPI_SPADE) {
+                // wave columns [0,32) = gamma, [32,64) = beta of the same 32 channels (host packs them so)
+                static_assert(EPI != LWG_EPI_SPADE || TN == 2, "SPADE epilogue needs gamma|beta in one wave");
+                const int ch = ((n_base + wn * TN * 32) >> 1) + (lane & 31);
+                const int ng = n_base + wn * TN * 32 + (lane & 31);
+                const float g = acc[i][0][r] + a.bias[ng];
+                const float bt = acc[i][TN - 1][r] + a.bias[ng + 32];
+                const float xv = a.xn[opix * a.YC + ch];
+                const float mu = a.mean[bimg * a.YC + ch], rs = a.rstd[bimg * a.YC + ch];
+                a.y[opix * a.YC + ch] = lwg_act((xv - mu) * rs * (1.f + g) + bt, a.act);
+            } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 xv = *reinterpret_cast<const floatx4*>(xr + 8 * g);
-                const floatx4 mu = *reinterpret_cast<const floatx4*>(mr + 8 * g);
-                const floatx4 rs = *reinterpret_cast<const floatx4*>(rr + 8 * g);
-                floatx4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float gm = acc[i][0][4 * g + c] + bias4[0][g][c];
-                    const float bt = acc[i][TN - 1][4 * g + c] + bias4[TN - 1][g][c];
-                    o[c] = lwg_act((xv[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n_base + wn * TN * 32 + j * 32 + (lane & 31);
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    if (EPI == LWG_EPI_RESIDUAL) v += a.res[opix * a.YC + a.ycoff + n];
+                    a.y[opix * a.YC + a.ycoff + n] = lwg_act(v, a.act);
                 }
-                *reinterpret_cast<floatx4*>(yr + 8 * g) = o;
             }
-        } else {
-            float* yr = a.y + opix * a.YC + a.ycoff + ncol0;
-            const float* rr = EPI == LWG_EPI_RESIDUAL ? a.res + opix * a.YC + a.ycoff + ncol0 : nullptr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    floatx4 o;
-                    floatx4 rv = floatx4{0.f, 0.f, 0.f, 0.f};
-                    if (EPI == LWG_EPI_RESIDUAL) rv = *reinterpret_cast<const floatx4*>(rr + 32 * j + 8 * g);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c] + rv[c], a.act);
-                    *reinterpret_cast<floatx4*>(yr + 32 * j + 8 * g) = o;
-                }
         }
     }
 }
@@ -394,7 +354,7 @@ extern "C" int lwg_conv2d_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t stream_) 
     const LwgConvArgs& a = *pa;
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
-    if (a.N % 64 != 0 || (Cin & 3) != 0 || (a.YC & 3) != 0 || (a.ycoff & 3) != 0) return (int)hipErrorInvalidValue;
+    if (a.N % 64 != 0 || (Cin & 3) != 0) return (int)hipErrorInvalidValue;
     // buffer-load addressing: every tensor the kernel gathers from must be smaller than LWG_OOB_OFFSET bytes
     const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
     if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;

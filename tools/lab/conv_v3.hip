@@ -18,22 +18,30 @@
 //   are issued before the MFMAs of phase g.  The global loads of step t+1 are issued between the first MFMAs
 //   of phase 0 with ZERO vector ALU work (per-pixel byte offsets are recomputed only when the tap or the
 //   concat source changes; the channel chunk rides in the scalar offset), their ds_writes go to the other LDS
-//   stage in the shadow of the first MFMAs of phase 3, then the single barrier of the step, then the fragment
-//   reads of step t+1 phase 0 - issued BEFORE the last 4 MFMAs of step t so their latency is covered.  The K
-//   loop is unrolled by two so every LDS address is a base register + immediate.
-// The MFMAs compute D^T (weight fragment as the row operand): a lane then owns one output pixel and 4x4
-// consecutive channels of each 32x32 tile, so the epilogue issues 16-byte NHWC stores and does the pixel
-// index math once per row tile.
+//   stage late in phase 3, then the single barrier of the step, then the fragment reads of step t+1 phase 0 -
+//   issued BEFORE the last 4 MFMAs of step t so their latency is covered.  The K loop is unrolled by two so
+//   every LDS address is a base register + immediate.
 // Epilogues fuse bias, ReLU/tanh/sigmoid, the residual add, or SPADE's IN(x)*(1+gamma)+beta.
 #include <type_traits>
 
-#include "lwg_common.h"
-#include "lwg_conv_args.h"
+#include "../../ipercore_amd/csrc/lwg_common.h"
+#include "../../ipercore_amd/csrc/lwg_conv_args.h"
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
 #define LWG_OOB_OFFSET 0xC0000000u  // >= any tensor's byte size (host enforces < 3 GiB): the buffer load returns 0
 #define LWG_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef LWG_LAB_TS
+__device__ unsigned long long lwg_lab_ts[8192 * 8];
+#define LWG_TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { lwg_lab_ts[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); lwg_lab_ts[blockIdx.x * 8 + 4 + (k)] = wall_clock64(); } } while (0)
+extern "C" int lwg_lab_read_ts(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lwg_lab_ts), sizeof(unsigned long long) * n);
+}
+#define LWG_TS_END() do { __builtin_amdgcn_s_waitcnt(0); LWG_TS(3); } while (0)
+#else
+#define LWG_TS(k)
+#define LWG_TS_END()
+#endif
 
 __device__ __forceinline__ floatx4 lwg_buf_load(const float* base, unsigned bytes, unsigned voff, unsigned soff) {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
@@ -50,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     constexpr int PB = BN / 32;  // B float4 loads per thread per K-step
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
 
+    LWG_TS(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_STAGE;
@@ -177,19 +186,13 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
 
     const int st_a = kq * A_ROW + mrow * 4;  // + 128 * p
     const int st_b = tid * 4;                // + 1024 * p   ([kq][n] is linear in idx)
-    auto lstore_a = [&](int buf) {
+    auto lstore = [&](int buf) {
         float* Ab = As + buf * A_STAGE + st_a;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[p];
-    };
-    auto lstore_b = [&](int buf) {
         float* Bb = Bs + buf * B_STAGE + st_b;
 #pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[p];
+#pragma unroll
         for (int p = 0; p < PB; ++p) *reinterpret_cast<floatx4*>(Bb + 1024 * p) = rb[p];
-    };
-    auto lstore = [&](int buf) {
-        lstore_a(buf);
-        lstore_b(buf);
     };
 
     floatx16 acc[TM][TN];
@@ -263,18 +266,13 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         mfma_e(0, 2);
         mfma_e(0, 3);
         LWG_SB();
-        // phase 3: the stores of step t+1 ride in the shadow of MFMAs 1..8, the barrier sits before the last 4
+        // phase 3: the barrier sits between the 12th and the 13th MFMA
         mfma_e(1, 0);
-        LWG_SB();
-        if (NEXT) lstore_a(CUR ^ 1);
-        LWG_SB();
         mfma_e(1, 1);
-        LWG_SB();
-        if (NEXT) lstore_b(CUR ^ 1);
-        LWG_SB();
         mfma_e(1, 2);
         LWG_SB();
         if (NEXT) {
+            lstore(CUR ^ 1);
             __syncthreads();
             read_frags(CUR ^ 1, 0, 0);
         }
@@ -282,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         mfma_e(1, 3);
         LWG_SB();
     };
+    LWG_TS(1);
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
     int t = 0;
@@ -296,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         step(c0{}, std::false_type{}, t);
     }
 
+    LWG_TS(2);
     // ---- epilogue.  The MFMAs computed D^T (weights as the row operand), so a lane owns ONE output pixel
     // m = lane&31 of each 32x32 tile and 16 channels n = 8*(r>>2) + 4*(lane>>5) + (r&3): four float4 per tile,
     // channel-contiguous in NHWC -> 16-byte stores, pixel index math once per row tile.
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
                 }
         }
     }
+    LWG_TS_END();
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
