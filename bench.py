@@ -36,10 +36,10 @@ class ConvTimer:
     """Brackets every conv launch with events on torch's current stream (the stream the kernels are launched on)."""
 
     def __init__(self):
-        self.pairs, self.flops, self.enabled, self.meta = [], 0.0, False, []
+        self.pairs, self.flops, self.bytes, self.enabled, self.meta = [], 0.0, 0.0, False, []
         self._start = None
 
-    def __call__(self, begin, M, spec):
+    def __call__(self, begin, M, spec, epi=0):
         if not self.enabled:
             return
         if begin:
@@ -50,6 +50,9 @@ class ConvTimer:
             stop.record()
             self.pairs.append((self._start, stop))
             self.flops += 2.0 * M * spec.algo_kn
+            # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
+            out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
+            self.bytes += 4.0 * (M * spec.stride ** 2 * spec.Cin + spec.w.numel() + out + (M * spec.N if epi == 1 else 0))
             self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn))
 
     def result(self):
@@ -107,8 +110,7 @@ def main():
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from ipercore_amd import ops, sharding
-    from tests import parity_utils as pu
+    from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
     FB, K, W, S = args.frame_batch, args.steps, args.warmup, args.size
     per_rank = (K + W) * FB
@@ -166,9 +168,17 @@ def main():
                        "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},
         }
         if n_launch:
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by tools/pmc_round.sh (separate --pmc passes)
+            if S == 512 and FB == 8 and os.path.exists(tpath):
+                with open(tpath) as fp:
+                    tj = json.load(fp)
+                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                                "traffic_source": traffic_src,
+                                "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
                                 "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
                                 "launches": n_launch, "avg_launch_us": round(conv_ms * 1e3 / n_launch, 2),
                                 "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),

@@ -24,7 +24,7 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
-CONV_HOOK = None     # bench.py installs a callable(begin, M, spec) to bracket conv launches with HIP events
+CONV_HOOK = None     # bench.py installs a callable(begin, M, spec, epi) to bracket conv launches with HIP events
 
 
 def _stream():
@@ -83,10 +83,10 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place)."""
     a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
     if CONV_HOOK is not None:
-        CONV_HOOK(True, a.M, spec)
+        CONV_HOOK(True, a.M, spec, epi)
     _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
-        CONV_HOOK(False, a.M, spec)
+        CONV_HOOK(False, a.M, spec, epi)
     return y
 
 

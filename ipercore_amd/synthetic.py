@@ -117,3 +117,45 @@ def tmp_asset_dir():
     d = os.environ.get("LWG_TMPDIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "lwg_synth")
     os.makedirs(d, exist_ok=True)
     return d
+
+
+# ---- one synthetic clip: the inputs of bench.py, smoke() and the parity tests ----
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def gen_cfg(num_filters, n_res, bg_filters):
+    return AttrDict(name="AttLWB-SPADE",
+                    BGNet=AttrDict(norm_type="instance", cond_nc=4, n_res_block=n_res, num_filters=list(bg_filters)),
+                    SIDNet=AttrDict(norm_type="None", cond_nc=6, n_res_block=n_res, num_filters=list(num_filters)),
+                    TSFNet=AttrDict(norm_type="instance", cond_nc=6, n_res_block=n_res, num_filters=list(num_filters)))
+
+
+def build_case(image_size=512, num_filters=(64, 128, 256), n_res=6, bg_filters=(64, 128, 128, 256), n_frames=8, ns=2,
+               seed=0):
+    S = int(image_size)
+    from .networks import generator_param_shapes
+    shapes = generator_param_shapes(num_filters, n_res, bg_filters)
+    case = AttrDict(
+        S=S, ns=ns, n_frames=n_frames, num_filters=list(num_filters), n_res=n_res, bg_filters=list(bg_filters),
+        smplh=smplh_model_dict(seed=seed),
+        state=fill_state_dict(shapes, seed=seed + 7),
+        src_smpl=smpl_sequence(ns, seed=seed + 11, pose_dim=72),
+        tgt_smpls=smpl_sequence(n_frames, seed=seed + 12, pose_dim=72),
+        uv_img=uniform_image((1, 3, S, S), seed + 6, "uv_img"),
+        bg_img=uniform_image((1, 3, S, S), seed + 5, "bg_img"),
+        src_img=uniform_image((1, ns, 3, S, S), seed + 4, "src_img"),
+    )
+    case.opt = AttrDict(image_size=S, gen_name="AttLWB-SPADE", temporal=False, only_vis=False, map_name="uv_seg",
+                        smpl_model_hand=case.smplh, neural_render_cfg=AttrDict(Generator=gen_cfg(num_filters, n_res, bg_filters)))
+    return case
+
+
+def make_imitator(case, frame_batch=8, device="cuda:0"):
+    import torch
+    from .imitator import Imitator
+    im = Imitator(case.opt, device=torch.device(device), frame_batch=frame_batch)
+    im.generator.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
+    im.generator.to(im.device)
+    im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    return im

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-conv-events"
+CMD="python $R/bench.py --steps 3 --warmup 2 --cpu-frames 0 --no-conv-events"
 run() { # name counters...
   local name=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$name" -o pmc -- $CMD > "$R/gpurun_out/pmc_$name.log" 2>&1 )
@@ -19,3 +19,7 @@ for p in ${PASSES:-A B C}; do
     D) run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS ;;
   esac
 done
+# per-launch HBM-side traffic of the dominant kernel -> profiles/pmc_traffic.json (read by bench.py) + per-kernel tables
+if [ -d gpurun_out/pmc_fetch ] && [ -d gpurun_out/pmc_write ]; then
+  python tools/pmc_summary.py --traffic gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_traffic.json
+fi

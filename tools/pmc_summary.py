@@ -37,5 +37,34 @@ def main():
     print(out)
 
 
+def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_kernel"):
+    """Per-launch HBM-side traffic of one kernel family from the FETCH_SIZE / WRITE_SIZE passes (separate rocprofv3
+    runs).  Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KiB;
+    on gfx950 FETCH_SIZE reports half of the bytes of 16-B/lane coalesced reads, so it is doubled; WRITE_SIZE is used
+    as reported (uncalibrated)."""
+    import json
+
+    def mean_kb(d, counter):
+        vals = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+    fk, nf = mean_kb(fetch_dir, "FETCH_SIZE")
+    wk, nw = mean_kb(write_dir, "WRITE_SIZE")
+    out = {"kernel": kernel_substr, "launches_fetch_pass": nf, "launches_write_pass": nw,
+           "fetch_size_kib_per_launch_raw": fk, "write_size_kib_per_launch_raw": wk,
+           "fetch_correction": 2.0,
+           "traffic_bytes_per_launch": None if fk is None or wk is None else (2.0 * fk + wk) * 1024.0}
+    with open(out_path, "w") as fp:
+        json.dump(out, fp, indent=1)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        traffic_json(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        main()
