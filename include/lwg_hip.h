@@ -151,6 +151,38 @@ int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size
 int lwg_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int Cp, int P, lwg_stream_t stream);
 int lwg_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int Cs, int P, lwg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Once-per-source image stage (Imitator.source_setup, models/imitator.py:177-246 -> FlowComposition.process_source,
+ * models/flowcomposition.py:452-512).  All tensors NCHW fp32 as in the reference API at this stage.
+ * lwg_morph_f32:          tools/utils/morphology/morph_ops.py:7-37 (mode 0 erode: pad 1, sum == ks^2; 1 dilate: pad 0,
+ *                         sum >= 1) and :40-63 (mode 2 soft_dilate: sum >= ks^2/2).  in/out (n,1,H,W); ws n*H*W floats.
+ * lwg_canny_f32:          tools/utils/morphology/canny_ops.py:137-212 CannyFilter.forward(img, low, high, True) for a
+ *                         1-channel image; gauss9 / sobelx9 are the reference's 3x3 kernels (row-major, HOST pointers;
+ *                         sobel_y is the transpose); edges (n,1,H,W) in {0,1}; ws 3*n*H*W floats.
+ * lwg_boundary_fill_f32:  flowcomposition.py:268-386 (cal_top_k_ids + morph_image + make_morph_image body): pixels with
+ *                         outpad*(1-confidant) != 0 take sum_k w_k * src[nn_k] over their 3 nearest edge pixels,
+ *                         w_k = d_k^2 / sum d^2; the rest src * confidant.  Distance ties -> lowest row-major edge
+ *                         index.  top3 (n,3,H,W) int32 optional (squared distances, -1 elsewhere).
+ *                         ws: n*(H*W + 1) int32; the edge counts land at ws[n*H*W + i] (>= 3 required per image
+ *                         that has uncertain pixels - the reference's topk raises otherwise).
+ * lwg_grid_sample_nchw_f32: F.grid_sample(img, grid) bilinear / zeros / align_corners=False as called at
+ *                         flowcomposition.py:117-118 (img_bstride = 0 broadcasts one image).
+ * lwg_uv_merge_f32:       flowcomposition.py:123-130: src_warp (ns,3,H,W), dilated vis (ns,1,H,W) -> merge_uv (3,H,W).
+ * lwg_pack_inputs_f32:    cat[a * mask, b] NCHW planes -> NHWC Cp channels (zero padded): make_bg_inputs
+ *                         (flowcomposition.py:250-260, a = src image, b = mask = eroded mask) and make_src_inputs
+ *                         (:262-265, a = morphed image, b = cond, mask = NULL).
+ * ------------------------------------------------------------------------------------------------ */
+int lwg_morph_f32(const float* in, float* out, int n, int H, int W, int ks, int mode, float* ws, lwg_stream_t stream);
+int lwg_canny_f32(const float* sil, int n, int H, int W, const float* gauss9, const float* sobelx9, float low, float high,
+                  float* edges, float* ws, lwg_stream_t stream);
+int lwg_boundary_fill_f32(const float* src, const float* confidant, const float* outpad, const float* edges, int n, int H,
+                          int W, float* out, int32_t* top3, int32_t* ws, lwg_stream_t stream);
+int lwg_grid_sample_nchw_f32(const float* img, size_t img_bstride, const float* grid, int n, int C, int H, int W, int Ho,
+                             int Wo, float* out, lwg_stream_t stream);
+int lwg_uv_merge_f32(const float* src_warp, const float* vis, int ns, int H, int W, float* out, lwg_stream_t stream);
+int lwg_pack_inputs_f32(const float* a, int Ca, const float* b, int Cb, const float* mask, int n, int H, int W, int Cp,
+                        float* out, lwg_stream_t stream);
+
 int lwg_device_cu_count(void);
 
 #ifdef __cplusplus

@@ -56,6 +56,13 @@ _SIGS = {
     "lwg_head_compose_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "lwg_nchw_to_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_nhwc_to_nchw_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_morph_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_canny_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                            ctypes.c_float, ctypes.c_float, c_f, c_f, c_f]),
+    "lwg_boundary_fill_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "lwg_grid_sample_nchw_f32": (c_i, [c_f, ctypes.c_size_t, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_uv_merge_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_pack_inputs_f32": (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
 }
 
 _lib = None

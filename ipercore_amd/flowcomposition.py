@@ -6,12 +6,15 @@ Built in this round (the per-frame path of ``Imitator.inference``):
   ``make_src_inputs`` (:262-265), and the fused ``frame_inputs`` that the MI355X runner actually calls: ONE
   pass over (fim, wim) producing cond, the UV flow + UV sample, the generator input and all source flows
   (``csrc/flow.hip``) instead of 2 + ns boolean-mask gathers with host syncs.
-Not built yet (source_setup): ``process_source`` / ``make_uv_img`` / ``make_morph_image`` /
-``make_bg_inputs`` (morphology, Canny, O(n1 n2) nearest-boundary fill) - they raise.
+Once-per-source stage (``Imitator.source_setup``): ``add_rendered_f2verts_fim_wim(use_morph=True)`` (:139-204),
+``make_morph_image`` (:335-386: silhouette morphology, Canny boundary, 3-nearest-boundary fill of the uncertain band -
+one O(n1 n2) kernel with no (n1, n2) matrix and no nonzero() host sync), ``make_uv_img`` (:87-137), ``make_bg_inputs``
+(:250-260), ``make_src_inputs`` (:262-265), ``process_source`` (:452-512) - kernels in ``csrc/source.hip``.
 """
 import torch
 
 from . import ops
+from .morphology import CannyFilter, morph
 from .renders import SMPLRenderer
 
 
@@ -23,6 +26,11 @@ class FlowComposition(torch.nn.Module):
         g = lambda k, d=None: getattr(opt, k, d) if not isinstance(opt, dict) else opt.get(k, d)    # noqa: E731
         self.image_size = int(g("image_size", 512))
         self.only_vis = bool(g("only_vis", False))
+        self.conf_erode_ks = int(g("conf_erode_ks", 3))        # deploy.toml:41
+        self.out_dilate_ks = int(g("out_dilate_ks", 51))       # deploy.toml:42
+        self.bg_ks = int(g("bg_ks", 11))                       # deploy.toml:11
+        self.num_source = int(g("num_source", 2))
+        self.time_step = int(g("time_step", 1))
         self.render = SMPLRenderer(
             face_path=g("face_path"), fim_enc_path=g("fim_enc_path"), uv_map_path=g("uv_map_path"),
             part_path=g("part_path"), front_path=g("front_path"), head_path=g("head_path"), facial_path=g("facial_path"),
@@ -45,10 +53,13 @@ class FlowComposition(torch.nn.Module):
     @torch.no_grad()
     def add_rendered_f2verts_fim_wim(self, smpl_info, use_morph=False, get_uv_info=True):
         """flowcomposition.py:139-204."""
-        if use_morph:
-            raise NotImplementedError("use_morph=True (source_setup silhouette morphology) is a 'next' row (SURVEY 8f-1)")
         f2pts, fim, wim = self.render.render_fim_wim(cam=smpl_info["cam"], vertices=smpl_info["verts"], smpl_faces=True)
         cond, _ = self.render.encode_fim(fim=fim, transpose=True)
+        if use_morph:
+            rendered_sil = 1 - cond[:, -1:]
+            human_sil = 1 - smpl_info["masks"] if "masks" in smpl_info else rendered_sil
+            smpl_info["confidant_sil"] = morph(human_sil, ks=self.conf_erode_ks, mode="erode")
+            smpl_info["outpad_sil"] = morph(((human_sil + rendered_sil) > 0).float(), ks=self.out_dilate_ks, mode="dilate")
         smpl_info["f2pts"] = f2pts
         smpl_info["only_vis_f2pts"] = _Lazy(lambda: self.render.get_vis_f2pts(f2pts, fim))   # consumed only if only_vis
         smpl_info["cond"], smpl_info["fim"], smpl_info["wim"] = cond, fim, wim
@@ -90,13 +101,57 @@ class FlowComposition(torch.nn.Module):
         return Tst.view(bs, ns, h, w, 2), None
 
     def make_src_inputs(self, src_img, src_info):
+        """flowcomposition.py:262-265."""
         return torch.cat([src_img, src_info["cond"]], dim=1)
 
-    def process_source(self, *a, **k):
-        raise NotImplementedError("process_source (morph / Canny / UV merge) is a 'next' row (SURVEY 8f-1); "
-                                  "use Imitator.set_source() with a prepared uv_img")
+    @torch.no_grad()
+    def make_bg_inputs(self, src_img, src_info):
+        """flowcomposition.py:250-260 -> (bs*ns, 4, h, w)."""
+        bg_mask = src_info["masks"] if "masks" in src_info else src_info["cond"][:, -1:, :, :]
+        src_bg_mask = morph(bg_mask.contiguous(), ks=self.bg_ks, mode="erode")
+        return torch.cat([src_img * src_bg_mask, src_bg_mask], dim=1)
 
-    make_uv_img = make_morph_image = make_bg_inputs = process_source
+    @torch.no_grad()
+    def make_morph_image(self, src_img, src_info, erode_ks=3, dilate_ks=11, want_debug=False):
+        """flowcomposition.py:335-386 -> (bs*ns, 3, h, w).  The reference calls it with erode_ks = dilate_ks = 0."""
+        confidant_sil = morph(src_info["confidant_sil"], ks=erode_ks, mode="erode") if erode_ks > 0 else src_info["confidant_sil"]
+        outpad_sil = morph(src_info["outpad_sil"], ks=dilate_ks, mode="dilate") if dilate_ks > 0 else src_info["outpad_sil"]
+        thin_edges = CannyFilter()(confidant_sil, 0.1, 0.9, True)
+        out, counts, top3 = ops.boundary_fill(src_img, confidant_sil, outpad_sil, thin_edges, want_top3=want_debug)
+        src_info["_edge_counts"] = counts            # device tensor; source_setup checks it once (topk needs >= 3 edges)
+        if want_debug:
+            return out, thin_edges, top3
+        return out
+
+    @torch.no_grad()
+    def make_uv_img(self, src_img, src_info):
+        """flowcomposition.py:87-137: (bs, ns, 3, h, w) -> merged UV image (bs, 3, h, w)."""
+        bs, ns, _, h, w = src_img.shape
+        n = bs * ns
+        uv_fim = self.uv_fim[0:1].expand(n, -1, -1).contiguous()
+        uv_wim = self.uv_wim[0:1].expand(n, -1, -1, -1).contiguous()
+        one_map = torch.ones(n, 1, h, w, dtype=torch.float32, device=src_img.device)
+        only_vis_Ts2uv = self.render.cal_bc_transform(src_info["only_vis_obj_f2pts"], uv_fim, uv_wim)
+        Ts2uv = self.render.cal_bc_transform(src_info["obj_f2pts"], uv_fim, uv_wim)
+        src_warp = ops.grid_sample(src_img.reshape(n, 3, h, w), Ts2uv)
+        vis_warp = ops.grid_sample(one_map, only_vis_Ts2uv)
+        vis_warp = morph(vis_warp, ks=13, mode="dilate")
+        outs = [ops.uv_merge(src_warp[b * ns:(b + 1) * ns], vis_warp[b * ns:(b + 1) * ns]) for b in range(bs)]
+        return torch.stack(outs, dim=0)
+
+    @torch.no_grad()
+    def process_source(self, src_img, src_info, primary_ids=None):
+        """flowcomposition.py:452-512 -> (uv_img (bs,3,h,w), input_G_bg (bs,len(primary),4,h,w), input_G_src (bs,ns,6,h,w))."""
+        bs, ns, _, h, w = src_img.shape
+        self.make_uv_setup(bs, self.num_source, self.time_step, src_img.device)
+        flat = src_img.reshape(bs * ns, 3, h, w).contiguous()
+        morph_src_img = self.make_morph_image(flat, src_info, erode_ks=0, dilate_ks=0)
+        morph_uv_img = self.make_uv_img(morph_src_img.view(bs, ns, 3, h, w), src_info)
+        input_G_src = self.make_src_inputs(morph_src_img, src_info).view(bs, ns, -1, h, w)
+        input_G_bg = self.make_bg_inputs(flat, src_info).view(bs, ns, -1, h, w)
+        if primary_ids is None:
+            primary_ids = [0]        # the reference draws one at random here (np.random.choice); its only caller passes [0]
+        return morph_uv_img, input_G_bg[:, primary_ids], input_G_src
 
     # ------------------------------------------------------------------ fused MI355X per-frame entry
     @torch.no_grad()

@@ -11,8 +11,8 @@ state, its own SMPL parameters and ``first_cam`` (:298-299), so ``inference`` wa
 flow pass, the generator (MFMA convs at batch B), one head + compositing kernel.  No host sync inside a batch.
 Frames of one clip shard over ranks with ``ipercore_amd.sharding`` (one all-gather of the output tensor).
 
-``source_setup`` (:177-246) needs the source-image morphology / UV-merge stage that is a "next" row
-(SURVEY 8f-1); until then sources enter through ``set_source`` with an already prepared UV image.
+``source_setup`` (:177-246) runs the once-per-source stage on the device (morphology, Canny boundary fill, UV merge,
+background network, SIDNet + K/V hoist); ``set_source`` enters with an already prepared UV image / background.
 """
 import os
 
@@ -71,9 +71,42 @@ class Imitator(object):
         return net
 
     # ------------------------------------------------------------------ source state
-    def source_setup(self, *args, **kwargs):
-        raise NotImplementedError("Imitator.source_setup needs process_source (morph / Canny / UV merge): 'next' row "
-                                  "(SURVEY 8f-1).  Use set_source(src_smpl, uv_img, bg_img, src_inputs=...)")
+    @torch.no_grad()
+    def source_setup(self, src_path, src_smpl, masks=None, bg_img=None, offsets=0, links_ids=None, visualizer=None):
+        """imitator.py:177-246.  ``src_path``: list of image paths (loaded like cv_utils.load_images, :190) or an
+        array / tensor (ns,3,S,S) in [-1,1]; ``masks`` (ns,1,S,S) foreground masks or None; ``bg_img`` (3,S,S) or None."""
+        dev, S = self.device, self.image_size
+        if isinstance(src_path, (list, tuple, str)):
+            src_np = load_images(src_path, S)
+        else:
+            src_np = np.asarray(src_path.detach().cpu() if torch.is_tensor(src_path) else src_path, dtype=np.float32)
+        src_img = torch.tensor(src_np[None], dtype=torch.float32, device=dev)            # (1, ns, 3, S, S)
+        src_smpl = torch.as_tensor(src_smpl, dtype=torch.float32, device=dev)
+        off = torch.as_tensor(np.asarray(offsets), dtype=torch.float32, device=dev) if not torch.is_tensor(offsets) else offsets.to(dev)
+        src_info = self.body_rec.get_details(src_smpl, off, links_ids=links_ids)
+        ns = src_smpl.shape[0]
+        src_info["num_source"] = ns
+        if masks is not None:
+            src_info["masks"] = 1.0 - torch.as_tensor(np.asarray(masks), dtype=torch.float32, device=dev)
+        self.flow_comp.add_rendered_f2verts_fim_wim(src_info, use_morph=True, get_uv_info=True)
+        src_info["offsets"], src_info["links_ids"] = off, links_ids
+        uv_img, input_G_bg, input_G_src = self.flow_comp.process_source(src_img, src_info, primary_ids=[0])
+        counts = src_info.pop("_edge_counts").cpu()                # the one host sync of source_setup
+        if int(counts.min()) < 3:
+            raise RuntimeError("source silhouette has fewer than 3 boundary pixels (the reference's topk(k=3) raises too)")
+        src_info["uv_img"] = uv_img
+        src_info["uv_img4"] = ops.nchw_to_nhwc(uv_img.contiguous(), c_pad=4)[0].contiguous()
+        if bool(_opt_get(self._opt, "use_inpaintor", False)) or bg_img is not None:
+            bg = torch.as_tensor(np.asarray(bg_img), dtype=torch.float32, device=dev)[None, None]
+        else:
+            bg = self.generator.forward_bg(input_G_bg.contiguous())
+        enc, res = self.generator.forward_src(input_G_src.contiguous(), only_enc=True)
+        src_info["img"] = src_img
+        src_info["bg"] = bg[:, 0].contiguous()
+        src_info["feats"] = (enc, res)
+        src_info["feats_nhwc"] = enc.lwg_cache
+        self.src_info = src_info
+        return src_info
 
     @torch.no_grad()
     def set_source(self, src_smpl, uv_img, bg_img, src_img=None, offsets=0, links_ids=None):
@@ -170,6 +203,22 @@ class Imitator(object):
                 else:
                     outputs.append(preds[i])
         return outputs
+
+
+def load_images(paths, image_size):
+    """cv_utils.load_images (cv_utils.py:45-66): (ns,3,S,S) RGB in [-1,1].  cv2 is not a dependency: PIL decodes and
+    resizes (bilinear), so a resized image is close to, not bit-identical with, cv2.resize."""
+    from PIL import Image
+    if isinstance(paths, str):
+        paths = [paths]
+    out = []
+    for p in paths:
+        im = Image.open(p).convert("RGB")
+        if im.size != (image_size, image_size):
+            im = im.resize((image_size, image_size), Image.BILINEAR)
+        a = np.asarray(im, dtype=np.float32) / 255.0
+        out.append((a * 2 - 1).transpose(2, 0, 1))
+    return np.stack(out, axis=0)
 
 
 def to_uint8_hwc(pred_chw):

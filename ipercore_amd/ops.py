@@ -231,3 +231,79 @@ def smpl_lbs(model, pose, beta, cam, offsets=None, links=None):
         _ptr(links, torch.int32), nlinks, B, nv, nj, _ptr(verts), _ptr(j3d), _ptr(j2d), _ptr(ws), _stream()),
         "lwg_smpl_lbs_f32")
     return verts, j3d, j2d
+
+
+# ---------------------------------------------------------------------------------------------- source_setup stage
+MORPH_MODES = {"erode": 0, "dilate": 1, "soft_dilate": 2}
+
+
+def morph(x, ks, mode="erode"):
+    """(n,1,H,W) mask -> morphed mask (tools/utils/morphology/morph_ops.py:7-63)."""
+    n, c, H, W = x.shape
+    assert c == 1
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    ws = torch.empty_like(x)
+    _lib.check(_lib.lib().lwg_morph_f32(_ptr(x), _ptr(out), n, H, W, int(ks), MORPH_MODES[mode], _ptr(ws), _stream()),
+               "lwg_morph_f32")
+    return out
+
+
+def canny_edges(sil, gauss9, sobelx9, low, high):
+    """(n,1,H,W) -> thin edges in {0,1} (canny_ops.py:137-212 with hysteresis).  gauss9/sobelx9: 9 python floats."""
+    import ctypes
+    n, c, H, W = sil.shape
+    assert c == 1
+    sil = sil.contiguous().float()
+    edges = torch.empty_like(sil)
+    ws = torch.empty(3 * sil.numel(), device=sil.device, dtype=torch.float32)
+    g = (ctypes.c_float * 9)(*[float(v) for v in gauss9])
+    s = (ctypes.c_float * 9)(*[float(v) for v in sobelx9])
+    _lib.check(_lib.lib().lwg_canny_f32(_ptr(sil), n, H, W, g, s, float(low), float(high), _ptr(edges), _ptr(ws), _stream()),
+               "lwg_canny_f32")
+    return edges
+
+
+def boundary_fill(src, confidant, outpad, edges, want_top3=False):
+    """flowcomposition.py:268-386 body -> (morph_img (n,3,H,W), edge counts (n,) int32 device, top3 or None)."""
+    n, _, H, W = src.shape
+    src, confidant, outpad, edges = (t.contiguous().float() for t in (src, confidant, outpad, edges))
+    out = torch.empty_like(src)
+    top3 = torch.empty(n, 3, H, W, device=src.device, dtype=torch.int32) if want_top3 else None
+    ws = torch.empty(n * (H * W + 1), device=src.device, dtype=torch.int32)
+    _lib.check(_lib.lib().lwg_boundary_fill_f32(_ptr(src), _ptr(confidant), _ptr(outpad), _ptr(edges), n, H, W, _ptr(out),
+                                                 _ptr(top3, torch.int32), _ptr(ws, torch.int32), _stream()),
+               "lwg_boundary_fill_f32")
+    return out, ws[n * H * W:], top3
+
+
+def grid_sample(img, grid):
+    """F.grid_sample(img (n|1,C,H,W), grid (n,Ho,Wo,2)) bilinear / zeros / align_corners=False."""
+    n, Ho, Wo, _ = grid.shape
+    nb, C, H, W = img.shape
+    assert nb in (1, n)
+    img, grid = img.contiguous().float(), grid.contiguous().float()
+    out = torch.empty(n, C, Ho, Wo, device=img.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_grid_sample_nchw_f32(_ptr(img), 0 if (nb == 1 and n > 1) else C * H * W, _ptr(grid), n, C, H, W,
+                                                    Ho, Wo, _ptr(out), _stream()), "lwg_grid_sample_nchw_f32")
+    return out
+
+
+def uv_merge(src_warp, vis):
+    """flowcomposition.py:123-130 for one batch item: (ns,3,H,W), (ns,1,H,W) -> (3,H,W)."""
+    ns, _, H, W = src_warp.shape
+    out = torch.empty(3, H, W, device=src_warp.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_uv_merge_f32(_ptr(src_warp.contiguous()), _ptr(vis.contiguous()), ns, H, W, _ptr(out), _stream()),
+               "lwg_uv_merge_f32")
+    return out
+
+
+def pack_inputs(a, b, mask, c_pad):
+    """cat[a * mask, b] (NCHW) -> NHWC with c_pad channels."""
+    n, Ca, H, W = a.shape
+    Cb = 0 if b is None else b.shape[1]
+    out = torch.empty(n, H, W, c_pad, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_pack_inputs_f32(_ptr(a.contiguous()), Ca, _ptr(None if b is None else b.contiguous()), Cb,
+                                               _ptr(None if mask is None else mask.contiguous()), n, H, W, c_pad, _ptr(out),
+                                               _stream()), "lwg_pack_inputs_f32")
+    return out

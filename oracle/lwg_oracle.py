@@ -439,3 +439,176 @@ def stabilize(model, smpls):
     new_cam[:, 0] = 1
     new_cam[:, 2] = new_y
     return torch.cat([new_cam, pose, shape], dim=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# a15: once-per-source image stage (Imitator.source_setup -> FlowComposition.process_source)
+# Pinned by tests/golden/golden_source_v1.npz (generated by tests/golden/make_golden_source.py from the reference's own
+# FlowComposition / morph / CannyFilter code, with cv2's two kernel-construction calls restated - see that script).
+# --------------------------------------------------------------------------------------------------
+def morph(mask, ks, mode="erode"):
+    """tools/utils/morphology/morph_ops.py:7-37."""
+    n_ks, pad_s = ks ** 2, ks // 2
+    kernel = torch.ones(1, 1, ks, ks, dtype=torch.float32)
+    if mode == "erode":
+        out = F.conv2d(F.pad(mask, [pad_s] * 4, value=1.0), kernel)
+        return (out == n_ks).float()
+    out = F.conv2d(F.pad(mask, [pad_s] * 4, value=0.0), kernel)
+    return (out >= 1).float()
+
+
+def canny_kernels():
+    """canny_ops.py:9-36 gaussian / sobel (float64 -> float32 like the reference's weight assignment) and the 8
+    directional kernels of :39-68.  cv2 is absent here, so the directional kernels are restated as what
+    getRotationMatrix2D + warpAffine + the |k| == 1 mask produce for 0..315 degrees: +1 at the centre, -1 at the
+    neighbour E, NE, N, NW, W, SW, S, SE (image y down; positive angle = counter-clockwise)."""
+    g1 = np.linspace(-1, 1, 3)
+    x, y = np.meshgrid(g1, g1)
+    d = (x ** 2 + y ** 2) ** 0.5
+    g = np.exp(-(d - 0) ** 2 / (2 * 1 ** 2)) / (2 * np.pi * 1 ** 2)
+    g = g / np.sum(g)
+    r = np.linspace(-1, 1, 3)
+    x, y = np.meshgrid(r, r)
+    den = x ** 2 + y ** 2
+    den[:, 1] = 1
+    sob = x / den
+    dirs = np.zeros((8, 3, 3))
+    for i, (dx, dy) in enumerate(((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))):
+        dirs[i, 1, 1] = 1
+        dirs[i, 1 + dy, 1 + dx] = -1
+    t = lambda a: torch.tensor(a, dtype=torch.float64).float()      # noqa: E731
+    return t(g)[None, None], t(sob)[None, None], t(sob.T)[None, None], t(dirs)[:, None]
+
+
+def _conv3_np(img, k9):
+    """3x3 cross-correlation, zero padding, taps accumulated in row-major order with one rounding per multiply and
+    per add (numpy fp32: IEEE on every host).  Equals torch's CPU conv2d on the authoring container bit for bit
+    (golden fixture) without depending on which oneDNN kernel another host's CPU selects."""
+    n, c, H, W = img.shape
+    p = np.pad(img, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    acc = np.zeros_like(img, dtype=np.float32)
+    for t in range(9):
+        acc = acc + np.float32(k9[t]) * p[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    return acc
+
+
+def canny(img, low, high):
+    """canny_ops.py:137-212 CannyFilter.forward(img (B,1,H,W), low, high, hysteresis=True) -> thin edges {0,1}.
+    Same operations in the same order as the reference, evaluated with numpy fp32 (every +,*,/,sqrt individually and
+    correctly rounded) so the result does not depend on the host CPU's vector ISA."""
+    kg, kx, ky, kd = (k.numpy() for k in canny_kernels())
+    x = img.numpy().astype(np.float32)
+    blurred = _conv3_np(x, kg.reshape(9))
+    gx, gy = _conv3_np(blurred, kx.reshape(9)), _conv3_np(blurred, ky.reshape(9))
+    mag = np.sqrt(gx * gx + gy * gy)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ori = np.arctan(gy / gx) * np.float32(360 / np.pi) + np.float32(180)
+        ori = np.round(ori / np.float32(45)) * np.float32(45)
+        pos_idx = np.mod(ori / np.float32(45), np.float32(8))
+    directional = np.stack([_conv3_np(mag, kd[i].reshape(9)) for i in range(8)], axis=1)[:, :, 0]
+    thin = mag.copy()
+    for pos_i in range(4):
+        neg_i = pos_i + 4
+        oriented = (pos_idx == pos_i) | (pos_idx == neg_i)
+        is_max = np.minimum(directional[:, pos_i], directional[:, neg_i]) > 0.0
+        thin[(~is_max[:, None]) & oriented] = 0.0
+    lowm, highm = thin > np.float32(low), thin > np.float32(high)
+    thin = lowm * np.float32(0.5) + highm * np.float32(0.5)
+    weak = thin == 0.5
+    weak_is_high = (_conv3_np(thin.astype(np.float32), np.full(9, 1.25, np.float32)) > 1) & weak
+    return torch.tensor((highm * 1 + weak_is_high * 1).astype(np.float32))
+
+
+def top_k_nearest(uncertain_pts, boundary_pts, top_k=3, chunk=4096):
+    """flowcomposition.py:268-293 cal_top_k_ids: squared distances (int64), the k smallest per row.  The reference's
+    topk(sorted=False) leaves the choice among equal distances to the backend; here ties go to the lowest boundary
+    index (composite key), one valid instance of that behaviour.  Returns (weights (n1,k) fp32, ids (n1,k), vals)."""
+    n2 = boundary_pts.shape[0]
+    vals, ids = [], []
+    ar = torch.arange(n2, dtype=torch.int64)[None]
+    for s in range(0, uncertain_pts.shape[0], chunk):
+        u = uncertain_pts[s:s + chunk]
+        d = ((u[:, None, :] - boundary_pts[None, :, :]) ** 2).sum(dim=-1)
+        key = d * n2 + ar
+        k, _ = key.topk(k=top_k, dim=-1, largest=False, sorted=True)
+        vals.append(k // n2)
+        ids.append(k % n2)
+    vals = torch.cat(vals) if vals else torch.zeros(0, top_k, dtype=torch.int64)
+    ids = torch.cat(ids) if ids else torch.zeros(0, top_k, dtype=torch.int64)
+    v = vals.float()
+    return v / torch.sum(v, dim=1, keepdim=True), ids, vals
+
+
+def make_morph_image(src_img, confidant_sil, outpad_sil):
+    """flowcomposition.py:295-386 with erode_ks = dilate_ks = 0 (the reference's call, :482-483).
+    Returns (morph_img (n,3,h,w), thin_edges, tie_mask (n,h,w) bool: pixels whose 3rd and 4th nearest boundary
+    distances coincide - there the reference's own result depends on the topk backend)."""
+    n, _, h, w = src_img.shape
+    thin = canny(confidant_sil, 0.1, 0.9)
+    uncertain_sil = outpad_sil * (1 - confidant_sil)
+    outs, ties = [], torch.zeros(n, h, w, dtype=torch.bool)
+    for i in range(n):
+        b_pts = thin[i, 0].nonzero(as_tuple=False)
+        u_pts = uncertain_sil[i, 0].nonzero(as_tuple=False)
+        img = src_img[i] * confidant_sil[i]
+        if u_pts.shape[0]:
+            weights, ids, vals = top_k_nearest(u_pts, b_pts, 3)
+            if b_pts.shape[0] > 3:
+                _, _, v4 = top_k_nearest(u_pts, b_pts, 4)
+                ties[i, u_pts[:, 0], u_pts[:, 1]] = v4[:, 2] == v4[:, 3]
+            nn = b_pts[ids.reshape(-1)]
+            rgbs = src_img[i][:, nn[:, 0], nn[:, 1]].view(3, -1, 3).permute(1, 0, 2)       # (n1, 3, k)
+            img[:, u_pts[:, 0], u_pts[:, 1]] = torch.matmul(rgbs, weights.unsqueeze(-1)).squeeze(-1).permute(1, 0)
+        outs.append(img)
+    return torch.stack(outs, dim=0), thin, ties
+
+
+def get_vis_f2pts(f2pts, fims, face_k_nearest):
+    """renders/nmr.py:639-681."""
+    out = []
+    for i in range(f2pts.shape[0]):
+        vis = torch.zeros_like(f2pts[i]) - 2.0
+        face_ids = fims[i].unique()[1:].long()
+        ids = torch.as_tensor(face_k_nearest)[face_ids].unique()
+        vis[ids] = f2pts[i][ids]
+        out.append(vis)
+    return torch.stack(out, dim=0)
+
+
+def make_uv_img(src_img, obj_f2pts, only_vis_obj_f2pts, uv_fim, uv_wim):
+    """flowcomposition.py:87-137: src_img (bs,ns,3,h,w); f2pts (bs*ns,nf,3,2); uv maps (1,h,w[,3]) -> (bs,3,h,w)."""
+    bs, ns, _, h, w = src_img.shape
+    n = bs * ns
+    fim, wim = uv_fim[0:1].repeat(n, 1, 1), uv_wim[0:1].repeat(n, 1, 1, 1)
+    only_vis_T = cal_bc_transform(only_vis_obj_f2pts, fim, wim)
+    T = cal_bc_transform(obj_f2pts, fim, wim)
+    src_warp = F.grid_sample(src_img.reshape(n, 3, h, w), T, align_corners=False).view(bs, ns, -1, h, w)
+    vis_warp = F.grid_sample(torch.ones(n, 1, h, w), only_vis_T, align_corners=False)
+    vis_warp = morph(vis_warp, ks=13, mode="dilate").view(bs, ns, -1, h, w)
+    vis_sum = torch.sum(vis_warp[:, 1:], dim=1)
+    temp = torch.sum(src_warp[:, 1:] * vis_warp[:, 1:], dim=1) / (vis_sum + 1e-5)
+    front_invisible = (1 - vis_warp[:, 0]) * (vis_sum >= 1).float()
+    return src_warp[:, 0] * (1 - front_invisible) + temp * front_invisible
+
+
+def process_source(src_img, cond, fim, obj_f2pts, obj_fim, uv_fim, uv_wim, face_k_nearest, masks=None,
+                   conf_erode_ks=3, out_dilate_ks=51, bg_ks=11):
+    """flowcomposition.py:139-204 (use_morph branch) + :452-512 for bs = 1, primary_ids = [0].
+    src_img (1,ns,3,h,w); cond (ns,3,h,w); masks: background masks (ns,1,h,w) (= 1 - foreground) or None.
+    Returns dict(uv_img, input_G_bg (1,1,4,h,w), input_G_src (1,ns,6,h,w), morph_img, thin_edges, tie_mask, ...)."""
+    _, ns, _, h, w = src_img.shape
+    rendered_sil = 1 - cond[:, -1:]
+    human_sil = 1 - masks if masks is not None else rendered_sil
+    confidant = morph(human_sil, conf_erode_ks, "erode")
+    outpad = morph(((human_sil + rendered_sil) > 0).float(), out_dilate_ks, "dilate")
+    flat = src_img.view(ns, 3, h, w)
+    morph_img, thin, ties = make_morph_image(flat, confidant, outpad)
+    only_vis_obj = get_vis_f2pts(obj_f2pts, obj_fim, face_k_nearest)
+    uv_img = make_uv_img(morph_img.view(1, ns, 3, h, w), obj_f2pts, only_vis_obj, uv_fim, uv_wim)
+    input_G_src = torch.cat([morph_img, cond], dim=1).view(1, ns, 6, h, w)
+    bg_mask = masks if masks is not None else cond[:, -1:]
+    src_bg_mask = morph(bg_mask, bg_ks, "erode")
+    input_G_bg = torch.cat([flat * src_bg_mask, src_bg_mask], dim=1).view(1, ns, 4, h, w)[:, [0]]
+    return {"uv_img": uv_img, "input_G_bg": input_G_bg, "input_G_src": input_G_src, "morph_img": morph_img,
+            "thin_edges": thin, "tie_mask": ties, "confidant_sil": confidant, "outpad_sil": outpad,
+            "only_vis_obj_f2pts": only_vis_obj}

@@ -35,6 +35,18 @@ def _cmp(got, want, tol, name):
     return m
 
 
+def _cmp_mostly(got, want, tol, max_bad_frac, name):
+    """For stages where the reference algorithm itself is discontinuous (a >= 1 threshold on a sum of bilinear weights
+    that are 1 - 1ulp or 1 depending on the host's rounding): all but a small fraction of the elements within tol."""
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape and torch.isfinite(got).all(), name
+    err = (got - want).abs()
+    bad = (err > tol).float().mean().item()
+    m = {"bad_frac": bad, "max_abs_within": err[err <= tol].max().item() if bad < 1 else float("nan"), "median": err.median().item()}
+    assert bad <= max_bad_frac, f"{name}: {bad:.4%} of elements differ by more than {tol}"
+    return m
+
+
 def _spec_dev(spec):
     return packing.spec_to(spec, DEV)
 
@@ -350,6 +362,83 @@ def check_pipeline_full_512():
     return _pipeline(512, [64, 128, 256], 6, [64, 128, 128, 256], n_frames=3, frame_batch=3, frames=[2])
 
 
+def _source_stage(S, ks, nf, nres, bgf):
+    """HIP source stage (FlowComposition.add_rendered_f2verts_fim_wim(use_morph) + process_source + Imitator.source_setup)
+    vs the oracle restatement (pinned against the reference's own process_source at S = 128 by the CPU suite)."""
+    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=2, ns=2)
+    case.opt.update(ks)
+    from ipercore_amd.imitator import Imitator
+    im = Imitator(case.opt, device=torch.device(DEV), frame_batch=2)
+    im.generator.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
+    im.generator.to(DEV)
+    smpls, img = pu.source_stage_inputs(S)
+    src_smpl = torch.tensor(smpls, device=DEV)
+    info = im.body_rec.get_details(src_smpl, torch.zeros((), device=DEV), links_ids=None)
+    # oracle on the HIP vertices: identical rasterizer inputs on both sides
+    o = pu.oracle_source_stage(S, ks, verts_cam=(info["cam"].cpu(), info["verts"].cpu()))
+    info["masks"] = 1.0 - o["fg"].to(DEV)
+    fc = im.flow_comp
+    fc.add_rendered_f2verts_fim_wim(info, use_morph=True, get_uv_info=True)
+    src_img = torch.tensor(img, device=DEV)
+    fc.make_uv_setup(1, 2, 1, DEV)
+    morph_img, thin, top3 = fc.make_morph_image(src_img.view(2, 3, S, S), info, erode_ks=0, dilate_ks=0, want_debug=True)
+    uv_img, g_bg, g_src = fc.process_source(src_img, info, primary_ids=[0])
+    torch.cuda.synchronize()
+    m = {"edges": int(thin.sum().item()), "uncertain": int((top3[:, 0] >= 0).sum().item())}
+    assert torch.equal(info["confidant_sil"].cpu(), o["confidant_sil"]) and torch.equal(info["outpad_sil"].cpu(), o["outpad_sil"])
+    m["edge_mismatch"] = int((thin.cpu() != o["thin_edges"]).sum().item())
+    assert m["edge_mismatch"] == 0, m
+    assert m["edges"] >= 3 and m["uncertain"] > 0
+    if S == 128 and ks["out_dilate_ks"] == 21:
+        # the same inputs as tests/golden/make_golden_source.py: compare with the REFERENCE's own outputs directly
+        g = np.load(os.path.join(ROOT, "tests", "golden", "golden_source_v1.npz"))
+        assert np.array_equal(info["confidant_sil"].cpu().numpy().astype(np.uint8), g["confidant_sil"])
+        assert np.array_equal(info["outpad_sil"].cpu().numpy().astype(np.uint8), g["outpad_sil"])
+        assert np.array_equal(thin.cpu().numpy().astype(np.uint8), g["thin_edges"]), "Canny edges differ from the reference's"
+        ties = o["tie_mask"][:, None].expand(-1, 3, -1, -1).numpy()
+        d = np.abs(g_src[0, :, 0:3].cpu().numpy() - g["input_G_src"][0, :, 0:3])
+        m["ref_morph_img_max_offtie"] = float(d[~ties].max())
+        assert m["ref_morph_img_max_offtie"] <= 1e-5
+        m["ref_input_G_bg"] = _cmp(g_bg, torch.tensor(g["input_G_bg"]), 1e-6, "input_G_bg vs reference")
+    # squared distances to the 3 nearest boundary pixels: exact integers, tie-invariant
+    from oracle import lwg_oracle as orc
+    for i in range(2):
+        b_pts = o["thin_edges"][i, 0].nonzero(as_tuple=False)
+        u_pts = (o["outpad_sil"] * (1 - o["confidant_sil"]))[i, 0].nonzero(as_tuple=False)
+        _, _, vals = orc.top_k_nearest(u_pts, b_pts, 3)
+        got = top3[i].cpu()[:, u_pts[:, 0], u_pts[:, 1]].permute(1, 0).long()
+        assert torch.equal(got, vals), "top-3 squared distances differ"
+        assert int((top3[i, 0].cpu() >= 0).sum()) == u_pts.shape[0]
+    m["morph_img"] = _cmp(morph_img, o["morph_img"], 1e-5, "morph image")          # same lowest-index tie rule on both sides
+    m["tie_frac"] = float(o["tie_mask"].float().mean())
+    # make_uv_img thresholds a 13x13 box sum of grid_sample(ones) at >= 1 (flowcomposition.py:120): a lone visible texel is
+    # 1 or 1 - 1ulp depending on the rounding of four bilinear weights, so a few 13x13 blocks may legitimately flip
+    m["uv_img"] = _cmp_mostly(uv_img, o["uv_img"], 5e-5, 0.01, "uv_img")
+    m["input_G_src"] = _cmp(g_src, o["input_G_src"], 1e-5, "input_G_src")
+    m["input_G_bg"] = _cmp(g_bg, o["input_G_bg"], 1e-6, "input_G_bg")
+    m["only_vis"] = _cmp(info["only_vis_obj_f2pts"], o["only_vis_obj_f2pts"], 0.0, "only_vis_obj_f2pts")
+    # whole source_setup through the runner API, then two frames
+    info2 = im.source_setup(img[0], smpls, masks=o["fg"].numpy(), bg_img=None, offsets=0, links_ids=None)
+    m["setup_uv"] = _cmp_mostly(info2["uv_img"], o["uv_img"], 5e-5, 0.01, "source_setup uv_img")
+    sd = {k: torch.tensor(v) for k, v in case.state.items()}
+    with torch.no_grad():
+        want_bg = orc.gen_forward_bg(sd, o["input_G_bg"], n_down=len(bgf), n_res=nres)
+    m["setup_bg"] = _cmp(info2["bg"], want_bg[:, 0], 2e-3, "source_setup bg")
+    pred = im.synthesize(im.prepare_sequence(case.tgt_smpls, "smooth"), "smooth")
+    assert torch.isfinite(pred).all() and pred.shape == (2, 3, S, S)
+    return m
+
+
+def check_source_setup_128():
+    return _source_stage(128, dict(conf_erode_ks=3, out_dilate_ks=21, bg_ks=11), [64, 64, 128], 2, [64, 64, 128])
+
+
+def check_source_setup_512():
+    """BASELINE size with the deploy.toml kernel sizes (conf_erode_ks 3, out_dilate_ks 51, bg_ks 11)."""
+    return _source_stage(512, dict(conf_erode_ks=3, out_dilate_ks=51, bg_ks=11), [64, 64, 128], 2, [64, 64, 128])
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
-       check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512]
+       check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
+       check_source_setup_512]

@@ -100,3 +100,49 @@ def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, devic
     m["pred_max"], m["pred_mean"] = d.max().item(), d.mean().item()
     m["pred_finite"] = bool(torch.isfinite(got).all())
     return m, got, im
+
+
+# ---- once-per-source stage: inputs shared by the golden script, the CPU pin test and the GPU check
+def source_stage_inputs(S, ns=2, seed=20):
+    """Same seeds as tests/golden/make_golden_source.py::source_inputs."""
+    from ipercore_amd import synthetic as syn
+    return syn.smpl_sequence(ns, seed=seed, pose_dim=72), syn.uniform_image((1, ns, 3, S, S), seed + 1, "src_img")
+
+
+def fg_masks_from_sil(sil):
+    """tests/golden/make_golden_source.py::fg_masks_from_sil (synthetic segmentation derived from the rendered silhouette)."""
+    s = sil.clone()
+    sh = torch.zeros_like(s)
+    sh[:, :, 1:, 2:] = s[:, :, :-1, :-2]
+    dil = (torch.nn.functional.max_pool2d(s, 3, 1, 1) > 0).float()
+    m = ((sh + dil) > 0).float()
+    m[:, :, :, : s.shape[-1] // 5] = 0
+    return m
+
+
+def oracle_source_stage(S, ks, smplh_dict=None, topo=None, verts_cam=None):
+    """The oracle's process_source on the seeded source-stage inputs.  ks: dict(conf_erode_ks, out_dilate_ks, bg_ks).
+    verts_cam = (cam, verts) overrides the oracle's own skinning (GPU check: identical rasterizer inputs)."""
+    from ipercore_amd import synthetic as syn
+    from oracle import lwg_oracle as orc
+    topo = topo or mesh.load_topology()
+    fim_obj = mesh.obj_from_topology(topo, "fim")
+    tables = oracle_tables(topo)
+    smpls, img = source_stage_inputs(S)
+    if verts_cam is None:
+        model = orc.SMPLHModel(smplh_dict or syn.smplh_model_dict(seed=0))
+        d = orc.smplh_get_details(model, smpls, 0, None)
+        cam, verts = d["cam"], d["verts"]
+    else:
+        cam, verts = verts_cam
+    _, fim, _ = orc.render_fim_wim(cam, verts, tables["smpl_faces"], S)
+    cond = orc.encode_fim(tables["map_fn"], fim)
+    obj_f2pts, obj_fim, _ = orc.render_fim_wim(cam, verts, fim_obj["faces"].astype(np.int32), S)
+    f_img2uvs = mesh.get_f2vts(fim_obj, z=1).astype(np.float32)
+    uv_fim, uv_wim = orc.render_uv_fim_wim(f_img2uvs, 1, S)
+    parts = {str(n): topo["part_" + str(n)] for n in topo["part_names"]}
+    fkn = mesh.find_part_k_nearest_faces(f_img2uvs, mesh.get_part_ids(f_img2uvs.shape[0], parts), k=3)
+    fg = fg_masks_from_sil((fim != -1).float().unsqueeze(1))
+    out = orc.process_source(torch.tensor(img), cond, fim, obj_f2pts, obj_fim, uv_fim, uv_wim, fkn, masks=1.0 - fg, **ks)
+    out.update(fg=fg, src_img=torch.tensor(img), smpls=smpls, obj_f2pts=obj_f2pts, uv_fim=uv_fim, uv_wim=uv_wim)
+    return out
