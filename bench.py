@@ -87,6 +87,33 @@ def cpu_baseline(case, n_frames):
                       f"OpenMP C rasterizer), {os.cpu_count()} host cpus"}
 
 
+def with_output(im, smpls, FB, n_frames, t_base):
+    """Reported separately: the same per-frame path WITH the output stage - device uint8 conversion, pinned async
+    D2H, PNG encoding + file writes on host threads (ipercore_amd/output.py).  Not the headline value."""
+    import shutil
+    import tempfile
+    from ipercore_amd.output import FrameWriter
+    d = tempfile.mkdtemp(prefix="lwg_bench_out_")
+    try:
+        w = FrameWriter(d, prefix="pred_")
+        n = min(n_frames, smpls.shape[0]) // FB * FB
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(0, n, FB):
+            tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, smpls[s:s + FB], "smooth", t=t_base + s)
+            w.submit(im.forward(tsf8, Tst)[0], s)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        paths = w.close()
+        dt = time.perf_counter() - t0
+        assert len(paths) == n
+        return {"value": round(n / dt, 2), "unit": "frames/s", "frames": n, "png_threads": w.workers,
+                "gpu_side_frames_per_s": round(n / t_gpu, 2),
+                "what": "per-frame path + uint8 conversion on the device + async D2H + PNG (zlib level 1) files on tmpfs/disk"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +123,7 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-conv-events", action="store_true")
+    ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     args = ap.parse_args()
 
@@ -187,6 +215,8 @@ def main():
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "conv_breakdown.json"), "w") as fp:
                 json.dump(timer.breakdown(), fp, indent=1)
+        if args.output_frames > 0 and world == 1:
+            line["with_output"] = with_output(im, mine, FB, args.output_frames, lo)
         if args.cpu_frames > 0:
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)

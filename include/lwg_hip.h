@@ -148,6 +148,10 @@ int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float* beta, int 
  * ------------------------------------------------------------------------------------------------ */
 int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
                          float* pred, float* mask, float* img, lwg_stream_t stream);
+/* lwg_frames_to_u8: the output conversion of Imitator.inference (models/imitator.py:368-372 ->
+ * cv_utils.save_cv2_img(normalize=True), tools/utils/filesio/cv_utils.py:100-116): pred (B,3,S,S) fp32 ->
+ * (B,S,S,3) uint8 = uint8((x+1)/2.0*255) in numpy fp32 arithmetic (truncation); bgr = 1: cv2's channel order. */
+int lwg_frames_to_u8(const float* pred, int B, int S, int bgr, uint8_t* out, lwg_stream_t stream);
 int lwg_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int Cp, int P, lwg_stream_t stream);
 int lwg_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int Cs, int P, lwg_stream_t stream);
 

@@ -153,3 +153,36 @@ extern "C" int lwg_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, 
     hipLaunchKernelGGL(lwg_nhwc_to_nchw_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, stream, src, dst, C, Cs, P);
     return (int)hipGetLastError();
 }
+
+// Output conversion of Imitator.inference (models/imitator.py:368-372 -> cv_utils.save_cv2_img(normalize=True),
+// tools/utils/filesio/cv_utils.py:100-116): (B,3,S,S) fp32 in [-1,1] -> (B,S,S,3) uint8 HWC, value
+// uint8((x + 1) / 2.0 * 255) with numpy's fp32 arithmetic (each operation rounded, conversion truncates toward zero).
+// bgr = 1 writes the channel order the reference hands to cv2.imwrite.  HBM-bound: 12 B in, 3 B out per pixel; done on
+// the device so the D2H copy is 0.75 MB/frame instead of 3 MB and the host threads only encode.
+__global__ void lwg_frames_to_u8_kernel(const float* __restrict__ pred, int B, int P, int bgr, unsigned char* __restrict__ out) {
+    const size_t total = (size_t)B * P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / P, pix = i - b * P;
+        const float* src = pred + b * 3 * (size_t)P + pix;
+        unsigned char v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = src[(size_t)c * P];
+            const float y = __fmul_rn(__fmul_rn(__fadd_rn(x, 1.f), 0.5f), 255.f);
+            v[c] = (unsigned char)(int)y;
+        }
+        unsigned char* o = out + i * 3;
+        o[0] = bgr ? v[2] : v[0];
+        o[1] = v[1];
+        o[2] = bgr ? v[0] : v[2];
+    }
+}
+
+extern "C" int lwg_frames_to_u8(const float* pred, int B, int S, int bgr, uint8_t* out, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pred || !out || B <= 0 || S <= 0) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)B * S * S;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_frames_to_u8_kernel, dim3(blocks), dim3(256), 0, stream, pred, B, S * S, bgr, out);
+    return (int)hipGetLastError();
+}

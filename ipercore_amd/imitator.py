@@ -192,16 +192,17 @@ class Imitator(object):
                   visualizer=None, verbose=True):
         """imitator.py:327-382."""
         tgt = self.prepare_sequence(tgt_smpls, cam_strategy)
+        if output_dir:
+            # device-side uint8 conversion + pinned async D2H + threaded PNG encoding: the frame loop never waits for disk
+            from .output import FrameWriter
+            writer = FrameWriter(output_dir, prefix=prefix)
+            for s in range(0, tgt.shape[0], self.frame_batch):
+                writer.submit(self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s), s)
+            return writer.close()
         outputs = []
         for s in range(0, tgt.shape[0], self.frame_batch):
             preds = self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s).cpu().numpy()
-            for i in range(preds.shape[0]):
-                if output_dir:
-                    path = os.path.join(output_dir, prefix + "{:0>8}.png".format(s + i))
-                    save_image(preds[i], path)
-                    outputs.append(path)
-                else:
-                    outputs.append(preds[i])
+            outputs.extend(preds[i] for i in range(preds.shape[0]))
         return outputs
 
 

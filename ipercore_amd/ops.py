@@ -307,3 +307,12 @@ def pack_inputs(a, b, mask, c_pad):
                                                _ptr(None if mask is None else mask.contiguous()), n, H, W, c_pad, _ptr(out),
                                                _stream()), "lwg_pack_inputs_f32")
     return out
+
+
+def frames_to_u8(pred, bgr=False):
+    """(B,3,S,S) fp32 in [-1,1] -> (B,S,S,3) uint8 with save_cv2_img(normalize=True)'s numerics (cv_utils.py:111-113)."""
+    B, C, S, S2 = pred.shape
+    assert C == 3 and S == S2
+    out = torch.empty(B, S, S, 3, device=pred.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().lwg_frames_to_u8(_ptr(pred), B, S, 1 if bgr else 0, _ptr(out, torch.uint8), _stream()), "lwg_frames_to_u8")
+    return out

@@ -1,0 +1,132 @@
+"""Output stage of ``Imitator.inference`` (reference models/imitator.py:368-372 + cv_utils.save_cv2_img,
+tools/utils/filesio/cv_utils.py:100-116), re-designed for a producer that emits hundreds of frames per second.
+
+The reference converts and writes one frame at a time on the inference thread (``.cpu().numpy()``, fp32 3 MB
+D2H, ``cv2.imwrite``): at the rates of the MI355X path that serialises everything behind one host core.  Here:
+
+* the fp32 -> uint8 conversion (same numerics: ``uint8((x + 1) / 2.0 * 255)``, truncation) runs on the device
+  (``lwg_frames_to_u8``), so the copy is 0.75 MB/frame;
+* the D2H copy goes through a ring of pinned host buffers on a side stream, ordered after the producing kernels by
+  an event, never blocking the compute stream;
+* PNG encoding + file writes run on a pool of host threads (zlib releases the GIL); ``close()`` joins them.
+
+File names are the reference's: ``"{prefix}{t:0>8}.png"`` (imitator.py:369).  Pixels on disk are RGB, exactly what
+``cv2.imwrite`` stores for the BGR array the reference hands it.
+"""
+import os
+import queue
+import threading
+
+import numpy as np
+import torch
+
+
+def encode_png(path, hwc_u8, compress_level=1):
+    from PIL import Image
+    Image.fromarray(hwc_u8, mode="RGB").save(path, compress_level=compress_level)
+    return path
+
+
+class FrameWriter(object):
+    """Asynchronous ``(B,3,S,S)`` fp32 device frames -> PNG files.  ``submit`` returns immediately; ``close`` joins."""
+
+    def __init__(self, output_dir, prefix="pred_", workers=None, ring=4, compress_level=1):
+        self.output_dir, self.prefix = output_dir, prefix
+        os.makedirs(output_dir, exist_ok=True)
+        self.compress_level = compress_level
+        self.workers = int(workers or min(32, max(2, (os.cpu_count() or 4) // 2)))
+        self.ring = ring
+        self._free = queue.Queue()         # pinned host buffers whose frames are all encoded
+        self._nbuf = 0
+        self._jobs = queue.Queue()
+        self._cv = threading.Condition()
+        self._submitted = 0
+        self._errors = []
+        self.paths = {}
+        self._copy_stream = None
+        self._threads = [threading.Thread(target=self._worker, daemon=True) for _ in range(self.workers)]
+        for t in self._threads:
+            t.start()
+
+    # ---- host side -------------------------------------------------------------------------------------------
+    def _worker(self):
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            batch, i = job
+            try:
+                batch["ready"].wait()                      # the D2H copy of this batch has landed
+                t = batch["t0"] + i
+                path = os.path.join(self.output_dir, self.prefix + "{:0>8}.png".format(t))
+                encode_png(path, batch["host"].numpy()[i], self.compress_level)
+                with self._cv:
+                    self.paths[t] = path
+            except Exception as e:                         # surfaced by close()
+                with self._cv:
+                    self._errors.append(e)
+            finally:
+                with self._cv:
+                    batch["left"] -= 1
+                    if batch["left"] == 0:
+                        self._free.put(batch["host"])
+                    self._cv.notify_all()
+
+    def _host_buffer(self, shape, pinned):
+        """A pinned (B,S,S,3) uint8 buffer; blocks while all ``ring`` buffers still hold frames being encoded."""
+        while True:
+            if self._nbuf < self.ring and self._free.empty():
+                self._nbuf += 1
+                return torch.empty(shape, dtype=torch.uint8, pin_memory=pinned)
+            buf = self._free.get()
+            if tuple(buf.shape) == tuple(shape):
+                return buf
+            self._nbuf -= 1                                # a last, smaller batch: drop the buffer and allocate
+
+    def _wait_copy(self, batch, event):
+        if event is not None:
+            event.synchronize()
+        batch["ready"].set()
+
+    # ---- producer side ---------------------------------------------------------------------------------------
+    def submit(self, pred, t0):
+        """pred: (B,3,S,S) fp32 frames t0 .. t0+B-1, on the device (or on the CPU: tests)."""
+        B = pred.shape[0]
+        event = None
+        if pred.is_cuda:
+            from . import ops
+            u8 = ops.frames_to_u8(pred.contiguous())
+            host = self._host_buffer(tuple(u8.shape), True)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=pred.device)
+            produced = torch.cuda.Event()
+            produced.record(torch.cuda.current_stream(pred.device))
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(produced)
+                host.copy_(u8, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(self._copy_stream)
+            u8.record_stream(self._copy_stream)
+        else:
+            host = self._host_buffer((B, pred.shape[2], pred.shape[3], 3), False)
+            x = np.transpose(pred.detach().numpy().astype(np.float32), (0, 2, 3, 1))
+            host.copy_(torch.from_numpy(((x + 1) / 2.0 * 255).astype(np.uint8)))
+        batch = {"host": host, "t0": int(t0), "left": B, "ready": threading.Event()}
+        with self._cv:
+            self._submitted += B
+        threading.Thread(target=self._wait_copy, args=(batch, event), daemon=True).start()
+        for i in range(B):
+            self._jobs.put((batch, i))
+
+    def close(self):
+        """Wait for every submitted frame to be on disk, stop the pool, return the paths in frame order."""
+        with self._cv:
+            while len(self.paths) + len(self._errors) < self._submitted:
+                self._cv.wait(timeout=0.1)
+        for _ in self._threads:
+            self._jobs.put(None)
+        for t in self._threads:
+            t.join()
+        if self._errors:
+            raise self._errors[0]
+        return [self.paths[t] for t in sorted(self.paths)]

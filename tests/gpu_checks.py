@@ -438,7 +438,30 @@ def check_source_setup_512():
     return _source_stage(512, dict(conf_erode_ks=3, out_dilate_ks=51, bg_ks=11), [64, 64, 128], 2, [64, 64, 128])
 
 
+def check_output_stage():
+    """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
+    the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
+    import tempfile
+    from PIL import Image
+    x = _rand((5, 3, 40, 40), 300).clamp(-1, 1)
+    x[0, :, 0, 0] = torch.tensor([1.0, -1.0, 0.0])
+    want = ((np.transpose(x.numpy(), (0, 2, 3, 1)) + 1) / 2.0 * 255).astype(np.uint8)
+    got = ops.frames_to_u8(x.to(DEV)).cpu().numpy()
+    assert np.array_equal(got, want), "uint8 conversion differs from numpy"
+    assert np.array_equal(ops.frames_to_u8(x.to(DEV), bgr=True).cpu().numpy(), want[..., ::-1])
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=7, ns=2)
+    im = pu.make_imitator(case, frame_batch=3)
+    frames = im.inference(case.tgt_smpls, cam_strategy="smooth", output_dir="")
+    with tempfile.TemporaryDirectory() as d:
+        paths = im.inference(case.tgt_smpls, cam_strategy="smooth", output_dir=d, prefix="pred_")
+        assert [os.path.basename(p) for p in paths] == ["pred_{:0>8}.png".format(t) for t in range(7)]
+        for t, p in enumerate(paths):
+            ref = ((np.transpose(frames[t], (1, 2, 0)) + 1) / 2.0 * 255).astype(np.uint8)
+            assert np.array_equal(np.asarray(Image.open(p)), ref), f"frame {t} on disk differs"
+    return {"frames": len(paths)}
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
-       check_source_setup_512]
+       check_source_setup_512, check_output_stage]

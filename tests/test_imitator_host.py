@@ -1,5 +1,7 @@
 """Host logic of the runner (Imitator / FlowComposition / SMPLRenderer / SMPLH wrappers, frame batching, camera
 pre-pass) on CPU with the C-ABI ops emulated (tests/emu_ops.py), against the oracle's frame-by-frame result."""
+import os
+
 import numpy as np
 import torch
 
@@ -61,3 +63,24 @@ def test_staged_parity_harness_on_emulated_abi(monkeypatch):
     assert m["fim_equal"] and m["src_fim_equal"] and m["wim_max"] == 0.0
     assert m["verts_max"] <= 1e-5 and m["src_verts_max"] <= 1e-5
     assert m["pred_max"] <= 2e-4 and m["Tst_max"] <= 1e-5
+
+
+def test_frame_writer_cpu(tmp_path):
+    """The async output stage with CPU tensors: names (imitator.py:369), numerics (cv_utils.py:111-113), ordering."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from ipercore_amd.output import FrameWriter
+    rs = np.random.RandomState(0)
+    frames = torch.tensor(rs.uniform(-1, 1, size=(7, 3, 24, 24)).astype(np.float32))
+    frames[0, 0, 0, 0], frames[0, 1, 0, 0], frames[0, 2, 0, 0] = 1.0, -1.0, 0.0
+    w = FrameWriter(str(tmp_path), prefix="pred_", workers=3, ring=2)
+    w.submit(frames[0:3], 0)
+    w.submit(frames[3:6], 3)
+    w.submit(frames[6:7], 6)           # a last, smaller batch
+    paths = w.close()
+    assert [os.path.basename(p) for p in paths] == ["pred_{:0>8}.png".format(t) for t in range(7)]
+    for t, p in enumerate(paths):
+        want = ((np.transpose(frames[t].numpy(), (1, 2, 0)) + 1) / 2.0 * 255).astype(np.uint8)
+        assert np.array_equal(np.asarray(Image.open(p)), want)
+    assert tuple(np.asarray(Image.open(paths[0]))[0, 0]) == (255, 0, 127)
