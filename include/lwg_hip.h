@@ -98,9 +98,9 @@ int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, cons
  *                          faces_v (B,nf,3,3) and/or f2pts (B,nf,3,2).
  * lwg_rasterize_fim_wim_f32: nmr.py:337,356 nr.rasterize_face_index_map_and_weight_map(faces, S, False):
  *                          faces_v (B,nf,3,3) -> fim (B,S,S) int32 (-1 = background), wim (B,S,S,3).
- *                          ws: lwg_rasterize_ws_bytes(B,nf) bytes of scratch.
+ *                          ws: lwg_rasterize_ws_bytes(B,nf,S) bytes of scratch; S <= 2048.
  * ------------------------------------------------------------------------------------------------ */
-size_t lwg_rasterize_ws_bytes(int B, int nf);
+size_t lwg_rasterize_ws_bytes(int B, int nf, int S);
 int lwg_project_faces_f32(const float* verts, const float* cam, const int32_t* faces, int B, int nv, int nf,
                           float eye_dist, float* faces_v, float* f2pts, lwg_stream_t stream);
 int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, int S, float near, float far, int32_t* fim,

@@ -4,8 +4,8 @@
 // (rotvec -> quaternion -> rotation matrix), bodynets/base_smpl.py:28-50 (link), :7-18 (j2d projection).
 //
 // The reference runs this per frame with B = 1: a 38 MB posedirs GEMV plus 52 sequential 4x4 matmul launches.
-// Here the whole frame batch goes through four small kernels; the pose-blend tensor is streamed ONCE per
-// group of up to 8 frames (HBM-bound: 38 MB / group), everything else is L2-resident.
+// Here the whole frame batch goes through five small kernels; the pose-blend tensor is streamed ONCE per
+// group of up to 8 frames by 323 workgroups (HBM-bound: 38 MB / group), everything else is L2-resident.
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
@@ -123,60 +123,83 @@ __global__ __launch_bounds__(64) void lwg_lbs_pose_kernel(const float* __restric
     }
 }
 
-// verts[b,v] = (sum_j W[v,j] A[b,j]) * [v_shaped[b,v] + posedirs^T pose_feature[b]; 1]
-// grid (ceil(nv/256), ceil(B/FB)); pose features of the frame group staged in LDS.
-__global__ __launch_bounds__(256) void lwg_lbs_skin_kernel(const float* __restrict__ v_shaped, const float* __restrict__ posedirs,
-                                                          const float* __restrict__ pose_feature, int npf,
-                                                          const float* __restrict__ W, const float* __restrict__ A, int nj,
-                                                          int nv, int B, float* __restrict__ verts) {
+// v_posed[b,col] = v_shaped[b,col] + sum_p pose_feature[b,p] * posedirs[p,col]      (col = 3*v + k)
+// grid (ceil(3nv/64), ceil(B/FB)), 4 waves: a lane owns one column for up to FB frames (posedirs is streamed once per
+// frame group, 256 contiguous bytes per wave load), wave w takes the rows p = w, w+4, ...; the four partial sums are
+// combined in wave order (fixed order: a frame's result does not depend on the batch it is in).
+__global__ __launch_bounds__(256) void lwg_lbs_posed_kernel(const float* __restrict__ v_shaped, const float* __restrict__ posedirs,
+                                                           const float* __restrict__ pose_feature, int npf, int nv3, int B,
+                                                           float* __restrict__ v_posed) {
     extern __shared__ float sm[];
-    float* spf = sm;                          // [FB][npf]
-    float* sA = sm + LWG_LBS_FB * npf;        // [FB][nj][12]
+    float* spf = sm;                                  // [FB][npf]
+    float* part = sm + LWG_LBS_FB * npf;              // [4][FB][64]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int b0 = blockIdx.y * LWG_LBS_FB;
     const int nb = min(LWG_LBS_FB, B - b0);
     for (int i = threadIdx.x; i < LWG_LBS_FB * npf; i += 256) {
         const int fb = i / npf;
         spf[i] = fb < nb ? pose_feature[(size_t)(b0 + fb) * npf + (i - fb * npf)] : 0.f;
     }
-    for (int i = threadIdx.x; i < LWG_LBS_FB * nj * 12; i += 256) {
-        const int fb = i / (nj * 12);
-        sA[i] = fb < nb ? A[(size_t)(b0 + fb) * nj * 12 + (i - fb * nj * 12)] : 0.f;
+    __syncthreads();
+    const int col = blockIdx.x * 64 + lane;
+    const bool ok = col < nv3;
+    float po[LWG_LBS_FB];
+#pragma unroll
+    for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] = 0.f;
+    if (ok) {
+        int p = wid;
+        for (; p + 12 < npf; p += 16) {               // four rows in flight per wave
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = posedirs[(size_t)(p + 4 * u) * nv3 + col];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] += spf[fb * npf + p + 4 * u] * d[u];
+        }
+        for (; p < npf; p += 4) {
+            const float d = posedirs[(size_t)p * nv3 + col];
+#pragma unroll
+            for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] += spf[fb * npf + p] * d;
+        }
     }
+#pragma unroll
+    for (int fb = 0; fb < LWG_LBS_FB; ++fb) part[(wid * LWG_LBS_FB + fb) * 64 + lane] = po[fb];
+    __syncthreads();
+    if (wid == 0 && ok) {
+        for (int fb = 0; fb < nb; ++fb) {
+            const float t = ((part[(0 * LWG_LBS_FB + fb) * 64 + lane] + part[(1 * LWG_LBS_FB + fb) * 64 + lane]) +
+                             part[(2 * LWG_LBS_FB + fb) * 64 + lane]) + part[(3 * LWG_LBS_FB + fb) * 64 + lane];
+            v_posed[(size_t)(b0 + fb) * nv3 + col] = t + v_shaped[(size_t)(b0 + fb) * nv3 + col];
+        }
+    }
+}
+
+// verts[b,v] = (sum_j W[v,j] A[b,j]) * [v_posed[b,v]; 1]        grid (ceil(nv/256), B); A[b] staged in LDS
+__global__ __launch_bounds__(256) void lwg_lbs_blend_kernel(const float* __restrict__ v_posed, const float* __restrict__ W,
+                                                           const float* __restrict__ A, int nj, int nv,
+                                                           float* __restrict__ verts) {
+    extern __shared__ float sA[];                     // [nj][12]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < nj * 12; i += 256) sA[i] = A[(size_t)b * nj * 12 + i];
     __syncthreads();
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nv) return;
-    float po[LWG_LBS_FB][3];
+    const float* vp = v_posed + ((size_t)b * nv + v) * 3;
+    const float x = vp[0], y = vp[1], z = vp[2];
+    float T[12];
 #pragma unroll
-    for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb][0] = po[fb][1] = po[fb][2] = 0.f;
-    const size_t row = (size_t)nv * 3;
-    for (int p = 0; p < npf; ++p) {
-        const float* pd = posedirs + (size_t)p * row + (size_t)v * 3;
-        const float d0 = pd[0], d1 = pd[1], d2 = pd[2];
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+    for (int j = 0; j < nj; ++j) {
+        const float w = W[(size_t)v * nj + j];
+        const float* a = sA + j * 12;
 #pragma unroll
-        for (int fb = 0; fb < LWG_LBS_FB; ++fb) {
-            const float f = spf[fb * npf + p];
-            po[fb][0] += f * d0; po[fb][1] += f * d1; po[fb][2] += f * d2;
-        }
+        for (int k = 0; k < 12; ++k) T[k] += w * a[k];
     }
-#pragma unroll
-    for (int fb = 0; fb < LWG_LBS_FB; ++fb) {
-        if (fb >= nb) break;
-        const float* vs = v_shaped + ((size_t)(b0 + fb) * nv + v) * 3;
-        const float x = po[fb][0] + vs[0], y = po[fb][1] + vs[1], z = po[fb][2] + vs[2];
-        float T[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) T[k] = 0.f;
-        for (int j = 0; j < nj; ++j) {
-            const float w = W[(size_t)v * nj + j];
-            const float* a = sA + (fb * nj + j) * 12;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) T[k] += w * a[k];
-        }
-        float* o = verts + ((size_t)(b0 + fb) * nv + v) * 3;
-        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
-        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
-        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
-    }
+    float* o = verts + ((size_t)b * nv + v) * 3;
+    o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+    o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+    o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
 }
 
 // linked[b, ids[i,0]] = verts[b, ids[i,1]]  (dst must already hold a copy of verts)
@@ -218,10 +241,13 @@ extern "C" int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float*
     hipLaunchKernelGGL(lwg_lbs_joints_kernel, dim3(nj, B), dim3(256), 0, stream, J_regressor, v_shaped, nv, nj, J);
     hipLaunchKernelGGL(lwg_lbs_pose_kernel, dim3(B), dim3(64), 0, stream, pose, pose_stride, cam, cam_stride, J, parents, nj, pf, A,
                        j3d, j2d);
-    const size_t lds = (size_t)LWG_LBS_FB * (npf + nj * 12) * sizeof(float);
+    const size_t lds = (size_t)LWG_LBS_FB * (npf + 4 * 64) * sizeof(float);
     float* skin_out = (links && nlinks > 0) ? vraw : verts;
-    hipLaunchKernelGGL(lwg_lbs_skin_kernel, dim3((nv + 255) / 256, (B + LWG_LBS_FB - 1) / LWG_LBS_FB), dim3(256), lds, stream,
-                       v_shaped, posedirs, pf, npf, lbs_weights, A, nj, nv, B, skin_out);
+    float* v_posed = (links && nlinks > 0) ? verts : vraw;      // scratch for the pose-blended rest vertices
+    hipLaunchKernelGGL(lwg_lbs_posed_kernel, dim3((nv3 + 63) / 64, (B + LWG_LBS_FB - 1) / LWG_LBS_FB), dim3(256), lds, stream,
+                       v_shaped, posedirs, pf, npf, nv3, B, v_posed);
+    hipLaunchKernelGGL(lwg_lbs_blend_kernel, dim3((nv + 255) / 256, B), dim3(256), (size_t)nj * 12 * sizeof(float), stream,
+                       v_posed, lbs_weights, A, nj, nv, skin_out);
     if (links && nlinks > 0) {
         hipError_t e = hipMemcpyAsync(verts, vraw, (size_t)B * nv3 * sizeof(float), hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return (int)e;

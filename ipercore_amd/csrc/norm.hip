@@ -44,20 +44,95 @@ __global__ __launch_bounds__(256) void lwg_in_stats_partial(const float* __restr
     }
 }
 
-__global__ void lwg_in_stats_final(const float* __restrict__ ws, int BC, int C, int nsplit, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC) return;
+// Vectorised pass 1 for C in {64, 128, 256} (every site of the generator): a lane owns 4 channels (16-byte loads), LPP =
+// C/4 lanes cover one pixel, the 256 threads cover PG = 256/LPP pixels per iteration, four iterations in flight.
+// grid (nsplit, B).  Same shifted-sum algebra; the PG partials are combined in a fixed order (deterministic).
+template <int LPP>
+__global__ __launch_bounds__(256) void lwg_in_stats_partial4(const float* __restrict__ x, int HW, int nsplit,
+                                                            float* __restrict__ ws) {
+    constexpr int C = LPP * 4, PG = 256 / LPP;
+    const int cq = threadIdx.x % LPP, pg = threadIdx.x / LPP;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    const floatx4* xb = reinterpret_cast<const floatx4*>(x + (size_t)b * HW * C) + cq;
+    floatx4 shift = {0.f, 0.f, 0.f, 0.f}, s1 = shift, s2 = shift;
+    int n = 0;
+    if (p0 < p1) shift = xb[(size_t)p0 * LPP];
+    int p = p0 + pg;
+    for (; p + 3 * PG < p1; p += 4 * PG) {
+        floatx4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xb[(size_t)(p + u * PG) * LPP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const floatx4 d = v[u] - shift;
+            s1 += d;
+            s2 += d * d;
+        }
+        n += 4;
+    }
+    for (; p < p1; p += PG) {
+        const floatx4 d = xb[(size_t)p * LPP] - shift;
+        s1 += d;
+        s2 += d * d;
+        ++n;
+    }
+    __shared__ floatx4 sh1[PG][LPP], sh2[PG][LPP];
+    __shared__ int shn[PG];
+    sh1[pg][cq] = s1;
+    sh2[pg][cq] = s2;
+    if (cq == 0) shn[pg] = n;
+    __syncthreads();
+    if (pg == 0) {
+        floatx4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+        float tn = 0.f;
+#pragma unroll
+        for (int g = 0; g < PG; ++g) { t1 += sh1[g][cq]; t2 += sh2[g][cq]; tn += (float)shn[g]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float mean = shift[k], m2 = 0.f;
+            if (tn > 0.f) { mean = shift[k] + t1[k] / tn; m2 = t2[k] - t1[k] * t1[k] / tn; }
+            float* o = ws + (((size_t)b * nsplit + split) * C + cq * 4 + k) * 3;
+            o[0] = tn; o[1] = mean; o[2] = m2 > 0.f ? m2 : 0.f;
+        }
+    }
+}
+
+// Pass 2: the nsplit partial records of 4 channels are fetched by 256 lanes at once (lane = (channel, split)), then one
+// lane per channel folds them in split order with Chan's update (sequential by construction, now on LDS latency).
+__global__ __launch_bounds__(256) void lwg_in_stats_final(const float* __restrict__ ws, int BC, int C, int nsplit, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ float sh[4][64][3];
+    const int ch = threadIdx.x >> 6, sp = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + ch;
     const int b = i / C, c = i - b * C;
+    if (i < BC && sp < nsplit && nsplit <= 64) {  // nsplit <= 64 on every call site; larger values take the direct path
+        const float* o = ws + (((size_t)b * nsplit + sp) * C + c) * 3;
+        sh[ch][sp][0] = o[0]; sh[ch][sp][1] = o[1]; sh[ch][sp][2] = o[2];
+    }
+    __syncthreads();
+    if (sp != 0 || i >= BC) return;
     float n = 0.f, mu = 0.f, m2 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 3;
-        const float nb = o[0];
-        if (nb <= 0.f) continue;
-        const float tot = n + nb, delta = o[1] - mu;
-        mu += delta * (nb / tot);
-        m2 += o[2] + delta * delta * (n * nb / tot);
-        n = tot;
+    if (nsplit <= 64) {
+        for (int s = 0; s < nsplit; ++s) {
+            const float nb = sh[ch][s][0];
+            if (nb <= 0.f) continue;
+            const float tot = n + nb, delta = sh[ch][s][1] - mu;
+            mu += delta * (nb / tot);
+            m2 += sh[ch][s][2] + delta * delta * (n * nb / tot);
+            n = tot;
+        }
+    } else {
+        for (int s = 0; s < nsplit; ++s) {
+            const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 3;
+            const float nb = o[0];
+            if (nb <= 0.f) continue;
+            const float tot = n + nb, delta = o[1] - mu;
+            mu += delta * (nb / tot);
+            m2 += o[2] + delta * delta * (n * nb / tot);
+            n = tot;
+        }
     }
     mean[i] = mu;
     rstd[i] = 1.0f / sqrtf(m2 / n + eps);
@@ -89,9 +164,16 @@ extern "C" int lwg_instnorm_stats_nhwc_f32(const float* x, int B, int HW, int C,
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !mean || !rstd || !ws || B <= 0 || HW <= 0 || C <= 0 || nsplit <= 0 || nsplit > 65535)
         return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(lwg_in_stats_partial, dim3((C + 63) / 64, nsplit, B), dim3(256), 0, stream, x, HW, C, nsplit, ws);
+    if (C == 64)
+        hipLaunchKernelGGL(lwg_in_stats_partial4<16>, dim3(nsplit, B), dim3(256), 0, stream, x, HW, nsplit, ws);
+    else if (C == 128)
+        hipLaunchKernelGGL(lwg_in_stats_partial4<32>, dim3(nsplit, B), dim3(256), 0, stream, x, HW, nsplit, ws);
+    else if (C == 256)
+        hipLaunchKernelGGL(lwg_in_stats_partial4<64>, dim3(nsplit, B), dim3(256), 0, stream, x, HW, nsplit, ws);
+    else
+        hipLaunchKernelGGL(lwg_in_stats_partial, dim3((C + 63) / 64, nsplit, B), dim3(256), 0, stream, x, HW, C, nsplit, ws);
     const int BC = B * C;
-    hipLaunchKernelGGL(lwg_in_stats_final, dim3((BC + 255) / 256), dim3(256), 0, stream, ws, BC, C, nsplit, eps, mean, rstd);
+    hipLaunchKernelGGL(lwg_in_stats_final, dim3((BC + 3) / 4), dim3(256), 0, stream, ws, BC, C, nsplit, eps, mean, rstd);
     return (int)hipGetLastError();
 }
 

@@ -6,10 +6,14 @@
 // back-face cull, three edge functions, clamped + renormalised weights, depth 1/sum(w/z), nearest wins, the
 // lowest face id wins exact depth ties (order-independent formulation of "first face wins").
 //
-// MI355X design: instead of the upstream per-pixel loop over all 13776 faces (3.6 G tests at 512^2), one
-// workgroup owns a 16x16 pixel tile; faces are streamed in chunks of 256, each lane tests one face's pixel
-// bounding box against the tile, survivors are compacted into LDS together with their 80-byte setup record,
-// and only those (a handful per chunk) are evaluated per pixel from LDS broadcasts.
+// MI355X design: instead of the upstream per-pixel loop over all 13776 faces (3.6 G tests at 512^2):
+//   1. setup (one lane per face): back-face cull, inverse matrix, conservative pixel bounding box, and the face id is
+//      appended to the list of every 64x64-pixel coarse bin its box touches (atomic cursor per bin; the order inside a
+//      list is irrelevant: the depth test is order-independent, ties go to the lowest face id);
+//   2. tiles: one workgroup owns a 16x16 pixel tile and streams only ITS BIN's list in chunks of 256; each lane tests
+//      one face's box against the tile, survivors are compacted into LDS with their 80-byte setup record; every pixel
+//      runs the three edge tests over the survivors (LDS broadcasts, 32 at a time into a bit mask) and then evaluates
+//      weights + depth only for the few faces that actually cover it.  Empty bins exit immediately.
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
@@ -40,56 +44,111 @@ __global__ void lwg_project_faces_kernel(const float* __restrict__ verts, const 
 }
 
 // ---- per-face setup: inverse matrix + conservative pixel bounding box ----
-__global__ void lwg_raster_setup_kernel(const float* __restrict__ faces_v, int total, int S,
-                                        float* __restrict__ rec, short4* __restrict__ bbox) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const float* f = faces_v + (size_t)i * 9;
-    float v[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = f[k];
+#define LWG_BIN 64  // coarse bin edge in pixels
+__global__ __launch_bounds__(256) void lwg_raster_setup_kernel(const float* __restrict__ faces_v, int nf, int S,
+                                                              float* __restrict__ rec, short4* __restrict__ bbox, int nbx,
+                                                              int* __restrict__ bin_count, int* __restrict__ bin_list) {
+    extern __shared__ int sbin[];  // [nbx*nbx] counts, then [nbx*nbx] global bases / cursors
+    const int nb2 = nbx * nbx;
+    int* scnt = sbin;
+    int* sbase = sbin + nb2;
+    for (int k = threadIdx.x; k < 2 * nb2; k += 256) sbin[k] = 0;
+    __syncthreads();
+    const int b = blockIdx.y, fid = blockIdx.x * 256 + threadIdx.x;
+    const bool live = fid < nf;
+    const size_t i = (size_t)b * nf + (live ? fid : 0);
     short4 bb = make_short4(32767, -32768, 32767, -32768);  // empty: overlaps no tile
-    float* r = rec + (size_t)i * LWG_REC_FLOATS;
-    const bool front = !((v[7] - v[1]) * (v[3] - v[0]) < (v[4] - v[1]) * (v[6] - v[0]));
-    float inv[9];
+    if (live) {
+        const float* f = faces_v + i * 9;
+        float v[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) inv[k] = 0.f;
-    if (front) {
-        float p[3][2];
-        const float fs = (float)S;
+        for (int k = 0; k < 9; ++k) v[k] = f[k];
+        float* r = rec + i * LWG_REC_FLOATS;
+        const bool front = !((v[7] - v[1]) * (v[3] - v[0]) < (v[4] - v[1]) * (v[6] - v[0]));
+        float inv[9];
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+        for (int k = 0; k < 9; ++k) inv[k] = 0.f;
+        if (front) {
+            float p[3][2];
+            const float fs = (float)S;
 #pragma unroll
-            for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (v[3 * n + d] * fs + fs - 1.0f);
-        const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
-        const float m[9] = {
-            p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+            for (int n = 0; n < 3; ++n)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) inv[k] = m[k] / den;
-        const float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
-        const float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymax = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
-        const float lim = (float)S + 1.f;
-        // one pixel of margin on every side: the inside test is evaluated in fp32 on normalised coordinates
-        if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax) {
-            const int x0 = (int)fmaxf(floorf(xmin) - 1.f, -1.f), x1 = (int)fminf(ceilf(xmax) + 1.f, lim);
-            const int y0 = (int)fmaxf(floorf(ymin) - 1.f, -1.f), y1 = (int)fminf(ceilf(ymax) + 1.f, lim);
-            if (xmax >= -2.f && ymax >= -2.f && xmin <= lim && ymin <= lim)
-                bb = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
+                for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (v[3 * n + d] * fs + fs - 1.0f);
+            const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
+            const float m[9] = {
+                p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) inv[k] = m[k] / den;
+            const float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
+            const float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymax = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
+            const float lim = (float)S + 1.f;
+            // one pixel of margin on every side: the inside test is evaluated in fp32 on normalised coordinates
+            if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax) {
+                const int x0 = (int)fmaxf(floorf(xmin) - 1.f, -1.f), x1 = (int)fminf(ceilf(xmax) + 1.f, lim);
+                const int y0 = (int)fmaxf(floorf(ymin) - 1.f, -1.f), y1 = (int)fminf(ceilf(ymax) + 1.f, lim);
+                if (xmax >= -2.f && ymax >= -2.f && xmin <= lim && ymin <= lim)
+                    bb = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
+            }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { r[k] = v[k]; r[9 + k] = inv[k]; }
-    r[18] = 0.f; r[19] = 0.f;
-    bbox[i] = bb;
+        for (int k = 0; k < 9; ++k) { r[k] = v[k]; r[9 + k] = inv[k]; }
+        r[18] = 0.f; r[19] = 0.f;
+        bbox[i] = bb;
+    }
+    // coarse bins touched by the box (bins are in image rows: row = S-1-y).  Three block-wide phases so that a bin's
+    // global cursor is bumped once per workgroup: count in LDS, reserve, scatter.
+    const bool inside = bb.x <= bb.y && bb.y >= 0 && bb.x <= S - 1 && bb.w >= 0 && bb.z <= S - 1;
+    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+    if (inside) {
+        bx0 = max(0, (int)bb.x) / LWG_BIN; bx1 = min(S - 1, (int)bb.y) / LWG_BIN;
+        by0 = (S - 1 - min(S - 1, (int)bb.w)) / LWG_BIN; by1 = (S - 1 - max(0, (int)bb.z)) / LWG_BIN;
+    }
+    for (int by = by0; by <= by1; ++by)
+        for (int bx = bx0; bx <= bx1; ++bx) atomicAdd(&scnt[by * nbx + bx], 1);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb2; k += 256) {
+        const int c = scnt[k];
+        if (c > 0) sbase[k] = atomicAdd(&bin_count[b * nb2 + k], c);
+        scnt[k] = 0;  // becomes the in-block cursor
+    }
+    __syncthreads();
+    for (int by = by0; by <= by1; ++by)
+        for (int bx = bx0; bx <= bx1; ++bx) {
+            const int k = by * nbx + bx;
+            const int slot = sbase[k] + atomicAdd(&scnt[k], 1);
+            bin_list[(size_t)(b * nb2 + k) * nf + slot] = fid;
+        }
 }
 
 __device__ __forceinline__ float lwg_clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
+// One candidate face at one pixel: the oracle's arithmetic in the oracle's order.  Returns false if the pixel centre is
+// outside the triangle or the depth is outside (near, far) (NaNs propagate to "not selected" exactly as in the oracle).
+__device__ __forceinline__ bool lwg_raster_eval(const float* f, float xp, float yp, float fxi, float fyi, float near, float far,
+                                                float& w0, float& w1, float& w2, float& zp) {
+    const bool o0 = (yp - f[1]) * (f[3] - f[0]) < (xp - f[0]) * (f[4] - f[1]);
+    const bool o1 = (yp - f[4]) * (f[6] - f[3]) < (xp - f[3]) * (f[7] - f[4]);
+    const bool o2 = (yp - f[7]) * (f[0] - f[6]) < (xp - f[6]) * (f[1] - f[7]);
+    if (o0 | o1 | o2) return false;
+    const float* m = f + 9;
+    w0 = m[0] * fxi + m[1] * fyi + m[2];
+    w1 = m[3] * fxi + m[4] * fyi + m[5];
+    w2 = m[6] * fxi + m[7] * fyi + m[8];
+    w0 = lwg_clamp01(w0); w1 = lwg_clamp01(w1); w2 = lwg_clamp01(w2);
+    const float ws = w0 + w1 + w2;
+    w0 = w0 / ws; w1 = w1 / ws; w2 = w2 / ws;
+    zp = 1.0f / (w0 / f[2] + w1 / f[5] + w2 / f[8]);
+    return !(zp <= near || far <= zp);
+}
+
 #define LWG_RCHUNK 256
 __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __restrict__ rec, const short4* __restrict__ bbox,
-                                                              int nf, int S, float near, float far,
+                                                              int nf, int S, float near, float far, int nbx,
+                                                              const int* __restrict__ bin_count,
+                                                              const int* __restrict__ bin_list,
                                                               int* __restrict__ fim, float* __restrict__ wim) {
     __shared__ __attribute__((aligned(16))) float srec[LWG_RCHUNK][LWG_REC_FLOATS];
     __shared__ int sid[LWG_RCHUNK];
@@ -107,15 +166,21 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     const float* recb = rec + (size_t)b * nf * LWG_REC_FLOATS;
     const short4* bbb = bbox + (size_t)b * nf;
 
+    // nearest depth wins, exact ties go to the lowest face id: the minimum of (depth, id) - independent of the order in
+    // which candidates are visited
     float zmin = far;
     int best = -1;
     float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f;
 
-    for (int base = 0; base < nf; base += LWG_RCHUNK) {
+    const int nb2 = nbx * nbx;
+    const int bin = b * nb2 + ((blockIdx.y * 16) / LWG_BIN) * nbx + (blockIdx.x * 16) / LWG_BIN;
+    const int nbin = bin_count[bin];
+    const int* blist = bin_list + (size_t)bin * nf;
+    for (int base = 0; base < nbin; base += LWG_RCHUNK) {
         if (tid == 0) scount = 0;
         __syncthreads();
-        const int fi = base + tid;
-        if (fi < nf) {
+        if (base + tid < nbin) {
+            const int fi = blist[base + tid];
             const short4 bb = bbb[fi];
             if (bb.x <= tx1 && bb.y >= tx0 && bb.z <= ty1 && bb.w >= ty0) {
                 const int slot = atomicAdd(&scount, 1);
@@ -128,24 +193,40 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
         }
         __syncthreads();
         const int n = scount;
-        for (int e = 0; e < n; ++e) {
-            const float* f = &srec[e][0];
-            if (((yp - f[1]) * (f[3] - f[0]) < (xp - f[0]) * (f[4] - f[1])) ||
-                ((yp - f[4]) * (f[6] - f[3]) < (xp - f[3]) * (f[7] - f[4])) ||
-                ((yp - f[7]) * (f[0] - f[6]) < (xp - f[6]) * (f[1] - f[7])))
-                continue;
-            const float* m = f + 9;
-            float w0 = m[0] * fxi + m[1] * fyi + m[2];
-            float w1 = m[3] * fxi + m[4] * fyi + m[5];
-            float w2 = m[6] * fxi + m[7] * fyi + m[8];
-            w0 = lwg_clamp01(w0); w1 = lwg_clamp01(w1); w2 = lwg_clamp01(w2);
-            const float ws = w0 + w1 + w2;
-            w0 = w0 / ws; w1 = w1 / ws; w2 = w2 / ws;
-            const float zp = 1.0f / (w0 / f[2] + w1 / f[5] + w2 / f[8]);
-            if (zp <= near || far <= zp) continue;
-            const int fid = sid[e];
-            if (zp < zmin || (zp == zmin && best >= 0 && fid < best)) {
-                zmin = zp; best = fid; wb0 = w0; wb1 = w1; wb2 = w2;
+        // Coverage first, arithmetic second.  A dense tile (hands, face) has hundreds of candidates but a pixel lies inside
+        // only a few of them; if the full evaluation (7 IEEE divisions) sat in the candidate loop, every wave would pay it
+        // for every candidate that covers ANY of its 64 pixels.  So: 32 candidates at a time, the three edge tests only
+        // (LDS broadcasts) into a per-pixel bit mask, then each pixel evaluates just its own hits.
+        for (int e0 = 0; e0 < n; e0 += 32) {
+            const int m = min(32, n - e0);
+            unsigned word = 0u;
+            const int m4 = (m + 3) & ~3;
+#pragma unroll 1
+            for (int j = 0; j < m4; j += 4) {
+                floatx4 q[4][3];  // the 12 LDS broadcasts of four candidates are issued before any is used
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const floatx4* rp = reinterpret_cast<const floatx4*>(&srec[min(e0 + j + u, n - 1)][0]);
+                    q[u][0] = rp[0]; q[u][1] = rp[1]; q[u][2] = rp[2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float f0 = q[u][0][0], f1 = q[u][0][1], f3 = q[u][0][3], f4 = q[u][1][0], f6 = q[u][1][2], f7 = q[u][1][3];
+                    const bool o0 = (yp - f1) * (f3 - f0) < (xp - f0) * (f4 - f1);
+                    const bool o1 = (yp - f4) * (f6 - f3) < (xp - f3) * (f7 - f4);
+                    const bool o2 = (yp - f7) * (f0 - f6) < (xp - f6) * (f1 - f7);
+                    word |= (unsigned)(!(o0 | o1 | o2) && (j + u < m)) << (j + u);
+                }
+            }
+            while (word) {
+                const int e = e0 + __ffs(word) - 1;
+                word &= word - 1;
+                float w0, w1, w2, zp;
+                if (!lwg_raster_eval(&srec[e][0], xp, yp, fxi, fyi, near, far, w0, w1, w2, zp)) continue;
+                const int fid = sid[e];
+                if (zp < zmin || (zp == zmin && best >= 0 && fid < best)) {
+                    zmin = zp; best = fid; wb0 = w0; wb1 = w1; wb2 = w2;
+                }
             }
         }
         __syncthreads();
@@ -157,9 +238,16 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     }
 }
 
-extern "C" size_t lwg_rasterize_ws_bytes(int B, int nf) {
-    return (size_t)B * nf * (LWG_REC_FLOATS * sizeof(float) + sizeof(short4));
+// scratch: setup records + boxes, then per-bin cursors and face lists (worst case every face in every bin;
+// S <= LWG_MAX_BINS_EDGE * 64 = 2048).
+#define LWG_MAX_BINS_EDGE 32
+static size_t lwg_raster_rec_bytes(int B, int nf) { return (size_t)B * nf * (LWG_REC_FLOATS * sizeof(float) + sizeof(short4)); }
+extern "C" size_t lwg_rasterize_ws_bytes(int B, int nf, int S) {
+    const int nbx = (S + LWG_BIN - 1) / LWG_BIN;
+    const size_t bins = (size_t)B * nbx * nbx;
+    return lwg_raster_rec_bytes(B, nf) + bins * sizeof(int) + bins * (size_t)nf * sizeof(int);
 }
+
 
 extern "C" int lwg_project_faces_f32(const float* verts, const float* cam, const int32_t* faces, int B, int nv, int nf,
                                      float eye_dist, float* faces_v, float* f2pts, lwg_stream_t stream_) {
@@ -175,13 +263,20 @@ extern "C" int lwg_project_faces_f32(const float* verts, const float* cam, const
 extern "C" int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, int S, float near, float far, int32_t* fim,
                                          float* wim, void* ws, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!faces_v || !fim || !wim || !ws || B <= 0 || nf <= 0 || S <= 0 || S > 16384 || B > 65535) return (int)hipErrorInvalidValue;
+    if (!faces_v || !fim || !wim || !ws || B <= 0 || nf <= 0 || S <= 0 || S > LWG_MAX_BINS_EDGE * LWG_BIN || B > 65535)
+        return (int)hipErrorInvalidValue;
     float* rec = reinterpret_cast<float*>(ws);
     short4* bbox = reinterpret_cast<short4*>(rec + (size_t)B * nf * LWG_REC_FLOATS);
-    const int total = B * nf;
-    hipLaunchKernelGGL(lwg_raster_setup_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, faces_v, total, S, rec, bbox);
+    const int nbx = (S + LWG_BIN - 1) / LWG_BIN;
+    const size_t bins = (size_t)B * nbx * nbx;
+    int* bin_count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + lwg_raster_rec_bytes(B, nf));
+    int* bin_list = bin_count + bins;
+    hipError_t e = hipMemsetAsync(bin_count, 0, bins * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lwg_raster_setup_kernel, dim3((nf + 255) / 256, B), dim3(256), (size_t)2 * nbx * nbx * sizeof(int), stream,
+                       faces_v, nf, S, rec, bbox, nbx, bin_count, bin_list);
     const int tiles = (S + 15) / 16;
-    hipLaunchKernelGGL(lwg_raster_tiles_kernel, dim3(tiles, tiles, B), dim3(256), 0, stream, rec, bbox, nf, S, near, far,
-                       fim, wim);
+    hipLaunchKernelGGL(lwg_raster_tiles_kernel, dim3(tiles, tiles, B), dim3(256), 0, stream, rec, bbox, nf, S, near, far, nbx,
+                       bin_count, bin_list, fim, wim);
     return (int)hipGetLastError();
 }

@@ -210,7 +210,7 @@ class AttentionLWBGenerator(nn.Module):
         att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], Tst, torch.empty_like(tsf_x), src_batched=batched)
         mean = tsf_x.new_empty(B, C)
         rstd = tsf_x.new_empty(B, C)
-        nsplit = max(1, min(64, (h * w) // 256))
+        nsplit = max(1, min(64, (h * w) // 64))
         ws = scratch.get(B * C * nsplit * 3, tsf_x.device)
         ops.instnorm_stats(tsf_x, mean, rstd, ws, eps=1e-5, nsplit=nsplit)
         actv = ops.conv2d(att, st["shared"], tsf_x.new_empty(B, h, w, st["shared"].N), act=ops.ACT_RELU)
@@ -262,7 +262,7 @@ class AttentionLWBGenerator(nn.Module):
         def norm(t, act, res=None):
             B, h, w, C = t.shape
             mean, rstd = t.new_empty(B, C), t.new_empty(B, C)
-            nsplit = max(1, min(64, (h * w) // 256))
+            nsplit = max(1, min(64, (h * w) // 64))
             ops.instnorm_stats(t, mean, rstd, scratch.get(B * C * nsplit * 3, t.device), eps=1e-5, nsplit=nsplit)
             return ops.instnorm_apply(t, mean, rstd, torch.empty_like(t), act=act, res=res)
 

@@ -94,7 +94,7 @@ def instnorm_stats(x, mean, rstd, ws, eps=1e-5, nsplit=None):
     B, H, W, C = x.shape
     HW = H * W
     if nsplit is None:
-        nsplit = max(1, min(64, HW // 256))
+        nsplit = max(1, min(64, HW // 64))
     assert ws.numel() >= B * C * nsplit * 3
     _lib.check(_lib.lib().lwg_instnorm_stats_nhwc_f32(_ptr(x), B, HW, C, eps, _ptr(mean), _ptr(rstd), _ptr(ws), nsplit,
                                                        _stream()), "lwg_instnorm_stats_nhwc_f32")
@@ -134,7 +134,7 @@ def rasterize_fim_wim(faces_v, image_size, near=0.1, far=100.0):
     dev = faces_v.device
     fim = torch.empty(B, S, S, device=dev, dtype=torch.int32)
     wim = torch.empty(B, S, S, 3, device=dev, dtype=torch.float32)
-    ws = torch.empty(_lib.lib().lwg_rasterize_ws_bytes(B, nf), device=dev, dtype=torch.uint8)
+    ws = torch.empty(_lib.lib().lwg_rasterize_ws_bytes(B, nf, S), device=dev, dtype=torch.uint8)
     _lib.check(_lib.lib().lwg_rasterize_fim_wim_f32(_ptr(faces_v), B, nf, S, near, far, _ptr(fim, torch.int32), _ptr(wim),
                                                      ws.data_ptr(), _stream()), "lwg_rasterize_fim_wim_f32")
     return fim, wim
