@@ -56,8 +56,23 @@ class ConvTimer:
             self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn))
 
     def result(self):
-        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
-        return ms, self.flops, len(self.pairs)
+        """(busy ms, flops, launches, mean launch ms).  busy = length of the UNION of the launches' [start, stop] intervals
+        on the device clock: with one stream that is the sum of the durations; with several streams, launches of
+        different streams overlap in time and share the machine, and flops / busy is the aggregate rate."""
+        if not self.pairs:
+            return 0.0, 0.0, 0, 0.0
+        base = self.pairs[0][0]
+        iv = sorted((base.elapsed_time(a), base.elapsed_time(b)) for a, b in self.pairs)
+        busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s0, e0 in iv[1:]:
+            if s0 > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        busy += cur_e - cur_s
+        mean = sum(e0 - s0 for s0, e0 in iv) / len(iv)
+        return busy, self.flops, len(self.pairs), mean
 
     def breakdown(self):
         """Per distinct conv shape: launches, total ms, achieved TFLOP/s (algorithmic flops / event time)."""
@@ -114,6 +129,33 @@ def with_output(im, smpls, FB, n_frames, t_base):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def pipelined(step, W, K, FB, n_streams, dev):
+    """Reported separately: the same K steps with independent frame batches in flight on several HIP streams, so that one
+    batch's launch gaps, kernel tails and HBM-bound kernels overlap another batch's MFMA work.  Not the headline value (the
+    per-kernel roofline accounting above needs launches that own the machine)."""
+    from ipercore_amd import ops
+    hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    try:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        for i in range(W):
+            with torch.cuda.stream(streams[i % n_streams]):
+                step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = []
+        for i in range(W, W + K):
+            with torch.cuda.stream(streams[i % n_streams]):
+                outs.append(step(i))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert all(torch.isfinite(o).all() for o in outs[-n_streams:])
+        return {"value": round(K * FB / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_step": round(dt / K * 1e3, 3)}
+    finally:
+        ops.CONV_HOOK = hook
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +164,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frame-batch", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--streams", type=int, default=1, help="frame batches in flight on separate HIP streams (see DESIGN.md 5)")
+    ap.add_argument("--pipelined-streams", type=int, default=3,
+                    help="extra (separately reported) measurement with this many frame batches in flight; 0/1 = skip")
     ap.add_argument("--no-conv-events", action="store_true")
     ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
@@ -162,11 +207,26 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    if streams:
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        for i in range(W):          # warm the side streams too
+            with torch.cuda.stream(streams[i % len(streams)]):
+                step(i)
+        torch.cuda.synchronize()
     timer.enabled = True
     outs = []
     t0 = time.perf_counter()
     for i in range(W, W + K):
-        outs.append(step(i))
+        if streams:
+            with torch.cuda.stream(streams[i % len(streams)]):
+                outs.append(step(i))
+        else:
+            outs.append(step(i))
+    if streams:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
     local = torch.cat(outs, dim=0)
     video = sharding.all_gather_frames(local, K * FB * world) if world > 1 else local
     torch.cuda.synchronize()
@@ -183,7 +243,7 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
-        conv_ms, conv_flops, n_launch = timer.result()
+        conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
         frames = K * FB * world
         line = {
             "metric": "synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}",
@@ -193,6 +253,7 @@ def main():
             "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])",
                        "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
                        "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
+                       "batches_in_flight": args.streams,
                        "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},
         }
         if n_launch:
@@ -208,13 +269,15 @@ def main():
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
                                 "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
-                                "launches": n_launch, "avg_launch_us": round(conv_ms * 1e3 / n_launch, 2),
+                                "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
         if args.conv_breakdown and n_launch:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "conv_breakdown.json"), "w") as fp:
                 json.dump(timer.breakdown(), fp, indent=1)
+        if args.pipelined_streams > 1 and args.streams == 1 and world == 1:
+            line["pipelined"] = pipelined(step, W, K, FB, args.pipelined_streams, dev)
         if args.output_frames > 0 and world == 1:
             line["with_output"] = with_output(im, mine, FB, args.output_frames, lo)
         if args.cpu_frames > 0:

@@ -49,7 +49,8 @@ typedef struct LwgConvArgs {
     int stride;        /* input sample position = (oy*stride + dy[tap], ox*stride + dx[tap]); zero outside */
     int ntaps;         /* number of kernel taps (<= LWG_MAX_TAPS) */
     int cshift;        /* log2(Cin/4) when Cin < 32, else unused */
-    const float* w;    /* packed weights [ceil(ntaps*Cin/32)*8][N][4]: k = tap*Cin + c -> w[k/4][n][k%4] */
+    const float* w;    /* packed weights [ceil(ntaps*Cin/32)*8][N][4]: w[k/4][n][k%4] with
+                          k = ((c/32)*ntaps + tap)*32 + c%32 when Cin % 32 == 0, k = tap*Cin + c when Cin < 32 */
     int N;             /* GEMM columns (Cout, or 2*Cout gamma|beta interleaved by 32 for LWG_EPI_SPADE) */
     const float* bias; /* [N] or NULL */
     float* y;          /* output NHWC (B,YH,YW,YC); row (b,oy,ox) -> pixel (oy*omul+ooy, ox*omul+oox) */

@@ -9,7 +9,10 @@
 //     from the NHWC activation tensor, 128 contiguous bytes per pixel.  Loads are raw buffer loads: a
 //     padding pixel gets an out-of-range offset and the hardware returns zeros (no branches, no exec masks).
 //   * Wp is the weight panel pre-packed on the host as [K/4][N][4] so a lane's 16-byte load is
-//     already the LDS image (k-quads are what one lane feeds to four consecutive MFMAs).
+//     already the LDS image (k-quads are what one lane feeds to four consecutive MFMAs).  K is ordered
+//     channel-chunk major, tap minor (k = ((c/32)*ntaps + tap)*32 + c%32; plain tap*Cin + c when Cin < 32): the
+//     taps of one 32-channel chunk are consecutive K-steps, so an activation chunk is fetched from HBM /
+//     Infinity Cache once and its shifted re-reads hit the XCD's L2.
 //   * a transposed conv (k4 s2 p1) is four such GEMMs (one per output parity) with 2x2 taps each.
 //
 // Pipeline (one wave must keep its SIMD's matrix pipe busy on its own - the two co-resident workgroups of a
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_STAGE;
-    int* taptab = reinterpret_cast<int*>(smem + 2 * A_STAGE + 2 * B_STAGE);  // [LWG_MAX_TAPS] dy*W+dx, then packed dy|dx
+    int* taptab = reinterpret_cast<int*>(smem + 2 * A_STAGE + 2 * B_STAGE);  // [3][LWG_MAX_TAPS]: tap byte offset in x0, in x1, packed dy|dx
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -83,13 +86,14 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     }
     if (tid < a.ntaps) {
         const int dy = a.dy[tid], dx = a.dx[tid];
-        taptab[tid] = dy * a.W + dx;
-        taptab[LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
+        taptab[tid] = (dy * a.W + dx) * a.C0 * 4;
+        taptab[LWG_MAX_TAPS + tid] = (dy * a.W + dx) * a.C1 * 4;
+        taptab[2 * LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
     }
     __syncthreads();  // taptab visible
     if (!SMALLC) {
         for (int tp = 0; tp < a.ntaps; ++tp) {
-            const int packed = taptab[LWG_MAX_TAPS + tp];
+            const int packed = taptab[2 * LWG_MAX_TAPS + tp];
             const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -106,13 +110,18 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     const int nsteps = (K4 + 7) >> 3;
     const unsigned wbytes = (unsigned)nsteps * 8u * a.N * 16u;
 
-    // ---- loader state: describes the K-step whose loads are issued next ----
+    // ---- loader state: describes the K-step whose loads are issued next.  K runs channel-chunk major, tap minor
+    // (k = ((c / 32) * ntaps + tap) * 32 + c % 32): consecutive steps gather the SAME 32 channels at neighbouring
+    // pixels, so the 9 (or 4, 49) shifted reads of an activation chunk are L2 hits instead of one trip to the
+    // Infinity Cache / HBM per tap.
     int ld_tap = 0, ld_cc = 0;     // tap and channel offset (concat space) of that step
+    int ld_use1 = 0;               // the chunk comes from x1 (skip concat)
     unsigned ld_soffA = 0;         // scalar byte offset of the channel chunk inside the current source
     unsigned ld_soffB = 0;         // scalar byte offset of the weight-panel step
     const float* ld_src = a.x0;
     unsigned ld_bytes = bytes0;
-    unsigned vbase[PA];            // per-row byte offset for the current (tap, source) segment, or LWG_OOB_OFFSET
+    unsigned pixb[PA];             // byte offset of (row p's pixel, channel quad kq) in the current source
+    unsigned vbase[PA];            // pixb + tap offset, or LWG_OOB_OFFSET where the tap leaves the image
     unsigned wvoff[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -121,32 +130,30 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         wvoff[p] = ((unsigned)kqb * a.N + n_base + n) * 16u;
     }
 
-    auto segment = [&]() {  // recompute vbase for (ld_tap, source of ld_cc); uniform, runs once per tap/source change
-        const bool use1 = ld_cc >= a.C0;
-        const int cs = use1 ? a.C1 : a.C0;
-        ld_src = use1 ? a.x1 : a.x0;
-        ld_bytes = use1 ? bytes1 : bytes0;
-        const int toff = taptab[ld_tap];
+    auto source = [&]() {  // (re)bind the loader to the source tensor of channel ld_cc; runs at most twice per tile
+        ld_use1 = ld_cc >= a.C0;
+        const int cs = ld_use1 ? a.C1 : a.C0;
+        ld_src = ld_use1 ? a.x1 : a.x0;
+        ld_bytes = ld_use1 ? bytes1 : bytes0;
+        ld_soffA = (unsigned)(ld_cc - (ld_use1 ? a.C0 : 0)) * 4u;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const bool ok = (vmask[p] >> ld_tap) & 1ull;
-            const unsigned off = ((unsigned)(pixlin[p] + toff) * (unsigned)cs + (unsigned)kq * 4u) * 4u;
-            vbase[p] = ok ? off : LWG_OOB_OFFSET;
-        }
-        ld_soffA = (unsigned)(ld_cc - (use1 ? a.C0 : 0)) * 4u;
+        for (int p = 0; p < PA; ++p) pixb[p] = ((unsigned)pixlin[p] * (unsigned)cs + (unsigned)kq * 4u) * 4u;
     };
-    auto advance = [&]() {  // move the loader state one K-step forward
+    auto tap_row = [&](int p, int toff) {  // 5 VALU: issued one row at a time in the shadow of the MFMAs
+        const bool ok = (vmask[p] >> ld_tap) & 1ull;
+        vbase[p] = ok ? pixb[p] + (unsigned)toff : LWG_OOB_OFFSET;
+    };
+    auto advance_scalar = [&]() {  // move the loader state one K-step forward (uniform); returns the tap byte offset
         ld_soffB += (unsigned)a.N * 128u;
-        if (SMALLC) return;
-        ld_cc += 32;
-        ld_soffA += 128u;
-        if (ld_cc == Cin) {
-            ld_cc = 0;
-            ++ld_tap;
-            segment();
-        } else if (ld_cc == a.C0) {
-            segment();
+        if (!SMALLC) {
+            if (++ld_tap == a.ntaps) {
+                ld_tap = 0;
+                ld_cc += 32;
+                ld_soffA += 128u;
+                if (ld_cc == a.C0 && a.C1 > 0) source();
+            }
         }
+        return SMALLC ? 0 : taptab[ld_use1 * LWG_MAX_TAPS + ld_tap];
     };
 
     floatx4 ra[PA], rb[PB];
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
             const int tap = k4 >> a.cshift;
             const int c = (k4 & ((1 << a.cshift) - 1)) * 4;
             const bool tap_ok = tap < a.ntaps;
-            const int packed = taptab[LWG_MAX_TAPS + (tap_ok ? tap : 0)];
+            const int packed = taptab[2 * LWG_MAX_TAPS + (tap_ok ? tap : 0)];
             const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -221,9 +228,21 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     };
 
     // ---- prologue: stage 0 ----
-    if (!SMALLC) segment();
+    if (!SMALLC) {
+        source();
+        const int toff0 = taptab[0];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) tap_row(p, toff0);
+    }
     load_a(0);
     load_b();
+    {   // loader state -> step 1
+        const int toff1 = advance_scalar();
+        if (!SMALLC) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) tap_row(p, toff1);
+        }
+    }
     lstore(0);
     __syncthreads();
     read_frags(0, 0, 0);
@@ -231,8 +250,6 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     auto step = [&](auto cur_c, auto next_c, int t) {
         constexpr int CUR = decltype(cur_c)::value;
         constexpr bool NEXT = decltype(next_c)::value;
-        if (NEXT) advance();
-        LWG_SB();
         // phase 0: fragments of g=1 in flight, loads of step t+1 issued between the MFMAs
         read_frags(CUR, 1, 1);
         LWG_SB();
@@ -247,14 +264,22 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         mfma_e(0, 2);
         mfma_e(0, 3);
         LWG_SB();
-        // phase 1
+        // phase 1: the loader state moves on to step t+2 (the offsets of its tap: one row per MFMA group)
         read_frags(CUR, 2, 0);
         LWG_SB();
-        mfma_e(1, 0);
-        mfma_e(1, 1);
-        mfma_e(1, 2);
-        mfma_e(1, 3);
+        int toff = 0;
+        if (NEXT) toff = advance_scalar();
         LWG_SB();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mfma_e(1, e);
+            LWG_SB();
+            if (NEXT && !SMALLC) {
+#pragma unroll
+                for (int p = e * PA / 4; p < (e + 1) * PA / 4; ++p) tap_row(p, toff);
+            }
+            LWG_SB();
+        }
         // phase 2
         read_frags(CUR, 3, 1);
         LWG_SB();
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
 static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr size_t lds = (size_t)2 * 8 * ((BM + 1) * 4 + BN * 4) * sizeof(float) + 2 * LWG_MAX_TAPS * sizeof(int);
+    constexpr size_t lds = (size_t)2 * 8 * ((BM + 1) * 4 + BN * 4) * sizeof(float) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_kernel<WAVES_M, WAVES_N, TM, TN, EPI, SMALLC>;
     static bool attr_done = false;
     if (!attr_done) {

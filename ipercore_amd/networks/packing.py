@@ -1,7 +1,8 @@
 """Weight re-layout for the HIP kernels (done once per weight load, on whatever device the weights live).
 
-The implicit-GEMM kernel (csrc/conv_igemm.hip) wants the GEMM B panel as ``[K/4][N][4]`` fp32 with
-``k = tap * Cin + c`` and K padded to a multiple of 32, so one lane's 16-byte load is four consecutive k of
+The implicit-GEMM kernel (csrc/conv_igemm.hip) wants the GEMM B panel as ``[K/4][N][4]`` fp32, K ordered
+channel-chunk major / tap minor (``k = ((c // 32) * ntaps + tap) * 32 + c % 32``; ``tap * Cin + c`` for the
+small-Cin first layers) and padded to a multiple of 32, so one lane's 16-byte load is four consecutive k of
 one output channel.  ``state_dict`` tensors keep PyTorch's OIHW / IOHW layouts (checkpoint compatibility);
 only these packed copies are what the kernels read.
 """
@@ -10,9 +11,13 @@ import torch
 from ..ops import ConvSpec
 
 
-def _panel(wk):
-    """(K, N) -> contiguous (ceil32(K)/4, N, 4)."""
+def _panel(wk, ntaps=None, cin=None):
+    """(K, N) with k = tap * Cin + c -> contiguous (ceil32(K)/4, N, 4) in the kernel's K order: when Cin % 32 == 0 the
+    32-channel chunks are the outer index and the taps the inner one (k' = ((c // 32) * ntaps + tap) * 32 + c % 32)."""
     K, N = wk.shape
+    if ntaps is not None and cin % 32 == 0:
+        assert K == ntaps * cin
+        wk = wk.view(ntaps, cin // 32, 32, N).permute(1, 0, 2, 3).reshape(K, N)
     Kp = (K + 31) // 32 * 32
     if Kp != K:
         wk = torch.cat([wk, wk.new_zeros(Kp - K, N)], dim=0)
@@ -39,7 +44,7 @@ def pack_conv(weight, bias=None, stride=1, pad=None, cin_pad=None, n_pad=None):
     w = weight.new_zeros(kh * kw, Cp, Np)
     w[:, :Cin, :N] = weight.permute(2, 3, 1, 0).reshape(kh * kw, Cin, N)
     taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
-    return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np)), _pad_vec(bias, Np), Np, Cp, taps, stride=stride,
+    return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np), kh * kw, Cp), _pad_vec(bias, Np), Np, Cp, taps, stride=stride,
                     algo_kn=kh * kw * Cin * N)
 
 
@@ -65,7 +70,7 @@ def pack_conv_transpose(weight, bias=None, n_pad=None):
                     m[:, :N] = weight[:, :, ky, kx]
                     mats.append(m)
             wk = torch.stack(mats, dim=0).reshape(len(taps) * Cin, Np)
-            specs.append(ConvSpec(_panel(wk), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px,
+            specs.append(ConvSpec(_panel(wk, len(taps), Cin), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px,
                                   algo_kn=len(taps) * Cin * N))
     return specs
 

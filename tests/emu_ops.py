@@ -16,9 +16,14 @@ from ipercore_amd import ops as real_ops
 ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
 
 
-def _unpanel(w):
+def _unpanel(w, ntaps, cin):
+    """Packed panel [K/4][N][4] (include/lwg_hip.h: chunk-major / tap-minor K when Cin % 32 == 0) -> (K, N) with the
+    logical k = tap * Cin + c."""
     K4, N, _ = w.shape
-    return w.permute(0, 2, 1).reshape(K4 * 4, N)
+    wk = w.permute(0, 2, 1).reshape(K4 * 4, N)
+    if cin % 32 == 0:
+        wk = wk[:ntaps * cin].view(cin // 32, ntaps, 32, N).permute(1, 0, 2, 3).reshape(ntaps * cin, N)
+    return wk
 
 
 def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0):
@@ -30,7 +35,7 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
         OH, OW = (YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul)
     else:
         OH, OW = out_hw
-    Wk = _unpanel(spec.w)
+    Wk = _unpanel(spec.w, spec.ntaps, Cin)
     assert Wk.shape[0] >= spec.ntaps * Cin and Wk.shape[1] == spec.N
     oy = torch.arange(OH) * spec.stride
     ox = torch.arange(OW) * spec.stride
