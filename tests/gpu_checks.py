@@ -347,6 +347,11 @@ def _pipeline(S, nf, nres, bgf, n_frames, frame_batch, frames=None):
     single = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=1)).cpu()
     m["batch_vs_single_max"] = (single - got).abs().max().item()
     assert m["batch_vs_single_max"] == 0.0, "batched and per-frame results differ"
+    # ... and neither must running the batches on several HIP streams
+    im3 = pu.make_imitator(case, frame_batch=1)
+    im3.streams = 3
+    m["streams_vs_single_max"] = (pu.run_hip(case, imitator=im3).cpu() - got).abs().max().item()
+    assert m["streams_vs_single_max"] == 0.0, "multi-stream and single-stream results differ"
     return m
 
 
