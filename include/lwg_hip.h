@@ -68,6 +68,17 @@ typedef struct LwgConvArgs {
 
 int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
 
+/* Backward of the same convolutions (personalization step, tools/trainers/lwg_trainer.py:326-352: loss.backward()
+ * through torch.nn.Conv2d / ConvTranspose2d).
+ * lwg_conv2d_wgrad_nhwc_f32: dW[K,N] = A[M,K]^T dY[M,N] on the matrix cores.  `args` is the FORWARD launch description
+ *   (x0/x1, taps, stride, OH/OW/M, N and the output mapping; args->y/w/bias/epi are ignored); dy has the layout of the
+ *   forward output; dw is (ntaps*Cin, N) row-major with K in the forward panel's order; ws: lwg_conv2d_wgrad_ws_floats().
+ * The data gradient is lwg_conv2d_nhwc_f32 itself on dy with a transposed panel (ipercore_amd/networks/packing.py
+ *   pack_dgrad_*); lwg_colsum_nhwc_f32 gives bias gradients (out[c] = sum over rows of x (rows, C); ws: 64*C floats). */
+size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M);
+int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* args, const float* dy, float* dw, float* ws, lwg_stream_t stream);
+int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.
  * Replaces nn.InstanceNorm2d at attlwb_spade_resunet.py:62,:83 and bg_inpaintor.py:14,17,33,40,51.

@@ -1,0 +1,255 @@
+// Weight gradient of the NHWC fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Backward of every torch.nn.Conv2d / ConvTranspose2d of the generator and discriminator in the personalization step
+// (reference iPERCore/tools/trainers/lwg_trainer.py:326-352 loss.backward(); layers as in
+// models/networks/generators/attlwb_spade_resunet.py and discriminators/patch_dis.py).  The data gradient needs no
+// kernel of its own: it is the forward kernel (csrc/conv_igemm.hip) run on dY with a transposed panel
+// (networks/packing.py: pack_dgrad).
+//
+// GEMM view:  dW[K, N] = A[M, K]^T * dY[M, N],  the reduction runs over the M = B*OH*OW output positions.
+//   * A is the same implicit operand as in the forward pass (row m = output position, k = (tap, channel) sampled at
+//     (oy*stride + dy, ox*stride + dx), zero outside the image), gathered with raw buffer loads (hardware zero fill);
+//     K in the forward panel's order (32-channel chunk major, tap minor; tap*Cin + c for the small-Cin first layers).
+//   * Workgroup = 4 waves, output tile 128 (k) x 128 (n), wave tile 64 x 64 = 2x2 MFMA tiles; the M range of the
+//     workgroup is walked in chunks of 32 rows: A chunk [32][128] and dY chunk [32][128] are staged in LDS
+//     (double buffered, loads of chunk i+1 in flight during the MFMAs of chunk i).  v_mfma_f32_32x32x2: lanes 0-31
+//     supply reduction index 2s, lanes 32-63 index 2s+1, so a fragment is one ds_read_b32 of a [m][k] row.
+//   * The reduction is split over gridDim.y workgroups; each writes its partial tile to a workspace slab and
+//     lwg_wgrad_reduce adds the slabs in slab order (deterministic - no float atomics).
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define LWG_OOB_OFFSET 0xC0000000u
+
+__device__ __forceinline__ floatx4 lwg_wg_buf_load(const float* base, unsigned bytes, unsigned voff) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+// a: the FORWARD geometry (x0/x1, taps, stride, OH/OW/M, N, output mapping YH/YW/YC/ycoff/omul/ooy/oox); a.y is unused.
+// dy_: gradient of the forward output, laid out like the forward y.  part: [gridDim.y][Ktot][N] partial sums.
+template <bool SMALLC>
+__global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArgs a, const float* __restrict__ dy_, int Ktot,
+                                                               int chunks_per_split, float* __restrict__ part) {
+    constexpr int BK = 128, BN = 128, BR = 32;           // output tile and reduction chunk
+    constexpr int ROW = 128;                             // floats per staged row (no pad: see header)
+    constexpr int STAGE = BR * ROW;                      // one operand, one stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                    // [2][BR][ROW]
+    float* Ys = smem + 2 * STAGE;                        // [2][BR][ROW]
+    int* taptab = reinterpret_cast<int*>(smem + 4 * STAGE);  // packed dy | dx << 16
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wk = wid >> 1, wn = wid & 1;
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tile_k = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int k_base = tile_k * BK, n_base = tile_n * BN;
+    if (tid < a.ntaps) taptab[tid] = (a.dy[tid] & 0xffff) | (a.dx[tid] << 16);
+    __syncthreads();
+
+    // ---- this thread's slice of the gather: row mrow of the chunk, channel quad kq of each of the 4 groups of 32 k ----
+    const int mrow = tid >> 3, kq = tid & 7;
+    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 4u;
+    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 4u;
+    const unsigned ybytes = (unsigned)a.B * a.YH * a.YW * a.YC * 4u;
+    // per group: source pointer, bytes, per-pixel channel count, channel offset, tap (dy, dx); k beyond Ktot -> invalid
+    const float* gsrc[4];
+    unsigned gbytes[4];
+    int gcs[4], gcoff[4], gdy[4], gdx[4];
+    bool gok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int tap, c;
+        const int k0 = k_base + g * 32;                  // first k of the group
+        gok[g] = k0 < Ktot;
+        if (SMALLC) {
+            const int k4 = (k0 >> 2) + kq;               // this lane's k-quad: tap and channel depend on the lane
+            tap = k4 >> a.cshift;
+            c = (k4 & ((1 << a.cshift) - 1)) * 4;
+            gok[g] = gok[g] && tap < a.ntaps;
+        } else {
+            const int G = k0 >> 5;                       // group id = cchunk * ntaps + tap
+            const int cchunk = G / a.ntaps;
+            tap = G - cchunk * a.ntaps;
+            c = cchunk * 32 + kq * 4;
+        }
+        const int tp = gok[g] ? tap : 0;
+        const int packed = taptab[tp];
+        gdy[g] = (int)(short)(packed & 0xffff);
+        gdx[g] = packed >> 16;
+        const bool use1 = c >= a.C0;
+        gsrc[g] = use1 ? a.x1 : a.x0;
+        gbytes[g] = use1 ? bytes1 : bytes0;
+        gcs[g] = use1 ? a.C1 : a.C0;
+        gcoff[g] = use1 ? c - a.C0 : c;
+    }
+    const int HW = a.OH * a.OW;
+    const bool direct = (a.omul == 1) && (a.YH == a.OH) && (a.YW == a.OW);
+
+    floatx4 rx[4], ry[4];
+    auto gload = [&](int chunk) {
+        const int m = chunk * BR + mrow;
+        const bool mok = m < a.M;
+        const int mm = mok ? m : 0;
+        const int b = mm / HW, rem = mm - b * HW;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const int iy0 = oy * a.stride, ix0 = ox * a.stride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int iy = iy0 + gdy[g], ix = ix0 + gdx[g];
+            const bool ok = mok && gok[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const unsigned off = ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)gcs[g] + (unsigned)gcoff[g]) * 4u;
+            rx[g] = lwg_wg_buf_load(gsrc[g], gbytes[g], ok ? off : LWG_OOB_OFFSET);
+        }
+        size_t opix = (size_t)mm;
+        if (!direct) opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n_base + (kq + 8 * j) * 4;
+            const bool ok = mok && n < a.N;
+            const unsigned off = (unsigned)((opix * a.YC + a.ycoff + n) * 4u);
+            ry[j] = lwg_wg_buf_load(dy_, ybytes, ok ? off : LWG_OOB_OFFSET);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* xb = Xs + buf * STAGE + mrow * ROW + kq * 4;
+        float* yb = Ys + buf * STAGE + mrow * ROW + kq * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(xb + g * 32) = rx[g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(yb + j * 32) = ry[j];
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks_total = (a.M + BR - 1) / BR;
+    const int c_begin = blockIdx.y * chunks_per_split;
+    const int c_end = min(nchunks_total, c_begin + chunks_per_split);
+    const int khalf = lane >> 5;
+    const float* fx = Xs + khalf * ROW + wk * 64 + (lane & 31);
+    const float* fy = Ys + khalf * ROW + wn * 64 + (lane & 31);
+
+    if (c_begin < c_end) {
+        gload(c_begin);
+        lstore(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cur = (c - c_begin) & 1;
+            if (c + 1 < c_end) gload(c + 1);
+            const float* px = fx + cur * STAGE;
+            const float* py = fy + cur * STAGE;
+#pragma unroll
+            for (int s = 0; s < BR / 2; ++s) {
+                const float a0 = px[2 * s * ROW], a1 = px[2 * s * ROW + 32];
+                const float b0 = py[2 * s * ROW], b1 = py[2 * s * ROW + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (c + 1 < c_end) lstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // ---- partial tile -> workspace slab blockIdx.y.  Lane owns column n = lane&31, rows k = (r&3) + 8*(r>>2) + 4*khalf ----
+    float* slab = part + (size_t)blockIdx.y * Ktot * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k_base + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (k >= Ktot) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n_base + wn * 64 + j * 32 + (lane & 31);
+                if (n < a.N) slab[(size_t)k * a.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// dW[i] = sum_s part[s][i] in slab order; optionally also the bias gradient db[n] = sum_m dY[m, n] is NOT computed here
+// (it is a plain column sum, done by lwg_colsum_nhwc_f32).
+__global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t total, float* __restrict__ dw) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
+        dw[i] = s;
+    }
+}
+
+// Column sums of an NHWC tensor viewed as (rows, C): out[c] = sum_r x[r, c] (bias gradients).  Two deterministic passes.
+__global__ __launch_bounds__(256) void lwg_colsum_partial_kernel(const float* __restrict__ x, size_t rows, int C, int rows_per_block,
+                                                                float* __restrict__ ws) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const size_t r0 = (size_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + (size_t)rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (size_t r = r0 + w; r < r1; r += 4) s += x[r * C + c];
+    __shared__ float sh[4][64];
+    sh[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
+    const int tiles = ((Ktot + 127) / 128) * ((N + 127) / 128);
+    const int nchunks = (M + 31) / 32;
+    int splits = (1024 + tiles - 1) / tiles;
+    if (splits > nchunks) splits = nchunks;
+    if (splits < 1) splits = 1;
+    return (size_t)splits * Ktot * N;
+}
+
+// args: forward geometry; dy: gradient of the forward output (same layout as y); dw: (ntaps*Cin, N) row-major in the
+// forward panel's K order.  ws: lwg_conv2d_wgrad_ws_floats(ntaps*Cin, N, M) floats.
+extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy, float* dw, float* ws, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa || !dy || !dw || !ws) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    const int Cin = a.C0 + a.C1;
+    if (!a.x0 || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0 || a.N <= 0 || (a.N & 3) || (Cin & 3) || (a.YC & 3) || (a.ycoff & 3))
+        return (int)hipErrorInvalidValue;
+    const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
+    if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.B * a.YH * a.YW * a.YC * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    const bool smallc = (Cin % 32) != 0;
+    if (smallc && (a.C1 != 0 || Cin > 16 || (Cin & (Cin - 1)) != 0 || (1 << a.cshift) != (Cin >> 2))) return (int)hipErrorInvalidValue;
+    if (!smallc && a.C1 != 0 && (a.C0 % 32 != 0 || !a.x1)) return (int)hipErrorInvalidValue;
+    const int Ktot = a.ntaps * Cin;
+    const int tiles = ((Ktot + 127) / 128) * ((a.N + 127) / 128);
+    const int nchunks = (a.M + 31) / 32;
+    int splits = (1024 + tiles - 1) / tiles;
+    if (splits > nchunks) splits = nchunks;
+    if (splits < 1) splits = 1;
+    const int cps = (nchunks + splits - 1) / splits;
+    const size_t lds = (size_t)4 * 32 * 128 * sizeof(float) + LWG_MAX_TAPS * sizeof(int);
+    auto kern = smallc ? lwg_conv_wgrad_kernel<true> : lwg_conv_wgrad_kernel<false>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[smallc]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done[smallc] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
+    const size_t total = (size_t)Ktot * a.N;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, total, dw);
+    return (int)hipGetLastError();
+}
+
+// out[c] = sum over rows of x (rows, C); ws: 64 * C floats.
+extern "C" int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !out || !ws || rows == 0 || C <= 0) return (int)hipErrorInvalidValue;
+    const int nblk = rows >= 64 * 64 ? 64 : (int)((rows + 63) / 64);
+    const int rpb = (int)((rows + nblk - 1) / nblk);
+    hipLaunchKernelGGL(lwg_colsum_partial_kernel, dim3((C + 63) / 64, nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
+    hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nblk, (size_t)C, out);
+    return (int)hipGetLastError();
+}

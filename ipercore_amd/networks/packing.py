@@ -99,3 +99,83 @@ def spec_to(spec, device):
     if spec.bias is not None:
         spec.bias = spec.bias.to(device)
     return spec
+
+
+# ---------------------------------------------------------------------------------------------- backward (training)
+def _taps_weights(weight, stride, pad):
+    """nn.Conv2d weight (N, Cin, kh, kw) -> (taps [(dy,dx)], W (ntaps, Cin, N))."""
+    N, Cin, kh, kw = weight.shape
+    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+    return taps, weight.permute(2, 3, 1, 0).reshape(kh * kw, Cin, N)
+
+
+def _dgrad_spec(taps_w, n_out, **kw):
+    """[( (dy,dx), Wt (Cin', N') )] -> ConvSpec whose GEMM columns are the ORIGINAL input channels."""
+    taps = [t for t, _ in taps_w]
+    wk = torch.cat([w for _, w in taps_w], dim=0)                 # (ntaps * Cin', N')
+    cin = taps_w[0][1].shape[0]
+    return ConvSpec(_panel(wk, len(taps), cin), None, n_out, cin, taps, **kw)
+
+
+def pack_dgrad_conv(weight, stride=1, pad=None):
+    """Data gradient of nn.Conv2d(weight (N, Cin, k, k), stride, pad) as forward-kernel launches on dY (B,OH,OW,N):
+    stride 1 -> one spec (taps negated, panels transposed); stride 2 -> four specs, one per input parity, that scatter
+    into dX with omul = 2 (dX[2a + p] = sum_{taps d == p mod 2} dY[a + (p - d) / 2] W_d^T)."""
+    weight = weight.detach().float()
+    N, Cin, kh, kw = weight.shape
+    pad = kh // 2 if pad is None else pad
+    taps, W = _taps_weights(weight, stride, pad)
+    Wt = W.permute(0, 2, 1).contiguous()                          # (ntaps, N, Cin)
+    if stride == 1:
+        return [_dgrad_spec([((-d[0], -d[1]), Wt[i]) for i, d in enumerate(taps)], Cin, stride=1)]
+    assert stride == 2
+    specs = []
+    for py in (0, 1):
+        for px in (0, 1):
+            tw = [(((py - d[0]) // 2, (px - d[1]) // 2), Wt[i]) for i, d in enumerate(taps)
+                  if (py - d[0]) % 2 == 0 and (px - d[1]) % 2 == 0]
+            specs.append(_dgrad_spec(tw, Cin, stride=1, omul=2, ooy=py, oox=px))
+    return specs
+
+
+def pack_dgrad_conv_transpose(weight):
+    """Data gradient of nn.ConvTranspose2d(k=4, s=2, p=1) weight (Cin, N, 4, 4): a stride-2, 16-tap convolution over dY
+    (B,2H,2W,N): dX[a] = sum_{parity p, tap e} dY[2 a + (p - 2 e)] W_{p,e}^T."""
+    weight = weight.detach().float()
+    Cin, N, kh, kw = weight.shape
+    tw = []
+    for py in (0, 1):
+        for px in (0, 1):
+            for ky, ey in _CT_TAPS[py]:
+                for kx, ex in _CT_TAPS[px]:
+                    tw.append(((py - 2 * ey, px - 2 * ex), weight[:, :, ky, kx].t().contiguous()))      # (N, Cin)
+    return [_dgrad_spec(tw, Cin, stride=2)]
+
+
+def unpack_wgrad(dwk, ntaps, cin):
+    """(ntaps*Cin, N) in the kernel's K order -> (ntaps, Cin, N)."""
+    N = dwk.shape[1]
+    if cin % 32 == 0:
+        return dwk.view(cin // 32, ntaps, 32, N).permute(1, 0, 2, 3).reshape(ntaps, cin, N)
+    return dwk.view(ntaps, cin, N)
+
+
+def wgrad_to_conv(dwk, ntaps, cin_packed, cin, n, kh, kw):
+    """-> nn.Conv2d weight gradient (N, Cin, kh, kw) (drops the zero-padded input / output channels)."""
+    return unpack_wgrad(dwk, ntaps, cin_packed)[:, :cin, :n].reshape(kh, kw, cin, n).permute(3, 2, 0, 1).contiguous()
+
+
+def wgrad_to_conv_transpose(dwks, cin, n):
+    """Four parity gradients (each (4*Cin, Np) in kernel order, taps as in pack_conv_transpose) -> (Cin, N, 4, 4)."""
+    g = dwks[0].new_zeros(cin, n, 4, 4)
+    i = 0
+    for py in (0, 1):
+        for px in (0, 1):
+            w = unpack_wgrad(dwks[i], 4, cin)                     # (4, Cin, Np)
+            t = 0
+            for ky, _ in _CT_TAPS[py]:
+                for kx, _ in _CT_TAPS[px]:
+                    g[:, :, ky, kx] = w[t][:, :n]
+                    t += 1
+            i += 1
+    return g

@@ -1,0 +1,260 @@
+"""Training (autograd) path of the AttLWB-SPADE generator for the personalization step.
+
+Reference: ``LWGTrainer.forward / optimize_G`` (tools/trainers/lwg_trainer.py:699-789) call
+``AttentionLWBGenerator.forward(bg, src, tsf, Tst, only_tsf=False)`` (attlwb_spade_resunet.py:633-699) and
+``loss.backward()`` (lwg_trainer.py:345).
+
+What runs where, this round:
+* every convolution / transposed convolution - forward, data gradient and weight gradient (> 99 % of the 1857 GFLOP of
+  a G step) - runs on the hand-written MFMA kernels: ``ConvFn`` is a ``torch.autograd.Function`` whose forward is
+  ``lwg_conv2d_nhwc_f32``, whose data gradient is the same kernel on dY with a transposed panel
+  (``packing.pack_dgrad_*``) and whose weight gradient is ``lwg_conv2d_wgrad_nhwc_f32``;
+* the glue between the convolutions (ReLU/tanh/sigmoid, InstanceNorm, SPADE modulation, the bilinear warp, the softmax
+  over sources, losses, Adam) is PyTorch-ROCm autograd on NHWC tensors in this round - HBM-bound elementwise work that
+  the inference path already fuses into HIP kernels; fusing their backward is the next step of this row.
+There is no CPU fallback: ``ConvFn`` raises on CPU tensors.
+
+The module reuses the parameter tree of ``generator.AttentionLWBGenerator`` (same ``state_dict`` keys), so a
+personalized checkpoint saved from here loads into the inference engine unchanged.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from . import packing
+
+_RELU, _NONE = 1, 0
+
+
+class ConvCfg(object):
+    """Static description of one layer: kind ('conv' | 'convT'), stride, pad, fused act (0 none, 1 relu),
+    zero-extension of input channels (cin_pad) / output channels (n_pad) to what the kernels need."""
+
+    def __init__(self, kind="conv", stride=1, pad=None, act=_NONE, cin_pad=None, n_pad=None, need_dx=True):
+        self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
+
+
+class ConvFn(torch.autograd.Function):
+    """y = act(conv(cat[x0, x1], weight) + bias) on NHWC tensors, all three passes on the MFMA kernels."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, cfg):
+        if not x0.is_cuda:
+            raise RuntimeError("ipercore_amd training convs run on the MI355X only (no CPU fallback)")
+        x0 = x0.contiguous()
+        x1 = None if x1 is None else x1.contiguous()
+        B, H, W, _ = x0.shape
+        dev = x0.device
+        if cfg.kind == "conv":
+            N = weight.shape[0]
+            spec = packing.spec_to(packing.pack_conv(weight, bias, cfg.stride, cfg.pad, cfg.cin_pad, cfg.n_pad), dev)
+            kh = weight.shape[2]
+            pad = kh // 2 if cfg.pad is None else cfg.pad
+            OH, OW = (H + 2 * pad - kh) // cfg.stride + 1, (W + 2 * pad - kh) // cfg.stride + 1
+            y = torch.empty(B, OH, OW, spec.N, device=dev, dtype=torch.float32)
+            ops.conv2d(x0, spec, y, x1=x1, act=cfg.act)
+            specs = [spec]
+        else:
+            N = weight.shape[1]
+            specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(weight, bias, cfg.n_pad)]
+            y = torch.empty(B, 2 * H, 2 * W, specs[0].N, device=dev, dtype=torch.float32)
+            for s in specs:
+                ops.conv2d(x0, s, y, act=cfg.act)
+        ctx.cfg, ctx.specs, ctx.N, ctx.has_bias = cfg, specs, N, bias is not None
+        ctx.has_x1 = x1 is not None
+        ctx.save_for_backward(x0, x1, weight, y if cfg.act == _RELU else None)
+        return y if y.shape[3] == N else y[..., :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight, y = ctx.saved_tensors
+        cfg, specs, N = ctx.cfg, ctx.specs, ctx.N
+        Np = specs[0].N
+        dy = dy.contiguous()
+        if Np != N:                                                   # zero-extended output channels carry no gradient
+            full = dy.new_zeros(dy.shape[0], dy.shape[1], dy.shape[2], Np)
+            full[..., :N] = dy
+            dy = full
+        if cfg.act == _RELU:
+            dy = dy * (y > 0)
+        dev = dy.device
+        C0 = x0.shape[3]
+        Cin_packed = specs[0].Cin
+        db = ops.colsum(dy)[:N] if ctx.has_bias else None
+        if cfg.kind == "conv":
+            Nw, Cin, kh, kw = weight.shape
+            dwk = ops.conv2d_wgrad(x0, specs[0], dy, x1=x1)
+            dw = packing.wgrad_to_conv(dwk, kh * kw, Cin_packed, Cin, N, kh, kw)
+            dx = None
+            if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+                wpad = weight
+                if Np != N or Cin_packed != Cin:                      # the dgrad panel must see the padded shapes
+                    wpad = weight.new_zeros(Np, Cin_packed, kh, kw)
+                    wpad[:N, :Cin] = weight
+                pad = kh // 2 if cfg.pad is None else cfg.pad
+                dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(wpad, cfg.stride, pad)]
+                B, H, W, _ = x0.shape
+                dx = torch.empty(B, H, W, Cin_packed, device=dev, dtype=torch.float32)
+                if cfg.stride == 1:
+                    ops.conv2d(dy, dspecs[0], dx)
+                else:
+                    for s in dspecs:
+                        ops.conv2d(dy, s, dx, out_hw=(H // 2, W // 2))
+        else:
+            Cin, Nw = weight.shape[0], weight.shape[1]
+            dwks = [ops.conv2d_wgrad(x0, s, dy) for s in specs]
+            dw = packing.wgrad_to_conv_transpose(dwks, Cin, N)
+            dx = None
+            if cfg.need_dx and ctx.needs_input_grad[0]:
+                wpad = weight
+                if Np != N:
+                    wpad = weight.new_zeros(Cin, Np, 4, 4)
+                    wpad[:, :N] = weight
+                dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(wpad)[0], dev)
+                B, H, W, _ = x0.shape
+                dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
+                ops.conv2d(dy, dspec, dx)
+        dx0 = dx1 = None
+        if dx is not None:
+            dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
+            if ctx.has_x1:
+                dx1 = dx[..., C0:]
+        return dx0, dx1, dw, db, None
+
+
+def conv(x0, weight, bias=None, x1=None, **kw):
+    return ConvFn.apply(x0, x1, weight, bias, ConvCfg(**kw))
+
+
+# ---------------------------------------------------------------------------------------------- NHWC glue (autograd)
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d(affine=False) on (B,H,W,C): biased variance over the pixels of each (b, c)."""
+    mu = x.mean(dim=(1, 2), keepdim=True)
+    var = x.var(dim=(1, 2), unbiased=False, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps)
+
+
+def lwb_transform(x, T):
+    """attlwb_spade_resunet.py:175-191 on NHWC features: flow resize (align_corners=True) + grid_sample (zeros)."""
+    h, w = x.shape[1:3]
+    if T.shape[1] != h or T.shape[2] != w:
+        T = F.interpolate(T.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    out = F.grid_sample(x.permute(0, 3, 1, 2), T, mode="bilinear", padding_mode="zeros", align_corners=False)
+    return out.permute(0, 2, 3, 1)
+
+
+class TrainableGenerator(object):
+    """Functional training forward over the parameters of an ``AttentionLWBGenerator`` (reference :633-699)."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.n_down = len(gen.num_filters)
+        self.n_res = gen.n_res_block
+        self.n_bg = len(gen.bg_filters) if gen.has_bg else 0
+
+    def p(self, name):
+        obj = self.gen
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        return obj
+
+    def cv(self, name, x, x1=None, **kw):
+        node = self.p(name)
+        return conv(x, node.weight, getattr(node, "bias", None), x1=x1, **kw)
+
+    # -- SelfAttentionLWB (:194-252) + SPADE (:80-93)
+    def attlwb(self, pfx, tsf_x, src_x, Tst):
+        bs, ns, S, _, _ = Tst.shape
+        h, w, C = tsf_x.shape[1:]
+        warp = lwb_transform(src_x, Tst.reshape(bs * ns, S, S, 2))
+        K = self.cv(pfx + ".fk", warp, pad=0).view(bs, ns, h, w, C)
+        V = self.cv(pfx + ".fv", warp, pad=0).view(bs, ns, h, w, C)
+        q = self.cv(pfx + ".fq", tsf_x, pad=0)
+        logits = (K * q.unsqueeze(1)).sum(dim=4, keepdim=True) / math.sqrt(C)
+        x = (torch.softmax(logits, dim=1) * V).sum(dim=1)
+        actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
+        gamma = self.cv(pfx + ".spade.mlp_gamma", actv)
+        beta = self.cv(pfx + ".spade.mlp_beta", actv)
+        return instance_norm(tsf_x) * (1 + gamma) + beta
+
+    def res_block(self, pfx, x):
+        return x + self.cv(pfx + ".main.2", self.cv(pfx + ".main.0", x, act=_RELU))
+
+    def head(self, img_name, att_name, x):
+        """The two 5x5 regressors as ONE conv with 4 (zero-extended to 64) output columns."""
+        w = torch.cat([self.p(img_name).weight, self.p(att_name).weight], dim=0)
+        y = conv(x, w, None, pad=2, n_pad=64)
+        return torch.tanh(y[..., 0:3]), torch.sigmoid(y[..., 3:4])
+
+    # -- the three branches (NHWC in / out)
+    def forward_bg(self, bg4):
+        """(n,S,S,4) -> (n,S,S,3)   (bg_inpaintor.py:24-60)."""
+        x, i = bg4, 0
+        x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, pad=3, cin_pad=4, need_dx=False)))
+        i += 3
+        for _ in range(self.n_bg - 1):
+            x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, stride=2)))
+            i += 3
+        for _ in range(self.n_res):
+            y = F.relu(instance_norm(self.cv(f"bg_net.main.{i}.main.0", x)))
+            x = x + instance_norm(self.cv(f"bg_net.main.{i}.main.3", y))
+            i += 1
+        for _ in range(self.n_bg - 1):
+            x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, kind="convT")))
+            i += 3
+        return torch.tanh(self.cv(f"bg_net.main.{i}", x, pad=3, n_pad=64))
+
+    def forward_src(self, src8):
+        """(n,S,S,8) -> (enc list, res list, img (n,S,S,3), mask (n,S,S,1))   (:450-478, only_enc=False)."""
+        x, enc, res = src8, [], []
+        for i in range(self.n_down):
+            x = self.cv(f"src_net.encoders.layers.{i}.0", x, stride=2, act=_RELU, cin_pad=8 if i == 0 else None, need_dx=i != 0)
+            enc.append(x)
+        for i in range(self.n_res):
+            x = self.res_block(f"src_net.res_blocks.{i}", x)
+            res.append(x)
+        for i in range(self.n_down):
+            x = self.cv(f"src_net.decoders.layers.{i}.0", x, kind="convT", act=_RELU)
+        img, mask = self.head("src_net.img_reg.0", "src_net.att_reg.0", x)
+        return enc, res, img, mask
+
+    def forward_tsf(self, tsf8, enc_src, res_src, Tst):
+        """(B,S,S,8), source features, Tst (B,ns,S,S,2) -> (img (B,S,S,3), mask (B,S,S,1))   (:480-535)."""
+        x, enc = tsf8, []
+        for i in range(self.n_down):
+            x = self.cv(f"tsf_net_enc.layers.{i}.0", x, stride=2, act=_RELU, cin_pad=8 if i == 0 else None, need_dx=i != 0)
+            x = self.attlwb(f"enc_attlwbs.{i}", x, enc_src[i], Tst)
+            enc.append(x)
+        for i in range(self.n_res):
+            x = self.res_block(f"res_blocks.{i}", x)
+            x = self.attlwb(f"res_attlwbs.{i}", x, res_src[i], Tst)
+        for i in range(self.n_down):
+            x = self.cv(f"tsf_net_dec.upconvs.{i}.0", x, kind="convT", act=_RELU)
+            if i != self.n_down - 1:
+                x = self.cv(f"tsf_net_dec.skippers.{i}.0", enc[self.n_down - 2 - i], x1=x, act=_RELU)
+        return self.head("tsf_img_reg.0", "tsf_att_reg.0", x)
+
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst):
+        """Reference signature (:633-699, temporal=False, only_tsf=False), NCHW in / out:
+        bg_inputs (bs,nb,4,h,w), src_inputs (bs,ns,6,h,w), tsf_inputs (bs,nt,6,h,w), Tst (bs,nt,ns,h,w,2)
+        -> bg (bs,nb,3,h,w), src_img (bs,ns,3,h,w), src_mask (bs,ns,1,h,w), tsf_img (bs,nt,3,h,w), tsf_mask (bs,nt,1,h,w)."""
+        bs, nb = bg_inputs.shape[:2]
+        ns, nt = src_inputs.shape[1], tsf_inputs.shape[1]
+        h, w = tsf_inputs.shape[-2:]
+        nhwc = lambda t, cp: F.pad(t.reshape(-1, t.shape[2], h, w).permute(0, 2, 3, 1), (0, cp - t.shape[2])).contiguous()   # noqa: E731
+        nchw = lambda t, n: t.permute(0, 3, 1, 2).reshape(bs, n, t.shape[3], h, w)                                             # noqa: E731
+        bg = self.forward_bg(nhwc(bg_inputs, 4))
+        enc, res, s_img, s_mask = self.forward_src(nhwc(src_inputs, 8))
+        imgs, masks = [], []
+        for t in range(nt):
+            if bs == 1:
+                e, r = enc, res
+            else:
+                raise NotImplementedError("bs > 1 per rank: run one sample per process (config 5 is 1 sample / GPU)")
+            img, mask = self.forward_tsf(nhwc(tsf_inputs[:, t:t + 1], 8), e, r, Tst[:, t].contiguous())
+            imgs.append(img)
+            masks.append(mask)
+        return (nchw(bg, nb), nchw(s_img, ns), nchw(s_mask, ns),
+                nchw(torch.cat(imgs, dim=0), nt), nchw(torch.cat(masks, dim=0), nt))

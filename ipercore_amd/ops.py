@@ -316,3 +316,26 @@ def frames_to_u8(pred, bgr=False):
     out = torch.empty(B, S, S, 3, device=pred.device, dtype=torch.uint8)
     _lib.check(_lib.lib().lwg_frames_to_u8(_ptr(pred), B, S, 1 if bgr else 0, _ptr(out, torch.uint8), _stream()), "lwg_frames_to_u8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- backward of the convs
+def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
+    """dW of the conv described by ``spec`` for inputs x0 (x1) and output gradient dy (laid out like the forward y) ->
+    (ntaps * Cin, N) fp32 in the forward panel's K order (see packing.unpack_wgrad)."""
+    a = conv_args(x0, spec, dy, x1=x1, out_hw=out_hw, ycoff=ycoff)
+    Ktot = spec.ntaps * spec.Cin
+    dw = torch.empty(Ktot, spec.N, device=x0.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().lwg_conv2d_wgrad_ws_floats(Ktot, spec.N, a.M), device=x0.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_conv2d_wgrad_nhwc_f32(a, _ptr(dy), _ptr(dw), _ptr(ws), _stream()), "lwg_conv2d_wgrad_nhwc_f32")
+    return dw
+
+
+def colsum(x2d_or_nhwc):
+    """Sum over every dimension but the last (bias gradient)."""
+    x = x2d_or_nhwc.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(64 * C, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_colsum_nhwc_f32(_ptr(x), rows, C, _ptr(out), _ptr(ws), _stream()), "lwg_colsum_nhwc_f32")
+    return out

@@ -302,6 +302,31 @@ def gen_forward_src(sd, src_inputs, n_down=3, n_res=6):
     return enc, res
 
 
+def gen_forward_src_full(sd, src_inputs, n_down=3, n_res=6):
+    """forward_src(only_enc=False) :450-478: features + the SIDNet decoder (Decoder :291-314) and regressors (:376-384)."""
+    bs, ns, _, h, w = src_inputs.shape
+    enc, res = gen_forward_src(sd, src_inputs, n_down, n_res)
+    x = res[-1]
+    for i in range(n_down):
+        x = F.relu(_convT(sd, f"src_net.decoders.layers.{i}.0", x))
+    img = torch.tanh(_conv(sd, "src_net.img_reg.0", x, pad=2))
+    mask = torch.sigmoid(_conv(sd, "src_net.att_reg.0", x, pad=2))
+    return enc, res, img.view(bs, ns, 3, h, w), mask.view(bs, ns, 1, h, w)
+
+
+def gen_forward_train(sd, bg_inputs, src_inputs, tsf_inputs, Tst, n_down=3, n_res=6, n_bg=4):
+    """AttentionLWBGenerator.forward(..., only_tsf=False) :633-699 with temporal=False, bs = 1: differentiable w.r.t. sd."""
+    bs, nt = tsf_inputs.shape[:2]
+    bg = gen_forward_bg(sd, bg_inputs, n_down=n_bg, n_res=n_res)
+    enc, res, s_img, s_mask = gen_forward_src_full(sd, src_inputs, n_down, n_res)
+    imgs, masks = [], []
+    for t in range(nt):
+        img, mask = gen_forward_tsf(sd, tsf_inputs[:, t], enc, res, Tst[:, t], n_down, n_res)
+        imgs.append(img)
+        masks.append(mask)
+    return bg, s_img, s_mask, torch.stack(imgs, dim=1), torch.stack(masks, dim=1)
+
+
 def gen_forward_tsf(sd, tsf_inputs, src_enc_outs, src_res_outs, Tst, n_down=3, n_res=6):
     """BaseAttentionLWBGenerator.forward_tsf :480-535 (temporal=False) -> (tsf_img, tsf_mask)."""
     x = tsf_inputs

@@ -9,6 +9,7 @@ import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ipercore_amd import ops, synthetic
 from ipercore_amd.geometry import mesh
@@ -466,7 +467,121 @@ def check_output_stage():
     return {"frames": len(paths)}
 
 
+def _conv_bwd_case(name, B, H, W, Cin, N, k, stride, pad, seed, C1=0, kind="conv", act=0, bias=True, cin_pad=None, n_pad=None,
+                   need_dx=True):
+    """ConvFn (forward + dgrad through the forward kernel + the wgrad MFMA kernel) vs torch autograd of F.conv2d on CPU."""
+    from ipercore_amd.networks import training as tr
+    if kind == "conv":
+        w = _rand((N, Cin, k, k), seed, 1.0 / np.sqrt(Cin * k * k))
+    else:
+        w = _rand((Cin, N, 4, 4), seed, 1.0 / np.sqrt(Cin * 4))
+    b = _rand((N,), seed + 1, 0.1) if bias else None
+    x = _rand((B, H, W, Cin), seed + 2)
+    # CPU reference (NCHW autograd)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = None if b is None else b.clone().requires_grad_(True)
+    xn = xr.permute(0, 3, 1, 2)
+    yr = F.conv2d(xn, wr, br, stride=stride, padding=pad) if kind == "conv" else F.conv_transpose2d(xn, wr, br, stride=2, padding=1)
+    if act:
+        yr = F.relu(yr)
+    g = _rand(tuple(yr.permute(0, 2, 3, 1).shape), seed + 3)
+    (yr.permute(0, 2, 3, 1) * g).sum().backward()
+    # HIP
+    Cp = Cin if cin_pad is None else cin_pad
+    xd = torch.zeros(B, H, W, Cp)
+    xd[..., :Cin] = x
+    xd = xd.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = None if b is None else b.to(DEV).requires_grad_(True)
+    if C1:
+        x0, x1 = xd[..., :Cp - C1], xd[..., Cp - C1:]
+    else:
+        x0, x1 = xd, None
+    y = tr.conv(x0, wd, bd, x1=x1, kind=kind, stride=stride, pad=pad, act=act, cin_pad=cin_pad, n_pad=n_pad, need_dx=need_dx)
+    (y * g.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    m = {"y": _cmp(y, yr.permute(0, 2, 3, 1), 2e-5, name + " y"),
+         "dw": _cmp(wd.grad, wr.grad, 2e-4, name + " dW"),
+         }
+    if need_dx:
+        m["dx"] = _cmp(xd.grad[..., :Cin], xr.grad, 2e-4, name + " dX")
+    if b is not None:
+        m["db"] = _cmp(bd.grad, br.grad, 2e-4, name + " db")
+    return m
+
+
+def check_conv_backward():
+    out, errors = {}, []
+
+    def run(key, *a, **k):
+        try:
+            out[key] = _conv_bwd_case(*a, **k)
+        except Exception as e:                      # report every failing shape, not only the first
+            errors.append(f"{key}: {type(e).__name__}: {e}")
+    run("3x3_s1", "3x3 s1 64->128", 2, 16, 32, 64, 128, 3, 1, 1, 400, act=1)
+    run("3x3_s1_tail", "3x3 s1 M/K tails", 3, 9, 7, 64, 64, 3, 1, 1, 410)          # M tail, K = 576 (4.5 tiles)
+    run("3x3_s2", "3x3 s2 64->128", 2, 16, 16, 64, 128, 3, 2, 1, 420, act=1, bias=False)
+    run("1x1", "1x1 256->256", 1, 8, 8, 256, 256, 1, 1, 0, 430)
+    run("concat", "3x3 concat 128+256", 1, 16, 16, 384, 256, 3, 1, 1, 440, C1=256, act=1)
+    run("convT", "convT 128->64", 2, 8, 8, 128, 64, 4, 2, 1, 450, kind="convT", act=1)
+    run("head5x5", "5x5 64->4 (n_pad)", 1, 16, 16, 64, 4, 5, 1, 2, 460, bias=False, n_pad=64)
+    run("first_layer", "3x3 s2 6->64 (cin_pad 8)", 1, 32, 32, 6, 64, 3, 2, 1, 470, cin_pad=8, bias=False, act=1, need_dx=False)
+    run("bg_first", "7x7 4->64", 1, 16, 16, 4, 64, 7, 1, 3, 480, cin_pad=4, need_dx=False)   # network inputs: no dX
+    assert not errors, errors
+    return out
+
+
+def check_generator_training_grads():
+    """One training forward + backward of the whole generator (bg + src with decoder + tsf) through ConvFn on the GPU vs
+    torch autograd through the oracle's functional generator on the CPU: outputs and EVERY parameter gradient."""
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    from ipercore_amd.networks.training import TrainableGenerator
+    S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
+    sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.to(DEV).train()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    bg_in = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"))
+    src_in = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_in = torch.tensor(synthetic.uniform_image((1, 1, 6, S, S), 9, "tsf_inputs"))
+    Tst = torch.tensor(g["render/Tst"]).view(1, 1, ns, S, S, 2)
+    tgt = [torch.tensor(synthetic.uniform_image(s, 500 + i, "tgt")) for i, s in enumerate(((1, 1, 3, S, S), (1, ns, 3, S, S), (1, ns, 1, S, S), (1, 1, 3, S, S), (1, 1, 1, S, S)))]
+
+    def loss_of(outs, dev):
+        return sum((o - t.to(dev)).abs().mean() for o, t in zip(outs, tgt))
+
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sdn.items()}
+    outs_ref = orc.gen_forward_train(sd, bg_in, src_in, tsf_in, Tst, n_down=len(nf), n_res=nres, n_bg=len(bgf))
+    loss_ref = loss_of(outs_ref, "cpu")
+    loss_ref.backward()
+    outs = TrainableGenerator(G).forward(bg_in.to(DEV), src_in.to(DEV), tsf_in.to(DEV), Tst.to(DEV))
+    loss = loss_of(outs, DEV)
+    loss.backward()
+    torch.cuda.synchronize()
+    m = {"loss": abs(loss.item() - loss_ref.item())}
+    assert m["loss"] <= 1e-4 * max(1.0, abs(loss_ref.item())), m
+    names = ("bg", "src_img", "src_mask", "tsf_img", "tsf_mask")
+    for n_, a_, b_ in zip(names, outs, outs_ref):
+        m[n_] = _cmp(a_, b_.detach(), 2e-3, n_)
+    # a bias in front of an InstanceNorm has a mathematically zero gradient (both sides hold rounding noise there), so the
+    # error of a parameter is measured against max(its own gradient scale, 1e-3 of the largest gradient in the network)
+    gmax = max(v.grad.abs().max().item() for v in sd.values())
+    worst, worst_name = 0.0, None
+    for k, p_ in G.named_parameters():
+        assert p_.grad is not None, f"no gradient for {k}"
+        ref = sd[k].grad
+        rel = (p_.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3 * gmax)
+        if rel > worst:
+            worst, worst_name = rel, k
+    m["worst_rel_grad_err"], m["worst_param"], m["n_params"] = worst, worst_name, len(sd)
+    assert worst <= 2e-3, m
+    return m
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
-       check_source_setup_512, check_output_stage]
+       check_source_setup_512, check_output_stage, check_conv_backward,
+       check_generator_training_grads]
