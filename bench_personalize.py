@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""bench_personalize.py - BASELINE configs[4]: the personalization step (G + D forward / backward / Adam) at 512x512,
+one sample per GPU, data parallel over N MI355X with ONE flat RCCL all-reduce of the gradients per network.
+
+    python bench_personalize.py [--gpus N] [--steps K] [--warmup W] [--size 512]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_personalize.py --gpus N)
+
+NOT the headline bench (that is bench.py: synthesized frames/s).  A step = LWGTrainer.optimize_parameters()
+(reference tools/trainers/lwg_trainer.py:326-352) on one synthetic sample (ns = 2 sources, nt = 1 target): G forward with
+only_tsf=False (bg + src with decoder + tsf), LSGAN + L1 + BCE mask + TV losses (VGG19 / SphereFace losses omitted: their
+checkpoints are not available offline - the reference's use_vgg="None", use_face=false configuration), backward, gradient
+all-reduce, Adam; then the discriminator step.  Every convolution (forward, dgrad, wgrad) runs on the hand-written MFMA
+kernels; the elementwise glue is PyTorch-ROCm autograd this round (ipercore_amd/networks/training.py).
+
+Prints ONE JSON line on rank 0: samples/s over all ranks, and the achieved conv TFLOP/s from the algorithmic conv flops of
+the step (forward + dgrad + wgrad of every ConvFn call, counted live).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    assert args.gpus == world
+
+    from ipercore_amd import ops, synthetic as syn
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator
+
+    S, ns = args.size, 2
+    nf, nres, bgf = [64, 128, 256], 6, [64, 128, 128, 256]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=syn.gen_cfg(nf, nres, bgf), temporal=False)
+    sd = syn.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    G.to(dev).train()
+    torch.manual_seed(0)
+    D = PatchGlobalDiscriminator().to(dev)
+    # one synthetic sample per rank (different seeds per rank: data parallel); flows from the real renderer path
+    case = syn.build_case(image_size=S, n_frames=1, ns=ns, seed=rank)
+    im = syn.make_imitator(case, frame_batch=1, device=dev)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, tgt[0:1], "smooth", t=0)
+    u = lambda shape, seed, name: torch.tensor(syn.uniform_image(shape, seed + 100 * rank, name), device=dev)   # noqa: E731
+    cond = im.src_info["cond"]
+    inp = {"input_G_bg": u((1, 1, 4, S, S), 10, "bg_inputs"),
+           "input_G_src": torch.cat([torch.tensor(case.src_img, device=dev)[0], cond], dim=1).unsqueeze(0),
+           "input_G_tsf": ops.nhwc_to_nchw(tsf8, channels=6).unsqueeze(0), "Tst": Tst.unsqueeze(1).contiguous(),
+           "real_src": torch.tensor(case.src_img, device=dev), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
+           "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
+    del im
+    tr = LWGTrainer(G, D)
+    tr.set_input(inp)
+
+    flops = [0.0]
+
+    def hook(begin, M, spec, epi=0):
+        if begin:
+            flops[0] += 2.0 * M * spec.algo_kn
+    for _ in range(args.warmup):
+        tr.optimize_parameters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.CONV_HOOK = hook                       # counts forward + dgrad launches; wgrad flops are added below (same 2*M*K*N)
+    wg = [0.0]
+    orig = ops.conv2d_wgrad
+
+    def counted_wgrad(x0, spec, dy, **kw):
+        M = dy.shape[0] * dy.shape[1] * dy.shape[2] // (spec.omul ** 2)
+        wg[0] += 2.0 * M * spec.algo_kn
+        return orig(x0, spec, dy, **kw)
+    ops.conv2d_wgrad = counted_wgrad
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lg, ld = tr.optimize_parameters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.CONV_HOOK, ops.conv2d_wgrad = None, orig
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        per_step = (flops[0] + wg[0]) / args.steps
+        print(json.dumps({
+            "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(args.steps * world / dt, 4),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + L1 tsf + BCE mask + TV",
+                       "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
+                                      f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},
+            "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(per_step / (dt / args.steps) / 1e12, 2),
+            "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

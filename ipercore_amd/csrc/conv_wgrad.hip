@@ -197,13 +197,20 @@ __global__ __launch_bounds__(256) void lwg_colsum_partial_kernel(const float* __
     if (w == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
+// Reduction splits: enough workgroups to fill the 256 CUs twice (2 workgroups/CU), at most 16 slabs (every slab is
+// written and read once more by the reduction), at least 8 chunks of 32 rows per workgroup.
+static int lwg_wgrad_splits(int Ktot, int N, int M) {
     const int tiles = ((Ktot + 127) / 128) * ((N + 127) / 128);
     const int nchunks = (M + 31) / 32;
-    int splits = (1024 + tiles - 1) / tiles;
-    if (splits > nchunks) splits = nchunks;
+    int splits = (512 + tiles - 1) / tiles;
+    if (splits > 16) splits = 16;
+    if (splits > nchunks / 8) splits = nchunks / 8;
     if (splits < 1) splits = 1;
-    return (size_t)splits * Ktot * N;
+    return splits;
+}
+
+extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
+    return (size_t)lwg_wgrad_splits(Ktot, N, M) * Ktot * N;
 }
 
 // args: forward geometry; dy: gradient of the forward output (same layout as y); dw: (ntaps*Cin, N) row-major in the
@@ -224,9 +231,7 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
     const int Ktot = a.ntaps * Cin;
     const int tiles = ((Ktot + 127) / 128) * ((a.N + 127) / 128);
     const int nchunks = (a.M + 31) / 32;
-    int splits = (1024 + tiles - 1) / tiles;
-    if (splits > nchunks) splits = nchunks;
-    if (splits < 1) splits = 1;
+    const int splits = lwg_wgrad_splits(Ktot, a.N, a.M);
     const int cps = (nchunks + splits - 1) / splits;
     const size_t lds = (size_t)4 * 32 * 128 * sizeof(float) + LWG_MAX_TAPS * sizeof(int);
     auto kern = smallc ? lwg_conv_wgrad_kernel<true> : lwg_conv_wgrad_kernel<false>;

@@ -1,0 +1,183 @@
+"""Personalization training step on the MI355X.
+
+Reference: ``LWGTrainer`` (iPERCore/tools/trainers/lwg_trainer.py:609-832) driven by
+``services/personalization.py:95-151``: per iteration ``forward`` (G with only_tsf=False), ``optimize_G`` (LSGAN +
+L1 reconstruction + transfer loss + BCE mask + TV), Adam step, ``optimize_D`` (LSGAN real/fake), Adam step
+(``optimize_parameters`` :326-352).  Discriminator: ``GlobalDiscriminator`` over ``PatchDiscriminator``
+(models/networks/discriminators/multi_scale_dis.py:47-107, patch_dis.py:8-70), factory name ``patch_global``.
+
+Every convolution of G and D (forward, data gradient, weight gradient) runs on the hand-written MFMA kernels through
+``networks.training.ConvFn``; the elementwise glue is PyTorch-ROCm autograd in this round (see that module).
+Losses that need weights the reference downloads (VGG19 perceptual ``vggloss.py``, SphereFace ``FaceLoss``) are not
+available offline: the step is the reference's ``use_vgg = "None"`` / ``use_face = false`` configuration, in which
+``crt_tsf`` is ``L1Loss`` (lwg_trainer.py:154-158).
+
+Data parallelism (BASELINE config 5: one sample per GPU): gradients are flattened into ONE fp32 buffer per network and
+reduced with a single RCCL all-reduce (``allreduce_grads``) - large, few collectives for point-to-point xGMI - instead of
+DDP's 25 MB buckets.  The reference's personalization itself is single-GPU (no collective).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .networks.training import TrainableGenerator, conv, instance_norm
+
+_RELU = 1
+
+
+class PatchGlobalDiscriminator(nn.Module):
+    """``patch_global``: GlobalDiscriminator(cfg) without the augmented-background branch (use_aug_bg=False, the
+    deploy.toml default).  Parameter names follow the reference modules: ``global_model.model.{0,2,5,8,11,14}``."""
+
+    def __init__(self, cond_nc=6, ndf=64, n_layers=4, max_nf_mult=8):
+        super().__init__()
+        chans = [cond_nc, ndf]
+        for n in range(1, n_layers):
+            chans.append(ndf * min(2 ** n, max_nf_mult))
+        chans.append(ndf * min(2 ** n_layers, max_nf_mult))
+        self.n_layers = n_layers
+        idx = [0] + [2 + 3 * (n - 1) for n in range(1, n_layers + 1)]          # Sequential indices of the convs
+        self.layer_names = [str(i) for i in idx] + [str(idx[-1] + 3)]
+        self.global_model = nn.Module()
+        self.global_model.model = nn.Module()
+        for i, name in enumerate(self.layer_names[:-1]):
+            m = nn.Module()
+            m.weight = nn.Parameter(torch.empty(chans[i + 1], chans[i], 4, 4))
+            m.bias = nn.Parameter(torch.empty(chans[i + 1]))
+            self.global_model.model.add_module(name, m)
+        m = nn.Module()
+        m.weight = nn.Parameter(torch.empty(1, chans[-1], 4, 4))
+        m.bias = nn.Parameter(torch.empty(1))
+        self.global_model.model.add_module(self.layer_names[-1], m)
+        for p in self.parameters():                                            # PyTorch Conv2d default init
+            if p.dim() == 4:
+                bound = 1.0 / (p.shape[1] * 16) ** 0.5
+                p.data.uniform_(-bound, bound)
+        for name in self.layer_names:
+            layer = getattr(self.global_model.model, name)
+            bound = 1.0 / (layer.weight.shape[1] * 16) ** 0.5
+            layer.bias.data.uniform_(-bound, bound)
+
+    def forward(self, x_nchw):
+        """(N, cond_nc, H, W) -> [patch logits (N, 1, h, w)]   (PatchDiscriminator.forward)."""
+        x = F.pad(x_nchw.permute(0, 2, 3, 1), (0, 8 - x_nchw.shape[1])).contiguous()
+        L = self.global_model.model
+        n = len(self.layer_names)
+        for i, name in enumerate(self.layer_names):
+            layer = getattr(L, name)
+            stride = 2 if i < self.n_layers else 1
+            if i == 0:
+                x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=8, need_dx=False), 0.2)
+            elif i < n - 1:
+                x = F.leaky_relu(instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1)), 0.2)
+            else:
+                x = conv(x, layer.weight, layer.bias, stride=stride, pad=1, n_pad=64)
+        return [x.permute(0, 3, 1, 2)]
+
+
+def lsgan_loss(outs, target):
+    """criterions/ganloss.py:7-21."""
+    return sum(torch.mean((o - target) ** 2) for o in outs) / len(outs)
+
+
+def tv_loss(mat):
+    """criterions/generals.py:7-13."""
+    return torch.mean(torch.abs(mat[:, :, :, :-1] - mat[:, :, :, 1:])) + torch.mean(torch.abs(mat[:, :, :-1, :] - mat[:, :, 1:, :]))
+
+
+def allreduce_grads(params, group=None):
+    """Average the gradients of ``params`` over the ranks with ONE all-reduce of a flat fp32 buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class TrainOpts(object):
+    """deploy.toml:76-102 defaults (use_vgg / use_face off: their checkpoints are not available offline)."""
+    lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
+    lr_G, lr_D = 1e-4, 1e-4
+    G_adam_b1, G_adam_b2, D_adam_b1, D_adam_b2 = 0.9, 0.999, 0.9, 0.999
+
+
+class LWGTrainer(object):
+    """lwg_trainer.py:609-832 for bs = 1 sample per process, share_bg = True, temporal = False, use_gan = True."""
+
+    def __init__(self, G, D=None, opts=None, group=None):
+        self.G, self.D, self.group = G, D, group
+        self.opts = opts or TrainOpts()
+        self.tg = TrainableGenerator(G)
+        o = self.opts
+        self.optimizer_G = torch.optim.Adam(G.parameters(), lr=o.lr_G, betas=(o.G_adam_b1, o.G_adam_b2))
+        self.optimizer_D = None if D is None else torch.optim.Adam(D.parameters(), lr=o.lr_D, betas=(o.D_adam_b1, o.D_adam_b2))
+        self.losses = {}
+
+    def set_input(self, inputs):
+        """The tensors LWGTrainer.set_input (:624-697) leaves on the trainer:
+        input_G_bg (1,nb,4,h,w), input_G_src (1,ns,6,h,w), input_G_tsf (1,nt,6,h,w), Tst (1,nt,ns,h,w,2),
+        real_src (1,ns,3,h,w), real_tsf (1,nt,3,h,w), real_bg (nb,3,h,w), body_mask (1,ns+nt,1,h,w)."""
+        self.inp = inputs
+
+    def forward(self):
+        """:699-730."""
+        i = self.inp
+        fake_bg, src_color, src_mask, tsf_color, tsf_mask = self.tg.forward(i["input_G_bg"], i["input_G_src"], i["input_G_tsf"], i["Tst"])
+        fake_src_imgs = src_mask * fake_bg + (1 - src_mask) * src_color             # share_bg: (1,1,3,h,w) broadcasts
+        fake_tsf_imgs = tsf_mask * fake_bg + (1 - tsf_mask) * tsf_color
+        return fake_bg, fake_src_imgs, fake_tsf_imgs, torch.cat([src_mask, tsf_mask], dim=1)
+
+    def optimize_G(self, fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks):
+        """:732-789 (use_vgg None -> crt_tsf = L1; use_face off)."""
+        i, o = self.inp, self.opts
+        bs, nt, c, h, w = fake_tsf_imgs.shape
+        fake_tsf = fake_tsf_imgs.view(bs * nt, c, h, w)
+        real_tsf = i["real_tsf"].view(bs * nt, c, h, w)
+        loss_adv = 0.0
+        if self.D is not None:
+            tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
+            loss_adv = lsgan_loss(self.D(torch.cat([fake_tsf, tsf_cond], dim=1)), 0) * o.lambda_D_prob
+        loss_rec = (F.l1_loss(fake_src_imgs, i["real_src"]) + F.l1_loss(fake_bg.view(-1, 3, h, w), i["real_bg"])) / 2 * o.lambda_rec
+        loss_tsf = F.l1_loss(fake_tsf, real_tsf) * o.lambda_tsf
+        fm = fake_masks.view(-1, 1, h, w)
+        loss_mask = F.binary_cross_entropy(fm, i["body_mask"].view(-1, 1, h, w)) * o.lambda_mask
+        loss_smooth = tv_loss(fm) * o.lambda_mask_smooth
+        self.losses.update(g_rec=loss_rec, g_tsf=loss_tsf, g_adv=loss_adv, g_mask=loss_mask, g_mask_smooth=loss_smooth)
+        return loss_rec + loss_tsf + loss_adv + loss_mask + loss_smooth
+
+    def optimize_D(self, fake_tsf_imgs):
+        """:791-832."""
+        i = self.inp
+        bs, nt, c, h, w = fake_tsf_imgs.shape
+        tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
+        fake_in = torch.cat([fake_tsf_imgs.detach().view(bs * nt, c, h, w), tsf_cond], dim=1)
+        real_in = torch.cat([i["real_tsf"].reshape(bs * nt, c, h, w), tsf_cond], dim=1)
+        d_real, d_fake = self.D(real_in), self.D(fake_in)
+        self.losses.update(d_real=sum(o.mean() for o in d_real).detach(), d_fake=sum(o.mean() for o in d_fake).detach())
+        return lsgan_loss(d_real, 1) + lsgan_loss(d_fake, -1)
+
+    def optimize_parameters(self):
+        """:326-352, plus the gradient all-reduce when the step is data parallel."""
+        fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
+        loss_G = self.optimize_G(fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
+        self.optimizer_G.zero_grad(set_to_none=True)
+        if self.D is not None:
+            self.optimizer_D.zero_grad(set_to_none=True)       # G's adversarial term also reaches D's leaves; dropped below
+        loss_G.backward()
+        allreduce_grads(list(self.G.parameters()), self.group)
+        self.optimizer_G.step()
+        loss_D = None
+        if self.D is not None:
+            self.optimizer_D.zero_grad(set_to_none=True)
+            loss_D = self.optimize_D(fake_tsf_imgs)
+            loss_D.backward()
+            allreduce_grads(list(self.D.parameters()), self.group)
+            self.optimizer_D.step()
+        return loss_G.detach(), None if loss_D is None else loss_D.detach()

@@ -580,8 +580,89 @@ def check_generator_training_grads():
     return m
 
 
+def _ref_patch_discriminator(D):
+    """The reference's PatchDiscriminator (patch_dis.py:8-70, norm_type='instance') rebuilt on the CPU with D's weights."""
+    import torch.nn as nn
+    L = D.global_model.model
+    seq, names = [], D.layer_names
+    for i, name in enumerate(names):
+        w = getattr(L, name).weight.detach().cpu()
+        c = nn.Conv2d(w.shape[1], w.shape[0], 4, stride=2 if i < D.n_layers else 1, padding=1)
+        c.weight.data.copy_(w)
+        c.bias.data.copy_(getattr(L, name).bias.detach().cpu())
+        seq.append(c)
+        if 0 < i < len(names) - 1:
+            seq.append(nn.InstanceNorm2d(w.shape[0], affine=False))
+        if i < len(names) - 1:
+            seq.append(nn.LeakyReLU(0.2))
+    return nn.Sequential(*seq)
+
+
+def check_discriminator_and_trainer_step():
+    """patch_global discriminator forward/backward vs the reference architecture on the CPU (torch autograd), then two
+    full LWGTrainer.optimize_parameters() steps (G + D, Adam) on synthetic inputs: finite, and the G loss goes down."""
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator
+    torch.manual_seed(0)
+    D = PatchGlobalDiscriminator().to(DEV)
+    ref = _ref_patch_discriminator(D)
+    x = _rand((1, 6, 128, 128), 600)
+    xr = x.clone().requires_grad_(True)
+    out_r = ref(xr)
+    (out_r ** 2).mean().backward()
+    xd = x.to(DEV)
+    out = D(xd)[0]
+    (out ** 2).mean().backward()
+    torch.cuda.synchronize()
+    m = {"d_out": _cmp(out, out_r.detach(), 2e-4, "D logits")}
+    convs = [mod for mod in ref if isinstance(mod, torch.nn.Conv2d)]
+    worst = 0.0
+    gmax = max(c.weight.grad.abs().max().item() for c in convs)
+    for name, c in zip(D.layer_names, convs):
+        layer = getattr(D.global_model.model, name)
+        for a_, b_ in ((layer.weight.grad, c.weight.grad), (layer.bias.grad, c.bias.grad)):
+            worst = max(worst, (a_.cpu() - b_).abs().max().item() / max(b_.abs().max().item(), 1e-3 * gmax))
+    m["d_worst_rel_grad_err"] = worst
+    assert worst <= 2e-3, m
+    assert sum(p.numel() for p in D.parameters()) == 6962625            # SURVEY appendix B: D (patch_global) parameters
+    # trainer steps
+    S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
+    sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.to(DEV).train()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed, name), device=DEV)      # noqa: E731
+    inp = {"input_G_bg": u((1, 1, 4, S, S), 10, "bg_inputs"), "input_G_src": u((1, ns, 6, S, S), 8, "src_inputs"),
+           "input_G_tsf": u((1, 1, 6, S, S), 9, "tsf_inputs"), "Tst": torch.tensor(g["render/Tst"], device=DEV).view(1, 1, ns, S, S, 2),
+           "real_src": u((1, ns, 3, S, S), 700, "real_src"), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
+           "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
+    D2 = PatchGlobalDiscriminator().to(DEV)
+    tr = LWGTrainer(G, D2)
+    tr.set_input(inp)
+    hist = []
+    for _ in range(3):
+        lg, ld = tr.optimize_parameters()
+        hist.append((lg.item(), ld.item()))
+    torch.cuda.synchronize()
+    m["gan_loss_history"] = hist
+    assert all(np.isfinite(v) for pair in hist for v in pair), hist          # (a GAN loss need not be monotone)
+    # without the adversarial term the objective is a plain regression: Adam at lr 1e-4 must make progress
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    tr = LWGTrainer(G, None)
+    tr.set_input(inp)
+    rec = [tr.optimize_parameters()[0].item() for _ in range(6)]
+    m["rec_loss_history"] = rec
+    assert all(np.isfinite(v) for v in rec) and rec[-1] < rec[0], rec
+    # the fine-tuned weights must still drive the inference engine (same parameter tree, panels repacked on version change)
+    G.eval()
+    img, mask = G.forward_tsf(inp["input_G_tsf"][:, 0], *G.forward_src(inp["input_G_src"], only_enc=True), inp["Tst"][:, 0].contiguous())
+    assert torch.isfinite(img).all() and torch.isfinite(mask).all()
+    return m
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads]
+       check_generator_training_grads, check_discriminator_and_trainer_step]

@@ -102,3 +102,33 @@ def test_all_gather_frames_gloo_world2(tmp_path, n):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+_GRAD_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ipercore_amd.trainers import allreduce_grads
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2, 2))]
+for i, p in enumerate(ps[:2]):
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+allreduce_grads(ps)                      # ps[2] has no gradient: skipped
+assert torch.allclose(ps[0].grad, torch.full((3, 5), 1.5)) and torch.allclose(ps[1].grad, torch.full((7,), 3.0)) and ps[2].grad is None
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_allreduce_grads_gloo_world2(tmp_path):
+    """The personalization step's data-parallel exchange: one flat all-reduce, mean over the ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "g.py"
+    script.write_text(_GRAD_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
