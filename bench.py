@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide); the bf16-operand kernel is L2/HBM bound, far below it
 
 
 class ConvTimer:
@@ -162,8 +163,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)   # the shader clock needs ~0.2 s of load to settle
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--frame-batch", type=int, default=8)
+    ap.add_argument("--frame-batch", type=int, default=0,
+                    help="frames per launch batch; 0 = 8 at 512x512 scaled by (512/size)^2 (the 64x64-feature layers need "
+                         ">= 32768 GEMM rows to give every CU two 128x128 tiles), clamped to [2, 64]")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="bf16: BASELINE configs[3] mode - bf16 MFMA operands in the convs (fp32 activations / accumulation); "
+                         "the headline metric (configs[1]) is fp32")
     ap.add_argument("--streams", type=int, default=1, help="frame batches in flight on separate HIP streams (see DESIGN.md 5)")
     ap.add_argument("--pipelined-streams", type=int, default=3,
                     help="extra (separately reported) measurement with this many frame batches in flight; 0/1 = skip")
@@ -185,10 +191,15 @@ def main():
 
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
-    FB, K, W, S = args.frame_batch, args.steps, args.warmup, args.size
+    S = args.size
+    FB = args.frame_batch or max(2, min(64, int(round(8 * (512.0 / S) ** 2))))
+    K, W = args.steps, args.warmup
     per_rank = (K + W) * FB
     case = pu.build_case(image_size=S, n_frames=per_rank * world, ns=2)
     im = pu.make_imitator(case, frame_batch=FB, device=dev)
+    if args.precision == "bf16":
+        im.generator.conv_precision = "bf16"
+        im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")          # sequence-global pre-pass, every rank identically
     lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
     mine = tgt[lo:hi].contiguous()
@@ -246,11 +257,15 @@ def main():
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
         frames = K * FB * world
         line = {
-            "metric": "synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}",
+            "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}")
+                      + ("" if args.precision == "fp32" else " [bf16 MFMA conv tiles]"),
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 activations + accumulation",
+            "data": "synthetic",
+            "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])"
+                       if args.precision == "fp32" else
+                       f"per-frame path {S}x{S}, AttLWB-SPADE generator with bf16 MFMA conv tiles (BASELINE configs[3] precision mode)",
                        "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
                        "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
                        "batches_in_flight": args.streams,
@@ -259,16 +274,18 @@ def main():
         if n_launch:
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by tools/pmc_round.sh (separate --pmc passes)
-            if S == 512 and FB == 8 and os.path.exists(tpath):
+            if S == 512 and FB == 8 and args.streams == 1 and args.precision == "fp32" and os.path.exists(tpath):
                 with open(tpath) as fp:
                     tj = json.load(fp)
                 traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
-                                "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
+                                "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)" if args.precision == "fp32" else
+                                "lwg_conv_igemm_bf16_kernel (bf16-operand MFMA implicit GEMM) + fp32 first layers",
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}

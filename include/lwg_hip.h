@@ -68,6 +68,11 @@ typedef struct LwgConvArgs {
 
 int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
 
+/* bf16-operand variant (BASELINE configs[3], "MFMA bf16 conv tiles"): same contract, except that args->w is the bf16 panel
+ * [ntaps*Cin/8][N][8] (same K order) and Cin % 32 == 0; activations stay fp32 in memory, are rounded to bf16 while staged
+ * into LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16). */
+int lwg_conv2d_nhwc_bf16mma(const LwgConvArgs* args, lwg_stream_t stream);
+
 /* Backward of the same convolutions (personalization step, tools/trainers/lwg_trainer.py:326-352: loss.backward()
  * through torch.nn.Conv2d / ConvTranspose2d).
  * lwg_conv2d_wgrad_nhwc_f32: dW[K,N] = A[M,K]^T dY[M,N] on the matrix cores.  `args` is the FORWARD launch description

@@ -32,6 +32,7 @@
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
+#include "lwg_conv_epilogue.h"
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
@@ -321,72 +322,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         step(c0{}, std::false_type{}, t);
     }
 
-    // ---- epilogue.  The MFMAs computed D^T (weights as the row operand), so a lane owns ONE output pixel
-    // m = lane&31 of each 32x32 tile and 16 channels n = 8*(r>>2) + 4*(lane>>5) + (r&3): four float4 per tile,
-    // channel-contiguous in NHWC -> 16-byte stores, pixel index math once per row tile.
-    const bool direct = (a.omul == 1) && (a.YH == a.OH) && (a.YW == a.OW);
-    const int ncol0 = n_base + wn * TN * 32 + 4 * khalf;  // + 32*j + 8*g
-    floatx4 bias4[TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bias4[j][g] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias4[j][g] = *reinterpret_cast<const floatx4*>(a.bias + ncol0 + 32 * j + 8 * g);
-        }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m_base + wm * TM * 32 + i * 32 + (lane & 31);
-        if (m >= a.M) continue;
-        size_t opix = (size_t)m;
-        int bimg = 0;
-        if (!direct || EPI == LWG_EPI_SPADE) {
-            const int b = m / HW;
-            bimg = b;
-            if (!direct) {
-                const int rem = m - b * HW;
-                const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
-            }
-        }
-        if (EPI == LWG_EPI_SPADE) {
-            // wave columns [0,32) = gamma, [32,64) = beta of the same 32 channels (host packs them so)
-            static_assert(EPI != LWG_EPI_SPADE || TN == 2, "SPADE epilogue needs gamma|beta in one wave");
-            const int ch0 = ((n_base + wn * TN * 32) >> 1) + 4 * khalf;
-            const float* xr = a.xn + opix * a.YC + ch0;
-            const float* mr = a.mean + (size_t)bimg * a.YC + ch0;
-            const float* rr = a.rstd + (size_t)bimg * a.YC + ch0;
-            float* yr = a.y + opix * a.YC + ch0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 xv = *reinterpret_cast<const floatx4*>(xr + 8 * g);
-                const floatx4 mu = *reinterpret_cast<const floatx4*>(mr + 8 * g);
-                const floatx4 rs = *reinterpret_cast<const floatx4*>(rr + 8 * g);
-                floatx4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float gm = acc[i][0][4 * g + c] + bias4[0][g][c];
-                    const float bt = acc[i][TN - 1][4 * g + c] + bias4[TN - 1][g][c];
-                    o[c] = lwg_act((xv[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
-                }
-                *reinterpret_cast<floatx4*>(yr + 8 * g) = o;
-            }
-        } else {
-            float* yr = a.y + opix * a.YC + a.ycoff + ncol0;
-            const float* rr = EPI == LWG_EPI_RESIDUAL ? a.res + opix * a.YC + a.ycoff + ncol0 : nullptr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    floatx4 o;
-                    floatx4 rv = floatx4{0.f, 0.f, 0.f, 0.f};
-                    if (EPI == LWG_EPI_RESIDUAL) rv = *reinterpret_cast<const floatx4*>(rr + 32 * j + 8 * g);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c] + rv[c], a.act);
-                    *reinterpret_cast<floatx4*>(yr + 32 * j + 8 * g) = o;
-                }
-        }
-    }
+    lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>

@@ -167,6 +167,8 @@ class AttentionLWBGenerator(nn.Module):
         for name, child in tree.named_children():     # graft the tree's top-level nodes onto this module
             self.add_module(name, child)
         self._packed = None
+        # "bf16": convs run with bf16 MFMA operands (fp32 activations in memory, fp32 accumulation) - BASELINE configs[3]
+        self.conv_precision = "fp32"
 
     # ------------------------------------------------------------------ plumbing
     def packed(self):
@@ -184,7 +186,7 @@ class AttentionLWBGenerator(nn.Module):
 
     # ------------------------------------------------------------------ NHWC engine
     @torch.no_grad()
-    def encode_sources(self, src8, batched=False, ns=None):
+    def _encode_sources_impl(self, src8, batched=False, ns=None):
         """src8: (n, S, S, 8) NHWC (6 used) -> SourceFeatures with K/V panels for the 9 AttLWB sites."""
         pk = self.packed()
         x = src8
@@ -225,7 +227,7 @@ class AttentionLWBGenerator(nn.Module):
         return y
 
     @torch.no_grad()
-    def run_tsf(self, tsf8, feats, Tst, bg=None, want_pred=True, want_mask=True, want_img=False):
+    def _run_tsf_impl(self, tsf8, feats, Tst, bg=None, want_pred=True, want_mask=True, want_img=False):
         """tsf8 (B,S,S,8) NHWC; feats: SourceFeatures; Tst (B,ns,S,S,2) -> (pred, mask, img) NCHW (None if not asked)."""
         pk = self.packed()
         scratch = _Scratch()
@@ -253,7 +255,7 @@ class AttentionLWBGenerator(nn.Module):
         return ops.head_compose(x, pk.head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img)
 
     @torch.no_grad()
-    def run_bg(self, bg4):
+    def _run_bg_impl(self, bg4):
         """bg4 (n,S,S,4) NHWC -> (n,3,S,S) NCHW."""
         pk = self.packed()
         scratch = _Scratch()
@@ -281,13 +283,29 @@ class AttentionLWBGenerator(nn.Module):
                 return ops.nhwc_to_nchw(y, channels=3)
 
     @torch.no_grad()
-    def run_src_decode(self, x):
+    def _run_src_decode_impl(self, x):
         """SIDNet decoder + regressors on the last res-block feature (forward_src(only_enc=False))."""
         pk = self.packed()
         for specs in pk.src_dec:
             x = self._upconv(x, specs, ops.ACT_RELU)
         _, mask, img = ops.head_compose(x, pk.src_head, None, want_pred=False, want_mask=True, want_img=True)
         return img, mask
+
+    def encode_sources(self, *a, **k):
+        with ops.conv_precision(self.conv_precision):
+            return self._encode_sources_impl(*a, **k)
+
+    def run_tsf(self, *a, **k):
+        with ops.conv_precision(self.conv_precision):
+            return self._run_tsf_impl(*a, **k)
+
+    def run_bg(self, *a, **k):
+        with ops.conv_precision(self.conv_precision):
+            return self._run_bg_impl(*a, **k)
+
+    def run_src_decode(self, *a, **k):
+        with ops.conv_precision(self.conv_precision):
+            return self._run_src_decode_impl(*a, **k)
 
     # ------------------------------------------------------------------ reference API (NCHW)
     @torch.no_grad()

@@ -24,6 +24,25 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
+CONV_PRECISION = "fp32"    # "bf16": convs with Cin % 32 == 0 run on the bf16-operand MFMA kernel (fp32 activations/accumulation)
+
+
+class conv_precision(object):
+    """Context manager: ``with ops.conv_precision("bf16"): ...``."""
+
+    def __init__(self, mode):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        global CONV_PRECISION
+        self.prev, CONV_PRECISION = CONV_PRECISION, self.mode
+
+    def __exit__(self, *exc):
+        global CONV_PRECISION
+        CONV_PRECISION = self.prev
+
+
 CONV_HOOK = None     # bench.py installs a callable(begin, M, spec, epi) to bracket conv launches with HIP events
 
 
@@ -33,7 +52,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -43,11 +62,21 @@ class ConvSpec:
         self.dy = [int(t[0]) for t in taps]
         self.dx = [int(t[1]) for t in taps]
         self.stride, self.omul, self.ooy, self.oox = stride, omul, ooy, oox
+        self._w16 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
             assert q in (1, 2, 4), "small-Cin path handles Cin in {4, 8, 16}"
             self.cshift = q.bit_length() - 1
+
+
+def _w16(spec):
+    """The bf16 panel [K/8][N][8] of a spec (same K order as the fp32 panel [K/4][N][4]), built once."""
+    if spec._w16 is None or spec._w16.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
+        spec._w16 = wk.view(K4 // 2, 8, N).permute(0, 2, 1).contiguous().to(torch.bfloat16)
+    return spec._w16
 
 
 def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
@@ -84,7 +113,11 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec, epi)
-    _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+    if CONV_PRECISION == "bf16" and spec.Cin % 32 == 0:
+        a.w = _ptr(_w16(spec), torch.bfloat16)
+        _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16mma(a, _stream()), "lwg_conv2d_nhwc_bf16mma")
+    else:
+        _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
         CONV_HOOK(False, a.M, spec, epi)
     return y

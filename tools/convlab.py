@@ -47,6 +47,9 @@ def load(path):
     h = ctypes.CDLL(os.path.abspath(path))
     h.lwg_conv2d_nhwc_f32.restype = ctypes.c_int
     h.lwg_conv2d_nhwc_f32.argtypes = [ctypes.POINTER(_lib.LwgConvArgs), ctypes.c_void_p]
+    if hasattr(h, "lwg_conv2d_nhwc_bf16mma"):
+        h.lwg_conv2d_nhwc_bf16mma.restype = ctypes.c_int
+        h.lwg_conv2d_nhwc_bf16mma.argtypes = [ctypes.POINTER(_lib.LwgConvArgs), ctypes.c_void_p]
     return h
 
 
@@ -82,10 +85,17 @@ def build_case(name):
     return x0, x1, y, launches
 
 
+BF16 = False
+
+
 def run(h, x0, x1, y, launches, stream):
     for spec, kw in launches:
         a = ops.conv_args(x0, spec, y, x1=x1, **kw)
-        e = h.lwg_conv2d_nhwc_f32(a, stream)
+        if BF16 and spec.Cin % 32 == 0:
+            a.w = ops._w16(spec).data_ptr()
+            e = h.lwg_conv2d_nhwc_bf16mma(a, stream)
+        else:
+            e = h.lwg_conv2d_nhwc_f32(a, stream)
         if e != 0:
             return e
     return 0
@@ -120,6 +130,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--bf16", action="store_true", help="after the fp32 pass of every lib, time its bf16-operand entry point too")
     args = ap.parse_args()
     libs = [(os.path.basename(p), load(p)) for p in args.libs]
     stream = torch.cuda.current_stream().cuda_stream
@@ -130,7 +141,9 @@ def main():
         flops = sum(2.0 * M * s.algo_kn for s, _ in launches)
         base = None
         us_hint = flops / 100e12 * 1e6
-        for lname, h in libs:
+        global BF16
+        todo = [(n_, h_, False) for n_, h_ in libs] + ([(n_ + " [bf16]", h_, True) for n_, h_ in libs] if args.bf16 else [])
+        for lname, h, BF16 in todo:
             y.fill_(float("nan"))
             e = run(h, x0, x1, y, launches, stream)
             torch.cuda.synchronize()
