@@ -64,6 +64,32 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
     return y
 
 
+def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
+    """CPU emulation of lwg_conv2d_wgrad_nhwc_f32: dW (ntaps*Cin, N) in the panel's K order (include/lwg_hip.h)."""
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    B, H, W, Cin = x.shape
+    YB, YH, YW, YC = dy.shape
+    OH, OW = out_hw if out_hw is not None else ((YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul))
+    ys = slice(spec.ooy, None, spec.omul) if spec.omul > 1 else slice(None)
+    xs = slice(spec.oox, None, spec.omul) if spec.omul > 1 else slice(None)
+    g = dy[:, ys, xs, ycoff:ycoff + spec.N][:, :OH, :OW].reshape(-1, spec.N)
+    oy, ox = torch.arange(OH) * spec.stride, torch.arange(OW) * spec.stride
+    rows = []
+    for t in range(spec.ntaps):
+        iy, ix = oy + spec.dy[t], ox + spec.dx[t]
+        vy, vx = (iy >= 0) & (iy < H), (ix >= 0) & (ix < W)
+        a = x[:, iy.clamp(0, H - 1)][:, :, ix.clamp(0, W - 1)] * (vy[:, None] & vx[None, :]).float()[None, :, :, None]
+        rows.append(a.reshape(-1, Cin).t().matmul(g))                      # (Cin, N) for tap t
+    dw = torch.stack(rows, dim=0)                                          # (ntaps, Cin, N), tap-major
+    if Cin % 32 == 0:
+        dw = dw.view(spec.ntaps, Cin // 32, 32, spec.N).permute(1, 0, 2, 3)
+    return dw.reshape(spec.ntaps * Cin, spec.N).contiguous()
+
+
+def colsum(x):
+    return x.reshape(-1, x.shape[-1]).sum(dim=0)
+
+
 def instnorm_stats(x, mean, rstd, ws, eps=1e-5, nsplit=None):
     B, H, W, C = x.shape
     v = x.reshape(B, H * W, C)
@@ -182,7 +208,7 @@ def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
-                 "smpl_lbs"):
+                 "smpl_lbs", "conv2d_wgrad", "colsum"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

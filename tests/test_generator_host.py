@@ -83,3 +83,47 @@ def test_cpu_tensors_fail_loudly():
 def test_unknown_network_name():
     with pytest.raises(ValueError):
         NetworksFactory.get_by_name("InputConcat", cfg=None)
+
+
+def test_training_conv_packing_cpu(monkeypatch):
+    """Host logic of the backward path on CPU: the dgrad panels (stride 1, stride 2 parity launches, transposed conv),
+    the wgrad K-order unpacking and ConvFn's plumbing (bias sums, channel padding, concat split), with the C ABI emulated
+    (tests/emu_ops.py), against torch autograd of F.conv2d / F.conv_transpose2d."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from ipercore_amd.networks import training as tr
+    emu_ops.install(monkeypatch)
+    monkeypatch.setattr(tr.ConvFn, "forward", staticmethod(_cpu_ok(tr.ConvFn.forward)))
+    rs = np.random.RandomState(3)
+    rnd = lambda *s: torch.tensor(rs.standard_normal(s).astype(np.float32))        # noqa: E731
+    cases = [("conv", 2, 8, 8, 64, 64, 3, 1, 1, 0, 1, None), ("conv", 1, 8, 8, 64, 128, 3, 2, 1, 0, 1, None),
+             ("conv", 1, 6, 6, 96, 64, 3, 1, 1, 32, 0, None), ("convT", 1, 4, 4, 64, 64, 4, 2, 1, 0, 1, None),
+             ("conv", 1, 8, 8, 64, 4, 5, 1, 2, 0, 0, 64), ("conv", 1, 8, 8, 64, 64, 4, 2, 1, 0, 0, None),
+             ("conv", 1, 9, 9, 64, 64, 4, 1, 1, 0, 0, None)]
+    for kind, B, H, W, Cin, N, k, stride, pad, C1, act, n_pad in cases:
+        w = rnd(*((N, Cin, k, k) if kind == "conv" else (Cin, N, 4, 4))) * 0.1
+        b = rnd(N) * 0.1
+        x = rnd(B, H, W, Cin)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xn = xr.permute(0, 3, 1, 2)
+        yr = F.conv2d(xn, wr, br, stride=stride, padding=pad) if kind == "conv" else F.conv_transpose2d(xn, wr, br, stride=2, padding=1)
+        yr = F.relu(yr) if act else yr
+        g = rnd(*yr.permute(0, 2, 3, 1).shape)
+        (yr.permute(0, 2, 3, 1) * g).sum().backward()
+        xd, wd, bd = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        x0, x1 = (xd, None) if not C1 else (xd[..., :Cin - C1], xd[..., Cin - C1:])
+        y = tr.conv(x0, wd, bd, x1=x1, kind=kind, stride=stride, pad=pad, act=act, n_pad=n_pad)
+        (y * g).sum().backward()
+        for name, a_, r_ in (("y", y, yr.permute(0, 2, 3, 1)), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+            err = (a_.detach() - r_.detach()).abs().max().item()
+            assert err <= 1e-4 * max(1.0, r_.abs().max().item()), (kind, k, stride, name, err)
+
+
+def _cpu_ok(fwd):
+    """ConvFn refuses CPU tensors on the product path; the host-logic test runs it on the emulated ABI."""
+    def wrapped(ctx, x0, x1, weight, bias, cfg):
+        import unittest.mock as um
+        with um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True):
+            return fwd(ctx, x0, x1, weight, bias, cfg)
+    return wrapped
