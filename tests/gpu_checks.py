@@ -683,8 +683,57 @@ def check_bf16_generator():
     return out
 
 
+def check_edge_cases():
+    """Ragged / degenerate inputs: image size not a multiple of the 16-px tile or the 64-px bin, a scene with every face
+    culled or off-screen (empty maps), flows that are background everywhere, a 1-frame batch, M not a multiple of 32."""
+    from oracle import lwg_oracle as orc
+    topo = mesh.load_topology()
+    t = pu.oracle_tables(topo)
+    cam, verts = _posed(2)
+    out = {}
+    for S in (100, 72):                                            # partial tiles, partial bins
+        fv = orc.project_faces(cam, verts, t["smpl_faces"])
+        fim_w, wim_w = orc.rasterize_fim_wim(fv.numpy(), S)
+        fim, wim = ops.rasterize_fim_wim(fv.to(DEV), S)
+        assert torch.equal(fim.cpu(), fim_w) and torch.equal(wim.cpu(), wim_w), f"raster mismatch at S={S}"
+        out[f"raster_S{S}_cover"] = float((fim_w >= 0).float().mean())
+    # empty scene: the mesh far off-screen, and the mesh mirrored (every face back-facing)
+    off = fv.clone()
+    off[..., 0] += 10.0
+    fim, wim = ops.rasterize_fim_wim(off.to(DEV), 64)
+    assert (fim == -1).all() and (wim == 0).all()
+    mir = fv.clone()
+    mir[..., 0] *= -1
+    fim_w, wim_w = orc.rasterize_fim_wim(mir.numpy(), 64)
+    fim, wim = ops.rasterize_fim_wim(mir.to(DEV), 64)
+    assert torch.equal(fim.cpu(), fim_w) and torch.equal(wim.cpu(), wim_w)
+    # flows of an empty map: every output of the fused consumer is the background value
+    S = 48
+    fimE = torch.full((1, S, S), -1, dtype=torch.int32)
+    wimE = torch.zeros(1, S, S, 3)
+    map_fn, fu = torch.tensor(t["map_fn"]), torch.tensor(t["f_uvs2img"])
+    uv4 = emu_ops.nchw_to_nhwc(torch.tensor(synthetic.uniform_image((1, 3, S, S), 6, "uv_img")), c_pad=4)[0].contiguous()
+    src = torch.zeros(2, 13776, 3, 2)
+    tsf, Tst, cond, tuv = ops.flow_compose(fimE.to(DEV), wimE.to(DEV), map_fn.to(DEV), fu.to(DEV), uv4.to(DEV), src.to(DEV), True, True)
+    assert (Tst == -2).all() and (tuv == -2).all() and (tsf[..., 0:3] == 0).all()
+    assert torch.equal(cond.cpu(), map_fn[-1].view(1, 3, 1, 1).expand(1, 3, S, S))
+    # attention with background flows everywhere: finite, equals softmax over the biases alone = mean of (bv) weights
+    C, h = 64, 12
+    q, bk, bv = _rand((1, h, h, C), 800).to(DEV), _rand((C,), 801).to(DEV), _rand((C,), 802).to(DEV)
+    Ks, Vs = _rand((2, h, h, C), 803).to(DEV), _rand((2, h, h, C), 804).to(DEV)
+    T = torch.full((1, 2, S, S, 2), -2.0, device=DEV)
+    att = ops.lwb_attention(q, Ks, Vs, bk, bv, T, torch.empty(1, h, h, C, device=DEV))
+    assert torch.isfinite(att).all() and (att - bv.view(1, 1, 1, C)).abs().max().item() <= 1e-5
+    # conv with M = 5*7 = 35 rows (one partial tile) and a 1-frame LBS batch
+    out["conv_m35"] = _conv_case("M=35", 1, 5, 7, 64, 64, 3, 1, 1, 810)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=1, bg_filters=[64, 64, 128], n_frames=1, ns=2)
+    pred = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=4))      # batch larger than the clip
+    assert pred.shape == (1, 3, 64, 64) and torch.isfinite(pred).all()
+    return out
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases]
