@@ -28,6 +28,8 @@
 // consecutive channels of each 32x32 tile, so the epilogue issues 16-byte NHWC stores and does the pixel
 // index math once per row tile.
 // Epilogues fuse bias, ReLU/tanh/sigmoid, the residual add, or SPADE's IN(x)*(1+gamma)+beta.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "lwg_common.h"
@@ -344,6 +346,17 @@ static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream) {
 
 template <int EPI, bool SMALLC>
 static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream) {
+    // small launches (one training sample, short clips): 128x128 tiles would leave most of the 256 CUs idle - 64x64 tiles
+    // quadruple the workgroup count (each wave then owns one 32x32 MFMA tile: fewer flops per staged byte, but it runs)
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if constexpr (EPI != LWG_EPI_SPADE && !SMALLC) {
+        static long small_thr = -1;
+        if (small_thr < 0) {
+            const char* ev = getenv("LWG_CONV_SMALL_TILES");   // tuning knob
+            small_thr = ev ? atol(ev) : 300;
+        }
+        if (tiles128 < small_thr) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream);  // 64 x 64
+    }
     if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg<2, 2, 2, 2, EPI, SMALLC>(a, stream);  // 128 x 128
     return launch_cfg<4, 1, 1, 2, EPI, SMALLC>(a, stream);                                                // 128 x 64
 }

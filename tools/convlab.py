@@ -40,6 +40,11 @@ SHAPES = {
     "enc1":     (8, 256, 256, 64, 0, 128, 3, 2, "conv"),      # stride-2 encoder
     "enc0":     (8, 512, 512, 8, 0, 64, 3, 2, "small"),       # first layer, Cin 6 -> 8
     "resres":   (8, 64, 64, 256, 0, 256, 3, 1, "res"),        # residual epilogue
+    # one training sample / 1-frame batches
+    "res64_b1": (1, 64, 64, 256, 0, 256, 3, 1, "conv"),
+    "res64_b2": (2, 64, 64, 256, 0, 256, 3, 1, "conv"),
+    "sh128_b1": (1, 128, 128, 128, 0, 128, 3, 1, "conv"),
+    "skip1_b1": (1, 256, 256, 64, 128, 128, 3, 1, "conv"),
 }
 
 
