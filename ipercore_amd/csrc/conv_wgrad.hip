@@ -16,6 +16,8 @@
 //     supply reduction index 2s, lanes 32-63 index 2s+1, so a fragment is one ds_read_b32 of a [m][k] row.
 //   * The reduction is split over gridDim.y workgroups; each writes its partial tile to a workspace slab and
 //     lwg_wgrad_reduce adds the slabs in slab order (deterministic - no float atomics).
+#include <type_traits>
+
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
         int tap, c;
         const int k0 = k_base + g * 32;                  // first k of the group
         gok[g] = k0 < Ktot;
-        if (SMALLC) {
+        bool use1 = false;                               // workgroup-uniform (a 32-channel chunk never straddles x0 | x1):
+        if (SMALLC) {                                    // keeps the buffer descriptor in SGPRs - no waterfall loop
             const int k4 = (k0 >> 2) + kq;               // this lane's k-quad: tap and channel depend on the lane
             tap = k4 >> a.cshift;
             c = (k4 & ((1 << a.cshift) - 1)) * 4;
@@ -72,12 +75,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
             const int cchunk = G / a.ntaps;
             tap = G - cchunk * a.ntaps;
             c = cchunk * 32 + kq * 4;
+            use1 = cchunk * 32 >= a.C0;
         }
         const int tp = gok[g] ? tap : 0;
         const int packed = taptab[tp];
         gdy[g] = (int)(short)(packed & 0xffff);
         gdx[g] = packed >> 16;
-        const bool use1 = c >= a.C0;
         gsrc[g] = use1 ? a.x1 : a.x0;
         gbytes[g] = use1 ? bytes1 : bytes0;
         gcs[g] = use1 ? a.C1 : a.C0;
@@ -86,30 +89,63 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
     const int HW = a.OH * a.OW;
     const bool direct = (a.omul == 1) && (a.YH == a.OH) && (a.YW == a.OW);
 
+    const int nchunks_total = (a.M + BR - 1) / BR;
+    const int c_begin = blockIdx.y * chunks_per_split;
+    const int c_end = min(nchunks_total, c_begin + chunks_per_split);
+
+    // this thread's GEMM row of the chunk being loaded: (image, oy, ox), advanced by 32 rows per chunk without divisions
+    int rm = c_begin * BR + mrow;
+    int rb, roy, rox;
+    {
+        const int mm = rm < a.M ? rm : 0;
+        rb = mm / HW;
+        const int rem = mm - rb * HW;
+        roy = rem / a.OW;
+        rox = rem - roy * a.OW;
+    }
     floatx4 rx[4], ry[4];
-    auto gload = [&](int chunk) {
-        const int m = chunk * BR + mrow;
-        const bool mok = m < a.M;
-        const int mm = mok ? m : 0;
-        const int b = mm / HW, rem = mm - b * HW;
-        const int oy = rem / a.OW, ox = rem - oy * a.OW;
-        const int iy0 = oy * a.stride, ix0 = ox * a.stride;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int iy = iy0 + gdy[g], ix = ix0 + gdx[g];
-            const bool ok = mok && gok[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const unsigned off = ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)gcs[g] + (unsigned)gcoff[g]) * 4u;
-            rx[g] = lwg_wg_buf_load(gsrc[g], gbytes[g], ok ? off : LWG_OOB_OFFSET);
+    // The eight loads of a chunk are issued as eight separate pieces between the MFMAs of the current chunk.
+    // row_setup(): per-chunk base offsets of this thread's row; load_piece(i): i < 4 activation group i, else dY quad i-4.
+    const unsigned tapb[4] = {   // (tap offset in pixels) * channels of the group's source * 4 + channel offset * 4  (constants)
+        (unsigned)((gdy[0] * a.W + gdx[0]) * gcs[0] + gcoff[0]) * 4u, (unsigned)((gdy[1] * a.W + gdx[1]) * gcs[1] + gcoff[1]) * 4u,
+        (unsigned)((gdy[2] * a.W + gdx[2]) * gcs[2] + gcoff[2]) * 4u, (unsigned)((gdy[3] * a.W + gdx[3]) * gcs[3] + gcoff[3]) * 4u};
+    bool r_ok = false;
+    int r_iy0 = 0, r_ix0 = 0;
+    unsigned r_pix = 0, r_yoff = 0;
+    auto row_setup = [&]() {
+        r_ok = rm < a.M;
+        r_iy0 = roy * a.stride;
+        r_ix0 = rox * a.stride;
+        r_pix = (unsigned)((rb * a.H + r_iy0) * a.W + r_ix0);
+        const size_t opix = direct ? (size_t)rm : ((size_t)rb * a.YH + (roy * a.omul + a.ooy)) * a.YW + (rox * a.omul + a.oox);
+        r_yoff = (unsigned)((opix * a.YC + a.ycoff + n_base + kq * 4) * 4u);
+        rm += BR;                                       // advance to the next chunk's row
+        rox += BR;
+        while (rox >= a.OW) {
+            rox -= a.OW;
+            if (++roy == a.OH) { roy = 0; ++rb; }
         }
-        size_t opix = (size_t)mm;
-        if (!direct) opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n_base + (kq + 8 * j) * 4;
-            const bool ok = mok && n < a.N;
-            const unsigned off = (unsigned)((opix * a.YC + a.ycoff + n) * 4u);
-            ry[j] = lwg_wg_buf_load(dy_, ybytes, ok ? off : LWG_OOB_OFFSET);
+    };
+    auto load_piece = [&](int i) {
+        if (i < 4) {
+            const int iy = r_iy0 + gdy[i], ix = r_ix0 + gdx[i];
+            const bool ok = r_ok && gok[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const unsigned off = r_pix * (unsigned)(gcs[i] * 4) + tapb[i];
+            rx[i] = lwg_wg_buf_load(gsrc[i], gbytes[i], ok ? off : LWG_OOB_OFFSET);
+        } else {
+            const int j = i - 4;
+            const bool ok = r_ok && n_base + (kq + 8 * j) * 4 < a.N;
+            ry[j] = lwg_wg_buf_load(dy_, ybytes, ok ? r_yoff + 128u * j : LWG_OOB_OFFSET);
         }
+    };
+    auto gload = [&]() {
+        row_setup();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) load_piece(i);
+    };
+    auto store_piece = [&](int buf, int i) {
+        if (i < 4) *reinterpret_cast<floatx4*>(Xs + buf * STAGE + mrow * ROW + kq * 4 + i * 32) = rx[i];
+        else *reinterpret_cast<floatx4*>(Ys + buf * STAGE + mrow * ROW + kq * 4 + (i - 4) * 32) = ry[i - 4];
     };
     auto lstore = [&](int buf) {
         float* xb = Xs + buf * STAGE + mrow * ROW + kq * 4;
@@ -128,33 +164,71 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks_total = (a.M + BR - 1) / BR;
-    const int c_begin = blockIdx.y * chunks_per_split;
-    const int c_end = min(nchunks_total, c_begin + chunks_per_split);
     const int khalf = lane >> 5;
     const float* fx = Xs + khalf * ROW + wk * 64 + (lane & 31);
     const float* fy = Ys + khalf * ROW + wn * 64 + (lane & 31);
+    // fragments of reduction step s: one scalar per operand tile (lanes 0-31: row 2s, lanes 32-63: row 2s+1)
+    float fa[2][2], fb[2][2];
+    auto read_frags = [&](int buf, int s_, int set) {
+        fa[set][0] = fx[buf * STAGE + 2 * s_ * ROW];
+        fa[set][1] = fx[buf * STAGE + 2 * s_ * ROW + 32];
+        fb[set][0] = fy[buf * STAGE + 2 * s_ * ROW];
+        fb[set][1] = fy[buf * STAGE + 2 * s_ * ROW + 32];
+    };
+    auto mfma4 = [&](int set) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][1], acc[1][1], 0, 0, 0);
+    };
 
     if (c_begin < c_end) {
-        gload(c_begin);
+        gload();
         lstore(0);
         __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int cur = (c - c_begin) & 1;
-            if (c + 1 < c_end) gload(c + 1);
-            const float* px = fx + cur * STAGE;
-            const float* py = fy + cur * STAGE;
+        read_frags(0, 0, 0);
+        // the chunk loop is unrolled by two so the LDS stage is a compile-time constant (base register + immediate)
+        auto chunk = [&](auto cur_c, auto next_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            constexpr bool NEXT = decltype(next_c)::value;
+            if (NEXT) row_setup();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < BR / 2; ++s) {
-                const float a0 = px[2 * s * ROW], a1 = px[2 * s * ROW + 32];
-                const float b0 = py[2 * s * ROW], b1 = py[2 * s * ROW + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int s_ = 0; s_ < BR / 2 - 1; ++s_) {    // fragments of step s+1 in flight during the MFMAs of step s
+                read_frags(CUR, s_ + 1, (s_ + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4(s_ & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (NEXT && s_ < 4) {                    // loads of the next chunk: two pieces after each of the first steps
+                    load_piece(2 * s_);
+                    load_piece(2 * s_ + 1);
+                }
+                if (NEXT && s_ >= 11) {                  // ... and their LDS stores in the shadow of the last steps
+                    store_piece(CUR ^ 1, 2 * (s_ - 11));
+                    store_piece(CUR ^ 1, 2 * (s_ - 11) + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (c + 1 < c_end) lstore(cur ^ 1);
-            __syncthreads();
+            if (NEXT) {
+                __syncthreads();
+                read_frags(CUR ^ 1, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(1);                                    // reduction step 15 (fragment set 1), covering the reads above
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using k0 = std::integral_constant<int, 0>;
+        using k1 = std::integral_constant<int, 1>;
+        int c = c_begin;
+        for (; c + 2 < c_end; c += 2) {
+            chunk(k0{}, std::true_type{});
+            chunk(k1{}, std::true_type{});
+        }
+        if (c_end - c == 2) {
+            chunk(k0{}, std::true_type{});
+            chunk(k1{}, std::false_type{});
+        } else {
+            chunk(k0{}, std::false_type{});
         }
     }
     // ---- partial tile -> workspace slab blockIdx.y.  Lane owns column n = lane&31, rows k = (r&3) + 8*(r>>2) + 4*khalf ----
@@ -197,14 +271,15 @@ __global__ __launch_bounds__(256) void lwg_colsum_partial_kernel(const float* __
     if (w == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-// Reduction splits: enough workgroups to fill the 256 CUs twice (2 workgroups/CU), at most 16 slabs (every slab is
-// written and read once more by the reduction), at least 8 chunks of 32 rows per workgroup.
+// Reduction splits: enough workgroups to fill the 256 CUs twice (2 workgroups/CU), at most 48 MB of slabs (every slab is
+// written and read once more by the reduction), at least 4 chunks of 32 rows per workgroup.
 static int lwg_wgrad_splits(int Ktot, int N, int M) {
     const int tiles = ((Ktot + 127) / 128) * ((N + 127) / 128);
     const int nchunks = (M + 31) / 32;
-    int splits = (512 + tiles - 1) / tiles;
-    if (splits > 16) splits = 16;
-    if (splits > nchunks / 8) splits = nchunks / 8;
+    int splits = 512 / tiles;          // tiles * splits <= 512 = one full wave of workgroups at 2 per CU (no ragged second wave)
+    const long slab = (long)Ktot * N * 4;
+    if ((long)splits * slab > (48l << 20)) splits = (int)((48l << 20) / slab);     // <= 48 MB of slabs per launch
+    if (splits > nchunks / 4) splits = nchunks / 4;
     if (splits < 1) splits = 1;
     return splits;
 }

@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--wgrad", action="store_true", help="time lwg_conv2d_wgrad_nhwc_f32 (weight gradient) of the first launch instead")
     ap.add_argument("--bf16", action="store_true", help="after the fp32 pass of every lib, time its bf16-operand entry point too")
     args = ap.parse_args()
     libs = [(os.path.basename(p), load(p)) for p in args.libs]
@@ -148,6 +149,31 @@ def main():
         us_hint = flops / 100e12 * 1e6
         global BF16
         todo = [(n_, h_, False) for n_, h_ in libs] + ([(n_ + " [bf16]", h_, True) for n_, h_ in libs] if args.bf16 else [])
+        if args.wgrad:
+            spec, kw = launches[0]
+            dy = torch.randn_like(y)
+            Ktot = spec.ntaps * spec.Cin
+            for lname, h in libs:
+                h.lwg_conv2d_wgrad_nhwc_f32.restype = ctypes.c_int
+                h.lwg_conv2d_wgrad_nhwc_f32.argtypes = [ctypes.POINTER(_lib.LwgConvArgs)] + [ctypes.c_void_p] * 4
+                h.lwg_conv2d_wgrad_ws_floats.restype = ctypes.c_size_t
+                a = ops.conv_args(x0, spec, dy, x1=x1)
+                dw = torch.empty(Ktot, spec.N, device=DEV)
+                ws = torch.empty(h.lwg_conv2d_wgrad_ws_floats(Ktot, spec.N, a.M), device=DEV)
+                call = lambda: h.lwg_conv2d_wgrad_nhwc_f32(a, dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), stream)   # noqa: E731
+                assert call() == 0
+                for _ in range(max(2, int(20000 / max(us_hint, 50.0)))):
+                    call()
+                s_, t_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                for _ in range(args.iters):
+                    call()
+                t_.record()
+                torch.cuda.synchronize()
+                us = s_.elapsed_time(t_) * 1e3 / args.iters
+                f1 = 2.0 * a.M * spec.algo_kn
+                print(f"{name:10s} {lname:24s} wgrad {us:9.1f} us  {f1 / us / 1e6:6.1f} TF/s  ({f1 / us / 1e6 / 157.3 * 100:4.1f}%)  ws {ws.numel() * 4 / 1e6:.0f} MB", flush=True)
+            continue
         for lname, h, BF16 in todo:
             y.fill_(float("nan"))
             e = run(h, x0, x1, y, launches, stream)
