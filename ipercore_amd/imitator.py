@@ -32,6 +32,42 @@ def _opt_get(opt, key, default=None):
     return getattr(opt, key, default)
 
 
+class TemporalFIFO(object):
+    """Ring of the last ``time_step`` synthesized frames (reference models/imitator.py:18-127): their projected faces
+    (for the Ttt flows, flowcomposition.py:569-579) and, per AttLWB site, the hoisted K / V projections of their SIDNet
+    features.  The ring lives in ONE preallocated K and V tensor per site laid out [ns sources | time_step slots], so the
+    attention kernel reads sources + temporal frames with no per-frame concatenation."""
+
+    def __init__(self, time_step, src_feats, src_f2pts):
+        self.time_step, self.index = time_step, 0
+        self.ns = src_feats.ns
+        self.f2pts = torch.cat([src_f2pts, src_f2pts.new_zeros((time_step,) + tuple(src_f2pts.shape[1:]))], dim=0)
+        self.kv = []
+        for k, v in src_feats.kv:
+            pad = k.new_zeros((time_step,) + tuple(k.shape[1:]))
+            self.kv.append((torch.cat([k, pad], dim=0), torch.cat([v, pad.clone()], dim=0)))
+        self.src_feats = src_feats
+
+    @property
+    def nt(self):
+        return min(self.index, self.time_step)
+
+    def append(self, f2pts, feats):
+        """f2pts (1,nf,3,2) of the frame just synthesized; feats: SourceFeatures of forward_src([pred, cond])."""
+        i = self.ns + self.index % self.time_step
+        self.f2pts[i:i + 1].copy_(f2pts)
+        for (K, V), (k, v) in zip(self.kv, feats.kv):
+            K[i:i + 1].copy_(k)
+            V[i:i + 1].copy_(v)
+        self.index += 1
+
+    def view(self):
+        """(f2pts (ns+nt,nf,3,2), SourceFeatures over ns+nt entries) - slots in ring order, as the reference concatenates."""
+        n = self.ns + self.nt
+        from .networks.generator import SourceFeatures
+        return self.f2pts[:n], SourceFeatures(self.src_feats.enc, self.src_feats.res, [(K[:n], V[:n]) for K, V in self.kv], n, False)
+
+
 class Imitator(object):
     def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8, streams=1):
         self._opt = opt
@@ -44,8 +80,8 @@ class Imitator(object):
         self.first_cam = None
         self.image_size = int(_opt_get(opt, "image_size", 512))
         self.temporal = bool(_opt_get(opt, "temporal", False))
-        if self.temporal:
-            raise NotImplementedError("temporal=True (TemporalFIFO) is a 'next' row (SURVEY 8f-4)")
+        self.time_step = int(_opt_get(opt, "time_step", 1))
+        self.temporal_fifo = None
         self._create_networks()
 
     def _create_networks(self):
@@ -198,6 +234,29 @@ class Imitator(object):
         return torch.cat(outs, dim=0)
 
     @torch.no_grad()
+    def synthesize_temporal(self, tgt_smpls, cam_strategy="smooth"):
+        """temporal=True (imitator.py:341-366): a recurrence - frame t attends to the sources and to the last ``time_step``
+        synthesized frames, so frames are produced one at a time (this mode does not shard over frames: replicas only)."""
+        src = self.src_info
+        key = "f2pts"
+        self.temporal_fifo = fifo = TemporalFIFO(self.time_step, src["feats_nhwc"], src[key].contiguous())
+        outs = []
+        for t in range(tgt_smpls.shape[0]):
+            if t == 0 and cam_strategy == "smooth" and self.first_cam is None:
+                self.first_cam = tgt_smpls[0:1, 0:3].clone()
+            ref_smpl = self.swap_params(src["cam"][0:1], src["shape"][0:1], tgt_smpls[t:t + 1], cam_strategy)
+            ref_info = self.body_rec.get_details(ref_smpl.contiguous(), src["offsets"], links_ids=src["links_ids"])
+            f2pts_all, feats = fifo.view()
+            tsf8, T, aux = self.flow_comp.frame_inputs(ref_info["cam"].contiguous(), ref_info["verts"], src["uv_img4"],
+                                                       f2pts_all.contiguous(), want_aux=True)      # Tst | Ttt in one pass
+            pred, _, _ = self.generator.run_tsf(tsf8, feats, T, bg=src["bg"], want_pred=True, want_mask=True)
+            # post_update (:397-401): SIDNet features of [pred, cond] enter the ring
+            cur8 = ops.pack_inputs(pred, aux["cond"], None, 8)
+            fifo.append(aux["f2pts"], self.generator.encode_sources(cur8, batched=False, ns=1))
+            outs.append(pred)
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
     def prepare_sequence(self, tgt_smpls, cam_strategy="smooth"):
         """The sequence-global pre-pass of inference (imitator.py:335-339): to device, stabilise, fix first_cam."""
         self.first_cam = None
@@ -212,6 +271,15 @@ class Imitator(object):
                   visualizer=None, verbose=True):
         """imitator.py:327-382."""
         tgt = self.prepare_sequence(tgt_smpls, cam_strategy)
+        if self.temporal:
+            preds = self.synthesize_temporal(tgt, cam_strategy)
+            if output_dir:
+                from .output import FrameWriter
+                writer = FrameWriter(output_dir, prefix=prefix)
+                writer.submit(preds, 0)
+                return writer.close()
+            preds = preds.cpu().numpy()
+            return [preds[i] for i in range(preds.shape[0])]
         if output_dir:
             # device-side uint8 conversion + pinned async D2H + threaded PNG encoding: the frame loop never waits for disk
             from .output import FrameWriter

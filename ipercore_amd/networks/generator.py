@@ -350,14 +350,23 @@ class AttentionLWBGenerator(nn.Module):
 
     @torch.no_grad()
     def forward_tsf(self, tsf_inputs, src_enc_outs, src_res_outs, Tst, temp_enc_outs=None, temp_res_outs=None, Ttt=None):
-        """(bs,6,h,w), src feats, Tst (bs,ns,h,w,2) -> (tsf_img (bs,3,h,w), tsf_mask (bs,1,h,w))  (:480-535)."""
-        if temp_enc_outs is not None or Ttt is not None:
-            raise NotImplementedError("temporal attention (Ttt / TemporalFIFO) is a 'next' row (SURVEY 8f-4)")
+        """(bs,6,h,w), src feats, Tst (bs,ns,h,w,2) -> (tsf_img (bs,3,h,w), tsf_mask (bs,1,h,w))  (:480-535).
+        temp_enc_outs / temp_res_outs ((bs*nt,c,h,w) lists) + Ttt (bs,nt,h,w,2): the temporal attention inputs (:232-243) -
+        their K / V join the sources' along the attention axis."""
         self._check(tsf_inputs, Tst)
         bs = tsf_inputs.shape[0]
         feats = self._features_from_api(src_enc_outs, src_res_outs, bs)
+        T = Tst.contiguous().float()
+        if temp_enc_outs is not None and Ttt is not None:
+            if bs != 1:
+                raise NotImplementedError("temporal attention runs one clip per process (bs = 1), as Imitator.inference does")
+            tfe = self._features_from_api(temp_enc_outs, temp_res_outs, bs)
+            feats = SourceFeatures(feats.enc, feats.res, [(torch.cat([k, tk], dim=0), torch.cat([v, tv], dim=0))
+                                                          for (k, v), (tk, tv) in zip(feats.kv, tfe.kv)],
+                                   feats.ns + Ttt.shape[1], batched=False)
+            T = torch.cat([T, Ttt.contiguous().float()], dim=1).contiguous()
         tsf8 = ops.nchw_to_nhwc(tsf_inputs.contiguous().float(), c_pad=8)
-        _, mask, img = self.run_tsf(tsf8, feats, Tst.contiguous().float(), bg=None, want_pred=False, want_mask=True, want_img=True)
+        _, mask, img = self.run_tsf(tsf8, feats, T, bg=None, want_pred=False, want_mask=True, want_img=True)
         return img, mask
 
     @torch.no_grad()
@@ -373,7 +382,8 @@ class AttentionLWBGenerator(nn.Module):
         imgs, masks = [], []
         for t in range(nt):
             if t != 0 and self.temporal:
-                raise NotImplementedError("temporal attention is a 'next' row (SURVEY 8f-4)")
+                raise NotImplementedError("multi-step temporal training forward (Ttt inside forward()) is not built; "
+                                          "temporal INFERENCE goes through Imitator(temporal=True) / forward_tsf(temp_*)")
             img, mask = self.forward_tsf(tsf_inputs[:, t], enc, res, Tst[:, t].contiguous())
             imgs.append(img)
             masks.append(mask)

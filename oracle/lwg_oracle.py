@@ -264,13 +264,19 @@ def lwb_transform(x, T):
     return F.grid_sample(x, T, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
-def attention_lwb(sd, p, tsf_x, src_x, Tst):
-    """SelfAttentionLWB.forward :208-252 + SelfAttentionBlock :106-139 + SPADE :80-93 (temporal=False)."""
+def attention_lwb(sd, p, tsf_x, src_x, Tst, temp_x=None, Ttt=None):
+    """SelfAttentionLWB.forward :208-252 + SelfAttentionBlock :106-139 + SPADE :80-93; with temporal features
+    (temp_x (bs*nt,c,h,w), Ttt (bs,nt,H,W,2)) their warped K / V are appended along the source axis (:232-243)."""
     bs, ns, H, W, _ = Tst.shape
     h, w = tsf_x.shape[-2:]
     warp = lwb_transform(src_x, Tst.reshape(bs * ns, H, W, 2))
     K = _conv(sd, p + ".fk", warp, pad=0).view(bs, ns, -1, h, w)
     V = _conv(sd, p + ".fv", warp, pad=0).view(bs, ns, -1, h, w)
+    if temp_x is not None and Ttt is not None:
+        nt = Ttt.shape[1]
+        twarp = lwb_transform(temp_x, Ttt.reshape(bs * nt, H, W, 2))
+        K = torch.cat([K, _conv(sd, p + ".fk", twarp, pad=0).view(bs, nt, -1, h, w)], dim=1)
+        V = torch.cat([V, _conv(sd, p + ".fv", twarp, pad=0).view(bs, nt, -1, h, w)], dim=1)
     q = _conv(sd, p + ".fq", tsf_x, pad=0)
     logits = (K * q.unsqueeze(1)).sum(dim=2, keepdim=True) / math.sqrt(K.shape[2])
     alpha = torch.softmax(logits, dim=1)
@@ -327,17 +333,19 @@ def gen_forward_train(sd, bg_inputs, src_inputs, tsf_inputs, Tst, n_down=3, n_re
     return bg, s_img, s_mask, torch.stack(imgs, dim=1), torch.stack(masks, dim=1)
 
 
-def gen_forward_tsf(sd, tsf_inputs, src_enc_outs, src_res_outs, Tst, n_down=3, n_res=6):
-    """BaseAttentionLWBGenerator.forward_tsf :480-535 (temporal=False) -> (tsf_img, tsf_mask)."""
+def gen_forward_tsf(sd, tsf_inputs, src_enc_outs, src_res_outs, Tst, n_down=3, n_res=6, temp_enc_outs=None,
+                    temp_res_outs=None, Ttt=None):
+    """BaseAttentionLWBGenerator.forward_tsf :480-535 -> (tsf_img, tsf_mask); temp_* / Ttt: the temporal attention inputs."""
     x = tsf_inputs
     enc = []
+    tmp = temp_enc_outs is not None and Ttt is not None
     for i in range(n_down):
         x = F.relu(_conv(sd, f"tsf_net_enc.layers.{i}.0", x, stride=2))
-        x = attention_lwb(sd, f"enc_attlwbs.{i}", x, src_enc_outs[i], Tst)
+        x = attention_lwb(sd, f"enc_attlwbs.{i}", x, src_enc_outs[i], Tst, temp_enc_outs[i] if tmp else None, Ttt if tmp else None)
         enc.append(x)
     for i in range(n_res):
         x = _res_block(sd, f"res_blocks.{i}", x)
-        x = attention_lwb(sd, f"res_attlwbs.{i}", x, src_res_outs[i], Tst)
+        x = attention_lwb(sd, f"res_attlwbs.{i}", x, src_res_outs[i], Tst, temp_res_outs[i] if tmp else None, Ttt if tmp else None)
     for i in range(n_down):                                                      # SkipDecoder :316-357
         x = F.relu(_convT(sd, f"tsf_net_dec.upconvs.{i}.0", x))
         if i != n_down - 1:
@@ -413,6 +421,64 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     return {"pred": pred, "mask": mask, "img": img, "tsf_inputs": tsf_inputs, "Tst": Tst, "fim": fim, "wim": wim,
             "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t, "own_verts": own_verts,
             "src_own_verts": src_info.get("own_verts"), "src_fim": src_info.get("fim")}
+
+
+class TemporalFIFO:
+    """models/imitator.py:18-127: ring of the last ``time_step`` synthesized frames (f2pts + their SIDNet features)."""
+
+    def __init__(self, time_step):
+        self.time_step, self.index = time_step, 0
+        self.f2pts, self.enc, self.res = [None] * time_step, [None] * time_step, [None] * time_step
+
+    @property
+    def nt(self):
+        return min(self.index, self.time_step)
+
+    def append(self, f2pts, enc, res):
+        i = self.index % self.time_step
+        self.f2pts[i], self.enc[i], self.res[i] = f2pts, enc, res
+        self.index += 1
+
+    def tensors(self):
+        n = self.nt
+        f2pts = torch.cat(self.f2pts[:n], dim=0)
+        enc = [torch.cat([self.enc[k][l] for k in range(n)], dim=0) for l in range(len(self.enc[0]))]
+        res = [torch.cat([self.res[k][l] for k in range(n)], dim=0) for l in range(len(self.res[0]))]
+        return f2pts, enc, res
+
+
+def imitate_sequence_temporal(model, tables, sd, src_info, tgt_smpls, image_size, time_step=1, cam_strategy="smooth"):
+    """Imitator.inference with temporal=True (models/imitator.py:341-366): frame t attends to the sources AND to the last
+    ``time_step`` synthesized frames (features of forward_src on [pred, cond], post_update :397-401), warped by Ttt
+    (flowcomposition.py:569-579).  Returns the list of preds."""
+    fifo = TemporalFIFO(time_step)
+    tgt = torch.as_tensor(tgt_smpls, dtype=torch.float32)
+    if cam_strategy == "smooth":
+        tgt = stabilize(model, tgt)
+    first_cam = tgt[0:1, 0:3].clone()
+    n_down, n_res = len(src_info["feats"][0]), len(src_info["feats"][1])
+    preds = []
+    for t in range(tgt.shape[0]):
+        cam = cam_swap(src_info["cam"][0:1], tgt[t:t + 1, 0:3], first_cam, cam_strategy)
+        ref_smpl = torch.cat([cam, tgt[t:t + 1, 3:-10], src_info["shape"][0:1]], dim=1)
+        ref = smplh_get_details(model, ref_smpl, src_info.get("offsets", 0), src_info.get("links_ids"))
+        f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
+        cond = encode_fim(tables["map_fn"], fim)
+        tsf_inputs, _ = make_tsf_inputs(src_info["uv_img"], tables["f_uvs2img"], cond, fim, wim)
+        Tst = make_trans_flow(src_info["f2pts"], fim, wim)
+        enc, res = src_info["feats"]
+        if t == 0:
+            img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down, n_res)
+        else:
+            tf2pts, tenc, tres = fifo.tensors()
+            Ttt = make_trans_flow(tf2pts, fim, wim)
+            img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down, n_res, tenc, tres, Ttt)
+        pred = compose(img, mask, src_info["bg"])
+        cur = torch.cat([pred, cond], dim=1).unsqueeze(1)
+        e2, r2 = gen_forward_src(sd, cur, n_down, n_res)
+        fifo.append(f2pts, e2, r2)
+        preds.append(pred)
+    return preds
 
 
 # --------------------------------------------------------------------------------------------------

@@ -732,8 +732,54 @@ def check_edge_cases():
     return out
 
 
+def check_temporal_mode():
+    """temporal=True: (1) the generator API with temporal attention inputs against the REFERENCE's own
+    AttentionLWBGenerator(temporal=True).forward_tsf (tests/golden/golden_temporal_v1.npz); (2) Imitator.inference with the
+    TemporalFIFO recurrence against the oracle's frame-by-frame restatement."""
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    gt = np.load(os.path.join(ROOT, "tests", "golden", "golden_temporal_v1.npz"))
+    S, nf, nres, bgf = 64, [64, 64, 128], 2, [64, 64, 128]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=True).eval()
+    sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.to(DEV)
+    Tst = torch.tensor(g["render/Tst"]).view(1, 2, S, S, 2)
+    Ttt = torch.roll(Tst, shifts=(3, -2), dims=(2, 3)).clone()
+    src_inputs = torch.tensor(synthetic.uniform_image((1, 2, 6, S, S), 8, "src_inputs"), device=DEV)
+    tmp_inputs = torch.tensor(synthetic.uniform_image((2, 1, 6, S, S), 30, "tmp_inputs"), device=DEV)
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"), device=DEV)
+    enc, res = G.forward_src(src_inputs, only_enc=True)
+    feats = [G.forward_src(tmp_inputs[k:k + 1], only_enc=True) for k in range(2)]
+    tenc = [torch.cat([feats[k][0][l] for k in range(2)], dim=0) for l in range(len(nf))]
+    tres = [torch.cat([feats[k][1][l] for k in range(2)], dim=0) for l in range(nres)]
+    img, mask = G.forward_tsf(tsf_inputs, enc, res, Tst.to(DEV), temp_enc_outs=tenc, temp_res_outs=tres, Ttt=Ttt.to(DEV))
+    torch.cuda.synchronize()
+    m = {"img": _cmp(img, torch.tensor(gt["img"]), 2e-3, "temporal tsf_img"), "mask": _cmp(mask, torch.tensor(gt["mask"]), 2e-3, "temporal mask")}
+    assert m["img"]["mean_abs"] <= 1e-4
+    # the runner: 5 frames, time_step = 2 (ring wraps), vs the oracle recurrence
+    case = pu.build_case(image_size=64, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=5, ns=2)
+    case.opt.update(temporal=True, time_step=2)
+    im = pu.make_imitator(case, frame_batch=1)
+    got = im.synthesize_temporal(im.prepare_sequence(case.tgt_smpls, "smooth"), "smooth").cpu()
+    model, tables, sd, info = pu.oracle_source(case, src_override=(im.src_info["cam"].cpu(), im.src_info["verts"].cpu()))
+    with torch.no_grad():
+        want = torch.cat(orc.imitate_sequence_temporal(model, tables, sd, info, case.tgt_smpls, 64, time_step=2), dim=0)
+    d = (got - want).abs()
+    m["sequence_max"], m["sequence_mean"] = d.max().item(), d.mean().item()
+    # silhouette pixels may flip where the two sides' vertices differ by 1e-7 (the map is discontinuous there): bound the mean
+    # tightly and the fraction of pixels off by more than the generator tolerance
+    m["frac_over_2e-3"] = (d > 2e-3).float().mean().item()
+    assert torch.isfinite(got).all() and m["sequence_mean"] <= 2e-4 and m["frac_over_2e-3"] <= 2e-3, m
+    nontemporal = pu.run_hip(case, imitator=pu.make_imitator(pu.build_case(image_size=64, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=5, ns=2), frame_batch=1)).cpu()
+    m["effect_of_temporal"] = (got[1:] - nontemporal[1:]).abs().max().item()
+    assert torch.equal(got[0], nontemporal[0]) and m["effect_of_temporal"] > 1e-3, m
+    return m
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode]

@@ -182,3 +182,31 @@ def test_source_stage_matches_reference(topo):
     assert np.array_equal(orc.morph(o["fg"], 5, "erode").numpy().astype(np.uint8), g["morph/erode5"])
     frac = torch.tensor(synthetic.uniform_image((1, 1, 128, 128), 23, "frac")).abs() * 0.3
     assert np.array_equal(orc.morph(frac, 13, "dilate").numpy().astype(np.uint8), g["morph/dilate13_frac"])
+
+
+# ---------------------------------------------------------------------------------------------- temporal attention
+def _temporal_inputs(golden):
+    """Same seeds as tests/golden/make_golden_temporal.py::temporal_inputs."""
+    Tst = torch.tensor(golden["render/Tst"]).view(1, 2, S, S, 2)
+    Ttt = torch.roll(Tst, shifts=(3, -2), dims=(2, 3)).clone()
+    src_inputs = torch.tensor(synthetic.uniform_image((1, 2, 6, S, S), 8, "src_inputs"))
+    tmp_inputs = torch.tensor(synthetic.uniform_image((2, 1, 6, S, S), 30, "tmp_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    return Tst, Ttt, src_inputs, tmp_inputs, tsf_inputs
+
+
+def test_temporal_forward_tsf_matches_reference(golden):
+    """oracle.gen_forward_tsf with temporal inputs vs the reference's AttentionLWBGenerator(temporal=True).forward_tsf."""
+    from ipercore_amd.networks import generator_param_shapes
+    gt = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_temporal_v1.npz"))
+    nf, nres, bgf = [64, 64, 128], 2, [64, 64, 128]
+    sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7).items()}
+    Tst, Ttt, src_inputs, tmp_inputs, tsf_inputs = _temporal_inputs(golden)
+    with torch.no_grad():
+        enc, res = orc.gen_forward_src(sd, src_inputs, len(nf), nres)
+        feats = [orc.gen_forward_src(sd, tmp_inputs[k:k + 1], len(nf), nres) for k in range(2)]
+        tenc = [torch.cat([feats[k][0][l] for k in range(2)], dim=0) for l in range(len(nf))]
+        tres = [torch.cat([feats[k][1][l] for k in range(2)], dim=0) for l in range(nres)]
+        img, mask = orc.gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, len(nf), nres, tenc, tres, Ttt)
+    assert float(gt["diff_vs_no_temporal"]) > 1e-2                      # the fixture really exercises the temporal branch
+    assert np.abs(img.numpy() - gt["img"]).max() <= 1e-5 and np.abs(mask.numpy() - gt["mask"]).max() <= 1e-5
