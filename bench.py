@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="bf16: BASELINE configs[3] mode - bf16 MFMA operands in the convs (fp32 activations / accumulation); "
                          "the headline metric (configs[1]) is fp32")
+    ap.add_argument("--workload", choices=("imitate", "novel_view"), default="imitate",
+                    help="novel_view: BASELINE configs[3] poses - create_T_pose_novel_view_smpl(180), global rotation y = 0..360")
     ap.add_argument("--streams", type=int, default=1, help="frame batches in flight on separate HIP streams (see DESIGN.md 5)")
     ap.add_argument("--pipelined-streams", type=int, default=3,
                     help="extra (separately reported) measurement with this many frame batches in flight; 0/1 = skip")
@@ -196,6 +198,11 @@ def main():
     K, W = args.steps, args.warmup
     per_rank = (K + W) * FB
     case = pu.build_case(image_size=S, n_frames=per_rank * world, ns=2)
+    if args.workload == "novel_view":
+        from ipercore_amd.imitator import create_T_pose_novel_view_smpl
+        nv = create_T_pose_novel_view_smpl(180)
+        nv[:, 0:3], nv[:, -10:] = case.src_smpl[0, 0:3], case.src_smpl[0, -10:]
+        case.tgt_smpls = np.concatenate([nv] * (case.tgt_smpls.shape[0] // 180 + 1), axis=0)[:case.tgt_smpls.shape[0]]
     im = pu.make_imitator(case, frame_batch=FB, device=dev)
     if args.precision == "bf16":
         im.generator.conv_precision = "bf16"
@@ -266,7 +273,7 @@ def main():
             "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])"
                        if args.precision == "fp32" else
                        f"per-frame path {S}x{S}, AttLWB-SPADE generator with bf16 MFMA conv tiles (BASELINE configs[3] precision mode)",
-                       "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
+                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
                        "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
                        "batches_in_flight": args.streams,
                        "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},

@@ -294,6 +294,52 @@ class Imitator(object):
         return outputs
 
 
+class Viewer(Imitator):
+    """Novel-view runner (reference models/imitator.py:403-462): the same per-frame path; ``inference`` has no ``prefix``
+    argument and writes ``pred_{t:0>8}.png``."""
+
+    def __init__(self, opt, device=torch.device("cuda:0"), **kw):
+        super().__init__(opt, device, **kw)
+        self._name = "Viewer"
+
+    @torch.no_grad()
+    def inference(self, tgt_smpls, cam_strategy="smooth", output_dir="", visualizer=None, verbose=True):
+        return super().inference(tgt_smpls, cam_strategy=cam_strategy, output_dir=output_dir, prefix="pred_",
+                                 visualizer=visualizer, verbose=verbose)
+
+
+class ModelsFactory(object):
+    """reference models/base_model.py:8-32."""
+
+    @staticmethod
+    def get_by_name(model_name, *args, **kwargs):
+        if model_name == "imitator":
+            return Imitator(*args, **kwargs)
+        if model_name == "viewer":
+            return Viewer(*args, **kwargs)
+        if model_name == "swapper":
+            raise NotImplementedError("Swapper (part-wise source mixing, imitator.py:465-622) is a 'next' row (SURVEY 8f-4)")
+        raise ValueError(f"Model {model_name} not recognized.")
+
+
+def create_T_pose_novel_view_smpl(length=180):
+    """services/base_runner.py:11-30: T-pose SMPL rows whose global rotation is R.from_euler("xyz", [180, y, 0]), y = 0..360."""
+    from scipy.spatial.transform import Rotation as R
+    smpls = np.zeros((length, 85), dtype=np.float32)
+    delta = 360 / (length - 1) if length > 1 else 0
+    for i in range(length):
+        smpls[i, 3:6] = R.from_euler("xyz", [180, delta * i, 0], degrees=True).as_rotvec()
+    return smpls
+
+
+def add_hands_params_to_smpl(smpls, hands_param):
+    """services/base_runner.py:33-55: (n,85) + hands (90,) or (n,90) -> (n,156+...)= [cam, pose[:66], hands, shape]."""
+    hands_param = np.asarray(hands_param, dtype=np.float32)
+    if hands_param.ndim == 1:
+        hands_param = np.tile(hands_param, reps=(smpls.shape[0], 1))
+    return np.concatenate([smpls[:, 0:3], smpls[:, 3:-10][:, 0:66], hands_param, smpls[:, -10:]], axis=1)
+
+
 def load_images(paths, image_size):
     """cv_utils.load_images (cv_utils.py:45-66): (ns,3,S,S) RGB in [-1,1].  cv2 is not a dependency: PIL decodes and
     resizes (bilinear), so a resized image is close to, not bit-identical with, cv2.resize."""

@@ -84,3 +84,25 @@ def test_frame_writer_cpu(tmp_path):
         want = ((np.transpose(frames[t].numpy(), (1, 2, 0)) + 1) / 2.0 * 255).astype(np.uint8)
         assert np.array_equal(np.asarray(Image.open(p)), want)
     assert tuple(np.asarray(Image.open(paths[0]))[0, 0]) == (255, 0, 127)
+
+
+def test_novel_view_smpls_and_viewer(monkeypatch):
+    """create_T_pose_novel_view_smpl / add_hands_params_to_smpl (services/base_runner.py:11-55) and the Viewer runner on the
+    emulated ABI: 156-dim hand-extended poses run through the same per-frame path as 72-dim ones with zero hands."""
+    from ipercore_amd.imitator import ModelsFactory, add_hands_params_to_smpl, create_T_pose_novel_view_smpl
+    smpls = create_T_pose_novel_view_smpl(5)
+    assert smpls.shape == (5, 85) and np.allclose(np.linalg.norm(smpls[:, 3:6], axis=1), np.pi, atol=1e-5)
+    assert np.allclose(smpls[0, 3:6], [np.pi, 0, 0], atol=1e-6) and np.allclose(np.abs(smpls[2, 3:6]), [0, 0, np.pi], atol=1e-5)
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=1, bg_filters=[64, 64, 128], n_frames=2, ns=2)
+    v = ModelsFactory.get_by_name("viewer", case.opt, device=torch.device("cpu"), frame_batch=2)
+    v.generator.load_state_dict({k: torch.tensor(x) for k, x in case.state.items()}, strict=True)
+    v.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    smpls[:, 0:3] = case.src_smpl[0, 0:3]
+    smpls[:, -10:] = case.src_smpl[0, -10:]
+    h = add_hands_params_to_smpl(smpls, v.body_rec.np_hands_mean)
+    assert h.shape == (5, 3 + 156 + 10)
+    out156 = v.inference(h[:3], cam_strategy="smooth")
+    out72 = v.inference(smpls[:3], cam_strategy="smooth")
+    assert len(out156) == 3 and out156[0].shape == (3, 64, 64)
+    assert all(np.abs(a - b).max() <= 1e-5 for a, b in zip(out156, out72))          # hands_mean = 0 in the synthetic model
