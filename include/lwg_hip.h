@@ -84,6 +84,22 @@ size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M);
 int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* args, const float* dy, float* dw, float* ws, lwg_stream_t stream);
 int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream);
 
+/* Elementwise / normalisation pieces of the personalization step and their backward (csrc/train_ops.hip); NHWC fp32.
+ *   act codes: LWG_ACTIVATION_* plus 4 = LeakyReLU(0.2) (discriminators/patch_dis.py:33-47).
+ * lwg_act_bwd_f32:        out = dy * act'(y)  (ReLU after the convs, tanh / sigmoid of the regressors), n % 4 == 0.
+ * lwg_norm_fwd_nhwc_f32:  y = act((x - mean) rstd (1 + gamma) + beta); gamma = beta = NULL: InstanceNorm + activation
+ *                         (bg_inpaintor.py:31-57); with gamma / beta (B,HW,C): SPADE (attlwb_spade_resunet.py:92).
+ * lwg_norm_bwd_nhwc_f32:  the backward of the above: dx (and dgamma, dbeta); ws: B*nsplit*C*2 floats.
+ * lwg_adam_step_f32:      torch.optim.Adam update (lwg_trainer.py:140-146) of a flat parameter buffer, step count t >= 1. */
+int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int act, float* out, lwg_stream_t stream);
+int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B,
+                          int HW, int C, int act, float* y, lwg_stream_t stream);
+int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                          const float* gamma, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma, float* dbeta,
+                          float* ws, lwg_stream_t stream);
+int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t,
+                      lwg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.
  * Replaces nn.InstanceNorm2d at attlwb_spade_resunet.py:62,:83 and bg_inpaintor.py:14,17,33,40,51.

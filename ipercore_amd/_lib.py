@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg_hip.h")
 
 LWG_MAX_TAPS = 52
 EPI_NONE, EPI_RESIDUAL, EPI_SPADE = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_LRELU = 0, 1, 2, 3, 4
 
 c_f = ctypes.c_void_p  # device pointers travel as void*
 c_i = ctypes.c_int
@@ -45,6 +45,10 @@ _SIGS = {
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
     "lwg_colsum_nhwc_f32": (c_i, [c_f, ctypes.c_size_t, c_i, c_f, c_f, c_f]),
+    "lwg_act_bwd_f32": (c_i, [c_f, c_f, ctypes.c_size_t, c_i, c_f, c_f]),
+    "lwg_norm_fwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_norm_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "lwg_adam_step_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_f]),
     "lwg_instnorm_stats_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
     "lwg_instnorm_apply_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_lwb_attention_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),

@@ -1,0 +1,224 @@
+// Elementwise / normalisation kernels of the personalization step (forward pieces that the inference path fuses into conv
+// epilogues, and their backward).  Reference ops: nn.InstanceNorm2d + ReLU / LeakyReLU (bg_inpaintor.py:31-57,
+// discriminators/patch_dis.py:33-47), SPADE's normalized * (1 + gamma) + beta (attlwb_spade_resunet.py:80-93), ReLU after
+// the convs, as differentiated by loss.backward() in tools/trainers/lwg_trainer.py:345,351.
+// All tensors NHWC fp32; HBM-bound streaming kernels with 16-byte accesses; reductions are two-pass and deterministic.
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define LWG_ACT_LRELU 4   // LeakyReLU(0.2) (patch discriminator); extends the activation codes of lwg_common.h for these kernels
+
+__device__ __forceinline__ float lwg_act_t(float v, int act) {
+    if (act == LWG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    return lwg_act(v, act);
+}
+// derivative of the activation expressed with its OUTPUT y (ReLU / LeakyReLU keep the sign; tanh' = 1 - y^2; sigmoid' = y(1-y))
+__device__ __forceinline__ float lwg_dact_from_y(float y, int act) {
+    if (act == LWG_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == LWG_ACT_LRELU) return y > 0.f ? 1.f : 0.2f;
+    if (act == LWG_ACT_TANH) return 1.f - y * y;
+    if (act == LWG_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------- activation backward
+// out = dy * act'(y)     (ReLU mask of ConvFn.backward, tanh / sigmoid of the regressors)
+__global__ void lwg_act_bwd_kernel(const floatx4* __restrict__ dy, const floatx4* __restrict__ y, size_t n4, int act,
+                                   floatx4* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const floatx4 g = dy[i], v = y[i];
+        floatx4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = g[k] * lwg_dact_from_y(v[k], act);
+        out[i] = o;
+    }
+}
+
+extern "C" int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int act, float* out, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!dy || !y || !out || n == 0 || (n & 3)) return (int)hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_act_bwd_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(dy),
+                       reinterpret_cast<const floatx4*>(y), n4, act, reinterpret_cast<floatx4*>(out));
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- normalise (+ modulate) forward
+// y = act( (x - mean) * rstd * (1 + gamma) + beta )   gamma / beta optional (NULL: plain InstanceNorm + activation)
+__global__ void lwg_norm_fwd_kernel(const floatx4* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const floatx4* __restrict__ gamma, const floatx4* __restrict__ beta, int HW, int C4,
+                                    size_t total4, int act, floatx4* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int b = (int)(i / ((size_t)HW * C4));
+        const floatx4 v = x[i];
+        const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + ((size_t)b * C4 + c4) * 4);
+        const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + ((size_t)b * C4 + c4) * 4);
+        floatx4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (v[k] - mu[k]) * rs[k];
+        if (gamma) {
+            const floatx4 g = gamma[i], bt = beta[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = o[k] * (1.f + g[k]) + bt[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = lwg_act_t(o[k], act);
+        y[i] = o;
+    }
+}
+
+extern "C" int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     int B, int HW, int C, int act, float* y, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !mean || !rstd || !y || (C & 3) || B <= 0 || HW <= 0 || ((gamma == nullptr) != (beta == nullptr))) return (int)hipErrorInvalidValue;
+    const size_t total4 = (size_t)B * HW * (C / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_norm_fwd_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(x), mean, rstd,
+                       reinterpret_cast<const floatx4*>(gamma), reinterpret_cast<const floatx4*>(beta), HW, C / 4, total4, act,
+                       reinterpret_cast<floatx4*>(y));
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- normalise (+ modulate) backward
+// With xhat = (x - mean) rstd, z = xhat (1 + gamma) + beta, y = act(z), g = dy act'(y):
+//   dgamma = g xhat, dbeta = g, dxhat = g (1 + gamma)            (gamma absent: dxhat = g)
+//   dx = rstd ( dxhat - mean_hw(dxhat) - xhat mean_hw(dxhat xhat) )
+// Pass 1 (partial): per (b, split, c) the sums of dxhat and dxhat*xhat over the split's pixels, and dgamma / dbeta.
+// Pass 2 (apply): folds the split sums in split order and writes dx.
+__global__ __launch_bounds__(256) void lwg_norm_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                  int HW, int C, int nsplit, int act, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ ws) {
+    const int C4 = C >> 2;
+    const int lpp = C4 < 64 ? C4 : 64;                 // lanes per pixel (channel quads handled by this block)
+    const int pgs = 256 / lpp;                         // pixel groups in flight
+    const int cql = threadIdx.x % lpp, pg = threadIdx.x / lpp;
+    const int cq = blockIdx.x * 64 + cql;              // blockIdx.x > 0 only when C > 256
+    const int split = blockIdx.y, b = blockIdx.z;
+    const bool cok = cq < C4 && pg < pgs;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    floatx4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (cok) {
+        const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + (size_t)b * C + cq * 4);
+        const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + (size_t)b * C + cq * 4);
+        for (int p = p0 + pg; p < p1; p += pgs) {
+            const size_t o = ((size_t)b * HW + p) * C + cq * 4;
+            const floatx4 g0 = *reinterpret_cast<const floatx4*>(dy + o), yv = *reinterpret_cast<const floatx4*>(y + o);
+            const floatx4 xv = *reinterpret_cast<const floatx4*>(x + o);
+            floatx4 gm = {0.f, 0.f, 0.f, 0.f};
+            if (gamma) gm = *reinterpret_cast<const floatx4*>(gamma + o);
+            floatx4 g, xh, dxh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[k] = g0[k] * lwg_dact_from_y(yv[k], act);
+                xh[k] = (xv[k] - mu[k]) * rs[k];
+                dxh[k] = g[k] * (1.f + gm[k]);
+                s1[k] += dxh[k];
+                s2[k] += dxh[k] * xh[k];
+            }
+            if (gamma) {
+                floatx4 dg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dg[k] = g[k] * xh[k];
+                *reinterpret_cast<floatx4*>(dgamma + o) = dg;
+                *reinterpret_cast<floatx4*>(dbeta + o) = g;
+            }
+        }
+    }
+    __shared__ floatx4 sh1[256], sh2[256];
+    sh1[threadIdx.x] = s1;
+    sh2[threadIdx.x] = s2;
+    __syncthreads();
+    if (pg == 0 && cq < C4) {
+        floatx4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+        for (int g = 0; g < pgs; ++g) { t1 += sh1[g * lpp + cql]; t2 += sh2[g * lpp + cql]; }
+        float* o = ws + (((size_t)b * nsplit + split) * C + cq * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[2 * k] = t1[k]; o[2 * k + 1] = t2[k]; }
+    }
+}
+
+__global__ void lwg_norm_bwd_apply_kernel(const floatx4* __restrict__ dy, const floatx4* __restrict__ y, const floatx4* __restrict__ x,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const floatx4* __restrict__ gamma, const float* __restrict__ ws, int HW, int C4, int nsplit,
+                                          size_t total4, int act, floatx4* __restrict__ dx) {
+    const float inv_hw = 1.f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int b = (int)(i / ((size_t)HW * C4));
+        floatx4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = m1;
+        for (int s = 0; s < nsplit; ++s) {                         // a few L2-resident floats per element
+            const float* o = ws + (((size_t)b * nsplit + s) * C4 + c4) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m1[k] += o[2 * k]; m2[k] += o[2 * k + 1]; }
+        }
+        const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + ((size_t)b * C4 + c4) * 4);
+        const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + ((size_t)b * C4 + c4) * 4);
+        const floatx4 g0 = dy[i], yv = y[i], xv = x[i];
+        floatx4 gm = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) gm = gamma[i];
+        floatx4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            const float dxh = g0[k] * lwg_dact_from_y(yv[k], act) * (1.f + gm[k]);
+            o[k] = rs[k] * (dxh - m1[k] * inv_hw - xh * (m2[k] * inv_hw));
+        }
+        dx[i] = o;
+    }
+}
+
+// dy, y, x (B,HW,C); mean, rstd (B,C); gamma (B,HW,C) or NULL.  Outputs dx, and dgamma / dbeta when gamma is given.
+// ws: B * nsplit * C * 2 floats, nsplit <= 64.
+extern "C" int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                                     const float* gamma, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma,
+                                     float* dbeta, float* ws, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!dy || !y || !x || !mean || !rstd || !dx || !ws || (C & 3) || B <= 0 || HW <= 0 || nsplit < 1 || nsplit > 65535 ||
+        (gamma && (!dgamma || !dbeta)))
+        return (int)hipErrorInvalidValue;
+    const int C4 = C / 4;
+    hipLaunchKernelGGL(lwg_norm_bwd_partial_kernel, dim3((C4 + 63) / 64, nsplit, B), dim3(256), 0, stream, dy, y, x, mean, rstd, gamma,
+                       HW, C, nsplit, act, dgamma, dbeta, ws);
+    const size_t total4 = (size_t)B * HW * C4;
+    const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(dy),
+                       reinterpret_cast<const floatx4*>(y), reinterpret_cast<const floatx4*>(x), mean, rstd,
+                       reinterpret_cast<const floatx4*>(gamma), ws, HW, C4, nsplit, total4, act, reinterpret_cast<floatx4*>(dx));
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (lwg_trainer.py:140-146; no weight decay, no amsgrad) over one flat fp32 parameter buffer:
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v / (1 - b2^t)) + eps)
+__global__ void lwg_adam_kernel(floatx4* __restrict__ p, const floatx4* __restrict__ g, floatx4* __restrict__ m, floatx4* __restrict__ v,
+                                size_t n4, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    const float step = lr / bc1, isq = 1.f / sqrtf(bc2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        floatx4 pp = p[i], mm = m[i], vv = v[i];
+        const floatx4 gg = g[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            pp[k] -= step * mm[k] / (sqrtf(vv[k]) * isq + eps);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+extern "C" int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                 int t, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!p || !g || !m || !v || n == 0 || (n & 3) || t < 1) return (int)hipErrorInvalidValue;
+    const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_adam_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<floatx4*>(p), reinterpret_cast<const floatx4*>(g),
+                       reinterpret_cast<floatx4*>(m), reinterpret_cast<floatx4*>(v), n4, lr, beta1, beta2, eps, bc1, bc2);
+    return (int)hipGetLastError();
+}

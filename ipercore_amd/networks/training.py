@@ -9,9 +9,10 @@ What runs where, this round:
   a G step) - runs on the hand-written MFMA kernels: ``ConvFn`` is a ``torch.autograd.Function`` whose forward is
   ``lwg_conv2d_nhwc_f32``, whose data gradient is the same kernel on dY with a transposed panel
   (``packing.pack_dgrad_*``) and whose weight gradient is ``lwg_conv2d_wgrad_nhwc_f32``;
-* the glue between the convolutions (ReLU/tanh/sigmoid, InstanceNorm, SPADE modulation, the bilinear warp, the softmax
-  over sources, losses, Adam) is PyTorch-ROCm autograd on NHWC tensors in this round - HBM-bound elementwise work that
-  the inference path already fuses into HIP kernels; fusing their backward is the next step of this row.
+* InstanceNorm (+ ReLU / LeakyReLU), SPADE's modulation, the ReLU masks and Adam are HIP kernels too (``NormAct``,
+  csrc/train_ops.hip); what remains PyTorch-ROCm autograd this round is the bilinear warp + softmax of the attention
+  block, tanh / sigmoid of the regressors, the compositing and the scalar losses - HBM-bound elementwise work that the
+  inference path fuses into HIP kernels; their fused backward is the next step of this row.
 There is no CPU fallback: ``ConvFn`` raises on CPU tensors.
 
 The module reuses the parameter tree of ``generator.AttentionLWBGenerator`` (same ``state_dict`` keys), so a
@@ -78,7 +79,7 @@ class ConvFn(torch.autograd.Function):
             full[..., :N] = dy
             dy = full
         if cfg.act == _RELU:
-            dy = dy * (y > 0)
+            dy = ops.act_bwd(dy, y, ops.ACT_RELU)
         dev = dy.device
         C0 = x0.shape[3]
         Cin_packed = specs[0].Cin
@@ -129,11 +130,27 @@ def conv(x0, weight, bias=None, x1=None, **kw):
 
 
 # ---------------------------------------------------------------------------------------------- NHWC glue (autograd)
-def instance_norm(x, eps=1e-5):
-    """nn.InstanceNorm2d(affine=False) on (B,H,W,C): biased variance over the pixels of each (b, c)."""
-    mu = x.mean(dim=(1, 2), keepdim=True)
-    var = x.var(dim=(1, 2), unbiased=False, keepdim=True)
-    return (x - mu) * torch.rsqrt(var + eps)
+class NormAct(torch.autograd.Function):
+    """y = act(InstanceNorm2d(x) * (1 + gamma) + beta) on (B,H,W,C), forward and backward on csrc/train_ops.hip
+    (statistics by the inference path's lwg_instnorm_stats).  gamma = beta = None: plain InstanceNorm + activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, act):
+        y, mean, rstd = ops.norm_fwd(x, gamma, beta, act)
+        ctx.act = act
+        ctx.save_for_backward(x.contiguous(), mean, rstd, None if gamma is None else gamma.contiguous(), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, y = ctx.saved_tensors
+        dx, dg, db = ops.norm_bwd(dy, y, x, mean, rstd, gamma, ctx.act)
+        return dx, dg, db, None
+
+
+def instance_norm(x, act=_NONE):
+    """nn.InstanceNorm2d(affine=False) (+ fused activation) on (B,H,W,C)."""
+    return NormAct.apply(x, None, None, act)
 
 
 def lwb_transform(x, T):
@@ -177,7 +194,7 @@ class TrainableGenerator(object):
         actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
         gamma = self.cv(pfx + ".spade.mlp_gamma", actv)
         beta = self.cv(pfx + ".spade.mlp_beta", actv)
-        return instance_norm(tsf_x) * (1 + gamma) + beta
+        return NormAct.apply(tsf_x, gamma, beta, _NONE)
 
     def res_block(self, pfx, x):
         return x + self.cv(pfx + ".main.2", self.cv(pfx + ".main.0", x, act=_RELU))
@@ -192,17 +209,17 @@ class TrainableGenerator(object):
     def forward_bg(self, bg4):
         """(n,S,S,4) -> (n,S,S,3)   (bg_inpaintor.py:24-60)."""
         x, i = bg4, 0
-        x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, pad=3, cin_pad=4, need_dx=False)))
+        x = instance_norm(self.cv(f"bg_net.main.{i}", x, pad=3, cin_pad=4, need_dx=False), _RELU)
         i += 3
         for _ in range(self.n_bg - 1):
-            x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, stride=2)))
+            x = instance_norm(self.cv(f"bg_net.main.{i}", x, stride=2), _RELU)
             i += 3
         for _ in range(self.n_res):
-            y = F.relu(instance_norm(self.cv(f"bg_net.main.{i}.main.0", x)))
+            y = instance_norm(self.cv(f"bg_net.main.{i}.main.0", x), _RELU)
             x = x + instance_norm(self.cv(f"bg_net.main.{i}.main.3", y))
             i += 1
         for _ in range(self.n_bg - 1):
-            x = F.relu(instance_norm(self.cv(f"bg_net.main.{i}", x, kind="convT")))
+            x = instance_norm(self.cv(f"bg_net.main.{i}", x, kind="convT"), _RELU)
             i += 3
         return torch.tanh(self.cv(f"bg_net.main.{i}", x, pad=3, n_pad=64))
 

@@ -7,7 +7,7 @@ CPU fallback on the product path.
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EPI_NONE, EPI_RESIDUAL, EPI_SPADE  # noqa: F401
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EPI_NONE, EPI_RESIDUAL, EPI_SPADE  # noqa: F401
 
 EYE_DIST = 2.7320508075688776   # 1/tan(30 deg) + 1 (reference renders/nmr.py:225)
 
@@ -372,3 +372,49 @@ def colsum(x2d_or_nhwc):
     ws = torch.empty(64 * C, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().lwg_colsum_nhwc_f32(_ptr(x), rows, C, _ptr(out), _ptr(ws), _stream()), "lwg_colsum_nhwc_f32")
     return out
+
+
+def act_bwd(dy, y, act):
+    """dy * act'(y) for ReLU / LeakyReLU(0.2) / tanh / sigmoid outputs y."""
+    dy, y = dy.contiguous(), y.contiguous()
+    out = torch.empty_like(dy)
+    _lib.check(_lib.lib().lwg_act_bwd_f32(_ptr(dy), _ptr(y), dy.numel(), act, _ptr(out), _stream()), "lwg_act_bwd_f32")
+    return out
+
+
+def _nsplit(hw):
+    return max(1, min(64, hw // 64))
+
+
+def norm_fwd(x, gamma=None, beta=None, act=ACT_NONE, eps=1e-5):
+    """y = act(InstanceNorm(x) * (1 + gamma) + beta) on NHWC -> (y, mean, rstd)."""
+    B, H, W, C = x.shape
+    x = x.contiguous()
+    mean, rstd = x.new_empty(B, C), x.new_empty(B, C)
+    ns = _nsplit(H * W)
+    instnorm_stats(x, mean, rstd, x.new_empty(B * C * ns * 3), eps=eps, nsplit=ns)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().lwg_norm_fwd_nhwc_f32(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(None if gamma is None else gamma.contiguous()),
+                                                 _ptr(None if beta is None else beta.contiguous()), B, H * W, C, act, _ptr(y),
+                                                 _stream()), "lwg_norm_fwd_nhwc_f32")
+    return y, mean, rstd
+
+
+def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=ACT_NONE):
+    """Backward of norm_fwd -> (dx, dgamma, dbeta)."""
+    B, H, W, C = x.shape
+    dy = dy.contiguous()
+    ns = _nsplit(H * W)
+    dx = torch.empty_like(x)
+    dg = torch.empty_like(x) if gamma is not None else None
+    db = torch.empty_like(x) if gamma is not None else None
+    ws = x.new_empty(B * ns * C * 2)
+    _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), B, H * W, C, act, ns,
+                                                 _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream()), "lwg_norm_bwd_nhwc_f32")
+    return dx, dg, db
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
+    """In-place Adam update of the flat fp32 buffers p, m, v with gradient g."""
+    _lib.check(_lib.lib().lwg_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(t), _stream()),
+               "lwg_adam_step_f32")

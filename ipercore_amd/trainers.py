@@ -12,15 +12,16 @@ Losses that need weights the reference downloads (VGG19 perceptual ``vggloss.py`
 available offline: the step is the reference's ``use_vgg = "None"`` / ``use_face = false`` configuration, in which
 ``crt_tsf`` is ``L1Loss`` (lwg_trainer.py:154-158).
 
-Data parallelism (BASELINE config 5: one sample per GPU): gradients are flattened into ONE fp32 buffer per network and
-reduced with a single RCCL all-reduce (``allreduce_grads``) - large, few collectives for point-to-point xGMI - instead of
-DDP's 25 MB buckets.  The reference's personalization itself is single-GPU (no collective).
+Data parallelism (BASELINE config 5: one sample per GPU): parameters and gradients of a network live in ONE flat fp32
+buffer each (``FlatAdam``); the gradient buffer is averaged in place with a single RCCL all-reduce - large, few
+collectives for point-to-point xGMI instead of DDP's 25 MB buckets - and updated by one fused Adam kernel.  The reference's personalization itself is single-GPU (no collective).
 """
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .networks.training import TrainableGenerator, conv, instance_norm
 
 _RELU = 1
@@ -70,7 +71,7 @@ class PatchGlobalDiscriminator(nn.Module):
             if i == 0:
                 x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=8, need_dx=False), 0.2)
             elif i < n - 1:
-                x = F.leaky_relu(instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1)), 0.2)
+                x = instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1), ops.ACT_LRELU)
             else:
                 x = conv(x, layer.weight, layer.bias, stride=stride, pad=1, n_pad=64)
         return [x.permute(0, 3, 1, 2)]
@@ -84,6 +85,49 @@ def lsgan_loss(outs, target):
 def tv_loss(mat):
     """criterions/generals.py:7-13."""
     return torch.mean(torch.abs(mat[:, :, :, :-1] - mat[:, :, :, 1:])) + torch.mean(torch.abs(mat[:, :, :-1, :] - mat[:, :, 1:, :]))
+
+
+class FlatAdam(object):
+    """torch.optim.Adam (lwg_trainer.py:140-146: lr, betas, eps 1e-8, no weight decay) over ONE flat fp32 buffer.
+
+    The parameters of the module are re-pointed at slices of a single buffer and their .grad at slices of a single gradient
+    buffer, so (a) the update is one HIP kernel (lwg_adam_step_f32) instead of a multi-tensor loop and (b) the data-parallel
+    exchange all-reduces the gradient buffer in place - no flatten / unflatten copies."""
+
+    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.module, self.lr, self.betas, self.eps, self.t = module, lr, betas, eps, 0
+        params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        n4 = (n + 3) // 4 * 4
+        dev = params[0].device
+        self.flat = torch.zeros(n4, device=dev)
+        self.grad = torch.zeros(n4, device=dev)
+        self.m, self.v = torch.zeros(n4, device=dev), torch.zeros(n4, device=dev)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        self.params = params
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:                      # autograd accumulates into the existing views
+            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
+                raise RuntimeError("a parameter's .grad was replaced; call zero_grad() of FlatAdam only")
+
+    def allreduce(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            self.grad.div_(dist.get_world_size(group))
+
+    def step(self):
+        self.t += 1
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        if hasattr(self.module, "_packed"):
+            self.module._packed = None             # the inference engine's packed panels are stale now
 
 
 def allreduce_grads(params, group=None):
@@ -116,8 +160,8 @@ class LWGTrainer(object):
         self.opts = opts or TrainOpts()
         self.tg = TrainableGenerator(G)
         o = self.opts
-        self.optimizer_G = torch.optim.Adam(G.parameters(), lr=o.lr_G, betas=(o.G_adam_b1, o.G_adam_b2))
-        self.optimizer_D = None if D is None else torch.optim.Adam(D.parameters(), lr=o.lr_D, betas=(o.D_adam_b1, o.D_adam_b2))
+        self.optimizer_G = FlatAdam(G, lr=o.lr_G, betas=(o.G_adam_b1, o.G_adam_b2))
+        self.optimizer_D = None if D is None else FlatAdam(D, lr=o.lr_D, betas=(o.D_adam_b1, o.D_adam_b2))
         self.losses = {}
 
     def set_input(self, inputs):
@@ -167,17 +211,15 @@ class LWGTrainer(object):
         """:326-352, plus the gradient all-reduce when the step is data parallel."""
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
         loss_G = self.optimize_G(fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
-        self.optimizer_G.zero_grad(set_to_none=True)
-        if self.D is not None:
-            self.optimizer_D.zero_grad(set_to_none=True)       # G's adversarial term also reaches D's leaves; dropped below
-        loss_G.backward()
-        allreduce_grads(list(self.G.parameters()), self.group)
+        self.optimizer_G.zero_grad()
+        loss_G.backward()                                   # G's adversarial term also reaches D's leaves; zeroed below
+        self.optimizer_G.allreduce(self.group)
         self.optimizer_G.step()
         loss_D = None
         if self.D is not None:
-            self.optimizer_D.zero_grad(set_to_none=True)
+            self.optimizer_D.zero_grad()
             loss_D = self.optimize_D(fake_tsf_imgs)
             loss_D.backward()
-            allreduce_grads(list(self.D.parameters()), self.group)
+            self.optimizer_D.allreduce(self.group)
             self.optimizer_D.step()
         return loss_G.detach(), None if loss_D is None else loss_D.detach()

@@ -778,8 +778,52 @@ def check_temporal_mode():
     return m
 
 
+def check_train_ops():
+    """csrc/train_ops.hip against torch autograd / torch.optim on the CPU: NormAct (InstanceNorm + ReLU, LeakyReLU at C = 512,
+    SPADE modulation), the activation backward, and the fused Adam update over several steps."""
+    from ipercore_amd.networks.training import NormAct
+    out = {}
+    for name, (B, H, W, C), act, spade in (("in_relu", (2, 16, 16, 64), ops.ACT_RELU, False), ("in_lrelu_c512", (1, 7, 9, 512), ops.ACT_LRELU, False),
+                                           ("in_none_c96", (2, 8, 8, 96), ops.ACT_NONE, False), ("spade", (2, 16, 16, 128), ops.ACT_NONE, True)):
+        x = _rand((B, H, W, C), 900, 1.5) + 0.7
+        gm, bt = (_rand((B, H, W, C), 901, 0.5), _rand((B, H, W, C), 902, 0.5)) if spade else (None, None)
+        g = _rand((B, H, W, C), 903)
+        xr = x.clone().requires_grad_(True)
+        gr, br = (gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)) if spade else (None, None)
+        xh = F.instance_norm(xr.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
+        z = xh * (1 + gr) + br if spade else xh
+        yr = {ops.ACT_RELU: F.relu, ops.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), ops.ACT_NONE: lambda t: t}[act](z)
+        (yr * g).sum().backward()
+        xd = x.to(DEV).requires_grad_(True)
+        gd, bd = (gm.to(DEV).requires_grad_(True), bt.to(DEV).requires_grad_(True)) if spade else (None, None)
+        y = NormAct.apply(xd, gd, bd, act)
+        (y * g.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        out[name] = {"y": _cmp(y, yr, 2e-5, name + " y"), "dx": _cmp(xd.grad, xr.grad, 2e-4, name + " dx")}
+        if spade:
+            out[name]["dgamma"] = _cmp(gd.grad, gr.grad, 2e-5, "dgamma")
+            out[name]["dbeta"] = _cmp(bd.grad, br.grad, 2e-5, "dbeta")
+    yv, dv = _rand((3, 5, 8), 910), _rand((3, 5, 8), 911)
+    for act, f in ((ops.ACT_TANH, torch.tanh), (ops.ACT_SIGMOID, torch.sigmoid)):
+        a = yv.clone().requires_grad_(True)
+        o = f(a)
+        o.backward(dv)
+        out[f"act_bwd_{act}"] = _cmp(ops.act_bwd(dv.to(DEV), o.detach().to(DEV), act), a.grad, 1e-5, "act_bwd")
+    n = 1000
+    p0, gs = _rand((n,), 920), [_rand((n,), 921 + i) for i in range(4)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2, betas=(0.9, 0.999))
+    pd, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t, g_ in enumerate(gs):
+        pr.grad = g_.clone()
+        opt.step()
+        ops.adam_step(pd, g_.to(DEV), m, v, 1e-2, 0.9, 0.999, 1e-8, t + 1)
+    out["adam"] = _cmp(pd, pr.detach(), 1e-5, "adam 4 steps")
+    return out
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops]
