@@ -86,6 +86,18 @@ def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
     return dw.reshape(spec.ntaps * Cin, spec.N).contiguous()
 
 
+def act_bwd(dy, y, act):
+    if act == real_ops.ACT_RELU:
+        return dy * (y > 0)
+    if act == real_ops.ACT_LRELU:
+        return dy * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+    if act == real_ops.ACT_TANH:
+        return dy * (1 - y * y)
+    if act == real_ops.ACT_SIGMOID:
+        return dy * y * (1 - y)
+    return dy
+
+
 def colsum(x):
     return x.reshape(-1, x.shape[-1]).sum(dim=0)
 
@@ -208,7 +220,7 @@ def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
-                 "smpl_lbs", "conv2d_wgrad", "colsum"):
+                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)
