@@ -122,6 +122,12 @@ int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* 
 int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
                           const float* T, float* out, int B, int ns, int h, int w, int C, int S,
                           int src_batched, lwg_stream_t stream);
+/* Backward of the above for the personalization step (lwg_trainer.py:649-697 runs the same block under autograd; the
+ * flows are constants there).  dq is written; dKs / dVs are accumulated with fp32 atomics and must be zero on entry;
+ * ns <= 8.  The bias gradients need no kernel: dbv = column sum of dout, dbk = 0. */
+int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
+                              const float* T, const float* dout, float* dq, float* dKs, float* dVs, int B, int ns,
+                              int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Renderer (replaces the `neural_renderer` CUDA package as used by renders/nmr.py).

@@ -129,3 +129,157 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
 #undef LWG_ATTN_LAUNCH
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the attention-form Liquid Warping Block (personalization step).  Per pixel, with K_s = warp_s(Ks) + bk,
+// V_s = warp_s(Vs) + bv, l_s = K_s.q / sqrt(C), a = softmax_s(l), out = sum_s a_s V_s and upstream gradient g = dout:
+//   dV_s = a_s g                      da_s = g . V_s            dl_s = a_s (da_s - sum_j a_j da_j)
+//   dK_s = dl_s q / sqrt(C)           dq   = sum_s dl_s K_s / sqrt(C)
+//   dKs[tap] += w_tap dK_s,  dVs[tap] += w_tap dV_s  (bilinear scatter: fp32 atomics - same as grid_sample's backward)
+//   dbv = sum_pixels g  (sum_s a_s = 1);   dbk = 0 exactly (a bias on every K shifts all logits of a pixel equally)
+// The flows are not differentiated (the reference computes them under no_grad, lwg_trainer.py:649-697).
+// One pixel per LPP = C/4 lanes, the gathers are recomputed instead of stored.  dKs / dVs must be zero on entry.
+template <int LPP>
+__global__ __launch_bounds__(256) void lwg_lwb_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ Ks,
+                                                              const float* __restrict__ Vs, const float* __restrict__ bk,
+                                                              const float* __restrict__ bv, const float* __restrict__ T,
+                                                              const float* __restrict__ dout, float* __restrict__ dq,
+                                                              float* __restrict__ dKs, float* __restrict__ dVs, int B, int ns, int h,
+                                                              int w, int S, int src_batched) {
+    constexpr int C = 4 * LPP;
+    constexpr int PPW = 64 / LPP;
+    constexpr int MAXS = 8;   // sources + temporal frames per pixel kept in registers
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cl = lane % LPP;
+    const long total = (long)B * h * w;
+    long gp = ((long)blockIdx.x * 4 + wid) * PPW + lane / LPP;
+    const bool live = gp < total;
+    if (!live) gp = total - 1;
+    const int hw = h * w;
+    const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
+    const int y = rem / w, x = rem - y * w;
+
+    const floatx4 q4 = *reinterpret_cast<const floatx4*>(q + gp * C + 4 * cl);
+    const floatx4 g4 = *reinterpret_cast<const floatx4*>(dout + gp * C + 4 * cl);
+    const floatx4 bk4 = *reinterpret_cast<const floatx4*>(bk + 4 * cl);
+    const floatx4 bv4 = *reinterpret_cast<const floatx4*>(bv + 4 * cl);
+
+    const float sc_y = h > 1 ? (float)(S - 1) / (float)(h - 1) : 0.f;
+    const float sc_x = w > 1 ? (float)(S - 1) / (float)(w - 1) : 0.f;
+    const float sy = sc_y * (float)y, sx = sc_x * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const bool same = (h == S) && (w == S);
+    const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+
+    float logit[MAXS], da[MAXS];
+    floatx4 kf[MAXS];                 // K_s (this lane's 4 channels) for dq
+    int tx0s[MAXS], ty0s[MAXS];
+    float wx1s[MAXS], wy1s[MAXS], wx0s[MAXS], wy0s[MAXS];
+    float mx = -INFINITY;
+    for (int s = 0; s < ns && s < MAXS; ++s) {
+        const float2* Tp = reinterpret_cast<const float2*>(T) + ((size_t)b * ns + s) * S * S;
+        float gx, gy;
+        if (same) {
+            const float2 t = Tp[(size_t)y * S + x];
+            gx = t.x; gy = t.y;
+        } else {
+            const float2 t00 = Tp[(size_t)y0 * S + x0], t01 = Tp[(size_t)y0 * S + x1];
+            const float2 t10 = Tp[(size_t)y1 * S + x0], t11 = Tp[(size_t)y1 * S + x1];
+            gx = ly0 * (lx0 * t00.x + lx1 * t01.x) + ly1 * (lx0 * t10.x + lx1 * t11.x);
+            gy = ly0 * (lx0 * t00.y + lx1 * t01.y) + ly1 * (lx0 * t10.y + lx1 * t11.y);
+        }
+        const float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        wx1s[s] = ix - fx0; wy1s[s] = iy - fy0; wx0s[s] = (fx0 + 1.f) - ix; wy0s[s] = (fy0 + 1.f) - iy;
+        tx0s[s] = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
+        ty0s[s] = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+        const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
+        const float* Kb = Ks + sidx * hw * C + 4 * cl;
+        const float* Vb = Vs + sidx * hw * C + 4 * cl;
+        floatx4 ka = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = ty0s[s] + (t >> 1), tx = tx0s[s] + (t & 1);
+            const float wt = ((t >> 1) ? wy1s[s] : wy0s[s]) * ((t & 1) ? wx1s[s] : wx0s[s]);
+            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                const size_t off = ((size_t)ty * w + tx) * C;
+                const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
+                const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ka[k] += k4[k] * wt; va[k] += v4[k] * wt; }
+            }
+        }
+        float dot = 0.f, dav = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            kf[s][k] = ka[k] + bk4[k];
+            dot += kf[s][k] * q4[k];
+            dav += (va[k] + bv4[k]) * g4[k];
+        }
+#pragma unroll
+        for (int off = LPP >> 1; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off, 64);
+            dav += __shfl_xor(dav, off, 64);
+        }
+        logit[s] = dot * inv_sqrt_c;
+        da[s] = dav;
+        mx = fmaxf(mx, logit[s]);
+    }
+    float den = 0.f;
+    for (int s = 0; s < ns && s < MAXS; ++s) { logit[s] = expf(logit[s] - mx); den += logit[s]; }
+    float adot = 0.f;
+    for (int s = 0; s < ns && s < MAXS; ++s) { logit[s] /= den; adot += logit[s] * da[s]; }   // logit[] now holds a_s
+    floatx4 dq4 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ns && s < MAXS; ++s) {
+        const float a = logit[s];
+        const float dl = a * (da[s] - adot) * inv_sqrt_c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dq4[k] += dl * kf[s][k];
+        if (!live) continue;
+        const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
+        float* dKb = dKs + sidx * hw * C + 4 * cl;
+        float* dVb = dVs + sidx * hw * C + 4 * cl;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = ty0s[s] + (t >> 1), tx = tx0s[s] + (t & 1);
+            const float wt = ((t >> 1) ? wy1s[s] : wy0s[s]) * ((t & 1) ? wx1s[s] : wx0s[s]);
+            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                const size_t off = ((size_t)ty * w + tx) * C;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    atomicAdd(dKb + off + k, wt * dl * q4[k]);
+                    atomicAdd(dVb + off + k, wt * a * g4[k]);
+                }
+            }
+        }
+    }
+    if (live) *reinterpret_cast<floatx4*>(dq + gp * C + 4 * cl) = dq4;
+}
+
+// dq (B,h,w,C) is written; dKs / dVs (shaped like Ks / Vs) are ACCUMULATED into (zero them first); ns <= 8.
+extern "C" int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
+                                         const float* T, const float* dout, float* dq, float* dKs, float* dVs, int B, int ns, int h,
+                                         int w, int C, int S, int src_batched, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!q || !Ks || !Vs || !bk || !bv || !T || !dout || !dq || !dKs || !dVs || B <= 0 || ns <= 0 || ns > 8 || h <= 0 || w <= 0 || S <= 0)
+        return (int)hipErrorInvalidValue;
+    const long total = (long)B * h * w;
+#define LWG_ATTN_BWD_LAUNCH(LPP)                                                                                      \
+    {                                                                                                                 \
+        const long per_block = 4 * (64 / LPP);                                                                        \
+        hipLaunchKernelGGL(lwg_lwb_attn_bwd_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
+                           stream, q, Ks, Vs, bk, bv, T, dout, dq, dKs, dVs, B, ns, h, w, S, src_batched);                    \
+    }
+    switch (C) {
+        case 32: LWG_ATTN_BWD_LAUNCH(8) break;
+        case 64: LWG_ATTN_BWD_LAUNCH(16) break;
+        case 128: LWG_ATTN_BWD_LAUNCH(32) break;
+        case 256: LWG_ATTN_BWD_LAUNCH(64) break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LWG_ATTN_BWD_LAUNCH
+    return (int)hipGetLastError();
+}

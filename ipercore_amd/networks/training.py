@@ -153,6 +153,26 @@ def instance_norm(x, act=_NONE):
     return NormAct.apply(x, None, None, act)
 
 
+class AttnFn(torch.autograd.Function):
+    """Attention-form LWB (flow resize + warp + softmax over the sources) with its HIP backward.
+    q (B,h,w,C) incl. bias; Ks/Vs (B*ns,h,w,C) = Wk x / Wv x without bias; T (B,ns,S,S,2) constant."""
+
+    @staticmethod
+    def forward(ctx, q, Ks, Vs, bk, bv, T):
+        q, Ks, Vs, T = q.contiguous(), Ks.contiguous(), Vs.contiguous(), T.contiguous()
+        out = ops.lwb_attention(q, Ks, Vs, bk, bv, T, torch.empty_like(q), src_batched=True)
+        ctx.save_for_backward(q, Ks, Vs, bk, bv, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, Ks, Vs, bk, bv, T = ctx.saved_tensors
+        dq, dKs, dVs = ops.lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=True)
+        dbv = ops.colsum(dout) if ctx.needs_input_grad[4] else None
+        dbk = torch.zeros_like(bk) if ctx.needs_input_grad[3] else None
+        return dq, dKs, dVs, dbk, dbv, None
+
+
 def lwb_transform(x, T):
     """attlwb_spade_resunet.py:175-191 on NHWC features: flow resize (align_corners=True) + grid_sample (zeros)."""
     h, w = x.shape[1:3]
@@ -170,6 +190,7 @@ class TrainableGenerator(object):
         self.n_down = len(gen.num_filters)
         self.n_res = gen.n_res_block
         self.n_bg = len(gen.bg_filters) if gen.has_bg else 0
+        self.fused_attention = True      # False: the eager warp + softmax chain (kept as the in-framework cross-check)
 
     def p(self, name):
         obj = self.gen
@@ -185,12 +206,19 @@ class TrainableGenerator(object):
     def attlwb(self, pfx, tsf_x, src_x, Tst):
         bs, ns, S, _, _ = Tst.shape
         h, w, C = tsf_x.shape[1:]
-        warp = lwb_transform(src_x, Tst.reshape(bs * ns, S, S, 2))
-        K = self.cv(pfx + ".fk", warp, pad=0).view(bs, ns, h, w, C)
-        V = self.cv(pfx + ".fv", warp, pad=0).view(bs, ns, h, w, C)
+        fk, fv = self.p(pfx + ".fk"), self.p(pfx + ".fv")
         q = self.cv(pfx + ".fq", tsf_x, pad=0)
-        logits = (K * q.unsqueeze(1)).sum(dim=4, keepdim=True) / math.sqrt(C)
-        x = (torch.softmax(logits, dim=1) * V).sum(dim=1)
+        if self.fused_attention:
+            # a 1x1 conv commutes with the zero-padded warp: project the source features, warp inside the kernel
+            Ks = conv(src_x, fk.weight, None, pad=0)
+            Vs = conv(src_x, fv.weight, None, pad=0)
+            x = AttnFn.apply(q, Ks, Vs, fk.bias, fv.bias, Tst)
+        else:
+            warp = lwb_transform(src_x, Tst.reshape(bs * ns, S, S, 2))
+            K = self.cv(pfx + ".fk", warp, pad=0).view(bs, ns, h, w, C)
+            V = self.cv(pfx + ".fv", warp, pad=0).view(bs, ns, h, w, C)
+            logits = (K * q.unsqueeze(1)).sum(dim=4, keepdim=True) / math.sqrt(C)
+            x = (torch.softmax(logits, dim=1) * V).sum(dim=1)
         actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
         gamma = self.cv(pfx + ".spade.mlp_gamma", actv)
         beta = self.cv(pfx + ".spade.mlp_beta", actv)

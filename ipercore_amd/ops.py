@@ -150,6 +150,20 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     return out
 
 
+def lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=False):
+    """Gradients of ``lwb_attention`` w.r.t. q, Ks, Vs (the flows are constants).  dbv = colsum(dout), dbk = 0."""
+    B, h, w, C = q.shape
+    ns, S = T.shape[1], T.shape[2]
+    dout = dout.contiguous()
+    dq = torch.empty_like(q)
+    dKs = torch.zeros_like(Ks)
+    dVs = torch.zeros_like(Vs)
+    _lib.check(_lib.lib().lwg_lwb_attention_bwd_f32(_ptr(q), _ptr(Ks), _ptr(Vs), _ptr(bk), _ptr(bv), _ptr(T), _ptr(dout), _ptr(dq),
+                                                     _ptr(dKs), _ptr(dVs), B, ns, h, w, C, S, 1 if src_batched else 0, _stream()),
+               "lwg_lwb_attention_bwd_f32")
+    return dq, dKs, dVs
+
+
 def project_faces(verts, cam, faces, want_faces_v=True, want_f2pts=True):
     B, nv, _ = verts.shape
     nf = faces.shape[0]

@@ -4,6 +4,7 @@ dict of metrics and raises AssertionError on failure; ``tests/test_gpu_parity.py
 (-m gpu) and ``tools/gpu_diag.py`` runs them all and dumps a JSON report (nothing here reads /root/reference).
 """
 import hashlib
+import math
 import os
 import time
 
@@ -822,8 +823,46 @@ def check_train_ops():
     return out
 
 
+def check_attention_backward():
+    """lwg_lwb_attention_bwd_f32 (AttnFn) against torch autograd through the reference chain on the CPU
+    (F.interpolate align_corners=True -> F.grid_sample zeros -> fk / fv 1x1 -> softmax over the sources), for every channel
+    width, with flow resize (h != S), out-of-range flows (-2 = background) and 1..4 sources."""
+    from ipercore_amd.networks.training import AttnFn
+    out = {}
+    for name, C, ns, h, S in (("c32", 32, 2, 24, 24), ("c64", 64, 3, 16, 64), ("c128", 128, 4, 12, 48), ("c256", 256, 1, 8, 64), ("c256_ns2", 256, 2, 16, 64)):
+        w = h
+        x = _rand((ns, h, w, C), 950)                      # source features
+        tx = _rand((1, h, w, C), 951)
+        Wq, Wk, Wv = (_rand((C, C), 952 + i, 1.0 / math.sqrt(C)) for i in range(3))
+        bq, bk, bv = (_rand((C,), 955 + i, 0.1) for i in range(3))
+        T = _rand((1, ns, S, S, 2), 958, 0.8)
+        T[:, :, : S // 4] = -2.0                          # background rows
+        g = _rand((1, h, w, C), 959)
+        leaves = [t.clone().requires_grad_(True) for t in (x, tx, Wq, Wk, Wv, bq, bk, bv)]
+        xr, txr, Wqr, Wkr, Wvr, bqr, bkr, bvr = leaves
+        Tr = F.interpolate(T[0].permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) if S != h else T[0]
+        warp = F.grid_sample(xr.permute(0, 3, 1, 2), Tr, mode="bilinear", padding_mode="zeros", align_corners=False).permute(0, 2, 3, 1)
+        K, V, q = warp @ Wkr.t() + bkr, warp @ Wvr.t() + bvr, txr @ Wqr.t() + bqr
+        a = torch.softmax((K * q).sum(-1, keepdim=True) / math.sqrt(C), dim=0)
+        yr = (a * V).sum(0, keepdim=True)
+        (yr * g).sum().backward()
+        dl = [t.to(DEV).requires_grad_(True) for t in (x, tx, Wq, Wk, Wv, bq, bk, bv)]
+        xd, txd, Wqd, Wkd, Wvd, bqd, bkd, bvd = dl
+        y = AttnFn.apply(txd @ Wqd.t() + bqd, xd @ Wkd.t(), xd @ Wvd.t(), bkd, bvd, T.to(DEV))
+        (y * g.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        m = {"y": _cmp(y, yr, 3e-4, name + " y")}   # q / Ks / Vs come from GPU matmuls here
+        gmax = max(t.grad.abs().max().item() for t in leaves)
+        for nm, a_, b_ in zip(("x", "tx", "Wq", "Wk", "Wv", "bq", "bk", "bv"), dl, leaves):
+            err = (a_.grad.cpu() - b_.grad).abs().max().item() / max(b_.grad.abs().max().item(), 1e-3 * gmax)
+            m["d" + nm] = err
+            assert err <= 5e-4, (name, nm, err)
+        out[name] = m
+    return out
+
+
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward]
