@@ -130,6 +130,31 @@ def with_output(im, smpls, FB, n_frames, t_base):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def split_products(step, im, W, K, FB, ref_outs):
+    """Reported separately: the same K steps with every Cin % 32 == 0 convolution on the bf16x6 kernel
+    (csrc/conv_igemm_split.hip: fp32 in / out / accumulate, each fp32 product formed from six bf16 MFMAs over an exact
+    three-way split of both operands).  Not the headline value; `max_abs_diff_vs_fp32_path` compares the frames."""
+    from ipercore_amd import ops
+    hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    prev = im.generator.conv_precision
+    im.generator.conv_precision = "split"
+    try:
+        for i in range(min(W, 4)):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = [step(i) for i in range(W, W + K)]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        diff = max((a - b).abs().max().item() for a, b in zip(outs, ref_outs))
+        return {"value": round(K * FB / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / K * 1e3, 3),
+                "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
+                "what": "bf16x6: exact 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per product, fp32 accumulation"}
+    finally:
+        im.generator.conv_precision = prev
+        ops.CONV_HOOK = hook
+
+
 def pipelined(step, W, K, FB, n_streams, dev):
     """Reported separately: the same K steps with independent frame batches in flight on several HIP streams, so that one
     batch's launch gaps, kernel tails and HBM-bound kernels overlap another batch's MFMA work.  Not the headline value (the
@@ -167,7 +192,7 @@ def main():
                     help="frames per launch batch; 0 = 8 at 512x512 scaled by (512/size)^2 (the 64x64-feature layers need "
                          ">= 32768 GEMM rows to give every CU two 128x128 tiles), clamped to [2, 64]")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "bf16", "split"), default="fp32",
                     help="bf16: BASELINE configs[3] mode - bf16 MFMA operands in the convs (fp32 activations / accumulation); "
                          "the headline metric (configs[1]) is fp32")
     ap.add_argument("--workload", choices=("imitate", "novel_view"), default="imitate",
@@ -176,6 +201,8 @@ def main():
     ap.add_argument("--pipelined-streams", type=int, default=3,
                     help="extra (separately reported) measurement with this many frame batches in flight; 0/1 = skip")
     ap.add_argument("--no-conv-events", action="store_true")
+    ap.add_argument("--no-split-extra", dest="split_extra", action="store_false",
+                    help="skip the separately reported bf16x6 (exact-split products) measurement")
     ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     args = ap.parse_args()
@@ -204,8 +231,8 @@ def main():
         nv[:, 0:3], nv[:, -10:] = case.src_smpl[0, 0:3], case.src_smpl[0, -10:]
         case.tgt_smpls = np.concatenate([nv] * (case.tgt_smpls.shape[0] // 180 + 1), axis=0)[:case.tgt_smpls.shape[0]]
     im = pu.make_imitator(case, frame_batch=FB, device=dev)
-    if args.precision == "bf16":
-        im.generator.conv_precision = "bf16"
+    if args.precision != "fp32":
+        im.generator.conv_precision = args.precision
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")          # sequence-global pre-pass, every rank identically
     lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
@@ -265,14 +292,17 @@ def main():
         frames = K * FB * world
         line = {
             "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}")
-                      + ("" if args.precision == "fp32" else " [bf16 MFMA conv tiles]"),
+                      + {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]"}[args.precision],
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 activations + accumulation",
+            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 activations + accumulation",
+                      "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])"
                        if args.precision == "fp32" else
-                       f"per-frame path {S}x{S}, AttLWB-SPADE generator with bf16 MFMA conv tiles (BASELINE configs[3] precision mode)",
+                       f"per-frame path {S}x{S}, AttLWB-SPADE generator with bf16 MFMA conv tiles (BASELINE configs[3] precision mode)"
+                       if args.precision == "bf16" else
+                       f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator, fp32 with bf16x6 exact-split products",
                        "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
                        "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
                        "batches_in_flight": args.streams,
@@ -287,12 +317,16 @@ def main():
                 traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            if args.precision == "split":
+                achieved *= 6.0          # executed bf16 MFMA flops: six partial products per algorithmic fp32 product
             line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
-                                "kernel": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)" if args.precision == "fp32" else
-                                "lwg_conv_igemm_bf16_kernel (bf16-operand MFMA implicit GEMM) + fp32 first layers",
+                                "kernel": {"fp32": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
+                                           "bf16": "lwg_conv_igemm_bf16_kernel (bf16-operand MFMA implicit GEMM) + fp32 first layers",
+                                           "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
+                                                    "MFMA work actually executed) + fp32 first layers"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
@@ -302,6 +336,8 @@ def main():
                 json.dump(timer.breakdown(), fp, indent=1)
         if args.pipelined_streams > 1 and args.streams == 1 and world == 1:
             line["pipelined"] = pipelined(step, W, K, FB, args.pipelined_streams, dev)
+        if args.split_extra and args.precision == "fp32" and args.streams == 1 and world == 1:
+            line["split_products"] = split_products(step, im, W, K, FB, outs)
         if args.output_frames > 0 and world == 1:
             line["with_output"] = with_output(im, mine, FB, args.output_frames, lo)
         if args.cpu_frames > 0:

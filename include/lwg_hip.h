@@ -72,6 +72,10 @@ int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
  * [ntaps*Cin/8][N][8] (same K order) and Cin % 32 == 0; activations stay fp32 in memory, are rounded to bf16 while staged
  * into LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16). */
 int lwg_conv2d_nhwc_bf16mma(const LwgConvArgs* args, lwg_stream_t stream);
+/* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
+ * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs
+ * per fp32 product, fp32 accumulation; dropped terms < 2^-23 |a b|.  Same contract and restrictions as the bf16 entry point. */
+int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* args, lwg_stream_t stream);
 
 /* Backward of the same convolutions (personalization step, tools/trainers/lwg_trainer.py:326-352: loss.backward()
  * through torch.nn.Conv2d / ConvTranspose2d).

@@ -24,14 +24,17 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
-CONV_PRECISION = "fp32"    # "bf16": convs with Cin % 32 == 0 run on the bf16-operand MFMA kernel (fp32 activations/accumulation)
+# "fp32": native fp32 MFMA.  "bf16": convs with Cin % 32 == 0 run on the bf16-operand MFMA kernel (operands ROUNDED to bf16,
+# fp32 accumulation).  "split": the same convs run on the bf16x6 kernel - both operands split EXACTLY into three bf16 parts,
+# six bf16 MFMAs per fp32 product, fp32 accumulation: fp32-level accuracy at 0.375 of the native matrix-pipe time.
+CONV_PRECISION = "fp32"
 
 
 class conv_precision(object):
     """Context manager: ``with ops.conv_precision("bf16"): ...``."""
 
     def __init__(self, mode):
-        assert mode in ("fp32", "bf16")
+        assert mode in ("fp32", "bf16", "split")
         self.mode = mode
 
     def __enter__(self):
@@ -52,7 +55,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16", "_w16x3")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -63,6 +66,7 @@ class ConvSpec:
         self.dx = [int(t[1]) for t in taps]
         self.stride, self.omul, self.ooy, self.oox = stride, omul, ooy, oox
         self._w16 = None
+        self._w16x3 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -77,6 +81,19 @@ def _w16(spec):
         wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
         spec._w16 = wk.view(K4 // 2, 8, N).permute(0, 2, 1).contiguous().to(torch.bfloat16)
     return spec._w16
+
+
+def _w16x3(spec):
+    """The three-plane bf16 panel [3][K/8][N][8] of a spec: w = hi + mid + lo exactly (round-to-nearest residual splits)."""
+    if spec._w16x3 is None or spec._w16x3.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
+        hi = wk.to(torch.bfloat16)
+        r1 = wk - hi.float()
+        mid = r1.to(torch.bfloat16)
+        lo = (r1 - mid.float()).to(torch.bfloat16)
+        spec._w16x3 = torch.stack([hi, mid, lo]).view(3, K4 // 2, 8, N).permute(0, 1, 3, 2).contiguous()
+    return spec._w16x3
 
 
 def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
@@ -116,6 +133,9 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     if CONV_PRECISION == "bf16" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16mma(a, _stream()), "lwg_conv2d_nhwc_bf16mma")
+    elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
+        a.w = _ptr(_w16x3(spec), torch.bfloat16)
+        _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
     else:
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:

@@ -684,6 +684,44 @@ def check_bf16_generator():
     return out
 
 
+def check_split_products():
+    """The bf16x6 convolution (csrc/conv_igemm_split.hip; ops.conv_precision("split")): fp32 in / out / accumulate with every
+    product formed from six bf16 MFMAs over an exact three-way split of both operands.
+    1. every conv / convT / SPADE-epilogue parity case of the fp32 kernel again in split mode, at the SAME tolerances;
+    2. error against an fp64 convolution next to the native fp32 MFMA kernel's (must not be worse than 1.25x);
+    3. the whole per-frame path in split mode against the fp32 path (frames in [-1, 1])."""
+    out = {}
+    with ops.conv_precision("split"):
+        out["conv_variants"] = check_conv_variants()
+        out["conv_transpose"] = check_conv_transpose()
+        out["spade_epilogue"] = check_spade_epilogue()
+    B, H, W, C, N = 2, 32, 32, 256, 256
+    x, w = _rand((B, H, W, C), 970), _rand((N, C, 3, 3), 971, 1.0 / np.sqrt(9 * C))
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    spec = _spec_dev(packing.pack_conv(w, None))
+    errs = {}
+    for mode in ("fp32", "split"):
+        with ops.conv_precision(mode):
+            y = ops.conv2d(x.to(DEV), spec, torch.full((B, H, W, N), float("nan"), device=DEV))
+        torch.cuda.synchronize()
+        d = y.cpu().double() - ref
+        errs[mode] = {"rms": d.pow(2).mean().sqrt().item(), "max": d.abs().max().item()}
+    errs["ref_rms"] = ref.pow(2).mean().sqrt().item()
+    out["vs_fp64"] = errs
+    assert errs["split"]["rms"] <= 1.25 * errs["fp32"]["rms"] and errs["split"]["max"] <= 1.5 * errs["fp32"]["max"], errs
+    assert errs["split"]["rms"] != errs["fp32"]["rms"], "split mode produced the fp32 kernel's result: the split kernel did not run"
+    case = pu.build_case(image_size=256, num_filters=[64, 128, 256], n_res=6, bg_filters=[64, 128, 128, 256], n_frames=2, ns=2)
+    im = pu.make_imitator(case, frame_batch=2)
+    ref_frames = pu.run_hip(case, imitator=im)
+    im.generator.conv_precision = "split"
+    im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    got = pu.run_hip(case, imitator=im)
+    torch.cuda.synchronize()
+    out["pipeline_256"] = {"max_abs": (got - ref_frames).abs().max().item(), "mean_abs": (got - ref_frames).abs().mean().item()}
+    assert torch.isfinite(got).all() and out["pipeline_256"]["max_abs"] <= 2e-4, out["pipeline_256"]
+    return out
+
+
 def check_edge_cases():
     """Ragged / degenerate inputs: image size not a multiple of the 16-px tile or the 64-px bin, a scene with every face
     culled or off-screen (empty maps), flows that are background everywhere, a 1-frame batch, M not a multiple of 32."""
@@ -865,4 +903,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products]

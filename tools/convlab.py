@@ -50,11 +50,10 @@ SHAPES = {
 
 def load(path):
     h = ctypes.CDLL(os.path.abspath(path))
-    h.lwg_conv2d_nhwc_f32.restype = ctypes.c_int
-    h.lwg_conv2d_nhwc_f32.argtypes = [ctypes.POINTER(_lib.LwgConvArgs), ctypes.c_void_p]
-    if hasattr(h, "lwg_conv2d_nhwc_bf16mma"):
-        h.lwg_conv2d_nhwc_bf16mma.restype = ctypes.c_int
-        h.lwg_conv2d_nhwc_bf16mma.argtypes = [ctypes.POINTER(_lib.LwgConvArgs), ctypes.c_void_p]
+    for sym in ("lwg_conv2d_nhwc_f32", "lwg_conv2d_nhwc_bf16mma", "lwg_conv2d_nhwc_f32_split"):
+        if hasattr(h, sym):
+            getattr(h, sym).restype = ctypes.c_int
+            getattr(h, sym).argtypes = [ctypes.POINTER(_lib.LwgConvArgs), ctypes.c_void_p]
     return h
 
 
@@ -90,13 +89,16 @@ def build_case(name):
     return x0, x1, y, launches
 
 
-BF16 = False
+BF16 = False      # False: fp32 MFMA; True: bf16 operands; "split": bf16x6
 
 
 def run(h, x0, x1, y, launches, stream):
     for spec, kw in launches:
         a = ops.conv_args(x0, spec, y, x1=x1, **kw)
-        if BF16 and spec.Cin % 32 == 0:
+        if BF16 == "split" and spec.Cin % 32 == 0:
+            a.w = ops._w16x3(spec).data_ptr()
+            e = h.lwg_conv2d_nhwc_f32_split(a, stream)
+        elif BF16 is True and spec.Cin % 32 == 0:
             a.w = ops._w16(spec).data_ptr()
             e = h.lwg_conv2d_nhwc_bf16mma(a, stream)
         else:
@@ -104,6 +106,26 @@ def run(h, x0, x1, y, launches, stream):
         if e != 0:
             return e
     return 0
+
+
+def ref64(name, x0, x1, launches):
+    """fp64 convolution of the case on the CPU (plain conv / res kinds only), NHWC, or None."""
+    B, H, W, C0, C1, N, k, stride, kind = SHAPES[name]
+    if kind not in ("conv", "res") or 2.0 * B * H * W * k * k * (C0 + C1) * N / stride ** 2 > 4e10:
+        return None
+    import torch.nn.functional as F
+    spec, kw = launches[0]
+    K4 = spec.w.shape[0]
+    wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N).cpu().double()          # kernel K order -> (tap, c, n)
+    Cin = C0 + C1
+    w = wk.view(Cin // 32, k * k, 32, N).permute(3, 0, 2, 1).reshape(N, Cin, k, k)
+    x = (x0 if x1 is None else torch.cat([x0, x1], dim=3)).cpu().double().permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    if kind == "res":
+        y = y + kw["res"].cpu().double()
+    elif kw.get("act") == ops.ACT_RELU:
+        y = y.clamp_min(0)
+    return y
 
 
 def timestamps(h, x0, x1, y, launches, stream):
@@ -137,6 +159,8 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--wgrad", action="store_true", help="time lwg_conv2d_wgrad_nhwc_f32 (weight gradient) of the first launch instead")
     ap.add_argument("--bf16", action="store_true", help="after the fp32 pass of every lib, time its bf16-operand entry point too")
+    ap.add_argument("--split", action="store_true", help="also time the bf16x6 (exact-split) entry point of every lib that has one")
+    ap.add_argument("--ref64", action="store_true", help="error of every variant against an fp64 convolution on the CPU (small plain-conv shapes)")
     args = ap.parse_args()
     libs = [(os.path.basename(p), load(p)) for p in args.libs]
     stream = torch.cuda.current_stream().cuda_stream
@@ -148,7 +172,10 @@ def main():
         base = None
         us_hint = flops / 100e12 * 1e6
         global BF16
-        todo = [(n_, h_, False) for n_, h_ in libs] + ([(n_ + " [bf16]", h_, True) for n_, h_ in libs] if args.bf16 else [])
+        todo = [(n_, h_, False) for n_, h_ in libs if hasattr(h_, "lwg_conv2d_nhwc_f32")]
+        todo += [(n_ + " [bf16]", h_, True) for n_, h_ in libs if hasattr(h_, "lwg_conv2d_nhwc_bf16mma")] if args.bf16 else []
+        todo += [(n_ + " [x6]", h_, "split") for n_, h_ in libs if hasattr(h_, "lwg_conv2d_nhwc_f32_split")] if args.split else []
+        y64 = ref64(name, x0, x1, launches) if args.ref64 else None
         if args.wgrad:
             spec, kw = launches[0]
             dy = torch.randn_like(y)
@@ -198,7 +225,13 @@ def main():
             us = s.elapsed_time(t) * 1e3 / args.iters
             tf = flops / (us * 1e-6) / 1e12
             rows.append({"shape": name, "lib": lname, "us": round(us, 1), "tflops": round(tf, 1), "maxdiff": diff})
-            print(f"{name:10s} {lname:28s} {us:9.1f} us  {tf:6.1f} TF/s  ({tf / 157.3 * 100:4.1f}%)  maxdiff {diff:.2e}", flush=True)
+            acc = ""
+            if y64 is not None:
+                d = out.cpu().double() - y64
+                rms = y64.pow(2).mean().sqrt().item()
+                rows[-1]["err64_max_over_rms"], rows[-1]["err64_rms_over_rms"] = d.abs().max().item() / rms, d.pow(2).mean().sqrt().item() / rms
+                acc = f"  vs fp64: max {rows[-1]['err64_max_over_rms']:.2e} rms {rows[-1]['err64_rms_over_rms']:.2e} (of ref rms)"
+            print(f"{name:10s} {lname:28s} {us:9.1f} us  {tf:6.1f} TF/s  ({tf / 157.3 * 100:4.1f}%)  maxdiff {diff:.2e}{acc}", flush=True)
             if hasattr(h, "lwg_lab_read_ts"):
                 timestamps(h, x0, x1, y, launches[:1], stream)
     if args.json:

@@ -30,7 +30,7 @@ if [[ " $WHAT " == *" bench "* ]]; then
   echo "bench exit=$?"; tail -3 gpurun_out/bench.log; tail -5 gpurun_out/bench.err
 fi
 if [[ " $WHAT " == *" prof "* ]]; then
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o lwg -- python "$OLDPWD/bench.py" --steps 4 --warmup 2 --cpu-frames 0 --no-conv-events --pipelined-streams 0 --output-frames 0 > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o lwg -- python "$OLDPWD/bench.py" --steps 4 --warmup 2 --cpu-frames 0 --no-conv-events --pipelined-streams 0 --output-frames 0 --no-split-extra > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1 )
   echo "prof exit=$?"; find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats*" | head -1); [ -n "$f" ] && head -25 "$f"
 fi

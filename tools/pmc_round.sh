@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
-CMD="python $R/bench.py --steps 3 --warmup 2 --cpu-frames 0 --no-conv-events --pipelined-streams 0 --output-frames 0"
+CMD="python $R/bench.py --steps 3 --warmup 2 --cpu-frames 0 --no-conv-events --pipelined-streams 0 --output-frames 0 --no-split-extra"
 run() { # name counters...
   local name=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$name" -o pmc -- $CMD > "$R/gpurun_out/pmc_$name.log" 2>&1 )
