@@ -132,6 +132,12 @@ int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, cons
 int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
                               const float* T, const float* dout, float* dq, float* dKs, float* dVs, int B, int ns,
                               int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
+/* The non-attention Liquid Warping Blocks (AddLWB / AvgLWB: generators/lwb_resunet.py:77-152; SoftGateLWB:
+ * generators/lwb_softgate_resunet.py:77-123) as one gather kernel:
+ *   out = (tsf_x + gate * scale_w * sum_s warp_s(src_x)) * scale_o        gate == NULL: 1
+ * Add: (1, 1); Avg: scale_o = 1/(ns+1); SoftGateAdd: gate, (1, 1); SoftGateAvg: gate, scale_w = 1/ns.  Layouts as above. */
+int lwg_lwb_fuse_f32(const float* tsf_x, const float* src_x, const float* gate, const float* T, float* out, int B, int ns,
+                     int h, int w, int C, int S, int src_batched, float scale_w, float scale_o, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Renderer (replaces the `neural_renderer` CUDA package as used by renders/nmr.py).

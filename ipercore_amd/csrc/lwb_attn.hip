@@ -283,3 +283,99 @@ extern "C" int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const 
 #undef LWG_ATTN_BWD_LAUNCH
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The non-attention Liquid Warping Blocks of the reference's other generators:
+//   AddLWB / AvgLWB      generators/lwb_resunet.py:77-152            out = sum | mean over [tsf_x, warp_1(src), .., warp_ns(src)]
+//   SoftGateLWB          generators/lwb_softgate_resunet.py:77-123   out = tsf_x + gate * (sum | mean over the warped sources)
+// as one gather kernel:   out = (tsf_x + gate * scale_w * sum_s warp_s(src_x)) * scale_o      (gate == nullptr: 1)
+// Same flow resize / grid_sample conventions, lane mapping and 16-byte gathers as lwg_lwb_attn_kernel.
+template <int LPP>
+__global__ __launch_bounds__(256) void lwg_lwb_fuse_kernel(const float* __restrict__ tsf, const float* __restrict__ src,
+                                                          const float* __restrict__ gate, const float* __restrict__ T,
+                                                          float* __restrict__ out, int B, int ns, int h, int w, int S, int src_batched,
+                                                          float scale_w, float scale_o) {
+    constexpr int C = 4 * LPP;
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cl = lane % LPP;
+    const long total = (long)B * h * w;
+    const long gp = ((long)blockIdx.x * 4 + wid) * PPW + lane / LPP;
+    if (gp >= total) return;
+    const int hw = h * w;
+    const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
+    const int y = rem / w, x = rem - y * w;
+
+    const float sc_y = h > 1 ? (float)(S - 1) / (float)(h - 1) : 0.f;
+    const float sc_x = w > 1 ? (float)(S - 1) / (float)(w - 1) : 0.f;
+    const float sy = sc_y * (float)y, sx = sc_x * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const bool same = (h == S) && (w == S);
+
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ns; ++s) {
+        const float2* Tp = reinterpret_cast<const float2*>(T) + ((size_t)b * ns + s) * S * S;
+        float gx, gy;
+        if (same) {
+            const float2 t = Tp[(size_t)y * S + x];
+            gx = t.x; gy = t.y;
+        } else {
+            const float2 t00 = Tp[(size_t)y0 * S + x0], t01 = Tp[(size_t)y0 * S + x1];
+            const float2 t10 = Tp[(size_t)y1 * S + x0], t11 = Tp[(size_t)y1 * S + x1];
+            gx = ly0 * (lx0 * t00.x + lx1 * t01.x) + ly1 * (lx0 * t10.x + lx1 * t11.x);
+            gy = ly0 * (lx0 * t00.y + lx1 * t01.y) + ly1 * (lx0 * t10.y + lx1 * t11.y);
+        }
+        const float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+        const int tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+        const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
+        const float* Sb = src + sidx * hw * C + 4 * cl;
+        floatx4 wv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+            const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                const floatx4 v4 = *reinterpret_cast<const floatx4*>(Sb + ((size_t)ty * w + tx) * C);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wv[k] += v4[k] * wt;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += wv[k];       // the reference sums the warped sources one after the other
+    }
+    const floatx4 t4 = *reinterpret_cast<const floatx4*>(tsf + gp * C + 4 * cl);
+    floatx4 g4 = {1.f, 1.f, 1.f, 1.f};
+    if (gate) g4 = *reinterpret_cast<const floatx4*>(gate + gp * C + 4 * cl);
+    floatx4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (t4[k] + g4[k] * (acc[k] * scale_w)) * scale_o;
+    *reinterpret_cast<floatx4*>(out + gp * C + 4 * cl) = r;
+}
+
+// tsf_x / gate / out (B,h,w,C); src_x (ns,h,w,C) or (B*ns,h,w,C); T (B,ns,S,S,2); gate may be NULL; C in {32,64,128,256}.
+extern "C" int lwg_lwb_fuse_f32(const float* tsf_x, const float* src_x, const float* gate, const float* T, float* out, int B, int ns,
+                                int h, int w, int C, int S, int src_batched, float scale_w, float scale_o, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!tsf_x || !src_x || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0) return (int)hipErrorInvalidValue;
+    const long total = (long)B * h * w;
+#define LWG_FUSE_LAUNCH(LPP)                                                                                          \
+    {                                                                                                                 \
+        const long per_block = 4 * (64 / LPP);                                                                        \
+        hipLaunchKernelGGL(lwg_lwb_fuse_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
+                           tsf_x, src_x, gate, T, out, B, ns, h, w, S, src_batched, scale_w, scale_o);                            \
+    }
+    switch (C) {
+        case 32: LWG_FUSE_LAUNCH(8) break;
+        case 64: LWG_FUSE_LAUNCH(16) break;
+        case 128: LWG_FUSE_LAUNCH(32) break;
+        case 256: LWG_FUSE_LAUNCH(64) break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LWG_FUSE_LAUNCH
+    return (int)hipGetLastError();
+}

@@ -8,10 +8,11 @@ class NetworksFactory(object):
 
     @staticmethod
     def get_by_name(network_name, *args, **kwargs):
-        from .generator import AttentionLWBFrontGenerator, AttentionLWBGenerator
-        if network_name == "AttLWB-SPADE":
-            return AttentionLWBGenerator(*args, **kwargs)
-        if network_name == "AttLWB-Front-SPADE":
-            return AttentionLWBFrontGenerator(*args, **kwargs)
-        raise ValueError(f"Network {network_name} is outside the MI355X hot path (SURVEY.md section 8): "
-                         "only AttLWB-SPADE / AttLWB-Front-SPADE are built")
+        from . import generator as g
+        table = {"AttLWB-SPADE": g.AttentionLWBGenerator, "AttLWB-Front-SPADE": g.AttentionLWBFrontGenerator,
+                 "AddLWB": g.AddLWBGenerator, "AvgLWB": g.AvgLWBGenerator,
+                 "SoftGateAddLWB": g.SoftGateAddLWBGenerator, "SoftGateAvgLWB": g.SoftGateAvgLWBGenerator}
+        if network_name in table:
+            return table[network_name](*args, **kwargs)
+        raise ValueError(f"Network {network_name} is outside the MI355X hot path (SURVEY.md section 8): built are "
+                         f"{sorted(table)}; AttLWB-AdaIN, InputConcat, TextureWarping and the discriminators' factory names are not")

@@ -104,6 +104,12 @@ class _Packed:
         self.src_dec = [convT(f"src_net.decoders.layers.{i}.0") for i in range(n_down)]
         self.src_head = P.pack_head(sd["src_net.img_reg.0.weight"], sd["src_net.att_reg.0.weight"]).to(dev)
         self.res = [(conv(f"res_blocks.{i}.main.0"), conv(f"res_blocks.{i}.main.2")) for i in range(n_res)]
+        if gen.lwb_kind == "att":
+            pass
+        elif gen.lwb_kind in ("sg_add", "sg_avg"):
+            site = lambda p: {"g0": conv(p + ".gate_conv.0"), "g2": conv(p + ".gate_conv.2")}      # noqa: E731
+        else:
+            site = lambda p: {}                                                                     # noqa: E731
         self.enc_sites = [site(f"enc_attlwbs.{i}") for i in range(n_down)]
         self.res_sites = [site(f"res_attlwbs.{i}") for i in range(n_res)]
         self.upconvs = [convT(f"tsf_net_dec.upconvs.{i}.0") for i in range(n_down)]
@@ -141,6 +147,9 @@ class SourceFeatures:
 
 class AttentionLWBGenerator(nn.Module):
     has_bg = True
+    # the Liquid Warping Block of the transfer stream: "att" (SelfAttentionLWB + SPADE), "add" / "avg" (AddLWB / AvgLWB),
+    # "sg_add" / "sg_avg" (SoftGateLWB) - see the subclasses at the end of this file
+    lwb_kind = "att"
 
     def __init__(self, cfg, temporal=False):
         super().__init__()
@@ -162,7 +171,8 @@ class AttentionLWBGenerator(nn.Module):
             self.bg_filters = [int(c) for c in _get(bgc, "num_filters")]
             bg_cond = int(_get(bgc, "cond_nc"))
         shapes = generator_param_shapes(self.num_filters, self.n_res_block, self.bg_filters or (), cond_nc=self.cond_nc,
-                                        bg_cond_nc=bg_cond, with_bg=self.has_bg)
+                                        bg_cond_nc=bg_cond, with_bg=self.has_bg,
+                                        lwb={"att": "att", "add": "plain", "avg": "plain"}.get(self.lwb_kind, "softgate"))
         tree = ParamTree(shapes)
         for name, child in tree.named_children():     # graft the tree's top-level nodes onto this module
             self.add_module(name, child)
@@ -200,14 +210,32 @@ class AttentionLWBGenerator(nn.Module):
             h = ops.conv2d(x, c0, torch.empty_like(x), act=ops.ACT_RELU)
             x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
             res.append(x)
+        return SourceFeatures(enc, res, self._project_sources(pk, enc, res), ns if ns is not None else src8.shape[0], batched)
+
+    def _project_sources(self, pk, enc, res):
+        """Per LWB site what the per-frame kernel gathers from: the hoisted K / V projections (attention) or the source
+        features themselves (Add / Avg / SoftGate blocks warp the raw features)."""
         kv = []
         for feats, sites in ((enc, pk.enc_sites), (res, pk.res_sites)):
             for f, st in zip(feats, sites):
-                kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
-        return SourceFeatures(enc, res, kv, ns if ns is not None else src8.shape[0], batched)
+                if self.lwb_kind == "att":
+                    kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
+                else:
+                    kv.append((f, None))
+        return kv
 
     def _attlwb(self, st, tsf_x, kv, Tst, batched, scratch):
         B, h, w, C = tsf_x.shape
+        if self.lwb_kind != "att":
+            ns = Tst.shape[1]
+            if self.lwb_kind == "add":
+                return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), src_batched=batched)
+            if self.lwb_kind == "avg":
+                return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), scale_o=1.0 / (ns + 1), src_batched=batched)
+            g = ops.conv2d(tsf_x, st["g0"], torch.empty_like(tsf_x), act=ops.ACT_RELU)
+            g = ops.conv2d(g, st["g2"], torch.empty_like(tsf_x), act=ops.ACT_SIGMOID)
+            return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), gate=g,
+                                scale_w=1.0 if self.lwb_kind == "sg_add" else 1.0 / ns, src_batched=batched)
         q = ops.conv2d(tsf_x, st["fq"], torch.empty_like(tsf_x))
         att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], Tst, torch.empty_like(tsf_x), src_batched=batched)
         mean = tsf_x.new_empty(B, C)
@@ -341,12 +369,8 @@ class AttentionLWBGenerator(nn.Module):
         pk = self.packed()
         enc = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_enc_outs]
         res = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_res_outs]
-        kv = []
-        for fl, sites in ((enc, pk.enc_sites), (res, pk.res_sites)):
-            for f, st in zip(fl, sites):
-                kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
         n = enc[0].shape[0]
-        return SourceFeatures(enc, res, kv, n // bs, batched=bs > 1)
+        return SourceFeatures(enc, res, self._project_sources(pk, enc, res), n // bs, batched=bs > 1)
 
     @torch.no_grad()
     def forward_tsf(self, tsf_inputs, src_enc_outs, src_res_outs, Tst, temp_enc_outs=None, temp_res_outs=None, Ttt=None):
@@ -357,7 +381,7 @@ class AttentionLWBGenerator(nn.Module):
         bs = tsf_inputs.shape[0]
         feats = self._features_from_api(src_enc_outs, src_res_outs, bs)
         T = Tst.contiguous().float()
-        if temp_enc_outs is not None and Ttt is not None:
+        if temp_enc_outs is not None and Ttt is not None and self.lwb_kind == "att":      # the other blocks ignore temp_x / Ttt
             if bs != 1:
                 raise NotImplementedError("temporal attention runs one clip per process (bs = 1), as Imitator.inference does")
             tfe = self._features_from_api(temp_enc_outs, temp_res_outs, bs)
@@ -399,6 +423,28 @@ class AttentionLWBFrontGenerator(AttentionLWBGenerator):
 
     def forward(self, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
         raise NotImplementedError("AttLWB-Front-SPADE.forward is used by LWGFrontTrainer only (training: next row)")
+
+
+class AddLWBGenerator(AttentionLWBGenerator):
+    """generators/lwb_resunet.py:509-518 (BaseLWBGenerator :315-506 with AddLWB :77-111): same three streams, the transfer
+    stream fuses by  tsf_x + sum_s warp_s(src_x)  - no block parameters."""
+    lwb_kind = "add"
+
+
+class AvgLWBGenerator(AttentionLWBGenerator):
+    """generators/lwb_resunet.py:521-531 with AvgLWB :114-152: mean over [tsf_x, warped sources]."""
+    lwb_kind = "avg"
+
+
+class SoftGateAddLWBGenerator(AttentionLWBGenerator):
+    """generators/lwb_softgate_resunet.py:522-525 (SoftGateLWBGenerator :317-519, SoftGateLWB :77-123):
+    tsf_x + sigmoid(conv3(relu(conv3(tsf_x)))) * sum_s warp_s(src_x)."""
+    lwb_kind = "sg_add"
+
+
+class SoftGateAvgLWBGenerator(AttentionLWBGenerator):
+    """generators/lwb_softgate_resunet.py:528-531: the gate times the mean of the warped sources."""
+    lwb_kind = "sg_avg"
 
 
 class _FeatList(list):

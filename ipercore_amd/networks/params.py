@@ -51,9 +51,17 @@ def bg_net_param_shapes(spec, cond_nc, filters, n_res):
     _conv(spec, f"bg_net.main.{i}", 3, filters[0], 7, bias=False)
 
 
+def _softgate(spec, p, c_src, c_tsf):
+    """SoftGateLWB.gate_conv (lwb_softgate_resunet.py:83-88): Conv3(in = src filters, out = tsf filters) + ReLU + Conv3 + Sigmoid."""
+    _conv(spec, p + ".gate_conv.0", c_tsf, c_src, 3)
+    _conv(spec, p + ".gate_conv.2", c_tsf, c_tsf, 3)
+
+
 def generator_param_shapes(num_filters=(64, 128, 256), n_res_block=6, bg_filters=(64, 128, 128, 256),
-                           cond_nc=6, bg_cond_nc=4, with_bg=True):
-    """OrderedDict name -> shape for AttLWB-SPADE (``with_bg=False`` gives AttLWB-Front-SPADE, :702-834)."""
+                           cond_nc=6, bg_cond_nc=4, with_bg=True, lwb="att"):
+    """OrderedDict name -> shape for AttLWB-SPADE (``with_bg=False`` gives AttLWB-Front-SPADE, :702-834).
+    lwb = "plain": AddLWB / AvgLWB (lwb_resunet.py:315-363, no block parameters); "softgate": SoftGateAdd/AvgLWB
+    (lwb_softgate_resunet.py:286-372)."""
     nf = list(num_filters)
     n_down = len(nf)
     spec = OrderedDict()
@@ -81,10 +89,18 @@ def generator_param_shapes(num_filters=(64, 128, 256), n_res_block=6, bg_filters
     for i in range(n_down):
         d_in = nf[-1] if i == 0 else rev[i - 1]
         _convT(spec, f"tsf_net_dec.upconvs.{i}.0", d_in, rev[i])
-    for i in range(n_down):
-        _attlwb(spec, f"enc_attlwbs.{i}", nf[i], nf[i], nf[i])
-    for i in range(n_res_block):
-        _attlwb(spec, f"res_attlwbs.{i}", nf[-1], nf[-1], nf[-1])
+    if lwb == "att":
+        for i in range(n_down):
+            _attlwb(spec, f"enc_attlwbs.{i}", nf[i], nf[i], nf[i])
+        for i in range(n_res_block):
+            _attlwb(spec, f"res_attlwbs.{i}", nf[-1], nf[-1], nf[-1])
+    elif lwb == "softgate":
+        for i in range(n_down):
+            _softgate(spec, f"enc_attlwbs.{i}", nf[i], nf[i])
+        for i in range(n_res_block):
+            _softgate(spec, f"res_attlwbs.{i}", nf[-1], nf[-1])
+    else:
+        assert lwb == "plain", lwb
     for i in range(n_res_block):
         _conv(spec, f"res_blocks.{i}.main.0", nf[-1], nf[-1], 3)
         _conv(spec, f"res_blocks.{i}.main.2", nf[-1], nf[-1], 3)

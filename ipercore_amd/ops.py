@@ -170,6 +170,16 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     return out
 
 
+def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batched=False):
+    """out = (tsf_x + gate * scale_w * sum_s warp_s(src_x)) * scale_o - AddLWB / AvgLWB / SoftGateLWB fusion."""
+    B, h, w, C = tsf_x.shape
+    ns, S = T.shape[1], T.shape[2]
+    assert T.shape[0] == B and src_x.shape[0] == (B * ns if src_batched else ns) and tuple(src_x.shape[1:]) == (h, w, C)
+    _lib.check(_lib.lib().lwg_lwb_fuse_f32(_ptr(tsf_x), _ptr(src_x), _ptr(gate), _ptr(T), _ptr(out), B, ns, h, w, C, S,
+                                           1 if src_batched else 0, float(scale_w), float(scale_o), _stream()), "lwg_lwb_fuse_f32")
+    return out
+
+
 def lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=False):
     """Gradients of ``lwb_attention`` w.r.t. q, Ks, Vs (the flows are constants).  dbv = colsum(dout), dbk = 0."""
     B, h, w, C = q.shape

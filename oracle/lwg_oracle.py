@@ -288,6 +288,22 @@ def attention_lwb(sd, p, tsf_x, src_x, Tst, temp_x=None, Ttt=None):
     return normalized * (1 + gamma) + beta
 
 
+def fuse_lwb(sd, p, tsf_x, src_x, Tst, kind):
+    """The non-attention Liquid Warping Blocks: ``AddLWB`` / ``AvgLWB`` (generators/lwb_resunet.py:77-152: sum / mean over
+    [tsf_x, warped sources]) and ``SoftGateLWB`` (generators/lwb_softgate_resunet.py:77-123: tsf_x + gate(tsf_x) * sum|mean of the
+    warped sources, gate = sigmoid(conv3(relu(conv3(tsf_x))))).  kind in {"add", "avg", "sg_add", "sg_avg"}."""
+    bs, ns, H, W, _ = Tst.shape
+    h, w = tsf_x.shape[-2:]
+    warp = lwb_transform(src_x, Tst.reshape(bs * ns, H, W, 2)).view(bs, ns, -1, h, w)
+    if kind == "add":
+        return tsf_x + warp.sum(dim=1)
+    if kind == "avg":
+        return torch.cat([tsf_x.unsqueeze(1), warp], dim=1).mean(dim=1)
+    fused = warp.sum(dim=1) if kind == "sg_add" else warp.mean(dim=1)
+    gate = torch.sigmoid(_conv(sd, p + ".gate_conv.2", F.relu(_conv(sd, p + ".gate_conv.0", tsf_x))))
+    return tsf_x + gate * fused
+
+
 def _res_block(sd, p, x):
     """ResidualBlock :14-25."""
     return x + _conv(sd, p + ".main.2", F.relu(_conv(sd, p + ".main.0", x)))
@@ -334,18 +350,26 @@ def gen_forward_train(sd, bg_inputs, src_inputs, tsf_inputs, Tst, n_down=3, n_re
 
 
 def gen_forward_tsf(sd, tsf_inputs, src_enc_outs, src_res_outs, Tst, n_down=3, n_res=6, temp_enc_outs=None,
-                    temp_res_outs=None, Ttt=None):
-    """BaseAttentionLWBGenerator.forward_tsf :480-535 -> (tsf_img, tsf_mask); temp_* / Ttt: the temporal attention inputs."""
+                    temp_res_outs=None, Ttt=None, lwb="att"):
+    """BaseAttentionLWBGenerator.forward_tsf :480-535 -> (tsf_img, tsf_mask); temp_* / Ttt: the temporal attention inputs.
+    lwb != "att": the same stream with the AddLWB / AvgLWB / SoftGateLWB blocks (lwb_resunet.py:414-455,
+    lwb_softgate_resunet.py:414-465; those generators ignore the temporal inputs)."""
     x = tsf_inputs
     enc = []
     tmp = temp_enc_outs is not None and Ttt is not None
+
+    def block(p, x_, src, tmp_feats, i_):
+        if lwb == "att":
+            return attention_lwb(sd, p, x_, src, Tst, tmp_feats[i_] if tmp else None, Ttt if tmp else None)
+        return fuse_lwb(sd, p, x_, src, Tst, lwb)
+
     for i in range(n_down):
         x = F.relu(_conv(sd, f"tsf_net_enc.layers.{i}.0", x, stride=2))
-        x = attention_lwb(sd, f"enc_attlwbs.{i}", x, src_enc_outs[i], Tst, temp_enc_outs[i] if tmp else None, Ttt if tmp else None)
+        x = block(f"enc_attlwbs.{i}", x, src_enc_outs[i], temp_enc_outs, i)
         enc.append(x)
     for i in range(n_res):
         x = _res_block(sd, f"res_blocks.{i}", x)
-        x = attention_lwb(sd, f"res_attlwbs.{i}", x, src_res_outs[i], Tst, temp_res_outs[i] if tmp else None, Ttt if tmp else None)
+        x = block(f"res_attlwbs.{i}", x, src_res_outs[i], temp_res_outs, i)
     for i in range(n_down):                                                      # SkipDecoder :316-357
         x = F.relu(_convT(sd, f"tsf_net_dec.upconvs.{i}.0", x))
         if i != n_down - 1:

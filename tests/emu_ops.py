@@ -137,6 +137,19 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     return out
 
 
+def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batched=False):
+    B, h, w, C = tsf_x.shape
+    ns, S = T.shape[1], T.shape[2]
+    Tf = T.reshape(B * ns, S, S, 2)
+    if S != h:
+        Tf = F.interpolate(Tf.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    Sn = src_x if src_batched else src_x.repeat(B, 1, 1, 1)
+    warp = F.grid_sample(Sn.permute(0, 3, 1, 2), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    fused = warp.view(B, ns, C, h, w).sum(dim=1).permute(0, 2, 3, 1) * scale_w
+    out.copy_((tsf_x + (fused if gate is None else gate * fused)) * scale_o)
+    return out
+
+
 def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
     B, S, _, C = x.shape
     w = wpk.view(5, 5, C, 4).permute(3, 2, 0, 1)
@@ -220,7 +233,7 @@ def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
-                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd"):
+                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

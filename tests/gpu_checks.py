@@ -335,6 +335,46 @@ def check_generator_golden():
     return out
 
 
+def check_lwb_variant_generators():
+    """AddLWB / AvgLWB / SoftGateAddLWB / SoftGateAvgLWB (reference networks/__init__.py:22-36) on the GPU - lwg_lwb_fuse_f32 +
+    the gate convs with the sigmoid epilogue - against outputs of the REFERENCE's own generators
+    (tests/golden/golden_lwb_variants_v1.npz), reduced and full width; plus a batched-source / multi-frame call against the oracle."""
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.networks import NetworksFactory
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    gv = np.load(os.path.join(ROOT, "tests", "golden", "golden_lwb_variants_v1.npz"))
+    S, ns, out = 64, 2, {}
+    src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    Tst = torch.tensor(g["render/Tst"]).view(1, ns, S, S, 2)
+    for name, kind in (("AddLWB", "add"), ("AvgLWB", "avg"), ("SoftGateAddLWB", "sg_add"), ("SoftGateAvgLWB", "sg_avg")):
+        for tag, nf, nres, bgf in (("tiny", [64, 64, 128], 2, [64, 64, 128]), ("full", [64, 128, 256], 6, [64, 128, 128, 256])):
+            G = NetworksFactory.get_by_name(name, cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).eval()
+            shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+            sdn = synthetic.fill_state_dict(shapes, seed=11)
+            G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+            G.to(DEV)
+            enc, res = G.forward_src(src_inputs.to(DEV), only_enc=True)
+            img, mask = G.forward_tsf(tsf_inputs.to(DEV), enc, res, Tst.to(DEV))
+            torch.cuda.synchronize()
+            out[f"{name}/{tag}"] = {"img": _cmp(img, torch.tensor(gv[f"{name}/{tag}/img"]), 2e-3, name + " img"),
+                                    "mask": _cmp(mask, torch.tensor(gv[f"{name}/{tag}/mask"]), 2e-3, name + " mask")}
+            assert out[f"{name}/{tag}"]["img"]["mean_abs"] <= 1e-4
+        # bs = 2 (batched sources: frame b warps rows b*ns+s) through the full forward(), oracle as the reference
+        sd = {k: torch.tensor(v) for k, v in sdn.items()}
+        src2 = torch.cat([src_inputs, src_inputs.flip(1) * 0.5], dim=0)
+        tsf2 = torch.cat([tsf_inputs, tsf_inputs * -0.7], dim=0)
+        T2 = torch.cat([Tst, Tst.flip(1)], dim=0)
+        bg2 = torch.tensor(synthetic.uniform_image((2, 1, 4, S, S), 10, "bg_inputs"))
+        outs = G(bg2.to(DEV), src2.to(DEV), tsf2.unsqueeze(1).to(DEV), T2.unsqueeze(1).to(DEV), only_tsf=True)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            e, r = orc.gen_forward_src(sd, src2, n_down=3, n_res=6)
+            want, _ = orc.gen_forward_tsf(sd, tsf2, e, r, T2, n_down=3, n_res=6, lwb=kind)
+        out[f"{name}/bs2"] = _cmp(outs[1][:, 0], want, 2e-3, name + " bs2")
+    return out
+
+
 def _pipeline(S, nf, nres, bgf, n_frames, frame_batch, frames=None):
     case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=n_frames, ns=2)
     t0 = time.time()
@@ -903,4 +943,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators]

@@ -1,5 +1,7 @@
 """Host logic of the generator (weight packing, launch orchestration, layouts, API) on CPU: the C-ABI ops are
 replaced by tests/emu_ops.py, the result is checked against the oracle and the reference-generated goldens."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,6 +74,29 @@ def test_generator_api_through_emulated_abi(monkeypatch, golden, tag, nf, nres, 
     outs = G(bg_inputs, src_inputs, tsf_inputs.unsqueeze(1), Tst.unsqueeze(1), only_tsf=True)
     assert outs[0].shape == (1, 1, 3, S, S) and outs[1].shape == (1, 1, 3, S, S) and outs[2].shape == (1, 1, 1, S, S)
     assert torch.allclose(outs[1][:, 0], img, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["AddLWB", "AvgLWB", "SoftGateAddLWB", "SoftGateAvgLWB"])
+def test_lwb_variant_generators_through_emulated_abi(monkeypatch, golden, name):
+    """The other Liquid Warping Block generators of the reference's factory (networks/__init__.py:22-36) behind the same API:
+    host logic (parameter tree, packing, block dispatch, scale factors) against the reference's own outputs."""
+    from ipercore_amd.networks import generator_param_shapes
+    emu_ops.install(monkeypatch)
+    gv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_lwb_variants_v1.npz"))
+    nf, nres, bgf, ns = [64, 64, 128], 2, [64, 64, 128], 2
+    G = NetworksFactory.get_by_name(name, cfg=synthetic.gen_cfg(nf, nres, bgf), temporal=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    assert shapes == {k: tuple(v) for k, v in generator_param_shapes(nf, nres, bgf, lwb="plain" if "Soft" not in name else "softgate").items()}
+    G.load_state_dict({k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=11).items()}, strict=True)
+    src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    Tst = torch.tensor(golden["render/Tst"]).view(1, ns, S, S, 2)
+    enc, res = G.forward_src(src_inputs, only_enc=True)
+    img, mask = G.forward_tsf(tsf_inputs, enc, res, Tst)
+    assert np.abs(img.numpy() - gv[f"{name}/tiny/img"]).max() <= 2e-4
+    assert np.abs(mask.numpy() - gv[f"{name}/tiny/mask"]).max() <= 2e-4
+    img2, _ = G.forward_tsf(tsf_inputs, list(enc), list(res), Tst)
+    assert torch.allclose(img, img2, atol=1e-6)
 
 
 def test_cpu_tensors_fail_loudly():

@@ -4,6 +4,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from ipercore_amd import synthetic
@@ -117,6 +118,33 @@ def test_generator_tiny(golden):
 
 def test_generator_full(golden):
     _gen_case(golden, "full", [64, 128, 256], 6, [64, 128, 128, 256])
+
+
+LWB_VARIANTS = (("AddLWB", "add", "plain"), ("AvgLWB", "avg", "plain"), ("SoftGateAddLWB", "sg_add", "softgate"),
+                ("SoftGateAvgLWB", "sg_avg", "softgate"))
+
+
+@pytest.mark.parametrize("name,kind,shapes_kind", LWB_VARIANTS)
+def test_lwb_variant_generators_match_reference(golden, name, kind, shapes_kind):
+    """AddLWB / AvgLWB / SoftGateAdd / SoftGateAvg transfer streams of the oracle against outputs of the reference's own
+    generators (tests/golden/make_golden_lwb_variants.py), and the parameter inventory against their state_dict keys."""
+    import hashlib
+    from ipercore_amd.networks import generator_param_shapes
+    gv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_lwb_variants_v1.npz"))
+    S, ns = 64, 2
+    src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"))
+    Tst = torch.tensor(golden["render/Tst"]).view(1, ns, S, S, 2)
+    for tag, nf, nres, bgf in (("tiny", [64, 64, 128], 2, [64, 64, 128]), ("full", [64, 128, 256], 6, [64, 128, 128, 256])):
+        shapes = generator_param_shapes(nf, nres, bgf, lwb=shapes_kind)
+        keys_sha = hashlib.sha256("\n".join(f"{k}:{tuple(shapes[k])}" for k in sorted(shapes)).encode()).hexdigest()
+        assert keys_sha == str(gv[f"{name}/{tag}/keys_sha"])
+        sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=11).items()}
+        with torch.no_grad():
+            enc, res = orc.gen_forward_src(sd, src_inputs, n_down=len(nf), n_res=nres)
+            img, mask = orc.gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(nf), n_res=nres, lwb=kind)
+        assert np.abs(img.numpy() - gv[f"{name}/{tag}/img"]).max() <= 1e-4
+        assert np.abs(mask.numpy() - gv[f"{name}/{tag}/mask"]).max() <= 1e-4
 
 
 def test_identity_warp_property(topo):
