@@ -233,6 +233,9 @@ int lwg_boundary_fill_f32(const float* src, const float* confidant, const float*
 int lwg_grid_sample_nchw_f32(const float* img, size_t img_bstride, const float* grid, int n, int C, int H, int W, int Ho,
                              int Wo, float* out, lwg_stream_t stream);
 int lwg_uv_merge_f32(const float* src_warp, const float* vis, int ns, int H, int W, float* out, lwg_stream_t stream);
+/* Swapper (FlowCompositionForSwapper.merge_uv_img, flowcomposition.py:816-856): n people's UV images (n,3,H,W) merged with
+ * their selected-part visibility maps (n,1,H,W):  out = sum_i uv_i * vis_i / (sum_j vis_j + 1e-7)  -> (3,H,W). */
+int lwg_uv_merge_parts_f32(const float* uv_imgs, const float* vis, int n, int H, int W, float* out, lwg_stream_t stream);
 int lwg_pack_inputs_f32(const float* a, int Ca, const float* b, int Cb, const float* mask, int n, int H, int W, int Cp,
                         float* out, lwg_stream_t stream);
 

@@ -74,6 +74,7 @@ _SIGS = {
     "lwg_boundary_fill_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "lwg_grid_sample_nchw_f32": (c_i, [c_f, ctypes.c_size_t, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_uv_merge_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_uv_merge_parts_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "lwg_pack_inputs_f32": (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
 }
 

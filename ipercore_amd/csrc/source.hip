@@ -353,6 +353,32 @@ extern "C" int lwg_uv_merge_f32(const float* src_warp, const float* vis, int ns,
     return (int)hipGetLastError();
 }
 
+// Swapper: UV images of several people merged by their selected-part visibility (flowcomposition.py:816-856, merge_uv_img):
+// norm_i = vis_i / (sum_j vis_j + 1e-7);  out = sum_i uv_i * norm_i, in the reference's order of operations.
+__global__ void lwg_uv_merge_parts_kernel(const float* __restrict__ uv, const float* __restrict__ vis, int n, int HW,
+                                          float* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float vs = 0.f;
+        for (int s = 0; s < n; ++s) vs += vis[(size_t)s * HW + i];
+        const float den = vs + 1e-7f;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        for (int s = 0; s < n; ++s) {
+            const float nv = vis[(size_t)s * HW + i] / den;
+            const float* u = uv + (size_t)s * 3 * HW;
+            o0 += u[i] * nv; o1 += u[(size_t)HW + i] * nv; o2 += u[2 * (size_t)HW + i] * nv;
+        }
+        out[i] = o0; out[(size_t)HW + i] = o1; out[2 * (size_t)HW + i] = o2;
+    }
+}
+
+extern "C" int lwg_uv_merge_parts_f32(const float* uv_imgs, const float* vis, int n, int H, int W, float* out, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!uv_imgs || !vis || !out || n <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+    const int HW = H * W;
+    hipLaunchKernelGGL(lwg_uv_merge_parts_kernel, dim3((HW + 255) / 256), dim3(256), 0, stream, uv_imgs, vis, n, HW, out);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------- network inputs
 // cat[a * mask?, b] (NCHW planes) -> NHWC with Cp channels (zero padded): the bg net input [img * m, m] (NHWC-4) and the
 // SIDNet input [morph_img, cond] (NHWC-8) (flowcomposition.py:250-266) written straight in the engine's layout.

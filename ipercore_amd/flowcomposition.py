@@ -19,6 +19,14 @@ from .renders import SMPLRenderer
 
 
 class FlowComposition(torch.nn.Module):
+    # flowcomposition.py:23-39: part name -> indices into the (sorted) body parts of smpl_part_info.json
+    PART_IDS = {
+        "head": [0], "torso": [1], "left_leg": [2], "right_leg": [3], "left_arm": [4], "right_arm": [5], "left_foot": [6],
+        "right_foot": [7], "left_hand": [8], "right_hand": [9], "facial": [10],
+        "upper": [1, 4, 5, 8, 9], "lower": [2, 3, 6, 7], "body": [1, 2, 3, 4, 5, 6, 7, 8, 9],
+        "all": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9],
+    }
+
     def __init__(self, opt):
         super().__init__()
         self._opt = opt
@@ -164,6 +172,77 @@ class FlowComposition(torch.nn.Module):
                                                 want_cond=want_aux, want_tuv=want_aux)
         aux = {"fim": fim, "wim": wim, "f2pts": f2pts, "cond": cond, "Tuv2t": tuv} if want_aux else None
         return tsf8, Tst, aux
+
+
+class FlowCompositionForSwapper(FlowComposition):
+    """flowcomposition.py:747-959: part-wise selection of source faces and the merge of several people's source state."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self._name = "FlowCompositionForSwapper"
+        self.all_faces_ids = list(range(self.render.nf))
+        self.part_faces = list(self.render.body_parts.values())
+
+    def get_selected_fids(self, selected_part_ids):
+        """:762-780 (face ids sorted: the reference returns them in set order, which only feeds index assignments)."""
+        fids = set()
+        for i in selected_part_ids:
+            fids |= set(int(f) for f in self.part_faces[i])
+        return sorted(fids)
+
+    def get_select_left_info(self, part_name="body"):
+        """:782-792."""
+        selected_part_ids = self.PART_IDS[part_name]
+        left_part_ids = [i for i in self.PART_IDS["all"] if i not in selected_part_ids]
+        return selected_part_ids, left_part_ids, self.get_selected_fids(selected_part_ids), self.get_selected_fids(left_part_ids)
+
+    @torch.no_grad()
+    def add_rendered_selected_f2pts(self, src_info, selected_fids):
+        """:794-814: f2pts with every non-selected face moved to -2 (outside any flow)."""
+        src_info["selected_obj_f2pts"] = self.render.get_selected_f2pts(src_info["obj_f2pts"], selected_fids)
+        src_info["selected_f2pts"] = self.render.get_selected_f2pts(src_info["f2pts"], selected_fids)
+        if self.only_vis:
+            fim = src_info["fim"]
+            src_info["selected_obj_f2pts"] = self.render.get_vis_f2pts(src_info["selected_obj_f2pts"], fim)
+            src_info["selected_f2pts"] = self.render.get_vis_f2pts(src_info["selected_f2pts"], fim)
+
+    @torch.no_grad()
+    def merge_uv_img(self, src_info_list):
+        """:816-856: every person's UV image weighted by where its selected faces land in UV space."""
+        S = self.image_size
+        one = torch.ones(1, 1, S, S, dtype=torch.float32, device=self.uv_fim.device)
+        uv, vis = [], []
+        for info in src_info_list:
+            Ts2uv = self.render.cal_bc_transform(info["selected_obj_f2pts"][0:1].contiguous(), self.uv_fim[0:1], self.uv_wim[0:1])
+            uv.append(info["uv_img"])
+            vis.append(ops.grid_sample(one, Ts2uv))
+        return ops.uv_merge_parts(torch.cat(uv, dim=0), torch.cat(vis, dim=0))
+
+    @torch.no_grad()
+    def merge_src_info(self, src_info_list, primary_ids):
+        """:858-959.  Per-source tensors are concatenated along the source axis; offsets / links / background come from the
+        primary person; the engine's NHWC feature cache is concatenated the same way."""
+        from .networks.generator import SourceFeatures, _FeatList
+        cat0 = ("cam", "shape", "pose", "fim", "wim", "f2pts", "obj_f2pts", "selected_f2pts", "selected_obj_f2pts")
+        out = {"num_source": sum(i["num_source"] for i in src_info_list)}
+        for k in cat0:
+            out[k] = torch.cat([_force(i[k]) for i in src_info_list], dim=0)
+        out["only_vis_f2pts"] = _Lazy(lambda: torch.cat([_force(i["only_vis_f2pts"]) for i in src_info_list], dim=0))
+        out["img"] = torch.cat([i["img"] for i in src_info_list], dim=1)
+        prim = src_info_list[primary_ids]
+        out["offsets"], out["links_ids"], out["bg"] = prim["offsets"], prim["links_ids"], prim["bg"]
+        enc = _FeatList(torch.cat(f, dim=0) for f in zip(*[i["feats"][0] for i in src_info_list]))
+        res = _FeatList(torch.cat(f, dim=0) for f in zip(*[i["feats"][1] for i in src_info_list]))
+        caches = [i["feats_nhwc"] for i in src_info_list]
+        kv = [tuple(None if parts[0] is None else torch.cat(parts, dim=0) for parts in zip(*site))
+              for site in zip(*[c.kv for c in caches])]
+        cache = SourceFeatures([torch.cat(f, dim=0) for f in zip(*[c.enc for c in caches])],
+                               [torch.cat(f, dim=0) for f in zip(*[c.res for c in caches])], kv, out["num_source"], batched=False)
+        enc.lwg_cache = res.lwg_cache = cache
+        out["feats"], out["feats_nhwc"] = (enc, res), cache
+        out["uv_img"] = self.merge_uv_img(src_info_list)
+        out["uv_img4"] = ops.nchw_to_nhwc(out["uv_img"].contiguous(), c_pad=4)[0].contiguous()
+        return out
 
 
 class _Lazy:

@@ -82,6 +82,7 @@ class Imitator(object):
         self.temporal = bool(_opt_get(opt, "temporal", False))
         self.time_step = int(_opt_get(opt, "time_step", 1))
         self.temporal_fifo = None
+        self.primary_ids = 0                      # which source's camera / shape drives the target (Swapper sets it)
         self._create_networks()
 
     def _create_networks(self):
@@ -206,9 +207,10 @@ class Imitator(object):
         return pred, mask
 
     @torch.no_grad()
-    def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0):
+    def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0, use_selected_f2pts=False):
         """Frames [t0, t0+n) of an (already stabilised) device tensor (n,85) -> pred (n,3,S,S) on the device."""
         outs = []
+        sel = dict(primary_ids=self.primary_ids, use_selected_f2pts=use_selected_f2pts)
         if self.streams > 1 and tgt_smpls.is_cuda:
             # frames are independent: batches alternate over HIP streams so one batch's kernel tails, launch gaps and
             # HBM-bound kernels overlap another batch's MFMA work (+6 % frames/s at 3 streams on MI355X)
@@ -220,7 +222,7 @@ class Imitator(object):
             for k, s in enumerate(range(0, tgt_smpls.shape[0], self.frame_batch)):
                 with torch.cuda.stream(self._side_streams[k % self.streams]):
                     chunk = tgt_smpls[s:s + self.frame_batch]
-                    tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s)
+                    tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s, **sel)
                     outs.append(self.forward(tsf8, Tst)[0])
             for st in self._side_streams:
                 cur.wait_stream(st)
@@ -229,22 +231,23 @@ class Imitator(object):
             return torch.cat(outs, dim=0)
         for s in range(0, tgt_smpls.shape[0], self.frame_batch):
             chunk = tgt_smpls[s:s + self.frame_batch]
-            tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s)
+            tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, chunk, cam_strategy, t=t0 + s, **sel)
             outs.append(self.forward(tsf8, Tst)[0])
         return torch.cat(outs, dim=0)
 
     @torch.no_grad()
-    def synthesize_temporal(self, tgt_smpls, cam_strategy="smooth"):
+    def synthesize_temporal(self, tgt_smpls, cam_strategy="smooth", use_selected_f2pts=False):
         """temporal=True (imitator.py:341-366): a recurrence - frame t attends to the sources and to the last ``time_step``
         synthesized frames, so frames are produced one at a time (this mode does not shard over frames: replicas only)."""
         src = self.src_info
-        key = "f2pts"
+        key = "selected_f2pts" if use_selected_f2pts else "f2pts"
         self.temporal_fifo = fifo = TemporalFIFO(self.time_step, src["feats_nhwc"], src[key].contiguous())
         outs = []
         for t in range(tgt_smpls.shape[0]):
             if t == 0 and cam_strategy == "smooth" and self.first_cam is None:
                 self.first_cam = tgt_smpls[0:1, 0:3].clone()
-            ref_smpl = self.swap_params(src["cam"][0:1], src["shape"][0:1], tgt_smpls[t:t + 1], cam_strategy)
+            p = self.primary_ids
+            ref_smpl = self.swap_params(src["cam"][p:p + 1], src["shape"][p:p + 1], tgt_smpls[t:t + 1], cam_strategy)
             ref_info = self.body_rec.get_details(ref_smpl.contiguous(), src["offsets"], links_ids=src["links_ids"])
             f2pts_all, feats = fifo.view()
             tsf8, T, aux = self.flow_comp.frame_inputs(ref_info["cam"].contiguous(), ref_info["verts"], src["uv_img4"],
@@ -272,7 +275,7 @@ class Imitator(object):
         """imitator.py:327-382."""
         tgt = self.prepare_sequence(tgt_smpls, cam_strategy)
         if self.temporal:
-            preds = self.synthesize_temporal(tgt, cam_strategy)
+            preds = self.synthesize_temporal(tgt, cam_strategy, use_selected_f2pts=use_selected_f2pts)
             if output_dir:
                 from .output import FrameWriter
                 writer = FrameWriter(output_dir, prefix=prefix)
@@ -285,11 +288,11 @@ class Imitator(object):
             from .output import FrameWriter
             writer = FrameWriter(output_dir, prefix=prefix)
             for s in range(0, tgt.shape[0], self.frame_batch):
-                writer.submit(self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s), s)
+                writer.submit(self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s, use_selected_f2pts=use_selected_f2pts), s)
             return writer.close()
         outputs = []
         for s in range(0, tgt.shape[0], self.frame_batch):
-            preds = self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s).cpu().numpy()
+            preds = self.synthesize(tgt[s:s + self.frame_batch], cam_strategy, t0=s, use_selected_f2pts=use_selected_f2pts).cpu().numpy()
             outputs.extend(preds[i] for i in range(preds.shape[0]))
         return outputs
 
@@ -308,6 +311,65 @@ class Viewer(Imitator):
                                  visualizer=visualizer, verbose=verbose)
 
 
+class Swapper(Imitator):
+    """Part-wise appearance swap between several people (reference models/imitator.py:468-622): every person contributes the
+    faces of its ``swap_parts``; the sources of all people feed the attention of ONE target driven by the primary person's
+    camera and shape.  Same per-frame kernels; ``inference(..., use_selected_f2pts=True)`` is how run_swapper drives it."""
+
+    def __init__(self, opt, device=torch.device("cuda:0"), **kw):
+        super().__init__(opt, device, **kw)
+        self._name = "Swapper"
+
+    def _create_networks(self):
+        from .flowcomposition import FlowCompositionForSwapper
+        self.body_rec = SMPLH(model_path=_opt_get(self._opt, "smpl_model_hand")).to(self.device)
+        self.weak_cam_swapper = cam_pose_utils.WeakPerspectiveCamera(self.body_rec)
+        self.flow_comp = FlowCompositionForSwapper(opt=self._opt).to(self.device)
+        self.generator = self._create_generator(_opt_get(_opt_get(self._opt, "neural_render_cfg"), "Generator")).to(self.device)
+
+    def get_selected_info_by_part_mask(self, swap_masks):
+        raise NotImplementedError                          # as in the reference (:489-500)
+
+    def get_selected_info_by_part_name(self, swap_parts, primary_ids=0):
+        """:502-546 -> (part ids per person, face ids per person); faces nobody selected go to the primary person."""
+        fc = self.flow_comp
+        selected_part_ids, selected_face_ids, all_faces = [], [], set()
+        for swap_part in swap_parts:
+            part_ids, face_ids = set(), set()
+            for sub_part in swap_part:
+                ids = fc.PART_IDS[sub_part]
+                part_ids |= set(ids)
+                face_ids |= set(fc.get_selected_fids(ids))
+            all_faces |= face_ids
+            selected_part_ids.append(sorted(part_ids))
+            selected_face_ids.append(sorted(face_ids))
+        left = set(fc.all_faces_ids) - all_faces
+        if left:
+            selected_face_ids[primary_ids] = sorted(set(selected_face_ids[primary_ids]) | left)
+        return selected_part_ids, selected_face_ids
+
+    @torch.no_grad()
+    def swap_source_setup(self, src_path_list, src_smpl_list, masks_list, bg_img_list=None, offsets_list=0, links_ids_list=None,
+                          swap_parts=(["head"], ["body"]), swap_masks=None, primary_ids=0, visualizer=None):
+        """:548-621 -> merged src_info (also kept as ``self.src_info``)."""
+        assert not (swap_parts is None and swap_masks is None)
+        if swap_parts is not None:
+            _, selected_face_ids = self.get_selected_info_by_part_name(swap_parts, primary_ids)
+        else:
+            _, selected_face_ids = self.get_selected_info_by_part_mask(swap_masks)
+        n = len(src_path_list)
+        pick = lambda lst, i, d=None: d if lst is None or isinstance(lst, (int, float)) else lst[i]     # noqa: E731
+        infos = []
+        for i in range(n):
+            info = self.source_setup(src_path_list[i], src_smpl_list[i], pick(masks_list, i), pick(bg_img_list, i),
+                                     offsets=pick(offsets_list, i, 0), links_ids=pick(links_ids_list, i), visualizer=visualizer)
+            self.flow_comp.add_rendered_selected_f2pts(info, [selected_face_ids[i]] * info["num_source"])
+            infos.append(info)
+        self.primary_ids = primary_ids
+        self.src_info = self.flow_comp.merge_src_info(infos, primary_ids=primary_ids)
+        return self.src_info
+
+
 class ModelsFactory(object):
     """reference models/base_model.py:8-32."""
 
@@ -318,7 +380,7 @@ class ModelsFactory(object):
         if model_name == "viewer":
             return Viewer(*args, **kwargs)
         if model_name == "swapper":
-            raise NotImplementedError("Swapper (part-wise source mixing, imitator.py:465-622) is a 'next' row (SURVEY 8f-4)")
+            return Swapper(*args, **kwargs)
         raise ValueError(f"Model {model_name} not recognized.")
 
 

@@ -375,6 +375,15 @@ def uv_merge(src_warp, vis):
     return out
 
 
+def uv_merge_parts(uv_imgs, vis):
+    """flowcomposition.py:816-856 (merge_uv_img): (n,3,H,W), (n,1,H,W) -> (1,3,H,W)."""
+    n, _, H, W = uv_imgs.shape
+    out = torch.empty(1, 3, H, W, device=uv_imgs.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_uv_merge_parts_f32(_ptr(uv_imgs.contiguous()), _ptr(vis.contiguous()), n, H, W, _ptr(out), _stream()),
+               "lwg_uv_merge_parts_f32")
+    return out
+
+
 def pack_inputs(a, b, mask, c_pad):
     """cat[a * mask, b] (NCHW) -> NHWC with c_pad channels."""
     n, Ca, H, W = a.shape

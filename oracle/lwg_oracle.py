@@ -727,3 +727,49 @@ def process_source(src_img, cond, fim, obj_f2pts, obj_fim, uv_fim, uv_wim, face_
     return {"uv_img": uv_img, "input_G_bg": input_G_bg, "input_G_src": input_G_src, "morph_img": morph_img,
             "thin_edges": thin, "tie_mask": ties, "confidant_sil": confidant, "outpad_sil": outpad,
             "only_vis_obj_f2pts": only_vis_obj}
+
+
+# ------------------------------------------------------------------------------------------------ Swapper
+PART_IDS = {     # models/flowcomposition.py:23-39
+    "head": [0], "torso": [1], "left_leg": [2], "right_leg": [3], "left_arm": [4], "right_arm": [5], "left_foot": [6],
+    "right_foot": [7], "left_hand": [8], "right_hand": [9], "facial": [10],
+    "upper": [1, 4, 5, 8, 9], "lower": [2, 3, 6, 7], "body": [1, 2, 3, 4, 5, 6, 7, 8, 9], "all": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9],
+}
+
+
+def select_faces_by_part_name(part_faces, nf, swap_parts, primary_ids=0):
+    """Swapper.get_selected_info_by_part_name (models/imitator.py:502-546): ``part_faces`` = list of face-id lists in the
+    renderer's body-part order; faces no person selected join the primary person's."""
+    selected, union = [], set()
+    for parts in swap_parts:
+        fids = set()
+        for name in parts:
+            for i in PART_IDS[name]:
+                fids |= set(int(f) for f in part_faces[i])
+        union |= fids
+        selected.append(fids)
+    left = set(range(nf)) - union
+    if left:
+        selected[primary_ids] |= left
+    return [sorted(s) for s in selected]
+
+
+def get_selected_f2pts(f2pts, selected_fids):
+    """nmr.py:601-637: (n, nf, 3, 2) with the faces outside ``selected_fids[i]`` set to -2."""
+    out = torch.full_like(f2pts, -2.0)
+    for i in range(f2pts.shape[0]):
+        ids = torch.as_tensor(selected_fids[i], dtype=torch.long)
+        out[i, ids] = f2pts[i, ids]
+    return out
+
+
+def merge_uv_img(uv_imgs, selected_obj_f2pts_first, uv_fim, uv_wim):
+    """FlowCompositionForSwapper.merge_uv_img (models/flowcomposition.py:816-856): uv_imgs [(1,3,h,w)] per person,
+    selected_obj_f2pts_first [(1,nf,3,2)] = each person's first source; uv_fim / uv_wim (1,h,w) / (1,h,w,3)."""
+    h, w = uv_fim.shape[-2:]
+    one = torch.ones(1, 1, h, w)
+    vis = [F.grid_sample(one, cal_bc_transform(f, uv_fim[0:1], uv_wim[0:1]), mode="bilinear", padding_mode="zeros", align_corners=False)
+           for f in selected_obj_f2pts_first]
+    imgs, vis = torch.cat(uv_imgs, dim=0), torch.cat(vis, dim=0)
+    norm = vis / (vis.sum(dim=0, keepdim=True) + 1e-7)
+    return (imgs * norm).sum(dim=0, keepdim=True)

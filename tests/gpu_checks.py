@@ -485,6 +485,70 @@ def check_source_setup_512():
     return _source_stage(512, dict(conf_erode_ks=3, out_dilate_ks=51, bg_ks=11), [64, 64, 128], 2, [64, 64, 128])
 
 
+def check_swapper():
+    """Swapper (reference models/imitator.py:468-622 + FlowCompositionForSwapper flowcomposition.py:747-959) on the GPU:
+    part-name face selection vs the reference's own (golden sha), selected f2pts / merged UV image / selected-face flows vs the
+    oracle (pinned to the reference by the CPU suite), and the merged multi-person source state driving the per-frame path."""
+    import hashlib
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.imitator import ModelsFactory
+    gs = np.load(os.path.join(ROOT, "tests", "golden", "golden_swapper_v1.npz"))
+    S, nf, nres, bgf = 128, [64, 64, 128], 2, [64, 64, 128]
+    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=3, ns=2)
+    case.opt.update(dict(conf_erode_ks=3, out_dilate_ks=21, bg_ks=11))
+    sw = ModelsFactory.get_by_name("swapper", case.opt, device=torch.device(DEV), frame_batch=3)
+    sw.generator.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
+    sw.generator.to(DEV)
+    out = {}
+    sha = lambda ls: hashlib.sha256(";".join(",".join(str(int(f)) for f in sorted(l)) for l in ls).encode()).hexdigest()   # noqa: E731
+    for tag, parts in (("head_body", (["head"], ["body"])), ("leftover", (["upper"], ["left_leg", "right_foot"]))):
+        _, fids = sw.get_selected_info_by_part_name(list(parts), primary_ids=0)
+        assert [len(f) for f in fids] == list(gs[f"{tag}/fids_count"]) and sha(fids) == str(gs[f"{tag}/fids_sha"]), tag
+    people = ((2, 20), (1, 40))
+    paths, smpls, masks = [], [], []
+    for ns, seed in people:
+        smpls.append(synthetic.smpl_sequence(ns, seed=seed, pose_dim=72))
+        paths.append(synthetic.uniform_image((ns, 3, S, S), seed + 1, "src_img"))
+        info = sw.body_rec.get_details(torch.tensor(smpls[-1], device=DEV), torch.zeros((), device=DEV), links_ids=None)
+        _, fim, _ = sw.flow_comp.render.render_fim_wim(cam=info["cam"], vertices=info["verts"], smpl_faces=True)
+        masks.append(pu.fg_masks_from_sil((fim != -1).float().unsqueeze(1).cpu()).numpy())
+    swap_parts = (["head"], ["body"])
+    merged = sw.swap_source_setup(paths, smpls, masks, bg_img_list=None, offsets_list=0, links_ids_list=None, swap_parts=swap_parts)
+    torch.cuda.synchronize()
+    assert merged["num_source"] == 3 and merged["f2pts"].shape[0] == 3 and merged["feats_nhwc"].enc[0].shape[0] == 3
+    _, fids = sw.get_selected_info_by_part_name(list(swap_parts))
+    per_src_fids = [fids[0], fids[0], fids[1]]
+    want_sel = orc.get_selected_f2pts(merged["f2pts"].cpu(), per_src_fids)
+    assert torch.equal(merged["selected_f2pts"].cpu(), want_sel), "selected_f2pts differ"
+    # merged UV image: the oracle's merge on the HIP side's per-person UV images and selected faces
+    fc = sw.flow_comp
+    uv_fim, uv_wim = fc.uv_fim[0:1].cpu(), fc.uv_wim[0:1].cpu()
+    sel_obj = orc.get_selected_f2pts(merged["obj_f2pts"].cpu(), per_src_fids)
+    # per-person UV images are not kept in the merged dict: rebuild them through the same source_setup calls
+    uv_imgs = []
+    for i in range(2):
+        info = sw.source_setup(paths[i], smpls[i], masks[i])
+        uv_imgs.append(info["uv_img"].cpu())
+    want_uv = orc.merge_uv_img(uv_imgs, [sel_obj[0:1], sel_obj[2:3]], uv_fim, uv_wim)
+    out["merge_uv"] = _cmp(merged["uv_img"], want_uv, 1e-5, "merged uv_img")
+    sw.src_info = merged
+    # selected-face flows + frames
+    tgt = sw.prepare_sequence(case.tgt_smpls, "smooth")
+    tsf8, Tst, ref = sw.make_inputs_for_tsf(merged, tgt, "smooth", t=0, primary_ids=0, use_selected_f2pts=True, want_aux=True)
+    torch.cuda.synchronize()
+    B = tgt.shape[0]
+    for b in range(B):
+        want = orc.cal_bc_transform(want_sel, ref["fim"][b:b + 1].cpu().repeat(3, 1, 1), ref["wim"][b:b + 1].cpu().repeat(3, 1, 1, 1))
+        out[f"Tst_{b}"] = _cmp(Tst[b], want, 1e-5, "selected-face flows")
+    frames_sel = sw.inference(case.tgt_smpls, "smooth", use_selected_f2pts=True)
+    frames_all = sw.inference(case.tgt_smpls, "smooth", use_selected_f2pts=False)
+    a, b_ = np.stack(frames_sel), np.stack(frames_all)
+    assert np.isfinite(a).all() and a.shape == (3, 3, S, S)
+    out["sel_vs_all_mean_abs"] = float(np.abs(a - b_).mean())
+    assert out["sel_vs_all_mean_abs"] > 0, "use_selected_f2pts had no effect"
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -943,4 +1007,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper]

@@ -147,6 +147,49 @@ def test_lwb_variant_generators_match_reference(golden, name, kind, shapes_kind)
         assert np.abs(mask.numpy() - gv[f"{name}/{tag}/mask"]).max() <= 1e-4
 
 
+SWAP_PEOPLE = ((2, 20), (1, 40))
+SWAP_PART_SETS = {"head_body": (["head"], ["body"]), "leftover": (["upper"], ["left_leg", "right_foot"])}
+
+
+def _fids_sha(lists):
+    return hashlib.sha256(";".join(",".join(str(int(f)) for f in sorted(l)) for l in lists).encode()).hexdigest()
+
+
+def test_swapper_pieces_match_reference(topo):
+    """Part-name face selection, selected_f2pts, merge_uv_img and the selected-face flows of the oracle against the reference's
+    own Swapper / FlowCompositionForSwapper (tests/golden/make_golden_swapper.py)."""
+    from tests import parity_utils as pu
+    gs = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_swapper_v1.npz"))
+    S = 128
+    t = pu.oracle_tables(topo)
+    fim_obj = mesh.obj_from_topology(topo, "fim")
+    obj_faces = fim_obj["faces"].astype(np.int32)
+    f_img2uvs = mesh.get_f2vts(fim_obj, z=1).astype(np.float32)
+    uv_fim, uv_wim = orc.render_uv_fim_wim(f_img2uvs, 1, S)
+    parts = {str(n): topo["part_" + str(n)] for n in topo["part_names"]}
+    part_faces = list(mesh.get_part_ids(f_img2uvs.shape[0], parts).values())
+    model = orc.SMPLHModel(synthetic.smplh_model_dict(seed=0))
+    for tag, swap_parts in SWAP_PART_SETS.items():
+        fids = orc.select_faces_by_part_name(part_faces, f_img2uvs.shape[0], swap_parts, primary_ids=0)
+        assert [len(f) for f in fids] == list(gs[f"{tag}/fids_count"]) and _fids_sha(fids) == str(gs[f"{tag}/fids_sha"])
+        uv_imgs, sel_obj, sel = [], [], []
+        for i, (ns, seed) in enumerate(SWAP_PEOPLE):
+            d = orc.smplh_get_details(model, synthetic.smpl_sequence(ns, seed=seed, pose_dim=72), 0, None)
+            f2pts, _, _ = orc.render_fim_wim(d["cam"], d["verts"], t["smpl_faces"], S)
+            obj_f2pts, _, _ = orc.render_fim_wim(d["cam"], d["verts"], obj_faces, S)
+            sel.append(orc.get_selected_f2pts(f2pts, [fids[i]] * ns))
+            sel_obj.append(orc.get_selected_f2pts(obj_f2pts, [fids[i]] * ns)[0:1])
+            uv_imgs.append(torch.tensor(synthetic.uniform_image((1, 3, S, S), seed + 5, "uv_img")))
+        sel = torch.cat(sel, dim=0)
+        assert int((sel[:, :, 0, 0] != -2).sum()) == int(gs[f"{tag}/selected_count"])
+        uv = orc.merge_uv_img(uv_imgs, sel_obj, uv_fim, uv_wim)
+        assert np.abs(uv.numpy() - gs[f"{tag}/uv_img"]).max() <= 1e-5
+        ref = orc.smplh_get_details(model, synthetic.smpl_sequence(1, seed=60, pose_dim=72), 0, None)
+        _, rfim, rwim = orc.render_fim_wim(ref["cam"], ref["verts"], t["smpl_faces"], S)
+        Tst = orc.cal_bc_transform(sel, rfim.repeat(3, 1, 1), rwim.repeat(3, 1, 1, 1))
+        assert np.abs(Tst.numpy() - gs[f"{tag}/Tst"][0]).max() <= 1e-5
+
+
 def test_identity_warp_property(topo):
     """T = cal_bc_transform(f2pts, fim, wim) reproduces the grid_sample coordinate of each
     covered pixel - the property the reference relies on when it uses T as a sampling grid."""
