@@ -22,7 +22,9 @@
 // shapes = 1.45-1.55x the native fp32 kernel, i.e. ~47 % of the bf16 pipe with six MFMAs per product; error against an fp64
 // convolution BELOW the native fp32 MFMA kernel's (rms 7.4e-7 vs 8.5e-7 of the output rms on the 3x3 256->256 layer).  What
 // is left is the barrier-per-stage structure (two co-resident workgroups fall into phase and idle together around the
-// barrier): the next step is an 8-wave workgroup whose two wave groups alternate MFMA / staging phases.
+// barrier).  Launches with N % 128 == 0 and >= 200 256x128 tiles use the 8-wave ping-pong kernel further down (+7-9 %).
+#include <cstdlib>
+
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 #include "lwg_conv_epilogue.h"
@@ -301,8 +303,317 @@ static hipError_t launch_cfg_split(const LwgConvArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave "ping-pong" schedule of the same computation: one 512-thread workgroup per CU owns a 256x128 tile; its two wave
+// groups (waves 0-3 / 4-7, one wave of each per SIMD) own the upper / lower 128 rows and ALTERNATE between an MFMA phase
+// (24 back-to-back MFMAs on fragments already in registers, raised priority) and a staging phase (LDS stores of a stage
+// loaded two phases earlier, global loads of a later stage, fragment reads for its next MFMA phase).  While one group's waves
+// occupy the matrix pipes the other group's waves use the VALU / LDS / VMEM pipes of the same SIMDs; one s_barrier per phase
+// keeps the groups exactly out of phase (two independent workgroups drift INTO phase and idle together, see the header).
+// Stage bookkeeping (g = group 0, h = group 1; phase 2t: g computes stage t, phase 2t+1: h computes stage t):
+//   g writes stage s (its A rows + its half of B) in phase 2s-3, h in phase 2s-2; g reads fragments of s at the end of phase
+//   2s-1, h at the end of phase 2s; buffer s&1 is therefore overwritten (with s+2) only after both groups read s, and every
+//   read of s comes at least one barrier after the last write of s.  Global loads are issued one staging phase (= two
+//   phases) before their LDS store.
+#ifndef LWG_PP_ABL
+#define LWG_PP_ABL 0      // lab only (wrong results): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no fragment reads
+#endif
+#ifndef LWG_PP_SGB
+#define LWG_PP_SGB 0
+#endif
+#ifndef LWG_SPLIT_PP_PRIO
+#define LWG_SPLIT_PP_PRIO 1
+#endif
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void lwg_conv_igemm_split_pp_kernel(const LwgConvArgs a) {
+    constexpr int TM = 2, TN = 2, BMG = 128, BN = 128;       // per wave group: 128 x 128, waves 2 x 2, 64 x 64 per wave
+    constexpr int A_ROW = (BMG + 8) * 16, B_ROW = BN * 16;
+    constexpr int A_PLANE = 2 * A_ROW, B_PLANE = 2 * B_ROW;
+    constexpr int A_GRP = 3 * A_PLANE, A_STAGE = 2 * A_GRP, B_STAGE = 3 * B_PLANE;
+    constexpr int PA = 2;                                     // float4 A loads per thread and stage
+    constexpr int B_HALF = 3 * BN;                            // 16-byte B items per group and stage (768 / 2)
+    constexpr int PB = 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char* As = smem_p;
+    char* Bs = smem_p + 2 * A_STAGE;
+    int* taptab = reinterpret_cast<int*>(smem_p + 2 * A_STAGE + 2 * B_STAGE);   // prologue only (validity masks)
+
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int gt = tid & 255, lane = tid & 63, wid = gt >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_n = a.N / BN;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % tiles_n, tile_m = lid / tiles_n;
+    const int m_base = tile_m * 256 + grp * BMG, n_base = tile_n * BN;
+
+    const int kq = gt & 3, mrow = gt >> 2;
+    const int HW = a.OH * a.OW;
+    const int Cin = a.C0 + a.C1;
+    int pixlin[PA];
+    unsigned long long vmask[PA];
+    {
+        int piy[PA], pix[PA];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int m = m_base + mrow + 64 * p;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / HW, rem = mm - b * HW;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            piy[p] = ok ? oy * a.stride : -1000;
+            pix[p] = ox * a.stride;
+            pixlin[p] = (b * a.H + oy * a.stride) * a.W + ox * a.stride;
+            vmask[p] = 0ull;
+        }
+        if (tid < a.ntaps) {
+            const int dy = a.dy[tid], dx = a.dx[tid];
+            taptab[tid] = (dy * a.W + dx) * a.C0 * 4;
+            taptab[LWG_MAX_TAPS + tid] = (dy * a.W + dx) * a.C1 * 4;
+            taptab[2 * LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
+        }
+        __syncthreads();
+        for (int tp = 0; tp < a.ntaps; ++tp) {
+            const int packed = taptab[2 * LWG_MAX_TAPS + tp];
+            const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int iy = piy[p] + dy, ix = pix[p] + dx;
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                vmask[p] |= (unsigned long long)ok << tp;
+            }
+        }
+    }
+
+    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 4u;
+    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 4u;
+    const int nsteps = a.ntaps * (Cin >> 4);
+    const unsigned plane_bytes = (unsigned)nsteps * 2u * a.N * 16u;
+    const unsigned wbytes = 3u * plane_bytes;
+
+    // per-tap byte offsets live in two VGPRs (lane i = tap i) and are fetched with v_readlane: no LDS round trip in the loop
+    const int tl = lane < a.ntaps ? lane : 0;
+    const int vtab0 = (a.dy[tl] * a.W + a.dx[tl]) * a.C0 * 4, vtab1 = (a.dy[tl] * a.W + a.dx[tl]) * a.C1 * 4;
+    int ld_tap = 0, ld_cc = 0, ld_use1 = 0, ld_half = 0;
+    unsigned ld_soffA = 0, ld_soffB = 0;
+    const float* ld_src = a.x0;
+    unsigned ld_bytes = bytes0;
+    unsigned pixb[PA], vbase[PA], wvoff[PB];
+    int st_b[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int loc = gt + 256 * p;                         // this group's items [grp * 384, grp * 384 + 384)
+        const int idx = grp * B_HALF + loc;
+        const int plane = idx / (2 * BN), rem = idx - plane * 2 * BN;
+        const int oct = rem / BN, n = rem - oct * BN;
+        const bool ok = loc < B_HALF;
+        wvoff[p] = ok ? (unsigned)plane * plane_bytes + ((unsigned)oct * a.N + n_base + n) * 16u : LWG_OOB_OFFSET;
+        st_b[p] = ok ? idx * 16 : -1;
+    }
+    auto source = [&]() {
+        ld_use1 = ld_cc >= a.C0;
+        const int cs = ld_use1 ? a.C1 : a.C0;
+        ld_src = ld_use1 ? a.x1 : a.x0;
+        ld_bytes = ld_use1 ? bytes1 : bytes0;
+        ld_soffA = (unsigned)(ld_cc - (ld_use1 ? a.C0 : 0)) * 4u;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) pixb[p] = ((unsigned)pixlin[p] * (unsigned)cs + (unsigned)kq * 4u) * 4u;
+    };
+    auto tap_rows = [&]() {
+        const int toff = __builtin_amdgcn_readlane(ld_use1 ? vtab1 : vtab0, ld_tap);
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool ok = (vmask[p] >> ld_tap) & 1ull;
+            vbase[p] = ok ? pixb[p] + (unsigned)toff : LWG_OOB_OFFSET;
+        }
+    };
+    auto advance = [&]() {
+        ld_soffB += (unsigned)a.N * 32u;
+        ld_half ^= 1;
+        if (ld_half) {
+            ld_soffA += 64u;
+            return;
+        }
+        ld_soffA -= 64u;
+        if (++ld_tap == a.ntaps) {
+            ld_tap = 0;
+            ld_cc += 32;
+            ld_soffA += 128u;
+            if (ld_cc == a.C0 && a.C1 > 0) source();
+        }
+        tap_rows();
+    };
+
+    floatx4 ra[PA], rb[PB];
+    auto gload = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[p] = lwg_sbuf_load(ld_src, ld_bytes, vbase[p], ld_soffA);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[p] = lwg_sbuf_load(a.w, wbytes, wvoff[p], ld_soffB);
+    };
+    const int st_a = grp * A_GRP + (kq >> 1) * A_ROW + mrow * 16 + (kq & 1) * 8;
+    uintx2 pkh[PA], pkm[PA], pkl[PA];                          // the split of ra: packed bf16 pairs per plane
+    auto split_a = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            lwg_split_pair(ra[p][0], ra[p][1], h0, m0, l0);
+            lwg_split_pair(ra[p][2], ra[p][3], h1, m1, l1);
+            pkh[p] = uintx2{h0, h1}; pkm[p] = uintx2{m0, m1}; pkl[p] = uintx2{l0, l1};
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* Ab = As + buf * A_STAGE + st_a;
+        char* Bb = Bs + buf * B_STAGE;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            *reinterpret_cast<uintx2*>(Ab + 64 * p * 16) = pkh[p];
+            *reinterpret_cast<uintx2*>(Ab + 64 * p * 16 + A_PLANE) = pkm[p];
+            *reinterpret_cast<uintx2*>(Ab + 64 * p * 16 + 2 * A_PLANE) = pkl[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            if (st_b[p] >= 0) *reinterpret_cast<floatx4*>(Bb + st_b[p]) = rb[p];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int khalf = lane >> 5;
+    const char* fr_a = As + grp * A_GRP + khalf * A_ROW + (wm * TM * 32 + (lane & 31)) * 16;
+    const char* fr_b = Bs + khalf * B_ROW + (wn * TN * 32 + (lane & 31)) * 16;
+    sbf16x8 fa[3][TM], fb[3][TN];
+    auto read_frags = [&](int cur) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const sbf16x8*>(fr_a + cur * A_STAGE + pl * A_PLANE + i * 512);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const sbf16x8*>(fr_b + cur * B_STAGE + pl * B_PLANE + j * 512);
+        }
+    };
+    // the MFMA phase also splits this wave's next A stage (loaded one staging phase earlier): ~45 VALU among 24 MFMAs - the
+    // staging phase of the OTHER group then issues no VALU beside address arithmetic and does not compete for the VALU port
+    auto mfmas_split = [&]() {
+        constexpr int PAIRS[6][2] = {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 0}, {0, 2}};
+        if (LWG_SPLIT_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (!(LWG_PP_ABL & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PAIRS[q][1]][j], fa[PAIRS[q][0]][i], acc[i][j], 0, 0, 0);
+        split_a();
+#if LWG_PP_SGB
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // 2 VALU
+        }
+#endif
+        if (LWG_SPLIT_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: stage 0 by everyone; group 0 also stores stage 1 and holds stage 2's loads, group 1 holds stage 1 (A already split)
+    source();
+    tap_rows();
+    gload();
+    split_a();
+    lstore(0);
+    advance();
+    gload();                                                  // stage 1 (nsteps is even, >= 2)
+    split_a();
+    if (grp == 0) {
+        lstore(1);
+        if (nsteps > 2) {
+            advance();
+            gload();                                          // stage 2: split during the first MFMA phase
+        }
+    }
+    __syncthreads();
+    if (grp == 0) read_frags(0);
+
+    // Each group runs its own loop (two barriers per iteration in both, so the groups meet at every phase boundary): straight-line
+    // bodies keep the loop-carried fragments / load registers in place (a per-phase branch on the group made the compiler copy
+    // them at every merge, behind an s_waitcnt vmcnt(0) that exposed the whole global-load latency in every phase).
+    if (grp == 0) {
+        int t = 0;
+        for (; t + 3 < nsteps; ++t) {          // phase 2t: compute t, split t+2 | phase 2t+1: store t+2, load t+3, read fragments of t+1
+            mfmas_split();
+            __syncthreads();
+            if (!(LWG_PP_ABL & 2)) lstore(t & 1);
+            advance();
+            if (!(LWG_PP_ABL & 1)) gload();
+            if (!(LWG_PP_ABL & 8)) read_frags((t + 1) & 1);
+            __syncthreads();
+        }
+        for (; t < nsteps; ++t) {
+            mfmas_split();
+            __syncthreads();
+            if (t + 2 < nsteps) lstore(t & 1);
+            if (t + 1 < nsteps) read_frags((t + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        int t = 0;
+        for (; t + 2 < nsteps; ++t) {          // phase 2t: store t+1, load t+2, read fragments of t | phase 2t+1: compute t, split t+2
+            if (!(LWG_PP_ABL & 2)) lstore((t + 1) & 1);
+            advance();
+            if (!(LWG_PP_ABL & 1)) gload();
+            if (!(LWG_PP_ABL & 8)) read_frags(t & 1);
+            __syncthreads();
+            mfmas_split();
+            __syncthreads();
+        }
+        for (; t < nsteps; ++t) {
+            if (t + 1 < nsteps) lstore((t + 1) & 1);
+            read_frags(t & 1);
+            __syncthreads();
+            mfmas_split();
+            __syncthreads();
+        }
+    }
+    lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
+}
+
+template <int EPI>
+static hipError_t launch_split_pp(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * (2 * 3 * 2 * (128 + 8) * 16 + 3 * 2 * 128 * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
+    auto kern = lwg_conv_igemm_split_pp_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 128;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+// the 256x128 ping-pong kernel needs N % 128 == 0 and enough tiles that one workgroup per CU keeps the chip busy
+static bool lwg_split_use_pp(const LwgConvArgs& a) {
+    static int mode = -1;                                     // LWG_SPLIT_PP=0 never, 1 whenever legal, unset: heuristic
+    if (mode < 0) {
+        const char* e = getenv("LWG_SPLIT_PP");
+        mode = e ? (atoi(e) ? 1 : 0) : 2;
+    }
+    if (mode == 0 || a.N % 128 != 0) return false;
+    if (mode == 1) return true;
+    const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);
+    const long waves = (tiles + 255) / 256;
+    return tiles >= 200 && (double)tiles / (double)(waves * 256) >= 0.75;
+}
+
 template <int EPI>
 static hipError_t launch_epi_split(const LwgConvArgs& a, hipStream_t stream) {
+    if (lwg_split_use_pp(a)) return launch_split_pp<EPI>(a, stream);
     if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg_split<2, 2, 2, 2, EPI>(a, stream);
     return launch_cfg_split<4, 1, 1, 2, EPI>(a, stream);
 }
