@@ -74,7 +74,8 @@ __device__ __forceinline__ void lwg_split_pair(float a, float b, unsigned& hi, u
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
 __global__ __launch_bounds__(256, LWG_SPLIT_OCC) void lwg_conv_igemm_split_kernel(const LwgConvArgs a) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int A_ROW = (BM + 8) * 16;     // bytes per k-octet row (+8 slots: the two octets land 32 banks apart)
+    constexpr int A_ROW = (BM + 4) * 16;     // bytes per k-octet row; +4 slots: LDS stores bank on (addr/4) % 32, the two octets of a
+                                             // 16-lane ds_write_b64 group land 16 banks apart (PMC: +8 gave 24 conflict cycles per wave-stage)
     constexpr int B_ROW = BN * 16;
     constexpr int A_PLANE = 2 * A_ROW, B_PLANE = 2 * B_ROW;        // BK = 16 = 2 octets
     constexpr int A_STAGE = 3 * A_PLANE, B_STAGE = 3 * B_PLANE;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, LWG_SPLIT_OCC) void lwg_conv_igemm_split_kerne
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
 static hipError_t launch_cfg_split(const LwgConvArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr size_t lds = (size_t)2 * 3 * 2 * ((BM + 8) * 16 + BN * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
+    constexpr size_t lds = (size_t)2 * 3 * 2 * ((BM + 4) * 16 + BN * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_split_kernel<WAVES_M, WAVES_N, TM, TN, EPI>;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a);
@@ -315,8 +316,23 @@ static hipError_t launch_cfg_split(const LwgConvArgs& a, hipStream_t stream) {
 //   2s-1, h at the end of phase 2s; buffer s&1 is therefore overwritten (with s+2) only after both groups read s, and every
 //   read of s comes at least one barrier after the last write of s.  Global loads are issued one staging phase (= two
 //   phases) before their LDS store.
+// Measured (lab build -DLWG_PP_TS, tools/ppts.py): MFMA phase 930 cycles (768 of pipe time), staging phase 790, barrier waits
+// 130-190 per phase: 75 % of the matrix pipe in cycles; the shader clock drops to ~1.76 GHz under this kernel (2.24 GHz under the
+// fp32 kernel), which is what separates it from the 2.4 GHz roofline.
 #ifndef LWG_PP_ABL
 #define LWG_PP_ABL 0      // lab only (wrong results): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no fragment reads
+#endif
+#ifndef LWG_PP_TS
+#define LWG_PP_TS 0       // lab only: per-wave cycle totals of the MFMA phases, staging phases and barrier waits of workgroup 0
+#endif
+#if LWG_PP_TS
+__device__ unsigned long long lwg_pp_ts[8 * 4];
+extern "C" int lwg_lab_read_pp_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lwg_pp_ts), sizeof(lwg_pp_ts)); }
+#define PP_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0): count the LDS round trips into the staging phase */
+#define PP_ACC(k) { const unsigned long long t1_ = __builtin_readcyclecounter(); ts_[k] += t1_ - tl_; tl_ = t1_; }
+#else
+#define PP_ACC(k)
+#define PP_LGKM0()
 #endif
 #ifndef LWG_PP_SGB
 #define LWG_PP_SGB 0
@@ -327,7 +343,7 @@ static hipError_t launch_cfg_split(const LwgConvArgs& a, hipStream_t stream) {
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void lwg_conv_igemm_split_pp_kernel(const LwgConvArgs a) {
     constexpr int TM = 2, TN = 2, BMG = 128, BN = 128;       // per wave group: 128 x 128, waves 2 x 2, 64 x 64 per wave
-    constexpr int A_ROW = (BMG + 8) * 16, B_ROW = BN * 16;
+    constexpr int A_ROW = (BMG + 4) * 16, B_ROW = BN * 16;
     constexpr int A_PLANE = 2 * A_ROW, B_PLANE = 2 * B_ROW;
     constexpr int A_GRP = 3 * A_PLANE, A_STAGE = 2 * A_GRP, B_STAGE = 3 * B_PLANE;
     constexpr int PA = 2;                                     // float4 A loads per thread and stage
@@ -543,16 +559,25 @@ __global__ __launch_bounds__(512, 1) void lwg_conv_igemm_split_pp_kernel(const L
     // Each group runs its own loop (two barriers per iteration in both, so the groups meet at every phase boundary): straight-line
     // bodies keep the loop-carried fragments / load registers in place (a per-phase branch on the group made the compiler copy
     // them at every merge, behind an s_waitcnt vmcnt(0) that exposed the whole global-load latency in every phase).
+#if LWG_PP_TS
+    unsigned long long ts_[4] = {0, 0, 0, 0};
+    unsigned long long tl_ = __builtin_readcyclecounter();
+#endif
     if (grp == 0) {
         int t = 0;
         for (; t + 3 < nsteps; ++t) {          // phase 2t: compute t, split t+2 | phase 2t+1: store t+2, load t+3, read fragments of t+1
             mfmas_split();
+            PP_ACC(0)
             __syncthreads();
+            PP_ACC(2)
             if (!(LWG_PP_ABL & 2)) lstore(t & 1);
             advance();
             if (!(LWG_PP_ABL & 1)) gload();
             if (!(LWG_PP_ABL & 8)) read_frags((t + 1) & 1);
+            PP_LGKM0()
+            PP_ACC(1)
             __syncthreads();
+            PP_ACC(3)
         }
         for (; t < nsteps; ++t) {
             mfmas_split();
@@ -568,9 +593,14 @@ __global__ __launch_bounds__(512, 1) void lwg_conv_igemm_split_pp_kernel(const L
             advance();
             if (!(LWG_PP_ABL & 1)) gload();
             if (!(LWG_PP_ABL & 8)) read_frags(t & 1);
+            PP_LGKM0()
+            PP_ACC(1)
             __syncthreads();
+            PP_ACC(3)
             mfmas_split();
+            PP_ACC(0)
             __syncthreads();
+            PP_ACC(2)
         }
         for (; t < nsteps; ++t) {
             if (t + 1 < nsteps) lstore((t + 1) & 1);
@@ -580,12 +610,16 @@ __global__ __launch_bounds__(512, 1) void lwg_conv_igemm_split_pp_kernel(const L
             __syncthreads();
         }
     }
+#if LWG_PP_TS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 4; ++k) lwg_pp_ts[(tid >> 6) * 4 + k] = ts_[k];
+#endif
     lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
 }
 
 template <int EPI>
 static hipError_t launch_split_pp(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * (2 * 3 * 2 * (128 + 8) * 16 + 3 * 2 * 128 * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
+    constexpr size_t lds = (size_t)2 * (2 * 3 * 2 * (128 + 4) * 16 + 3 * 2 * 128 * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_split_pp_kernel<EPI>;
     static bool attr_done = false;
     if (!attr_done) {
