@@ -103,6 +103,16 @@ int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const
                           float* ws, lwg_stream_t stream);
 int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t,
                       lwg_stream_t stream);
+/* Weight panels straight from the parameter tensors, one launch each (the personalization step re-packs every weight and
+ * un-packs every weight gradient every step).  w (D0, D1, KH, KW) contiguous; kidx[tap] = ky*KW + kx of the weight slice a GEMM
+ * tap reads; transposed = 0: value = w[n][c][kidx] (Conv2d forward, ConvTranspose2d data gradient), 1: w[c][n][kidx]
+ * (ConvTranspose2d forward, Conv2d data gradient); (cin, nout) zero-extended to (cin_pad, n_pad); out = the
+ * [ceil32(ntaps*cin_pad)/4][n_pad][4] panel lwg_conv2d_nhwc_f32 reads.  lwg_unpack_wgrad_f32 is the inverse for the
+ * (ntaps*cin_pad, n_pad) output of lwg_conv2d_wgrad_nhwc_f32; weight positions no tap maps to are left untouched. */
+int lwg_pack_panel_f32(const float* w, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
+                       int cin_pad, int nout, int n_pad, float* out, lwg_stream_t stream);
+int lwg_unpack_wgrad_f32(const float* dwk, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
+                         int cin_pad, int nout, int n_pad, float* dw, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.

@@ -222,3 +222,94 @@ extern "C" int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, s
                        reinterpret_cast<floatx4*>(m), reinterpret_cast<floatx4*>(v), n4, lr, beta1, beta2, eps, bc1, bc2);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight panels straight from the parameter tensors (personalization step: every step re-packs every weight - forward panel,
+// data-gradient panel - and un-packs every weight gradient; as chains of torch view / permute / cat / copy kernels that was
+// ~1600 launches and 15 % of the step).  One launch per panel:
+//   panel[(k / 4), n, k % 4]  with  k = ((c / 32) * ntaps + tap) * 32 + c % 32   (cin_pad % 32 == 0)   or   tap * cin_pad + c
+//   value = W[n][c][kidx[tap]] (transposed = 0: Conv2d forward, ConvTranspose2d data gradient)
+//         = W[c][n][kidx[tap]] (transposed = 1: ConvTranspose2d forward, Conv2d data gradient),   0 beyond (cin, nout)
+// W is (D0, D1, KH, KW) contiguous, kidx[tap] = ky * KW + kx of the weight slice a GEMM tap reads.
+struct LwgTapIdx {
+    int kidx[LWG_MAX_TAPS];
+};
+
+__device__ __forceinline__ void lwg_korder_decode(int k, int ntaps, int cin_pad, int& tap, int& c) {
+    if ((cin_pad & 31) == 0) {
+        const int chunk = k / (ntaps * 32), rem = k - chunk * ntaps * 32;
+        tap = rem >> 5;
+        c = chunk * 32 + (rem & 31);
+    } else {
+        tap = k / cin_pad;
+        c = k - tap * cin_pad;
+    }
+}
+
+__global__ void lwg_pack_panel_kernel(const float* __restrict__ w, int D1, int KHW, int transposed, LwgTapIdx taps, int ntaps, int cin,
+                                      int cin_pad, int nout, int n_pad, int Kp, float* __restrict__ out) {
+    const int total = (Kp >> 2) * n_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k4 = i / n_pad, n = i - k4 * n_pad;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = k4 * 4 + kk;
+            if (k < ntaps * cin_pad && n < nout) {
+                int tap, c;
+                lwg_korder_decode(k, ntaps, cin_pad, tap, c);
+                if (c < cin) v[kk] = w[((size_t)(transposed ? c : n) * D1 + (transposed ? n : c)) * KHW + taps.kidx[tap]];
+            }
+        }
+        *reinterpret_cast<floatx4*>(out + (size_t)i * 4) = v;
+    }
+}
+
+extern "C" int lwg_pack_panel_f32(const float* w, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
+                                  int cin_pad, int nout, int n_pad, float* out, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!w || !kidx || !out || ntaps < 1 || ntaps > LWG_MAX_TAPS || cin < 1 || cin > cin_pad || nout < 1 || nout > n_pad)
+        return (int)hipErrorInvalidValue;
+    if ((transposed ? cin : nout) > D0 || (transposed ? nout : cin) > D1) return (int)hipErrorInvalidValue;
+    LwgTapIdx t;
+    for (int i = 0; i < ntaps; ++i) {
+        if (kidx[i] < 0 || kidx[i] >= KH * KW) return (int)hipErrorInvalidValue;
+        t.kidx[i] = kidx[i];
+    }
+    const int Kp = (ntaps * cin_pad + 31) / 32 * 32;
+    const int total = (Kp / 4) * n_pad;
+    hipLaunchKernelGGL(lwg_pack_panel_kernel, dim3((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), dim3(256), 0, stream, w, D1,
+                       KH * KW, transposed, t, ntaps, cin, cin_pad, nout, n_pad, Kp, out);
+    return (int)hipGetLastError();
+}
+
+// The inverse for weight gradients: dwk (ntaps * cin_pad, n_pad) in the kernel's K order (lwg_conv2d_wgrad_nhwc_f32) ->
+// dW[n][c][kidx[tap]] (transposed = 0) or dW[c][n][kidx[tap]] (transposed = 1); weight positions no tap maps to are untouched
+// (the four parity launches of a transposed convolution fill disjoint positions of one dW).
+__global__ void lwg_unpack_wgrad_kernel(const float* __restrict__ dwk, int D1, int KHW, int transposed, LwgTapIdx taps, int ntaps, int cin,
+                                        int cin_pad, int nout, int n_pad, float* __restrict__ dw) {
+    const int total = ntaps * cin * nout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i % nout, r = i / nout;
+        const int c = r % cin, tap = r / cin;
+        const int k = (cin_pad & 31) == 0 ? ((c >> 5) * ntaps + tap) * 32 + (c & 31) : tap * cin_pad + c;
+        dw[((size_t)(transposed ? c : n) * D1 + (transposed ? n : c)) * KHW + taps.kidx[tap]] = dwk[(size_t)k * n_pad + n];
+    }
+}
+
+extern "C" int lwg_unpack_wgrad_f32(const float* dwk, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
+                                    int cin_pad, int nout, int n_pad, float* dw, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!dwk || !kidx || !dw || ntaps < 1 || ntaps > LWG_MAX_TAPS || cin < 1 || cin > cin_pad || nout < 1 || nout > n_pad)
+        return (int)hipErrorInvalidValue;
+    if ((transposed ? cin : nout) > D0 || (transposed ? nout : cin) > D1) return (int)hipErrorInvalidValue;
+    LwgTapIdx t;
+    for (int i = 0; i < ntaps; ++i) {
+        if (kidx[i] < 0 || kidx[i] >= KH * KW) return (int)hipErrorInvalidValue;
+        t.kidx[i] = kidx[i];
+    }
+    const int total = ntaps * cin * nout;
+    hipLaunchKernelGGL(lwg_unpack_wgrad_kernel, dim3((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), dim3(256), 0, stream, dwk,
+                       D1, KH * KW, transposed, t, ntaps, cin, cin_pad, nout, n_pad, dw);
+    return (int)hipGetLastError();
+}

@@ -8,6 +8,7 @@ only these packed copies are what the kernels read.
 """
 import torch
 
+from .. import ops
 from ..ops import ConvSpec
 
 
@@ -41,9 +42,12 @@ def pack_conv(weight, bias=None, stride=1, pad=None, cin_pad=None, n_pad=None):
     pad = kh // 2 if pad is None else pad
     Cp = Cin if cin_pad is None else cin_pad
     Np = N if n_pad is None else n_pad
+    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+    if weight.is_cuda:                      # one HIP launch instead of a chain of view / permute / copy kernels
+        return ConvSpec(ops.pack_panel(weight.contiguous(), False, range(kh * kw), Cin, Cp, N, Np), _pad_vec(bias, Np), Np, Cp, taps,
+                        stride=stride, algo_kn=kh * kw * Cin * N)
     w = weight.new_zeros(kh * kw, Cp, Np)
     w[:, :Cin, :N] = weight.permute(2, 3, 1, 0).reshape(kh * kw, Cin, N)
-    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
     return ConvSpec(_panel(w.reshape(kh * kw * Cp, Np), kh * kw, Cp), _pad_vec(bias, Np), Np, Cp, taps, stride=stride,
                     algo_kn=kh * kw * Cin * N)
 
@@ -62,13 +66,19 @@ def pack_conv_transpose(weight, bias=None, n_pad=None):
     specs = []
     for py in (0, 1):
         for px in (0, 1):
-            taps, mats = [], []
+            taps, mats, kidx = [], [], []
             for ky, dy in _CT_TAPS[py]:
                 for kx, dx in _CT_TAPS[px]:
                     taps.append((dy, dx))
-                    m = weight.new_zeros(Cin, Np)
-                    m[:, :N] = weight[:, :, ky, kx]
-                    mats.append(m)
+                    kidx.append(ky * 4 + kx)
+                    if not weight.is_cuda:
+                        m = weight.new_zeros(Cin, Np)
+                        m[:, :N] = weight[:, :, ky, kx]
+                        mats.append(m)
+            if weight.is_cuda:
+                specs.append(ConvSpec(ops.pack_panel(weight.contiguous(), True, kidx, Cin, Cin, N, Np), _pad_vec(bias, Np), Np, Cin, taps,
+                                      stride=1, omul=2, ooy=py, oox=px, algo_kn=len(taps) * Cin * N))
+                continue
             wk = torch.stack(mats, dim=0).reshape(len(taps) * Cin, Np)
             specs.append(ConvSpec(_panel(wk, len(taps), Cin), _pad_vec(bias, Np), Np, Cin, taps, stride=1, omul=2, ooy=py, oox=px,
                                   algo_kn=len(taps) * Cin * N))
@@ -117,38 +127,52 @@ def _dgrad_spec(taps_w, n_out, **kw):
     return ConvSpec(_panel(wk, len(taps), cin), None, n_out, cin, taps, **kw)
 
 
-def pack_dgrad_conv(weight, stride=1, pad=None):
+def pack_dgrad_conv(weight, stride=1, pad=None, n_pad=None, cin_pad=None):
     """Data gradient of nn.Conv2d(weight (N, Cin, k, k), stride, pad) as forward-kernel launches on dY (B,OH,OW,N):
     stride 1 -> one spec (taps negated, panels transposed); stride 2 -> four specs, one per input parity, that scatter
-    into dX with omul = 2 (dX[2a + p] = sum_{taps d == p mod 2} dY[a + (p - d) / 2] W_d^T)."""
+    into dX with omul = 2 (dX[2a + p] = sum_{taps d == p mod 2} dY[a + (p - d) / 2] W_d^T).
+    n_pad / cin_pad: the zero-extended channel counts the forward launch used (dY has n_pad channels, dX gets cin_pad)."""
     weight = weight.detach().float()
     N, Cin, kh, kw = weight.shape
+    Np = N if n_pad is None else n_pad
+    Cp = Cin if cin_pad is None else cin_pad
     pad = kh // 2 if pad is None else pad
-    taps, W = _taps_weights(weight, stride, pad)
-    Wt = W.permute(0, 2, 1).contiguous()                          # (ntaps, N, Cin)
+    taps = [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
     if stride == 1:
-        return [_dgrad_spec([((-d[0], -d[1]), Wt[i]) for i, d in enumerate(taps)], Cin, stride=1)]
-    assert stride == 2
-    specs = []
-    for py in (0, 1):
-        for px in (0, 1):
-            tw = [(((py - d[0]) // 2, (px - d[1]) // 2), Wt[i]) for i, d in enumerate(taps)
-                  if (py - d[0]) % 2 == 0 and (px - d[1]) % 2 == 0]
-            specs.append(_dgrad_spec(tw, Cin, stride=1, omul=2, ooy=py, oox=px))
-    return specs
+        groups = [(dict(stride=1), [((-d[0], -d[1]), i) for i, d in enumerate(taps)])]
+    else:
+        assert stride == 2
+        groups = [(dict(stride=1, omul=2, ooy=py, oox=px),
+                   [(((py - d[0]) // 2, (px - d[1]) // 2), i) for i, d in enumerate(taps) if (py - d[0]) % 2 == 0 and (px - d[1]) % 2 == 0])
+                  for py in (0, 1) for px in (0, 1)]
+    if weight.is_cuda:                      # GEMM input channels = N (dim 0), GEMM columns = Cin (dim 1): the "transposed" read
+        w = weight.contiguous()
+        return [ConvSpec(ops.pack_panel(w, True, [i for _, i in tl], N, Np, Cin, Cp), None, Cp, Np, [t for t, _ in tl], **kw)
+                for kw, tl in groups]
+    if Np != N or Cp != Cin:
+        wpad = weight.new_zeros(Np, Cp, kh, kw)
+        wpad[:N, :Cin] = weight
+        weight = wpad
+    _, W = _taps_weights(weight, stride, pad)
+    Wt = W.permute(0, 2, 1).contiguous()                          # (ntaps, N, Cin)
+    return [_dgrad_spec([(t, Wt[i]) for t, i in tl], Cp, **kw) for kw, tl in groups]
 
 
-def pack_dgrad_conv_transpose(weight):
+def pack_dgrad_conv_transpose(weight, n_pad=None):
     """Data gradient of nn.ConvTranspose2d(k=4, s=2, p=1) weight (Cin, N, 4, 4): a stride-2, 16-tap convolution over dY
-    (B,2H,2W,N): dX[a] = sum_{parity p, tap e} dY[2 a + (p - 2 e)] W_{p,e}^T."""
+    (B,2H,2W,n_pad): dX[a] = sum_{parity p, tap e} dY[2 a + (p - 2 e)] W_{p,e}^T."""
     weight = weight.detach().float()
     Cin, N, kh, kw = weight.shape
-    tw = []
-    for py in (0, 1):
-        for px in (0, 1):
-            for ky, ey in _CT_TAPS[py]:
-                for kx, ex in _CT_TAPS[px]:
-                    tw.append(((py - 2 * ey, px - 2 * ex), weight[:, :, ky, kx].t().contiguous()))      # (N, Cin)
+    Np = N if n_pad is None else n_pad
+    tl = [((py - 2 * ey, px - 2 * ex), ky * 4 + kx) for py in (0, 1) for px in (0, 1) for ky, ey in _CT_TAPS[py] for kx, ex in _CT_TAPS[px]]
+    if weight.is_cuda:                      # GEMM input channels = N (dim 1), columns = Cin (dim 0)
+        return [ConvSpec(ops.pack_panel(weight.contiguous(), False, [i for _, i in tl], N, Np, Cin, Cin), None, Cin, Np,
+                         [t for t, _ in tl], stride=2)]
+    if Np != N:
+        wpad = weight.new_zeros(Cin, Np, 4, 4)
+        wpad[:, :N] = weight
+        weight = wpad
+    tw = [(t, weight[:, :, i // 4, i % 4].t().contiguous()) for t, i in tl]                              # (N, Cin)
     return [_dgrad_spec(tw, Cin, stride=2)]
 
 
@@ -162,11 +186,22 @@ def unpack_wgrad(dwk, ntaps, cin):
 
 def wgrad_to_conv(dwk, ntaps, cin_packed, cin, n, kh, kw):
     """-> nn.Conv2d weight gradient (N, Cin, kh, kw) (drops the zero-padded input / output channels)."""
+    if dwk.is_cuda:
+        return ops.unpack_wgrad(dwk, torch.empty(n, cin, kh, kw, device=dwk.device, dtype=torch.float32), False, range(ntaps), cin,
+                                cin_packed, n)
     return unpack_wgrad(dwk, ntaps, cin_packed)[:, :cin, :n].reshape(kh, kw, cin, n).permute(3, 2, 0, 1).contiguous()
 
 
 def wgrad_to_conv_transpose(dwks, cin, n):
     """Four parity gradients (each (4*Cin, Np) in kernel order, taps as in pack_conv_transpose) -> (Cin, N, 4, 4)."""
+    if dwks[0].is_cuda:
+        g = torch.empty(cin, n, 4, 4, device=dwks[0].device, dtype=torch.float32)      # the four parities cover all 16 positions
+        i = 0
+        for py in (0, 1):
+            for px in (0, 1):
+                ops.unpack_wgrad(dwks[i], g, True, [ky * 4 + kx for ky, _ in _CT_TAPS[py] for kx, _ in _CT_TAPS[px]], cin, cin, n)
+                i += 1
+        return g
     g = dwks[0].new_zeros(cin, n, 4, 4)
     i = 0
     for py in (0, 1):

@@ -90,12 +90,8 @@ class ConvFn(torch.autograd.Function):
             dw = packing.wgrad_to_conv(dwk, kh * kw, Cin_packed, Cin, N, kh, kw)
             dx = None
             if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-                wpad = weight
-                if Np != N or Cin_packed != Cin:                      # the dgrad panel must see the padded shapes
-                    wpad = weight.new_zeros(Np, Cin_packed, kh, kw)
-                    wpad[:N, :Cin] = weight
-                pad = kh // 2 if cfg.pad is None else cfg.pad
-                dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(wpad, cfg.stride, pad)]
+                pad = kh // 2 if cfg.pad is None else cfg.pad            # the dgrad panel sees the padded channel counts
+                dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(weight, cfg.stride, pad, n_pad=Np, cin_pad=Cin_packed)]
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin_packed, device=dev, dtype=torch.float32)
                 if cfg.stride == 1:
@@ -109,11 +105,7 @@ class ConvFn(torch.autograd.Function):
             dw = packing.wgrad_to_conv_transpose(dwks, Cin, N)
             dx = None
             if cfg.need_dx and ctx.needs_input_grad[0]:
-                wpad = weight
-                if Np != N:
-                    wpad = weight.new_zeros(Cin, Np, 4, 4)
-                    wpad[:, :N] = weight
-                dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(wpad)[0], dev)
+                dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
                 ops.conv2d(dy, dspec, dx)

@@ -4,6 +4,8 @@ PyTorch-ROCm is plumbing here: it owns device memory and the stream; every compu
 ``liblwg_hip.so``.  All wrappers require contiguous CUDA tensors and raise otherwise - there is no eager /
 CPU fallback on the product path.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -413,6 +415,32 @@ def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
     dw = torch.empty(Ktot, spec.N, device=x0.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().lwg_conv2d_wgrad_ws_floats(Ktot, spec.N, a.M), device=x0.device, dtype=torch.float32)
     _lib.check(_lib.lib().lwg_conv2d_wgrad_nhwc_f32(a, _ptr(dy), _ptr(dw), _ptr(ws), _stream()), "lwg_conv2d_wgrad_nhwc_f32")
+    return dw
+
+
+def pack_panel(w, transposed, kidx, cin, cin_pad, nout, n_pad):
+    """Weight (D0,D1,KH,KW) on the device -> the fp32 GEMM panel [ceil32(ntaps*cin_pad)/4][n_pad][4] in one launch
+    (csrc/train_ops.hip lwg_pack_panel_f32; see include/lwg_hip.h for the index convention)."""
+    w = w.detach()
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    D0, D1, KH, KW = w.shape
+    ntaps = len(kidx)
+    Kp = (ntaps * cin_pad + 31) // 32 * 32
+    out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
+    arr = (ctypes.c_int * ntaps)(*[int(k) for k in kidx])
+    _lib.check(_lib.lib().lwg_pack_panel_f32(_ptr(w), D0, D1, KH, KW, 1 if transposed else 0, arr, ntaps, cin, cin_pad, nout, n_pad,
+                                             _ptr(out), _stream()), "lwg_pack_panel_f32")
+    return out
+
+
+def unpack_wgrad(dwk, dw, transposed, kidx, cin, cin_pad, nout):
+    """(ntaps*cin_pad, n_pad) weight gradient in kernel K order -> positions kidx of dw (D0,D1,KH,KW), in place."""
+    D0, D1, KH, KW = dw.shape
+    ntaps = len(kidx)
+    assert dwk.is_contiguous() and dw.is_contiguous() and dwk.shape[0] == ntaps * cin_pad
+    arr = (ctypes.c_int * ntaps)(*[int(k) for k in kidx])
+    _lib.check(_lib.lib().lwg_unpack_wgrad_f32(_ptr(dwk), D0, D1, KH, KW, 1 if transposed else 0, arr, ntaps, cin, cin_pad, nout,
+                                               dwk.shape[1], _ptr(dw), _stream()), "lwg_unpack_wgrad_f32")
     return dw
 
 

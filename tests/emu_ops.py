@@ -229,11 +229,45 @@ def smpl_lbs(model, pose, beta, cam, offsets=None, links=None):
     return verts, j3d, j2d
 
 
+def _korder(ntaps, cin_pad):
+    """k index of (tap, c) in the kernel's K order (include/lwg_hip.h, lwg_pack_panel_f32)."""
+    tap = torch.arange(ntaps).view(-1, 1)
+    c = torch.arange(cin_pad).view(1, -1)
+    if cin_pad % 32 == 0:
+        return ((c // 32) * ntaps + tap) * 32 + c % 32
+    return tap * cin_pad + c
+
+
+def pack_panel(w, transposed, kidx, cin, cin_pad, nout, n_pad):
+    w = w.detach().float()
+    D0, D1, KH, KW = w.shape
+    kidx = list(kidx)
+    ntaps = len(kidx)
+    Kp = (ntaps * cin_pad + 31) // 32 * 32
+    flat = torch.zeros(Kp, n_pad)
+    wk = w.reshape(D0, D1, KH * KW)[:, :, kidx]                                   # (D0, D1, ntaps)
+    m = wk.permute(2, 0, 1) if transposed else wk.permute(2, 1, 0)                # (ntaps, c, n)
+    k = _korder(ntaps, cin_pad)[:, :cin]
+    flat[k.reshape(-1), :nout] = m[:, :cin, :nout].reshape(ntaps * cin, nout)
+    return flat.view(Kp // 4, 4, n_pad).permute(0, 2, 1).contiguous()
+
+
+def unpack_wgrad(dwk, dw, transposed, kidx, cin, cin_pad, nout):
+    D0, D1, KH, KW = dw.shape
+    kidx = list(kidx)
+    ntaps = len(kidx)
+    k = _korder(ntaps, cin_pad)[:, :cin]
+    m = dwk[k.reshape(-1), :nout].view(ntaps, cin, nout)                          # (tap, c, n)
+    flat = dw.view(D0, D1, KH * KW)
+    flat[:cin if transposed else nout, :nout if transposed else cin][:, :, kidx] = m.permute(1, 2, 0) if transposed else m.permute(2, 1, 0)
+    return dw
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
-                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse"):
+                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)
