@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
+                    help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,7 +73,10 @@ def main():
            "real_src": torch.tensor(case.src_img, device=dev), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
            "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
     del im
-    tr = LWGTrainer(G, D)
+    from ipercore_amd.trainers import TrainOpts
+    topts = TrainOpts()
+    topts.conv_precision = args.precision
+    tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
 
     flops = [0.0]
@@ -112,7 +117,7 @@ def main():
         print(json.dumps({
             "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(args.steps * world / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "dtype": "f32" if args.precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
             "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + L1 tsf + BCE mask + TV",
                        "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
                                       f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},

@@ -150,6 +150,9 @@ class TrainOpts(object):
     lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
     lr_G, lr_D = 1e-4, 1e-4
     G_adam_b1, G_adam_b2, D_adam_b1, D_adam_b2 = 0.9, 0.999, 0.9, 0.999
+    # "split": forward and data-gradient convs with Cin % 32 == 0 run on the bf16x6 kernel (fp32-level accuracy);
+    # weight gradients stay on the fp32 MFMA kernel
+    conv_precision = "fp32"
 
 
 class LWGTrainer(object):
@@ -209,6 +212,10 @@ class LWGTrainer(object):
 
     def optimize_parameters(self):
         """:326-352, plus the gradient all-reduce when the step is data parallel."""
+        with ops.conv_precision(self.opts.conv_precision):
+            return self._optimize_parameters()
+
+    def _optimize_parameters(self):
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
         loss_G = self.optimize_G(fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
         self.optimizer_G.zero_grad()

@@ -49,6 +49,35 @@ def test_conv_args_struct_layout_matches_header():
     assert got == [ctypes.sizeof(A), A.w.offset, A.y.offset, A.res.offset, A.dy.offset, A.dx.offset]
 
 
+def test_invalid_arguments_are_rejected_on_the_host():
+    """Every entry point validates its arguments before any launch and returns hipErrorInvalidValue (1): no GPU is touched,
+    so the error contract of include/lwg_hip.h can be checked here.  (The reference raises from torch / its CUDA extension;
+    the drop-in surfaces these codes as RuntimeError through _lib.check.)"""
+    L = _lib.lib()
+    bad = 0xdead0000                     # a non-NULL pointer that is never dereferenced: the shape checks fail first
+    a = _lib.LwgConvArgs()
+    assert L.lwg_conv2d_nhwc_f32(None, None) == 1
+    assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # NULL tensors
+    a.x0, a.w, a.y = bad, bad, bad
+    a.B, a.H, a.W, a.C0, a.OH, a.OW, a.M, a.N, a.YH, a.YW, a.YC = 1, 8, 8, 64, 8, 8, 64, 48, 8, 8, 48
+    a.ntaps, a.stride, a.omul = 9, 1, 1
+    assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # N not a multiple of 64
+    a.N = a.YC = 64
+    a.ntaps = 99
+    assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # more taps than LWG_MAX_TAPS
+    a.ntaps, a.C0 = 9, 24
+    assert L.lwg_conv2d_nhwc_bf16mma(a, None) == 1 and L.lwg_conv2d_nhwc_f32_split(a, None) == 1    # Cin % 32 != 0
+    assert L.lwg_lwb_attention_f32(bad, bad, bad, bad, bad, bad, bad, 1, 2, 8, 8, 48, 8, 0, None) == 1   # C not in {32,64,128,256}
+    assert L.lwg_lwb_attention_bwd_f32(bad, bad, bad, bad, bad, bad, bad, bad, bad, bad, 1, 9, 8, 8, 64, 8, 0, None) == 1   # ns > 8
+    assert L.lwg_lwb_fuse_f32(bad, None, None, bad, bad, 1, 2, 8, 8, 64, 8, 0, 1.0, 1.0, None) == 1       # NULL sources
+    assert L.lwg_rasterize_fim_wim_f32(bad, 1, 16, 4096, 0.1, 100.0, bad, bad, bad, None) == 1            # S > 2048
+    assert L.lwg_head_compose_f32(bad, bad, None, 0, 1, 64, 60, bad, None, None, None) == 1               # C % 8 != 0 / pred without bg
+    kidx = (ctypes.c_int * 2)(0, 99)
+    assert L.lwg_pack_panel_f32(bad, 64, 64, 3, 3, 0, kidx, 2, 64, 64, 64, 64, bad, None) == 1            # tap index outside the kernel
+    with pytest.raises(RuntimeError):
+        _lib.check(1, "lwg_conv2d_nhwc_f32")
+
+
 def test_ops_refuse_cpu_tensors():
     from ipercore_amd import ops
     with pytest.raises(RuntimeError):
