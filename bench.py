@@ -238,6 +238,7 @@ def main():
     lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
     mine = tgt[lo:hi].contiguous()
 
+    lo_out = rank * K * FB                                   # this rank's block inside the gathered (K * FB * world) video
     timer = ConvTimer()
     ops.CONV_HOOK = None if args.no_conv_events else timer
 
@@ -251,9 +252,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         # untimed: the first collective of a size class sets up RCCL's channels / buffers - do it once at the timed shape
-        warm = last.new_zeros((K * FB,) + tuple(last.shape[1:]))
-        sharding.all_gather_frames(warm, K * FB * world)
-        del warm
+        wg = sharding.OverlappedGather(FB * world)
+        wg.submit(last, 0)
+        wg.finish()
+        del wg
         dist.barrier()
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
@@ -266,6 +268,7 @@ def main():
         torch.cuda.synchronize()
     timer.enabled = True
     outs = []
+    og = sharding.OverlappedGather(K * FB * world) if world > 1 else None     # each step's frames go to RCCL as they appear
     t0 = time.perf_counter()
     for i in range(W, W + K):
         if streams:
@@ -273,11 +276,19 @@ def main():
                 outs.append(step(i))
         else:
             outs.append(step(i))
+        if og is not None and not streams:
+            og.submit(outs[-1], (i - W) * FB)
     if streams:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
-    local = torch.cat(outs, dim=0)
-    video = sharding.all_gather_frames(local, K * FB * world) if world > 1 else local
+        if og is not None:
+            for j, o in enumerate(outs):
+                og.submit(o, j * FB)
+    if og is not None:
+        video = og.finish()
+        local = video[lo_out:lo_out + K * FB]
+    else:
+        video = local = torch.cat(outs, dim=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -308,7 +319,8 @@ def main():
                        if args.precision == "bf16" else
                        f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator, fp32 with bf16x6 exact-split products",
                        "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
-                       "parallelism": f"frame-shard x{world}" + (" + all-gather of the output video" if world > 1 else ""),
+                       "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather of the output video, chunked behind the frame loop"
+                                                                  if world > 1 else ""),
                        "batches_in_flight": args.streams,
                        "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},
         }

@@ -111,8 +111,20 @@ class Fake:
     def prepare_sequence(self, s, cam): return torch.as_tensor(s)
     def synthesize(self, chunk, cam, t0=0): return chunk[:, None, None, None].expand(-1, 3, 2, 2) * 2 + 1
 seq = torch.arange(n, dtype=torch.float32)
-vid = sharding.sharded_synthesize(Fake(), seq)
+for overlap in (True, False):
+    vid = sharding.sharded_synthesize(Fake(), seq, overlap=overlap)
+    assert vid.shape == (n, 3, 2, 2) and torch.equal(vid[:, 0, 0, 0], seq * 2 + 1), (overlap, vid[:, 0, 0, 0])
+# chunked overlap with a frame batch that does not divide the shard, and a shard one frame short
+class Fake3(Fake):
+    frame_batch = 3
+vid = sharding.sharded_synthesize(Fake3(), seq, overlap=True)
 assert torch.equal(vid[:, 0, 0, 0], seq * 2 + 1)
+og = sharding.OverlappedGather(n)
+lo, hi = sharding.shard_range(n, rank, world)
+for off in range(0, og.cap, 2):
+    m = min(2, og.cap - off)
+    og.submit(full[lo + off:min(lo + off + m, hi)].clone(), off, length=m)
+assert torch.equal(og.finish(), full)
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 '''
