@@ -1,6 +1,6 @@
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import numpy as np
 sys.argv = ["convlab", "--split", "--iters", "3", "--shapes", sys.argv[1], "tools/lab/pp_ts.so"]
 os.environ["LWG_SPLIT_PP"] = "1"
 import tools.convlab as cl
