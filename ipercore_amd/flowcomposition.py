@@ -108,6 +108,19 @@ class FlowComposition(torch.nn.Module):
                                            ref_info["wim"].repeat(max(ns, nt), 1, 1, 1)[0:n])
         return Tst.view(bs, ns, h, w, 2), None
 
+    @torch.no_grad()
+    def make_batch_trans_flow(self, bs, ns, nt, src_info, ref_info, temporal=False, use_selected_f2pts=False):
+        """flowcomposition.py:584-662 (training form): Tst (bs, nt, ns, h, w, 2): every target frame of a sample against every
+        source of the same sample.  temporal flows (Ttt) are produced by the runner's recurrent path only."""
+        if temporal:
+            raise NotImplementedError("Ttt for multi-step temporal training is not built (temporal inference is: Imitator(temporal=True))")
+        h = w = self.image_size
+        key = "selected_f2pts" if use_selected_f2pts else ("only_vis_f2pts" if self.only_vis else "f2pts")
+        f2 = _force(src_info[key]).view(bs, 1, ns, -1, 3, 2).expand(bs, nt, ns, -1, 3, 2).reshape(bs * nt * ns, -1, 3, 2).contiguous()
+        fim = ref_info["fim"].view(bs, nt, 1, h, w).expand(bs, nt, ns, h, w).reshape(bs * nt * ns, h, w).contiguous()
+        wim = ref_info["wim"].view(bs, nt, 1, h, w, 3).expand(bs, nt, ns, h, w, 3).reshape(bs * nt * ns, h, w, 3).contiguous()
+        return self.render.cal_bc_transform(f2, fim, wim).view(bs, nt, ns, h, w, 2), None
+
     def make_src_inputs(self, src_img, src_info):
         """flowcomposition.py:262-265."""
         return torch.cat([src_img, src_info["cond"]], dim=1)

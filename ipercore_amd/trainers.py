@@ -22,6 +22,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .bodynets import SMPLH
+from .flowcomposition import FlowComposition
+from .morphology import morph
 from .networks.training import TrainableGenerator, conv, instance_norm
 
 _RELU = 1
@@ -155,11 +158,78 @@ class TrainOpts(object):
     conv_precision = "fp32"
 
 
+class FlowCompositionForTrainer(FlowComposition):
+    """tools/trainers/base.py:90-141: the per-sample input stage of the trainers - body model, renders, the once-per-source
+    image stage, target conditions and the (bs, nt, ns) flows - on the same HIP kernels the runner uses.
+    ``body_model``: any model with ``get_details`` (the runner's SMPL-H is the default; the reference's trainers use the older
+    24-joint SMPL, bodynets/batch_smpl.py:283-436, which is not built - the LBS kernel itself is generic in the joint count)."""
+
+    def __init__(self, opt, body_model=None):
+        super().__init__(opt)
+        g = lambda k, d=None: getattr(opt, k, d) if not isinstance(opt, dict) else opt.get(k, d)    # noqa: E731
+        self.smpl = body_model if body_model is not None else SMPLH(model_path=g("smpl_model_hand"))
+        self.ft_ks = int(g("ft_ks", 1))                      # deploy.toml:12
+        self.share_bg = bool(g("share_bg", True))
+
+    @torch.no_grad()
+    def forward(self, src_img, ref_img, src_smpl, ref_smpl, src_mask=None, ref_mask=None, links_ids=None, offsets=0, temporal=False):
+        """-> input_G_bg (bs,nb,4,h,w), input_G_src (bs,ns,6,h,w), input_G_tsf (bs,nt,6,h,w), Tst (bs,nt,ns,h,w,2), Ttt,
+        src_mask (bs,ns,1,h,w), tsf_mask (bs,nt,1,h,w), head_bbox (bs*nt,4), body_bbox (bs*nt,4), uv_img (bs,3,h,w)."""
+        bs, ns, _, h, w = src_img.shape
+        nt = ref_img.shape[1]
+        self.make_uv_setup(bs, self.num_source, self.time_step, src_img.device)
+        sl = rl = None
+        if links_ids is not None:
+            nv, c = links_ids.shape[-2:]
+            sl = links_ids.expand(bs, ns, nv, c).reshape(bs * ns, nv, c)
+            rl = links_ids.expand(bs, nt, nv, c).reshape(bs * nt, nv, c)
+        src_info = self.smpl.get_details(src_smpl.reshape(bs * ns, -1).contiguous(), offsets, links_ids=sl)
+        ref_info = self.smpl.get_details(ref_smpl.reshape(bs * nt, -1).contiguous(), offsets, links_ids=rl)
+        if src_mask is not None:
+            src_info["masks"] = src_mask.reshape(bs * ns, 1, h, w).contiguous()
+        if ref_mask is not None:
+            ref_info["masks"] = ref_mask.reshape(bs * nt, 1, h, w).contiguous()
+        self.add_rendered_f2verts_fim_wim(src_info, use_morph=True, get_uv_info=True)
+        self.add_rendered_f2verts_fim_wim(ref_info, use_morph=False, get_uv_info=False)
+        primary = None if self.share_bg else list(range(ns))
+        uv_img, input_G_bg, input_G_src = self.process_source(src_img, src_info, primary_ids=primary)
+        src_info.pop("_edge_counts", None)
+        input_G_tsf = self.make_tsf_inputs(uv_img, ref_info)
+        Tst, Ttt = self.make_batch_trans_flow(bs, ns, nt, src_info, ref_info, temporal=temporal)
+        sm = src_info["masks"] if src_mask is not None else src_info["cond"][:, -1:]
+        tm = ref_info["masks"] if ref_mask is not None else ref_info["cond"][:, -1:]
+        sm = morph(sm.contiguous(), ks=self.ft_ks, mode="erode").view(bs, ns, 1, h, w)
+        tm = morph(tm.contiguous(), ks=self.ft_ks, mode="erode").view(bs, nt, 1, h, w)
+        return (input_G_bg, input_G_src, input_G_tsf, Tst, Ttt, sm, tm, self.cal_head_bbox_by_kps(ref_info["j2d"]),
+                self.cal_body_bbox_by_kps(ref_info["j2d"]), uv_img)
+
+    def cal_head_bbox_by_kps(self, kps, neck_ids=12):
+        """base.py:205-246 -> (N, 4) long (min_x, max_x, min_y, max_y) in pixels (tiny host-visible bookkeeping: torch ops)."""
+        S = self.image_size
+        k = (kps + 1) / 2.0
+        min_x = (k[:, neck_ids:, 0] - 0.05).min(dim=1)[0].clamp_min(0.0)
+        max_x = (k[:, neck_ids:, 0] + 0.05).max(dim=1)[0].clamp_max(1.0)
+        min_y = (k[:, neck_ids:, 1] - 0.05).min(dim=1)[0].clamp_min(0.0)
+        max_y = k[:, neck_ids:, 1].max(dim=1)[0].clamp_max(1.0)
+        return torch.stack([(min_x * S).long(), (max_x * S).long(), (min_y * S).long(), (max_y * S).long()], dim=1)
+
+    def cal_body_bbox_by_kps(self, kps, factor=1.2):
+        """base.py:248-285."""
+        S = self.image_size
+        k = (kps + 1) / 2.0
+        out = []
+        for d in (0, 1):
+            lo, hi = k[:, :, d].min(dim=1)[0], k[:, :, d].max(dim=1)[0]
+            mid, ext = (lo + hi) / 2, (hi - lo) * factor
+            out += [((mid - ext / 2).clamp_min(0.0) * S).long(), ((mid + ext / 2).clamp_max(1.0) * S).long()]
+        return torch.stack(out, dim=1)
+
+
 class LWGTrainer(object):
     """lwg_trainer.py:609-832 for bs = 1 sample per process, share_bg = True, temporal = False, use_gan = True."""
 
-    def __init__(self, G, D=None, opts=None, group=None):
-        self.G, self.D, self.group = G, D, group
+    def __init__(self, G, D=None, opts=None, group=None, flow_comp=None):
+        self.G, self.D, self.group, self.flow_comp = G, D, group, flow_comp
         self.opts = opts or TrainOpts()
         self.tg = TrainableGenerator(G)
         o = self.opts
@@ -167,11 +237,34 @@ class LWGTrainer(object):
         self.optimizer_D = None if D is None else FlatAdam(D, lr=o.lr_D, betas=(o.D_adam_b1, o.D_adam_b2))
         self.losses = {}
 
-    def set_input(self, inputs):
-        """The tensors LWGTrainer.set_input (:624-697) leaves on the trainer:
-        input_G_bg (1,nb,4,h,w), input_G_src (1,ns,6,h,w), input_G_tsf (1,nt,6,h,w), Tst (1,nt,ns,h,w,2),
-        real_src (1,ns,3,h,w), real_tsf (1,nt,3,h,w), real_bg (nb,3,h,w), body_mask (1,ns+nt,1,h,w)."""
-        self.inp = inputs
+    def set_input(self, inputs, device=None, flow_comp=None, ns=None):
+        """lwg_trainer.py:624-697.  ``inputs`` is either the dataset sample of the reference (``PersonalizedDataset.__getitem__``,
+        data/personalized_dataset.py:163-191: images (1,ns+nt,3,h,w), smpls (1,ns+nt,85), masks (1,ns+nt,1,h,w), bg (1,3,h,w),
+        offsets, links_ids) - then ``flow_comp`` (a FlowCompositionForTrainer) builds the network inputs on the device - or the
+        tensors that stage leaves on the trainer: input_G_bg (1,nb,4,h,w), input_G_src (1,ns,6,h,w), input_G_tsf (1,nt,6,h,w),
+        Tst (1,nt,ns,h,w,2), real_src (1,ns,3,h,w), real_tsf (1,nt,3,h,w), real_bg (nb,3,h,w), body_mask (1,ns+nt,1,h,w)."""
+        if "images" not in inputs:
+            self.inp = inputs
+            return
+        fc = flow_comp if flow_comp is not None else self.flow_comp
+        assert fc is not None, "set_input(sample) needs a FlowCompositionForTrainer (LWGTrainer(..., flow_comp=...))"
+        dev = device if device is not None else next(self.G.parameters()).device
+        to = lambda k: torch.as_tensor(inputs[k], dtype=torch.float32).to(dev)     # noqa: E731
+        images, smpls, masks, bg = to("images"), to("smpls"), to("masks"), to("bg")
+        offsets = to("offsets") if "offsets" in inputs else 0
+        links = torch.as_tensor(inputs["links_ids"]).to(dev) if inputs.get("links_ids") is not None else None
+        ns = fc.num_source if ns is None else ns
+        S = images.shape[-1]
+        g_bg, g_src, g_tsf, Tst, _, _, tsf_mask, head_bbox, body_bbox, uv_img = fc(
+            images[:, :ns].contiguous(), images[:, ns:].contiguous(), smpls[:, :ns].contiguous(), smpls[:, ns:].contiguous(),
+            src_mask=masks[:, :ns].contiguous(), ref_mask=masks[:, ns:].contiguous(), links_ids=links, offsets=offsets)
+        if not fc.share_bg:
+            tsf_img = images[:, ns:]
+            g_bg = torch.cat([g_bg, torch.cat([tsf_img * tsf_mask, tsf_mask], dim=2)], dim=1)
+        self.inp = {"input_G_bg": g_bg.contiguous(), "input_G_src": g_src.contiguous(), "input_G_tsf": g_tsf.contiguous(),
+                    "Tst": Tst.contiguous(), "real_src": images[:, :ns].contiguous(), "real_tsf": images[:, ns:].contiguous(),
+                    "real_bg": bg.view(-1, 3, S, S), "body_mask": masks, "uv_img": uv_img, "head_bbox": head_bbox,
+                    "body_bbox": body_bbox}
 
     def forward(self):
         """:699-730."""
@@ -230,3 +323,22 @@ class LWGTrainer(object):
             self.optimizer_D.allreduce(self.group)
             self.optimizer_D.step()
         return loss_G.detach(), None if loss_D is None else loss_D.detach()
+
+
+def personalize(trainer, samples, n_iters, ckpt_path=None, log_every=0):
+    """services/personalization.py:95-151 without the process / DataLoader / TensorBoard shell: cycle over ``samples`` (dataset
+    samples or prepared input dicts) for ``n_iters`` optimisation steps and save ``G.state_dict()`` where ``Imitator`` looks for
+    ``personalized_ckpt_path`` (imitator.py:160-168).  Returns the (loss_G, loss_D) history as floats."""
+    hist, it = [], 0
+    while it < n_iters:
+        for sample in samples:
+            trainer.set_input(sample)
+            lg, ld = trainer.optimize_parameters()
+            it += 1
+            if log_every and it % log_every == 0:
+                hist.append((float(lg), None if ld is None else float(ld)))
+            if it >= n_iters:
+                break
+    if ckpt_path:
+        torch.save({k: v.detach().cpu() for k, v in trainer.G.state_dict().items()}, ckpt_path)
+    return hist

@@ -549,6 +549,76 @@ def check_swapper():
     return out
 
 
+def check_personalize_loop():
+    """The input stage of the trainers and the personalization loop end to end (reference lwg_trainer.py:624-697 set_input via
+    FlowCompositionForTrainer tools/trainers/base.py:90-141; services/personalization.py:95-151): a dataset-shaped sample
+    (images, smpls, masks, bg) -> network inputs on the GPU vs the oracle's composition (process_source, make_tsf_inputs,
+    make_trans_flow - each pinned to the reference by the CPU suite), then personalize() for a few steps, the saved
+    personalized.pth picked up by a fresh Imitator."""
+    import tempfile
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.imitator import Imitator
+    from ipercore_amd.networks import NetworksFactory
+    from ipercore_amd.trainers import FlowCompositionForTrainer, LWGTrainer, PatchGlobalDiscriminator, personalize
+    S, nf, nres, bgf, ns = 128, [64, 64, 128], 2, [64, 64, 128], 2
+    ks = dict(conf_erode_ks=3, out_dilate_ks=21, bg_ks=11)
+    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=2, ns=ns)
+    case.opt.update(ks)
+    im0 = Imitator(case.opt, device=torch.device(DEV), frame_batch=2)
+    fc = FlowCompositionForTrainer(case.opt, body_model=im0.body_rec).to(DEV)
+    smpls, img = pu.source_stage_inputs(S)                                       # the seeded inputs of the source-stage goldens
+    tgt_smpl = synthetic.smpl_sequence(1, seed=60, pose_dim=72)
+    tgt_img = synthetic.uniform_image((1, 1, 3, S, S), 61, "tgt_img")
+    all_smpl = torch.tensor(np.concatenate([smpls, tgt_smpl], axis=0)[None], device=DEV)
+    info = fc.smpl.get_details(all_smpl[0], torch.zeros((), device=DEV), links_ids=None)
+    _, fim_all, wim_all = fc.render.render_fim_wim(cam=info["cam"], vertices=info["verts"], smpl_faces=True)
+    fg = pu.fg_masks_from_sil((fim_all != -1).float().unsqueeze(1).cpu())
+    sample = {"images": np.concatenate([img, tgt_img], axis=1), "smpls": all_smpl.cpu().numpy(), "masks": (1.0 - fg)[None].numpy(),
+              "bg": synthetic.uniform_image((1, 3, S, S), 62, "bg")}
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
+    G.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
+    G.to(DEV).train()
+    torch.manual_seed(0)
+    D = PatchGlobalDiscriminator().to(DEV)
+    tr = LWGTrainer(G, D, flow_comp=fc)
+    tr.set_input(sample)
+    torch.cuda.synchronize()
+    inp, out = tr.inp, {}
+    # oracle composition on the HIP vertices (identical rasterizer inputs on both sides)
+    o = pu.oracle_source_stage(S, ks, verts_cam=(info["cam"][:ns].cpu(), info["verts"][:ns].cpu()))
+    assert torch.equal(o["fg"], fg[:ns])
+    out["input_G_src"] = _cmp(inp["input_G_src"], o["input_G_src"], 1e-5, "input_G_src")
+    out["input_G_bg"] = _cmp(inp["input_G_bg"], o["input_G_bg"], 1e-6, "input_G_bg")
+    out["uv_img"] = _cmp_mostly(inp["uv_img"], o["uv_img"], 5e-5, 0.01, "uv_img")
+    t = pu.oracle_tables()
+    rf, rw = fim_all[ns:].cpu(), wim_all[ns:].cpu()
+    want_tsf, _ = orc.make_tsf_inputs(inp["uv_img"].cpu(), t["f_uvs2img"], orc.encode_fim(t["map_fn"], rf), rf, rw)
+    out["input_G_tsf"] = _cmp(inp["input_G_tsf"][0], want_tsf, 2e-5, "input_G_tsf")
+    f2pts, _, _ = orc.render_fim_wim(info["cam"][:ns].cpu(), info["verts"][:ns].cpu(), t["smpl_faces"], S)
+    out["Tst"] = _cmp(inp["Tst"][0, 0], orc.make_trans_flow(f2pts, rf, rw)[0], 1e-5, "Tst")
+    assert inp["body_bbox"].shape == (1, 4) and inp["head_bbox"].shape == (1, 4)
+    # the loop: a few steps on this sample, checkpoint, reload through the runner
+    w0 = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    with tempfile.TemporaryDirectory() as d:
+        ck = os.path.join(d, "personalized.pth")
+        hist = personalize(tr, [sample], n_iters=3, ckpt_path=ck, log_every=1)
+        torch.cuda.synchronize()
+        assert len(hist) == 3 and all(np.isfinite(h[0]) and np.isfinite(h[1]) for h in hist), hist
+        out["loss_G"] = [h[0] for h in hist]
+        case.opt["meta_data"] = pu.AttrDict(personalized_ckpt_path=ck)
+        im = Imitator(case.opt, device=torch.device(DEV), frame_batch=2)
+        moved = 0.0
+        for k, v in im.generator.state_dict().items():
+            assert torch.equal(v.cpu(), G.state_dict()[k].cpu()), f"{k}: personalized checkpoint not loaded"
+            moved = max(moved, (v.cpu() - w0[k].cpu()).abs().max().item())
+        out["max_weight_change"] = moved
+        assert moved > 0
+        im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+        frames = im.inference(case.tgt_smpls, "smooth")
+        assert np.isfinite(np.stack(frames)).all()
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1007,4 +1077,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop]
