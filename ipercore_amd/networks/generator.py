@@ -394,10 +394,8 @@ class AttentionLWBGenerator(nn.Module):
         return img, mask
 
     @torch.no_grad()
-    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
-        """:633-699 with temporal=False: Tst (bs, nt, ns, h, w, 2), tsf_inputs (bs, nt, 6, h, w)."""
+    def _forward_streams(self, src_inputs, tsf_inputs, Tst, only_tsf):
         bs, nt = Tst.shape[0], Tst.shape[1]
-        bg_img = self.forward_bg(bg_inputs)
         if only_tsf:
             enc, res = self.forward_src(src_inputs, only_enc=True)
             src_imgs = src_masks = None
@@ -411,7 +409,13 @@ class AttentionLWBGenerator(nn.Module):
             img, mask = self.forward_tsf(tsf_inputs[:, t], enc, res, Tst[:, t].contiguous())
             imgs.append(img)
             masks.append(mask)
-        imgs, masks = torch.stack(imgs, dim=1), torch.stack(masks, dim=1)
+        return src_imgs, src_masks, torch.stack(imgs, dim=1), torch.stack(masks, dim=1)
+
+    @torch.no_grad()
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
+        """:633-699 with temporal=False: Tst (bs, nt, ns, h, w, 2), tsf_inputs (bs, nt, 6, h, w)."""
+        bg_img = self.forward_bg(bg_inputs)
+        src_imgs, src_masks, imgs, masks = self._forward_streams(src_inputs, tsf_inputs, Tst, only_tsf)
         if only_tsf:
             return bg_img, imgs, masks
         return bg_img, src_imgs, src_masks, imgs, masks
@@ -421,8 +425,13 @@ class AttentionLWBFrontGenerator(AttentionLWBGenerator):
     """attlwb_spade_resunet.py:702-834: same network without the background branch."""
     has_bg = False
 
+    @torch.no_grad()
     def forward(self, src_inputs, tsf_inputs, Tst, Ttt=None, only_tsf=True):
-        raise NotImplementedError("AttLWB-Front-SPADE.forward is used by LWGFrontTrainer only (training: next row)")
+        """:778-834: the same two streams, no background branch."""
+        src_imgs, src_masks, imgs, masks = self._forward_streams(src_inputs, tsf_inputs, Tst, only_tsf)
+        if only_tsf:
+            return imgs, masks
+        return src_imgs, src_masks, imgs, masks
 
 
 class AddLWBGenerator(AttentionLWBGenerator):

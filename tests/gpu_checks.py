@@ -619,6 +619,34 @@ def check_personalize_loop():
     return out
 
 
+def check_reference_shape_tests():
+    """The reference's OWN unit tests for this path, run against the drop-in with the same inputs and asserts:
+    tests/test_models/test_networks/test_generators.py:52-104 (AttentionLWBGenerator / AttentionLWBFrontGenerator, bs = 4, ns = 5,
+    nt = 2 at 512^2, only_tsf = False) and test_discriminators.py:55-79 (PatchDiscriminator (4,6,512,512) -> (4,1,30,30))."""
+    from ipercore_amd.networks import NetworksFactory
+    from ipercore_amd.trainers import PatchGlobalDiscriminator
+    cfg = pu.gen_cfg([64, 128, 256], 6, [64, 128, 128, 256])
+    torch.manual_seed(0)
+    src_inputs, tsf_inputs = torch.rand(4, 5, 6, 512, 512, device=DEV), torch.rand(4, 2, 6, 512, 512, device=DEV)
+    Tst, Ttt = torch.rand(4, 2, 5, 512, 512, 2, device=DEV), torch.rand(4, 1, 512, 512, 2, device=DEV)
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=cfg, temporal=False).to(DEV).eval()
+    bg_img, src_img, src_mask, tsf_img, tsf_mask = G(torch.rand(4, 5, 4, 512, 512, device=DEV), src_inputs, tsf_inputs, Tst, Ttt, only_tsf=False)
+    assert tuple(bg_img.shape) == (4, 5, 3, 512, 512) and tuple(src_img.shape) == (4, 5, 3, 512, 512)
+    assert tuple(src_mask.shape) == (4, 5, 1, 512, 512) and tuple(tsf_img.shape) == (4, 2, 3, 512, 512) and tuple(tsf_mask.shape) == (4, 2, 1, 512, 512)
+    assert all(torch.isfinite(t).all() for t in (bg_img, src_img, src_mask, tsf_img, tsf_mask))
+    del G, bg_img
+    F_ = NetworksFactory.get_by_name("AttLWB-Front-SPADE", cfg=cfg, temporal=False).to(DEV).eval()
+    src_img, src_mask, tsf_img, tsf_mask = F_(src_inputs, tsf_inputs, Tst, Ttt, only_tsf=False)
+    assert tuple(src_img.shape) == (4, 5, 3, 512, 512) and tuple(src_mask.shape) == (4, 5, 1, 512, 512)
+    assert tuple(tsf_img.shape) == (4, 2, 3, 512, 512) and tuple(tsf_mask.shape) == (4, 2, 1, 512, 512)
+    D = PatchGlobalDiscriminator().to(DEV)
+    with torch.no_grad():
+        outs = D(torch.rand(4, 6, 512, 512, device=DEV))
+    torch.cuda.synchronize()
+    assert tuple(outs[0].shape) == (4, 1, 30, 30), outs[0].shape
+    return {"patch_map": list(outs[0].shape)}
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1077,4 +1105,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests]
