@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--use-vgg", action="store_true", help="VGG19 perceptual transfer loss (deploy.toml:83; seeded weights when "
+                                                          "vgg19-dcbb9e9d.pth is absent) instead of L1")
     ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
                     help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
     args = ap.parse_args()
@@ -76,6 +78,7 @@ def main():
     from ipercore_amd.trainers import TrainOpts
     topts = TrainOpts()
     topts.conv_precision = args.precision
+    topts.use_vgg = "VGG19" if args.use_vgg else "None"
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
 
@@ -118,7 +121,7 @@ def main():
             "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(args.steps * world / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "dtype": "f32" if args.precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
-            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + L1 tsf + BCE mask + TV",
+            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if args.use_vgg else "L1") + " tsf + BCE mask + TV",
                        "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
                                       f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},
             "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(per_step / (dt / args.steps) / 1e12, 2),

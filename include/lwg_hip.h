@@ -113,6 +113,10 @@ int lwg_pack_panel_f32(const float* w, int D0, int D1, int KH, int KW, int trans
                        int cin_pad, int nout, int n_pad, float* out, lwg_stream_t stream);
 int lwg_unpack_wgrad_f32(const float* dwk, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
                          int cin_pad, int nout, int n_pad, float* dw, lwg_stream_t stream);
+/* MaxPool2d(2, 2) on NHWC (VGG19 perceptual loss, criterions/vggloss.py): y (B,H/2,W/2,C); the backward writes all of dx
+ * (B,H,W,C), each gradient going to the first maximum of its window in scan order.  H, W even; C % 4 == 0. */
+int lwg_maxpool2_fwd_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, lwg_stream_t stream);
+int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.

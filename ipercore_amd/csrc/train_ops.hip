@@ -313,3 +313,72 @@ extern "C" int lwg_unpack_wgrad_f32(const float* dwk, int D0, int D1, int KH, in
                        D1, KH * KW, transposed, t, ntaps, cin, cin_pad, nout, n_pad, dw);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 2, stride 2) on NHWC, forward and backward (VGG19 perceptual loss of the personalization step,
+// criterions/vggloss.py:6-96).  The backward routes each gradient to the FIRST maximum of its window in scan order
+// (0,0) (0,1) (1,0) (1,1), as ATen's max_pool2d_with_indices does; H and W even.
+__global__ void lwg_maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int OH, int OW, int C4) {
+    const size_t total = (size_t)B * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const size_t p = i / C4;
+        const int ox = (int)(p % OW);
+        const size_t q = p / OW;
+        const int oy = (int)(q % OH), b = (int)(q / OH);
+        const floatx4* xb = reinterpret_cast<const floatx4*>(x) + (((size_t)b * 2 * OH + 2 * oy) * 2 * OW + 2 * ox) * C4 + c;
+        const floatx4 a = xb[0], bb = xb[C4], cc = xb[(size_t)2 * OW * C4], d = xb[(size_t)2 * OW * C4 + C4];
+        floatx4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = fmaxf(fmaxf(a[k], bb[k]), fmaxf(cc[k], d[k]));
+        reinterpret_cast<floatx4*>(y)[i] = r;
+    }
+}
+
+__global__ void lwg_maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int OH,
+                                        int OW, int C4) {
+    const size_t total = (size_t)B * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const size_t p = i / C4;
+        const int ox = (int)(p % OW);
+        const size_t q = p / OW;
+        const int oy = (int)(q % OH), b = (int)(q / OH);
+        const size_t base = (((size_t)b * 2 * OH + 2 * oy) * 2 * OW + 2 * ox) * C4 + c;
+        const size_t off[4] = {0, (size_t)C4, (size_t)2 * OW * C4, (size_t)2 * OW * C4 + C4};
+        const floatx4* xb = reinterpret_cast<const floatx4*>(x) + base;
+        floatx4 v[4], g = reinterpret_cast<const floatx4*>(dy)[i], o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[t] = xb[off[t]]; o[t] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int best = 0;
+            float m = v[0][k];
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+                if (v[t][k] > m) { m = v[t][k]; best = t; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t][k] = t == best ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) (reinterpret_cast<floatx4*>(dx) + base)[off[t]] = o[t];
+    }
+}
+
+extern "C" int lwg_maxpool2_fwd_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(lwg_maxpool2_fwd_kernel, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0,
+                       stream, x, y, B, H / 2, W / 2, C / 4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(lwg_maxpool2_bwd_kernel, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0,
+                       stream, x, dy, dx, B, H / 2, W / 2, C / 4);
+    return (int)hipGetLastError();
+}

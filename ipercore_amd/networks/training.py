@@ -83,11 +83,14 @@ class ConvFn(torch.autograd.Function):
         dev = dy.device
         C0 = x0.shape[3]
         Cin_packed = specs[0].Cin
-        db = ops.colsum(dy)[:N] if ctx.has_bias else None
+        want_dw = ctx.needs_input_grad[2]                            # frozen weights (the VGG19 of the perceptual loss): data gradient only
+        db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
         if cfg.kind == "conv":
             Nw, Cin, kh, kw = weight.shape
-            dwk = ops.conv2d_wgrad(x0, specs[0], dy, x1=x1)
-            dw = packing.wgrad_to_conv(dwk, kh * kw, Cin_packed, Cin, N, kh, kw)
+            dw = None
+            if want_dw:
+                dwk = ops.conv2d_wgrad(x0, specs[0], dy, x1=x1)
+                dw = packing.wgrad_to_conv(dwk, kh * kw, Cin_packed, Cin, N, kh, kw)
             dx = None
             if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                 pad = kh // 2 if cfg.pad is None else cfg.pad            # the dgrad panel sees the padded channel counts
@@ -101,8 +104,10 @@ class ConvFn(torch.autograd.Function):
                         ops.conv2d(dy, s, dx, out_hw=(H // 2, W // 2))
         else:
             Cin, Nw = weight.shape[0], weight.shape[1]
-            dwks = [ops.conv2d_wgrad(x0, s, dy) for s in specs]
-            dw = packing.wgrad_to_conv_transpose(dwks, Cin, N)
+            dw = None
+            if want_dw:
+                dwks = [ops.conv2d_wgrad(x0, s, dy) for s in specs]
+                dw = packing.wgrad_to_conv_transpose(dwks, Cin, N)
             dx = None
             if cfg.need_dx and ctx.needs_input_grad[0]:
                 dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
@@ -163,6 +168,21 @@ class AttnFn(torch.autograd.Function):
         dbv = ops.colsum(dout) if ctx.needs_input_grad[4] else None
         dbk = torch.zeros_like(bk) if ctx.needs_input_grad[3] else None
         return dq, dKs, dVs, dbk, dbv, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) on NHWC (csrc/train_ops.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, dy)
 
 
 def lwb_transform(x, T):

@@ -444,6 +444,21 @@ def unpack_wgrad(dwk, dw, transposed, kidx, cin, cin_pad, nout):
     return dw
 
 
+def maxpool2_fwd(x):
+    """MaxPool2d(2, 2) on (B,H,W,C) NHWC."""
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_maxpool2_fwd_nhwc_f32(_ptr(x), _ptr(y), B, H, W, C, _stream()), "lwg_maxpool2_fwd_nhwc_f32")
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().lwg_maxpool2_bwd_nhwc_f32(_ptr(x), _ptr(dy.contiguous()), _ptr(dx), B, H, W, C, _stream()), "lwg_maxpool2_bwd_nhwc_f32")
+    return dx
+
+
 def colsum(x2d_or_nhwc):
     """Sum over every dimension but the last (bias gradient)."""
     x = x2d_or_nhwc.contiguous()

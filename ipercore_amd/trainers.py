@@ -16,6 +16,9 @@ Data parallelism (BASELINE config 5: one sample per GPU): parameters and gradien
 buffer each (``FlatAdam``); the gradient buffer is averaged in place with a single RCCL all-reduce - large, few
 collectives for point-to-point xGMI instead of DDP's 25 MB buckets - and updated by one fused Adam kernel.  The reference's personalization itself is single-GPU (no collective).
 """
+import math
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -25,7 +28,7 @@ from . import ops
 from .bodynets import SMPLH
 from .flowcomposition import FlowComposition
 from .morphology import morph
-from .networks.training import TrainableGenerator, conv, instance_norm
+from .networks.training import MaxPool2Fn, TrainableGenerator, conv, instance_norm
 
 _RELU = 1
 
@@ -148,6 +151,65 @@ def allreduce_grads(params, group=None):
         off += n
 
 
+class VGG19Features(nn.Module):
+    """criterions/vggloss.py:10-96 (VGG19, before_relu=False): torchvision's ``vgg19().features`` cut after relu1_1, relu2_1,
+    relu3_1, relu4_1, relu5_1 - 13 frozen 3x3 convolutions (+ReLU) and four 2x2 max-pools on the MFMA / HIP kernels.
+    ``state_dict`` keys follow torchvision (``features.{i}.weight``), so ``vgg19-dcbb9e9d.pth`` loads unchanged; without a
+    checkpoint the weights are seeded He-normal (the loss then has the right cost and gradient structure, not the trained metric)."""
+    CFG = ((0, 3, 64), (2, 64, 64), "M", (5, 64, 128), (7, 128, 128), "M", (10, 128, 256), (12, 256, 256), (14, 256, 256), (16, 256, 256), "M",
+           (19, 256, 512), (21, 512, 512), (23, 512, 512), (25, 512, 512), "M", (28, 512, 512))
+    TAPS = (0, 5, 10, 19, 28)                # conv indices whose ReLU output is a loss feature (slice_ids [2, 7, 12, 21, 30])
+
+    def __init__(self, ckpt_path=None, seed=0):
+        super().__init__()
+        self.features = nn.Module()
+        g = torch.Generator().manual_seed(seed)
+        for item in self.CFG:
+            if item == "M":
+                continue
+            idx, cin, cout = item
+            layer = nn.Module()
+            layer.weight = nn.Parameter(torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin)), requires_grad=False)
+            layer.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+            self.features.add_module(str(idx), layer)
+        if ckpt_path and os.path.exists(ckpt_path):
+            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+
+    def forward(self, x_nchw):
+        """(N,3,H,W) in the generator's [-1,1] range (the reference feeds it un-normalised too) -> five NHWC feature maps."""
+        x = F.pad(x_nchw.permute(0, 2, 3, 1), (0, 64 - x_nchw.shape[1])).contiguous()      # 3 -> 64 channels: the data gradient of
+        outs = []                                                                           # the first conv needs N' % 64 == 0
+        for item in self.CFG:
+            if item == "M":
+                x = MaxPool2Fn.apply(x)
+                continue
+            idx = item[0]
+            layer = getattr(self.features, str(idx))
+            x = conv(x, layer.weight, layer.bias, act=1, cin_pad=64 if idx == 0 else None)
+            if idx in self.TAPS:
+                outs.append(x)
+        return outs
+
+
+class VGGLoss(nn.Module):
+    """criterions/vggloss.py:261-292: sum_i w_i * L1(vgg_i(x), vgg_i(y).detach()), inputs resized to 224x224 (bilinear,
+    align_corners=True) as the trainers do (lwg_trainer.py:153-155, resize=True)."""
+    WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+
+    def __init__(self, ckpt_path=None, resize=True):
+        super().__init__()
+        self.vgg, self.resize = VGG19Features(ckpt_path), resize
+
+    def forward(self, x, y):
+        if self.resize:
+            x = F.interpolate(x, size=(224, 224), mode="bilinear", align_corners=True)
+            y = F.interpolate(y, size=(224, 224), mode="bilinear", align_corners=True)
+        with torch.no_grad():
+            fy = self.vgg(y)
+        fx = self.vgg(x)
+        return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, fx, fy))
+
+
 class TrainOpts(object):
     """deploy.toml:76-102 defaults (use_vgg / use_face off: their checkpoints are not available offline)."""
     lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
@@ -156,6 +218,10 @@ class TrainOpts(object):
     # "split": forward and data-gradient convs with Cin % 32 == 0 run on the bf16x6 kernel (fp32-level accuracy);
     # weight gradients stay on the fp32 MFMA kernel
     conv_precision = "fp32"
+    # "VGG19": the transfer loss is the VGG19 perceptual loss (deploy.toml:83, the reference's default) instead of L1;
+    # vgg_loss_path: torchvision vgg19 state_dict (used when the file exists, seeded weights otherwise)
+    use_vgg = "None"
+    vgg_loss_path = "./assets/checkpoints/losses/vgg19-dcbb9e9d.pth"
 
 
 class FlowCompositionForTrainer(FlowComposition):
@@ -236,6 +302,11 @@ class LWGTrainer(object):
         self.optimizer_G = FlatAdam(G, lr=o.lr_G, betas=(o.G_adam_b1, o.G_adam_b2))
         self.optimizer_D = None if D is None else FlatAdam(D, lr=o.lr_D, betas=(o.D_adam_b1, o.D_adam_b2))
         self.losses = {}
+        self.crt_tsf = None
+        if o.use_vgg == "VGG19":
+            self.crt_tsf = VGGLoss(ckpt_path=o.vgg_loss_path).to(next(G.parameters()).device)
+        elif o.use_vgg not in ("None", None, False):
+            raise NotImplementedError(f"use_vgg = {o.use_vgg}: only VGG19 (the reference's default) is built")
 
     def set_input(self, inputs, device=None, flow_comp=None, ns=None):
         """lwg_trainer.py:624-697.  ``inputs`` is either the dataset sample of the reference (``PersonalizedDataset.__getitem__``,
@@ -285,7 +356,7 @@ class LWGTrainer(object):
             tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
             loss_adv = lsgan_loss(self.D(torch.cat([fake_tsf, tsf_cond], dim=1)), 0) * o.lambda_D_prob
         loss_rec = (F.l1_loss(fake_src_imgs, i["real_src"]) + F.l1_loss(fake_bg.view(-1, 3, h, w), i["real_bg"])) / 2 * o.lambda_rec
-        loss_tsf = F.l1_loss(fake_tsf, real_tsf) * o.lambda_tsf
+        loss_tsf = (F.l1_loss(fake_tsf, real_tsf) if self.crt_tsf is None else self.crt_tsf(fake_tsf, real_tsf)) * o.lambda_tsf
         fm = fake_masks.view(-1, 1, h, w)
         loss_mask = F.binary_cross_entropy(fm, i["body_mask"].view(-1, 1, h, w)) * o.lambda_mask
         loss_smooth = tv_loss(fm) * o.lambda_mask_smooth

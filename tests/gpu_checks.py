@@ -647,6 +647,83 @@ def check_reference_shape_tests():
     return {"patch_map": list(outs[0].shape)}
 
 
+def check_vgg_loss():
+    """VGG19 perceptual loss (criterions/vggloss.py:10-96,261-292; the reference's default transfer loss, deploy.toml:83) on the
+    MFMA conv kernels + lwg_maxpool2_*: loss value and gradient w.r.t. the fake image against torch autograd on the CPU through
+    the same network written with F.conv2d / F.max_pool2d; then one trainer step with use_vgg = "VGG19"."""
+    from ipercore_amd.networks import NetworksFactory
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts, VGGLoss
+    crt = VGGLoss(ckpt_path=None).to(DEV)
+    x, y = _rand((2, 3, 96, 96), 990, 0.5), _rand((2, 3, 96, 96), 991, 0.5)
+    sd = {k: v.detach().cpu() for k, v in crt.vgg.state_dict().items()}
+
+    def ref_feats(t):
+        outs = []
+        for item in crt.vgg.CFG:
+            if item == "M":
+                t = F.max_pool2d(t, 2, 2)
+                continue
+            t = F.relu(F.conv2d(t, sd[f"features.{item[0]}.weight"], sd[f"features.{item[0]}.bias"], padding=1))
+            if item[0] in crt.vgg.TAPS:
+                outs.append(t)
+        return outs
+
+    rs = lambda t: F.interpolate(t, size=(224, 224), mode="bilinear", align_corners=True)      # noqa: E731
+    with torch.no_grad():
+        fy = ref_feats(rs(y))
+        loss_ref = sum(w * F.l1_loss(a, b) for w, a, b in zip(crt.WEIGHTS, ref_feats(rs(x)), fy))
+        loss = crt(x.to(DEV), y.to(DEV))
+    out = {"loss": loss.item(), "loss_ref": loss_ref.item()}
+    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * abs(loss_ref.item()), out
+    # gradient through the network: a smooth surrogate (weighted MSE of the five feature maps) at 64x64 - the L1 of the real loss
+    # has a sign(), and every ReLU whose pre-activation lands within rounding of zero flips between two fp32 implementations and
+    # moves its whole receptive field; at 224x224 (13 ReLU layers, ~1e7 activations) a few such flips are certain, so the
+    # comparison is made where they are improbable and still tolerates a 0.2 % outlier fraction
+    xs, ys = _rand((2, 3, 64, 64), 992, 0.5), _rand((2, 3, 64, 64), 993, 0.5)
+    with torch.no_grad():
+        fys = ref_feats(ys)
+        fyd = crt.vgg(ys.to(DEV))
+    xr = xs.clone().requires_grad_(True)
+    sum(w * F.mse_loss(a, b) for w, a, b in zip(crt.WEIGHTS, ref_feats(xr), fys)).backward()
+    xd = xs.to(DEV).requires_grad_(True)
+    sum(w * F.mse_loss(a, b) for w, a, b in zip(crt.WEIGHTS, crt.vgg(xd), fyd)).backward()
+    torch.cuda.synchronize()
+    gerr = (xd.grad.cpu() - xr.grad).abs() / xr.grad.abs().max().item()
+    out["grad_rel_err_median"], out["grad_outlier_frac"] = gerr.median().item(), (gerr > 5e-4).float().mean().item()
+    assert out["grad_outlier_frac"] <= 2e-3, out
+    # and the real loss is differentiable end to end
+    xd2 = x.to(DEV).requires_grad_(True)
+    crt(xd2, y.to(DEV)).backward()
+    assert torch.isfinite(xd2.grad).all() and xd2.grad.abs().max().item() > 0
+    # maxpool tie rule (first maximum in scan order) and plain values
+    from ipercore_amd.networks.training import MaxPool2Fn
+    t = torch.zeros(1, 4, 4, 4)
+    t[0, :2, :2, :] = 1.0                                      # a 4-way tie in window (0, 0)
+    t[0, 2, 3, 1] = 2.0
+    tr_ = t.clone().permute(0, 3, 1, 2).requires_grad_(True)
+    F.max_pool2d(tr_, 2, 2).sum().backward()
+    td = t.to(DEV).requires_grad_(True)
+    MaxPool2Fn.apply(td).sum().backward()
+    assert torch.equal(td.grad.cpu(), tr_.grad.permute(0, 2, 3, 1)), "maxpool backward tie rule"
+    # one trainer step with the perceptual loss
+    S, nf, nres, bgf, ns = 64, [64, 64, 128], 2, [64, 64, 128], 2
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).to(DEV).train()
+    topts = TrainOpts()
+    topts.use_vgg = "VGG19"
+    tr = LWGTrainer(G, PatchGlobalDiscriminator().to(DEV), opts=topts)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    U = lambda shp, sd_, nm: torch.tensor(synthetic.uniform_image(shp, sd_, nm), device=DEV)     # noqa: E731
+    tr.set_input({"input_G_bg": U((1, 1, 4, S, S), 10, "bg_inputs"), "input_G_src": U((1, ns, 6, S, S), 8, "src_inputs"),
+                  "input_G_tsf": U((1, 1, 6, S, S), 9, "tsf_inputs"), "Tst": torch.tensor(g["render/Tst"], device=DEV).view(1, 1, ns, S, S, 2),
+                  "real_src": U((1, ns, 3, S, S), 500, "tgt"), "real_tsf": U((1, 1, 3, S, S), 501, "tgt"), "real_bg": U((1, 3, S, S), 502, "tgt"),
+                  "body_mask": (U((1, ns + 1, 1, S, S), 503, "tgt") > 0).float()})
+    lg, ld = tr.optimize_parameters()
+    torch.cuda.synchronize()
+    out["trainer_loss_G"] = float(lg)
+    assert np.isfinite(float(lg)) and np.isfinite(float(ld)) and float(tr.losses["g_tsf"]) > 0
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1105,4 +1182,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss]
