@@ -720,7 +720,7 @@ def check_vgg_loss():
     lg, ld = tr.optimize_parameters()
     torch.cuda.synchronize()
     out["trainer_loss_G"] = float(lg)
-    assert np.isfinite(float(lg)) and np.isfinite(float(ld)) and float(tr.losses["g_tsf"]) > 0
+    assert np.isfinite(float(lg)) and np.isfinite(float(ld)) and float(tr.losses["g_tsf"].detach()) > 0
     return out
 
 
