@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--use-vgg", action="store_true", help="VGG19 perceptual transfer loss (deploy.toml:83; seeded weights when "
                                                           "vgg19-dcbb9e9d.pth is absent) instead of L1")
+    ap.add_argument("--use-face", action="store_true", help="SphereFace (Sphere20a) loss on the head crop (deploy.toml:77-79)")
     ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
                     help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
     args = ap.parse_args()
@@ -73,12 +74,14 @@ def main():
            "input_G_src": torch.cat([torch.tensor(case.src_img, device=dev)[0], cond], dim=1).unsqueeze(0),
            "input_G_tsf": ops.nhwc_to_nchw(tsf8, channels=6).unsqueeze(0), "Tst": Tst.unsqueeze(1).contiguous(),
            "real_src": torch.tensor(case.src_img, device=dev), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
-           "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
+           "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float(),
+           "head_bbox": torch.tensor([[S * 3 // 8, S * 5 // 8, S // 16, S * 5 // 16]])}        # a head-sized box (min_x, max_x, min_y, max_y)
     del im
     from ipercore_amd.trainers import TrainOpts
     topts = TrainOpts()
     topts.conv_precision = args.precision
     topts.use_vgg = "VGG19" if args.use_vgg else "None"
+    topts.use_face = bool(args.use_face)
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
 
@@ -121,7 +124,7 @@ def main():
             "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(args.steps * world / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "dtype": "f32" if args.precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
-            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if args.use_vgg else "L1") + " tsf + BCE mask + TV",
+            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if args.use_vgg else "L1") + " tsf" + (" + Sphere20a face" if args.use_face else "") + " + BCE mask + TV",
                        "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
                                       f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},
             "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(per_step / (dt / args.steps) / 1e12, 2),

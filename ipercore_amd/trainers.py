@@ -210,6 +210,79 @@ class VGGLoss(nn.Module):
         return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, fx, fy))
 
 
+class Sphere20aFeatures(nn.Module):
+    """criterions/faceloss.py:203-285 (Sphere20a): 20 frozen 3x3 convolutions (four of them stride 2) with per-channel PReLU and
+    residual adds, then fc5; parameter names as in ``sphere20a_20171020.pth`` (conv{b}_{i}, relu{b}_{i}, fc5) so the checkpoint
+    loads when present (strict=False: its fc6 classifier head is not part of the loss).  The convolutions run on the MFMA kernels
+    (data gradient only: the network is frozen); PReLU / residual adds / fc5 are PyTorch-ROCm autograd + one library GEMM."""
+    BLOCKS = ((1, 3, 64, 3), (2, 64, 128, 5), (3, 128, 256, 9), (4, 256, 512, 3))          # (block, cin, cout, number of convs)
+
+    def __init__(self, ckpt_path=None, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        for b, cin, cout, n in self.BLOCKS:
+            for i in range(1, n + 1):
+                ci = cin if i == 1 else cout
+                conv_ = nn.Module()
+                conv_.weight = nn.Parameter(torch.randn(cout, ci, 3, 3, generator=g) * math.sqrt(2.0 / (9 * ci)), requires_grad=False)
+                conv_.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+                self.add_module(f"conv{b}_{i}", conv_)
+                act = nn.Module()
+                act.weight = nn.Parameter(torch.full((cout,), 0.25), requires_grad=False)
+                self.add_module(f"relu{b}_{i}", act)
+        self.fc5 = nn.Module()
+        self.fc5.weight = nn.Parameter(torch.randn(512, 512 * 7 * 6, generator=g) * math.sqrt(1.0 / (512 * 7 * 6)), requires_grad=False)
+        self.fc5.bias = nn.Parameter(torch.zeros(512), requires_grad=False)
+        if ckpt_path and os.path.exists(ckpt_path):
+            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+
+    def _cp(self, b, i, x, stride=1, first=False):
+        c, a = getattr(self, f"conv{b}_{i}"), getattr(self, f"relu{b}_{i}")
+        y = conv(x, c.weight, c.bias, stride=stride, cin_pad=64 if first else None)
+        return torch.where(y >= 0, y, y * a.weight)                                      # nn.PReLU(C) on NHWC
+
+    def forward(self, x_nchw):
+        """(N,3,112,96) -> [block1 (N,56,48,64), block2 (N,28,24,128), block3 (N,14,12,256), block4 (N,7,6,512), fc5 (N,512)]."""
+        x = F.pad(x_nchw.permute(0, 2, 3, 1), (0, 64 - x_nchw.shape[1])).contiguous()
+        outs = []
+        for b, cin, cout, n in self.BLOCKS:
+            x = self._cp(b, 1, x, stride=2, first=b == 1)
+            for i in range(2, n + 1, 2):
+                x = x + self._cp(b, i + 1, self._cp(b, i, x))
+            outs.append(x)
+        outs.append(F.linear(x.permute(0, 3, 1, 2).reshape(x.shape[0], -1), self.fc5.weight, self.fc5.bias))
+        return outs
+
+
+class FaceLoss(nn.Module):
+    """criterions/faceloss.py:288-406 (Sphere20a branch): heads cropped by bounding box, resized to 112x96 (bilinear,
+    align_corners=True), weighted L1 between the five Sphere20a features; the second argument is the target (detached)."""
+    WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+    HEIGHT, WIDTH = 112, 96
+
+    def __init__(self, pretrained_path=None):
+        super().__init__()
+        self.net = Sphere20aFeatures(pretrained_path)
+
+    def crop_head_bbox(self, imgs, bboxs):
+        """:384-406; bboxs (N,4) = [min_x, max_x, min_y, max_y] (a host read of N*4 integers per step, as in the reference)."""
+        heads = []
+        for i, (x0, x1, y0, y1) in enumerate(bboxs.tolist()):
+            if x0 != x1 and y0 != y1:
+                heads.append(F.interpolate(imgs[i:i + 1, :, y0:y1, x0:x1], size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True))
+        return torch.cat(heads, dim=0) if heads else None
+
+    def forward(self, imgs1, imgs2, bbox1=None, bbox2=None):
+        h1 = self.crop_head_bbox(imgs1, bbox1) if bbox1 is not None else F.interpolate(imgs1, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
+        h2 = self.crop_head_bbox(imgs2, bbox2) if bbox2 is not None else F.interpolate(imgs2, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
+        if h1 is None or h2 is None:
+            return imgs1.new_zeros(())
+        with torch.no_grad():
+            f2 = self.net(h2)
+        f1 = self.net(h1)
+        return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, f1, f2))
+
+
 class TrainOpts(object):
     """deploy.toml:76-102 defaults (use_vgg / use_face off: their checkpoints are not available offline)."""
     lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
@@ -222,6 +295,10 @@ class TrainOpts(object):
     # vgg_loss_path: torchvision vgg19 state_dict (used when the file exists, seeded weights otherwise)
     use_vgg = "None"
     vgg_loss_path = "./assets/checkpoints/losses/vgg19-dcbb9e9d.pth"
+    # the SphereFace (Sphere20a) loss on the head crop of the transferred image (deploy.toml:77-79, lambda_face :87)
+    use_face = False
+    face_loss_path = "./assets/checkpoints/losses/sphere20a_20171020.pth"
+    lambda_face = 5.0
 
 
 class FlowCompositionForTrainer(FlowComposition):
@@ -307,6 +384,7 @@ class LWGTrainer(object):
             self.crt_tsf = VGGLoss(ckpt_path=o.vgg_loss_path).to(next(G.parameters()).device)
         elif o.use_vgg not in ("None", None, False):
             raise NotImplementedError(f"use_vgg = {o.use_vgg}: only VGG19 (the reference's default) is built")
+        self.crt_face = FaceLoss(o.face_loss_path).to(next(G.parameters()).device) if o.use_face else None
 
     def set_input(self, inputs, device=None, flow_comp=None, ns=None):
         """lwg_trainer.py:624-697.  ``inputs`` is either the dataset sample of the reference (``PersonalizedDataset.__getitem__``,
@@ -357,11 +435,14 @@ class LWGTrainer(object):
             loss_adv = lsgan_loss(self.D(torch.cat([fake_tsf, tsf_cond], dim=1)), 0) * o.lambda_D_prob
         loss_rec = (F.l1_loss(fake_src_imgs, i["real_src"]) + F.l1_loss(fake_bg.view(-1, 3, h, w), i["real_bg"])) / 2 * o.lambda_rec
         loss_tsf = (F.l1_loss(fake_tsf, real_tsf) if self.crt_tsf is None else self.crt_tsf(fake_tsf, real_tsf)) * o.lambda_tsf
+        loss_face = 0.0
+        if self.crt_face is not None:                                     # :775-779
+            loss_face = self.crt_face(fake_tsf, real_tsf, bbox1=i["head_bbox"], bbox2=i["head_bbox"]) * o.lambda_face
         fm = fake_masks.view(-1, 1, h, w)
         loss_mask = F.binary_cross_entropy(fm, i["body_mask"].view(-1, 1, h, w)) * o.lambda_mask
         loss_smooth = tv_loss(fm) * o.lambda_mask_smooth
-        self.losses.update(g_rec=loss_rec, g_tsf=loss_tsf, g_adv=loss_adv, g_mask=loss_mask, g_mask_smooth=loss_smooth)
-        return loss_rec + loss_tsf + loss_adv + loss_mask + loss_smooth
+        self.losses.update(g_rec=loss_rec, g_tsf=loss_tsf, g_face=loss_face, g_adv=loss_adv, g_mask=loss_mask, g_mask_smooth=loss_smooth)
+        return loss_rec + loss_tsf + loss_face + loss_adv + loss_mask + loss_smooth
 
     def optimize_D(self, fake_tsf_imgs):
         """:791-832."""

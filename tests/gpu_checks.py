@@ -724,6 +724,91 @@ def check_vgg_loss():
     return out
 
 
+def _face_state_dict():
+    """tests/golden/make_golden_faceloss.py::face_state_dict."""
+    from ipercore_amd.trainers import Sphere20aFeatures
+    shapes = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None).state_dict().items()}
+    sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=13).items()}
+    for k in sd:
+        if k.startswith("relu"):
+            sd[k] = 0.25 + 0.1 * sd[k]
+    return sd
+
+
+def check_face_loss():
+    """SphereFace loss (criterions/faceloss.py:203-406, the reference's default use_face = true): the five Sphere20a features and
+    the loss value on the GPU against outputs of the REFERENCE's own Sphere20a (tests/golden/golden_faceloss_v1.npz), the head
+    crop by bounding box, the gradient w.r.t. the fake image against torch autograd on the CPU, and a trainer step with it."""
+    from ipercore_amd.networks import NetworksFactory
+    from ipercore_amd.trainers import FaceLoss, LWGTrainer, PatchGlobalDiscriminator, TrainOpts
+    gf = np.load(os.path.join(ROOT, "tests", "golden", "golden_faceloss_v1.npz"))
+    crt = FaceLoss(None)
+    sd = _face_state_dict()
+    crt.net.load_state_dict(sd, strict=True)
+    crt.to(DEV)
+    x = torch.tensor(synthetic.uniform_image((2, 3, 112, 96), 70, "face_x"))
+    y = torch.tensor(synthetic.uniform_image((2, 3, 112, 96), 71, "face_y"))
+    out = {}
+    with torch.no_grad():
+        fx = crt.net(x.to(DEV))
+        loss = crt(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    for i, f in enumerate(fx):
+        got = f.permute(0, 3, 1, 2)[:, ::8] if f.dim() == 4 else f
+        out[f"fx{i}"] = _cmp(got, torch.tensor(gf[f"fx{i}"]), 2e-4, f"sphere20a feature {i}")
+    out["loss"], out["loss_ref"] = loss.item(), float(gf["loss"])
+    assert abs(out["loss"] - out["loss_ref"]) <= 2e-4 * abs(out["loss_ref"]), out
+
+    def ref_feats(t):                                        # the same network with torch ops on the CPU (autograd reference)
+        outs = []
+        cp = lambda b, i, v, st=1: F.prelu(F.conv2d(v, sd[f"conv{b}_{i}.weight"], sd[f"conv{b}_{i}.bias"], stride=st, padding=1), sd[f"relu{b}_{i}.weight"])   # noqa: E731
+        for b, _, _, n in crt.net.BLOCKS:
+            t = cp(b, 1, t, 2)
+            for i in range(2, n + 1, 2):
+                t = t + cp(b, i + 1, cp(b, i, t))
+            outs.append(t)
+        outs.append(F.linear(t.reshape(t.shape[0], -1), sd["fc5.weight"], sd["fc5.bias"]))
+        return outs
+
+    xr = x.clone().requires_grad_(True)
+    with torch.no_grad():
+        fyr = ref_feats(y)
+        fyd = crt.net(y.to(DEV))
+    sum(w * F.mse_loss(a, b) for w, a, b in zip(crt.WEIGHTS, ref_feats(xr), fyr)).backward()
+    xd = x.to(DEV).requires_grad_(True)
+    fd = crt.net(xd)
+    fd = [f.permute(0, 3, 1, 2) if f.dim() == 4 else f for f in fd]
+    fyd = [f.permute(0, 3, 1, 2) if f.dim() == 4 else f for f in fyd]
+    sum(w * F.mse_loss(a, b) for w, a, b in zip(crt.WEIGHTS, fd, fyd)).backward()
+    torch.cuda.synchronize()
+    gerr = (xd.grad.cpu() - xr.grad).abs() / xr.grad.abs().max().item()
+    out["grad_rel_err_median"], out["grad_outlier_frac"] = gerr.median().item(), (gerr > 5e-4).float().mean().item()
+    assert out["grad_outlier_frac"] <= 2e-3, out
+    # head crop + a degenerate box (skipped, as the reference does)
+    imgs = _rand((2, 3, 128, 128), 995, 0.5).to(DEV)
+    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10]])
+    heads = crt.crop_head_bbox(imgs, box)
+    want = F.interpolate(imgs[0:1, :, 10:90, 20:84], size=(112, 96), mode="bilinear", align_corners=True)
+    assert heads.shape == (1, 3, 112, 96) and torch.equal(heads, want)
+    # trainer step with both perceptual losses
+    S, nf, nres, bgf, ns = 64, [64, 64, 128], 2, [64, 64, 128], 2
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).to(DEV).train()
+    topts = TrainOpts()
+    topts.use_vgg, topts.use_face = "VGG19", True
+    tr = LWGTrainer(G, PatchGlobalDiscriminator().to(DEV), opts=topts)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    U = lambda shp, sd_, nm: torch.tensor(synthetic.uniform_image(shp, sd_, nm), device=DEV)     # noqa: E731
+    tr.set_input({"input_G_bg": U((1, 1, 4, S, S), 10, "bg_inputs"), "input_G_src": U((1, ns, 6, S, S), 8, "src_inputs"),
+                  "input_G_tsf": U((1, 1, 6, S, S), 9, "tsf_inputs"), "Tst": torch.tensor(g["render/Tst"], device=DEV).view(1, 1, ns, S, S, 2),
+                  "real_src": U((1, ns, 3, S, S), 500, "tgt"), "real_tsf": U((1, 1, 3, S, S), 501, "tgt"), "real_bg": U((1, 3, S, S), 502, "tgt"),
+                  "body_mask": (U((1, ns + 1, 1, S, S), 503, "tgt") > 0).float(), "head_bbox": torch.tensor([[16, 48, 4, 40]])})
+    lg, ld = tr.optimize_parameters()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(lg)) and float(tr.losses["g_face"].detach()) > 0
+    out["trainer_g_face"] = float(tr.losses["g_face"].detach())
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1182,4 +1267,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss]

@@ -190,6 +190,19 @@ def test_swapper_pieces_match_reference(topo):
         assert np.abs(Tst.numpy() - gs[f"{tag}/Tst"][0]).max() <= 1e-5
 
 
+def test_loss_network_parameter_inventories():
+    """The frozen loss networks keep the parameter names of the checkpoints the reference loads: Sphere20a
+    (criterions/faceloss.py:203-257, pinned by the golden generated from the reference class itself: the state_dict loaded there
+    with strict=True) and torchvision's VGG19 ``features.{i}`` indices (criterions/vggloss.py:12-40)."""
+    from ipercore_amd.trainers import Sphere20aFeatures, VGG19Features
+    sp = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None).state_dict().items()}
+    assert len(sp) == 62 and sp["conv1_1.weight"] == (64, 3, 3, 3) and sp["relu4_3.weight"] == (512,) and sp["fc5.weight"] == (512, 512 * 7 * 6)
+    assert sum(1 for k in sp if k.startswith("conv") and k.endswith(".weight")) == 20
+    vg = {k: tuple(v.shape) for k, v in VGG19Features(None).state_dict().items()}
+    assert sorted(int(k.split(".")[1]) for k in vg if k.endswith(".weight")) == [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28]
+    assert vg["features.0.weight"] == (64, 3, 3, 3) and vg["features.28.weight"] == (512, 512, 3, 3)
+
+
 def test_identity_warp_property(topo):
     """T = cal_bc_transform(f2pts, fim, wim) reproduces the grid_sample coordinate of each
     covered pixel - the property the reference relies on when it uses T as a sampling grid."""
