@@ -121,3 +121,50 @@ class SMPLH(nn.Module):
                                      cam=cam.contiguous())
         return {"theta": theta, "cam": cam, "pose": pose, "shape": shape, "verts": verts, "j2d": self._last_j2d,
                 "j3d": j3d}
+
+
+class SMPL(SMPLH):
+    """The 24-joint SMPL of the reference's trainers (bodynets/batch_smpl.py:283-436, used by FlowCompositionForTrainer,
+    tools/trainers/base.py:95-97): same linear blend skinning kernel with nj = 24, theta = 72 axis-angle values, and the 19
+    COCO+ keypoints regressed from the POSED vertices (``cocoplus_regressor``) as ``j3d`` / ``j2d``.
+    Rotations: the reference builds them with Rodrigues' formula on theta / norm(theta + 1e-8) (batch_smpl.py:73-109); the LBS
+    kernel goes through the quaternion of the same axis / angle (the SMPL-H route) - equal up to fp32 rounding (checked against
+    the reference class to 1e-5 on the vertices)."""
+    NUM_JOINTS = 24
+
+    def __init__(self, model_path, rotate=False, **kwargs):
+        nn.Module.__init__(self)
+        if rotate:
+            raise NotImplementedError("rotate_base (batch_smpl.py:174-187) is not used by the trainers")
+        if isinstance(model_path, dict):
+            data = model_path
+        else:
+            with open(model_path, "rb") as fp:
+                data = pickle.load(fp, encoding="latin1")
+        f32 = lambda a: torch.tensor(np.ascontiguousarray(_dense(a), dtype=np.float32))    # noqa: E731
+        self.use_pca = False
+        self.faces = _dense(data["f"])
+        self.register_buffer("faces_tensor", torch.tensor(self.faces.astype(np.int64)))
+        self.register_buffer("v_template", f32(data["v_template"]))
+        self.register_buffer("shapedirs", f32(data["shapedirs"])[:, :, :10].contiguous())
+        pd = _dense(data["posedirs"])
+        self.register_buffer("posedirs", f32(np.reshape(pd, [-1, pd.shape[-1]]).T))
+        self.register_buffer("J_regressor", f32(data["J_regressor"]))
+        parents = torch.tensor(_dense(data["kintree_table"])[0].astype(np.int64))
+        parents[0] = -1
+        self.register_buffer("parents", parents)
+        self.register_buffer("parents_i32", parents.to(torch.int32))
+        self.register_buffer("lbs_weights", f32(data["weights"]))
+        self.register_buffer("joint_regressor", f32(data["cocoplus_regressor"]).t().contiguous())      # (6890, 19)
+
+    def _full_pose(self, theta):
+        assert theta.shape[1] == 72, "SMPL takes 24 x 3 axis-angle values (quaternion / 6-D / matrix inputs are not built)"
+        return theta.contiguous()
+
+    @torch.no_grad()
+    def forward(self, beta, theta, offsets=0, links_ids=None, get_skin=False, cam=None):
+        """batch_smpl.py:332-436 -> (verts (B,6890,3), COCO+ joints (B,19,3), theta)."""
+        verts, _, full_pose = super().forward(beta, theta, offsets=offsets, links_ids=links_ids, get_skin=True, cam=None)
+        joints = torch.einsum("bvc,vj->bjc", verts, self.joint_regressor)          # library GEMM: 19 keypoints from the posed mesh
+        self._last_j2d = None if cam is None else cam[:, None, 0:1] * (joints[:, :, :2] + cam[:, None, 1:3])     # base_smpl.py:7-18
+        return verts, joints, full_pose

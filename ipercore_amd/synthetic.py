@@ -54,6 +54,39 @@ def smplh_model_dict(seed=0, topo=None):
     }
 
 
+def smpl_model_dict(seed=0, topo=None, sparse=False):
+    """A synthetic 24-joint SMPL parameter dict with the pickle schema bodynets/batch_smpl.py:283-330 reads (incl. the 19-point
+    ``cocoplus_regressor``); ``sparse``: J_regressor / cocoplus_regressor as scipy CSC matrices, as in smpl_model.pkl."""
+    topo = topo or mesh.load_topology()
+    nj = 24
+    parents = np.zeros(nj, dtype=np.int64)
+    r = _rs(seed, "smpl24/parents")
+    for j in range(1, nj):
+        parents[j] = r.randint(max(0, j - 4), j)
+    kintree = np.stack([parents, np.arange(nj, dtype=np.int64)], axis=0)
+    kintree[0, 0] = 4294967295 % (2 ** 31)
+    J = _softmax(_rs(seed, "smpl24/J_regressor").standard_normal((nj, NUM_VERTS)), axis=1)
+    coco = _softmax(_rs(seed, "smpl24/cocoplus").standard_normal((19, NUM_VERTS)), axis=1)
+    if sparse:
+        import scipy.sparse as sp
+        J, coco = sp.csc_matrix(J), sp.csc_matrix(coco)
+    return {
+        "v_template": topo["v"].astype(np.float64),
+        "shapedirs": (0.01 * _rs(seed, "smpl24/shapedirs").standard_normal((NUM_VERTS, 3, 10))),
+        "posedirs": (0.001 * _rs(seed, "smpl24/posedirs").standard_normal((NUM_VERTS, 3, (nj - 1) * 9))),
+        "J_regressor": J, "cocoplus_regressor": coco,
+        "weights": _softmax(_rs(seed, "smpl24/weights").standard_normal((NUM_VERTS, nj)), axis=1),
+        "kintree_table": kintree,
+        "f": topo["faces_uv"].astype(np.uint32),
+    }
+
+
+def write_smpl_pickle(path, seed=0):
+    with open(path, "wb") as fp:
+        pickle.dump(smpl_model_dict(seed, sparse=True), fp, protocol=2)
+    return path
+
+
 def write_smplh_pickle(path, seed=0):
     with open(path, "wb") as fp:
         pickle.dump(smplh_model_dict(seed), fp, protocol=2)

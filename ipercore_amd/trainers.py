@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .bodynets import SMPLH
+from .bodynets import SMPL, SMPLH
 from .flowcomposition import FlowComposition
 from .morphology import morph
 from .networks.training import MaxPool2Fn, TrainableGenerator, conv, instance_norm
@@ -304,13 +304,16 @@ class TrainOpts(object):
 class FlowCompositionForTrainer(FlowComposition):
     """tools/trainers/base.py:90-141: the per-sample input stage of the trainers - body model, renders, the once-per-source
     image stage, target conditions and the (bs, nt, ns) flows - on the same HIP kernels the runner uses.
-    ``body_model``: any model with ``get_details`` (the runner's SMPL-H is the default; the reference's trainers use the older
-    24-joint SMPL, bodynets/batch_smpl.py:283-436, which is not built - the LBS kernel itself is generic in the joint count)."""
+    ``body_model``: any model with ``get_details``; default: the trainers' 24-joint ``SMPL`` (bodynets/batch_smpl.py:283-436)
+    when ``opt.smpl_model`` exists, else the runner's SMPL-H (``opt.smpl_model_hand``)."""
 
     def __init__(self, opt, body_model=None):
         super().__init__(opt)
         g = lambda k, d=None: getattr(opt, k, d) if not isinstance(opt, dict) else opt.get(k, d)    # noqa: E731
-        self.smpl = body_model if body_model is not None else SMPLH(model_path=g("smpl_model_hand"))
+        if body_model is None:
+            p24 = g("smpl_model")
+            body_model = SMPL(model_path=p24) if (p24 is not None and (isinstance(p24, dict) or os.path.exists(p24))) else SMPLH(model_path=g("smpl_model_hand"))
+        self.smpl = body_model
         self.ft_ks = int(g("ft_ks", 1))                      # deploy.toml:12
         self.share_bg = bool(g("share_bg", True))
 

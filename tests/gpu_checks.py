@@ -809,6 +809,31 @@ def check_face_loss():
     return out
 
 
+def check_smpl24():
+    """bodynets.SMPL (the trainers' 24-joint body model, reference bodynets/batch_smpl.py:283-436) on the LBS kernel with
+    nj = 24 against outputs of the REFERENCE's own class (golden_smpl24_v1.npz) and the oracle, incl. offsets and links."""
+    from oracle import lwg_oracle as orc
+    from ipercore_amd.bodynets import SMPL
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_smpl24_v1.npz"))
+    model = synthetic.smpl_model_dict(seed=0)
+    net = SMPL(model).to(DEV)
+    smpls = torch.tensor(synthetic.smpl_sequence(3, seed=80, pose_dim=72), device=DEV)
+    offsets = torch.tensor(0.002 * synthetic.uniform_image((6890, 3), 81, "offsets"), device=DEV)
+    d = net.get_details(smpls, offsets)
+    torch.cuda.synchronize()
+    out = {"verts_vs_reference": _cmp(d["verts"][:, ::10], torch.tensor(g["verts_sub"]), 1e-5, "SMPL-24 verts"),
+           "j3d_vs_reference": _cmp(d["j3d"], torch.tensor(g["j3d"]), 1e-5, "COCO+ joints"),
+           "j2d_vs_reference": _cmp(d["j2d"], torch.tensor(g["j2d"]), 1e-5, "COCO+ 2-D")}
+    o = orc.smpl24_get_details(model, smpls.cpu().numpy(), offsets.cpu())
+    out["verts_vs_oracle"] = _cmp(d["verts"], o["verts"], 1e-5, "SMPL-24 verts (all)")
+    links = np.stack([np.arange(10, 20), np.arange(100, 110)], axis=1)
+    dl = net.get_details(smpls, offsets, links_ids=links)
+    want = o["verts"].clone()
+    want[:, links[:, 0]] = o["verts"][:, links[:, 1]]
+    out["links"] = _cmp(dl["verts"], want, 1e-5, "links")
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1267,4 +1292,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24]

@@ -190,6 +190,17 @@ def test_swapper_pieces_match_reference(topo):
         assert np.abs(Tst.numpy() - gs[f"{tag}/Tst"][0]).max() <= 1e-5
 
 
+def test_smpl24_matches_reference():
+    """The oracle's 24-joint SMPL (trainers' body model) against the reference's own SMPL.get_details
+    (tests/golden/make_golden_smpl24.py): vertices, the 19 COCO+ joints and their projection."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_smpl24_v1.npz"))
+    smpls = synthetic.smpl_sequence(3, seed=80, pose_dim=72)
+    offsets = torch.tensor(0.002 * synthetic.uniform_image((6890, 3), 81, "offsets"))
+    d = orc.smpl24_get_details(synthetic.smpl_model_dict(seed=0), smpls, offsets)
+    assert np.abs(d["verts"].numpy()[:, ::10] - g["verts_sub"]).max() <= 2e-6
+    assert np.abs(d["j3d"].numpy() - g["j3d"]).max() <= 2e-6 and np.abs(d["j2d"].numpy() - g["j2d"]).max() <= 2e-6
+
+
 def test_loss_network_parameter_inventories():
     """The frozen loss networks keep the parameter names of the checkpoints the reference loads: Sphere20a
     (criterions/faceloss.py:203-257, pinned by the golden generated from the reference class itself: the state_dict loaded there
