@@ -124,10 +124,63 @@ class FlatAdam(object):
             if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
                 raise RuntimeError("a parameter's .grad was replaced; call zero_grad() of FlatAdam only")
 
+    # ---- data-parallel exchange, overlapped with backward ---------------------------------------------------------------
+    def arm(self, group=None, n_buckets=4):
+        """Call before the backward whose gradients this optimizer will apply.  The flat gradient buffer is cut into
+        ``n_buckets`` contiguous ranges (a few large collectives: xGMI rings are per-link bound, so 145 MB of G gradients go
+        out as ~36 MB pieces, not DDP's 25 MB x many); a post-accumulate hook per parameter counts the range down and hands it to
+        an ``async_op`` all-reduce the moment its last gradient has been accumulated - the exchange of the late layers runs
+        on RCCL's stream while backward is still computing the early ones.  ``allreduce()`` afterwards only finishes the job."""
+        self._works, self._issued = [], set()
+        self._group = group
+        self._armed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if not self._armed:
+            return
+        if not hasattr(self, "_bucket_of"):
+            total = self.grad.numel()
+            bounds = [(total * b // n_buckets) // 4 * 4 for b in range(n_buckets)] + [total]
+            self._ranges = [(bounds[b], bounds[b + 1]) for b in range(n_buckets) if bounds[b + 1] > bounds[b]]
+            self._bucket_of, self._members = [], [0] * len(self._ranges)
+            off = 0
+            for p in self.params:
+                touched = [b for b, (lo, hi) in enumerate(self._ranges) if lo < off + p.numel() and off < hi]
+                self._bucket_of.append(touched)            # a parameter may straddle a boundary: it counts for both ranges
+                for b in touched:
+                    self._members[b] += 1
+                off += p.numel()
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+        self._pending = list(self._members)
+
+    def _on_grad(self, i):
+        if not getattr(self, "_armed", False):
+            return
+        for b in self._bucket_of[i]:
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._issue(b)
+
+    def _issue(self, b):
+        lo, hi = self._ranges[b]
+        self._issued.add(b)
+        self._works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+
     def allreduce(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        """Average the flat gradient buffer over the ranks.  After ``arm()``: wait for the ranges already in flight and send the
+        ones whose parameters received no gradient in this backward; without ``arm()``: one all-reduce of the whole buffer."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if getattr(self, "_armed", False):
+            for b in range(len(self._ranges)):
+                if b not in self._issued:
+                    self._issue(b)
+            for w in self._works:
+                w.wait()
+            self.overlapped_ranges = len(self._issued)
+            self._armed = False
+        else:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
-            self.grad.div_(dist.get_world_size(group))
+        self.grad.div_(dist.get_world_size(group))
 
     def step(self):
         self.t += 1
@@ -467,6 +520,7 @@ class LWGTrainer(object):
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
         loss_G = self.optimize_G(fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
         self.optimizer_G.zero_grad()
+        self.optimizer_G.arm(self.group)
         loss_G.backward()                                   # G's adversarial term also reaches D's leaves; zeroed below
         self.optimizer_G.allreduce(self.group)
         self.optimizer_G.step()
@@ -474,6 +528,7 @@ class LWGTrainer(object):
         if self.D is not None:
             self.optimizer_D.zero_grad()
             loss_D = self.optimize_D(fake_tsf_imgs)
+            self.optimizer_D.arm(self.group, n_buckets=1)
             loss_D.backward()
             self.optimizer_D.allreduce(self.group)
             self.optimizer_D.step()

@@ -172,3 +172,58 @@ def test_allreduce_grads_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+_FLAT_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ipercore_amd.trainers import FlatAdam
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+unused = torch.nn.Linear(8, 8)                      # never reached by the loss: its range must still be exchanged
+mod = torch.nn.ModuleList([net, unused])
+opt = FlatAdam(mod, lr=1e-3)
+x = torch.randn(5, 16, generator=torch.Generator().manual_seed(10 + rank))
+for trial in range(2):                              # the second pass re-arms the same hooks
+    opt.zero_grad()
+    gs = torch.autograd.grad(net(x).pow(2).sum(), list(net.parameters()))        # this rank's gradient, computed aside
+    local = torch.zeros_like(opt.grad)
+    off = 0
+    for p_ in opt.params:
+        if any(p_ is q for q in net.parameters()):
+            g_ = gs[[i for i, q in enumerate(net.parameters()) if q is p_][0]]
+            local[off:off + p_.numel()] = g_.reshape(-1)
+        off += p_.numel()
+    opt.arm(None, n_buckets=3)
+    net(x).pow(2).sum().backward()
+    in_flight = len(opt._issued)                    # ranges handed to the collective DURING backward
+    opt.allreduce(None)
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    assert torch.allclose(opt.grad, sum(both) / world, atol=1e-7), (opt.grad - sum(both) / world).abs().max()
+    assert opt.overlapped_ranges == 3 and in_flight >= 1, (opt.overlapped_ranges, in_flight)
+    assert net[0].weight.grad.data_ptr() == opt.grad.data_ptr()          # still views of the flat buffer
+# un-armed: one collective over the whole buffer
+opt.zero_grad(); net(x).pow(2).sum().backward(); local = opt.grad.clone(); opt.allreduce(None)
+both = [torch.zeros_like(local) for _ in range(world)]; dist.all_gather(both, local)
+assert torch.allclose(opt.grad, sum(both) / world, atol=1e-7)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_flat_adam_overlapped_allreduce_gloo_world2(tmp_path):
+    """FlatAdam.arm(): the flat gradient buffer goes out in a few large ranges as soon as backward has filled them
+    (post-accumulate hooks + async collectives); the result equals the plain mean over the ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "f.py"
+    script.write_text(_FLAT_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
