@@ -79,6 +79,12 @@ class Imitator(object):
         self.src_info = None
         self.first_cam = None
         self.image_size = int(_opt_get(opt, "image_size", 512))
+        # the conv kernels address activations with 32-bit buffer offsets (< 3 GiB per tensor, include/lwg_hip.h); the largest
+        # NHWC tensor of a frame batch is the last decoder output (B, S, S, 64) fp32
+        max_fb = max(1, int((3 << 30) // (self.image_size * self.image_size * 64 * 4)) - 1)
+        if self.frame_batch > max_fb:
+            print(f"[ipercore_amd] frame_batch {self.frame_batch} -> {max_fb} at {self.image_size}x{self.image_size} (3 GiB per-tensor limit of the conv kernels)")
+            self.frame_batch = max_fb
         self.temporal = bool(_opt_get(opt, "temporal", False))
         self.time_step = int(_opt_get(opt, "time_step", 1))
         self.temporal_fifo = None
