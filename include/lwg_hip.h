@@ -83,7 +83,7 @@ int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* args, lwg_stream_t stream);
  *   (x0/x1, taps, stride, OH/OW/M, N and the output mapping; args->y/w/bias/epi are ignored); dy has the layout of the
  *   forward output; dw is (ntaps*Cin, N) row-major with K in the forward panel's order; ws: lwg_conv2d_wgrad_ws_floats().
  * The data gradient is lwg_conv2d_nhwc_f32 itself on dy with a transposed panel (ipercore_amd/networks/packing.py
- *   pack_dgrad_*); lwg_colsum_nhwc_f32 gives bias gradients (out[c] = sum over rows of x (rows, C); ws: 64*C floats). */
+ *   pack_dgrad_*); lwg_colsum_nhwc_f32 gives bias gradients (out[c] = sum over rows of x (rows, C); ws: 512*C floats). */
 size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M);
 int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* args, const float* dy, float* dw, float* ws, lwg_stream_t stream);
 int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream);

@@ -258,6 +258,35 @@ __global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nspl
 }
 
 // Column sums of an NHWC tensor viewed as (rows, C): out[c] = sum_r x[r, c] (bias gradients).  Two deterministic passes.
+// C % 4 == 0: a lane owns four consecutive channels (16-byte loads), C/4 lanes cover a row, 256 / (C/4) rows per pass;
+// up to 512 row blocks keep every CU streaming (the first version used 64 blocks of 4-byte loads: 2.4 TB/s).
+__global__ __launch_bounds__(256) void lwg_colsum_partial4_kernel(const float* __restrict__ x, size_t rows, int C, int rows_per_block,
+                                                                 float* __restrict__ ws) {
+    const int C4 = C >> 2;
+    const int lanes_per_row = C4 < 256 ? C4 : 256;          // C <= 1024
+    const int rpp = 256 / lanes_per_row;                     // rows per pass of the block
+    const int cq = threadIdx.x % lanes_per_row, rr = threadIdx.x / lanes_per_row;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (size_t)rows_per_block);
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rr < rpp)
+        for (size_t r = r0 + rr; r < r1; r += rpp) {
+            const floatx4 v = *reinterpret_cast<const floatx4*>(x + r * C + 4 * cq);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += v[k];
+        }
+    __shared__ floatx4 sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rr == 0) {
+        for (int j = 1; j < rpp; ++j) {
+            const floatx4 v = sh[j * lanes_per_row + cq];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += v[k];
+        }
+        *reinterpret_cast<floatx4*>(ws + (size_t)blockIdx.x * C + 4 * cq) = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void lwg_colsum_partial_kernel(const float* __restrict__ x, size_t rows, int C, int rows_per_block,
                                                                 float* __restrict__ ws) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
@@ -327,6 +356,13 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
 extern "C" int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !out || !ws || rows == 0 || C <= 0) return (int)hipErrorInvalidValue;
+    if ((C & 3) == 0 && C <= 1024 && (256 % (C / 4 < 256 ? C / 4 : 256)) == 0) {
+        const int nblk = rows >= 512 * 64 ? 512 : (int)((rows + 63) / 64);      // ws holds nblk * C floats (callers size it 512 * C)
+        const int rpb = (int)((rows + nblk - 1) / nblk);
+        hipLaunchKernelGGL(lwg_colsum_partial4_kernel, dim3(nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
+        hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nblk, (size_t)C, out);
+        return (int)hipGetLastError();
+    }
     const int nblk = rows >= 64 * 64 ? 64 : (int)((rows + 63) / 64);
     const int rpb = (int)((rows + nblk - 1) / nblk);
     hipLaunchKernelGGL(lwg_colsum_partial_kernel, dim3((C + 63) / 64, nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);

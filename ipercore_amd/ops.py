@@ -465,7 +465,7 @@ def colsum(x2d_or_nhwc):
     C = x.shape[-1]
     rows = x.numel() // C
     out = torch.empty(C, device=x.device, dtype=torch.float32)
-    ws = torch.empty(64 * C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(512 * C, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().lwg_colsum_nhwc_f32(_ptr(x), rows, C, _ptr(out), _ptr(ws), _stream()), "lwg_colsum_nhwc_f32")
     return out
 
