@@ -332,13 +332,8 @@ static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t lds = (size_t)2 * 8 * ((BM + 1) * 4 + BN * 4) * sizeof(float) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_kernel<WAVES_M, WAVES_N, TM, TN, EPI, SMALLC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0ull;
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a);
     return hipGetLastError();

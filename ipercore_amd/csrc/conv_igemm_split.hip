@@ -621,11 +621,8 @@ template <int EPI>
 static hipError_t launch_split_pp(const LwgConvArgs& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * (2 * 3 * 2 * (128 + 4) * 16 + 3 * 2 * 128 * 16) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_split_pp_kernel<EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0ull;
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 128;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, stream, a);
     return hipGetLastError();

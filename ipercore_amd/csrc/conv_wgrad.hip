@@ -339,12 +339,8 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
     const int cps = (nchunks + splits - 1) / splits;
     const size_t lds = (size_t)4 * 32 * 128 * sizeof(float) + LWG_MAX_TAPS * sizeof(int);
     auto kern = smallc ? lwg_conv_wgrad_kernel<true> : lwg_conv_wgrad_kernel<false>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[smallc]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done[smallc] = true;
-    }
+    static unsigned long long attr_done[2] = {0ull, 0ull};
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[smallc]); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
     const size_t total = (size_t)Ktot * a.N;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -32,3 +32,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// More than 64 KB of dynamic LDS is an opt-in per kernel AND per device: `done` holds one bit per device ordinal (one process may
+// drive several GPUs even though the runners use one process per GPU).
+static inline hipError_t lwg_allow_dynamic_lds(const void* kern, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+    return e;
+}
