@@ -40,6 +40,10 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 
 #define LWG_OOB_OFFSET 0xC0000000u  // >= any tensor's byte size (host enforces < 3 GiB): the buffer load returns 0
 #define LWG_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef LWG_CONV_DMA_B
+#define LWG_CONV_DMA_B 0     // 1: the weight panel goes global -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR round trip.
+                             // Bit-identical results; measured A/B/A/B with tools/convlab.py: within 0.3 % of the register path (kept off)
+#endif
 
 __device__ __forceinline__ floatx4 lwg_buf_load(const float* base, unsigned bytes, unsigned voff, unsigned soff) {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
@@ -184,6 +188,15 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
 #pragma unroll
         for (int p = 0; p < PB; ++p) rb[p] = lwg_buf_load(a.w, wbytes, wvoff[p], ld_soffB);
     };
+    // LDS-DMA form: lane i of a wave lands at (M0 base) + 16 * i, i.e. the wave's 1 KB slice of the lane-linear B stage
+    const int wave_b = __builtin_amdgcn_readfirstlane(tid >> 6) * 256;          // floats
+    auto dma_b = [&](int buf) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(Bs + buf * B_STAGE + wave_b + 1024 * p), 16,
+                                                     (int)wvoff[p], (int)ld_soffB, 0, 0);
+    };
 
     const int st_a = kq * A_ROW + mrow * 4;  // + 128 * p
     const int st_b = tid * 4;                // + 1024 * p   ([kq][n] is linear in idx)
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         for (int p = 0; p < PA; ++p) tap_row(p, toff0);
     }
     load_a(0);
-    load_b();
+    if (LWG_CONV_DMA_B) dma_b(0); else load_b();
     {   // loader state -> step 1
         const int toff1 = advance_scalar();
         if (!SMALLC) {
@@ -246,7 +259,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
             for (int p = 0; p < PA; ++p) tap_row(p, toff1);
         }
     }
-    lstore(0);
+    if (LWG_CONV_DMA_B) {
+        lstore_a(0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the DMA of stage 0 has landed
+    } else {
+        lstore(0);
+    }
     __syncthreads();
     read_frags(0, 0, 0);
 
@@ -262,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         LWG_SB();
         mfma_e(0, 1);
         LWG_SB();
-        if (NEXT) load_b();
+        if (NEXT) {
+            if (LWG_CONV_DMA_B) dma_b(CUR ^ 1); else load_b();
+        }
         LWG_SB();
         mfma_e(0, 2);
         mfma_e(0, 3);
@@ -298,11 +318,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         LWG_SB();
         mfma_e(1, 1);
         LWG_SB();
-        if (NEXT) lstore_b(CUR ^ 1);
+        if (NEXT && !LWG_CONV_DMA_B) lstore_b(CUR ^ 1);
         LWG_SB();
         mfma_e(1, 2);
         LWG_SB();
         if (NEXT) {
+            if (LWG_CONV_DMA_B) __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0) before the barrier that publishes the stage
             __syncthreads();
             read_frags(CUR ^ 1, 0, 0);
         }
