@@ -356,7 +356,7 @@ def main():
             line["split_products"] = split_products(step, im, W, K, FB, outs)
         if args.output_frames > 0 and world == 1:
             line["with_output"] = with_output(im, mine, FB, args.output_frames, lo)
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)
         print(json.dumps(line), flush=True)
