@@ -247,10 +247,13 @@ def main():
         tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, chunk, "smooth", t=lo + i * FB)
         return im.forward(tsf8, Tst)[0]
 
+    last = None
     for i in range(W):
         last = step(i)
     torch.cuda.synchronize()
     if world > 1:
+        if last is None:                                     # --warmup 0: the collective still gets its untimed first call
+            last = step(0)
         # untimed: the first collective of a size class sets up RCCL's channels / buffers - do it once at the timed shape
         wg = sharding.OverlappedGather(FB * world)
         wg.submit(last, 0)
