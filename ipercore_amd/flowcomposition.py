@@ -1,8 +1,8 @@
 """Flow composition of the runner (reference iPERCore/models/flowcomposition.py:21-744), per-frame part.
 
 Built in this round (the per-frame path of ``Imitator.inference``):
-  ``add_rendered_f2verts_fim_wim`` (:139-204, without the source-only ``use_morph`` branch),
-  ``make_tsf_inputs`` (:206-248), ``make_trans_flow`` (:514-582, temporal=False), ``make_uv_setup`` (:78-85),
+  ``add_rendered_f2verts_fim_wim`` (:139-204), ``make_tsf_inputs`` (:206-248), ``make_trans_flow`` (:514-582, temporal=False),
+  ``make_batch_trans_flow`` (:584-662), ``make_uv_setup`` (:78-85),
   ``make_src_inputs`` (:262-265), and the fused ``frame_inputs`` that the MI355X runner actually calls: ONE
   pass over (fim, wim) producing cond, the UV flow + UV sample, the generator input and all source flows
   (``csrc/flow.hip``) instead of 2 + ns boolean-mask gathers with host syncs.
@@ -99,7 +99,8 @@ class FlowComposition(torch.nn.Module):
     def make_trans_flow(self, bs, ns, nt, src_info, temp_info, ref_info, temporal=True, use_selected_f2pts=False):
         """flowcomposition.py:514-582 -> (Tst (bs,ns,h,w,2), Ttt)."""
         if temporal:
-            raise NotImplementedError("temporal flows (Ttt) are a 'next' row (SURVEY 8f-4)")
+            raise NotImplementedError("Ttt comes out of the runner's fused pass (Imitator.synthesize_temporal -> frame_inputs with the "
+                                      "ring's f2pts appended); this reference-shaped helper only builds Tst")
         h = w = self.image_size
         key = "selected_f2pts" if use_selected_f2pts else ("only_vis_f2pts" if self.only_vis else "f2pts")
         src_f2pts = _force(src_info[key])

@@ -19,8 +19,9 @@ MI355X design (not a translation of the reference's layer objects):
     the warp, as the reference does) - see ``csrc/lwb_attn.hip``;
   - frames are independent when ``temporal=False`` so the engine takes a batch of frames per call.
 
-Inference only in this round: the methods run under ``torch.no_grad()`` on CUDA tensors and raise on CPU
-tensors (no fallback).  The backward pass for personalization is a "next" row.
+These methods are the inference engine: they run under ``torch.no_grad()`` on CUDA tensors and raise on CPU tensors (no
+fallback).  The differentiable forward for the personalization step lives in ``networks/training.py``
+(``TrainableGenerator`` over the same parameter tree; ``trainers.LWGTrainer``).
 """
 import math
 
@@ -188,8 +189,8 @@ class AttentionLWBGenerator(nn.Module):
 
     def _check(self, *tensors):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("training (autograd) through the HIP generator is not built yet (SURVEY 8f-3); "
-                                      "call under torch.no_grad() / .eval()")
+            raise NotImplementedError("these methods are the no_grad inference engine: call under torch.no_grad() / .eval(), or train "
+                                      "through ipercore_amd.networks.training.TrainableGenerator (trainers.LWGTrainer)")
         for t in tensors:
             if t is not None and not t.is_cuda:
                 raise RuntimeError("ipercore_amd generator runs on the MI355X only: got a CPU tensor (no fallback)")

@@ -38,7 +38,7 @@ def rasterize_face_index_map(faces, image_size, anti_aliasing=False, near=0.1, f
 
 def _next_row(name):
     def f(*a, **k):
-        raise NotImplementedError(f"neural_renderer.{name} is a 'next' row (SURVEY.md 8f-4): not on the Imitator path")
+        raise NotImplementedError(f"neural_renderer.{name} is not built: not on the Imitator path, and the package that defines it is not vendored (no output to pin it to; DESIGN.md 7)")
     return f
 
 

@@ -171,6 +171,6 @@ class SMPLRenderer(nn.Module):
         return torch.stack([yv, xv], dim=-1)
 
     def render(self, *args, **kwargs):
-        raise NotImplementedError("textured rendering (nr.rasterize + nr.lighting) is a 'next' row (SURVEY 8f-4)")
+        raise NotImplementedError("textured rendering (nr.rasterize + nr.lighting) is not built: not on the Imitator path, and the neural_renderer package that defines it is not vendored (DESIGN.md 7)")
 
     forward = render
