@@ -168,6 +168,12 @@ int lwg_project_faces_f32(const float* verts, const float* cam, const int32_t* f
                           float eye_dist, float* faces_v, float* f2pts, lwg_stream_t stream);
 int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, int S, float near, float far, int32_t* fim,
                               float* wim, void* ws, lwg_stream_t stream);
+/* Textured rendering from the maps above (SMPLRenderer.render -> nr.rasterize, renders/nmr.py:271-290): perspective-correct
+ * trilinear sampling of per-face T x T x T textures.  PARITY UNPINNED: neural_renderer is not vendored with the reference
+ * and the reference holds no output of this function; the published forward_texture_sampling algorithm is restated.
+ * textures (B | 1, nf, T, T, T, 3); bg_color: 3 host floats; rgb (B, S, S, 3) on the pixel grid of (fim, wim). */
+int lwg_texture_sample_f32(const int32_t* fim, const float* wim, const float* faces_v, const float* textures, int B, int nf,
+                           int S, int T, int tex_batched, float eps, const float* bg_color3_host, float* rgb, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flow composition from (fim, wim).

@@ -62,6 +62,7 @@ _SIGS = {
     "lwg_rasterize_ws_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_project_faces_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f]),
     "lwg_rasterize_fim_wim_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_f, c_f]),
+    "lwg_texture_sample_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.POINTER(ctypes.c_float), c_f, c_f]),
     "lwg_flow_compose_f32": (c_i, [c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f]),
     "lwg_bc_transform_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "lwg_encode_fim_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),

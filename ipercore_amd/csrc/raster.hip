@@ -280,3 +280,71 @@ extern "C" int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, in
                        bin_count, bin_list, fim, wim);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Textured rendering on top of the (fim, wim) maps: neural_renderer's texture sampling as called by SMPLRenderer.render
+// (renders/nmr.py:271-290 -> nr.rasterize).  The package that defines it is NOT vendored with the reference and the reference
+// holds no output of it, so this restates the published algorithm of neural_renderer's `forward_texture_sampling`
+// (parity unpinned, see oracle/lwg_oracle.py::texture_sample):
+//   zp = 1 / sum_k (w_k / z_k);   t_k = clamp(w_k * (T - 1) * zp / z_k, 0, T - 1 - eps)        (perspective-correct texel coordinate)
+//   rgb = trilinear blend of the 8 texels around (t_0, t_1, t_2) of the face's T x T x T texture;  background colour elsewhere.
+// Image orientation: the same pixel grid as (fim, wim) - SMPLRenderer.render hands the SAME pre-flipped vertices to nr.rasterize
+// and to nr.rasterize_face_index_map (nmr.py:279-290), whose maps index images top row first on the per-frame path.
+// One thread per pixel; faces_v (B,nf,3,3) supplies z_k; textures (B,nf,T,T,T,3) or (1,nf,...) when tex_batched = 0.
+__global__ void lwg_texture_sample_kernel(const int* __restrict__ fim, const float* __restrict__ wim, const float* __restrict__ faces_v,
+                                          const float* __restrict__ tex, int nf, int S, int T, int tex_batched, float eps, float bg0,
+                                          float bg1, float bg2, float* __restrict__ rgb) {
+    const int b = blockIdx.y;
+    const size_t npx = (size_t)S * S;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = (size_t)b * npx + p;
+        const int fi = fim[i];
+        float* o = rgb + i * 3;
+        if (fi < 0) {
+            o[0] = bg0; o[1] = bg1; o[2] = bg2;
+            continue;
+        }
+        const float* w = wim + i * 3;
+        const float* f = faces_v + ((size_t)b * nf + fi) * 9;
+        const float z0 = f[2], z1 = f[5], z2 = f[8];
+        const float zp = 1.f / (w[0] / z0 + w[1] / z1 + w[2] / z2);
+        float t[3] = {w[0] * (float)(T - 1) * (zp / z0), w[1] * (float)(T - 1) * (zp / z1), w[2] * (float)(T - 1) * (zp / z2)};
+        int ti[3];
+        float tf[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t[k] = fminf(fmaxf(t[k], 0.f), (float)(T - 1) - eps);
+            ti[k] = (int)t[k];
+            tf[k] = t[k] - (float)ti[k];
+        }
+        const float* tx = tex + ((size_t)(tex_batched ? b : 0) * nf + fi) * T * T * T * 3;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int pn = 0; pn < 8; ++pn) {
+            float ww = 1.f;
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int hi = (pn >> k) & 1;
+                ww *= hi ? tf[k] : 1.f - tf[k];
+                const int tk = ti[k] + hi < T ? ti[k] + hi : T - 1;
+                idx = idx * T + tk;
+            }
+            c0 += ww * tx[idx * 3 + 0];
+            c1 += ww * tx[idx * 3 + 1];
+            c2 += ww * tx[idx * 3 + 2];
+        }
+        o[0] = c0; o[1] = c1; o[2] = c2;
+    }
+}
+
+extern "C" int lwg_texture_sample_f32(const int32_t* fim, const float* wim, const float* faces_v, const float* textures, int B, int nf,
+                                      int S, int T, int tex_batched, float eps, const float* bg_color3_host, float* rgb, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!fim || !wim || !faces_v || !textures || !rgb || !bg_color3_host || B <= 0 || B > 65535 || nf <= 0 || S <= 0 || T < 1 || T > 16)
+        return (int)hipErrorInvalidValue;
+    const size_t npx = (size_t)S * S;
+    hipLaunchKernelGGL(lwg_texture_sample_kernel, dim3((unsigned)((npx + 255) / 256 < 4096 ? (npx + 255) / 256 : 4096), B), dim3(256), 0, stream,
+                       fim, wim, faces_v, textures, nf, S, T, tex_batched, eps, bg_color3_host[0], bg_color3_host[1], bg_color3_host[2], rgb);
+    return (int)hipGetLastError();
+}

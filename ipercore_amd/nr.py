@@ -2,8 +2,8 @@
 
     import ipercore_amd.nr as nr        # or: sys.modules["neural_renderer"] = ipercore_amd.nr
 
-Only the functions on the per-frame path and source_setup are built; the textured /
-silhouette / depth renderers raise.  All take and return tensors on the same CUDA device.
+The functions on the per-frame path and source_setup are built and pinned; ``rasterize`` (textured) and
+``lighting`` restate the package's published algorithm without a reference output to pin them to; silhouette / depth raise.  All take and return tensors on the same CUDA device.
 """
 import torch
 
@@ -42,7 +42,38 @@ def _next_row(name):
     return f
 
 
-rasterize = _next_row("rasterize")
+def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1), color_directional=(1, 1, 1),
+             direction=(0, 1, 0)):
+    """neural_renderer.lighting as called at nmr.py:258-266: per-face light = ambient + directional * relu(n . d), applied to the
+    (bs,nf,T,T,T,3) textures.  PARITY UNPINNED (package not vendored): the published formula, normals from cross(v0 - v1, v2 - v1)."""
+    bs, nf = faces.shape[:2]
+    dev = faces.device
+    light = torch.zeros(bs, nf, 3, device=dev)
+    col = lambda c: torch.as_tensor(c, dtype=torch.float32, device=dev).reshape(-1, 3).expand(bs, 3) if torch.as_tensor(c).dim() <= 1 \
+        else torch.as_tensor(c, dtype=torch.float32, device=dev)                                                   # noqa: E731
+    if intensity_ambient != 0:
+        light = light + intensity_ambient * col(color_ambient)[:, None, :]
+    if intensity_directional != 0:
+        f = faces.reshape(bs * nf, 3, 3)
+        normals = torch.nn.functional.normalize(torch.cross(f[:, 0] - f[:, 1], f[:, 2] - f[:, 1], dim=1), eps=1e-5).reshape(bs, nf, 3)
+        d = col(direction)
+        cos = torch.relu((normals * d[:, None, :]).sum(dim=2))
+        light = light + intensity_directional * (col(color_directional)[:, None, :] * cos[:, :, None])
+    return textures * light[:, :, None, None, None, :]
+
+
+def rasterize(faces, textures, image_size=256, anti_aliasing=True, near=0.1, far=100, eps=1e-3, background_color=(0, 0, 0)):
+    """neural_renderer.rasterize as called at nmr.py:286-287 -> images (bs,3,S,S): index / weight maps at S (2 S with
+    anti_aliasing, then a 2x2 average), perspective-correct trilinear texture sampling (csrc/raster.hip lwg_texture_sample_f32).
+    PARITY UNPINNED, see include/lwg_hip.h.  The image is on the pixel grid of rasterize_face_index_map for the same faces."""
+    S = image_size * 2 if anti_aliasing else image_size
+    faces = faces.float().contiguous()
+    fim, wim = ops.rasterize_fim_wim(faces, S, near, far)
+    rgb = ops.texture_sample(fim, wim, faces, textures.float(), eps=eps, background_color=background_color).permute(0, 3, 1, 2)
+    if anti_aliasing:
+        rgb = torch.nn.functional.avg_pool2d(rgb, kernel_size=2)
+    return rgb.contiguous()
+
+
 rasterize_silhouettes = _next_row("rasterize_silhouettes")
 rasterize_depth = _next_row("rasterize_depth")
-lighting = _next_row("lighting")

@@ -219,6 +219,19 @@ def rasterize_fim_wim(faces_v, image_size, near=0.1, far=100.0):
     return fim, wim
 
 
+def texture_sample(fim, wim, faces_v, textures, eps=1e-3, background_color=(0.0, 0.0, 0.0)):
+    """rgb (B,S,S,3) from the index / weight maps, faces_v (B,nf,3,3) and per-face textures (B|1,nf,T,T,T,3)."""
+    B, S = fim.shape[0], fim.shape[1]
+    nf, T = faces_v.shape[1], textures.shape[2]
+    assert textures.shape[0] in (1, B) and textures.shape[1] == nf
+    rgb = torch.empty(B, S, S, 3, device=fim.device, dtype=torch.float32)
+    bg = (ctypes.c_float * 3)(*[float(c) for c in background_color])
+    _lib.check(_lib.lib().lwg_texture_sample_f32(_ptr(fim, torch.int32), _ptr(wim), _ptr(faces_v.contiguous()), _ptr(textures.contiguous()), B, nf,
+                                                 S, T, 1 if textures.shape[0] == B and B > 1 else (1 if textures.shape[0] == B else 0),
+                                                 float(eps), bg, _ptr(rgb), _stream()), "lwg_texture_sample_f32")
+    return rgb
+
+
 def flow_compose(fim, wim, map_fn, f_uvs2img, uv_img4, src_f2pts, want_cond=False, want_tuv=False):
     B, S, _ = fim.shape
     nf = f_uvs2img.shape[0]

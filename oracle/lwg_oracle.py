@@ -818,3 +818,58 @@ def smpl24_get_details(model, theta, offsets=0):
     joints = torch.stack([verts[:, :, k] @ coco for k in range(3)], dim=2)
     j2d = cam[:, None, 0:1] * (joints[:, :, :2] + cam[:, None, 1:])
     return {"theta": theta, "cam": cam, "pose": pose, "shape": beta, "verts": verts, "j3d": joints, "j2d": j2d}
+
+
+# ------------------------------------------------------------------------------------------------ textured rendering
+# PARITY UNPINNED: neural_renderer (requirements/build.txt: iPERDance/neural_renderer@e5f54f7) is not vendored with the
+# reference and the reference holds no output of nr.rasterize / nr.lighting.  These restate the package's published
+# algorithm (forward_texture_sampling, lighting) as SMPLRenderer.render calls them (renders/nmr.py:271-290); the image is taken
+# on the pixel grid of rasterize_face_index_map for the same faces (render() hands both the same pre-flipped vertices).
+def nr_lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1), color_directional=(1, 1, 1),
+                direction=(0, 1, 0)):
+    bs, nf = faces.shape[:2]
+    light = torch.zeros(bs, nf, 3)
+    if intensity_ambient != 0:
+        light = light + intensity_ambient * torch.tensor(color_ambient, dtype=torch.float32)[None, None, :]
+    if intensity_directional != 0:
+        f = faces.reshape(bs * nf, 3, 3)
+        n = F.normalize(torch.cross(f[:, 0] - f[:, 1], f[:, 2] - f[:, 1], dim=1), eps=1e-5).reshape(bs, nf, 3)
+        cos = torch.relu((n * torch.tensor(direction, dtype=torch.float32)[None, None, :]).sum(dim=2))
+        light = light + intensity_directional * torch.tensor(color_directional, dtype=torch.float32)[None, None, :] * cos[:, :, None]
+    return textures * light[:, :, None, None, None, :]
+
+
+def texture_sample(fim, wim, faces_v, textures, eps=1e-3, background_color=(0.0, 0.0, 0.0)):
+    """fim (B,S,S) int, wim (B,S,S,3), faces_v (B,nf,3,3), textures (B,nf,T,T,T,3) -> rgb (B,S,S,3)."""
+    B, S = fim.shape[:2]
+    T = textures.shape[2]
+    out = torch.tensor(background_color, dtype=torch.float32).expand(B, S, S, 3).clone()
+    for b in range(B):
+        m = fim[b] >= 0
+        fi = fim[b][m].long()
+        w = wim[b][m]                                                    # (P,3)
+        z = faces_v[b, fi][:, :, 2]                                      # (P,3)
+        zp = 1.0 / (w / z).sum(dim=1, keepdim=True)
+        t = (w * (T - 1) * (zp / z)).clamp(0.0, (T - 1) - eps)
+        ti = t.to(torch.int64)
+        tf = t - ti.to(torch.float32)
+        tex = textures[b, fi].reshape(fi.shape[0], T * T * T, 3)
+        acc = torch.zeros(fi.shape[0], 3)
+        for pn in range(8):
+            ww = torch.ones(fi.shape[0])
+            idx = torch.zeros(fi.shape[0], dtype=torch.int64)
+            for k in range(3):
+                hi = (pn >> k) & 1
+                ww = ww * (tf[:, k] if hi else 1.0 - tf[:, k])
+                idx = idx * T + (ti[:, k] + hi).clamp_max(T - 1)
+            acc = acc + ww[:, None] * tex[torch.arange(fi.shape[0]), idx]
+        out[b][m] = acc
+    return out
+
+
+def nr_rasterize(faces_v, textures, image_size, anti_aliasing=True, near=0.1, far=100.0, eps=1e-3, background_color=(0.0, 0.0, 0.0)):
+    """-> images (B,3,S,S)."""
+    S = image_size * 2 if anti_aliasing else image_size
+    fim, wim = rasterize_fim_wim(faces_v.numpy() if torch.is_tensor(faces_v) else faces_v, S, near, far)
+    rgb = texture_sample(fim, wim, torch.as_tensor(faces_v), textures, eps, background_color).permute(0, 3, 1, 2)
+    return F.avg_pool2d(rgb, 2) if anti_aliasing else rgb

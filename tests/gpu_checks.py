@@ -834,6 +834,50 @@ def check_smpl24():
     return out
 
 
+def check_textured_render():
+    """SMPLRenderer.forward / render / extract_tex + nr.rasterize / nr.lighting (reference renders/nmr.py:243-296,435-456) on the
+    GPU against the oracle's restatement.  PARITY UNPINNED at the source (neural_renderer is not vendored with the reference): this
+    checks kernel == oracle, not oracle == reference."""
+    from oracle import lwg_oracle as orc
+    from ipercore_amd import nr
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=1, ns=2)
+    im = pu.make_imitator(case, frame_batch=1)
+    R = im.flow_comp.render
+    R.set_bgcolor((-1, -1, -1))
+    smpls = torch.tensor(synthetic.smpl_sequence(2, seed=20, pose_dim=72), device=DEV)
+    d = im.body_rec.get_details(smpls, torch.zeros((), device=DEV), links_ids=None)
+    uv = torch.tensor(synthetic.uniform_image((2, 3, 64, 64), 31, "uv_img"), device=DEV)
+    out = {}
+    for dyn in (False, True):
+        for aa in (False, True):
+            R.anti_aliasing = aa
+            images, textures, fim = R.forward(d["cam"], d["verts"], uv, dynamic=dyn, get_fim=True)
+            torch.cuda.synchronize()
+            # oracle on the HIP vertices and HIP textures (extract_tex = the grid_sample kernel, checked elsewhere)
+            t = pu.oracle_tables()
+            fv = orc.project_faces(d["cam"].cpu(), d["verts"].cpu(), t["smpl_faces"])
+            lit = orc.nr_lighting(torch.stack([d["verts"].cpu()[b][torch.tensor(t["smpl_faces"]).long()] for b in range(2)]), textures.cpu(), 1, 0)
+            want = orc.nr_rasterize(fv, lit, 64, anti_aliasing=aa, near=R.near, far=R.far, eps=1e-3, background_color=(-1, -1, -1))
+            out[f"dyn{int(dyn)}_aa{int(aa)}"] = _cmp(images, want, 2e-5, "textured image")
+            assert tuple(textures.shape) == (2, R.nf, 3, 3, 3, 3) and tuple(images.shape) == (2, 3, 64, 64)
+            fim_w, _ = orc.rasterize_fim_wim(fv.numpy(), 64, R.near, R.far)
+            assert torch.equal(fim.cpu(), fim_w)
+    # textures from the static sampler = grid_sample of the UV image at img2uv_sampler
+    tex_w = torch.nn.functional.grid_sample(uv.cpu(), R.img2uv_sampler.cpu()[None].expand(2, -1, -1, -1), mode="bilinear",
+                                            padding_mode="zeros", align_corners=False)
+    tex_w = tex_w.view(2, 3, R.nf, 3, 3).permute(0, 2, 3, 4, 1).unsqueeze(4).repeat(1, 1, 1, 1, 3, 1)
+    out["extract_tex"] = _cmp(R.extract_tex(uv, R.img2uv_sampler[None].expand(2, -1, -1, -1)), tex_w, 1e-5, "extract_tex")
+    # directional light
+    R.set_ambient_light(0.3, 0.7, (1, 0.5, 1))
+    R.anti_aliasing = False
+    images, _ = R.render(d["cam"], d["verts"], textures)
+    lit = orc.nr_lighting(torch.stack([d["verts"].cpu()[b][torch.tensor(t["smpl_faces"]).long()] for b in range(2)]), textures.cpu(), 0.7, 0.3,
+                          direction=(1, 0.5, 1))
+    out["lit"] = _cmp(images, orc.nr_rasterize(fv, lit, 64, anti_aliasing=False, near=R.near, far=R.far, background_color=(-1, -1, -1)), 2e-5, "lit image")
+    assert torch.equal(nr.lighting(torch.zeros(1, 4, 3, 3, device=DEV), torch.ones(1, 4, 2, 2, 2, 3, device=DEV), 1, 0).cpu(), torch.ones(1, 4, 2, 2, 2, 3))
+    return out
+
+
 def check_output_stage():
     """lwg_frames_to_u8 vs numpy's save_cv2_img arithmetic (exact) and Imitator.inference(output_dir=...) end to end:
     the PNGs decode to uint8((pred + 1) / 2 * 255) of the frames inference() returns without output_dir."""
@@ -1292,4 +1336,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render]

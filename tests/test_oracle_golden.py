@@ -201,6 +201,35 @@ def test_smpl24_matches_reference():
     assert np.abs(d["j3d"].numpy() - g["j3d"]).max() <= 2e-6 and np.abs(d["j2d"].numpy() - g["j2d"]).max() <= 2e-6
 
 
+def test_textured_render_properties(topo):
+    """The (parity-unpinned) textured renderer of the oracle: a constant texture reproduces its colour inside the silhouette and
+    the background colour outside; unit ambient light is the identity, a directional light only dims; a texture that is linear in
+    the barycentric texel index reproduces perspective-correct interpolation (sum of weights = 1 -> constant)."""
+    from tests import parity_utils as pu
+    t = pu.oracle_tables(topo)
+    model = orc.SMPLHModel(synthetic.smplh_model_dict(seed=0))
+    d = orc.smplh_get_details(model, synthetic.smpl_sequence(1, seed=20, pose_dim=72), 0, None)
+    fv = orc.project_faces(d["cam"], d["verts"], t["smpl_faces"])
+    nf, T, S = fv.shape[1], 3, 48
+    col = torch.tensor([0.2, -0.4, 0.6])
+    tex = torch.ones(1, nf, T, T, T, 3) * col
+    fim, _ = orc.rasterize_fim_wim(fv.numpy(), S, 0.1, 25.0)
+    img = orc.nr_rasterize(fv, tex, S, anti_aliasing=False, near=0.1, far=25.0, background_color=(-1, -1, -1))
+    inside = fim[0] >= 0
+    assert (img[0][:, inside] - col[:, None]).abs().max() <= 1e-6 and (img[0][:, ~inside] == -1).all()
+    assert torch.equal(orc.nr_lighting(fv, tex, 1, 0), tex)
+    lit = orc.nr_lighting(fv, tex.abs(), 0.7, 0.3, direction=(1, 0.5, 1))
+    assert (lit <= tex.abs() * (0.7 + 0.3 * (1.5 ** 0.5 * 1.5)) + 1e-6).all() and (lit >= 0.7 * tex.abs() - 1e-6).all()
+    # texel value = i0 + i1 + i2 (in texel units): perspective-correct weights sum to T - 1 -> constant image
+    g = torch.arange(T, dtype=torch.float32)
+    lin = (g[:, None, None] + g[None, :, None] + g[None, None, :])[None, None, ..., None].expand(1, nf, T, T, T, 3)
+    img2 = orc.nr_rasterize(fv, lin.contiguous(), S, anti_aliasing=False, near=0.1, far=25.0)
+    vals = img2[0][:, inside]
+    assert (vals - (T - 1)).abs().max() <= 2e-3           # the clamp at T - 1 - eps moves saturated texels by eps
+    aa = orc.nr_rasterize(fv, tex, S, anti_aliasing=True, near=0.1, far=25.0, background_color=(-1, -1, -1))
+    assert aa.shape == (1, 3, S, S) and aa.min() >= -1 - 1e-6 and aa.max() <= 0.6 + 1e-6
+
+
 def test_loss_network_parameter_inventories():
     """The frozen loss networks keep the parameter names of the checkpoints the reference loads: Sphere20a
     (criterions/faceloss.py:203-257, pinned by the golden generated from the reference class itself: the state_dict loaded there
