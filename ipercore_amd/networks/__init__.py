@@ -14,5 +14,8 @@ class NetworksFactory(object):
                  "SoftGateAddLWB": g.SoftGateAddLWBGenerator, "SoftGateAvgLWB": g.SoftGateAvgLWBGenerator}
         if network_name in table:
             return table[network_name](*args, **kwargs)
+        if network_name in ("patch_global", "patch_global_local", "patch_global_body_head"):
+            from ..trainers import create_discriminator
+            return create_discriminator(network_name, *args, **kwargs)
         raise ValueError(f"Network {network_name} is outside the MI355X hot path (SURVEY.md section 8): built are "
                          f"{sorted(table)}; AttLWB-AdaIN, InputConcat, TextureWarping and the discriminators' factory names are not")

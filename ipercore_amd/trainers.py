@@ -33,54 +33,143 @@ from .networks.training import MaxPool2Fn, TrainableGenerator, conv, instance_no
 _RELU = 1
 
 
-class PatchGlobalDiscriminator(nn.Module):
-    """``patch_global``: GlobalDiscriminator(cfg) without the augmented-background branch (use_aug_bg=False, the
-    deploy.toml default).  Parameter names follow the reference modules: ``global_model.model.{0,2,5,8,11,14}``."""
+class PatchDiscriminator(nn.Module):
+    """discriminators/patch_dis.py:8-70 with norm_type = "instance", use_sigmoid = False: 4x4 convolutions (n_layers of stride 2,
+    then two of stride 1), InstanceNorm + LeakyReLU(0.2) between them, on the MFMA kernels (``ConvFn``) + ``NormAct``.
+    Parameter names follow the reference Sequential: ``model.{0,2,5,8,11,14}``."""
 
-    def __init__(self, cond_nc=6, ndf=64, n_layers=4, max_nf_mult=8):
+    def __init__(self, input_nc=6, ndf=64, n_layers=4, max_nf_mult=8, norm_type="instance", use_sigmoid=False):
         super().__init__()
-        chans = [cond_nc, ndf]
+        if norm_type != "instance" or use_sigmoid:
+            raise NotImplementedError("only norm_type='instance', use_sigmoid=False (deploy.toml / AttLWB-SPADE.toml) are built")
+        chans = [input_nc, ndf]
         for n in range(1, n_layers):
             chans.append(ndf * min(2 ** n, max_nf_mult))
         chans.append(ndf * min(2 ** n_layers, max_nf_mult))
-        self.n_layers = n_layers
+        self.n_layers, self.input_nc = n_layers, input_nc
         idx = [0] + [2 + 3 * (n - 1) for n in range(1, n_layers + 1)]          # Sequential indices of the convs
         self.layer_names = [str(i) for i in idx] + [str(idx[-1] + 3)]
-        self.global_model = nn.Module()
-        self.global_model.model = nn.Module()
+        self.model = nn.Module()
         for i, name in enumerate(self.layer_names[:-1]):
             m = nn.Module()
             m.weight = nn.Parameter(torch.empty(chans[i + 1], chans[i], 4, 4))
             m.bias = nn.Parameter(torch.empty(chans[i + 1]))
-            self.global_model.model.add_module(name, m)
+            self.model.add_module(name, m)
         m = nn.Module()
         m.weight = nn.Parameter(torch.empty(1, chans[-1], 4, 4))
         m.bias = nn.Parameter(torch.empty(1))
-        self.global_model.model.add_module(self.layer_names[-1], m)
-        for p in self.parameters():                                            # PyTorch Conv2d default init
-            if p.dim() == 4:
-                bound = 1.0 / (p.shape[1] * 16) ** 0.5
-                p.data.uniform_(-bound, bound)
-        for name in self.layer_names:
-            layer = getattr(self.global_model.model, name)
+        self.model.add_module(self.layer_names[-1], m)
+        for name in self.layer_names:                                          # PyTorch Conv2d default init
+            layer = getattr(self.model, name)
             bound = 1.0 / (layer.weight.shape[1] * 16) ** 0.5
+            layer.weight.data.uniform_(-bound, bound)
             layer.bias.data.uniform_(-bound, bound)
 
     def forward(self, x_nchw):
-        """(N, cond_nc, H, W) -> [patch logits (N, 1, h, w)]   (PatchDiscriminator.forward)."""
-        x = F.pad(x_nchw.permute(0, 2, 3, 1), (0, 8 - x_nchw.shape[1])).contiguous()
-        L = self.global_model.model
+        """(N, input_nc, H, W) -> patch logits (N, 1, h, w)."""
+        cp = 8 if x_nchw.shape[1] <= 8 else (x_nchw.shape[1] + 3) // 4 * 4
+        x = F.pad(x_nchw.permute(0, 2, 3, 1), (0, cp - x_nchw.shape[1])).contiguous()
         n = len(self.layer_names)
         for i, name in enumerate(self.layer_names):
-            layer = getattr(L, name)
+            layer = getattr(self.model, name)
             stride = 2 if i < self.n_layers else 1
             if i == 0:
-                x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=8, need_dx=False), 0.2)
+                x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=cp, need_dx=False), 0.2)
             elif i < n - 1:
                 x = instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1), ops.ACT_LRELU)
             else:
                 x = conv(x, layer.weight, layer.bias, stride=stride, pad=1, n_pad=64)
-        return [x.permute(0, 3, 1, 2)]
+        return x.permute(0, 3, 1, 2)
+
+
+def _cfg_get(cfg, key, default):
+    if cfg is None:
+        return default
+    return cfg.get(key, default) if isinstance(cfg, dict) else getattr(cfg, key, default)
+
+
+def crop_img(imgs, rects, fact=2):
+    """multi_scale_dis.py:21-44: crop (min_x, max_x, min_y, max_y) boxes and resize them to (H / fact, W / fact); degenerate boxes
+    are dropped (a host read of the N x 4 integers, as in the reference)."""
+    _, _, H, W = imgs.shape
+    crops = []
+    for i, (x0, x1, y0, y1) in enumerate(torch.as_tensor(rects).tolist()):
+        if x0 != x1 and y0 != y1:
+            crops.append(F.interpolate(imgs[i:i + 1, :, y0:y1, x0:x1], size=(H // fact, W // fact), mode="bilinear", align_corners=True))
+    return torch.cat(crops, dim=0) if crops else crops
+
+
+def _reduce_outs(outs):
+    with torch.no_grad():
+        return sum(o.mean() for o in outs) / len(outs)
+
+
+class GlobalDiscriminator(nn.Module):
+    """multi_scale_dis.py:47-107 (``patch_global``).  ``forward`` takes the reference's dict ({"x", "bg_x"[, "get_avg"]}) or, as the
+    trainer here uses it, the image tensor itself (-> list of logits)."""
+    CROPS = ()                                             # (model attribute, rect key, size factor) of the sub-classes
+
+    def __init__(self, cfg=None, use_aug_bg=False, **kw):
+        super().__init__()
+        g = lambda k, d: kw.get(k, _cfg_get(cfg, k, d))                                           # noqa: E731
+        mk = lambda nc: PatchDiscriminator(nc, g("ndf", 64), g("n_layers", 4), g("max_nf_mult", 8), g("norm_type", "instance"),     # noqa: E731
+                                           g("use_sigmoid", False))
+        self.global_model = mk(g("cond_nc", 6))
+        for attr, _, _ in self.CROPS:
+            setattr(self, attr, mk(g("cond_nc", 6)))
+        self.bg_model = mk(g("bg_cond_nc", 4)) if use_aug_bg else None
+        self.use_aug_bg = use_aug_bg
+
+    # the attributes the single-network form exposed
+    n_layers = property(lambda self: self.global_model.n_layers)
+    layer_names = property(lambda self: self.global_model.layer_names)
+
+    def forward(self, inputs):
+        if torch.is_tensor(inputs):
+            inputs = {"x": inputs, "bg_x": None}
+        x, bg_x = inputs["x"], inputs.get("bg_x")
+        outs = []
+        if bg_x is not None and self.use_aug_bg:
+            outs.append(self.bg_model(bg_x))
+        outs.append(self.global_model(x))
+        if self.use_aug_bg and not self.CROPS:                 # GlobalDiscriminator lists [global, bg] (:96-100)
+            outs = outs[::-1]
+        for attr, key, fact in self.CROPS:
+            if inputs.get(key) is None:
+                raise ValueError(f"{type(self).__name__} needs inputs['{key}'] (N, 4 = (min_x, max_x, min_y, max_y))")
+            crops = crop_img(x, inputs[key], fact=fact)
+            if len(crops) != 0:
+                outs.append(getattr(self, attr)(crops))
+        if inputs.get("get_avg", False):
+            return outs, _reduce_outs(outs)
+        return outs
+
+
+class GlobalLocalDiscriminator(GlobalDiscriminator):
+    """multi_scale_dis.py:110-191 (``patch_global_local``): + a second PatchDiscriminator on the body crop at half size."""
+    CROPS = (("local_model", "body_rects", 2),)
+
+
+class GlobalBodyHeadDiscriminator(GlobalDiscriminator):
+    """multi_scale_dis.py:194-284 (``patch_global_body_head``): + body crop at half size and head crop at quarter size."""
+    CROPS = (("body_model", "body_rects", 2), ("head_model", "head_rects", 4))
+
+
+class PatchGlobalDiscriminator(GlobalDiscriminator):
+    """``patch_global`` as the personalization step uses it: GlobalDiscriminator without the augmented-background branch
+    (use_aug_bg=False, the deploy.toml default), keyword arguments instead of a cfg."""
+
+    def __init__(self, cond_nc=6, ndf=64, n_layers=4, max_nf_mult=8):
+        super().__init__(None, False, cond_nc=cond_nc, ndf=ndf, n_layers=n_layers, max_nf_mult=max_nf_mult)
+
+
+def create_discriminator(name, cfg=None, use_aug_bg=False):
+    """The discriminator entries of the reference's NetworksFactory (networks/__init__.py:50-60)."""
+    table = {"patch_global": GlobalDiscriminator, "patch_global_local": GlobalLocalDiscriminator,
+             "patch_global_body_head": GlobalBodyHeadDiscriminator}
+    if name not in table:
+        raise ValueError(f"Network {name} not recognized (built: {sorted(table)}; multi_scale is not)")
+    return table[name](cfg, use_aug_bg=use_aug_bg)
 
 
 def lsgan_loss(outs, target):
@@ -488,7 +577,7 @@ class LWGTrainer(object):
         loss_adv = 0.0
         if self.D is not None:
             tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
-            loss_adv = lsgan_loss(self.D(torch.cat([fake_tsf, tsf_cond], dim=1)), 0) * o.lambda_D_prob
+            loss_adv = lsgan_loss(self.D(self._d_inputs(torch.cat([fake_tsf, tsf_cond], dim=1))), 0) * o.lambda_D_prob
         loss_rec = (F.l1_loss(fake_src_imgs, i["real_src"]) + F.l1_loss(fake_bg.view(-1, 3, h, w), i["real_bg"])) / 2 * o.lambda_rec
         loss_tsf = (F.l1_loss(fake_tsf, real_tsf) if self.crt_tsf is None else self.crt_tsf(fake_tsf, real_tsf)) * o.lambda_tsf
         loss_face = 0.0
@@ -500,6 +589,11 @@ class LWGTrainer(object):
         self.losses.update(g_rec=loss_rec, g_tsf=loss_tsf, g_face=loss_face, g_adv=loss_adv, g_mask=loss_mask, g_mask_smooth=loss_smooth)
         return loss_rec + loss_tsf + loss_face + loss_adv + loss_mask + loss_smooth
 
+    def _d_inputs(self, x):
+        """:755-765 / :808-826: the discriminator's dict (no augmented background in personalization; the body / head boxes feed
+        the patch_global_local / patch_global_body_head variants)."""
+        return {"x": x, "bg_x": None, "body_rects": self.inp.get("body_bbox"), "head_rects": self.inp.get("head_bbox"), "get_avg": False}
+
     def optimize_D(self, fake_tsf_imgs):
         """:791-832."""
         i = self.inp
@@ -507,7 +601,7 @@ class LWGTrainer(object):
         tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
         fake_in = torch.cat([fake_tsf_imgs.detach().view(bs * nt, c, h, w), tsf_cond], dim=1)
         real_in = torch.cat([i["real_tsf"].reshape(bs * nt, c, h, w), tsf_cond], dim=1)
-        d_real, d_fake = self.D(real_in), self.D(fake_in)
+        d_real, d_fake = self.D(self._d_inputs(real_in)), self.D(self._d_inputs(fake_in))
         self.losses.update(d_real=sum(o.mean() for o in d_real).detach(), d_fake=sum(o.mean() for o in d_fake).detach())
         return lsgan_loss(d_real, 1) + lsgan_loss(d_fake, -1)
 

@@ -616,6 +616,18 @@ def check_personalize_loop():
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
         frames = im.inference(case.tgt_smpls, "smooth")
         assert np.isfinite(np.stack(frames)).all()
+    # the same sample against the three-branch discriminator (train_aug_bg.toml:56 dis_name), boxes from the composition
+    from ipercore_amd.trainers import create_discriminator
+    dcfg = pu.AttrDict(cond_nc=6, bg_cond_nc=4, ndf=32, n_layers=3, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    D3 = create_discriminator("patch_global_body_head", dcfg).to(DEV)
+    tr3 = LWGTrainer(G, D3, flow_comp=fc)
+    tr3.set_input(sample)
+    lg, ld = tr3.optimize_parameters()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lg).item() and torch.isfinite(ld).item()
+    got = {k: sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in getattr(D3, k).parameters()) for k in ("global_model", "body_model", "head_model")}
+    assert got["global_model"] == 10 and got["body_model"] == 10, got            # head box may be empty at this size; then it is dropped
+    out["body_head_D_step"] = [lg.item(), ld.item(), got]
     return out
 
 
@@ -644,7 +656,59 @@ def check_reference_shape_tests():
         outs = D(torch.rand(4, 6, 512, 512, device=DEV))
     torch.cuda.synchronize()
     assert tuple(outs[0].shape) == (4, 1, 30, 30), outs[0].shape
-    return {"patch_map": list(outs[0].shape)}
+    # test_discriminators.py:81-175: the composed discriminators through the factory, dict inputs, with / without the aug-bg branch
+    del D, F_
+    from ipercore_amd.synthetic import AttrDict
+    dcfg = AttrDict(cond_nc=6, bg_cond_nc=4, ndf=64, n_layers=4, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    x, bg_x = torch.rand(4, 6, 512, 512, device=DEV), torch.rand(4, 4, 512, 512, device=DEV)
+    rects = torch.tensor([[100, 400, 50, 500]] * 4)
+    heads = torch.tensor([[200, 300, 60, 160]] * 4)
+    shapes = {}
+    for name, want in (("patch_global", [(4, 1, 30, 30)]), ("patch_global_local", [(4, 1, 30, 30), (4, 1, 14, 14)]),
+                       ("patch_global_body_head", [(4, 1, 30, 30), (4, 1, 14, 14), (4, 1, 6, 6)])):
+        for aug in (False, True):
+            Dn = NetworksFactory.get_by_name(name, dcfg, use_aug_bg=aug).to(DEV)
+            with torch.no_grad():
+                outs, avg = Dn({"x": x, "bg_x": bg_x, "body_rects": rects, "head_rects": heads, "get_avg": True})
+            got = [tuple(o.shape) for o in outs]
+            exp = want + [(4, 1, 30, 30)] if (aug and name == "patch_global") else ([(4, 1, 30, 30)] if aug else []) + want
+            assert got == exp, (name, aug, got, exp)
+            assert torch.isfinite(avg).item()
+            shapes[f"{name}{'+bg' if aug else ''}"] = [list(g) for g in got]
+            del Dn
+    torch.cuda.synchronize()
+    return {"patch_maps": shapes}
+
+
+def check_discriminator_variants():
+    """patch_global_body_head with the augmented-background branch (multi_scale_dis.py:194-284; crop_img :21-44, reduce_tensor
+    :9-18): every output map, the average and the input gradient against the reference architecture rebuilt with F.conv2d /
+    InstanceNorm2d on the CPU from the same weights; one degenerate head box is dropped as the reference drops it."""
+    from ipercore_amd.trainers import create_discriminator, crop_img
+    from ipercore_amd.synthetic import AttrDict
+    dcfg = AttrDict(cond_nc=6, bg_cond_nc=4, ndf=32, n_layers=3, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    torch.manual_seed(3)
+    D = create_discriminator("patch_global_body_head", dcfg, use_aug_bg=True).to(DEV)
+    refs = {k: _ref_patch_discriminator(getattr(D, k)) for k in ("global_model", "body_model", "head_model", "bg_model")}
+    S = 256
+    x, bg_x = _rand((2, 6, S, S), 611), _rand((2, 4, S, S), 612)
+    body = torch.tensor([[40, 200, 20, 250], [60, 180, 10, 230]])
+    head = torch.tensor([[100, 160, 20, 90], [120, 120, 30, 80]])                      # the second one is degenerate (min_x == max_x)
+    xr = x.clone().requires_grad_(True)
+    outs_r = [refs["bg_model"](bg_x), refs["global_model"](xr), refs["body_model"](crop_img(xr, body, 2)), refs["head_model"](crop_img(xr, head, 4))]
+    sum((o ** 2).mean() for o in outs_r).backward()
+    xd = x.to(DEV).requires_grad_(True)
+    outs, avg = D({"x": xd, "bg_x": bg_x.to(DEV), "body_rects": body, "head_rects": head, "get_avg": True})
+    sum((o ** 2).mean() for o in outs).backward()
+    torch.cuda.synchronize()
+    assert [tuple(o.shape) for o in outs] == [tuple(o.shape) for o in outs_r], [o.shape for o in outs]
+    assert outs[3].shape[0] == 1
+    errs = [float((a.detach().cpu() - b.detach()).abs().max()) for a, b in zip(outs, outs_r)]
+    avg_r = sum(o.detach().mean() for o in outs_r) / 4
+    gerr = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    out = {"max_abs_err": errs, "avg": avg.item(), "avg_ref": avg_r.item(), "rel_grad_err": gerr}
+    assert max(errs) <= 2e-4 and abs(avg.item() - avg_r.item()) <= 1e-5 and gerr <= 2e-3, out
+    return out
 
 
 def check_vgg_loss():
@@ -1017,7 +1081,8 @@ def check_generator_training_grads():
 def _ref_patch_discriminator(D):
     """The reference's PatchDiscriminator (patch_dis.py:8-70, norm_type='instance') rebuilt on the CPU with D's weights."""
     import torch.nn as nn
-    L = D.global_model.model
+    D = getattr(D, "global_model", D)
+    L = D.model
     seq, names = [], D.layer_names
     for i, name in enumerate(names):
         w = getattr(L, name).weight.detach().cpu()
@@ -1336,4 +1401,4 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render]
+       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants]

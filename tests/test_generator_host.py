@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from ipercore_amd import synthetic
 from ipercore_amd.networks import NetworksFactory, generator_param_shapes
@@ -152,3 +153,39 @@ def _cpu_ok(fwd):
         with um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True):
             return fwd(ctx, x0, x1, weight, bias, cfg)
     return wrapped
+
+
+def test_discriminator_variants_host_logic(monkeypatch):
+    """multi_scale_dis.py:47-284 host side: sub-network inventory / parameter names, output order (bg, global, body, head; global
+    first for patch_global), crop_img's resize and its dropping of degenerate boxes, reduce_tensor - with the sub-networks stubbed
+    (their convolutions are GPU checks)."""
+    from ipercore_amd import trainers as T
+    from ipercore_amd.synthetic import AttrDict
+    cfg = AttrDict(cond_nc=6, bg_cond_nc=4, ndf=16, n_layers=4, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    D = NetworksFactory.get_by_name("patch_global_body_head", cfg, use_aug_bg=True)
+    keys = list(D.state_dict().keys())
+    assert len(keys) == 48 and all(f"{m}.model.{i}.{p}" in keys for m in ("global_model", "body_model", "head_model", "bg_model")
+                                   for i in (0, 2, 5, 8, 11, 14) for p in ("weight", "bias"))
+    assert tuple(D.bg_model.model.__getattr__("0").weight.shape) == (16, 4, 4, 4) and tuple(D.head_model.model.__getattr__("14").weight.shape) == (1, 128, 4, 4)
+    seen = []
+
+    def stub(self, x):
+        seen.append((self.input_nc, tuple(x.shape)))
+        return x.mean(dim=1, keepdim=True)
+    monkeypatch.setattr(T.PatchDiscriminator, "forward", stub)
+    x, bg = torch.rand(3, 6, 64, 64), torch.rand(3, 4, 64, 64)
+    body = torch.tensor([[4, 40, 2, 60], [8, 8, 0, 30], [0, 64, 0, 64]])
+    head = torch.tensor([[10, 30, 2, 20], [12, 28, 4, 4], [5, 5, 0, 9]])
+    outs, avg = D({"x": x, "bg_x": bg, "body_rects": body, "head_rects": head, "get_avg": True})
+    assert seen == [(4, (3, 4, 64, 64)), (6, (3, 6, 64, 64)), (6, (2, 6, 32, 32)), (6, (1, 6, 16, 16))]
+    assert abs(avg.item() - sum(o.mean().item() for o in outs) / 4) < 1e-6
+    ref = F.interpolate(x[0:1, :, 2:60, 4:40], size=(32, 32), mode="bilinear", align_corners=True)
+    assert torch.equal(T.crop_img(x, body, 2)[0:1], ref)
+    assert len(T.crop_img(x, torch.tensor([[1, 1, 0, 5]] * 3), 2)) == 0
+    G1 = NetworksFactory.get_by_name("patch_global", cfg, use_aug_bg=True)
+    outs = G1({"x": x, "bg_x": bg, "get_avg": False})
+    assert [o.shape[1] for o in outs] == [1, 1] and torch.equal(outs[0], x.mean(dim=1, keepdim=True))     # [global, bg]
+    outs = G1(x)                                                                                           # the trainer's tensor form
+    assert len(outs) == 1
+    with pytest.raises(ValueError):
+        NetworksFactory.get_by_name("multi_scale", cfg)
