@@ -94,9 +94,10 @@ class ConvFn(torch.autograd.Function):
             dx = None
             if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                 pad = kh // 2 if cfg.pad is None else cfg.pad            # the dgrad panel sees the padded channel counts
-                dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(weight, cfg.stride, pad, n_pad=Np, cin_pad=Cin_packed)]
+                Cd = (Cin_packed + 63) // 64 * 64                        # GEMM columns of the dgrad launch: the kernel's granularity is 64
+                dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(weight, cfg.stride, pad, n_pad=Np, cin_pad=Cd)]
                 B, H, W, _ = x0.shape
-                dx = torch.empty(B, H, W, Cin_packed, device=dev, dtype=torch.float32)
+                dx = torch.empty(B, H, W, Cd, device=dev, dtype=torch.float32)
                 if cfg.stride == 1:
                     ops.conv2d(dy, dspecs[0], dx)
                 else:
@@ -118,7 +119,7 @@ class ConvFn(torch.autograd.Function):
         if dx is not None:
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
             if ctx.has_x1:
-                dx1 = dx[..., C0:]
+                dx1 = dx[..., C0:C0 + x1.shape[3]]
         return dx0, dx1, dw, db, None
 
 

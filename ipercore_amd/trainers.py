@@ -42,6 +42,8 @@ class PatchDiscriminator(nn.Module):
         super().__init__()
         if norm_type != "instance" or use_sigmoid:
             raise NotImplementedError("only norm_type='instance', use_sigmoid=False (deploy.toml / AttLWB-SPADE.toml) are built")
+        if ndf % 32:
+            raise ValueError("ndf must be a multiple of 32 (channel granularity of the MFMA conv kernels)")
         chans = [input_nc, ndf]
         for n in range(1, n_layers):
             chans.append(ndf * min(2 ** n, max_nf_mult))
@@ -73,10 +75,11 @@ class PatchDiscriminator(nn.Module):
         for i, name in enumerate(self.layer_names):
             layer = getattr(self.model, name)
             stride = 2 if i < self.n_layers else 1
+            npad = None if layer.weight.shape[0] % 64 == 0 else (layer.weight.shape[0] + 63) // 64 * 64
             if i == 0:
-                x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=cp, need_dx=False), 0.2)
+                x = F.leaky_relu(conv(x, layer.weight, layer.bias, stride=stride, pad=1, cin_pad=cp, n_pad=npad), 0.2)   # dX only when the input asks for it: G's adversarial term
             elif i < n - 1:
-                x = instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1), ops.ACT_LRELU)
+                x = instance_norm(conv(x, layer.weight, layer.bias, stride=stride, pad=1, n_pad=npad), ops.ACT_LRELU)
             else:
                 x = conv(x, layer.weight, layer.bias, stride=stride, pad=1, n_pad=64)
         return x.permute(0, 3, 1, 2)

@@ -31,6 +31,12 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
     B, H, W, Cin = x.shape
     assert Cin == spec.Cin
     YB, YH, YW, YC = y.shape
+    # the argument contract lwg_conv2d_nhwc_f32 enforces on the host (csrc/conv_igemm.hip, hipErrorInvalidValue otherwise)
+    assert spec.N % 64 == 0 and Cin % 4 == 0 and YC % 4 == 0 and ycoff % 4 == 0, (spec.N, Cin, YC, ycoff)
+    if Cin % 32:
+        assert x1 is None and Cin <= 16 and Cin & (Cin - 1) == 0 and epi == 0, Cin
+    elif x1 is not None:
+        assert x0.shape[3] % 32 == 0
     if out_hw is None:
         OH, OW = (YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul)
     else:
@@ -69,6 +75,11 @@ def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
     x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
     B, H, W, Cin = x.shape
     YB, YH, YW, YC = dy.shape
+    assert spec.N % 4 == 0 and Cin % 4 == 0 and YC % 4 == 0 and ycoff % 4 == 0       # lwg_conv2d_wgrad_nhwc_f32's host contract
+    if Cin % 32:
+        assert x1 is None and Cin <= 16 and Cin & (Cin - 1) == 0, Cin
+    elif x1 is not None:
+        assert x0.shape[3] % 32 == 0
     OH, OW = out_hw if out_hw is not None else ((YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul))
     ys = slice(spec.ooy, None, spec.omul) if spec.omul > 1 else slice(None)
     xs = slice(spec.oox, None, spec.omul) if spec.omul > 1 else slice(None)

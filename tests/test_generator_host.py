@@ -144,6 +144,18 @@ def test_training_conv_packing_cpu(monkeypatch):
         for name, a_, r_ in (("y", y, yr.permute(0, 2, 3, 1)), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
             err = (a_.detach() - r_.detach()).abs().max().item()
             assert err <= 1e-4 * max(1.0, r_.abs().max().item()), (kind, k, stride, name, err)
+    # a first layer that hands back dX (the discriminator under G's adversarial term): 6 real channels zero-extended to 8,
+    # 32 output channels zero-extended to 64, dgrad columns 8 -> 64
+    w, b, x = rnd(32, 6, 4, 4) * 0.1, rnd(32) * 0.1, rnd(1, 8, 8, 8)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr[..., :6].permute(0, 3, 1, 2), wr, b, stride=2, padding=1).permute(0, 2, 3, 1)
+    g = rnd(*yr.shape)
+    (yr * g).sum().backward()
+    xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = tr.conv(xd, wd, b, stride=2, pad=1, cin_pad=8, n_pad=64)
+    (y * g).sum().backward()
+    assert y.shape == yr.shape and (y - yr).abs().max().item() <= 1e-5
+    assert (xd.grad - xr.grad).abs().max().item() <= 1e-5 and (wd.grad - wr.grad).abs().max().item() <= 1e-4
 
 
 def _cpu_ok(fwd):
@@ -161,12 +173,12 @@ def test_discriminator_variants_host_logic(monkeypatch):
     (their convolutions are GPU checks)."""
     from ipercore_amd import trainers as T
     from ipercore_amd.synthetic import AttrDict
-    cfg = AttrDict(cond_nc=6, bg_cond_nc=4, ndf=16, n_layers=4, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    cfg = AttrDict(cond_nc=6, bg_cond_nc=4, ndf=32, n_layers=4, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
     D = NetworksFactory.get_by_name("patch_global_body_head", cfg, use_aug_bg=True)
     keys = list(D.state_dict().keys())
     assert len(keys) == 48 and all(f"{m}.model.{i}.{p}" in keys for m in ("global_model", "body_model", "head_model", "bg_model")
                                    for i in (0, 2, 5, 8, 11, 14) for p in ("weight", "bias"))
-    assert tuple(D.bg_model.model.__getattr__("0").weight.shape) == (16, 4, 4, 4) and tuple(D.head_model.model.__getattr__("14").weight.shape) == (1, 128, 4, 4)
+    assert tuple(D.bg_model.model.__getattr__("0").weight.shape) == (32, 4, 4, 4) and tuple(D.head_model.model.__getattr__("14").weight.shape) == (1, 256, 4, 4)
     seen = []
 
     def stub(self, x):
