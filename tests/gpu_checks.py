@@ -1109,11 +1109,14 @@ def check_discriminator_and_trainer_step():
     xr = x.clone().requires_grad_(True)
     out_r = ref(xr)
     (out_r ** 2).mean().backward()
-    xd = x.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
     out = D(xd)[0]
     (out ** 2).mean().backward()
     torch.cuda.synchronize()
     m = {"d_out": _cmp(out, out_r.detach(), 2e-4, "D logits")}
+    # the gradient the generator receives through D (its adversarial term, lwg_trainer.py:755-768)
+    m["d_input_rel_grad_err"] = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    assert m["d_input_rel_grad_err"] <= 2e-3, m
     convs = [mod for mod in ref if isinstance(mod, torch.nn.Conv2d)]
     worst = 0.0
     gmax = max(c.weight.grad.abs().max().item() for c in convs)
