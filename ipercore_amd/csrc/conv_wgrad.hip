@@ -257,6 +257,41 @@ __global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nspl
     }
 }
 
+// Few elements, many slabs (bias column sums: C <= 1024 elements over up to 512 row blocks; the weight gradient of a 1x1 conv:
+// 4096 elements over 512 splits): with one thread per element each thread walks all slabs through dependent loads (120 us for
+// 512 slabs).  G lanes share an element - lane g adds slabs g, g + G, ... - and a fixed-order LDS pass adds the G partial sums
+// (deterministic: the association depends only on (nsplit, G)).
+template <int G>
+__global__ __launch_bounds__(256) void lwg_slab_reduce_g_kernel(const float* __restrict__ part, int nsplit, size_t total,
+                                                                float* __restrict__ out) {
+    constexpr int EPB = 256 / G;                                   // elements per block
+    __shared__ float sh[256];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    const size_t i = (size_t)blockIdx.x * EPB + e;
+    float s = 0.f;
+    if (i < total)
+        for (int k = g; k < nsplit; k += G) s += part[(size_t)k * total + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < total) {
+        float t = sh[e];
+#pragma unroll
+        for (int j = 1; j < G; ++j) t += sh[j * EPB + e];
+        out[i] = t;
+    }
+}
+
+static void lwg_launch_slab_reduce(const float* part, int nsplit, size_t total, float* out, hipStream_t stream) {
+    if (total < 65536 && nsplit >= 64) {
+        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, total, out);
+    } else if (total < 65536 && nsplit >= 16) {
+        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, total, out);
+    } else {
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, total, out);
+    }
+}
+
 // Column sums of an NHWC tensor viewed as (rows, C): out[c] = sum_r x[r, c] (bias gradients).  Two deterministic passes.
 // C % 4 == 0: a lane owns four consecutive channels (16-byte loads), C/4 lanes cover a row, 256 / (C/4) rows per pass;
 // up to 512 row blocks keep every CU streaming (the first version used 64 blocks of 4-byte loads: 2.4 TB/s).
@@ -342,9 +377,7 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
     static unsigned long long attr_done[2] = {0ull, 0ull};
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[smallc]); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
-    const size_t total = (size_t)Ktot * a.N;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, total, dw);
+    lwg_launch_slab_reduce(ws, splits, (size_t)Ktot * a.N, dw, stream);
     return (int)hipGetLastError();
 }
 
@@ -356,12 +389,12 @@ extern "C" int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* ou
         const int nblk = rows >= 512 * 64 ? 512 : (int)((rows + 63) / 64);      // ws holds nblk * C floats (callers size it 512 * C)
         const int rpb = (int)((rows + nblk - 1) / nblk);
         hipLaunchKernelGGL(lwg_colsum_partial4_kernel, dim3(nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
-        hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nblk, (size_t)C, out);
+        lwg_launch_slab_reduce(ws, nblk, (size_t)C, out, stream);
         return (int)hipGetLastError();
     }
     const int nblk = rows >= 64 * 64 ? 64 : (int)((rows + 63) / 64);
     const int rpb = (int)((rows + nblk - 1) / nblk);
     hipLaunchKernelGGL(lwg_colsum_partial_kernel, dim3((C + 63) / 64, nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
-    hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nblk, (size_t)C, out);
+    lwg_launch_slab_reduce(ws, nblk, (size_t)C, out, stream);
     return (int)hipGetLastError();
 }

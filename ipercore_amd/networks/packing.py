@@ -192,6 +192,14 @@ def wgrad_to_conv(dwk, ntaps, cin_packed, cin, n, kh, kw):
     return unpack_wgrad(dwk, ntaps, cin_packed)[:, :cin, :n].reshape(kh, kw, cin, n).permute(3, 2, 0, 1).contiguous()
 
 
+def wgrad_thin_to_conv(dwk, kh, kw, ns, n, cin):
+    """Weight gradient of the thin backward form (training.ConvFn._backward_thin): (kh*kw*ns, Cd) rows k = tap * ns + n
+    (the small-Cin K order), columns = input channels -> nn.Conv2d gradient (N, Cin, kh, kw)."""
+    if dwk.is_cuda:
+        return ops.unpack_wgrad(dwk, torch.empty(n, cin, kh, kw, device=dwk.device, dtype=torch.float32), True, range(kh * kw), n, ns, cin)
+    return dwk.view(kh, kw, ns, dwk.shape[1])[:, :, :n, :cin].permute(2, 3, 0, 1).contiguous()
+
+
 def wgrad_to_conv_transpose(dwks, cin, n):
     """Four parity gradients (each (4*Cin, Np) in kernel order, taps as in pack_conv_transpose) -> (Cin, N, 4, 4)."""
     if dwks[0].is_cuda:

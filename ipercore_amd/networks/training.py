@@ -65,6 +65,9 @@ class ConvFn(torch.autograd.Function):
                 ops.conv2d(x0, s, y, act=cfg.act)
         ctx.cfg, ctx.specs, ctx.N, ctx.has_bias = cfg, specs, N, bias is not None
         ctx.has_x1 = x1 is not None
+        # a regressor (3 / 4 / 1 output channels zero-extended to 64): its backward runs on the thin forms below
+        ctx.thin = (cfg.kind == "conv" and cfg.stride == 1 and N <= 16 and x1 is None and cfg.act == _NONE and specs[0].Cin % 64 == 0
+                    and specs[0].Cin == x0.shape[3])
         ctx.save_for_backward(x0, x1, weight, y if cfg.act == _RELU else None)
         return y if y.shape[3] == N else y[..., :N]
 
@@ -74,6 +77,8 @@ class ConvFn(torch.autograd.Function):
         cfg, specs, N = ctx.cfg, ctx.specs, ctx.N
         Np = specs[0].N
         dy = dy.contiguous()
+        if ctx.thin:
+            return ConvFn._backward_thin(ctx, x0, weight, dy)
         if Np != N:                                                   # zero-extended output channels carry no gradient
             full = dy.new_zeros(dy.shape[0], dy.shape[1], dy.shape[2], Np)
             full[..., :N] = dy
@@ -121,6 +126,36 @@ class ConvFn(torch.autograd.Function):
             if ctx.has_x1:
                 dx1 = dx[..., C0:C0 + x1.shape[3]]
         return dx0, dx1, dw, db, None
+
+
+def _backward_thin(ctx, x0, weight, dy):
+    """Backward of a stride-1 conv with N <= 16 outputs WITHOUT the zero-extension to 64 columns the forward launch needed
+    (the 5x5 / 7x7 image and mask regressors at full resolution: 16x fewer MFMA flops than the padded forms).
+    dY is zero-extended to Ns = 4 / 8 / 16 channels only and becomes the INPUT of a small-Cin convolution with negated taps:
+      dX = that conv of dY (the forward kernel's K-slot path, K = taps * Ns),
+      dW = that conv's weight gradient with x in the role of the output gradient:
+           dW'[(tap, n)][c] = sum_q dY[q - tap][n] x[q][c] = sum_p x[p + tap][c] dY[p][n]  - the forward conv's dW[n][c][tap]."""
+    cfg, N = ctx.cfg, ctx.N
+    Nw, Cin, kh, kw = weight.shape
+    Ns = 4 if N <= 4 else (8 if N <= 8 else 16)
+    if Ns != N:
+        dy = F.pad(dy, (0, Ns - N))
+    db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+    want_dx = cfg.need_dx and ctx.needs_input_grad[0]
+    dx = dw = None
+    if want_dx or ctx.needs_input_grad[2]:
+        pad = kh // 2 if cfg.pad is None else cfg.pad
+        Cd = x0.shape[3]
+        dspec = packing.spec_to(packing.pack_dgrad_conv(weight, 1, pad, n_pad=Ns, cin_pad=Cd)[0], dy.device)
+        if want_dx:
+            dx = torch.empty(x0.shape, device=dy.device, dtype=torch.float32)
+            ops.conv2d(dy, dspec, dx)
+        if ctx.needs_input_grad[2]:
+            dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, Ns, N, Cin)
+    return dx, None, dw, db, None
+
+
+ConvFn._backward_thin = staticmethod(_backward_thin)
 
 
 def conv(x0, weight, bias=None, x1=None, **kw):

@@ -126,7 +126,10 @@ def test_training_conv_packing_cpu(monkeypatch):
     cases = [("conv", 2, 8, 8, 64, 64, 3, 1, 1, 0, 1, None), ("conv", 1, 8, 8, 64, 128, 3, 2, 1, 0, 1, None),
              ("conv", 1, 6, 6, 96, 64, 3, 1, 1, 32, 0, None), ("convT", 1, 4, 4, 64, 64, 4, 2, 1, 0, 1, None),
              ("conv", 1, 8, 8, 64, 4, 5, 1, 2, 0, 0, 64), ("conv", 1, 8, 8, 64, 64, 4, 2, 1, 0, 0, None),
-             ("conv", 1, 9, 9, 64, 64, 4, 1, 1, 0, 0, None)]
+             ("conv", 1, 9, 9, 64, 64, 4, 1, 1, 0, 0, None), ("conv", 2, 8, 8, 64, 3, 7, 1, 3, 0, 0, 64)]
+    thin_calls = []
+    orig_thin = tr.ConvFn._backward_thin
+    monkeypatch.setattr(tr.ConvFn, "_backward_thin", staticmethod(lambda *a: (thin_calls.append(1), orig_thin(*a))[1]))
     for kind, B, H, W, Cin, N, k, stride, pad, C1, act, n_pad in cases:
         w = rnd(*((N, Cin, k, k) if kind == "conv" else (Cin, N, 4, 4))) * 0.1
         b = rnd(N) * 0.1
@@ -144,6 +147,7 @@ def test_training_conv_packing_cpu(monkeypatch):
         for name, a_, r_ in (("y", y, yr.permute(0, 2, 3, 1)), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
             err = (a_.detach() - r_.detach()).abs().max().item()
             assert err <= 1e-4 * max(1.0, r_.abs().max().item()), (kind, k, stride, name, err)
+    assert len(thin_calls) == 2          # the two regressor shapes (N = 4 and 3) took the thin backward forms
     # a first layer that hands back dX (the discriminator under G's adversarial term): 6 real channels zero-extended to 8,
     # 32 output channels zero-extended to 64, dgrad columns 8 -> 64
     w, b, x = rnd(32, 6, 4, 4) * 0.1, rnd(32) * 0.1, rnd(1, 8, 8, 8)
