@@ -128,30 +128,34 @@ class ConvFn(torch.autograd.Function):
         return dx0, dx1, dw, db, None
 
 
-def _backward_thin(ctx, x0, weight, dy):
-    """Backward of a stride-1 conv with N <= 16 outputs WITHOUT the zero-extension to 64 columns the forward launch needed
+def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
+    """Backward of a stride-1 conv with N <= 16 outputs WITHOUT the zero-extension to 64 columns a forward MFMA launch needs
     (the 5x5 / 7x7 image and mask regressors at full resolution: 16x fewer MFMA flops than the padded forms).
-    dY is zero-extended to Ns = 4 / 8 / 16 channels only and becomes the INPUT of a small-Cin convolution with negated taps:
+    dy (B,H,W,Ns), Ns = 4 / 8 / 16 >= N, becomes the INPUT of a small-Cin convolution with negated taps:
       dX = that conv of dY (the forward kernel's K-slot path, K = taps * Ns),
       dW = that conv's weight gradient with x in the role of the output gradient:
            dW'[(tap, n)][c] = sum_q dY[q - tap][n] x[q][c] = sum_p x[p + tap][c] dY[p][n]  - the forward conv's dW[n][c][tap]."""
+    N, Cin, kh, kw = weight.shape
+    dx = dw = None
+    if want_dx or want_dw:
+        dspec = packing.spec_to(packing.pack_dgrad_conv(weight, 1, pad, n_pad=dy.shape[3], cin_pad=x0.shape[3])[0], dy.device)
+        if want_dx:
+            dx = torch.empty(x0.shape, device=dy.device, dtype=torch.float32)
+            ops.conv2d(dy, dspec, dx)
+        if want_dw:
+            dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, dy.shape[3], N, Cin)
+    return dx, dw
+
+
+def _backward_thin(ctx, x0, weight, dy):
     cfg, N = ctx.cfg, ctx.N
-    Nw, Cin, kh, kw = weight.shape
     Ns = 4 if N <= 4 else (8 if N <= 8 else 16)
     if Ns != N:
         dy = F.pad(dy, (0, Ns - N))
     db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-    want_dx = cfg.need_dx and ctx.needs_input_grad[0]
-    dx = dw = None
-    if want_dx or ctx.needs_input_grad[2]:
-        pad = kh // 2 if cfg.pad is None else cfg.pad
-        Cd = x0.shape[3]
-        dspec = packing.spec_to(packing.pack_dgrad_conv(weight, 1, pad, n_pad=Ns, cin_pad=Cd)[0], dy.device)
-        if want_dx:
-            dx = torch.empty(x0.shape, device=dy.device, dtype=torch.float32)
-            ops.conv2d(dy, dspec, dx)
-        if ctx.needs_input_grad[2]:
-            dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, Ns, N, Cin)
+    kh = weight.shape[2]
+    dx, dw = thin_backward(x0, weight, dy, kh // 2 if cfg.pad is None else cfg.pad, cfg.need_dx and ctx.needs_input_grad[0],
+                           ctx.needs_input_grad[2])
     return dx, None, dw, db, None
 
 
@@ -160,6 +164,31 @@ ConvFn._backward_thin = staticmethod(_backward_thin)
 
 def conv(x0, weight, bias=None, x1=None, **kw):
     return ConvFn.apply(x0, x1, weight, bias, ConvCfg(**kw))
+
+
+class HeadFn(torch.autograd.Function):
+    """img = tanh(conv5x5(x, w_img)), mask = sigmoid(conv5x5(x, w_att)) (attlwb_spade_resunet.py:375-384, 604-613; no bias) on
+    the inference path's fused regressor kernel (csrc/head.hip: 4 output channels per pixel on the vector ALUs instead of an
+    MFMA launch zero-extended to 64 columns); backward = the activations' derivatives + ``thin_backward``.
+    x (B,S,S,C) NHWC -> img (B,3,S,S), mask (B,1,S,S) NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, w_img, w_att):
+        if not x.is_cuda:
+            raise RuntimeError("ipercore_amd training ops run on the MI355X only (no CPU fallback)")
+        x = x.contiguous()
+        _, mask, img = ops.head_compose(x, packing.pack_head(w_img, w_att).to(x.device), None, want_pred=False, want_mask=True, want_img=True)
+        ctx.save_for_backward(x, w_img, w_att, img, mask)
+        return img, mask
+
+    @staticmethod
+    def backward(ctx, dimg, dmask):
+        x, w_img, w_att, img, mask = ctx.saved_tensors
+        dpre = torch.cat([dimg * (1.0 - img * img), dmask * (mask * (1.0 - mask))], dim=1)            # (B,4,S,S)
+        dy = ops.nchw_to_nhwc(dpre, c_pad=4)
+        dx, dw = thin_backward(x, torch.cat([w_img, w_att], dim=0).detach(), dy, 2, ctx.needs_input_grad[0],
+                               ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, None if dw is None else dw[:3], None if dw is None else dw[3:4]
 
 
 # ---------------------------------------------------------------------------------------------- NHWC glue (autograd)
@@ -276,10 +305,9 @@ class TrainableGenerator(object):
         return x + self.cv(pfx + ".main.2", self.cv(pfx + ".main.0", x, act=_RELU))
 
     def head(self, img_name, att_name, x):
-        """The two 5x5 regressors as ONE conv with 4 (zero-extended to 64) output columns."""
-        w = torch.cat([self.p(img_name).weight, self.p(att_name).weight], dim=0)
-        y = conv(x, w, None, pad=2, n_pad=64)
-        return torch.tanh(y[..., 0:3]), torch.sigmoid(y[..., 3:4])
+        """The two 5x5 regressors with their tanh / sigmoid: one fused launch (``HeadFn``); NHWC views of its NCHW outputs."""
+        img, mask = HeadFn.apply(x, self.p(img_name).weight, self.p(att_name).weight)
+        return img.permute(0, 2, 3, 1), mask.permute(0, 2, 3, 1)
 
     # -- the three branches (NHWC in / out)
     def forward_bg(self, bg4):

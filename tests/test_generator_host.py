@@ -160,6 +160,21 @@ def test_training_conv_packing_cpu(monkeypatch):
     (y * g).sum().backward()
     assert y.shape == yr.shape and (y - yr).abs().max().item() <= 1e-5
     assert (xd.grad - xr.grad).abs().max().item() <= 1e-5 and (wd.grad - wr.grad).abs().max().item() <= 1e-4
+    # the fused regressor pair (HeadFn: csrc/head.hip forward, thin backward forms) against tanh / sigmoid of F.conv2d
+    import unittest.mock as um
+    x, wi, wa = rnd(2, 12, 12, 64), rnd(3, 64, 5, 5) * 0.05, rnd(1, 64, 5, 5) * 0.05
+    xr, wir, war = (t.clone().requires_grad_(True) for t in (x, wi, wa))
+    xn = xr.permute(0, 3, 1, 2)
+    ir, mr = torch.tanh(F.conv2d(xn, wir, padding=2)), torch.sigmoid(F.conv2d(xn, war, padding=2))
+    gi, gm = rnd(*ir.shape), rnd(*mr.shape)
+    ((ir * gi).sum() + (mr * gm).sum()).backward()
+    xd, wid, wad = (t.clone().requires_grad_(True) for t in (x, wi, wa))
+    with um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True):
+        img, mask = tr.HeadFn.apply(xd, wid, wad)
+    ((img * gi).sum() + (mask * gm).sum()).backward()
+    for name, a_, r_ in (("img", img, ir), ("mask", mask, mr), ("dx", xd.grad, xr.grad), ("dw_img", wid.grad, wir.grad), ("dw_att", wad.grad, war.grad)):
+        err = (a_.detach() - r_.detach()).abs().max().item()
+        assert err <= 1e-4 * max(1.0, r_.abs().max().item()), (name, err)
 
 
 def _cpu_ok(fwd):
