@@ -99,43 +99,39 @@ __global__ __launch_bounds__(256) void lwg_in_stats_partial4(const float* __rest
     }
 }
 
-// Pass 2: the nsplit partial records of 4 channels are fetched by 256 lanes at once (lane = (channel, split)), then one
-// lane per channel folds them in split order with Chan's update (sequential by construction, now on LDS latency).
+// Pass 2: one wave per (image, channel), lane = split.  The nsplit <= 64 partial records (count, mean, M2) are merged with Chan's
+// pairwise update as a fixed-shape shuffle tree (6 rounds; the first version folded them sequentially in one lane: 64 dependent
+// divisions, 15 us per launch and 54 launches per frame batch).  Deterministic: the tree depends on nsplit only.
 __global__ __launch_bounds__(256) void lwg_in_stats_final(const float* __restrict__ ws, int BC, int C, int nsplit, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd) {
-    __shared__ float sh[4][64][3];
     const int ch = threadIdx.x >> 6, sp = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + ch;
+    if (i >= BC) return;                                         // wave-uniform
     const int b = i / C, c = i - b * C;
-    if (i < BC && sp < nsplit && nsplit <= 64) {  // nsplit <= 64 on every call site; larger values take the direct path
-        const float* o = ws + (((size_t)b * nsplit + sp) * C + c) * 3;
-        sh[ch][sp][0] = o[0]; sh[ch][sp][1] = o[1]; sh[ch][sp][2] = o[2];
-    }
-    __syncthreads();
-    if (sp != 0 || i >= BC) return;
     float n = 0.f, mu = 0.f, m2 = 0.f;
-    if (nsplit <= 64) {
-        for (int s = 0; s < nsplit; ++s) {
-            const float nb = sh[ch][s][0];
-            if (nb <= 0.f) continue;
-            const float tot = n + nb, delta = sh[ch][s][1] - mu;
-            mu += delta * (nb / tot);
-            m2 += sh[ch][s][2] + delta * delta * (n * nb / tot);
-            n = tot;
-        }
-    } else {
-        for (int s = 0; s < nsplit; ++s) {
-            const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 3;
-            const float nb = o[0];
-            if (nb <= 0.f) continue;
-            const float tot = n + nb, delta = o[1] - mu;
-            mu += delta * (nb / tot);
-            m2 += o[2] + delta * delta * (n * nb / tot);
+    for (int s = sp; s < nsplit; s += 64) {                      // one record per lane on every call site (nsplit <= 64)
+        const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 3;
+        const float nb = o[0];
+        if (nb <= 0.f) continue;
+        const float tot = n + nb, delta = o[1] - mu, r = nb / tot;
+        mu += delta * r;
+        m2 += o[2] + delta * delta * (n * r);
+        n = tot;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float nb = __shfl_down(n, off, 64), mub = __shfl_down(mu, off, 64), m2b = __shfl_down(m2, off, 64);
+        if (nb > 0.f) {
+            const float tot = n + nb, delta = mub - mu, r = nb / tot;
+            mu += delta * r;
+            m2 += m2b + delta * delta * (n * r);
             n = tot;
         }
     }
-    mean[i] = mu;
-    rstd[i] = 1.0f / sqrtf(m2 / n + eps);
+    if (sp == 0) {
+        mean[i] = mu;
+        rstd[i] = 1.0f / sqrtf(m2 / n + eps);
+    }
 }
 
 __global__ __launch_bounds__(256) void lwg_in_apply(const floatx4* __restrict__ x, const float* __restrict__ mean,

@@ -604,7 +604,16 @@ class LWGTrainer(object):
         tsf_cond = i["input_G_tsf"][:, :, -3:].reshape(bs * nt, 3, h, w)
         fake_in = torch.cat([fake_tsf_imgs.detach().view(bs * nt, c, h, w), tsf_cond], dim=1)
         real_in = torch.cat([i["real_tsf"].reshape(bs * nt, c, h, w), tsf_cond], dim=1)
-        d_real, d_fake = self.D(self._d_inputs(real_in)), self.D(self._d_inputs(fake_in))
+        # real and fake ride through D as ONE batch (its InstanceNorm is per sample, so the logits are those of two separate
+        # calls; the deep layers of D have M = 31^2 rows per sample - two samples fill twice the workgroups per launch)
+        n = real_in.shape[0]
+        both = self._d_inputs(torch.cat([real_in, fake_in], dim=0))
+        for k in ("body_rects", "head_rects"):
+            if both[k] is not None:
+                both[k] = torch.cat([torch.as_tensor(both[k])] * 2, dim=0)
+        outs = self.D(both)
+        d_real, d_fake = [o[:o.shape[0] // 2] for o in outs], [o[o.shape[0] // 2:] for o in outs]
+        assert outs[0].shape[0] == 2 * n
         self.losses.update(d_real=sum(o.mean() for o in d_real).detach(), d_fake=sum(o.mean() for o in d_fake).detach())
         return lsgan_loss(d_real, 1) + lsgan_loss(d_fake, -1)
 
@@ -615,10 +624,15 @@ class LWGTrainer(object):
 
     def _optimize_parameters(self):
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
+        d_params = [] if self.D is None else list(self.D.parameters())
+        for p in d_params:                                  # G's adversarial term needs D's data gradients only (the reference
+            p.requires_grad_(False)                         # computes, then discards, D's weight gradients here)
         loss_G = self.optimize_G(fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
+        for p in d_params:
+            p.requires_grad_(True)
         self.optimizer_G.zero_grad()
         self.optimizer_G.arm(self.group)
-        loss_G.backward()                                   # G's adversarial term also reaches D's leaves; zeroed below
+        loss_G.backward()
         self.optimizer_G.allreduce(self.group)
         self.optimizer_G.step()
         loss_D = None
