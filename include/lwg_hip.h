@@ -67,6 +67,12 @@ typedef struct LwgConvArgs {
 } LwgConvArgs;
 
 int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
+/* The same launch with an optional workspace: small-M / large-K launches (one training sample, the discriminator's deep layers:
+ * fewer 64x64 output tiles than the chip has room for) are split over K into lwg_conv2d_ws_floats(args) / (M*N) slices whose
+ * dense (M,N) slabs a finishing kernel adds in slice order (deterministic) before bias / activation / output geometry.
+ * lwg_conv2d_ws_floats returns 0 when the launch would not be split; ws = NULL runs it whole. */
+size_t lwg_conv2d_ws_floats(const LwgConvArgs* args);
+int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stream);
 
 /* bf16-operand variant (BASELINE configs[3], "MFMA bf16 conv tiles"): same contract, except that args->w is the bf16 panel
  * [ntaps*Cin/8][N][8] (same K order) and Cin % 32 == 0; activations stay fp32 in memory, are rounded to bf16 while staged

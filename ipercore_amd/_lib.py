@@ -41,6 +41,8 @@ _SIGS = {
     "lwg_abi_version": (c_i, []),
     "lwg_device_cu_count": (c_i, []),
     "lwg_conv2d_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
+    "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16mma": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),

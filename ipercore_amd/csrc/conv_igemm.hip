@@ -51,7 +51,7 @@ __device__ __forceinline__ floatx4 lwg_buf_load(const float* base, unsigned byte
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
-__global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArgs a) {
+__global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArgs a, const int split_chunks, float* __restrict__ slabs) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_ROW = (BM + 1) * 4;  // floats per k-quad row; +1 float4 pad => conflict-free b128 stores
     constexpr int B_ROW = BN * 4;
@@ -114,17 +114,21 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 4u;
     const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 4u;
     const int K4 = a.ntaps * (Cin >> 2);
-    const int nsteps = (K4 + 7) >> 3;
-    const unsigned wbytes = (unsigned)nsteps * 8u * a.N * 16u;
+    const int nsteps_all = (K4 + 7) >> 3;
+    const unsigned wbytes = (unsigned)nsteps_all * 8u * a.N * 16u;
+    // split-K (blockIdx.y = slice): this workgroup reduces the channel chunks [cc_first, cc_first + split_chunks) over all taps
+    // and leaves a dense slab; lwg_splitk_finish_kernel adds the slices.  split_chunks == 0: the whole K range, normal epilogue.
+    const int cc_first = (!SMALLC && split_chunks > 0) ? (int)blockIdx.y * split_chunks * 32 : 0;
+    const int nsteps = (!SMALLC && split_chunks > 0) ? (min(Cin - cc_first, split_chunks * 32) >> 5) * a.ntaps : nsteps_all;
 
     // ---- loader state: describes the K-step whose loads are issued next.  K runs channel-chunk major, tap minor
     // (k = ((c / 32) * ntaps + tap) * 32 + c % 32): consecutive steps gather the SAME 32 channels at neighbouring
     // pixels, so the 9 (or 4, 49) shifted reads of an activation chunk are L2 hits instead of one trip to the
     // Infinity Cache / HBM per tap.
-    int ld_tap = 0, ld_cc = 0;     // tap and channel offset (concat space) of that step
+    int ld_tap = 0, ld_cc = cc_first;  // tap and channel offset (concat space) of that step
     int ld_use1 = 0;               // the chunk comes from x1 (skip concat)
     unsigned ld_soffA = 0;         // scalar byte offset of the channel chunk inside the current source
-    unsigned ld_soffB = 0;         // scalar byte offset of the weight-panel step
+    unsigned ld_soffB = (unsigned)((cc_first >> 5) * a.ntaps) * (unsigned)a.N * 128u;   // scalar byte offset of the weight-panel step
     const float* ld_src = a.x0;
     unsigned ld_bytes = bytes0;
     unsigned pixb[PA];             // byte offset of (row p's pixel, channel quad kq) in the current source
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     // ---- prologue: stage 0 ----
     if (!SMALLC) {
         source();
-        const int toff0 = taptab[0];
+        const int toff0 = taptab[ld_use1 * LWG_MAX_TAPS];      // a split-K slice may start inside x1
 #pragma unroll
         for (int p = 0; p < PA; ++p) tap_row(p, toff0);
     }
@@ -345,23 +349,99 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         step(c0{}, std::false_type{}, t);
     }
 
+    if (EPI == LWG_EPI_NONE && !SMALLC && split_chunks > 0) {
+        lwg_conv_epilogue_slab<TM, TN>(slabs + (size_t)blockIdx.y * a.M * a.N, a.M, a.N, acc, m_base, n_base, wm, wn, lane);
+        return;
+    }
     lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
 }
 
+// y[row m -> output pixel][ycoff + n] = act(sum_s slab[s][m][n] + bias[n]): the epilogue of a split-K launch (slices added in
+// slice order: deterministic).
+__global__ __launch_bounds__(256) void lwg_splitk_finish_kernel(const LwgConvArgs a, const float* __restrict__ slabs, int nslices) {
+    const int N4 = a.N >> 2;
+    const size_t total = (size_t)a.M * N4, MN = (size_t)a.M * a.N;
+    const int HW = a.OH * a.OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N4), n = (int)(i - (size_t)m * N4) * 4;
+        floatx4 s = *reinterpret_cast<const floatx4*>(slabs + (size_t)m * a.N + n);
+        for (int k = 1; k < nslices; ++k) {
+            const floatx4 v = *reinterpret_cast<const floatx4*>(slabs + k * MN + (size_t)m * a.N + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += v[c];
+        }
+        if (a.bias) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += b4[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = lwg_act(s[c], a.act);
+        const int b = m / HW, rem = m - b * HW;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const size_t opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+        *reinterpret_cast<floatx4*>(a.y + opix * a.YC + a.ycoff + n) = s;
+    }
+}
+
+// Split-K plan of a launch (0 slices = run it whole).  Only the 64x64-tile regime (one training sample, the discriminator's
+// deep layers: M of a few thousand rows against K of a few thousand) is split: the tile grid alone leaves most CUs with one
+// workgroup or none, while 3-4 fit (33 KB LDS, ~80 VGPRs).  Slices are whole 32-channel chunks (all taps of a chunk stay
+// together, so the L2-friendly tap-minor K order is kept) with at least 8 K-steps each.
+static int lwg_conv_split_plan(const LwgConvArgs& a, int* chunks_per_slice) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* ev = getenv("LWG_CONV_SPLITK");            // tuning knob: 0 disables
+        enabled = ev ? atoi(ev) : 1;
+    }
+    const int Cin = a.C0 + a.C1;
+    if (!enabled || a.epi != LWG_EPI_NONE || (Cin % 32) != 0) return 0;
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (tiles128 >= 300) return 0;                              // not the 64x64 regime (launch_epi)
+    const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
+    const int chunks = Cin / 32;
+    if (tiles >= 512 || chunks < 2) return 0;
+    int want = (int)((1024 + tiles - 1) / tiles);               // aim at ~1024 workgroups = 4 per CU
+    if (want > 8) want = 8;
+    int cps = (chunks + want - 1) / want;
+    while (cps * a.ntaps < 8 && cps < chunks) ++cps;
+    const int slices = (chunks + cps - 1) / cps;
+    if (slices < 2) return 0;
+    *chunks_per_slice = cps;
+    return slices;
+}
+
+extern "C" size_t lwg_conv2d_ws_floats(const LwgConvArgs* pa) {
+    if (!pa || pa->M <= 0 || pa->N <= 0) return 0;
+    int cps = 0;
+    return (size_t)lwg_conv_split_plan(*pa, &cps) * (size_t)pa->M * (size_t)pa->N;
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
-static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream) {
+static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream, float* ws = nullptr) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t lds = (size_t)2 * 8 * ((BM + 1) * 4 + BN * 4) * sizeof(float) + 3 * LWG_MAX_TAPS * sizeof(int);
     auto kern = lwg_conv_igemm_kernel<WAVES_M, WAVES_N, TM, TN, EPI, SMALLC>;
     static unsigned long long attr_done = 0ull;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a);
+    if constexpr (EPI == LWG_EPI_NONE && !SMALLC && BM == 64 && BN == 64) {
+        int cps = 0;
+        const int slices = ws ? lwg_conv_split_plan(a, &cps) : 0;
+        if (slices > 1) {
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, slices), dim3(256), lds, stream, a, cps, ws);
+            const size_t total4 = (size_t)a.M * (a.N / 4);
+            const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(lwg_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, slices);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, 0, (float*)nullptr);
     return hipGetLastError();
 }
 
 template <int EPI, bool SMALLC>
-static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream) {
+static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream, float* ws = nullptr) {
     // small launches (one training sample, short clips): 128x128 tiles would leave most of the 256 CUs idle - 64x64 tiles
     // quadruple the workgroup count (each wave then owns one 32x32 MFMA tile: fewer flops per staged byte, but it runs)
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -371,14 +451,18 @@ static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream) {
             const char* ev = getenv("LWG_CONV_SMALL_TILES");   // tuning knob
             small_thr = ev ? atol(ev) : 300;
         }
-        if (tiles128 < small_thr) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream);  // 64 x 64
+        if (tiles128 < small_thr) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream, ws);  // 64 x 64 (split-K when ws is given)
     }
     if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg<2, 2, 2, 2, EPI, SMALLC>(a, stream);  // 128 x 128
     return launch_cfg<4, 1, 1, 2, EPI, SMALLC>(a, stream);                                                // 128 x 64
 }
 
 // Host-side validation + dispatch; returns hipError_t as int (hipErrorInvalidValue for contract violations).
-extern "C" int lwg_conv2d_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
+extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stream_t stream_);
+extern "C" int lwg_conv2d_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t stream_) { return lwg_conv2d_nhwc_f32_ws(pa, nullptr, stream_); }
+
+// ws: NULL, or lwg_conv2d_ws_floats(args) floats - small-M / large-K launches then run split-K through it.
+extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
@@ -403,5 +487,5 @@ extern "C" int lwg_conv2d_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t stream_) 
         return (int)launch_epi<LWG_EPI_RESIDUAL, false>(a, stream);
     }
     if (a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
-    return smallc ? (int)launch_epi<LWG_EPI_NONE, true>(a, stream) : (int)launch_epi<LWG_EPI_NONE, false>(a, stream);
+    return smallc ? (int)launch_epi<LWG_EPI_NONE, true>(a, stream) : (int)launch_epi<LWG_EPI_NONE, false>(a, stream, ws);
 }

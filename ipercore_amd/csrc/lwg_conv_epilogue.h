@@ -76,3 +76,26 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
         }
     }
 }
+
+// Split-K launches: the raw partial sums of one K slice as a dense (M, N) slab (no bias / activation / output geometry; the
+// finishing kernel applies those once the slices are added up).
+template <int TM, int TN>
+__device__ __forceinline__ void lwg_conv_epilogue_slab(float* __restrict__ slab, int M, int N, floatx16 (&acc)[TM][TN], int m_base,
+                                                       int n_base, int wm, int wn, int lane) {
+    const int ncol0 = n_base + wn * TN * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_base + wm * TM * 32 + i * 32 + (lane & 31);
+        if (m >= M) continue;
+        float* yr = slab + (size_t)m * N + ncol0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                floatx4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = acc[i][j][4 * g + c];
+                *reinterpret_cast<floatx4*>(yr + 32 * j + 8 * g) = o;
+            }
+    }
+}

@@ -139,7 +139,12 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
     else:
-        _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+        nws = _lib.lib().lwg_conv2d_ws_floats(a)            # > 0: a small-M / large-K launch the library runs split-K
+        if nws:
+            ws = torch.empty(nws, device=x0.device, dtype=torch.float32)
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_ws(a, _ptr(ws), _stream()), "lwg_conv2d_nhwc_f32_ws")
+        else:
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
         CONV_HOOK(False, a.M, spec, epi)
     return y

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ipercore_amd import ops, synthetic
+from ipercore_amd import _lib, ops, synthetic
 from ipercore_amd.geometry import mesh
 from ipercore_amd.networks import packing
 from tests import emu_ops
@@ -69,7 +69,10 @@ def _conv_case(name, B, H, W, Cin, N, k, stride, pad, seed, cin_pad=None, C1=0, 
     got = ops.conv2d(x0.to(DEV), sd, torch.full((B, OH, OW, N), float("nan"), device=DEV), x1=None if x1 is None else x1.to(DEV),
                      epi=epi, act=act, res=None if res is None else res.to(DEV))
     torch.cuda.synchronize()
-    return _cmp(got, want, 2e-5, name)
+    m = _cmp(got, want, 2e-5, name)
+    a = ops.conv_args(x0.to(DEV), sd, got, None if x1 is None else x1.to(DEV), epi, act, None if res is None else res.to(DEV))
+    m["splitk_slices"] = int(_lib.lib().lwg_conv2d_ws_floats(a) // (a.M * a.N))
+    return m
 
 
 def check_conv_variants():
@@ -84,6 +87,14 @@ def check_conv_variants():
     out["3x3_residual"] = _conv_case("residual", 2, 8, 8, 256, 256, 3, 1, 1, 80, epi=ops.EPI_RESIDUAL)
     out["3x3_tail_m"] = _conv_case("M tail", 3, 9, 7, 64, 128, 3, 1, 1, 90)
     out["3x3_tanh_sigmoid"] = _conv_case("tanh", 1, 8, 8, 64, 64, 3, 1, 1, 95, act=ops.ACT_TANH)
+    # split-K regime (small M, large K: one training sample, the discriminator's deep layers) and its boundary
+    out["4x4_s2_256_512_D"] = _conv_case("D 256->512 s2", 1, 64, 64, 256, 512, 4, 2, 1, 96)
+    out["4x4_s1_512_512_D"] = _conv_case("D 512->512 s1 (M = 31^2)", 1, 32, 32, 512, 512, 4, 1, 1, 97, act=ops.ACT_RELU)
+    out["3x3_res_256"] = _conv_case("res block 64^2", 1, 64, 64, 256, 256, 3, 1, 1, 98)
+    out["3x3_unsplit_64x64_tiles"] = _conv_case("64x64 tiles, no split", 4, 64, 64, 64, 128, 3, 1, 1, 99)
+    assert out["4x4_s2_256_512_D"]["splitk_slices"] == 8 and out["4x4_s1_512_512_D"]["splitk_slices"] == 8, out
+    assert out["3x3_res_256"]["splitk_slices"] == 4 and out["3x3_concat"]["splitk_slices"] == 6, out      # the concat case crosses x0 | x1
+    assert out["3x3_unsplit_64x64_tiles"]["splitk_slices"] == 0 and out["3x3_residual"]["splitk_slices"] == 0, out
     return out
 
 
