@@ -91,7 +91,7 @@ def check_conv_variants():
     out["4x4_s2_256_512_D"] = _conv_case("D 256->512 s2", 1, 64, 64, 256, 512, 4, 2, 1, 96)
     out["4x4_s1_512_512_D"] = _conv_case("D 512->512 s1 (M = 31^2)", 1, 32, 32, 512, 512, 4, 1, 1, 97, act=ops.ACT_RELU)
     out["3x3_res_256"] = _conv_case("res block 64^2", 1, 64, 64, 256, 256, 3, 1, 1, 98)
-    out["3x3_unsplit_64x64_tiles"] = _conv_case("64x64 tiles, no split", 4, 64, 64, 64, 128, 3, 1, 1, 99)
+    out["3x3_unsplit_64x64_tiles"] = _conv_case("64x64 tiles, no split", 6, 64, 64, 64, 128, 3, 1, 1, 99)
     assert out["4x4_s2_256_512_D"]["splitk_slices"] == 8 and out["4x4_s1_512_512_D"]["splitk_slices"] == 8, out
     assert out["3x3_res_256"]["splitk_slices"] == 4 and out["3x3_concat"]["splitk_slices"] == 6, out      # the concat case crosses x0 | x1
     assert out["3x3_unsplit_64x64_tiles"]["splitk_slices"] == 0 and out["3x3_residual"]["splitk_slices"] == 0, out
