@@ -55,14 +55,14 @@ class ConvFn(torch.autograd.Function):
             pad = kh // 2 if cfg.pad is None else cfg.pad
             OH, OW = (H + 2 * pad - kh) // cfg.stride + 1, (W + 2 * pad - kh) // cfg.stride + 1
             y = torch.empty(B, OH, OW, spec.N, device=dev, dtype=torch.float32)
-            ops.conv2d(x0, spec, y, x1=x1, act=cfg.act)
+            ops.conv2d(x0, spec, y, x1=x1, act=cfg.act, splitk=True)
             specs = [spec]
         else:
             N = weight.shape[1]
             specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(weight, bias, cfg.n_pad)]
             y = torch.empty(B, 2 * H, 2 * W, specs[0].N, device=dev, dtype=torch.float32)
             for s in specs:
-                ops.conv2d(x0, s, y, act=cfg.act)
+                ops.conv2d(x0, s, y, act=cfg.act, splitk=True)
         ctx.cfg, ctx.specs, ctx.N, ctx.has_bias = cfg, specs, N, bias is not None
         ctx.has_x1 = x1 is not None
         # a regressor (3 / 4 / 1 output channels zero-extended to 64): its backward runs on the thin forms below
@@ -104,10 +104,10 @@ class ConvFn(torch.autograd.Function):
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cd, device=dev, dtype=torch.float32)
                 if cfg.stride == 1:
-                    ops.conv2d(dy, dspecs[0], dx)
+                    ops.conv2d(dy, dspecs[0], dx, splitk=True)
                 else:
                     for s in dspecs:
-                        ops.conv2d(dy, s, dx, out_hw=(H // 2, W // 2))
+                        ops.conv2d(dy, s, dx, out_hw=(H // 2, W // 2), splitk=True)
         else:
             Cin, Nw = weight.shape[0], weight.shape[1]
             dw = None
@@ -119,7 +119,7 @@ class ConvFn(torch.autograd.Function):
                 dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
-                ops.conv2d(dy, dspec, dx)
+                ops.conv2d(dy, dspec, dx, splitk=True)
         dx0 = dx1 = None
         if dx is not None:
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
@@ -141,7 +141,7 @@ def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
         dspec = packing.spec_to(packing.pack_dgrad_conv(weight, 1, pad, n_pad=dy.shape[3], cin_pad=x0.shape[3])[0], dy.device)
         if want_dx:
             dx = torch.empty(x0.shape, device=dy.device, dtype=torch.float32)
-            ops.conv2d(dy, dspec, dx)
+            ops.conv2d(dy, dspec, dx, splitk=True)
         if want_dw:
             dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, dy.shape[3], N, Cin)
     return dx, dw

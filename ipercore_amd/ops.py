@@ -127,8 +127,10 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
 
 
 def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
-           out_hw=None, ycoff=0):
-    """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place)."""
+           out_hw=None, ycoff=0, splitk=False):
+    """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place).
+    splitk: let the library split small-M / large-K launches over K (the training step's one-sample launches).  Off on the
+    synthesis path: a frame's result must not depend on how many frames share its launch (batch invariance is a parity check)."""
     a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec, epi)
@@ -139,7 +141,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
     else:
-        nws = _lib.lib().lwg_conv2d_ws_floats(a)            # > 0: a small-M / large-K launch the library runs split-K
+        nws = _lib.lib().lwg_conv2d_ws_floats(a) if splitk else 0    # > 0: a small-M / large-K launch the library runs split-K
         if nws:
             ws = torch.empty(nws, device=x0.device, dtype=torch.float32)
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_ws(a, _ptr(ws), _stream()), "lwg_conv2d_nhwc_f32_ws")

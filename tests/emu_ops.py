@@ -26,7 +26,7 @@ def _unpanel(w, ntaps, cin):
     return wk
 
 
-def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0):
+def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0, splitk=False):
     x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
     B, H, W, Cin = x.shape
     assert Cin == spec.Cin

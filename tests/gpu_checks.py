@@ -67,7 +67,7 @@ def _conv_case(name, B, H, W, Cin, N, k, stride, pad, seed, cin_pad=None, C1=0, 
     want = emu_ops.conv2d(x0, spec, torch.zeros(B, OH, OW, N), x1=x1, epi=epi, act=act, res=res)
     sd = _spec_dev(packing.pack_conv(w, b, stride=stride, pad=pad, cin_pad=cin_pad))
     got = ops.conv2d(x0.to(DEV), sd, torch.full((B, OH, OW, N), float("nan"), device=DEV), x1=None if x1 is None else x1.to(DEV),
-                     epi=epi, act=act, res=None if res is None else res.to(DEV))
+                     epi=epi, act=act, res=None if res is None else res.to(DEV), splitk=True)
     torch.cuda.synchronize()
     m = _cmp(got, want, 2e-5, name)
     a = ops.conv_args(x0.to(DEV), sd, got, None if x1 is None else x1.to(DEV), epi, act, None if res is None else res.to(DEV))
