@@ -7,10 +7,12 @@ L1 reconstruction + transfer loss + BCE mask + TV), Adam step, ``optimize_D`` (L
 (models/networks/discriminators/multi_scale_dis.py:47-107, patch_dis.py:8-70), factory name ``patch_global``.
 
 Every convolution of G and D (forward, data gradient, weight gradient) runs on the hand-written MFMA kernels through
-``networks.training.ConvFn``; the elementwise glue is PyTorch-ROCm autograd in this round (see that module).
-Losses that need weights the reference downloads (VGG19 perceptual ``vggloss.py``, SphereFace ``FaceLoss``) are not
-available offline: the step is the reference's ``use_vgg = "None"`` / ``use_face = false`` configuration, in which
-``crt_tsf`` is ``L1Loss`` (lwg_trainer.py:154-158).
+``networks.training.ConvFn``; part of the elementwise glue is PyTorch-ROCm autograd (see that module).
+The composed discriminators ``patch_global_local`` / ``patch_global_body_head`` (multi_scale_dis.py:110-284) are built on the same
+``PatchDiscriminator``.  The VGG19 perceptual loss (``vggloss.py``) and the SphereFace loss (``faceloss.py``) run on the same conv
+kernels with frozen weights; their checkpoints are not available offline, so without ``vgg_loss_path`` / ``face_loss_path`` they use
+seeded weights (``TrainOpts.use_vgg = "None"`` / ``use_face = False``, the default here, is the reference's L1 transfer loss,
+lwg_trainer.py:154-158).
 
 Data parallelism (BASELINE config 5: one sample per GPU): parameters and gradients of a network live in ONE flat fp32
 buffer each (``FlatAdam``); the gradient buffer is averaged in place with a single RCCL all-reduce - large, few
