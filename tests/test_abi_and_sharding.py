@@ -77,6 +77,31 @@ def test_invalid_arguments_are_rejected_on_the_host():
         _lib.check(1, "lwg_conv2d_nhwc_f32")
 
 
+def test_splitk_plan_is_a_host_function():
+    """lwg_conv2d_ws_floats (csrc/conv_igemm.hip lwg_conv_split_plan) decides on the host which launches run split-K: only the
+    64x64-tile regime (< 300 128x128 tiles and < 512 64x64 tiles), whole 32-channel chunks, >= 8 K-steps per slice, <= 8 slices,
+    never a fused-epilogue or small-Cin launch."""
+    L = _lib.lib()
+
+    def slices(M, N, Cin, ntaps, epi=0):
+        a = _lib.LwgConvArgs()
+        a.M, a.N, a.C0, a.ntaps, a.epi = M, N, Cin, ntaps, epi
+        n = L.lwg_conv2d_ws_floats(a)
+        assert n % (M * N) == 0
+        return n // (M * N)
+    assert L.lwg_conv2d_ws_floats(None) == 0
+    assert slices(1024, 512, 256, 16) == 8            # D 256 -> 512, 4x4 s2 at 64^2
+    assert slices(961, 512, 512, 16) == 8             # D 512 -> 512, 4x4 s1 (M = 31^2): 16 chunks -> 2 per slice
+    assert slices(4096, 256, 256, 9) == 4             # res block at 64^2: 256 tiles -> 4 slices of 2 chunks
+    assert slices(256, 256, 384, 9) == 6              # 12 chunks, capped at 8 slices -> 2 chunks each
+    assert slices(512, 128, 64, 9) == 2
+    assert slices(64, 256, 256, 1) == 0               # 1x1: 8 K-steps in all -> one slice
+    assert slices(16384, 128, 64, 9) == 0             # 512 tiles of 64x64: filled already
+    assert slices(65536, 256, 256, 9) == 0            # 128x128-tile regime
+    assert slices(1024, 512, 256, 16, epi=1) == 0 and slices(1024, 512, 256, 16, epi=2) == 0      # fused epilogues run whole
+    assert slices(4096, 64, 8, 9) == 0                # small-Cin path
+
+
 def test_ops_refuse_cpu_tensors():
     from ipercore_amd import ops
     with pytest.raises(RuntimeError):
