@@ -127,6 +127,19 @@ class ConvFn(torch.autograd.Function):
                 dx1 = dx[..., C0:C0 + x1.shape[3]]
         return dx0, dx1, dw, db, None
 
+    @staticmethod
+    def _backward_thin(ctx, x0, weight, dy):
+        """A regressor's backward on the thin forms (``thin_backward``): dY zero-extended to 4 / 8 / 16 channels, not 64."""
+        cfg, N = ctx.cfg, ctx.N
+        Ns = 4 if N <= 4 else (8 if N <= 8 else 16)
+        if Ns != N:
+            dy = F.pad(dy, (0, Ns - N))
+        db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        kh = weight.shape[2]
+        dx, dw = thin_backward(x0, weight, dy, kh // 2 if cfg.pad is None else cfg.pad, cfg.need_dx and ctx.needs_input_grad[0],
+                               ctx.needs_input_grad[2])
+        return dx, None, dw, db, None
+
 
 def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
     """Backward of a stride-1 conv with N <= 16 outputs WITHOUT the zero-extension to 64 columns a forward MFMA launch needs
@@ -145,21 +158,6 @@ def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
         if want_dw:
             dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, dy.shape[3], N, Cin)
     return dx, dw
-
-
-def _backward_thin(ctx, x0, weight, dy):
-    cfg, N = ctx.cfg, ctx.N
-    Ns = 4 if N <= 4 else (8 if N <= 8 else 16)
-    if Ns != N:
-        dy = F.pad(dy, (0, Ns - N))
-    db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-    kh = weight.shape[2]
-    dx, dw = thin_backward(x0, weight, dy, kh // 2 if cfg.pad is None else cfg.pad, cfg.need_dx and ctx.needs_input_grad[0],
-                           ctx.needs_input_grad[2])
-    return dx, None, dw, db, None
-
-
-ConvFn._backward_thin = staticmethod(_backward_thin)
 
 
 def conv(x0, weight, bias=None, x1=None, **kw):
