@@ -105,6 +105,12 @@ def main():
         wg[0] += 2.0 * M * spec.algo_kn
         return orig(x0, spec, dy, **kw)
     ops.conv2d_wgrad = counted_wgrad
+    orig_u = ops.conv2d_wgrad_unpacked
+
+    def counted_wgrad_unpacked(x0, spec, dy, *a, **kw):
+        wg[0] += 2.0 * (dy.shape[0] * dy.shape[1] * dy.shape[2] // (spec.omul ** 2)) * spec.algo_kn
+        return orig_u(x0, spec, dy, *a, **kw)
+    ops.conv2d_wgrad_unpacked = counted_wgrad_unpacked
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lg, ld = tr.optimize_parameters()
@@ -113,7 +119,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.CONV_HOOK, ops.conv2d_wgrad = None, orig
+    ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = None, orig, orig_u
+    # host share: one step from an idle queue - time until the last launch is enqueued vs until the GPU is done
+    host_ms, total_ms = [], []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        tr.optimize_parameters()
+        h1 = time.perf_counter()
+        torch.cuda.synchronize()
+        host_ms.append((h1 - h0) * 1e3)
+        total_ms.append((time.perf_counter() - h0) * 1e3)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -128,6 +144,7 @@ def main():
                        "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
                                       f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},
             "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(per_step / (dt / args.steps) / 1e12, 2),
+            "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
             "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}), flush=True)
     if world > 1:
         dist.barrier()

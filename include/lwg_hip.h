@@ -92,6 +92,10 @@ int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* args, lwg_stream_t stream);
  *   pack_dgrad_*); lwg_colsum_nhwc_f32 gives bias gradients (out[c] = sum over rows of x (rows, C); ws: 512*C floats). */
 size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M);
 int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* args, const float* dy, float* dw, float* ws, lwg_stream_t stream);
+/* The same weight gradient written straight into the parameter's gradient tensor dw (D0,D1,KH,KW) - the slab reduction and
+ * lwg_unpack_wgrad_f32 (below; same transposed / kidx / cin / nout convention, cin_pad = C0 + C1, n_pad = N) in one launch. */
+int lwg_conv2d_wgrad_unpacked_f32(const LwgConvArgs* args, const float* dy, float* ws, float* dw, int D0, int D1, int KH, int KW,
+                                  int transposed, const int* kidx, int cin, int nout, lwg_stream_t stream);
 int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream);
 
 /* Elementwise / normalisation pieces of the personalization step and their backward (csrc/train_ops.hip); NHWC fp32.

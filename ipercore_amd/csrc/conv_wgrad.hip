@@ -292,6 +292,65 @@ static void lwg_launch_slab_reduce(const float* part, int nsplit, size_t total, 
     }
 }
 
+// The slab reduction of a weight gradient fused with its un-packing: element i of the OUTPUT (tap, c, n; n fastest) is the sum
+// over the slices of slab[k(tap, c)][n] and lands at the parameter tensor's own position (nn.Conv2d (N, Cin, KH, KW), or
+// (Cin, N, KH, KW) for transposed = 1) - what lwg_wgrad_reduce_kernel + lwg_unpack_wgrad_f32 did in two launches and one extra
+// pass over dW (~150 launch pairs per training step).
+struct LwgUnpackMap {
+    int D1, KHW, transposed, ntaps, cin, cin_pad, nout, n_pad;
+    int kidx[LWG_MAX_TAPS];
+};
+
+__device__ __forceinline__ void lwg_unpack_map(const LwgUnpackMap& u, size_t i, size_t& src, size_t& dst) {
+    const int n = (int)(i % u.nout), r = (int)(i / u.nout);
+    const int c = r % u.cin, tap = r / u.cin;
+    const int k = (u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c;
+    src = (size_t)k * u.n_pad + n;
+    dst = ((size_t)(u.transposed ? c : n) * u.D1 + (u.transposed ? n : c)) * u.KHW + u.kidx[tap];
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void lwg_slab_reduce_unpack_kernel(const float* __restrict__ part, int nsplit, size_t slab, size_t total,
+                                                                     const LwgUnpackMap u, float* __restrict__ out) {
+    constexpr int EPB = 256 / G;
+    __shared__ float sh[256];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    for (size_t i0 = (size_t)blockIdx.x * EPB; i0 < total; i0 += (size_t)gridDim.x * EPB) {
+        const size_t i = i0 + e;
+        size_t src = 0, dst = 0;
+        float s = 0.f;
+        if (i < total) {
+            lwg_unpack_map(u, i, src, dst);
+            for (int k = g; k < nsplit; k += G) s += part[(size_t)k * slab + src];
+        }
+        if (G == 1) {
+            if (i < total) out[dst] = s;
+        } else {
+            __syncthreads();
+            sh[threadIdx.x] = s;
+            __syncthreads();
+            if (g == 0 && i < total) {
+                float t = sh[e];
+#pragma unroll
+                for (int j = 1; j < G; ++j) t += sh[j * EPB + e];
+                out[dst] = t;
+            }
+        }
+    }
+}
+
+static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t slab, size_t total, const LwgUnpackMap& u, float* out,
+                                          hipStream_t stream) {
+    if (total < 65536 && nsplit >= 64) {
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
+    } else if (total < 65536 && nsplit >= 16) {
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
+    } else {
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<1>, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
+    }
+}
+
 // Column sums of an NHWC tensor viewed as (rows, C): out[c] = sum_r x[r, c] (bias gradients).  Two deterministic passes.
 // C % 4 == 0: a lane owns four consecutive channels (16-byte loads), C/4 lanes cover a row, 256 / (C/4) rows per pass;
 // up to 512 row blocks keep every CU streaming (the first version used 64 blocks of 4-byte loads: 2.4 TB/s).
@@ -352,11 +411,9 @@ extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
     return (size_t)lwg_wgrad_splits(Ktot, N, M) * Ktot * N;
 }
 
-// args: forward geometry; dy: gradient of the forward output (same layout as y); dw: (ntaps*Cin, N) row-major in the
-// forward panel's K order.  ws: lwg_conv2d_wgrad_ws_floats(ntaps*Cin, N, M) floats.
-extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy, float* dw, float* ws, lwg_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!pa || !dy || !dw || !ws) return (int)hipErrorInvalidValue;
+// Validation + the slab launch shared by the two entry points; *splits_out slices of (Ktot, N) land in ws.
+static int lwg_wgrad_launch(const LwgConvArgs* pa, const float* dy, float* ws, hipStream_t stream, int* splits_out) {
+    if (!pa || !dy || !ws) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0 || a.N <= 0 || (a.N & 3) || (Cin & 3) || (a.YC & 3) || (a.ycoff & 3))
@@ -377,7 +434,40 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
     static unsigned long long attr_done[2] = {0ull, 0ull};
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[smallc]); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
-    lwg_launch_slab_reduce(ws, splits, (size_t)Ktot * a.N, dw, stream);
+    *splits_out = splits;
+    return 0;
+}
+
+// args: forward geometry; dy: gradient of the forward output (same layout as y); dw: (ntaps*Cin, N) row-major in the
+// forward panel's K order.  ws: lwg_conv2d_wgrad_ws_floats(ntaps*Cin, N, M) floats.
+extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy, float* dw, float* ws, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!dw) return (int)hipErrorInvalidValue;
+    int splits = 0;
+    if (int e = lwg_wgrad_launch(pa, dy, ws, stream, &splits); e != 0) return e;
+    lwg_launch_slab_reduce(ws, splits, (size_t)pa->ntaps * (pa->C0 + pa->C1) * pa->N, dw, stream);
+    return (int)hipGetLastError();
+}
+
+// The same weight gradient delivered in the parameter's own layout: dw is the (D0, D1, KH, KW) gradient tensor of an
+// nn.Conv2d (transposed = 0: (N, Cin, KH, KW)) or of the GEMM-transposed forms (transposed = 1: (Cin-of-the-GEMM, N, KH, KW)),
+// tap t of the launch goes to kernel position kidx[t]; cin <= C0 + C1 and nout <= N drop the zero-extended channels.  Positions no
+// tap maps to are left untouched (the four parity launches of a transposed convolution fill one tensor).
+extern "C" int lwg_conv2d_wgrad_unpacked_f32(const LwgConvArgs* pa, const float* dy, float* ws, float* dw, int D0, int D1, int KH, int KW,
+                                             int transposed, const int* kidx, int cin, int nout, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa || !dw || !kidx || cin < 1 || nout < 1 || cin > pa->C0 + pa->C1 || nout > pa->N) return (int)hipErrorInvalidValue;
+    if ((transposed ? cin : nout) > D0 || (transposed ? nout : cin) > D1 || pa->ntaps < 1 || pa->ntaps > LWG_MAX_TAPS) return (int)hipErrorInvalidValue;
+    LwgUnpackMap u;
+    u.D1 = D1; u.KHW = KH * KW; u.transposed = transposed; u.ntaps = pa->ntaps; u.cin = cin; u.cin_pad = pa->C0 + pa->C1;
+    u.nout = nout; u.n_pad = pa->N;
+    for (int i = 0; i < pa->ntaps; ++i) {
+        if (kidx[i] < 0 || kidx[i] >= KH * KW) return (int)hipErrorInvalidValue;
+        u.kidx[i] = kidx[i];
+    }
+    int splits = 0;
+    if (int e = lwg_wgrad_launch(pa, dy, ws, stream, &splits); e != 0) return e;
+    lwg_launch_slab_reduce_unpack(ws, splits, (size_t)u.ntaps * u.cin_pad * u.n_pad, (size_t)u.ntaps * cin * nout, u, dw, stream);
     return (int)hipGetLastError();
 }
 

@@ -192,6 +192,37 @@ def wgrad_to_conv(dwk, ntaps, cin_packed, cin, n, kh, kw):
     return unpack_wgrad(dwk, ntaps, cin_packed)[:, :cin, :n].reshape(kh, kw, cin, n).permute(3, 2, 0, 1).contiguous()
 
 
+def wgrad_conv(x0, spec, dy, x1, kh, kw, cin, n):
+    """nn.Conv2d weight gradient (N, Cin, kh, kw) of the launch ``spec``: on the device ONE reduction launch writes it in place
+    (ops.conv2d_wgrad_unpacked); the host-logic tests take the two-step form."""
+    if dy.is_cuda:
+        return ops.conv2d_wgrad_unpacked(x0, spec, dy, torch.empty(n, cin, kh, kw, device=dy.device, dtype=torch.float32), False,
+                                         range(kh * kw), cin, n, x1=x1)
+    return wgrad_to_conv(ops.conv2d_wgrad(x0, spec, dy, x1=x1), kh * kw, spec.Cin, cin, n, kh, kw)
+
+
+def wgrad_conv_transpose(x0, specs, dy, cin, n):
+    """nn.ConvTranspose2d(4, 2, 1) weight gradient (Cin, N, 4, 4) from its four parity launches."""
+    if dy.is_cuda:
+        g = torch.empty(cin, n, 4, 4, device=dy.device, dtype=torch.float32)           # the four parities cover all 16 positions
+        i = 0
+        for py in (0, 1):
+            for px in (0, 1):
+                ops.conv2d_wgrad_unpacked(x0, specs[i], dy, g, True, [ky * 4 + kx for ky, _ in _CT_TAPS[py] for kx, _ in _CT_TAPS[px]], cin, n)
+                i += 1
+        return g
+    return wgrad_to_conv_transpose([ops.conv2d_wgrad(x0, s, dy) for s in specs], cin, n)
+
+
+def wgrad_thin(dy, dspec, x0, kh, kw, ns, n, cin):
+    """Weight gradient of the thin backward form (training.thin_backward): the role-swapped launch's rows are (tap, n), its
+    columns the input channels -> (N, Cin, kh, kw)."""
+    if dy.is_cuda:
+        return ops.conv2d_wgrad_unpacked(dy, dspec, x0, torch.empty(n, cin, kh, kw, device=dy.device, dtype=torch.float32), True,
+                                         range(kh * kw), n, cin)
+    return wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, ns, n, cin)
+
+
 def wgrad_thin_to_conv(dwk, kh, kw, ns, n, cin):
     """Weight gradient of the thin backward form (training.ConvFn._backward_thin): (kh*kw*ns, Cd) rows k = tap * ns + n
     (the small-Cin K order), columns = input channels -> nn.Conv2d gradient (N, Cin, kh, kw)."""

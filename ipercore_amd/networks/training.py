@@ -94,8 +94,7 @@ class ConvFn(torch.autograd.Function):
             Nw, Cin, kh, kw = weight.shape
             dw = None
             if want_dw:
-                dwk = ops.conv2d_wgrad(x0, specs[0], dy, x1=x1)
-                dw = packing.wgrad_to_conv(dwk, kh * kw, Cin_packed, Cin, N, kh, kw)
+                dw = packing.wgrad_conv(x0, specs[0], dy, x1, kh, kw, Cin, N)
             dx = None
             if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                 pad = kh // 2 if cfg.pad is None else cfg.pad            # the dgrad panel sees the padded channel counts
@@ -112,8 +111,7 @@ class ConvFn(torch.autograd.Function):
             Cin, Nw = weight.shape[0], weight.shape[1]
             dw = None
             if want_dw:
-                dwks = [ops.conv2d_wgrad(x0, s, dy) for s in specs]
-                dw = packing.wgrad_to_conv_transpose(dwks, Cin, N)
+                dw = packing.wgrad_conv_transpose(x0, specs, dy, Cin, N)
             dx = None
             if cfg.need_dx and ctx.needs_input_grad[0]:
                 dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
@@ -156,7 +154,7 @@ def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
             dx = torch.empty(x0.shape, device=dy.device, dtype=torch.float32)
             ops.conv2d(dy, dspec, dx, splitk=True)
         if want_dw:
-            dw = packing.wgrad_thin_to_conv(ops.conv2d_wgrad(dy, dspec, x0), kh, kw, dy.shape[3], N, Cin)
+            dw = packing.wgrad_thin(dy, dspec, x0, kh, kw, dy.shape[3], N, Cin)
     return dx, dw
 
 

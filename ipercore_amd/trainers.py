@@ -208,15 +208,35 @@ class FlatAdam(object):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
-            p.grad = self.grad[off:off + k].view_as(p)
             off += k
         self.params = params
+        self._slots, off = [], 0
+        for p in params:                           # a parameter's range of the flat gradient buffer
+            self._slots.append(self.grad[off:off + p.numel()].view_as(p))
+            p.grad = self._slots[-1]
+            off += p.numel()
 
     def zero_grad(self):
+        """Gradients start each step as None: autograd then KEEPS the tensor a backward function hands it (no accumulation
+        kernel per parameter - ~330 small adds, 1.6 ms of a 34 ms step) and ``_gather`` moves them into the flat buffer with one
+        multi-tensor copy before they are exchanged / applied.  Ranges of parameters that receive no gradient stay zero."""
         self.grad.zero_()
-        for p in self.params:                      # autograd accumulates into the existing views
-            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
-                raise RuntimeError("a parameter's .grad was replaced; call zero_grad() of FlatAdam only")
+        for p in self.params:
+            p.grad = None
+
+    def _gather(self, indices=None):
+        """p.grad (whatever tensor autograd left there) -> its range of the flat buffer; p.grad becomes that view."""
+        idx = range(len(self.params)) if indices is None else indices
+        src, dst = [], []
+        for i in idx:
+            p, slot = self.params[i], self._slots[i]
+            if p.grad is None or p.grad.data_ptr() == slot.data_ptr():
+                continue
+            src.append(p.grad.detach())
+            dst.append(slot)
+            p.grad = slot
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     # ---- data-parallel exchange, overlapped with backward ---------------------------------------------------------------
     def arm(self, group=None, n_buckets=4):
@@ -235,12 +255,14 @@ class FlatAdam(object):
             bounds = [(total * b // n_buckets) // 4 * 4 for b in range(n_buckets)] + [total]
             self._ranges = [(bounds[b], bounds[b + 1]) for b in range(n_buckets) if bounds[b + 1] > bounds[b]]
             self._bucket_of, self._members = [], [0] * len(self._ranges)
+            self._params_of = [[] for _ in self._ranges]
             off = 0
-            for p in self.params:
+            for i, p in enumerate(self.params):
                 touched = [b for b, (lo, hi) in enumerate(self._ranges) if lo < off + p.numel() and off < hi]
                 self._bucket_of.append(touched)            # a parameter may straddle a boundary: it counts for both ranges
                 for b in touched:
                     self._members[b] += 1
+                    self._params_of[b].append(i)
                 off += p.numel()
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
@@ -256,6 +278,7 @@ class FlatAdam(object):
 
     def _issue(self, b):
         lo, hi = self._ranges[b]
+        self._gather(self._params_of[b])
         self._issued.add(b)
         self._works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
 
@@ -264,6 +287,7 @@ class FlatAdam(object):
         ones whose parameters received no gradient in this backward; without ``arm()``: one all-reduce of the whole buffer."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
+        self._gather()
         if getattr(self, "_armed", False):
             for b in range(len(self._ranges)):
                 if b not in self._issued:
@@ -278,6 +302,7 @@ class FlatAdam(object):
 
     def step(self):
         self.t += 1
+        self._gather()
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
         if hasattr(self.module, "_packed"):
             self.module._packed = None             # the inference engine's packed panels are stale now

@@ -231,7 +231,8 @@ for trial in range(2):                              # the second pass re-arms th
     assert opt.overlapped_ranges == 3 and in_flight >= 1, (opt.overlapped_ranges, in_flight)
     assert net[0].weight.grad.data_ptr() == opt.grad.data_ptr()          # still views of the flat buffer
 # un-armed: one collective over the whole buffer
-opt.zero_grad(); net(x).pow(2).sum().backward(); local = opt.grad.clone(); opt.allreduce(None)
+opt.zero_grad(); net(x).pow(2).sum().backward(); opt._gather(); local = opt.grad.clone(); opt.allreduce(None)
+assert unused.weight.grad is None and net[0].weight.grad.data_ptr() == opt.grad.data_ptr()
 both = [torch.zeros_like(local) for _ in range(world)]; dist.all_gather(both, local)
 assert torch.allclose(opt.grad, sum(both) / world, atol=1e-7)
 dist.barrier(); dist.destroy_process_group()
