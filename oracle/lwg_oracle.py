@@ -775,6 +775,46 @@ def merge_uv_img(uv_imgs, selected_obj_f2pts_first, uv_fim, uv_wim):
     return (imgs * norm).sum(dim=0, keepdim=True)
 
 
+# ------------------------------------------------------------------------------------------------ discriminators (row a16)
+def patch_discriminator(sd, prefix, x, n_layers):
+    """models/networks/discriminators/patch_dis.py:8-70 (norm_type = "instance", no sigmoid) from a state_dict:
+    ``{prefix}model.{0, 2, 5, ...}``: n_layers 4x4 stride-2 convs then two of stride 1, InstanceNorm + LeakyReLU(0.2) between them."""
+    idx = [0] + [2 + 3 * (n - 1) for n in range(1, n_layers + 1)]
+    idx.append(idx[-1] + 3)
+    for i, k in enumerate(idx):
+        x = F.conv2d(x, sd[f"{prefix}model.{k}.weight"], sd[f"{prefix}model.{k}.bias"], stride=2 if i < n_layers else 1, padding=1)
+        if i == len(idx) - 1:
+            break
+        if i > 0:
+            x = F.instance_norm(x, eps=1e-5)
+        x = F.leaky_relu(x, 0.2)
+    return x
+
+
+def crop_img(imgs, rects, fact=2):
+    """multi_scale_dis.py:21-44: boxes (min_x, max_x, min_y, max_y) cropped and resized to (H / fact, W / fact); degenerate ones dropped."""
+    H, W = imgs.shape[-2:]
+    crops = [F.interpolate(imgs[i:i + 1, :, y0:y1, x0:x1], size=(H // fact, W // fact), mode="bilinear", align_corners=True)
+             for i, (x0, x1, y0, y1) in enumerate(torch.as_tensor(rects).tolist()) if x0 != x1 and y0 != y1]
+    return torch.cat(crops, dim=0) if crops else []
+
+
+def discriminator_forward(name, sd, x, bg_x, body_rects, head_rects, n_layers, use_aug_bg):
+    """multi_scale_dis.py:82-107 (patch_global: [global, bg]), :152-191 (patch_global_local: [bg, global, local]) and :236-284
+    (patch_global_body_head: [bg, global, body, head]) -> (outs, reduce_tensor(outs) :9-18)."""
+    pd = lambda p, t: patch_discriminator(sd, p, t, n_layers)                                          # noqa: E731
+    outs = [pd("global_model.", x)]
+    if bg_x is not None and use_aug_bg:
+        outs = outs + [pd("bg_model.", bg_x)] if name == "patch_global" else [pd("bg_model.", bg_x)] + outs
+    crops = {"patch_global": (), "patch_global_local": (("local_model.", body_rects, 2),),
+             "patch_global_body_head": (("body_model.", body_rects, 2), ("head_model.", head_rects, 4))}[name]
+    for prefix, rects, fact in crops:
+        c = crop_img(x, rects, fact)
+        if len(c) != 0:
+            outs.append(pd(prefix, c))
+    return outs, sum(o.mean() for o in outs) / len(outs)
+
+
 # ------------------------------------------------------------------------------------------------ SMPL (24 joints), trainers
 def batch_rodrigues(theta):
     """bodynets/batch_smpl.py:73-109: R = cos*I + (1 - cos) r r^T + sin*skew(r), angle = |theta + 1e-8|, r = theta / angle."""

@@ -719,6 +719,22 @@ def check_discriminator_variants():
     gerr = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
     out = {"max_abs_err": errs, "avg": avg.item(), "avg_ref": avg_r.item(), "rel_grad_err": gerr}
     assert max(errs) <= 2e-4 and abs(avg.item() - avg_r.item()) <= 1e-5 and gerr <= 2e-3, out
+    # the three composed networks against outputs of the reference's OWN classes (golden_discriminators_v1.npz: seeded weights,
+    # aug-bg branch on, one degenerate head box; generated by tests/golden/make_golden_discriminators.py)
+    from tests.golden import make_golden_discriminators as mk
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_discriminators_v1.npz"))
+    gx, gbg, gbody, ghead = mk.inputs()
+    for name in mk.NAMES:
+        Dn = create_discriminator(name, AttrDict(**mk.CFG), use_aug_bg=True)
+        Dn.load_state_dict(mk.seeded_state_dict(Dn, 17), strict=True)
+        Dn.to(DEV)
+        with torch.no_grad():
+            outs, avg = Dn({"x": gx.to(DEV), "bg_x": gbg.to(DEV), "body_rects": gbody, "head_rects": ghead, "get_avg": True})
+        torch.cuda.synchronize()
+        assert len(outs) == int(g[f"{name}/n"]), (name, len(outs))
+        e = max(float(np.abs(o.cpu().numpy() - g[f"{name}/out{i}"]).max()) for i, o in enumerate(outs))
+        out[f"{name}_vs_reference_max_abs"] = e
+        assert e <= 2e-4 and abs(avg.item() - float(g[f"{name}/avg"])) <= 1e-5, (name, e, avg.item(), float(g[f"{name}/avg"]))
     return out
 
 
