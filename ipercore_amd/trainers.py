@@ -641,7 +641,7 @@ class LWGTrainer(object):
         outs = self.D(both)
         d_real, d_fake = [o[:o.shape[0] // 2] for o in outs], [o[o.shape[0] // 2:] for o in outs]
         assert outs[0].shape[0] == 2 * n
-        self.losses.update(d_real=sum(o.mean() for o in d_real).detach(), d_fake=sum(o.mean() for o in d_fake).detach())
+        self.losses.update(d_real=_reduce_outs(d_real), d_fake=_reduce_outs(d_fake))           # reduce_tensor, multi_scale_dis.py:9-18
         return lsgan_loss(d_real, 1) + lsgan_loss(d_fake, -1)
 
     def optimize_parameters(self):

@@ -1154,6 +1154,26 @@ def check_discriminator_and_trainer_step():
     m["d_worst_rel_grad_err"] = worst
     assert worst <= 2e-3, m
     assert sum(p.numel() for p in D.parameters()) == 6962625            # D (patch_global) parameters
+    # loss assembly + HIP discriminator against the values of the reference's OWN LWGTrainer.optimize_G / optimize_D
+    # (golden_trainer_losses_v1.npz: seeded tensors and weights, tests/golden/make_golden_trainer_losses.py)
+    from tests.golden import make_golden_trainer_losses as mkl
+    from tests.golden.make_golden_discriminators import seeded_state_dict
+    from tests.test_oracle_golden import _trainer_on_golden_tensors
+    from ipercore_amd.trainers import create_discriminator
+    gl = np.load(os.path.join(ROOT, "tests", "golden", "golden_trainer_losses_v1.npz"))
+    Dg = create_discriminator("patch_global", synthetic.AttrDict(**mkl.DCFG))
+    Dg.load_state_dict(seeded_state_dict(Dg, 23), strict=True)
+    trg, tg = _trainer_on_golden_tensors(Dg.to(DEV))
+    trg.inp = {k: v.to(DEV) for k, v in trg.inp.items()}
+    tg = {k: v.to(DEV) for k, v in tg.items()}
+    with torch.no_grad():
+        lg_ = trg.optimize_G(tg["fake_bg"], tg["fake_src_imgs"], tg["fake_tsf_imgs"], tg["fake_masks"])
+        ld_ = trg.optimize_D(tg["fake_tsf_imgs"])
+    torch.cuda.synchronize()
+    got = dict(loss_G=lg_, loss_D=ld_, **{k: trg.losses[k] for k in ("g_rec", "g_tsf", "g_adv", "g_mask", "g_mask_smooth", "d_real", "d_fake")})
+    m["losses_vs_reference_trainer"] = {k: [float(v), float(gl[k])] for k, v in got.items()}
+    for k, v in got.items():
+        assert abs(float(v) - float(gl[k])) <= 2e-4 * max(1.0, abs(float(gl[k]))), (k, float(v), float(gl[k]))
     # trainer steps
     S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)

@@ -354,3 +354,41 @@ def test_discriminators_against_reference_classes():
         for i, o in enumerate(outs):
             assert np.abs(o.numpy() - g[f"{name}/out{i}"]).max() <= 2e-5, (name, i)
         assert abs(float(avg) - float(g[f"{name}/avg"])) <= 1e-6
+
+
+def _trainer_on_golden_tensors(D):
+    """A LWGTrainer shell around the tensors of golden_trainer_losses_v1 (no generator, no optimizers: optimize_G / optimize_D only
+    read ``inp``, ``opts`` and ``D``)."""
+    from tests.golden import make_golden_trainer_losses as mk
+    from ipercore_amd.trainers import LWGTrainer, TrainOpts
+    t = mk.tensors()
+    tr = object.__new__(LWGTrainer)
+    tr.D, tr.crt_tsf, tr.crt_face, tr.losses = D, None, None, {}
+    tr.opts = TrainOpts()
+    for k, v in mk.LAMBDAS.items():
+        setattr(tr.opts, k, v)
+    tr.inp = {"input_G_tsf": t["input_G_tsf"], "real_src": t["real_src"], "real_tsf": t["real_tsf"], "real_bg": t["real_bg"],
+              "body_mask": t["body_mask"]}
+    return tr, t
+
+
+def test_trainer_loss_assembly_against_reference_methods():
+    """LWGTrainer.optimize_G / optimize_D of the PRODUCT (their loss assembly is plain torch) against the values the reference's own
+    LWGTrainer.optimize_G / optimize_D produced on the same seeded tensors (golden_trainer_losses_v1.npz, generated by
+    tests/golden/make_golden_trainer_losses.py).  The discriminator inside is the oracle's restatement here (its HIP form is
+    compared with the reference's classes by the GPU checks); the same comparison runs on the GPU with the HIP discriminator."""
+    from tests.golden import make_golden_trainer_losses as mk
+    from tests.golden.make_golden_discriminators import seeded_state_dict
+    from ipercore_amd.trainers import create_discriminator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_trainer_losses_v1.npz"))
+    sd = seeded_state_dict(create_discriminator("patch_global", synthetic.AttrDict(**mk.DCFG)), 23)
+
+    def D(inputs):
+        return orc.discriminator_forward("patch_global", sd, inputs["x"], None, None, None, mk.DCFG["n_layers"], False)[0]
+    tr, t = _trainer_on_golden_tensors(D)
+    with torch.no_grad():
+        loss_g = tr.optimize_G(t["fake_bg"], t["fake_src_imgs"], t["fake_tsf_imgs"], t["fake_masks"])
+        loss_d = tr.optimize_D(t["fake_tsf_imgs"])
+    got = dict(loss_G=loss_g, loss_D=loss_d, **{k: tr.losses[k] for k in ("g_rec", "g_tsf", "g_adv", "g_mask", "g_mask_smooth", "d_real", "d_fake")})
+    for k, v in got.items():
+        assert abs(float(v) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
