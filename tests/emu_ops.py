@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from ipercore_amd import ops as real_ops
 
-ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
+ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid, 4: lambda v: F.leaky_relu(v, 0.2)}
 
 
 def _unpanel(w, ntaps, cin):
@@ -128,7 +128,7 @@ def instnorm_apply(x, mean, rstd, y, act=0, res=None):
     return y
 
 
-def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
+def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False, _differentiable=False):
     B, h, w, C = q.shape
     ns, S = T.shape[1], T.shape[2]
     Tf = T.reshape(B * ns, S, S, 2)
@@ -144,7 +144,10 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     Vw = Vw.view(B, ns, C, h, w) + bv.view(1, 1, C, 1, 1)
     logits = (Kw * q.permute(0, 3, 1, 2).unsqueeze(1)).sum(dim=2, keepdim=True) / math.sqrt(C)
     a = torch.softmax(logits, dim=1)
-    out.copy_((a * Vw).sum(dim=1).permute(0, 2, 3, 1))
+    res = (a * Vw).sum(dim=1).permute(0, 2, 3, 1)
+    if _differentiable:
+        return res
+    out.copy_(res)
     return out
 
 
@@ -274,11 +277,59 @@ def unpack_wgrad(dwk, dw, transposed, kidx, cin, cin_pad, nout):
     return dw
 
 
+def _norm_ref(x, mean, rstd, gamma, beta, act):
+    xn = (x - mean[:, None, None, :]) * rstd[:, None, None, :]
+    if gamma is not None:
+        xn = xn * (1 + gamma) + beta
+    return ACT[act](xn)
+
+
+def norm_fwd(x, gamma=None, beta=None, act=0, eps=1e-5):
+    """lwg_instnorm_stats + lwg_norm_fwd_nhwc_f32: y = act(IN(x) * (1 + gamma) + beta), biased variance."""
+    v = x.reshape(x.shape[0], -1, x.shape[3])
+    mean, rstd = v.mean(1), 1.0 / torch.sqrt(v.var(1, unbiased=False) + eps)
+    return _norm_ref(x, mean, rstd, gamma, beta, act), mean, rstd
+
+
+def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=0):
+    """lwg_norm_bwd_nhwc_f32 by torch autograd through the same formula (statistics are functions of x)."""
+    with torch.enable_grad():
+        xr = x.detach().clone().requires_grad_(True)
+        gr = None if gamma is None else gamma.detach().clone().requires_grad_(True)
+        br = None if gamma is None else torch.zeros_like(gamma).requires_grad_(True)
+        v = xr.reshape(xr.shape[0], -1, xr.shape[3])
+        eps = 1e-5
+        out = _norm_ref(xr, v.mean(1), 1.0 / torch.sqrt(v.var(1, unbiased=False) + eps), gr, br, act)
+        gs = torch.autograd.grad(out, [xr] if gamma is None else [xr, gr, br], dy)
+    return (gs[0], None, None) if gamma is None else tuple(gs)
+
+
+def lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=False):
+    """lwg_lwb_attention_bwd_f32 by torch autograd through the emulated forward."""
+    with torch.enable_grad():
+        qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, Ks, Vs))
+        out = lwb_attention(qr, kr, vr, bk, bv, T, torch.empty_like(q), src_batched=src_batched, _differentiable=True)
+        return torch.autograd.grad(out, [qr, kr, vr], dout)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
+    """lwg_adam_step_f32 = torch.optim.Adam's update (no weight decay, no amsgrad)."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    step = lr / (1 - beta1 ** t)
+    p.addcdiv_(m, (v / (1 - beta2 ** t)).sqrt() + eps, value=-step)
+
+
+def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None, out_hw=None, ycoff=0):
+    return unpack_wgrad(conv2d_wgrad(x0, spec, dy, x1=x1, out_hw=out_hw, ycoff=ycoff), dw, transposed, kidx, cin, spec.Cin, nout)
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
-                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad"):
+                 "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
+                 "lwb_attention_bwd", "adam_step", "conv2d_wgrad_unpacked"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

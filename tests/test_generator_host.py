@@ -220,3 +220,68 @@ def test_discriminator_variants_host_logic(monkeypatch):
     assert len(outs) == 1
     with pytest.raises(ValueError):
         NetworksFactory.get_by_name("multi_scale", cfg)
+
+
+def _as_device(fn):
+    """Run ``fn`` with torch.Tensor.is_cuda reporting True: the product's CUDA-only guards and its device-side packing /
+    un-packing paths are taken, against the emulated C ABI (tests/emu_ops.py)."""
+    import unittest.mock as um
+    with um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True):
+        return fn()
+
+
+def test_training_graph_host_logic_cpu(monkeypatch):
+    """The WHOLE training graph of the generator (bg + src with decoder + tsf: every ConvFn / NormAct / AttnFn / HeadFn, the thin
+    regressor backward, concat splits, parity launches) and of the discriminator (incl. the gradient it hands back to its input)
+    through the emulated C ABI on the CPU, against torch autograd through the oracle: outputs and EVERY parameter gradient.
+    The GPU suite makes the same comparison on the kernels (check_generator_training_grads); this one keeps the host logic under
+    the CPU suite."""
+    from ipercore_amd.networks.training import TrainableGenerator
+    from ipercore_amd.trainers import PatchDiscriminator
+    emu_ops.install(monkeypatch)
+    S_, ns, nf, nres, bgf = 32, 2, [64, 64, 128], 1, [64, 64, 128]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=synthetic.gen_cfg(nf, nres, bgf), temporal=False)
+    sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.train()
+    u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed, name))           # noqa: E731
+    bg_in, src_in, tsf_in = u((1, 1, 4, S_, S_), 10, "bg_inputs"), u((1, ns, 6, S_, S_), 8, "src_inputs"), u((1, 1, 6, S_, S_), 9, "tsf_inputs")
+    Tst = u((1, 1, ns, S_, S_, 2), 11, "Tst") * 1.1                                                   # some samples leave the image
+    tgt = [u(s, 500 + i, "tgt") for i, s in enumerate(((1, 1, 3, S_, S_), (1, ns, 3, S_, S_), (1, ns, 1, S_, S_), (1, 1, 3, S_, S_), (1, 1, 1, S_, S_)))]
+    loss_of = lambda outs: sum(((o - t) ** 2).mean() for o, t in zip(outs, tgt))                      # noqa: E731  (smooth: no sign flips)
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sdn.items()}
+    outs_ref = orc.gen_forward_train(sd, bg_in, src_in, tsf_in, Tst, n_down=len(nf), n_res=nres, n_bg=len(bgf))
+    loss_of(outs_ref).backward()
+
+    def run():
+        outs = TrainableGenerator(G).forward(bg_in, src_in, tsf_in, Tst)
+        loss_of(outs).backward()
+        return outs
+    outs = _as_device(run)
+    for name, a_, b_ in zip(("bg", "src_img", "src_mask", "tsf_img", "tsf_mask"), outs, outs_ref):
+        assert (a_.detach() - b_.detach()).abs().max().item() <= 2e-4, name
+    gmax = max(v.grad.abs().max().item() for v in sd.values())
+    for k, p_ in G.named_parameters():
+        assert p_.grad is not None, f"no gradient for {k}"
+        rel = (p_.grad - sd[k].grad).abs().max().item() / max(sd[k].grad.abs().max().item(), 1e-3 * gmax)
+        assert rel <= 2e-3, (k, rel)
+    # the discriminator: logits, parameter gradients and the gradient handed back to the input (G's adversarial term)
+    torch.manual_seed(1)
+    D = PatchDiscriminator(6, 32, 3, 8)
+    dsd = {"d." + k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    x = u((2, 6, 64, 64), 12, "dis_x")
+    xr = x.clone().requires_grad_(True)
+    (orc.patch_discriminator(dsd, "d.", xr, 3) ** 2).mean().backward()
+    xd = x.clone().requires_grad_(True)
+
+    def run_d():
+        out = D(xd)
+        (out ** 2).mean().backward()
+        return out
+    out = _as_device(run_d)
+    assert (out.detach() - orc.patch_discriminator(dsd, "d.", x, 3).detach()).abs().max().item() <= 1e-4
+    assert xd.grad is not None and (xd.grad - xr.grad).abs().max().item() <= 2e-3 * xr.grad.abs().max().item()
+    dmax = max(v.grad.abs().max().item() for v in dsd.values())
+    for k, p_ in D.named_parameters():
+        ref = dsd["d." + k].grad
+        assert (p_.grad - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-3 * dmax), k
