@@ -285,3 +285,60 @@ def test_training_graph_host_logic_cpu(monkeypatch):
     for k, p_ in D.named_parameters():
         ref = dsd["d." + k].grad
         assert (p_.grad - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-3 * dmax), k
+
+
+def test_trainer_step_host_logic_cpu(monkeypatch):
+    """One LWGTrainer.optimize_parameters() (lwg_trainer.py:326-352: forward, G loss / backward / Adam, then the D loss on the
+    detached fakes of the SAME forward / backward / Adam) through the emulated C ABI: both loss values and the gradients the two
+    Adam updates consumed (the flat buffers of FlatAdam) against torch autograd through the oracle's generator and discriminator
+    with the loss assembly restated here; the parameters move."""
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
+    emu_ops.install(monkeypatch)
+    S_, ns, nf, nres, bgf = 32, 2, [64, 64, 128], 1, [64, 64, 128]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=synthetic.gen_cfg(nf, nres, bgf), temporal=False)
+    sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.train()
+    torch.manual_seed(2)
+    D = PatchGlobalDiscriminator(ndf=32, n_layers=3)
+    u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed, name))           # noqa: E731
+    inp = {"input_G_bg": u((1, 1, 4, S_, S_), 10, "bg_inputs"), "input_G_src": u((1, ns, 6, S_, S_), 8, "src_inputs"),
+           "input_G_tsf": u((1, 1, 6, S_, S_), 9, "tsf_inputs"), "Tst": u((1, 1, ns, S_, S_, 2), 11, "Tst"),
+           "real_src": u((1, ns, 3, S_, S_), 700, "real_src"), "real_tsf": u((1, 1, 3, S_, S_), 701, "real_tsf"),
+           "real_bg": u((1, 3, S_, S_), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S_, S_), 703, "mask") > 0).float()}
+    sdG = {k: torch.tensor(v, requires_grad=True) for k, v in sdn.items()}
+    sdD = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    o = TrainOpts()
+    # ---- the step restated on the oracle (plain torch, CPU)
+    bg, s_col, s_mask, t_col, t_mask = orc.gen_forward_train(sdG, inp["input_G_bg"], inp["input_G_src"], inp["input_G_tsf"], inp["Tst"],
+                                                             n_down=len(nf), n_res=nres, n_bg=len(bgf))
+    fake_src, fake_tsf = s_mask * bg + (1 - s_mask) * s_col, t_mask * bg + (1 - t_mask) * t_col
+    cond = inp["input_G_tsf"][:, :, -3:].reshape(1, 3, S_, S_)
+    dis = lambda x: orc.patch_discriminator(sdD, "global_model.", x, 3)                                 # noqa: E731
+    l1 = torch.nn.functional.l1_loss
+    fm = torch.cat([s_mask, t_mask], dim=1).view(-1, 1, S_, S_)
+    tv = (fm[:, :, :, :-1] - fm[:, :, :, 1:]).abs().mean() + (fm[:, :, :-1, :] - fm[:, :, 1:, :]).abs().mean()
+    loss_g = ((l1(fake_src, inp["real_src"]) + l1(bg.view(-1, 3, S_, S_), inp["real_bg"])) / 2 * o.lambda_rec
+              + l1(fake_tsf.view(1, 3, S_, S_), inp["real_tsf"].view(1, 3, S_, S_)) * o.lambda_tsf
+              + (dis(torch.cat([fake_tsf.view(1, 3, S_, S_), cond], dim=1)) ** 2).mean() * o.lambda_D_prob
+              + torch.nn.functional.binary_cross_entropy(fm, inp["body_mask"].view(-1, 1, S_, S_)) * o.lambda_mask + tv * o.lambda_mask_smooth)
+    gG = torch.autograd.grad(loss_g, list(sdG.values()))
+    d_real = dis(torch.cat([inp["real_tsf"].view(1, 3, S_, S_), cond], dim=1))
+    d_fake = dis(torch.cat([fake_tsf.detach().view(1, 3, S_, S_), cond], dim=1))
+    loss_d = ((d_real - 1) ** 2).mean() + ((d_fake + 1) ** 2).mean()
+    gD = torch.autograd.grad(loss_d, list(sdD.values()))
+    # ---- the product's step
+    tr = LWGTrainer(G, D, opts=o)
+    tr.set_input(inp)
+    w0 = {k: v.detach().clone() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
+    lg, ld = _as_device(tr.optimize_parameters)
+    assert abs(lg.item() - loss_g.item()) <= 1e-4 * abs(loss_g.item()) and abs(ld.item() - loss_d.item()) <= 1e-4 * abs(loss_d.item())
+    for mod, ref_sd, ref_g in ((G, sdG, gG), (D, sdD, gD)):
+        gmax = max(g_.abs().max().item() for g_ in ref_g)
+        for (k, p_), g_ in zip(mod.named_parameters(), ref_g):
+            assert list(ref_sd.keys()).index(k) >= 0 and p_.grad is not None, k
+            g_ = ref_g[list(ref_sd.keys()).index(k)]
+            assert (p_.grad - g_).abs().max().item() <= 2e-3 * max(g_.abs().max().item(), 1e-3 * gmax), k
+    moved = {k: (v.detach() - w0[k]).abs().max().item() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
+    # Adam's first step: |dw| <= lr; every weight tensor is updated (a bias in front of an InstanceNorm has a zero gradient)
+    assert max(moved.values()) <= 1.001e-4 and all(v > 0 for k, v in moved.items() if k.endswith("weight")), moved
