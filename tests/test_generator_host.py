@@ -342,3 +342,59 @@ def test_trainer_step_host_logic_cpu(monkeypatch):
     moved = {k: (v.detach() - w0[k]).abs().max().item() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
     # Adam's first step: |dw| <= lr; every weight tensor is updated (a bias in front of an InstanceNorm has a zero gradient)
     assert max(moved.values()) <= 1.001e-4 and all(v > 0 for k, v in moved.items() if k.endswith("weight")), moved
+
+
+def test_loss_networks_host_logic_cpu(monkeypatch):
+    """The two frozen loss networks of the personalization step through the emulated C ABI on the CPU:
+    Sphere20aFeatures / FaceLoss against outputs of the reference's OWN Sphere20a (golden_faceloss_v1.npz: five features + the loss),
+    VGG19Features / VGGLoss against the same network written with F.conv2d / F.max_pool2d (value and image gradient; frozen
+    weights take ConvFn's data-gradient-only path)."""
+    from tests.golden.make_golden_faceloss import face_state_dict
+    from ipercore_amd.trainers import FaceLoss, VGGLoss
+    emu_ops.install(monkeypatch)
+    gf = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_faceloss_v1.npz"))
+    crt = FaceLoss(None)
+    crt.net.load_state_dict(face_state_dict(), strict=True)
+    x, y = torch.tensor(synthetic.uniform_image((2, 3, 112, 96), 70, "face_x")), torch.tensor(synthetic.uniform_image((2, 3, 112, 96), 71, "face_y"))
+
+    def run_face():
+        with torch.no_grad():
+            return crt.net(x), crt(x, y)
+    fx, loss = _as_device(run_face)
+    for i, f in enumerate(fx):
+        got = f.permute(0, 3, 1, 2)[:, ::8] if f.dim() == 4 else f
+        assert (got - torch.tensor(gf[f"fx{i}"])).abs().max().item() <= 2e-4, i
+    assert abs(loss.item() - float(gf["loss"])) <= 2e-4 * abs(float(gf["loss"]))
+    # VGG19 perceptual loss at a small size
+    vcrt = VGGLoss(ckpt_path=None)
+    sd = {k: v.detach() for k, v in vcrt.vgg.state_dict().items()}
+
+    def ref_feats(t):
+        outs = []
+        for item in vcrt.vgg.CFG:
+            if item == "M":
+                t = F.max_pool2d(t, 2, 2)
+                continue
+            t = F.relu(F.conv2d(t, sd[f"features.{item[0]}.weight"], sd[f"features.{item[0]}.bias"], padding=1))
+            if item[0] in vcrt.vgg.TAPS:
+                outs.append(t)
+        return outs
+    a, b = torch.tensor(synthetic.uniform_image((1, 3, 32, 32), 990, "vgg_x")) * 0.5, torch.tensor(synthetic.uniform_image((1, 3, 32, 32), 991, "vgg_y")) * 0.5
+    with torch.no_grad():
+        fb = ref_feats(b)
+    ar = a.clone().requires_grad_(True)
+    sum(w * F.mse_loss(p, q) for w, p, q in zip(vcrt.WEIGHTS, ref_feats(ar), fb)).backward()
+    ad = a.clone().requires_grad_(True)
+
+    def run_vgg():
+        with torch.no_grad():
+            fbd = vcrt.vgg(b)
+        feats = vcrt.vgg(ad)
+        sum(w * F.mse_loss(p, q) for w, p, q in zip(vcrt.WEIGHTS, feats, fbd)).backward()
+        return feats
+    feats = _as_device(run_vgg)
+    for p, q in zip(feats, ref_feats(a)):
+        q = q.permute(0, 2, 3, 1) if p.shape != q.shape else q
+        assert (p.detach() - q).abs().max().item() <= 1e-4 * max(1.0, q.abs().max().item())
+    assert (ad.grad - ar.grad).abs().max().item() <= 2e-3 * ar.grad.abs().max().item()
+    assert all(p.grad is None for p in vcrt.vgg.parameters())                  # frozen: no weight gradients were formed
