@@ -3,18 +3,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
 
-A step = one pass of the hot path (camera swap, SMPL-H skinning, projection +
-rasterization, fused flows, AttLWB-SPADE forward_tsf, head + compositing) over one batch of ``--frame-batch``
-synthetic target frames of BASELINE.json configs[1] (512x512, one source/reference pair, ns = 2, random-init
-weights of the real architecture, synthetic SMPL-H + T-pose template geometry).  Inputs (SMPL parameters, cached
-source state) are resident in HBM before the timed region; source_setup and PNG writing are outside it.  With
-N > 1 the clip is frame-sharded (weak scaling: every rank renders K batches) and the timed region ends with the
-single RCCL all-gather of the output video tensor.
+Workload (all N): ONE source/reference pair, a ``--frames``-frame reference clip (300: BASELINE.json configs[2]; the same clip on
+one GPU is configs[1]).  A step = one pass of the hot path (camera swap, SMPL-H skinning, projection +
+rasterization, fused flows, AttLWB-SPADE forward_tsf, head + compositing) over the WHOLE clip: every rank renders its contiguous
+shard (37 / 38 frames at N = 8) in batches of ``--frame-batch`` frames and the output video tensor is assembled by the RCCL
+all-gather, issued chunk by chunk behind the frame loop (ipercore_amd/sharding.py).  Total work is fixed as N grows: STRONG
+scaling; ``value`` = frames of the clip x K / wall time (max over ranks, barrier + synchronize on both sides).  Inputs (SMPL
+parameters, cached source state) are resident in HBM before the timed region; the sequence-global pre-pass (stabilize),
+source_setup and PNG writing are outside it.  Synthetic data, random-init (seeded) weights of the real architecture.
+``--mode batch`` is the former weak-scaling measurement (a step = one frame batch per rank).
 
-Prints ONE JSON line on rank 0.  ``roofline`` is for the dominant kernel (the fp32 MFMA implicit-GEMM conv):
-algorithmic conv flops of all its launches in the timed region / their HIP-event time, against the 157.3
-TFLOP/s fp32 matrix peak of gfx950.  ``cpu_baseline`` times the CPU oracle ("port") on this host for a few
-frames of the same workload.
+Prints ONE JSON line on rank 0.  ``roofline`` is for the dominant kernel (the MFMA implicit-GEMM conv): algorithmic conv flops of
+all its launches in the timed region / their HIP-event time, against the matrix peak of the dtype.  ``cpu_baseline`` times the CPU
+oracle ("port") on this host for a few frames of the same workload and, where the reference checkout is importable
+(LWG_REFERENCE, default /root/reference - the authoring container, not the GPU box), the reference's own modules ("reference").
+Extra objects, each measured in its own loop and never the headline: ``pipelined``, ``split_products``, ``with_output``,
+``b1_latency`` (frame_batch = 1), ``novel_view_1024_bf16`` (BASELINE configs[3]), ``personalize_step`` (configs[4]).
 """
 import argparse
 import json
@@ -30,7 +34,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide); the bf16-operand kernel is L2/HBM bound, far below it
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide)
+PEAK_HBM_TBS = 8.0
 
 
 class ConvTimer:
@@ -40,7 +45,10 @@ class ConvTimer:
         self.pairs, self.flops, self.bytes, self.enabled, self.meta = [], 0.0, 0.0, False, []
         self._start = None
 
-    def __call__(self, begin, M, spec, epi=0):
+    def reset(self):
+        self.pairs, self.flops, self.bytes, self.meta = [], 0.0, 0.0, []
+
+    def __call__(self, begin, M, spec, epi=0, act_bytes=4):
         if not self.enabled:
             return
         if begin:
@@ -53,7 +61,8 @@ class ConvTimer:
             self.flops += 2.0 * M * spec.algo_kn
             # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
             out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
-            self.bytes += 4.0 * (M * spec.stride ** 2 * spec.Cin + spec.w.numel() + out + (M * spec.N if epi == 1 else 0))
+            self.bytes += float(act_bytes) * (M * spec.stride ** 2 * spec.Cin + out + (M * spec.N if epi == 1 else 0)) + \
+                float(act_bytes) * spec.w.numel()
             self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn))
 
     def result(self):
@@ -89,20 +98,102 @@ class ConvTimer:
         return sorted(rows, key=lambda r: -r["ms"])
 
 
+# ---------------------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline(case, n_frames):
-    """The oracle (CPU restatement of the reference algorithm) on the host cores, a bounded sample."""
+    """The oracle (CPU restatement of the reference algorithm) on the host cores, a bounded sample: the per-frame loop only
+    (the source state is built first, untimed - source-side work is not part of the per-frame metric)."""
+    from oracle import lwg_oracle as orc
     from tests import parity_utils as pu
+    model, tables, sd, info = pu.oracle_source(case)
+    tgt = orc.stabilize(model, torch.tensor(case.tgt_smpls))
+    first_cam = tgt[0:1, 0:3].clone()
     t0 = time.time()
-    pu.oracle_source(case)                       # source-side work is not part of the per-frame metric
-    t_src = time.time() - t0
-    t0 = time.time()
-    pu.run_oracle(case, frames=list(range(n_frames)))
-    dt = time.time() - t0 - t_src                # run_oracle rebuilds the source state once
-    return {"value": round(n_frames / max(dt, 1e-9), 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_frames} frames @{case.S}x{case.S} ns={case.ns} through oracle/lwg_oracle.py (torch-CPU fp32 + "
-                      f"OpenMP C rasterizer), {os.cpu_count()} host cpus"}
+    for t in range(n_frames):
+        with torch.no_grad():
+            r = orc.imitate_frame(model, tables, sd, info, tgt[t], first_cam, case.S, "smooth")
+    dt = time.time() - t0
+    assert torch.isfinite(r["pred"]).all()
+    out = {"value": round(n_frames / max(dt, 1e-9), 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_frames} frames @{case.S}x{case.S} ns={case.ns} through oracle/lwg_oracle.py (torch-CPU fp32 + "
+                     f"OpenMP C rasterizer), {os.cpu_count()} host cpus"}
+    ref = cpu_baseline_reference(case, n_frames)
+    if ref is not None:
+        out["reference"] = ref
+    return out
 
 
+def cpu_baseline_reference(case, n_frames):
+    """The reference's OWN modules (forward_tsf, cal_bc_transform, encode_fim, lbs + grid_sample / compose) timed on this
+    host, when its checkout is importable (LWG_REFERENCE, default /root/reference: the authoring container - the GPU box has no
+    copy, and then this returns None and the line carries the port only).  The rasterizer call inside SMPLRenderer goes to the
+    oracle's C restatement (neural_renderer is not vendored with the reference): that leg is "restatement", everything else "reference"."""
+    ref_root = os.environ.get("LWG_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "iPERCore")):
+        return None
+    try:
+        from tests.golden import make_golden as mg       # the import recipe of SURVEY 8c (stubs neural_renderer / cv2 / torchvision)
+        mg.install_stubs()
+        import torch.nn.functional as F
+        from iPERCore.models.networks.generators.attlwb_spade_resunet import AttentionLWBGenerator
+        from iPERCore.tools.human_digitalizer.bodynets.batch_smplh import SMPLH
+        from iPERCore.tools.human_digitalizer.renders.nmr import SMPLRenderer
+        from iPERCore.tools.utils.geometry.cam_pose_utils import WeakPerspectiveCamera
+        from ipercore_amd import synthetic
+        S, ns = case.S, case.ns
+        tmp = synthetic.tmp_asset_dir()
+        cfgdir = os.path.join(ref_root, "assets/configs/pose3d")
+        render = SMPLRenderer(face_path=synthetic.write_smpl_faces_npy(os.path.join(tmp, "smpl_faces.npy")),
+                              fim_enc_path=os.path.join(cfgdir, "mapper_fim_enc.txt"), uv_map_path=os.path.join(cfgdir, "mapper_uv.txt"),
+                              part_path=os.path.join(cfgdir, "smpl_part_info.json"), front_path=os.path.join(cfgdir, "front_body.json"),
+                              head_path=os.path.join(cfgdir, "head.json"), facial_path=os.path.join(cfgdir, "front_facial.json"),
+                              map_name="uv_seg", tex_size=3, image_size=S, fill_back=False, anti_aliasing=True,
+                              background_color=(0, 0, 0), has_front=True, top_k=3)
+        smplh = SMPLH(model_path=synthetic.write_smplh_pickle(os.path.join(tmp, "smplh_synth.pkl"), seed=0))
+        G = AttentionLWBGenerator(mg.gen_cfg(case.num_filters, case.n_res, case.bg_filters), temporal=False).eval()
+        G.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
+        wcam = WeakPerspectiveCamera(smplh)
+        t_leg = {"lbs": 0.0, "rasterize (restatement)": 0.0, "encode_fim + cal_bc_transform": 0.0, "grid_sample": 0.0, "forward_tsf": 0.0}
+        with torch.no_grad():
+            src = smplh.get_details(torch.tensor(case.src_smpl), 0, links_ids=None)
+            src_f2pts, src_fim, _ = render.render_fim_wim(src["cam"], src["verts"], smpl_faces=True)
+            src_cond, _ = render.encode_fim(fim=src_fim, transpose=True)
+            enc, res = G.forward_src(torch.cat([torch.tensor(case.src_img)[0], src_cond], dim=1).unsqueeze(0), only_enc=True)
+            uv_img, bg = torch.tensor(case.uv_img), torch.tensor(case.bg_img)
+            f_uvs2img = render.get_f_uvs2img(1)
+            tgt = wcam.stabilize(torch.tensor(case.tgt_smpls))
+            first_cam = tgt[0:1, 0:3].clone()
+            t_all = time.time()
+            for t in range(n_frames):
+                t0 = time.time()
+                cam = WeakPerspectiveCamera.cam_swap(src["cam"][0:1], tgt[t:t + 1, 0:3], first_cam, "smooth")
+                ref = smplh.get_details(torch.cat([cam, tgt[t:t + 1, 3:-10], src["shape"][0:1]], dim=1), 0, links_ids=None)
+                t1 = time.time()
+                _, fim, wim = render.render_fim_wim(ref["cam"], ref["verts"], smpl_faces=True)
+                t2 = time.time()
+                cond, _ = render.encode_fim(fim=fim, transpose=True)
+                Tuv2t = render.cal_bc_transform(f_uvs2img.clone(), fim, wim)
+                Tst = render.cal_bc_transform(src_f2pts, fim.repeat(ns, 1, 1), wim.repeat(ns, 1, 1, 1))
+                t3 = time.time()
+                syn = F.grid_sample(uv_img, Tuv2t)
+                t4 = time.time()
+                img, mask = G.forward_tsf(torch.cat([syn, cond], dim=1), enc, res, Tst.view(1, ns, S, S, 2))
+                pred = mask * bg + (1 - mask) * img
+                t5 = time.time()
+                for k, d in zip(t_leg, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                    t_leg[k] += d
+            dt = time.time() - t_all
+        assert torch.isfinite(pred).all()
+        return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "reference",
+                "legs_ms_per_frame": {k: round(v / n_frames * 1e3, 1) for k, v in t_leg.items()},
+                "frames_per_s_reference_legs_only": round(n_frames / max(sum(v for k, v in t_leg.items() if "restatement" not in k), 1e-9), 4),
+                "sample": f"{n_frames} frames @{S}x{S} ns={ns}: the reference's own SMPLH.get_details, SMPLRenderer.encode_fim / "
+                          f"cal_bc_transform, F.grid_sample and AttentionLWBGenerator.forward_tsf (torch-CPU fp32, imported from {ref_root}); "
+                          "its external rasterizer call = the oracle's C restatement"}
+    except Exception as e:                       # the baseline is a courtesy measurement: never fail the bench line over it
+        return {"kind": "reference", "error": f"{type(e).__name__}: {e}"}
+
+
+# ---------------------------------------------------------------------------------------------------------- extra measurements
 def with_output(im, smpls, FB, n_frames, t_base):
     """Reported separately: the same per-frame path WITH the output stage - device uint8 conversion, pinned async
     D2H, PNG encoding + file writes on host threads (ipercore_amd/output.py).  Not the headline value."""
@@ -130,8 +221,20 @@ def with_output(im, smpls, FB, n_frames, t_base):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def split_products(step, im, W, K, FB, ref_outs):
-    """Reported separately: the same K steps with every Cin % 32 == 0 convolution on the bf16x6 kernel
+def _timed_clips(render, W, K):
+    for _ in range(W):
+        render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(K):
+        out = render()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def split_products(im, render, n, W, K, ref_video):
+    """Reported separately: the same clip with every Cin % 32 == 0 convolution on the bf16x6 kernel
     (csrc/conv_igemm_split.hip: fp32 in / out / accumulate, each fp32 product formed from six bf16 MFMAs over an exact
     three-way split of both operands).  Not the headline value; `max_abs_diff_vs_fp32_path` compares the frames."""
     from ipercore_amd import ops
@@ -139,15 +242,9 @@ def split_products(step, im, W, K, FB, ref_outs):
     prev = im.generator.conv_precision
     im.generator.conv_precision = "split"
     try:
-        for i in range(min(W, 4)):
-            step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        outs = [step(i) for i in range(W, W + K)]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        diff = max((a - b).abs().max().item() for a, b in zip(outs, ref_outs))
-        return {"value": round(K * FB / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / K * 1e3, 3),
+        dt, video = _timed_clips(render, W, K)
+        diff = (video - ref_video).abs().max().item()
+        return {"value": round(K * n / dt, 3), "unit": "frames/s", "ms_per_clip": round(dt / K * 1e3, 3), "clips": K,
                 "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
                 "what": "bf16x6: exact 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per product, fp32 accumulation"}
     finally:
@@ -155,45 +252,135 @@ def split_products(step, im, W, K, FB, ref_outs):
         ops.CONV_HOOK = hook
 
 
-def pipelined(step, W, K, FB, n_streams, dev):
-    """Reported separately: the same K steps with independent frame batches in flight on several HIP streams, so that one
-    batch's launch gaps, kernel tails and HBM-bound kernels overlap another batch's MFMA work.  Not the headline value (the
-    per-kernel roofline accounting above needs launches that own the machine)."""
+def pipelined(im, render, n, W, K, n_streams):
+    """Reported separately: the same clip with independent frame batches in flight on several HIP streams (Imitator(streams=n)), so
+    that one batch's launch gaps, kernel tails and HBM-bound kernels overlap another batch's MFMA work.  Not the headline value (the
+    per-kernel roofline accounting needs launches that own the machine)."""
     from ipercore_amd import ops
     hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    prev = im.streams
+    im.streams = n_streams
     try:
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-        for i in range(W):
-            with torch.cuda.stream(streams[i % n_streams]):
-                step(i)
+        dt, video = _timed_clips(render, W, K)
+        assert torch.isfinite(video).all()
+        return {"value": round(K * n / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_clip": round(dt / K * 1e3, 3), "clips": K}
+    finally:
+        im.streams = prev
+        ops.CONV_HOOK = hook
+
+
+def b1_latency(im, tgt, timer, n_frames=64):
+    """frame_batch = 1 - the reference's calling convention (one frame per Imitator.forward, imitator.py:341): per-frame time when
+    single frames are issued back to back, the wall time of ONE frame from an idle queue (launch to last byte), and the conv kernel's
+    roofline fraction in that regime (the 64x64-feature layers then have 4096 GEMM rows: one 128x128 tile row per 8 CUs)."""
+    from ipercore_amd import ops
+    prev = im.frame_batch
+    im.frame_batch = 1
+    hook = ops.CONV_HOOK
+    try:
+        ops.CONV_HOOK = None
+        n = min(n_frames, tgt.shape[0])
+        im.synthesize(tgt[:8], "smooth")
+        idle = []
+        for i in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            im.synthesize(tgt[i:i + 1], "smooth", t0=i)
+            torch.cuda.synchronize()
+            idle.append((time.perf_counter() - t0) * 1e3)
+        timer.reset()
+        timer.enabled, ops.CONV_HOOK = True, timer
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        outs = []
-        for i in range(W, W + K):
-            with torch.cuda.stream(streams[i % n_streams]):
-                outs.append(step(i))
+        im.synthesize(tgt[:n], "smooth")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        assert all(torch.isfinite(o).all() for o in outs[-n_streams:])
-        return {"value": round(K * FB / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_step": round(dt / K * 1e3, 3)}
+        timer.enabled = False
+        conv_ms, conv_flops, n_launch, mean_ms = timer.result()
+        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        return {"frame_batch": 1, "frames": n, "ms_per_frame_back_to_back": round(dt / n * 1e3, 3), "frames_per_s": round(n / dt, 2),
+                "ms_one_frame_from_idle_median": round(float(np.median(idle)), 3), "ms_one_frame_from_idle_min": round(min(idle), 3),
+                "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
+                             "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
+    finally:
+        im.frame_batch = prev
+        ops.CONV_HOOK = hook
+        timer.reset()
+
+
+def novel_view_smpls(case, hands_mean, length=180):
+    """BASELINE configs[3] poses as services/run_viewer.py:69-77 builds them: create_T_pose_novel_view_smpl(180) (base_runner.py:11-30),
+    the source's shape and body pose (T_pose = False), add_hands_params_to_smpl."""
+    from ipercore_amd.imitator import add_hands_params_to_smpl, create_T_pose_novel_view_smpl
+    nv = create_T_pose_novel_view_smpl(length)
+    nv[:, -10:] = case.src_smpl[0, -10:]
+    nv[:, 6:-10] = case.src_smpl[0, 6:-10]
+    return add_hands_params_to_smpl(nv, hands_mean).astype(np.float32)
+
+
+def novel_view_1024_bf16(dev, timer, W, K):
+    """BASELINE configs[3] on this GPU, reported beside the headline: 1024x1024, the 180 novel-view poses, bf16 MFMA conv tiles with
+    bf16 activation storage, fp32 renderer; a step = the 180-frame clip."""
+    from ipercore_amd import ops, synthetic as syn
+    S, n = 1024, 180
+    case = syn.build_case(image_size=S, n_frames=1, ns=2)
+    FB = 2
+    im = syn.make_imitator(case, frame_batch=FB, device=dev)
+    im.generator.conv_precision = "bf16"
+    im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    tgt = im.prepare_sequence(novel_view_smpls(case, im.body_rec.np_hands_mean, n), "smooth")
+    hook = ops.CONV_HOOK
+    try:
+        ops.CONV_HOOK = None
+        for _ in range(W):
+            im.synthesize(tgt, "smooth")
+        timer.reset()
+        timer.enabled, ops.CONV_HOOK = True, timer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            video = im.synthesize(tgt, "smooth")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        assert torch.isfinite(video).all()
+        conv_ms, conv_flops, n_launch, mean_ms = timer.result()
+        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": FB, "image_size": S,
+                "dtype": "bf16 MFMA operands + bf16 activation storage, f32 accumulation / renderer",
+                "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
+                             "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 1),
+                             "algorithmic_bytes_per_launch": round(timer.bytes / max(n_launch, 1), 1),
+                             "hbm_time_at_peak_us_per_launch": round(timer.bytes / max(n_launch, 1) / (PEAK_HBM_TBS * 1e12) * 1e6, 2),
+                             "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
     finally:
         ops.CONV_HOOK = hook
+        timer.reset()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)   # the shader clock needs ~0.2 s of load to settle
+    ap.add_argument("--warmup", type=int, default=5)    # the shader clock needs ~0.2 s of load to settle
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=0, help="frames of the reference clip rendered per step (0 = 300, BASELINE configs[2]; "
+                                                          "180 for --workload novel_view)")
+    ap.add_argument("--mode", choices=("clip", "batch"), default="clip",
+                    help="clip: a step = the whole clip, frame-sharded over the ranks (strong scaling, the default); batch: a step = one "
+                         "frame batch per rank (weak scaling, the round-1 measurement)")
     ap.add_argument("--frame-batch", type=int, default=0,
                     help="frames per launch batch; 0 = 8 at 512x512 scaled by (512/size)^2 (the 64x64-feature layers need "
                          ">= 32768 GEMM rows to give every CU two 128x128 tiles), clamped to [2, 64]")
+    ap.add_argument("--gather-dtype", choices=("f32", "u8"), default="f32",
+                    help="N > 1: exchange the (n,3,S,S) fp32 video the reference returns, or the (n,S,S,3) uint8 video its PNG writer "
+                         "consumes (device-side conversion; a quarter of the bytes on the xGMI ring)")
+    ap.add_argument("--no-overlap-gather", dest="overlap", action="store_false", help="one all-gather after the frame loop")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=("fp32", "bf16", "split"), default="fp32",
-                    help="bf16: BASELINE configs[3] mode - bf16 MFMA operands in the convs (fp32 activations / accumulation); "
+                    help="bf16: BASELINE configs[3] mode - bf16 MFMA operands and bf16 activation storage in the convs (fp32 accumulation); "
                          "the headline metric (configs[1]) is fp32")
     ap.add_argument("--workload", choices=("imitate", "novel_view"), default="imitate",
                     help="novel_view: BASELINE configs[3] poses - create_T_pose_novel_view_smpl(180), global rotation y = 0..360")
@@ -201,8 +388,10 @@ def main():
     ap.add_argument("--pipelined-streams", type=int, default=3,
                     help="extra (separately reported) measurement with this many frame batches in flight; 0/1 = skip")
     ap.add_argument("--no-conv-events", action="store_true")
-    ap.add_argument("--no-split-extra", dest="split_extra", action="store_false",
-                    help="skip the separately reported bf16x6 (exact-split products) measurement")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="skip every separately reported measurement (pipelined, split_products, with_output, b1_latency, "
+                         "novel_view_1024_bf16, personalize_step)")
+    ap.add_argument("--no-split-extra", dest="split_extra", action="store_false")
     ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     args = ap.parse_args()
@@ -214,8 +403,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":       # the host driver supports dmabuf IPC only (RCCL needs it)
+            if rank == 0:
+                print("[bench] HSA_ENABLE_IPC_MODE_LEGACY was not 0 in the environment: setting it for RCCL", file=sys.stderr)
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        assert dist.get_world_size() == world
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
@@ -223,117 +416,119 @@ def main():
     S = args.size
     FB = args.frame_batch or max(2, min(64, int(round(8 * (512.0 / S) ** 2))))
     K, W = args.steps, args.warmup
-    per_rank = (K + W) * FB
-    case = pu.build_case(image_size=S, n_frames=per_rank * world, ns=2)
-    if args.workload == "novel_view":
-        from ipercore_amd.imitator import create_T_pose_novel_view_smpl
-        nv = create_T_pose_novel_view_smpl(180)
-        nv[:, 0:3], nv[:, -10:] = case.src_smpl[0, 0:3], case.src_smpl[0, -10:]
-        case.tgt_smpls = np.concatenate([nv] * (case.tgt_smpls.shape[0] // 180 + 1), axis=0)[:case.tgt_smpls.shape[0]]
+    clip = args.mode == "clip"
+    n_clip = args.frames or (180 if args.workload == "novel_view" else 300)
+    n_seq = n_clip if clip else (K + W) * FB * world
+    case = pu.build_case(image_size=S, n_frames=n_seq, ns=2)
     im = pu.make_imitator(case, frame_batch=FB, device=dev)
+    im.streams = max(1, args.streams)
+    if args.workload == "novel_view":
+        nv = novel_view_smpls(case, im.body_rec.np_hands_mean, 180)
+        case.tgt_smpls = np.concatenate([nv] * (n_seq // 180 + 1), axis=0)[:n_seq]
     if args.precision != "fp32":
         im.generator.conv_precision = args.precision
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")          # sequence-global pre-pass, every rank identically
-    lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
-    mine = tgt[lo:hi].contiguous()
+    act_bytes = 2 if args.precision == "bf16" else 4
 
-    lo_out = rank * K * FB                                   # this rank's block inside the gathered (K * FB * world) video
     timer = ConvTimer()
-    ops.CONV_HOOK = None if args.no_conv_events else timer
+    hook = None if args.no_conv_events else (lambda b, M, spec, epi=0: timer(b, M, spec, epi, act_bytes))
+    ops.CONV_HOOK = hook
 
-    def step(i):
-        chunk = mine[i * FB:(i + 1) * FB]
-        tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, chunk, "smooth", t=lo + i * FB)
-        return im.forward(tsf8, Tst)[0]
+    post = None
+    if args.gather_dtype == "u8":
+        def post(x):
+            return ops.frames_to_u8(x) if x.shape[0] else torch.empty((0, S, S, 3), device=x.device, dtype=torch.uint8)
+    stats = {}
+
+    if clip:
+        def step(i):
+            st = {"sync": torch.cuda.synchronize} if world > 1 else {}
+            v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=post, stats=st)
+            stats.setdefault("exposed_gather_s", []).append(st.get("exposed_gather_s"))
+            stats.update({k: st[k] for k in ("shard", "bytes_received", "chunks") if k in st})
+            return v
+        frames_per_step = n_clip
+    else:
+        lo, hi = sharding.shard_range(tgt.shape[0], rank, world)
+        mine = tgt[lo:hi].contiguous()
+
+        def step(i):
+            chunk = mine[i * FB:(i + 1) * FB]
+            tsf8, Tst, _ = im.make_inputs_for_tsf(im.src_info, chunk, "smooth", t=lo + i * FB)
+            out = im.forward(tsf8, Tst)[0]
+            return out if world == 1 else sharding.all_gather_frames(out, FB * world)
+        frames_per_step = FB * world
 
     last = None
-    for i in range(W):
+    for i in range(W):                       # untimed: settles the clock and, for N > 1, sets up RCCL's channels at the timed sizes
         last = step(i)
+    if last is None and world > 1:
+        last = step(0)
     torch.cuda.synchronize()
     if world > 1:
-        if last is None:                                     # --warmup 0: the collective still gets its untimed first call
-            last = step(0)
-        # untimed: the first collective of a size class sets up RCCL's channels / buffers - do it once at the timed shape
-        wg = sharding.OverlappedGather(FB * world)
-        wg.submit(last, 0)
-        wg.finish()
-        del wg
         dist.barrier()
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
-    if streams:
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-        for i in range(W):          # warm the side streams too
-            with torch.cuda.stream(streams[i % len(streams)]):
-                step(i)
-        torch.cuda.synchronize()
+    stats.pop("exposed_gather_s", None)
+    timer.reset()
     timer.enabled = True
-    outs = []
-    og = sharding.OverlappedGather(K * FB * world) if world > 1 else None     # each step's frames go to RCCL as they appear
     t0 = time.perf_counter()
     for i in range(W, W + K):
-        if streams:
-            with torch.cuda.stream(streams[i % len(streams)]):
-                outs.append(step(i))
-        else:
-            outs.append(step(i))
-        if og is not None and not streams:
-            og.submit(outs[-1], (i - W) * FB)
-    if streams:
-        for st in streams:
-            torch.cuda.current_stream().wait_stream(st)
-        if og is not None:
-            for j, o in enumerate(outs):
-                og.submit(o, j * FB)
-    if og is not None:
-        video = og.finish()
-        local = video[lo_out:lo_out + K * FB]
-    else:
-        video = local = torch.cat(outs, dim=0)
+        last = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    assert video.shape[0] == K * FB * world and torch.isfinite(local).all()
+    assert last.shape[0] == frames_per_step and bool(torch.isfinite(last.float()).all())
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    per_rank = None
+    if world > 1 and clip:
+        mine_stats = {"rank": rank, "shard": list(stats.get("shard", ())), "frames": stats["shard"][1] - stats["shard"][0],
+                      "exposed_gather_ms_per_step": round(1e3 * float(np.mean([x for x in stats.get("exposed_gather_s", []) if x is not None] or [0.0])), 3),
+                      "bytes_received_per_step": stats.get("bytes_received")}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_stats)
 
     if rank == 0:
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
-        frames = K * FB * world
+        frames = K * frames_per_step
+        prec_tag = {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]"}[args.precision]
         line = {
-            "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}")
-                      + {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]"}[args.precision],
+            "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}") + prec_tag,
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 activations + accumulation",
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if clip else "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator fp32 (BASELINE configs[1])"
+            "config": {"workload": (f"run_imitator {S}x{S} single src/ref pair, {n_clip}-frame reference clip frame-sharded over {world} GPU(s), "
+                                    "AttLWB-SPADE generator fp32 (BASELINE configs[1] at N = 1, configs[2] at N = 8)" if clip else
+                                    f"run_imitator {S}x{S} single src/ref pair, one {FB}-frame batch per GPU per step (weak scaling)")
                        if args.precision == "fp32" else
-                       f"per-frame path {S}x{S}, AttLWB-SPADE generator with bf16 MFMA conv tiles (BASELINE configs[3] precision mode)"
-                       if args.precision == "bf16" else
-                       f"run_imitator {S}x{S} single src/ref pair, AttLWB-SPADE generator, fp32 with bf16x6 exact-split products",
-                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step_per_gpu": FB,
-                       "parallelism": f"frame-shard x{world}" + (" + RCCL all-gather of the output video, chunked behind the frame loop"
+                       f"per-frame path {S}x{S}, AttLWB-SPADE generator, precision mode {args.precision}",
+                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step": frames_per_step,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "parallelism": f"frame-shard x{world}" + (f" + RCCL all-gather of the output video ({args.gather_dtype}), " +
+                                                                  ("chunked behind the frame loop" if args.overlap else "one collective")
                                                                   if world > 1 else ""),
                        "batches_in_flight": args.streams,
                        "weights": "random-init (seeded) of the real architecture, 36,276,992 params"},
         }
+        if per_rank is not None:
+            line["config"]["per_rank"] = per_rank
         if n_launch:
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by tools/pmc_round.sh (separate --pmc passes)
-            if S == 512 and FB == 8 and args.streams == 1 and args.precision == "fp32" and os.path.exists(tpath):
+            tname = {"fp32": "pmc_traffic.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
+            tpath = os.path.join(ROOT, "profiles", tname) if tname else None       # written by tools/pmc_round.sh (separate --pmc passes)
+            if tpath and S == (512 if args.precision == "fp32" else 1024) and args.streams == 1 and os.path.exists(tpath):
                 with open(tpath) as fp:
                     tj = json.load(fp)
-                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             if args.precision == "split":
@@ -343,22 +538,42 @@ def main():
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
                                 "kernel": {"fp32": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
-                                           "bf16": "lwg_conv_igemm_bf16_kernel (bf16-operand MFMA implicit GEMM) + fp32 first layers",
+                                           "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
                                                     "MFMA work actually executed) + fp32 first layers"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
-                                "algorithmic_gflop_per_frame": round(conv_flops / (K * FB) / 1e9, 2),
+                                "algorithmic_gflop_per_frame": round(conv_flops * world / frames / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
+            if args.precision == "bf16":
+                line["roofline"]["hbm_time_at_peak_us_per_launch"] = round(timer.bytes / n_launch / (PEAK_HBM_TBS * 1e12) * 1e6, 2)
         if args.conv_breakdown and n_launch:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "conv_breakdown.json"), "w") as fp:
                 json.dump(timer.breakdown(), fp, indent=1)
-        if args.pipelined_streams > 1 and args.streams == 1 and world == 1:
-            line["pipelined"] = pipelined(step, W, K, FB, args.pipelined_streams, dev)
-        if args.split_extra and args.precision == "fp32" and args.streams == 1 and world == 1:
-            line["split_products"] = split_products(step, im, W, K, FB, outs)
-        if args.output_frames > 0 and world == 1:
-            line["with_output"] = with_output(im, mine, FB, args.output_frames, lo)
+        timer.reset()
+        if args.extras and world == 1 and args.streams == 1 and clip:
+            Ke = max(2, K // 5)
+
+            def render():
+                return im.synthesize(tgt, "smooth")
+            if args.pipelined_streams > 1:
+                line["pipelined"] = pipelined(im, render, n_clip, 1, Ke, args.pipelined_streams)
+            if args.split_extra and args.precision == "fp32":
+                line["split_products"] = split_products(im, render, n_clip, 1, Ke, last)
+            if args.output_frames > 0:
+                line["with_output"] = with_output(im, tgt, FB, args.output_frames, 0)
+            if args.precision == "fp32" and S == 512:
+                line["b1_latency"] = b1_latency(im, tgt, timer)
+                ops.CONV_HOOK = hook
+                try:
+                    line["novel_view_1024_bf16"] = novel_view_1024_bf16(dev, timer, 1, 3)
+                except Exception as e:
+                    line["novel_view_1024_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    import bench_personalize
+                    line["personalize_step"] = bench_personalize.measure(dev, steps=10, warmup=4, size=512)
+                except Exception as e:
+                    line["personalize_step"] = {"error": f"{type(e).__name__}: {e}"}
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)

@@ -7,9 +7,9 @@ one sample per GPU, data parallel over N MI355X with ONE flat RCCL all-reduce of
 
 NOT the headline bench (that is bench.py: synthesized frames/s).  A step = LWGTrainer.optimize_parameters()
 (reference tools/trainers/lwg_trainer.py:326-352) on one synthetic sample (ns = 2 sources, nt = 1 target): G forward with
-only_tsf=False (bg + src with decoder + tsf), LSGAN + L1 + BCE mask + TV losses (VGG19 / SphereFace losses omitted: their
-checkpoints are not available offline - the reference's use_vgg="None", use_face=false configuration), backward, gradient
-all-reduce, Adam; then the discriminator step.  Every convolution (forward, dgrad, wgrad) runs on the hand-written MFMA
+only_tsf=False (bg + src with decoder + tsf), LSGAN + L1 + BCE mask + TV losses (--use-vgg / --use-face add the VGG19 and
+SphereFace losses on seeded weights: their checkpoints are not available offline), backward, gradient all-reduce (global batch =
+N samples, BASELINE configs[4]: 8), Adam; then the discriminator step.  Every convolution (forward, dgrad, wgrad) runs on the hand-written MFMA
 kernels; the elementwise glue is PyTorch-ROCm autograd this round (ipercore_amd/networks/training.py).
 
 Prints ONE JSON line on rank 0: samples/s over all ranks, and the achieved conv TFLOP/s from the algorithmic conv flops of
@@ -28,34 +28,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--use-vgg", action="store_true", help="VGG19 perceptual transfer loss (deploy.toml:83; seeded weights when "
-                                                          "vgg19-dcbb9e9d.pth is absent) instead of L1")
-    ap.add_argument("--use-face", action="store_true", help="SphereFace (Sphere20a) loss on the head crop (deploy.toml:77-79)")
-    ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
-                    help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
-    args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
-    assert args.gpus == world
-
+def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None):
+    """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
+    static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
-    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
 
-    S, ns = args.size, 2
+    S, ns = size, 2
     nf, nres, bgf = [64, 128, 256], 6, [64, 128, 128, 256]
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=syn.gen_cfg(nf, nres, bgf), temporal=False)
     sd = syn.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
@@ -77,11 +57,13 @@ def main():
            "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float(),
            "head_bbox": torch.tensor([[S * 3 // 8, S * 5 // 8, S // 16, S * 5 // 16]])}        # a head-sized box (min_x, max_x, min_y, max_y)
     del im
-    from ipercore_amd.trainers import TrainOpts
     topts = TrainOpts()
-    topts.conv_precision = args.precision
-    topts.use_vgg = "VGG19" if args.use_vgg else "None"
-    topts.use_face = bool(args.use_face)
+    topts.conv_precision = precision
+    topts.use_vgg = "VGG19" if use_vgg else "None"
+    topts.use_face = bool(use_face)
+    topts.allow_seeded_loss_nets = True        # the licensed checkpoints are not available offline: seeded weights, same cost per step
+    if graph is not None and hasattr(topts, "use_graph"):
+        topts.use_graph = bool(graph)
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
 
@@ -90,13 +72,6 @@ def main():
     def hook(begin, M, spec, epi=0):
         if begin:
             flops[0] += 2.0 * M * spec.algo_kn
-    for _ in range(args.warmup):
-        tr.optimize_parameters()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ops.CONV_HOOK = hook                       # counts forward + dgrad launches; wgrad flops are added below (same 2*M*K*N)
     wg = [0.0]
     orig = ops.conv2d_wgrad
 
@@ -104,22 +79,34 @@ def main():
         M = dy.shape[0] * dy.shape[1] * dy.shape[2] // (spec.omul ** 2)
         wg[0] += 2.0 * M * spec.algo_kn
         return orig(x0, spec, dy, **kw)
-    ops.conv2d_wgrad = counted_wgrad
     orig_u = ops.conv2d_wgrad_unpacked
 
     def counted_wgrad_unpacked(x0, spec, dy, *a, **kw):
         wg[0] += 2.0 * (dy.shape[0] * dy.shape[1] * dy.shape[2] // (spec.omul ** 2)) * spec.algo_kn
         return orig_u(x0, spec, dy, *a, **kw)
-    ops.conv2d_wgrad_unpacked = counted_wgrad_unpacked
+    # the algorithmic conv flops of a step are counted on ONE eager step (forward + dgrad launches through the hook, the weight
+    # gradients through the wrappers: same 2*M*K*N), outside the timed region - a replayed graph makes no Python calls to count
+    prev_hook = ops.CONV_HOOK
+    ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = hook, counted_wgrad, counted_wgrad_unpacked
+    try:
+        tr.optimize_parameters()
+    finally:
+        ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = prev_hook, orig, orig_u
+    per_step = flops[0] + wg[0]
+    for _ in range(warmup):
+        tr.optimize_parameters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         lg, ld = tr.optimize_parameters()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = None, orig, orig_u
     # host share: one step from an idle queue - time until the last launch is enqueued vs until the GPU is done
     host_ms, total_ms = [], []
     for _ in range(3):
@@ -134,18 +121,55 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    if rank != 0:
+        return None
+    nG, nD = sum(p.numel() for p in G.parameters()), sum(p.numel() for p in D.parameters())
+    tf = per_step / (dt / steps) / 1e12
+    return {
+        "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(steps * world / dt, 4),
+        "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "dtype": "f32" if precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
+        "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if use_vgg else "L1") + " tsf" + (" + Sphere20a face" if use_face else "") + " + BCE mask + TV",
+                   "global_batch": world,
+                   "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
+                                  f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges overlapped with backward",
+                   "step": getattr(tr, "step_mode", "eager launches")},
+        "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
+        "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                     "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
+        "bytes_allreduced_per_step": (nG + nD) * 4 if world > 1 else 0,
+        "allreduce_overlap": getattr(tr.optimizer_G, "overlapped_ranges", None),
+        "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
+        "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--use-vgg", action="store_true", help="VGG19 perceptual transfer loss (deploy.toml:83; seeded weights: "
+                                                          "vgg19-dcbb9e9d.pth is not available offline) instead of L1")
+    ap.add_argument("--use-face", action="store_true", help="SphereFace (Sphere20a) loss on the head crop (deploy.toml:77-79)")
+    ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
+                    help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    assert args.gpus == world
+    res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
+                  graph=None if args.graph else False)
     if rank == 0:
-        per_step = (flops[0] + wg[0]) / args.steps
-        print(json.dumps({
-            "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(args.steps * world / dt, 4),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "dtype": "f32" if args.precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
-            "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if args.use_vgg else "L1") + " tsf" + (" + Sphere20a face" if args.use_face else "") + " + BCE mask + TV",
-                       "parallelism": f"dp{world}: one flat RCCL all-reduce per network ({sum(p.numel() for p in G.parameters())} + "
-                                      f"{sum(p.numel() for p in D.parameters())} fp32 gradients)"},
-            "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(per_step / (dt / args.steps) / 1e12, 2),
-            "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
-            "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}), flush=True)
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,31 +77,77 @@ class SMPLH(nn.Module):
         return theta.contiguous()
 
     def _links_2d(self, links_ids, device):
+        """links_ids (n, 2|3) -> (n, 2) int32 (from, to) pairs shared by the whole batch (base_smpl.py:44-45: every row is
+        applied).  A per-batch (B, nv, 3) tensor whose rows are all the same sample - what FlowComposition.forward builds with
+        ``links_ids.expand(bs, ns, nv, c)`` (flowcomposition.py:695-701) - reduces to the rows whose has_linked flag is 1
+        (base_smpl.py:47-49); genuinely different per-sample links return None (``forward`` then skins row by row)."""
         ids = torch.as_tensor(links_ids)
-        if ids.dim() != 2:
-            raise NotImplementedError("per-batch (bs, nv, 3) links_ids are not handled on the device yet")
+        if ids.dim() == 3:
+            if ids.shape[0] > 1 and not bool((ids == ids[0:1]).all()):
+                return None
+            ids = ids[0]
+            if ids.shape[1] >= 3:
+                ids = ids[ids[:, 2] == 1]
+        elif ids.dim() != 2:
+            raise ValueError(f"links_ids must be (n, 2|3) or (B, n, 3), got {tuple(ids.shape)}")
         return ids[:, 0:2].to(device=device, dtype=torch.int32).contiguous()
+
+    @staticmethod
+    def _offsets_rows(offsets, B, device):
+        """offsets: 0 / (nv, 3) / (bs, nv, 3) -> None, (nv, 3) or (B, nv, 3) on the device.  The reference adds a (bs, nv, 3)
+        tensor to a (bs * ns, nv, 3) template by broadcasting (smplx/lbs.py:176, flowcomposition.py:703): bs = 1 is the dataset
+        sample's collated (1, nv, 3); bs > 1 rows are repeated for the ns / nt frames of their sample."""
+        if isinstance(offsets, np.ndarray):
+            offsets = torch.tensor(offsets)
+        if not torch.is_tensor(offsets) or offsets.numel() <= 1:
+            return None
+        off = offsets.to(device=device, dtype=torch.float32)
+        if off.dim() == 3:
+            if off.shape[0] == 1:
+                off = off[0]
+            elif off.shape[0] != B:
+                if B % off.shape[0] != 0:
+                    raise ValueError(f"offsets batch {off.shape[0]} does not divide the {B} skinned rows")
+                off = off.repeat_interleave(B // off.shape[0], dim=0)
+        return off.contiguous()
 
     @torch.no_grad()
     def forward(self, beta, theta, offsets=0, links_ids=None, get_skin=False, cam=None):
         """batch_smplh.py:137-180 -> (vertices (B,6890,3), joints (B,52,3), full_pose)."""
         full_pose = self._full_pose(theta.float())
-        off = None
-        if torch.is_tensor(offsets):
-            if offsets.numel() > 1:
-                off = offsets.to(device=full_pose.device, dtype=torch.float32).contiguous()
-        elif isinstance(offsets, np.ndarray) and offsets.size > 1:
-            off = torch.tensor(offsets, device=full_pose.device, dtype=torch.float32)
-        links = None if links_ids is None else self._links_2d(links_ids, full_pose.device)
-        verts, j3d, j2d = ops.smpl_lbs(self._device_model(), full_pose, beta.float().contiguous(),
-                                       None if cam is None else cam.float().contiguous(), off, links)
+        B, dev = full_pose.shape[0], full_pose.device
+        off = self._offsets_rows(offsets, B, dev)
+        beta = beta.float().contiguous()
+        cam = None if cam is None else cam.float().contiguous()
+        links = None if links_ids is None else self._links_2d(links_ids, dev)
+        if links_ids is not None and links is None:
+            # per-sample links (B, nv, 3) that really differ: one skinning call per row, each with its own flagged pairs
+            ids = torch.as_tensor(links_ids)
+            rows = []
+            for b in range(B):
+                lb = ids[b][ids[b][:, 2] == 1][:, 0:2].to(device=dev, dtype=torch.int32).contiguous()
+                ob = off if (off is None or off.dim() == 2) else off[b].contiguous()
+                rows.append(ops.smpl_lbs(self._device_model(), full_pose[b:b + 1], beta[b:b + 1], None if cam is None else cam[b:b + 1],
+                                         ob, lb if lb.shape[0] else None))
+            verts, j3d = torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
+            j2d = None if cam is None else torch.cat([r[2] for r in rows])
+        else:
+            verts, j3d, j2d = ops.smpl_lbs(self._device_model(), full_pose, beta, cam, off,
+                                           links if (links is not None and links.shape[0]) else None)
         self._last_j2d = j2d
         return verts, j3d, full_pose
 
     def link(self, verts, linked_ids):
         """base_smpl.py:28-50 (2-D ids)."""
-        ids = self._links_2d(linked_ids, verts.device).long()
+        ids = self._links_2d(linked_ids, verts.device)
         out = verts.clone()
+        if ids is None:                                                     # per-sample pairs (base_smpl.py:46-49)
+            l3 = torch.as_tensor(linked_ids).to(verts.device)
+            for b in range(verts.shape[0]):
+                sel = l3[b][l3[b][:, 2] == 1].long()
+                out[b, sel[:, 0]] = verts[b, sel[:, 1]]
+            return out
+        ids = ids.long()
         out[:, ids[:, 0]] = verts[:, ids[:, 1]]
         return out
 

@@ -217,6 +217,8 @@ class Imitator(object):
         """Frames [t0, t0+n) of an (already stabilised) device tensor (n,85) -> pred (n,3,S,S) on the device."""
         outs = []
         sel = dict(primary_ids=self.primary_ids, use_selected_f2pts=use_selected_f2pts)
+        if tgt_smpls.shape[0] == 0:               # an empty shard (clip shorter than the number of ranks): an empty video block
+            return torch.empty((0, 3, self.image_size, self.image_size), device=tgt_smpls.device, dtype=torch.float32)
         if self.streams > 1 and tgt_smpls.is_cuda:
             # frames are independent: batches alternate over HIP streams so one batch's kernel tails, launch gaps and
             # HBM-bound kernels overlap another batch's MFMA work (+6 % frames/s at 3 streams on MI355X)

@@ -105,8 +105,8 @@ class ConvFn(torch.autograd.Function):
                 if cfg.stride == 1:
                     ops.conv2d(dy, dspecs[0], dx, splitk=True)
                 else:
-                    for s in dspecs:
-                        ops.conv2d(dy, s, dx, out_hw=(H // 2, W // 2), splitk=True)
+                    for s in dspecs:             # one launch per input parity (py, px): rows py, py + 2, .. < H - ceil for odd sizes
+                        ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
         else:
             Cin, Nw = weight.shape[0], weight.shape[1]
             dw = None

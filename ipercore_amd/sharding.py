@@ -45,9 +45,9 @@ def all_gather_frames(local, n_frames, group=None):
 class OverlappedGather(object):
     """The same all-gather issued chunk by chunk WHILE the frame loop runs: every frame batch is handed to RCCL as soon as it is
     synthesized (``async_op`` collectives run on RCCL's own stream over xGMI), so only the last chunk's transfer is exposed
-    instead of the whole video (8 ranks x 160 frames at 512^2: 3.5 GB received per rank, ~30 ms on the per-link-bound ring vs
-    ~2 ms for one 8-frame chunk).  Every rank must submit the same chunk schedule: offsets 0, m, 2m, .. of its own shard, the
-    last chunk of a short shard zero-padded by ``submit``."""
+    instead of the whole video (8 ranks x 300 frames at 512^2 fp32: 0.83 GB received per rank, ~8 ms on the per-link-bound ring
+    vs ~0.6 ms for one 8-frame chunk).  Every rank must submit the same chunk schedule: offsets 0, m, 2m, .. of its own shard,
+    the last chunk of a short shard zero-padded by ``submit`` (an all-padding chunk for a shard that ended earlier)."""
 
     def __init__(self, n_frames, group=None):
         self.n, self.group = int(n_frames), group
@@ -56,20 +56,29 @@ class OverlappedGather(object):
         self.starts = [shard_range(self.n, r, self.world)[0] for r in range(self.world)]
         self.cap = max(self.counts)
         self.pending = []
+        self.bytes_received = 0           # per rank, all chunks (incl. its own block and the padding)
+        self.exposed_s = None             # finish(sync=...): wall time between "compute done" and "video assembled"
 
     def submit(self, frames, offset, length=None):
-        """frames: this rank's frames [offset, offset + k) of its shard, k <= length; ``length`` = the chunk length every rank uses
-        (default k): shorter chunks are zero-padded so the collective has one size on all ranks."""
+        """frames: this rank's frames [offset, offset + k) of its shard, 0 <= k <= length; ``length`` = the chunk length every rank
+        uses (default k): shorter chunks are zero-padded so the collective has one size on all ranks."""
         m = frames.shape[0] if length is None else int(length)
         if frames.shape[0] != m:
             frames = torch.cat([frames, frames.new_zeros((m - frames.shape[0],) + tuple(frames.shape[1:]))], dim=0)
         frames = frames.contiguous()
         out = frames.new_empty((self.world * m,) + tuple(frames.shape[1:]))
         work = dist.all_gather_into_tensor(out, frames, group=self.group, async_op=True)
+        self.bytes_received += out.numel() * out.element_size()
         self.pending.append((int(offset), m, out, work, frames))
 
-    def finish(self):
-        """Wait for every chunk and assemble the (n_frames, ...) video in frame order."""
+    def finish(self, sync=None):
+        """Wait for every chunk and assemble the (n_frames, ...) video in frame order.  ``sync``: a callable that drains the compute
+        stream (torch.cuda.synchronize); given, ``exposed_s`` records how long the gather ran past the end of the computation."""
+        import time
+        t0 = None
+        if sync is not None:
+            sync()
+            t0 = time.perf_counter()
         video = None
         for offset, m, out, work, _ in self.pending:
             work.wait()
@@ -80,29 +89,49 @@ class OverlappedGather(object):
                 if k > 0:
                     video[self.starts[r] + offset:self.starts[r] + offset + k] = out[r * m:r * m + k]
         self.pending = []
+        if sync is not None:
+            sync()
+            self.exposed_s = time.perf_counter() - t0
         return video
 
 
-def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, group=None, overlap=True):
-    """Every rank: prepare the whole sequence, synthesize its block, all-gather the (N,3,S,S) video tensor
-    (``overlap``: chunk by chunk behind the frame loop, see OverlappedGather; False: one collective at the end)."""
+def chunk_plan(n_frames, world_size, frame_batch):
+    """The chunk schedule every rank follows for a clip of ``n_frames``: [(offset in the shard, chunk length)], the same list on
+    all ranks (collectives must match), sized by the LONGEST shard; rank r's frames of a chunk are
+    [lo_r + off, min(lo_r + off + m, hi_r)) - possibly fewer than m, possibly none."""
+    cap = max(shard_counts(n_frames, world_size))
+    fb = max(1, int(frame_batch))
+    return [(off, min(fb, cap - off)) for off in range(0, cap, fb)]
+
+
+def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, group=None, overlap=True, prepared=False, post=None,
+                       stats=None):
+    """Every rank: prepare the whole sequence, synthesize its block, all-gather the video tensor
+    (``overlap``: chunk by chunk behind the frame loop, see OverlappedGather; False: one collective at the end).
+    prepared: ``tgt_smpls`` is already the output of ``imitator.prepare_sequence`` (the sequence-global pre-pass, identical on every
+    rank).  post: a per-chunk transform applied before the exchange - ``ops.frames_to_u8`` turns the (n,3,S,S) fp32 video into the
+    (n,S,S,3) uint8 one the PNG writer consumes: a quarter of the bytes on the xGMI ring.  stats: a dict that receives this rank's
+    shard, the bytes it received and (when ``stats["sync"]`` is a callable) the exposed gather time."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    tgt = imitator.prepare_sequence(tgt_smpls, cam_strategy)
+    tgt = tgt_smpls if prepared else imitator.prepare_sequence(tgt_smpls, cam_strategy)
     n = tgt.shape[0]
     lo, hi = shard_range(n, rank, world)
+    fin = (lambda x: x) if post is None else post
+    if stats is not None:
+        stats.update(rank=rank, world=world, shard=(lo, hi))
     if not (gather and overlap and world > 1):
-        local = imitator.synthesize(tgt[lo:hi], cam_strategy, t0=lo)
+        local = fin(imitator.synthesize(tgt[lo:hi], cam_strategy, t0=lo))
         return all_gather_frames(local, n, group) if gather else local
     og = OverlappedGather(n, group)
-    fb = max(1, int(getattr(imitator, "frame_batch", 8)))
-    proto = None
-    for off in range(0, og.cap, fb):
-        m = min(fb, og.cap - off)
-        a, b = lo + off, min(lo + off + m, hi)
-        if b > a:
-            proto = frames = imitator.synthesize(tgt[a:b], cam_strategy, t0=a)
-        else:                                           # a shard one frame shorter than the longest: an all-padding last chunk
-            frames = proto[:0]
-        og.submit(frames, off, length=m)
-    return og.finish()
+    for off, m in chunk_plan(n, world, getattr(imitator, "frame_batch", 8)):
+        a = min(lo + off, hi)
+        b = min(lo + off + m, hi)
+        # an empty slice (this shard ended before the longest one, or holds no frame at all) still yields a correctly shaped
+        # (0, ...) block from the imitator: the collective then carries padding only for this rank
+        og.submit(fin(imitator.synthesize(tgt[a:b], cam_strategy, t0=a)), off, length=m)
+    video = og.finish(sync=None if stats is None else stats.get("sync"))
+    if stats is not None:
+        stats.update(bytes_received=og.bytes_received, exposed_gather_s=og.exposed_s, chunks=len(chunk_plan(n, world, getattr(imitator, "frame_batch", 8))))
+        stats.pop("sync", None)
+    return video

@@ -10,9 +10,10 @@ Every convolution of G and D (forward, data gradient, weight gradient) runs on t
 ``networks.training.ConvFn``; part of the elementwise glue is PyTorch-ROCm autograd (see that module).
 The composed discriminators ``patch_global_local`` / ``patch_global_body_head`` (multi_scale_dis.py:110-284) are built on the same
 ``PatchDiscriminator``.  The VGG19 perceptual loss (``vggloss.py``) and the SphereFace loss (``faceloss.py``) run on the same conv
-kernels with frozen weights; their checkpoints are not available offline, so without ``vgg_loss_path`` / ``face_loss_path`` they use
-seeded weights (``TrainOpts.use_vgg = "None"`` / ``use_face = False``, the default here, is the reference's L1 transfer loss,
-lwg_trainer.py:154-158).
+kernels with frozen weights.  ``TrainOpts`` defaults to the reference's loss set (deploy.toml: use_vgg = "VGG19", use_face = true);
+their checkpoints are not distributable, and a missing file raises - as the reference does - unless
+``TrainOpts.allow_seeded_loss_nets`` (benchmarks / tests: seeded weights) is set or the two losses are switched off
+(``use_vgg = "None"`` / ``use_face = False`` is the reference's L1 transfer loss, lwg_trainer.py:154-158).
 
 Data parallelism (BASELINE config 5: one sample per GPU): parameters and gradients of a network live in ONE flat fp32
 buffer each (``FlatAdam``); the gradient buffer is averaged in place with a single RCCL all-reduce - large, few
@@ -323,6 +324,25 @@ def allreduce_grads(params, group=None):
         off += n
 
 
+def _load_frozen(net, ckpt_path, allow_seeded, what):
+    """Load the pretrained weights of a frozen loss network, or fail the way the reference does (its torch.load raises on a missing
+    file, vggloss.py:30-33 / faceloss.py:300-303).  Seeded weights are an explicit opt-in for benchmarks and tests
+    (``allow_seeded``): a step then has the right cost and gradient structure, NOT the trained metric."""
+    if ckpt_path and os.path.exists(ckpt_path):
+        sd = torch.load(ckpt_path, map_location="cpu")
+        if isinstance(sd, dict) and "state_dict" in sd and all(not torch.is_tensor(v) for k, v in sd.items() if k != "state_dict"):
+            sd = sd["state_dict"]
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        res = net.load_state_dict(sd, strict=False)       # unexpected keys are fine (torchvision's classifier, Sphere20a's fc6)
+        if res.missing_keys:
+            raise RuntimeError(f"{what}: checkpoint {ckpt_path} lacks {len(res.missing_keys)} of the network's tensors "
+                               f"(first: {res.missing_keys[:3]}) - refusing to train against partly random features")
+        return
+    if not allow_seeded:
+        raise FileNotFoundError(f"{what}: pretrained weights not found at {ckpt_path!r}.  The reference cannot personalize without them "
+                                "either; set TrainOpts.allow_seeded_loss_nets = True ONLY for benchmarks / tests (seeded weights).")
+
+
 class VGG19Features(nn.Module):
     """criterions/vggloss.py:10-96 (VGG19, before_relu=False): torchvision's ``vgg19().features`` cut after relu1_1, relu2_1,
     relu3_1, relu4_1, relu5_1 - 13 frozen 3x3 convolutions (+ReLU) and four 2x2 max-pools on the MFMA / HIP kernels.
@@ -332,7 +352,7 @@ class VGG19Features(nn.Module):
            (19, 256, 512), (21, 512, 512), (23, 512, 512), (25, 512, 512), "M", (28, 512, 512))
     TAPS = (0, 5, 10, 19, 28)                # conv indices whose ReLU output is a loss feature (slice_ids [2, 7, 12, 21, 30])
 
-    def __init__(self, ckpt_path=None, seed=0):
+    def __init__(self, ckpt_path=None, seed=0, allow_seeded=False):
         super().__init__()
         self.features = nn.Module()
         g = torch.Generator().manual_seed(seed)
@@ -344,8 +364,7 @@ class VGG19Features(nn.Module):
             layer.weight = nn.Parameter(torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin)), requires_grad=False)
             layer.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
             self.features.add_module(str(idx), layer)
-        if ckpt_path and os.path.exists(ckpt_path):
-            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+        _load_frozen(self, ckpt_path, allow_seeded, "VGG19 perceptual loss (use_vgg)")
 
     def forward(self, x_nchw):
         """(N,3,H,W) in the generator's [-1,1] range (the reference feeds it un-normalised too) -> five NHWC feature maps."""
@@ -368,9 +387,9 @@ class VGGLoss(nn.Module):
     align_corners=True) as the trainers do (lwg_trainer.py:153-155, resize=True)."""
     WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
 
-    def __init__(self, ckpt_path=None, resize=True):
+    def __init__(self, ckpt_path=None, resize=True, allow_seeded=False):
         super().__init__()
-        self.vgg, self.resize = VGG19Features(ckpt_path), resize
+        self.vgg, self.resize = VGG19Features(ckpt_path, allow_seeded=allow_seeded), resize
 
     def forward(self, x, y):
         if self.resize:
@@ -389,7 +408,7 @@ class Sphere20aFeatures(nn.Module):
     (data gradient only: the network is frozen); PReLU / residual adds / fc5 are PyTorch-ROCm autograd + one library GEMM."""
     BLOCKS = ((1, 3, 64, 3), (2, 64, 128, 5), (3, 128, 256, 9), (4, 256, 512, 3))          # (block, cin, cout, number of convs)
 
-    def __init__(self, ckpt_path=None, seed=0):
+    def __init__(self, ckpt_path=None, seed=0, allow_seeded=False):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         for b, cin, cout, n in self.BLOCKS:
@@ -405,8 +424,7 @@ class Sphere20aFeatures(nn.Module):
         self.fc5 = nn.Module()
         self.fc5.weight = nn.Parameter(torch.randn(512, 512 * 7 * 6, generator=g) * math.sqrt(1.0 / (512 * 7 * 6)), requires_grad=False)
         self.fc5.bias = nn.Parameter(torch.zeros(512), requires_grad=False)
-        if ckpt_path and os.path.exists(ckpt_path):
-            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+        _load_frozen(self, ckpt_path, allow_seeded, "SphereFace loss (use_face)")
 
     def _cp(self, b, i, x, stride=1, first=False):
         c, a = getattr(self, f"conv{b}_{i}"), getattr(self, f"relu{b}_{i}")
@@ -432,9 +450,9 @@ class FaceLoss(nn.Module):
     WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
     HEIGHT, WIDTH = 112, 96
 
-    def __init__(self, pretrained_path=None):
+    def __init__(self, pretrained_path=None, allow_seeded=False):
         super().__init__()
-        self.net = Sphere20aFeatures(pretrained_path)
+        self.net = Sphere20aFeatures(pretrained_path, allow_seeded=allow_seeded)
 
     def crop_head_bbox(self, imgs, bboxs):
         """:384-406; bboxs (N,4) = [min_x, max_x, min_y, max_y] (a host read of N*4 integers per step, as in the reference)."""
@@ -456,7 +474,9 @@ class FaceLoss(nn.Module):
 
 
 class TrainOpts(object):
-    """deploy.toml:76-102 defaults (use_vgg / use_face off: their checkpoints are not available offline)."""
+    """deploy.toml:76-102 defaults, incl. the reference's loss set (use_vgg = "VGG19", use_face = true).  Their checkpoints are not
+    distributable: without the files the trainer raises unless ``allow_seeded_loss_nets`` is set (benchmarks / tests), or the two
+    losses are switched off explicitly (use_vgg = "None", use_face = False: the reference's L1 transfer loss, lwg_trainer.py:154-158)."""
     lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
     lr_G, lr_D = 1e-4, 1e-4
     G_adam_b1, G_adam_b2, D_adam_b1, D_adam_b2 = 0.9, 0.999, 0.9, 0.999
@@ -465,27 +485,42 @@ class TrainOpts(object):
     conv_precision = "fp32"
     # "VGG19": the transfer loss is the VGG19 perceptual loss (deploy.toml:83, the reference's default) instead of L1;
     # vgg_loss_path: torchvision vgg19 state_dict (used when the file exists, seeded weights otherwise)
-    use_vgg = "None"
+    use_vgg = "VGG19"
     vgg_loss_path = "./assets/checkpoints/losses/vgg19-dcbb9e9d.pth"
     # the SphereFace (Sphere20a) loss on the head crop of the transferred image (deploy.toml:77-79, lambda_face :87)
-    use_face = False
+    use_face = True
     face_loss_path = "./assets/checkpoints/losses/sphere20a_20171020.pth"
     lambda_face = 5.0
+    allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
+
+    @classmethod
+    def l1_transfer(cls):
+        """The reference's configuration without the two pretrained loss networks (use_vgg = "None", use_face = false)."""
+        o = cls()
+        o.use_vgg, o.use_face = "None", False
+        return o
 
 
 class FlowCompositionForTrainer(FlowComposition):
     """tools/trainers/base.py:90-141: the per-sample input stage of the trainers - body model, renders, the once-per-source
     image stage, target conditions and the (bs, nt, ns) flows - on the same HIP kernels the runner uses.
-    ``body_model``: any model with ``get_details``; default: the trainers' 24-joint ``SMPL`` (bodynets/batch_smpl.py:283-436)
-    when ``opt.smpl_model`` exists, else the runner's SMPL-H (``opt.smpl_model_hand``)."""
+    ``body_model``: any model with ``get_details``; default: the trainers' 24-joint ``SMPL`` (bodynets/batch_smpl.py:283-436) from
+    ``opt.smpl_model`` (raises when the pickle is missing, as the reference does).  An explicitly passed SMPL-H has no COCO+
+    keypoints: its head / body boxes are then None and the box-dependent losses / discriminator crops refuse to run."""
 
     def __init__(self, opt, body_model=None):
         super().__init__(opt)
         g = lambda k, d=None: getattr(opt, k, d) if not isinstance(opt, dict) else opt.get(k, d)    # noqa: E731
         if body_model is None:
             p24 = g("smpl_model")
-            body_model = SMPL(model_path=p24) if (p24 is not None and (isinstance(p24, dict) or os.path.exists(p24))) else SMPLH(model_path=g("smpl_model_hand"))
+            if p24 is None or not (isinstance(p24, dict) or os.path.exists(p24)):
+                # the head / body boxes below index the 19 COCO+ keypoints of the trainers' SMPL (base.py:205-285); with SMPL-H's 52
+                # joints they would silently crop shoulders and hands - the reference raises here too (base.py:95)
+                raise FileNotFoundError(f"opt.smpl_model = {p24!r}: the trainers' 24-joint SMPL pickle is required "
+                                        "(pass body_model=SMPLH(...) explicitly to train without keypoint-based crops)")
+            body_model = SMPL(model_path=p24)
         self.smpl = body_model
+        self.has_cocoplus = isinstance(body_model, SMPL)
         self.ft_ks = int(g("ft_ks", 1))                      # deploy.toml:12
         self.share_bg = bool(g("share_bg", True))
 
@@ -518,8 +553,9 @@ class FlowCompositionForTrainer(FlowComposition):
         tm = ref_info["masks"] if ref_mask is not None else ref_info["cond"][:, -1:]
         sm = morph(sm.contiguous(), ks=self.ft_ks, mode="erode").view(bs, ns, 1, h, w)
         tm = morph(tm.contiguous(), ks=self.ft_ks, mode="erode").view(bs, nt, 1, h, w)
-        return (input_G_bg, input_G_src, input_G_tsf, Tst, Ttt, sm, tm, self.cal_head_bbox_by_kps(ref_info["j2d"]),
-                self.cal_body_bbox_by_kps(ref_info["j2d"]), uv_img)
+        head_bbox = self.cal_head_bbox_by_kps(ref_info["j2d"]) if self.has_cocoplus else None
+        body_bbox = self.cal_body_bbox_by_kps(ref_info["j2d"]) if self.has_cocoplus else None
+        return input_G_bg, input_G_src, input_G_tsf, Tst, Ttt, sm, tm, head_bbox, body_bbox, uv_img
 
     def cal_head_bbox_by_kps(self, kps, neck_ids=12):
         """base.py:205-246 -> (N, 4) long (min_x, max_x, min_y, max_y) in pixels (tiny host-visible bookkeeping: torch ops)."""
@@ -556,10 +592,10 @@ class LWGTrainer(object):
         self.losses = {}
         self.crt_tsf = None
         if o.use_vgg == "VGG19":
-            self.crt_tsf = VGGLoss(ckpt_path=o.vgg_loss_path).to(next(G.parameters()).device)
+            self.crt_tsf = VGGLoss(ckpt_path=o.vgg_loss_path, allow_seeded=o.allow_seeded_loss_nets).to(next(G.parameters()).device)
         elif o.use_vgg not in ("None", None, False):
             raise NotImplementedError(f"use_vgg = {o.use_vgg}: only VGG19 (the reference's default) is built")
-        self.crt_face = FaceLoss(o.face_loss_path).to(next(G.parameters()).device) if o.use_face else None
+        self.crt_face = FaceLoss(o.face_loss_path, allow_seeded=o.allow_seeded_loss_nets).to(next(G.parameters()).device) if o.use_face else None
 
     def set_input(self, inputs, device=None, flow_comp=None, ns=None):
         """lwg_trainer.py:624-697.  ``inputs`` is either the dataset sample of the reference (``PersonalizedDataset.__getitem__``,
@@ -582,6 +618,10 @@ class LWGTrainer(object):
         g_bg, g_src, g_tsf, Tst, _, _, tsf_mask, head_bbox, body_bbox, uv_img = fc(
             images[:, :ns].contiguous(), images[:, ns:].contiguous(), smpls[:, :ns].contiguous(), smpls[:, ns:].contiguous(),
             src_mask=masks[:, :ns].contiguous(), ref_mask=masks[:, ns:].contiguous(), links_ids=links, offsets=offsets)
+        if head_bbox is None and (self.crt_face is not None or (self.D is not None and getattr(self.D, "CROPS", ()))):
+            raise RuntimeError("the body model of this FlowCompositionForTrainer has no COCO+ keypoints (SMPL-H passed explicitly): the "
+                               "head / body boxes of FaceLoss and of the patch_global_local / patch_global_body_head discriminators "
+                               "cannot be formed - use the trainers' 24-joint SMPL (opt.smpl_model)")
         if not fc.share_bg:
             tsf_img = images[:, ns:]
             g_bg = torch.cat([g_bg, torch.cat([tsf_img * tsf_mask, tsf_mask], dim=2)], dim=1)

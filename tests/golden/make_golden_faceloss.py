@@ -24,7 +24,7 @@ from ipercore_amd.trainers import Sphere20aFeatures  # noqa: E402
 def face_state_dict():
     """Seeded Sphere20a parameters independent of torch's RNG: synthetic.fill_state_dict (numpy), PReLU slopes moved to
     0.25 + 0.1 * (that value) so that every channel has its own slope.  tests/gpu_checks.py rebuilds the same dict."""
-    shapes = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None).state_dict().items()}
+    shapes = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None, allow_seeded=True).state_dict().items()}
     sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=13).items()}
     for k in sd:
         if k.startswith("relu"):

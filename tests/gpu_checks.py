@@ -9,6 +9,7 @@ import os
 import time
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -232,7 +233,7 @@ def _posed(n_frames=2, seed=1):
     return d["cam"].contiguous(), d["verts"].contiguous()
 
 
-def check_raster(sizes=(64, 128, 256)):
+def check_raster(sizes=(64, 128, 256, 512, 1024)):
     from oracle import lwg_oracle as orc
     topo = mesh.load_topology()
     faces = torch.tensor(topo["faces_uv"].astype(np.int32))
@@ -317,7 +318,7 @@ def check_identity_warp_512():
     return res
 
 
-def check_generator_golden():
+def check_generator_golden(conv_precision="fp32"):
     """The generator API on the GPU against outputs of the REFERENCE's own module (tests/golden)."""
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
@@ -327,6 +328,7 @@ def check_generator_golden():
         sd = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
         G.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
         G.to(DEV)
+        G.conv_precision = conv_precision
         src_inputs = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"), device=DEV)
         tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, S, S), 9, "tsf_inputs"), device=DEV)
         bg_inputs = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"), device=DEV)
@@ -386,25 +388,44 @@ def check_lwb_variant_generators():
     return out
 
 
-def _pipeline(S, nf, nres, bgf, n_frames, frame_batch, frames=None):
-    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=n_frames, ns=2)
-    t0 = time.time()
-    m, got, im = pu.staged_parity(case, frame_batch=frame_batch, frames=frames)
-    m["total_s"] = time.time() - t0
+_RUNS = {}          # oracle runs are the expensive part of this file: one per (configuration), shared by the checks that need its frames
+
+
+def _parity_asserts(m):
     assert m["pred_finite"], "non-finite frames"
     assert m["src_verts_max"] <= 1e-5 and m["verts_max"] <= 1e-5, m        # LBS verts |d| <= 1e-5
     assert m["src_fim_equal"] and m["fim_equal"] and m["wim_max"] == 0.0, m  # index maps bit-exact on identical vertices
     assert m["Tst_max"] <= 1e-5 and m["tsf_inputs_max"] <= 2e-4, m
     assert m["pred_max"] <= 2e-3 and m["pred_mean"] <= 1e-4, m               # SURVEY 8c generator tolerance
-    # frames are independent: the batch composition must not change a frame (bitwise)
-    single = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=1)).cpu()
-    m["batch_vs_single_max"] = (single - got).abs().max().item()
-    assert m["batch_vs_single_max"] == 0.0, "batched and per-frame results differ"
-    # ... and neither must running the batches on several HIP streams
-    im3 = pu.make_imitator(case, frame_batch=1)
-    im3.streams = 3
-    m["streams_vs_single_max"] = (pu.run_hip(case, imitator=im3).cpu() - got).abs().max().item()
-    assert m["streams_vs_single_max"] == 0.0, "multi-stream and single-stream results differ"
+
+
+def _run_cached(key, case, frame_batch, frames=None):
+    """staged_parity of ``case`` once per key -> dict(case, m, got (all frames, CPU), im, want (oracle frames of ``idx``), idx)."""
+    if key not in _RUNS:
+        t0 = time.time()
+        m, got, im = pu.staged_parity(case, frame_batch=frame_batch, frames=frames, return_want=True)
+        want = m.pop("want")
+        m["total_s"] = time.time() - t0
+        _RUNS[key] = dict(case=case, m=m, got=got, im=im, want=want, idx=m["frames"])
+    return _RUNS[key]
+
+
+def _pipeline(S, nf, nres, bgf, n_frames, frame_batch, frames=None, ns=2, key=None, variants=True):
+    case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=n_frames, ns=ns)
+    r = _run_cached(key or ("imitate", S, tuple(nf), nres, n_frames, frame_batch, ns, None if frames is None else tuple(frames)), case,
+                    frame_batch, frames)
+    m, got = dict(r["m"]), r["got"]
+    _parity_asserts(m)
+    if variants:
+        # frames are independent: the batch composition must not change a frame (bitwise)
+        single = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=1)).cpu()
+        m["batch_vs_single_max"] = (single - got).abs().max().item()
+        assert m["batch_vs_single_max"] == 0.0, "batched and per-frame results differ"
+        # ... and neither must running the batches on several HIP streams
+        im3 = pu.make_imitator(case, frame_batch=1)
+        im3.streams = 3
+        m["streams_vs_single_max"] = (pu.run_hip(case, imitator=im3).cpu() - got).abs().max().item()
+        assert m["streams_vs_single_max"] == 0.0, "multi-stream and single-stream results differ"
     return m
 
 
@@ -416,8 +437,116 @@ def check_pipeline_full_256():
     return _pipeline(256, [64, 128, 256], 6, [64, 128, 128, 256], n_frames=3, frame_batch=3)
 
 
+FULL = ([64, 128, 256], 6, [64, 128, 128, 256])
+
+
 def check_pipeline_full_512():
-    return _pipeline(512, [64, 128, 256], 6, [64, 128, 128, 256], n_frames=3, frame_batch=3, frames=[2])
+    """BASELINE configs[1] as bench.py runs it: the full architecture at 512x512, ns = 2, ONE 8-frame batch, EVERY frame of it
+    against the oracle (stage by stage: vertices, index maps bit-exact, flows, frames)."""
+    return _pipeline(512, *FULL, n_frames=8, frame_batch=8, key="full512")
+
+
+def _novel_view_case(S, n_frames):
+    """BASELINE configs[3] poses exactly as services/run_viewer.py:69-77 builds them: create_T_pose_novel_view_smpl
+    (base_runner.py:11-30; global rotation R.from_euler("xyz", [180, y, 0]), here y = 0, 90, 180, 270 = length 5 without the
+    closing 360), the source's shape and body pose (T_pose = False), add_hands_params_to_smpl (156-value poses) - followed by one
+    imitation frame so the batch of 2 also mixes regimes.  Back-facing bodies (y = 180) and side views exercise the cull rule."""
+    from ipercore_amd.imitator import add_hands_params_to_smpl, create_T_pose_novel_view_smpl
+    case = pu.build_case(image_size=S, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=n_frames, ns=2)
+    nv = create_T_pose_novel_view_smpl(5)[:4]
+    nv[:, -10:] = case.src_smpl[0, -10:]
+    nv[:, 6:-10] = case.src_smpl[0, 6:-10]
+    seq = np.concatenate([nv, case.tgt_smpls[:max(0, n_frames - 4)]], axis=0)[:n_frames]
+    case.tgt_smpls = add_hands_params_to_smpl(seq, np.asarray(case.smplh["hands_meanl"].tolist() + case.smplh["hands_meanr"].tolist(),
+                                                               dtype=np.float32)).astype(np.float32)
+    return case
+
+
+def check_pipeline_full_1024():
+    """BASELINE configs[3] geometry: 1024x1024 (16 x 16 coarse bins, 64 x 64 pixel tiles per image in the rasterizer), the 2-frame
+    batch regime bench.py uses at this size, the four novel-view poses + one imitation frame, every frame against the oracle."""
+    r = _run_cached("novel1024", _novel_view_case(1024, 5), 2)
+    m = dict(r["m"])
+    _parity_asserts(m)
+    cover = [(r["im"].src_info["fim"] >= 0).float().mean().item()]
+    m["src_cover"] = cover[0]
+    single = pu.run_hip(r["case"], imitator=pu.make_imitator(r["case"], frame_batch=1)).cpu()
+    m["batch_vs_single_max"] = (single - r["got"]).abs().max().item()
+    assert m["batch_vs_single_max"] == 0.0, "batched and per-frame results differ at 1024"
+    return m
+
+
+def check_novel_view_256():
+    """The same pose set through the whole path at 256x256 (all four views + an imitation frame, batch of 3: a view pair and a
+    view / imitation pair share launches)."""
+    r = _run_cached("novel256", _novel_view_case(256, 6), 3)
+    m = dict(r["m"])
+    _parity_asserts(m)
+    return m
+
+
+def check_num_source_1_and_8():
+    """deploy.toml:7-8: num_source = 2 by default, MAX_NUM_SOURCE = 8.  The per-frame path (flows for every source, attention over
+    ns sources, K/V cache of ns rows) against the oracle with ONE source and with EIGHT."""
+    out = {}
+    out["ns1_tiny_128"] = _pipeline(128, [64, 64, 128], 2, [64, 64, 128], n_frames=3, frame_batch=2, ns=1, variants=False)
+    out["ns8_full_128"] = _pipeline(128, *FULL, n_frames=3, frame_batch=3, ns=8, variants=False)
+    out["ns1_full_256"] = _pipeline(256, *FULL, n_frames=2, frame_batch=2, ns=1, variants=False)
+    return out
+
+
+def _psnr(a, b):
+    mse = ((a.double() - b.double()) ** 2).mean().item()
+    return 10 * np.log10(4.0 / max(mse, 1e-20))        # frames are in [-1, 1]: peak-to-peak 2
+
+
+def _precision_rerun(r, mode):
+    """The frames of a cached run again with every Cin % 32 == 0 convolution in ``mode`` (source features rebuilt in that mode too);
+    the geometry stages are fp32 in every mode, so the oracle frames of the cached run remain the reference."""
+    case, im = r["case"], r["im"]
+    prev = im.generator.conv_precision
+    im.generator.conv_precision = mode
+    try:
+        im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+        got = pu.run_hip(case, imitator=im).cpu()
+    finally:
+        im.generator.conv_precision = prev
+        im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    assert torch.isfinite(got).all()
+    return got
+
+
+def check_bf16_vs_oracle():
+    """BASELINE configs[3] precision mode against the fp32 ORACLE (PSNR >= 40 dB), at 512x512 (8 imitation frames) and
+    at 1024x1024 (novel-view poses): bf16 MFMA operands / bf16 activation storage on the HIP side, fp32 torch-CPU on the other."""
+    out = {}
+    for key, build in (("full512", lambda: check_pipeline_full_512()), ("novel1024", lambda: check_pipeline_full_1024())):
+        if key not in _RUNS:
+            build()
+        r = _RUNS[key]
+        got = _precision_rerun(r, "bf16")
+        per_frame = [_psnr(got[t], r["want"][k]) for k, t in enumerate(r["idx"])]
+        d = (got[r["idx"]] - r["want"]).abs()
+        out[key] = {"psnr_db_min": min(per_frame), "psnr_db_all": _psnr(got[r["idx"]], r["want"]), "max_abs": d.max().item(), "mean_abs": d.mean().item(),
+                    "vs_fp32_path_psnr_db": _psnr(got, r["got"])}
+        assert out[key]["psnr_db_min"] >= 40.0, out
+        assert (got - r["got"]).abs().max().item() > 0, "bf16 mode produced the fp32 path's frames bit for bit: the bf16 kernels did not run"
+    return out
+
+
+def check_split_vs_oracle():
+    """conv_precision("split") (bf16x6 exact-split products) end to end at the fp32 tolerances: the 8-frame 512x512 batch against the
+    oracle (max <= 2e-3, mean <= 1e-4) and the generator API against outputs of the REFERENCE's own module."""
+    if "full512" not in _RUNS:
+        check_pipeline_full_512()
+    r = _RUNS["full512"]
+    got = _precision_rerun(r, "split")
+    d = (got[r["idx"]] - r["want"]).abs()
+    out = {"pipeline_512": {"pred_max": d.max().item(), "pred_mean": d.mean().item(), "vs_fp32_path_max": (got - r["got"]).abs().max().item()}}
+    assert d.max().item() <= 2e-3 and d.mean().item() <= 1e-4, out
+    assert out["pipeline_512"]["vs_fp32_path_max"] > 0, "split mode produced the fp32 kernel's frames: the split kernel did not run"
+    out["generator_golden"] = check_generator_golden(conv_precision="split")
+    return out
 
 
 def _source_stage(S, ks, nf, nres, bgf):
@@ -570,31 +699,49 @@ def check_personalize_loop():
     from oracle import lwg_oracle as orc
     from ipercore_amd.imitator import Imitator
     from ipercore_amd.networks import NetworksFactory
-    from ipercore_amd.trainers import FlowCompositionForTrainer, LWGTrainer, PatchGlobalDiscriminator, personalize
+    from ipercore_amd.trainers import FlowCompositionForTrainer, LWGTrainer, PatchGlobalDiscriminator, TrainOpts, personalize
     S, nf, nres, bgf, ns = 128, [64, 64, 128], 2, [64, 64, 128], 2
     ks = dict(conf_erode_ks=3, out_dilate_ks=21, bg_ks=11)
     case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=2, ns=ns)
     case.opt.update(ks)
-    im0 = Imitator(case.opt, device=torch.device(DEV), frame_batch=2)
-    fc = FlowCompositionForTrainer(case.opt, body_model=im0.body_rec).to(DEV)
+    # the trainers' body model: the 24-joint SMPL with its 19 COCO+ keypoints (tools/trainers/base.py:95-97) - the head / body
+    # boxes index those keypoints, so the SMPL-H of the runner is not a stand-in
+    smpl24 = synthetic.smpl_model_dict(seed=0)
+    case.opt["smpl_model"] = smpl24
+    with pytest.raises(FileNotFoundError):
+        FlowCompositionForTrainer(pu.AttrDict({**case.opt, "smpl_model": "/nonexistent/smpl_model.pkl"}))
+    fc = FlowCompositionForTrainer(case.opt).to(DEV)
     smpls, img = pu.source_stage_inputs(S)                                       # the seeded inputs of the source-stage goldens
     tgt_smpl = synthetic.smpl_sequence(1, seed=60, pose_dim=72)
     tgt_img = synthetic.uniform_image((1, 1, 3, S, S), 61, "tgt_img")
     all_smpl = torch.tensor(np.concatenate([smpls, tgt_smpl], axis=0)[None], device=DEV)
-    info = fc.smpl.get_details(all_smpl[0], torch.zeros((), device=DEV), links_ids=None)
+    # offsets / links_ids exactly as PersonalizedDataset.__getitem__ + the DataLoader hand them over (personalized_dataset.py:163-191):
+    # (1, nv, 3) float offsets and (1, nv, 3) long (from, to, has_linked) rows
+    offsets = (0.004 * synthetic._rs(63, "offsets").standard_normal((1, 6890, 3))).astype(np.float32)
+    r = synthetic._rs(64, "links")
+    links = np.stack([np.arange(6890), r.permutation(6890), (r.uniform(size=6890) < 0.01).astype(np.int64)], axis=1)[None].astype(np.int64)
+    info = fc.smpl.get_details(all_smpl[0], torch.tensor(offsets, device=DEV), links_ids=torch.tensor(links).expand(ns + 1, -1, -1))
+    want_v = orc.link(orc.smpl24_get_details(smpl24, all_smpl[0].cpu(), torch.tensor(offsets))["verts"], torch.tensor(links).expand(ns + 1, -1, -1))
+    m_verts = _cmp(info["verts"], want_v, 1e-5, "SMPL-24 verts with (1,nv,3) offsets and (B,nv,3) links")
+    assert int(links[0, :, 2].sum()) > 20 and (info["verts"].cpu() - fc.smpl.get_details(all_smpl[0], 0, None)["verts"].cpu()).abs().max() > 1e-3
+    # links that really differ per sample take the row-by-row form (base_smpl.py:46-49)
+    l3 = torch.tensor(links).repeat(ns + 1, 1, 1)
+    l3[1, :, 2] = 0
+    got3 = fc.smpl.get_details(all_smpl[0], torch.tensor(offsets, device=DEV), links_ids=l3)["verts"]
+    _cmp(got3, orc.link(orc.smpl24_get_details(smpl24, all_smpl[0].cpu(), torch.tensor(offsets))["verts"], l3), 1e-5, "per-sample links")
     _, fim_all, wim_all = fc.render.render_fim_wim(cam=info["cam"], vertices=info["verts"], smpl_faces=True)
     fg = pu.fg_masks_from_sil((fim_all != -1).float().unsqueeze(1).cpu())
     sample = {"images": np.concatenate([img, tgt_img], axis=1), "smpls": all_smpl.cpu().numpy(), "masks": (1.0 - fg)[None].numpy(),
-              "bg": synthetic.uniform_image((1, 3, S, S), 62, "bg")}
+              "bg": synthetic.uniform_image((1, 3, S, S), 62, "bg"), "offsets": offsets, "links_ids": links}
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
     G.load_state_dict({k: torch.tensor(v) for k, v in case.state.items()}, strict=True)
     G.to(DEV).train()
     torch.manual_seed(0)
     D = PatchGlobalDiscriminator().to(DEV)
-    tr = LWGTrainer(G, D, flow_comp=fc)
+    tr = LWGTrainer(G, D, opts=TrainOpts.l1_transfer(), flow_comp=fc)
     tr.set_input(sample)
     torch.cuda.synchronize()
-    inp, out = tr.inp, {}
+    inp, out = tr.inp, {"verts_offsets_links": m_verts}
     # oracle composition on the HIP vertices (identical rasterizer inputs on both sides)
     o = pu.oracle_source_stage(S, ks, verts_cam=(info["cam"][:ns].cpu(), info["verts"][:ns].cpu()))
     assert torch.equal(o["fg"], fg[:ns])
@@ -631,7 +778,7 @@ def check_personalize_loop():
     from ipercore_amd.trainers import create_discriminator
     dcfg = pu.AttrDict(cond_nc=6, bg_cond_nc=4, ndf=32, n_layers=3, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
     D3 = create_discriminator("patch_global_body_head", dcfg).to(DEV)
-    tr3 = LWGTrainer(G, D3, flow_comp=fc)
+    tr3 = LWGTrainer(G, D3, opts=TrainOpts.l1_transfer(), flow_comp=fc)
     tr3.set_input(sample)
     lg, ld = tr3.optimize_parameters()
     torch.cuda.synchronize()
@@ -744,7 +891,7 @@ def check_vgg_loss():
     the same network written with F.conv2d / F.max_pool2d; then one trainer step with use_vgg = "VGG19"."""
     from ipercore_amd.networks import NetworksFactory
     from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts, VGGLoss
-    crt = VGGLoss(ckpt_path=None).to(DEV)
+    crt = VGGLoss(ckpt_path=None, allow_seeded=True).to(DEV)
     x, y = _rand((2, 3, 96, 96), 990, 0.5), _rand((2, 3, 96, 96), 991, 0.5)
     sd = {k: v.detach().cpu() for k, v in crt.vgg.state_dict().items()}
 
@@ -799,8 +946,8 @@ def check_vgg_loss():
     # one trainer step with the perceptual loss
     S, nf, nres, bgf, ns = 64, [64, 64, 128], 2, [64, 64, 128], 2
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).to(DEV).train()
-    topts = TrainOpts()
-    topts.use_vgg = "VGG19"
+    topts = TrainOpts.l1_transfer()
+    topts.use_vgg, topts.allow_seeded_loss_nets = "VGG19", True
     tr = LWGTrainer(G, PatchGlobalDiscriminator().to(DEV), opts=topts)
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
     U = lambda shp, sd_, nm: torch.tensor(synthetic.uniform_image(shp, sd_, nm), device=DEV)     # noqa: E731
@@ -818,7 +965,7 @@ def check_vgg_loss():
 def _face_state_dict():
     """tests/golden/make_golden_faceloss.py::face_state_dict."""
     from ipercore_amd.trainers import Sphere20aFeatures
-    shapes = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None).state_dict().items()}
+    shapes = {k: tuple(v.shape) for k, v in Sphere20aFeatures(None, allow_seeded=True).state_dict().items()}
     sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=13).items()}
     for k in sd:
         if k.startswith("relu"):
@@ -833,7 +980,7 @@ def check_face_loss():
     from ipercore_amd.networks import NetworksFactory
     from ipercore_amd.trainers import FaceLoss, LWGTrainer, PatchGlobalDiscriminator, TrainOpts
     gf = np.load(os.path.join(ROOT, "tests", "golden", "golden_faceloss_v1.npz"))
-    crt = FaceLoss(None)
+    crt = FaceLoss(None, allow_seeded=True)
     sd = _face_state_dict()
     crt.net.load_state_dict(sd, strict=True)
     crt.to(DEV)
@@ -885,7 +1032,7 @@ def check_face_loss():
     S, nf, nres, bgf, ns = 64, [64, 64, 128], 2, [64, 64, 128], 2
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).to(DEV).train()
     topts = TrainOpts()
-    topts.use_vgg, topts.use_face = "VGG19", True
+    topts.use_vgg, topts.use_face, topts.allow_seeded_loss_nets = "VGG19", True, True
     tr = LWGTrainer(G, PatchGlobalDiscriminator().to(DEV), opts=topts)
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
     U = lambda shp, sd_, nm: torch.tensor(synthetic.uniform_image(shp, sd_, nm), device=DEV)     # noqa: E731
@@ -1046,6 +1193,8 @@ def check_conv_backward():
     run("3x3_s1", "3x3 s1 64->128", 2, 16, 32, 64, 128, 3, 1, 1, 400, act=1)
     run("3x3_s1_tail", "3x3 s1 M/K tails", 3, 9, 7, 64, 64, 3, 1, 1, 410)          # M tail, K = 576 (4.5 tiles)
     run("3x3_s2", "3x3 s2 64->128", 2, 16, 16, 64, 128, 3, 2, 1, 420, act=1, bias=False)
+    run("3x3_s2_odd", "3x3 s2 64->64, odd 9x7 input", 2, 9, 7, 64, 64, 3, 2, 1, 425)     # parity launches of unequal row / column counts
+    run("4x4_s2_odd", "4x4 s2 64->64, odd 11x13 input (D's kernel)", 1, 11, 13, 64, 64, 4, 2, 1, 427)
     run("1x1", "1x1 256->256", 1, 8, 8, 256, 256, 1, 1, 0, 430)
     run("concat", "3x3 concat 128+256", 1, 16, 16, 384, 256, 3, 1, 1, 440, C1=256, act=1)
     run("convT", "convT 128->64", 2, 8, 8, 128, 64, 4, 2, 1, 450, kind="convT", act=1)
@@ -1128,7 +1277,7 @@ def check_discriminator_and_trainer_step():
     """patch_global discriminator forward/backward vs the reference architecture on the CPU (torch autograd), then two
     full LWGTrainer.optimize_parameters() steps (G + D, Adam) on synthetic inputs: finite, and the G loss goes down."""
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
-    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator
+    from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
     torch.manual_seed(0)
     D = PatchGlobalDiscriminator().to(DEV)
     ref = _ref_patch_discriminator(D)
@@ -1187,7 +1336,7 @@ def check_discriminator_and_trainer_step():
            "real_src": u((1, ns, 3, S, S), 700, "real_src"), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
            "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
     D2 = PatchGlobalDiscriminator().to(DEV)
-    tr = LWGTrainer(G, D2)
+    tr = LWGTrainer(G, D2, opts=TrainOpts.l1_transfer())
     tr.set_input(inp)
     hist = []
     for _ in range(3):
@@ -1198,7 +1347,7 @@ def check_discriminator_and_trainer_step():
     assert all(np.isfinite(v) for pair in hist for v in pair), hist          # (a GAN loss need not be monotone)
     # without the adversarial term the objective is a plain regression: Adam at lr 1e-4 must make progress
     G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
-    tr = LWGTrainer(G, None)
+    tr = LWGTrainer(G, None, opts=TrainOpts.l1_transfer())
     tr.set_input(inp)
     rec = [tr.optimize_parameters()[0].item() for _ in range(6)]
     m["rec_loss_history"] = rec
@@ -1449,6 +1598,7 @@ def check_attention_backward():
 
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
-       check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_source_setup_128,
+       check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
+       check_pipeline_full_1024, check_bf16_vs_oracle, check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
        check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants]

@@ -69,7 +69,7 @@ def run_oracle(case, cam_strategy="smooth", frames=None, return_all=False, src_o
     return (pred, extra) if return_all else pred
 
 
-def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, device="cuda:0", imitator=None):
+def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, device="cuda:0", imitator=None, return_want=False):
     """HIP path vs oracle, stage by stage (the end-to-end map is discontinuous at silhouette pixels, so each stage
     is compared on identical inputs): (1) skinned vertices HIP vs oracle; (2) fim/wim exact given the HIP vertices;
     (3) generator input / flows; (4) final frames.  Returns a metrics dict; the caller asserts."""
@@ -99,6 +99,8 @@ def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, devic
     d = (got[idx] - want).abs()
     m["pred_max"], m["pred_mean"] = d.max().item(), d.mean().item()
     m["pred_finite"] = bool(torch.isfinite(got).all())
+    if return_want:
+        m["want"] = want
     return m, got, im
 
 

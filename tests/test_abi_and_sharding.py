@@ -169,6 +169,71 @@ def test_all_gather_frames_gloo_world2(tmp_path, n):
         assert p.returncode == 0, out.decode()
 
 
+_CLIP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ipercore_amd import sharding
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+class Fake:
+    image_size = 2
+    def __init__(self, fb): self.frame_batch = fb; self.calls = []
+    def prepare_sequence(self, s, cam): return torch.as_tensor(s)
+    def synthesize(self, chunk, cam, t0=0):
+        self.calls.append((int(t0), int(chunk.shape[0])))
+        if chunk.shape[0] == 0:
+            return torch.empty((0, 3, 2, 2))
+        return chunk[:, None, None, None].expand(-1, 3, 2, 2) * 2 + 1
+for n, fb in [(int(a), int(b)) for a, b in (c.split(":") for c in sys.argv[2].split(","))]:
+    seq = torch.arange(n, dtype=torch.float32)
+    lo, hi = sharding.shard_range(n, rank, world)
+    for overlap in (True, False):
+        im, st = Fake(fb), {}
+        vid = sharding.sharded_synthesize(im, seq, overlap=overlap, prepared=True, stats=st)
+        assert vid.shape == (n, 3, 2, 2) and torch.equal(vid[:, 0, 0, 0], seq * 2 + 1), (n, fb, overlap, vid[:, 0, 0, 0])
+        assert st["shard"] == (lo, hi) and st["world"] == world
+        assert sum(k for _, k in im.calls) == hi - lo                      # every frame of the shard rendered exactly once
+        if overlap:
+            plan = sharding.chunk_plan(n, world, fb)
+            assert st["chunks"] == len(plan) == len(im.calls)               # one collective per planned chunk on EVERY rank
+            assert st["bytes_received"] == sum(m for _, m in plan) * world * 3 * 2 * 2 * 4
+    # the per-chunk transform (the uint8 video): applied before the exchange, also to the all-padding chunks
+    u8 = sharding.sharded_synthesize(Fake(fb), seq, prepared=True, post=lambda x: x.permute(0, 2, 3, 1).to(torch.uint8))
+    assert u8.dtype == torch.uint8 and u8.shape == (n, 2, 2, 3) and torch.equal(u8[:, 0, 0, 0].float(), (seq * 2 + 1) % 256)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def _run_gloo(tmp_path, script_text, world, *argv):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(script_text)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()
+
+
+def test_clip_schedule_gloo_world2_and_3(tmp_path):
+    """BASELINE configs[2]'s schedule (reference loop: services/run_imitator.py:19-84 -> Imitator.inference): a 300-frame clip in
+    contiguous shards, 8-frame chunks behind the frame loop; plus the degenerate clips - fewer frames than ranks (an empty shard),
+    a last chunk that is all padding on the short shards, a frame batch that does not divide the shard."""
+    _run_gloo(tmp_path, _CLIP_WORKER, 2, "300:8,7:3,1:8,5:1")
+    _run_gloo(tmp_path, _CLIP_WORKER, 3, "300:8,2:8,7:1,301:8")
+
+
+def test_clip_schedule_gloo_world8_300_frames(tmp_path):
+    """The configuration itself: 8 ranks, 300 frames -> shards of 38/38/38/38/37/37/37/37, five chunks of (8, 8, 8, 8, 6) frames,
+    the last one carrying one padding frame on the four short shards."""
+    assert sharding.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
+    assert sharding.chunk_plan(300, 8, 8) == [(0, 8), (8, 8), (16, 8), (24, 8), (32, 6)]
+    _run_gloo(tmp_path, _CLIP_WORKER, 8, "300:8,5:8")
+
+
 _GRAD_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
