@@ -10,7 +10,7 @@
  * Conventions (every function):
  *   - all pointers are DEVICE pointers into buffers owned by the caller (PyTorch-ROCm allocations);
  *     kernels never allocate, never synchronise, and are enqueued on `stream` (a hipStream_t passed as void*);
- *   - tensors are contiguous; activations are NHWC fp32; face/vertex/pixel indices are int32;
+ *   - tensors are contiguous; activations are NHWC fp32 (bf16 in the *_bf16 entry points); face/vertex/pixel indices are int32;
  *   - the return value is a hipError_t cast to int (0 = hipSuccess; 1 = hipErrorInvalidValue is also used
  *     for contract violations detected on the host side before any launch).
  */
@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-#define LWG_ABI_VERSION 1
+#define LWG_ABI_VERSION 2
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -38,6 +38,7 @@ int lwg_abi_version(void);
 #define LWG_MAX_TAPS 52
 enum { LWG_EPI_NONE = 0, LWG_EPI_RESIDUAL = 1, LWG_EPI_SPADE = 2 };
 enum { LWG_ACTIVATION_NONE = 0, LWG_ACTIVATION_RELU = 1, LWG_ACTIVATION_TANH = 2, LWG_ACTIVATION_SIGMOID = 3 };
+enum { LWG_DT_F32 = 0, LWG_DT_BF16 = 1 };   /* activation storage type (BASELINE configs[3]: bf16 activations end to end) */
 
 typedef struct LwgConvArgs {
     const float* x0;   /* input, NHWC (B,H,W,C0); each input tensor must be < 3 GiB (32-bit buffer offsets) */
@@ -62,6 +63,8 @@ typedef struct LwgConvArgs {
     const float* xn;   /* LWG_EPI_SPADE: tensor to normalise (B,YH,YW,YC) */
     const float* mean; /* LWG_EPI_SPADE: (B,YC) instance mean   */
     const float* rstd; /* LWG_EPI_SPADE: (B,YC) 1/sqrt(var+eps) */
+    int xdt;           /* LWG_DT_*: storage type of x0 / x1 (the float* fields then point at bf16 data) */
+    int ydt;           /* LWG_DT_*: storage type of y, res and xn */
     signed char dy[LWG_MAX_TAPS];
     signed char dx[LWG_MAX_TAPS];
 } LwgConvArgs;
@@ -74,10 +77,18 @@ int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
 size_t lwg_conv2d_ws_floats(const LwgConvArgs* args);
 int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stream);
 
-/* bf16-operand variant (BASELINE configs[3], "MFMA bf16 conv tiles"): same contract, except that args->w is the bf16 panel
- * [ntaps*Cin/8][N][8] (same K order) and Cin % 32 == 0; activations stay fp32 in memory, are rounded to bf16 while staged
- * into LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16). */
-int lwg_conv2d_nhwc_bf16mma(const LwgConvArgs* args, lwg_stream_t stream);
+/* BASELINE configs[3] ("MFMA bf16 conv tiles"): bf16 activations in HBM end to end, bf16 MFMA operands, fp32 accumulation.
+ * Same launch description as lwg_conv2d_nhwc_f32 with xdt = ydt = LWG_DT_BF16: x0 / x1 / y / res / xn are bf16 NHWC tensors
+ * (bias, mean, rstd stay fp32), Cin % 64 == 0 (C0 % 64 == 0 when C1 > 0), N % 64 == 0, YC % 8 == 0, ycoff % 8 == 0, and
+ * args->w is the bf16 panel [ntaps*Cin/64][N][64] with k = ((c/64)*ntaps + tap)*64 + c%64, whose eight 16-byte k-octets of a
+ * row n are stored at slot  octet ^ ((n >> 1) & 7)  (the LDS image the kernel's fragment reads expect: conflict-free
+ * ds_read_b128 on 128-byte rows).  The first layer of a network (fp32 image-like input, Cin < 32) runs lwg_conv2d_nhwc_f32 with
+ * ydt = LWG_DT_BF16 (LWG_EPI_NONE only): fp32 in, bf16 out. */
+int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
+/* The deep-pipeline form of the same convolution (BK = 32, four LDS stages, counted vmcnt): N % 128 == 0, Cin % 32 == 0 and
+ * args->w = the bf16 panel [ntaps*Cin/32][N][32] with k = ((c/32)*ntaps + tap)*32 + c%32 (the fp32 panel's K order), the four
+ * 16-byte k-octets of row n at slot  octet ^ ((n >> 2) & 3). */
+int lwg_conv2d_nhwc_bf16_p4(const LwgConvArgs* args, lwg_stream_t stream);
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs
  * per fp32 product, fp32 accumulation; dropped terms < 2^-23 |a b|.  Same contract and restrictions as the bf16 entry point. */
@@ -136,6 +147,9 @@ int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B,
  * ------------------------------------------------------------------------------------------------ */
 int lwg_instnorm_stats_nhwc_f32(const float* x, int B, int HW, int C, float eps, float* mean, float* rstd,
                                 float* ws, int nsplit, lwg_stream_t stream);
+/* The statistics of a bf16 (B,HW,C) tensor (fp32 arithmetic and outputs), C in {64,128,256}, nsplit <= 64. */
+int lwg_instnorm_stats_nhwc_bf16(const void* x, int B, int HW, int C, float eps, float* mean, float* rstd, float* ws, int nsplit,
+                                 lwg_stream_t stream);
 int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* res,
                                 float* y, int B, int HW, int C, int act, lwg_stream_t stream);
 
@@ -150,6 +164,9 @@ int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* 
 int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
                           const float* T, float* out, int B, int ns, int h, int w, int C, int S,
                           int src_batched, lwg_stream_t stream);
+/* The same block on bf16 q / Ks / Vs / out (BASELINE configs[3]: bf16 activation storage); bk / bv / T stay fp32; C in {64,128,256}. */
+int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void* Vs, const float* bk, const float* bv, const float* T, void* out,
+                           int B, int ns, int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
 /* Backward of the above for the personalization step (lwg_trainer.py:649-697 runs the same block under autograd; the
  * flows are constants there).  dq is written; dKs / dVs are accumulated with fp32 atomics and must be zero on entry;
  * ns <= 8.  The bias gradients need no kernel: dbv = column sum of dout, dbk = 0. */
@@ -227,6 +244,12 @@ int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float* beta, int 
  * ------------------------------------------------------------------------------------------------ */
 int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
                          float* pred, float* mask, float* img, lwg_stream_t stream);
+/* The same head on a bf16 NHWC input (B,S,S,64) with the regressors on the matrix cores (v_mfma_f32_16x16x32_bf16): wb is the bf16
+ * operand panel [ky 5][pass 2][channel half 2][lane 64][8]: lane l of a block holds row (l % 16) = 4 * tap + output and the
+ * k-octet (l / 16) of the 32 channels; pass 0 carries the taps kx = 0..3, pass 1 the tap kx = 4 in its rows 0..3 (rows 4..15 zero).
+ * Outputs fp32 NCHW as lwg_head_compose_f32. */
+int lwg_head_compose_bf16(const void* x, const void* wb, const float* bg, size_t bg_bstride, int B, int S, int C, float* pred,
+                          float* mask, float* img, lwg_stream_t stream);
 /* lwg_frames_to_u8: the output conversion of Imitator.inference (models/imitator.py:368-372 ->
  * cv_utils.save_cv2_img(normalize=True), tools/utils/filesio/cv_utils.py:100-116): pred (B,3,S,S) fp32 ->
  * (B,S,S,3) uint8 = uint8((x+1)/2.0*255) in numpy fp32 arithmetic (truncation); bgr = 1: cv2's channel order. */

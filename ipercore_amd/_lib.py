@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg_hip.h")
 LWG_MAX_TAPS = 52
 EPI_NONE, EPI_RESIDUAL, EPI_SPADE = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_LRELU = 0, 1, 2, 3, 4
+DT_F32, DT_BF16 = 0, 1
 
 c_f = ctypes.c_void_p  # device pointers travel as void*
 c_i = ctypes.c_int
@@ -33,6 +34,7 @@ class LwgConvArgs(ctypes.Structure):
         ("omul", c_i), ("ooy", c_i), ("oox", c_i),
         ("epi", c_i), ("act", c_i),
         ("res", c_f), ("xn", c_f), ("mean", c_f), ("rstd", c_f),
+        ("xdt", c_i), ("ydt", c_i),
         ("dy", ctypes.c_byte * LWG_MAX_TAPS), ("dx", ctypes.c_byte * LWG_MAX_TAPS),
     ]
 
@@ -43,7 +45,8 @@ _SIGS = {
     "lwg_conv2d_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
-    "lwg_conv2d_nhwc_bf16mma": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_nhwc_bf16_p4": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
@@ -60,6 +63,9 @@ _SIGS = {
     "lwg_instnorm_stats_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
     "lwg_instnorm_apply_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_lwb_attention_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_lwb_attention_bf16": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_instnorm_stats_nhwc_bf16": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
+    "lwg_head_compose_bf16": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "lwg_lwb_fuse_f32": (c_i, [c_f] * 5 + [c_i] * 7 + [ctypes.c_float, ctypes.c_float, c_f]),
     "lwg_lwb_attention_bwd_f32": (c_i, [c_f] * 10 + [c_i] * 7 + [c_f]),
     "lwg_rasterize_ws_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
@@ -109,7 +115,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 1:
+        if handle.lwg_abi_version() != 2:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -469,6 +469,7 @@ extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stre
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
     if (a.N % 64 != 0 || (Cin & 3) != 0 || (a.YC & 3) != 0 || (a.ycoff & 3) != 0) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_F32 || (a.ydt != LWG_DT_F32 && (a.ydt != LWG_DT_BF16 || a.epi != LWG_EPI_NONE || ws))) return (int)hipErrorInvalidValue;
     // buffer-load addressing: every tensor the kernel gathers from must be smaller than LWG_OOB_OFFSET bytes
     const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
     if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;

@@ -662,6 +662,7 @@ extern "C" int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* pa, lwg_stream_t str
     const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
     if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
     if ((unsigned long long)a.ntaps * Cin * a.N * 6ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32) return (int)hipErrorInvalidValue;
     if (a.epi == LWG_EPI_SPADE) {
         if (!a.xn || !a.mean || !a.rstd || !a.bias || a.N % 128 != 0 || a.YC * 2 != a.N) return (int)hipErrorInvalidValue;
         return (int)launch_epi_split<LWG_EPI_SPADE>(a, stream);

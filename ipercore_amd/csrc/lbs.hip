@@ -126,7 +126,9 @@ __global__ __launch_bounds__(64) void lwg_lbs_pose_kernel(const float* __restric
 // v_posed[b,col] = v_shaped[b,col] + sum_p pose_feature[b,p] * posedirs[p,col]      (col = 3*v + k)
 // grid (ceil(3nv/64), ceil(B/FB)), 4 waves: a lane owns one column for up to FB frames (posedirs is streamed once per
 // frame group, 256 contiguous bytes per wave load), wave w takes the rows p = w, w+4, ...; the four partial sums are
-// combined in wave order (fixed order: a frame's result does not depend on the batch it is in).
+// combined in wave order (fixed order: a frame's result does not depend on the batch it is in).  The multiply-adds are EXPLICIT
+// fused fmaf: left to -ffp-contract the compiler packed some of the FB frame slots into v_pk_mul / v_pk_add pairs and fused the
+// others, so frames 6 and 7 of an 8-frame batch differed in the last bit from the same frames skinned alone (slot 0).
 __global__ __launch_bounds__(256) void lwg_lbs_posed_kernel(const float* __restrict__ v_shaped, const float* __restrict__ posedirs,
                                                            const float* __restrict__ pose_feature, int npf, int nv3, int B,
                                                            float* __restrict__ v_posed) {
@@ -155,12 +157,12 @@ __global__ __launch_bounds__(256) void lwg_lbs_posed_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] += spf[fb * npf + p + 4 * u] * d[u];
+                for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] = __builtin_fmaf(spf[fb * npf + p + 4 * u], d[u], po[fb]);
         }
         for (; p < npf; p += 4) {
             const float d = posedirs[(size_t)p * nv3 + col];
 #pragma unroll
-            for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] += spf[fb * npf + p] * d;
+            for (int fb = 0; fb < LWG_LBS_FB; ++fb) po[fb] = __builtin_fmaf(spf[fb * npf + p], d, po[fb]);
         }
     }
 #pragma unroll

@@ -71,7 +71,15 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                     if (EPI == LWG_EPI_RESIDUAL) rv = *reinterpret_cast<const floatx4*>(rr + 32 * j + 8 * g);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c] + rv[c], a.act);
-                    *reinterpret_cast<floatx4*>(yr + 32 * j + 8 * g) = o;
+                    if (EPI == LWG_EPI_NONE && a.ydt == LWG_DT_BF16) {      // first layer of the bf16 mode: fp32 in, bf16 NHWC out
+                        typedef __bf16 lwg_bf16x4 __attribute__((ext_vector_type(4)));
+                        lwg_bf16x4 ob;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ob[c] = (__bf16)o[c];
+                        *reinterpret_cast<lwg_bf16x4*>(reinterpret_cast<__bf16*>(a.y) + opix * a.YC + a.ycoff + ncol0 + 32 * j + 8 * g) = ob;
+                    } else {
+                        *reinterpret_cast<floatx4*>(yr + 32 * j + 8 * g) = o;
+                    }
                 }
         }
     }

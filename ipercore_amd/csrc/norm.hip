@@ -134,6 +134,106 @@ __global__ __launch_bounds__(256) void lwg_in_stats_final(const float* __restric
     }
 }
 
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lwg_unpack8(const uintx4 v, float (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = __builtin_bit_cast(float, v[k] << 16);
+        f[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- InstanceNorm statistics
+// Pass 1 of csrc/norm.hip on a bf16 (B, HW, C) tensor, C in {64, 128, 256}: a lane owns 8 channels (one 16-byte load), LPP = C/8
+// lanes cover a pixel, PG = 256/LPP pixels per iteration, four iterations in flight; shifted sums; records (n, mean, M2) per
+// (image, split, channel) in the layout lwg_in_stats_final (norm.hip) merges.  grid (nsplit, B).
+template <int LPP>
+__global__ __launch_bounds__(256) void lwg_in_stats_partial8_bf16(const __bf16* __restrict__ x, int HW, int nsplit, float* __restrict__ ws) {
+    constexpr int C = LPP * 8, PG = 256 / LPP;
+    const int cq = threadIdx.x % LPP, pg = threadIdx.x / LPP;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    const uintx4* xb = reinterpret_cast<const uintx4*>(x + (size_t)b * HW * C) + cq;
+    float shift[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) shift[k] = s1[k] = s2[k] = 0.f;
+    int n = 0;
+    if (p0 < p1) lwg_unpack8(xb[(size_t)p0 * LPP], shift);
+    int p = p0 + pg;
+    for (; p + 3 * PG < p1; p += 4 * PG) {
+        uintx4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xb[(size_t)(p + u * PG) * LPP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            lwg_unpack8(v[u], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float d = f[k] - shift[k];
+                s1[k] += d;
+                s2[k] += d * d;
+            }
+        }
+        n += 4;
+    }
+    for (; p < p1; p += PG) {
+        float f[8];
+        lwg_unpack8(xb[(size_t)p * LPP], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = f[k] - shift[k];
+            s1[k] += d;
+            s2[k] += d * d;
+        }
+        ++n;
+    }
+    __shared__ float sh1[PG][LPP][8], sh2[PG][LPP][8];
+    __shared__ int shn[PG];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sh1[pg][cq][k] = s1[k];
+        sh2[pg][cq][k] = s2[k];
+    }
+    if (cq == 0) shn[pg] = n;
+    __syncthreads();
+    if (pg == 0) {
+        float tn = 0.f;
+#pragma unroll
+        for (int g = 0; g < PG; ++g) tn += (float)shn[g];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) { t1 += sh1[g][cq][k]; t2 += sh2[g][cq][k]; }
+            float mean = shift[k], m2 = 0.f;
+            if (tn > 0.f) { mean = shift[k] + t1 / tn; m2 = t2 - t1 * t1 / tn; }
+            float* o = ws + (((size_t)b * nsplit + split) * C + cq * 8 + k) * 3;
+            o[0] = tn; o[1] = mean; o[2] = m2 > 0.f ? m2 : 0.f;
+        }
+    }
+}
+
+extern "C" int lwg_instnorm_stats_nhwc_bf16(const void* x, int B, int HW, int C, float eps, float* mean, float* rstd, float* ws,
+                                            int nsplit, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !mean || !rstd || !ws || B <= 0 || HW <= 0 || nsplit <= 0 || nsplit > 64 || B > 65535) return (int)hipErrorInvalidValue;
+    const __bf16* xb = reinterpret_cast<const __bf16*>(x);
+    if (C == 64)
+        hipLaunchKernelGGL(lwg_in_stats_partial8_bf16<8>, dim3(nsplit, B), dim3(256), 0, stream, xb, HW, nsplit, ws);
+    else if (C == 128)
+        hipLaunchKernelGGL(lwg_in_stats_partial8_bf16<16>, dim3(nsplit, B), dim3(256), 0, stream, xb, HW, nsplit, ws);
+    else if (C == 256)
+        hipLaunchKernelGGL(lwg_in_stats_partial8_bf16<32>, dim3(nsplit, B), dim3(256), 0, stream, xb, HW, nsplit, ws);
+    else
+        return (int)hipErrorInvalidValue;
+    const int BC = B * C;
+    hipLaunchKernelGGL(lwg_in_stats_final, dim3((BC + 3) / 4), dim3(256), 0, stream, ws, BC, C, nsplit, eps, mean, rstd);
+    return (int)hipGetLastError();
+}
+
+
 __global__ __launch_bounds__(256) void lwg_in_apply(const floatx4* __restrict__ x, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const floatx4* __restrict__ res,
                                                    floatx4* __restrict__ y, int HW, int C4, size_t total4, int act) {

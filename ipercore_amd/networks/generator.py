@@ -116,6 +116,8 @@ class _Packed:
         self.upconvs = [convT(f"tsf_net_dec.upconvs.{i}.0") for i in range(n_down)]
         self.skippers = [conv(f"tsf_net_dec.skippers.{i}.0") for i in range(n_down - 1)]
         self.head = P.pack_head(sd["tsf_img_reg.0.weight"], sd["tsf_att_reg.0.weight"]).to(dev)
+        # bf16 mode: the same regressors as an MFMA operand panel (csrc/bf16_ops.hip); needs the 64-channel decoder output
+        self.head16 = P.pack_head_bf16(sd["tsf_img_reg.0.weight"], sd["tsf_att_reg.0.weight"]).to(dev) if nf[0] == 64 else None
         self.bg = None
         if gen.has_bg:
             bgf = gen.bg_filters
@@ -178,7 +180,8 @@ class AttentionLWBGenerator(nn.Module):
         for name, child in tree.named_children():     # graft the tree's top-level nodes onto this module
             self.add_module(name, child)
         self._packed = None
-        # "bf16": convs run with bf16 MFMA operands (fp32 activations in memory, fp32 accumulation) - BASELINE configs[3]
+        # "bf16": BASELINE configs[3] - every activation tensor of the engine is stored as bf16, the convs run on the bf16 MFMA kernel
+        # (fp32 accumulation), InstanceNorm statistics / attention / head read bf16; the first conv of a stream takes the fp32 input
         self.conv_precision = "fp32"
 
     # ------------------------------------------------------------------ plumbing
@@ -201,10 +204,11 @@ class AttentionLWBGenerator(nn.Module):
         """src8: (n, S, S, 8) NHWC (6 used) -> SourceFeatures with K/V panels for the 9 AttLWB sites."""
         pk = self.packed()
         x = src8
+        adt = self._act_dtype()
         enc, res = [], []
         for i, spec in enumerate(pk.src_enc):
             n, H, W, _ = x.shape
-            y = x.new_empty(n, H // 2, W // 2, spec.N)
+            y = x.new_empty(n, H // 2, W // 2, spec.N, dtype=adt)
             x = ops.conv2d(x, spec, y, act=ops.ACT_RELU)
             enc.append(x)
         for c0, c1 in pk.src_res:
@@ -239,8 +243,8 @@ class AttentionLWBGenerator(nn.Module):
                                 scale_w=1.0 if self.lwb_kind == "sg_add" else 1.0 / ns, src_batched=batched)
         q = ops.conv2d(tsf_x, st["fq"], torch.empty_like(tsf_x))
         att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], Tst, torch.empty_like(tsf_x), src_batched=batched)
-        mean = tsf_x.new_empty(B, C)
-        rstd = tsf_x.new_empty(B, C)
+        mean = tsf_x.new_empty(B, C, dtype=torch.float32)
+        rstd = tsf_x.new_empty(B, C, dtype=torch.float32)
         nsplit = max(1, min(64, (h * w) // 64))
         ws = scratch.get(B * C * nsplit * 3, tsf_x.device)
         ops.instnorm_stats(tsf_x, mean, rstd, ws, eps=1e-5, nsplit=nsplit)
@@ -262,11 +266,17 @@ class AttentionLWBGenerator(nn.Module):
         scratch = _Scratch()
         n_down = len(pk.tsf_enc)
         x = tsf8
+        adt = self._act_dtype()
+        if adt != torch.float32 and self.lwb_kind != "att":
+            raise NotImplementedError("bf16 activation storage is built for the attention LWB (AttLWB-SPADE) generators")
+        if feats.kv[0][0].dtype != adt:
+            raise RuntimeError(f"source features are {feats.kv[0][0].dtype} but the generator runs in {self.conv_precision} mode: "
+                               "rebuild them (Imitator.set_source / forward_src) after changing conv_precision")
         enc = []
         site = 0
         for i, spec in enumerate(pk.tsf_enc):
             B, H, W, _ = x.shape
-            x = ops.conv2d(x, spec, x.new_empty(B, H // 2, W // 2, spec.N), act=ops.ACT_RELU)
+            x = ops.conv2d(x, spec, x.new_empty(B, H // 2, W // 2, spec.N, dtype=adt), act=ops.ACT_RELU)
             x = self._attlwb(pk.enc_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
             site += 1
             enc.append(x)
@@ -281,7 +291,17 @@ class AttentionLWBGenerator(nn.Module):
                 skip = enc[n_down - 2 - i]
                 sp = pk.skippers[i]
                 x = ops.conv2d(skip, sp, x.new_empty(x.shape[0], x.shape[1], x.shape[2], sp.N), x1=x, act=ops.ACT_RELU)
-        return ops.head_compose(x, pk.head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img)
+        head = pk.head
+        if x.dtype == torch.bfloat16:
+            if pk.head16 is not None:
+                head = pk.head16
+            else:
+                x = x.float()
+        return ops.head_compose(x, head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img)
+
+    def _act_dtype(self):
+        """Storage type of the engine's activation tensors: bf16 in the "bf16" precision mode (BASELINE configs[3]), else fp32."""
+        return torch.bfloat16 if self.conv_precision == "bf16" else torch.float32
 
     @torch.no_grad()
     def _run_bg_impl(self, bg4):
@@ -317,7 +337,7 @@ class AttentionLWBGenerator(nn.Module):
         pk = self.packed()
         for specs in pk.src_dec:
             x = self._upconv(x, specs, ops.ACT_RELU)
-        _, mask, img = ops.head_compose(x, pk.src_head, None, want_pred=False, want_mask=True, want_img=True)
+        _, mask, img = ops.head_compose(x.float(), pk.src_head, None, want_pred=False, want_mask=True, want_img=True)
         return img, mask
 
     def encode_sources(self, *a, **k):
@@ -329,7 +349,8 @@ class AttentionLWBGenerator(nn.Module):
             return self._run_tsf_impl(*a, **k)
 
     def run_bg(self, *a, **k):
-        with ops.conv_precision(self.conv_precision):
+        # once per source, InstanceNorm after every conv: fp32 tensors in every mode ("split" still speeds up its products)
+        with ops.conv_precision("fp32" if self.conv_precision == "bf16" else self.conv_precision):
             return self._run_bg_impl(*a, **k)
 
     def run_src_decode(self, *a, **k):
@@ -355,8 +376,8 @@ class AttentionLWBGenerator(nn.Module):
         bs, ns, c, h, w = src_inputs.shape
         src8 = ops.nchw_to_nhwc(src_inputs.reshape(bs * ns, c, h, w).contiguous().float(), c_pad=8)
         feats = self.encode_sources(src8, batched=bs > 1, ns=ns)
-        enc = _FeatList(ops.nhwc_to_nchw(t) for t in feats.enc)
-        res = _FeatList(ops.nhwc_to_nchw(t) for t in feats.res)
+        enc = _FeatList(ops.nhwc_to_nchw(t.float()) for t in feats.enc)
+        res = _FeatList(ops.nhwc_to_nchw(t.float()) for t in feats.res)
         enc.lwg_cache = res.lwg_cache = feats
         if only_enc:
             return enc, res
@@ -368,8 +389,9 @@ class AttentionLWBGenerator(nn.Module):
         if cache is not None and getattr(src_res_outs, "lwg_cache", None) is cache:
             return cache
         pk = self.packed()
-        enc = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_enc_outs]
-        res = [ops.nchw_to_nhwc(t.contiguous().float()) for t in src_res_outs]
+        adt = self._act_dtype()
+        enc = [ops.nchw_to_nhwc(t.contiguous().float()).to(adt) for t in src_enc_outs]
+        res = [ops.nchw_to_nhwc(t.contiguous().float()).to(adt) for t in src_res_outs]
         n = enc[0].shape[0]
         return SourceFeatures(enc, res, self._project_sources(pk, enc, res), n // bs, batched=bs > 1)
 

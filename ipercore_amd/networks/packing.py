@@ -104,6 +104,25 @@ def pack_head(w_img, w_att):
     return w.permute(2, 3, 1, 0).reshape(25, w.shape[1], 4).contiguous()
 
 
+def pack_head_bf16(w_img, w_att):
+    """tsf_img_reg (3,64,5,5) + tsf_att_reg (1,64,5,5) -> the bf16 MFMA operand panel of csrc/bf16_ops.hip lwg_head_bf16_kernel:
+    [ky 5][pass 2][channel half 2][lane 64][8]; lane l holds row (l % 16) = 4 * tap + output and channels half*32 + 8*(l // 16) + e;
+    pass 0: taps kx = 0..3; pass 1: tap kx = 4 in rows 0..3, rows 4..15 zero."""
+    w = torch.cat([w_img.detach().float(), w_att.detach().float()], dim=0).cpu()  # (4 outputs, 64, 5, 5); a 12.8 KB table: built on the host
+    assert w.shape == (4, 64, 5, 5), w.shape
+    out = w.new_zeros(5, 2, 2, 64, 8)
+    lane = torch.arange(64)
+    row, koct = lane % 16, lane // 16
+    tap, o = row // 4, row % 4
+    for ky in range(5):
+        for ch in range(2):
+            for e in range(8):
+                c = ch * 32 + koct * 8 + e
+                out[ky, 0, ch, :, e] = w[o, c, ky, tap]
+                out[ky, 1, ch, :, e] = torch.where(tap == 0, w[o, c, ky, 4], torch.zeros(()))
+    return out.contiguous().to(torch.bfloat16)
+
+
 def spec_to(spec, device):
     spec.w = spec.w.to(device)
     if spec.bias is not None:

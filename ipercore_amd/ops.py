@@ -26,8 +26,8 @@ def _ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
-# "fp32": native fp32 MFMA.  "bf16": convs with Cin % 32 == 0 run on the bf16-operand MFMA kernel (operands ROUNDED to bf16,
-# fp32 accumulation).  "split": the same convs run on the bf16x6 kernel - both operands split EXACTLY into three bf16 parts,
+# "fp32": native fp32 MFMA.  "bf16": the engine keeps every activation tensor in bf16 and the convs with Cin % 64 == 0 run on the bf16
+# MFMA kernel (dispatch is by tensor dtype: ops.conv2d on bf16 tensors; this flag tells the generator what to allocate).  "split": the same convs run on the bf16x6 kernel - both operands split EXACTLY into three bf16 parts,
 # six bf16 MFMAs per fp32 product, fp32 accumulation: fp32-level accuracy at 0.375 of the native matrix-pipe time.
 CONV_PRECISION = "fp32"
 
@@ -57,7 +57,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16", "_w16x3")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16v3", "_w16x3")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -67,7 +67,8 @@ class ConvSpec:
         self.dy = [int(t[0]) for t in taps]
         self.dx = [int(t[1]) for t in taps]
         self.stride, self.omul, self.ooy, self.oox = stride, omul, ooy, oox
-        self._w16 = None
+        self._w16v2 = None
+        self._w16v3 = None
         self._w16x3 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
@@ -76,13 +77,39 @@ class ConvSpec:
             self.cshift = q.bit_length() - 1
 
 
-def _w16(spec):
-    """The bf16 panel [K/8][N][8] of a spec (same K order as the fp32 panel [K/4][N][4]), built once."""
-    if spec._w16 is None or spec._w16.device != spec.w.device:
+def _w16v2(spec):
+    """The bf16 panel of lwg_conv2d_nhwc_bf16, built once per spec from the fp32 panel [K/4][N][4] (K order: 32-channel chunk major,
+    tap minor): [ntaps*Cin/64][N][64] with k = ((c/64)*ntaps + tap)*64 + c%64, the eight 16-byte k-octets of row n stored at slot
+    octet ^ ((n >> 1) & 7) (include/lwg_hip.h)."""
+    if spec._w16v2 is None or spec._w16v2.device != spec.w.device:
         K4, N, _ = spec.w.shape
-        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
-        spec._w16 = wk.view(K4 // 2, 8, N).permute(0, 2, 1).contiguous().to(torch.bfloat16)
-    return spec._w16
+        cin, nt = spec.Cin, spec.ntaps
+        assert cin % 64 == 0 and K4 * 4 == nt * cin, (cin, nt, K4)
+        wk = spec.w.permute(0, 2, 1).reshape(cin // 64, 2, nt, 32, N)             # [c64][half][tap][c%32][n]
+        wk = wk.permute(0, 2, 1, 3, 4).reshape(cin // 64 * nt, 64, N)              # [kstep][k%64][n]
+        rows = wk.permute(0, 2, 1).reshape(cin // 64 * nt, N, 8, 8)                # [kstep][n][octet][8]
+        n = torch.arange(N, device=spec.w.device)
+        slot = torch.arange(8, device=spec.w.device)
+        src = slot[None, :] ^ ((n[:, None] >> 1) & 7)                              # octet stored at slot s of row n
+        rows = torch.gather(rows, 2, src[None, :, :, None].expand(rows.shape[0], N, 8, 8))
+        spec._w16v2 = rows.reshape(cin // 64 * nt, N, 64).contiguous().to(torch.bfloat16)
+    return spec._w16v2
+
+
+def _w16v3(spec):
+    """The bf16 panel of lwg_conv2d_nhwc_bf16_p4: [ntaps*Cin/32][N][32] in the fp32 panel's K order, octet slots permuted by
+    (n >> 2) & 3 (include/lwg_hip.h)."""
+    if spec._w16v3 is None or spec._w16v3.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        rows = spec.w.permute(0, 2, 1).reshape(K4 // 8, 32, N).permute(0, 2, 1).reshape(K4 // 8, N, 4, 8)     # [kstep][n][octet][8]
+        n = torch.arange(N, device=spec.w.device)
+        src = torch.arange(4, device=spec.w.device)[None, :] ^ ((n[:, None] >> 2) & 3)
+        rows = torch.gather(rows, 2, src[None, :, :, None].expand(rows.shape[0], N, 4, 8))
+        spec._w16v3 = rows.reshape(K4 // 8, N, 32).contiguous().to(torch.bfloat16)
+    return spec._w16v3
+
+
+BF16_PIPE4 = False      # lab switch: route N % 128 == 0 bf16 convolutions to the four-stage BK = 32 variant
 
 
 def _w16x3(spec):
@@ -110,16 +137,19 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
     else:
         OH, OW = out_hw
     a = _lib.LwgConvArgs()
-    a.x0, a.x1 = _ptr(x0), _ptr(x1)
+    xdt, ydt = x0.dtype, y.dtype
+    a.xdt = _lib.DT_BF16 if xdt == torch.bfloat16 else _lib.DT_F32
+    a.ydt = _lib.DT_BF16 if ydt == torch.bfloat16 else _lib.DT_F32
+    a.x0, a.x1 = _ptr(x0, xdt), _ptr(x1, xdt)
     a.C0, a.C1 = C0, C1
     a.B, a.H, a.W = B, H, W
     a.OH, a.OW, a.M = OH, OW, B * OH * OW
     a.stride, a.ntaps, a.cshift = spec.stride, spec.ntaps, spec.cshift
     a.w, a.N, a.bias = _ptr(spec.w), spec.N, _ptr(spec.bias)
-    a.y, a.YH, a.YW, a.YC, a.ycoff = _ptr(y), YH, YW, YC, ycoff
+    a.y, a.YH, a.YW, a.YC, a.ycoff = _ptr(y, ydt), YH, YW, YC, ycoff
     a.omul, a.ooy, a.oox = spec.omul, spec.ooy, spec.oox
     a.epi, a.act = epi, act
-    a.res, a.xn, a.mean, a.rstd = _ptr(res), _ptr(xn), _ptr(mean), _ptr(rstd)
+    a.res, a.xn, a.mean, a.rstd = _ptr(res, ydt), _ptr(xn, ydt), _ptr(mean), _ptr(rstd)
     for i in range(spec.ntaps):
         a.dy[i] = spec.dy[i]
         a.dx[i] = spec.dx[i]
@@ -134,9 +164,19 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec, epi)
-    if CONV_PRECISION == "bf16" and spec.Cin % 32 == 0:
-        a.w = _ptr(_w16(spec), torch.bfloat16)
-        _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16mma(a, _stream()), "lwg_conv2d_nhwc_bf16mma")
+    if x0.dtype == torch.bfloat16:
+        # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
+        if y.dtype != torch.bfloat16 or spec.Cin % 64 != 0:
+            raise ValueError("bf16 convolutions need bf16 outputs and Cin % 64 == 0")
+        if BF16_PIPE4 and spec.N % 128 == 0:
+            a.w = _ptr(_w16v3(spec), torch.bfloat16)
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16_p4(a, _stream()), "lwg_conv2d_nhwc_bf16_p4")
+        else:
+            a.w = _ptr(_w16v2(spec), torch.bfloat16)
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16(a, _stream()), "lwg_conv2d_nhwc_bf16")
+    elif y.dtype == torch.bfloat16:
+        # the first layer of a network in bf16 mode: fp32 image-like input (Cin < 32) on the fp32 kernel, bf16 output
+        _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
@@ -158,6 +198,10 @@ def instnorm_stats(x, mean, rstd, ws, eps=1e-5, nsplit=None):
     if nsplit is None:
         nsplit = max(1, min(64, HW // 64))
     assert ws.numel() >= B * C * nsplit * 3
+    if x.dtype == torch.bfloat16:
+        _lib.check(_lib.lib().lwg_instnorm_stats_nhwc_bf16(_ptr(x, torch.bfloat16), B, HW, C, eps, _ptr(mean), _ptr(rstd), _ptr(ws), nsplit,
+                                                            _stream()), "lwg_instnorm_stats_nhwc_bf16")
+        return
     _lib.check(_lib.lib().lwg_instnorm_stats_nhwc_f32(_ptr(x), B, HW, C, eps, _ptr(mean), _ptr(rstd), _ptr(ws), nsplit,
                                                        _stream()), "lwg_instnorm_stats_nhwc_f32")
 
@@ -174,6 +218,11 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     ns = T.shape[1]
     S = T.shape[2]
     assert T.shape[0] == B and Ks.shape[0] == (B * ns if src_batched else ns) and tuple(Ks.shape[1:]) == (h, w, C)
+    if q.dtype == torch.bfloat16:
+        bf = torch.bfloat16
+        _lib.check(_lib.lib().lwg_lwb_attention_bf16(_ptr(q, bf), _ptr(Ks, bf), _ptr(Vs, bf), _ptr(bk), _ptr(bv), _ptr(T), _ptr(out, bf), B, ns, h,
+                                                      w, C, S, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_bf16")
+        return out
     _lib.check(_lib.lib().lwg_lwb_attention_f32(_ptr(q), _ptr(Ks), _ptr(Vs), _ptr(bk), _ptr(bv), _ptr(T), _ptr(out), B, ns, h,
                                                  w, C, S, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_f32")
     return out
@@ -283,6 +332,10 @@ def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
     if bg is not None and bg.shape[0] != 1:
         assert bg.shape[0] == B
         bstride = 3 * S * S
+    if x.dtype == torch.bfloat16:                    # wpk: packing.pack_head_bf16
+        _lib.check(_lib.lib().lwg_head_compose_bf16(_ptr(x, torch.bfloat16), _ptr(wpk, torch.bfloat16), _ptr(bg), bstride, B, S, C, _ptr(pred),
+                                                     _ptr(mask), _ptr(img), _stream()), "lwg_head_compose_bf16")
+        return pred, mask, img
     _lib.check(_lib.lib().lwg_head_compose_f32(_ptr(x), _ptr(wpk), _ptr(bg), bstride, B, S, C, _ptr(pred), _ptr(mask), _ptr(img),
                                                 _stream()), "lwg_head_compose_f32")
     return pred, mask, img

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/lwg_hip.h but not exported"
     assert set(_lib._SIGS) == set(names)
-    assert _lib.lib().lwg_abi_version() == 1
+    assert _lib.lib().lwg_abi_version() == 2
     assert _lib.lib().lwg_rasterize_ws_bytes(2, 13776, 512) == 2 * 13776 * 88 + 2 * 64 * 4 + 2 * 64 * 13776 * 4
 
 
@@ -65,7 +65,22 @@ def test_invalid_arguments_are_rejected_on_the_host():
     a.ntaps = 99
     assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # more taps than LWG_MAX_TAPS
     a.ntaps, a.C0 = 9, 24
-    assert L.lwg_conv2d_nhwc_bf16mma(a, None) == 1 and L.lwg_conv2d_nhwc_f32_split(a, None) == 1    # Cin % 32 != 0
+    assert L.lwg_conv2d_nhwc_f32_split(a, None) == 1                                                 # Cin % 32 != 0
+    a.C0 = 64
+    assert L.lwg_conv2d_nhwc_bf16(a, None) == 1                                                      # fp32 tensors handed to the bf16 kernel
+    a.xdt = a.ydt = _lib.DT_BF16
+    a.C0 = 96
+    assert L.lwg_conv2d_nhwc_bf16(a, None) == 1                                                      # Cin % 64 != 0
+    a.C0, a.YC = 64, 68
+    assert L.lwg_conv2d_nhwc_bf16(a, None) == 1                                                      # YC % 8 != 0 (16-byte bf16 stores)
+    a.YC, a.xdt = 64, _lib.DT_F32
+    a.epi = 1
+    a.res = bad
+    assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                                       # fp32 -> bf16 is EPI_NONE only
+    a.epi, a.res, a.ydt = 0, None, _lib.DT_F32
+    assert L.lwg_lwb_attention_bf16(bad, bad, bad, bad, bad, bad, bad, 1, 2, 8, 8, 32, 8, 0, None) == 1  # C = 32 is fp32-only
+    assert L.lwg_instnorm_stats_nhwc_bf16(bad, 1, 64, 96, 1e-5, bad, bad, bad, 4, None) == 1          # C not in {64,128,256}
+    assert L.lwg_head_compose_bf16(bad, bad, None, 0, 1, 64, 128, None, bad, None, None) == 1         # C != 64
     assert L.lwg_lwb_attention_f32(bad, bad, bad, bad, bad, bad, bad, 1, 2, 8, 8, 48, 8, 0, None) == 1   # C not in {32,64,128,256}
     assert L.lwg_lwb_attention_bwd_f32(bad, bad, bad, bad, bad, bad, bad, bad, bad, bad, 1, 9, 8, 8, 64, 8, 0, None) == 1   # ns > 8
     assert L.lwg_lwb_fuse_f32(bad, None, None, bad, bad, 1, 2, 8, 8, 64, 8, 0, 1.0, 1.0, None) == 1       # NULL sources
