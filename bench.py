@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide)
 PEAK_HBM_TBS = 8.0
+FB_512 = {"fp32": 16, "split": 16, "bf16": 32}      # default frame batch at 512x512 per precision mode (scaled by (512 / size)^2)
 
 
 class ConvTimer:
@@ -61,9 +62,10 @@ class ConvTimer:
             self.flops += 2.0 * M * spec.algo_kn
             # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
             out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
-            self.bytes += float(act_bytes) * (M * spec.stride ** 2 * spec.Cin + out + (M * spec.N if epi == 1 else 0)) + \
+            nbytes = float(act_bytes) * (M * spec.stride ** 2 * spec.Cin + out + (M * spec.N if epi == 1 else 0)) + \
                 float(act_bytes) * spec.w.numel()
-            self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn))
+            self.bytes += nbytes
+            self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn, nbytes))
 
     def result(self):
         """(busy ms, flops, launches, mean launch ms).  busy = length of the UNION of the launches' [start, stop] intervals
@@ -83,6 +85,20 @@ class ConvTimer:
         busy += cur_e - cur_s
         mean = sum(e0 - s0 for s0, e0 in iv) / len(iv)
         return busy, self.flops, len(self.pairs), mean
+
+    def governing(self, peak_tflops, peak_tbs=PEAK_HBM_TBS):
+        """Fraction of the GOVERNING roof, launch by launch: a launch's roof time is max(flops / matrix peak, algorithmic bytes / HBM
+        peak) - the 1x1 and up-sampling layers of the bf16 mode are HBM-bound, the 3x3 layers matrix-bound; sum of roof times over
+        sum of measured times.  Also the share of the measured time spent in HBM-governed launches."""
+        roof = meas = hbm_meas = 0.0
+        for (a, b), m in zip(self.pairs, self.meta):
+            t_mfma, t_hbm = m[6] / (peak_tflops * 1e12), m[7] / (peak_tbs * 1e12)
+            dt = a.elapsed_time(b) * 1e-3
+            roof += max(t_mfma, t_hbm)
+            meas += dt
+            if t_hbm > t_mfma:
+                hbm_meas += dt
+        return (roof / meas, hbm_meas / meas) if meas > 0 else (0.0, 0.0)
 
     def breakdown(self):
         """Per distinct conv shape: launches, total ms, achieved TFLOP/s (algorithmic flops / event time)."""
@@ -325,7 +341,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
     from ipercore_amd import ops, synthetic as syn
     S, n = 1024, 180
     case = syn.build_case(image_size=S, n_frames=1, ns=2)
-    FB = 2
+    FB = 8
     im = syn.make_imitator(case, frame_batch=FB, device=dev)
     im.generator.conv_precision = "bf16"
     im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
@@ -336,7 +352,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
         for _ in range(W):
             im.synthesize(tgt, "smooth")
         timer.reset()
-        timer.enabled, ops.CONV_HOOK = True, timer
+        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0: timer(b, M, spec, epi, 2))     # bf16 tensors: 2 bytes per element
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
@@ -347,13 +363,29 @@ def novel_view_1024_bf16(dev, timer, W, K):
         assert torch.isfinite(video).all()
         conv_ms, conv_flops, n_launch, mean_ms = timer.result()
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        gov, hbm_share = timer.governing(PEAK_BF16_MFMA_TFLOPS)
+        nbytes_launch = timer.bytes / max(n_launch, 1)
+        timer.enabled, ops.CONV_HOOK = False, None
+        prev_streams, im.streams = im.streams, 3             # the same clip with three frame batches in flight on HIP streams
+        try:
+            im.synthesize(tgt, "smooth")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                im.synthesize(tgt, "smooth")
+            torch.cuda.synchronize()
+            piped = K * n / (time.perf_counter() - t1)
+        finally:
+            im.streams = prev_streams
         return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": FB, "image_size": S,
+                "pipelined_3_streams_frames_per_s": round(piped, 2),
                 "dtype": "bf16 MFMA operands + bf16 activation storage, f32 accumulation / renderer",
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
                              "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 1),
-                             "algorithmic_bytes_per_launch": round(timer.bytes / max(n_launch, 1), 1),
-                             "hbm_time_at_peak_us_per_launch": round(timer.bytes / max(n_launch, 1) / (PEAK_HBM_TBS * 1e12) * 1e6, 2),
+                             "algorithmic_bytes_per_launch": round(nbytes_launch, 1),
+                             "hbm_time_at_peak_us_per_launch": round(nbytes_launch / (PEAK_HBM_TBS * 1e12) * 1e6, 2),
+                             "frac_of_governing_roof": round(gov, 4), "share_of_conv_time_in_hbm_governed_launches": round(hbm_share, 4),
                              "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
     finally:
         ops.CONV_HOOK = hook
@@ -372,8 +404,8 @@ def main():
                     help="clip: a step = the whole clip, frame-sharded over the ranks (strong scaling, the default); batch: a step = one "
                          "frame batch per rank (weak scaling, the round-1 measurement)")
     ap.add_argument("--frame-batch", type=int, default=0,
-                    help="frames per launch batch; 0 = 8 at 512x512 scaled by (512/size)^2 (the 64x64-feature layers need "
-                         ">= 32768 GEMM rows to give every CU two 128x128 tiles), clamped to [2, 64]")
+                    help="frames per launch batch; 0 = 16 (fp32) / 32 (bf16) at 512x512 scaled by (512/size)^2, clamped to [2, 64]: "
+                         "measured 456 / 471 / 475 frames/s at 8 / 16 / 24 (fp32, 512x512)")
     ap.add_argument("--gather-dtype", choices=("f32", "u8"), default="f32",
                     help="N > 1: exchange the (n,3,S,S) fp32 video the reference returns, or the (n,S,S,3) uint8 video its PNG writer "
                          "consumes (device-side conversion; a quarter of the bytes on the xGMI ring)")
@@ -414,7 +446,10 @@ def main():
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
     S = args.size
-    FB = args.frame_batch or max(2, min(64, int(round(8 * (512.0 / S) ** 2))))
+    # frames per launch batch: fp32 - 16 at 512x512 (the 64x64-feature layers then have 65536 GEMM rows = two rounds of 128x128 tiles
+    # per CU, so one round's prologue / epilogue runs under the other's K loop); bf16 - 8 at 1024x1024 (32 at 512x512): the 8-wave
+    # 256x256-tile kernel needs >= 65536 rows to give every CU a tile
+    FB = args.frame_batch or max(2, min(64, int(round((FB_512[args.precision]) * (512.0 / S) ** 2))))
     K, W = args.steps, args.warmup
     clip = args.mode == "clip"
     n_clip = args.frames or (180 if args.workload == "novel_view" else 300)
@@ -546,6 +581,9 @@ def main():
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
             if args.precision == "bf16":
                 line["roofline"]["hbm_time_at_peak_us_per_launch"] = round(timer.bytes / n_launch / (PEAK_HBM_TBS * 1e12) * 1e6, 2)
+                gov, hbm_share = timer.governing(PEAK_BF16_MFMA_TFLOPS)
+                line["roofline"]["frac_of_governing_roof"] = round(gov, 4)
+                line["roofline"]["share_of_conv_time_in_hbm_governed_launches"] = round(hbm_share, 4)
         if args.conv_breakdown and n_launch:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "conv_breakdown.json"), "w") as fp:

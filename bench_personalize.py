@@ -86,12 +86,14 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         return orig_u(x0, spec, dy, *a, **kw)
     # the algorithmic conv flops of a step are counted on ONE eager step (forward + dgrad launches through the hook, the weight
     # gradients through the wrappers: same 2*M*K*N), outside the timed region - a replayed graph makes no Python calls to count
-    prev_hook = ops.CONV_HOOK
+    prev_hook, want_graph = ops.CONV_HOOK, getattr(tr.opts, "use_graph", False)
     ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = hook, counted_wgrad, counted_wgrad_unpacked
+    tr.opts.use_graph = False                  # the counting step runs eager (a capture would run - and count - its warm-up steps too)
     try:
         tr.optimize_parameters()
     finally:
         ops.CONV_HOOK, ops.conv2d_wgrad, ops.conv2d_wgrad_unpacked = prev_hook, orig, orig_u
+        tr.opts.use_graph = want_graph
     per_step = flops[0] + wg[0]
     for _ in range(warmup):
         tr.optimize_parameters()

@@ -85,10 +85,13 @@ int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stre
  * ds_read_b128 on 128-byte rows).  The first layer of a network (fp32 image-like input, Cin < 32) runs lwg_conv2d_nhwc_f32 with
  * ydt = LWG_DT_BF16 (LWG_EPI_NONE only): fp32 in, bf16 out. */
 int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
-/* The deep-pipeline form of the same convolution (BK = 32, four LDS stages, counted vmcnt): N % 128 == 0, Cin % 32 == 0 and
- * args->w = the bf16 panel [ntaps*Cin/32][N][32] with k = ((c/32)*ntaps + tap)*32 + c%32 (the fp32 panel's K order), the four
- * 16-byte k-octets of row n at slot  octet ^ ((n >> 2) & 3). */
-int lwg_conv2d_nhwc_bf16_p4(const LwgConvArgs* args, lwg_stream_t stream);
+/* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches with N % 128 == 0, as the
+ * halo-tile kernel with register-streamed weights: args->w = the bf16 panel [ntaps*Cin/64][4][N][16] - element
+ * [step][ks][n][e] = weight of GEMM column n at k = step*64 + ks*16 + e (k order as above) - and, for LWG_EPI_SPADE, columns
+ * (and args->bias) interleaved gamma | beta in blocks of 16: column 32q + r is gamma of channel 16q + r (r < 16) or beta of
+ * channel 16q + r - 16. */
+int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* args, lwg_stream_t stream);
+
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs
  * per fp32 product, fp32 accumulation; dropped terms < 2^-23 |a b|.  Same contract and restrictions as the bf16 entry point. */
@@ -124,6 +127,10 @@ int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const
                           float* ws, lwg_stream_t stream);
 int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t,
                       lwg_stream_t stream);
+/* The same update with the step count kept on the device (*t_dev is incremented, then read): what a captured (hipGraph) training step
+ * must use, because a host-side step count would be frozen into the graph. */
+int lwg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                          int* t_dev, lwg_stream_t stream);
 /* Weight panels straight from the parameter tensors, one launch each (the personalization step re-packs every weight and
  * un-packs every weight gradient every step).  w (D0, D1, KH, KW) contiguous; kidx[tap] = ky*KW + kx of the weight slice a GEMM
  * tap reads; transposed = 0: value = w[n][c][kidx] (Conv2d forward, ConvTranspose2d data gradient), 1: w[c][n][kidx]

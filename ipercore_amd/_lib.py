@@ -46,7 +46,7 @@ _SIGS = {
     "lwg_conv2d_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
-    "lwg_conv2d_nhwc_bf16_p4": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
@@ -56,6 +56,7 @@ _SIGS = {
     "lwg_norm_fwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_norm_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
     "lwg_adam_step_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_f]),
+    "lwg_adam_step_dev_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "lwg_pack_panel_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),
     "lwg_unpack_wgrad_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),
     "lwg_maxpool2_fwd_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

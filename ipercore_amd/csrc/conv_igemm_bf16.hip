@@ -43,9 +43,12 @@ __device__ __forceinline__ float lwg_bf16_lo(unsigned u) { return __builtin_bit_
 __device__ __forceinline__ float lwg_bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
 // D^T accumulator tiles -> bf16 NHWC with the fused epilogue (shared by the kernel variants below).
-template <int TM, int TN, int EPI>
+// SPATIAL = false: GEMM row m_base + r is output position (b, oy, ox) in row-major order.  SPATIAL = true (the halo-tile kernel):
+// the workgroup's 128 rows are the 8 x 16 pixel block whose corner (image tb, row ty0, column tx0) the caller passes; row r is
+// pixel (ty0 + r / 16, tx0 + r % 16) and rows outside the image are dead.
+template <int TM, int TN, int EPI, bool SPATIAL = false>
 __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
-                                                  int lane) {
+                                                  int lane, int tb = 0, int ty0 = 0, int tx0 = 0) {
     const int khalf = lane >> 5;
     const int HW = a.OH * a.OW;
     // ---- epilogue: D^T tiles -> bf16 NHWC.  acc[i][j][4*g + c] = pixel (lane & 31) of row tile i, channel 8*g + 4*khalf + c of
@@ -91,22 +94,63 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
     };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m_base + wm * TM * 32 + i * 32 + (lane & 31);
-        const bool live = m < a.M;
-        const int mm = live ? m : 0;
-        size_t opix = (size_t)mm;
+        bool live;
+        size_t opix;
         int bimg = 0;
-        if (!direct || EPI == LWG_EPI_SPADE) {
-            const int b = mm / HW;
-            bimg = b;
-            if (!direct) {
-                const int rem = mm - b * HW;
-                const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+        if (SPATIAL) {
+            const int r = wm * TM * 32 + i * 32 + (lane & 31);
+            const int oy = ty0 + (r >> 4), ox = tx0 + (r & 15);
+            live = oy < a.OH && ox < a.OW;
+            bimg = tb;
+            opix = live ? ((size_t)tb * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox) : 0;
+        } else {
+            const int m = m_base + wm * TM * 32 + i * 32 + (lane & 31);
+            live = m < a.M;
+            const int mm = live ? m : 0;
+            opix = (size_t)mm;
+            if (!direct || EPI == LWG_EPI_SPADE) {
+                const int b = mm / HW;
+                bimg = b;
+                if (!direct) {
+                    const int rem = mm - b * HW;
+                    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                    opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+                }
             }
         }
-        if (EPI == LWG_EPI_SPADE) {
-            static_assert(EPI != LWG_EPI_SPADE || TN == 2, "SPADE epilogue needs gamma|beta in one wave");
+        if (EPI == LWG_EPI_SPADE && TN == 1) {
+            // register-streamed-weights kernel: a wave owns ONE 32-column tile = gamma | beta of 16 output channels (the host
+            // interleaves the SPADE panel in blocks of 16 for it): D^T groups g = 0, 1 are gamma of channels 8g + 4*khalf + c,
+            // groups 2, 3 beta of the same channels
+            const int chb = (n_base + wn * 32) >> 1;                // first of the wave's 16 output channels
+            uintx2 xv[2] = {{0u, 0u}, {0u, 0u}};
+            if (live) {
+                xv[0] = *reinterpret_cast<const uintx2*>(xnb + opix * a.YC + chb + 4 * khalf);
+                xv[1] = *reinterpret_cast<const uintx2*>(xnb + opix * a.YC + chb + 8 + 4 * khalf);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int ch = chb + 8 * g + 4 * khalf;
+                const floatx4 mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)bimg * a.YC + ch);
+                const floatx4 rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)bimg * a.YC + ch);
+                const floatx4 bg4 = *reinterpret_cast<const floatx4*>(a.bias + n_base + wn * 32 + 8 * g + 4 * khalf);
+                const floatx4 bb4 = *reinterpret_cast<const floatx4*>(a.bias + n_base + wn * 32 + 16 + 8 * g + 4 * khalf);
+                const float xf[4] = {lwg_bf16_lo(xv[g][0]), lwg_bf16_hi(xv[g][0]), lwg_bf16_lo(xv[g][1]), lwg_bf16_hi(xv[g][1])};
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gm = acc[i][0][4 * g + c] + bg4[c];
+                    const float bt = acc[i][0][4 * (g + 2) + c] + bb4[c];
+                    o[c] = lwg_act((xf[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
+                }
+                if (live) {
+                    uintx2 pk;
+                    pk[0] = lwg_pack_bf16x2(o[0], o[1]);
+                    pk[1] = lwg_pack_bf16x2(o[2], o[3]);
+                    *reinterpret_cast<uintx2*>(yb + opix * a.YC + ch) = pk;
+                }
+            }
+        } else if (EPI == LWG_EPI_SPADE) {
             // wave columns [0,32) = gamma, [32,64) = beta of the same 32 output channels
             const int chb = (n_base + wn * TN * 32) >> 1;           // first of the wave's 32 output channels
             float xf[4][4], o[4][4];
@@ -121,7 +165,7 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float gm = acc[i][0][4 * g + c] + bg4[c];
-                    const float bt = acc[i][1][4 * g + c] + bb4[c];
+                    const float bt = acc[i][TN - 1][4 * g + c] + bb4[c];
                     o[g][c] = lwg_act((xf[g][c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
                 }
             }
@@ -147,12 +191,13 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool DMA_A>
-__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_kernel(const LwgConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 : 1) void lwg_conv_bf16_kernel(const LwgConvArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;                    // waves per workgroup: 4 (128 x 128 / 128 x 64 tiles) or 8 (256 x 256)
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;    // bytes: [row][64 bf16]
-    constexpr int PA = BM / 32;                              // 8-row DMA pieces per wave per K-step (A)
-    constexpr int PB = BN / 32;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int PA = BM / (8 * NW);                        // 8-row DMA pieces per wave per K-step (A)
+    constexpr int PB = BN / (8 * NW);
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
 
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* As = smem_c;
@@ -332,123 +377,92 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_kernel(const LwgConvArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Deep-pipeline variant: BK = 32 per stage, FOUR LDS stages (the same 64 KB per 128 x 128 tile, two workgroups per CU), the
-// DMA of K-step t+3 issued while step t computes.  One barrier per step does both jobs: "everyone's stage-t pieces have landed"
-// (each wave first waits for its OWN pieces with a counted s_waitcnt vmcnt(N) that leaves the younger stages' DMAs in flight -
-// never vmcnt(0) inside the loop) and "everyone is done reading stage t-1", which is the stage the new DMAs overwrite.
-// LDS image: [row][32 bf16] = 64-byte rows; k-octet o of row r sits at slot o ^ ((r >> 2) & 3) (conflict-free ds_read_b128 for
-// 64-byte rows); a DMA piece = 16 rows.  Weight panel: [ntaps*Cin/32][N][32], K order of the fp32 panel (32-channel chunk major,
-// tap minor), slots permuted the same way (ops._w16v3).
-#define LWG_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// Halo-tile variant for the stride-1 convolutions whose taps lie in [-1, 1]^2 (every 3x3 conv of the generator and the 2x2-tap
+// parity launches of its transposed convs: > 90 % of the flops).  The linear kernel above re-fetches an activation chunk once per
+// tap (9 x for a 3x3 conv) - all L2 hits, but every one of them travels L2 -> LDS again, and that path (about 55 GB/s per CU
+// here, measured) is what bounds the kernel, not the matrix pipe.  Here a workgroup's 128 GEMM rows are an 8 x 16 PIXEL BLOCK of
+// one image: its (8+2) x (16+2) halo, 64 channels deep, is staged ONCE per channel chunk (23 KB by LDS-DMA, out-of-image pixels
+// = out-of-range offsets = zeros) and all taps read their operand fragments from it at shifted pixel positions; only the weight
+// panel of the (chunk, tap) step streams every step.  L2 -> LDS bytes per 3x3 step: 16 KB + 23.5/9 KB instead of 32 KB.
+// LDS image of the halo: [pixel hp = hy*18 + hx][128 B], k-octet o at slot o ^ ((hp >> 1) & 7) (the same rule as the row tiles:
+// a fragment read's 32 lanes are two runs of 16 consecutive halo pixels).  Two halo buffers (chunk c+1 lands while chunk c
+// computes) + two weight stages = 78 KB: two workgroups per CU.
+#define LWG_HALO_W 18
+#define LWG_HALO_PIX 180
+#define LWG_HALO_PIECES 23                 // 8 pixels per DMA piece; the 23rd is half used
+#define LWG_HALO_BYTES (LWG_HALO_PIECES * 1024)
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_kernel4(const LwgConvArgs a) {
+__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_halo_kernel(const LwgConvArgs a) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int NST = 4;
-    constexpr int A_STAGE = BM * 64, B_STAGE = BN * 64;      // bytes: [row][32 bf16]
-    constexpr int PA = BM / 64;                              // 16-row DMA pieces per wave per K-step
-    constexpr int PB = BN / 64;
-    static_assert(WAVES_M * WAVES_N == 4 && PA + PB == 4, "4 waves; the vmcnt thresholds below assume 4 DMA instructions per wave and step");
+    static_assert(BM == 128 && WAVES_M * WAVES_N == 4, "an 8 x 16 pixel block per 4-wave workgroup");
+    constexpr int B_STAGE = BN * 128;
+    constexpr int PB = BN / 32;
+    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;           // halo pieces per wave (the last wave has one fewer)
 
-    extern __shared__ __attribute__((aligned(16))) char smem_d[];
-    char* As = smem_d;
-    char* Bs = smem_d + NST * A_STAGE;
-    int* taptab = reinterpret_cast<int*>(smem_d + NST * A_STAGE + NST * B_STAGE);  // [3][LWG_MAX_TAPS]
+    extern __shared__ __attribute__((aligned(16))) char smem_h[];
+    char* Ah = smem_h;                                       // [2][LWG_HALO_BYTES]
+    char* Bs = smem_h + 2 * LWG_HALO_BYTES;                  // [2][B_STAGE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
     const int tiles_n = a.N / BN;
+    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
     const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = lid % tiles_n, tile_m = lid / tiles_n;
-    const int m_base = tile_m * BM, n_base = tile_n * BN;
+    const int tile_n = lid % tiles_n;
+    int rest = lid / tiles_n;
+    const int tix = rest % tiles_x;
+    rest /= tiles_x;
+    const int tiy = rest % tiles_y, tb = rest / tiles_y;
+    const int x0 = tix * 16, y0 = tiy * 8;
+    const int n_base = tile_n * BN;
 
-    const int HW = a.OH * a.OW;
     const int Cin = a.C0 + a.C1;
-    int pixlin[PA], piy[PA], pix[PA];
-    unsigned long long vmask[PA];
-    const unsigned chunk16 = (unsigned)((lane & 3) ^ (lane >> 4)) * 16u;     // row = piece*16 + lane/4: (row >> 2) & 3 = lane >> 4
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int r = (wid * PA + p) * 16 + (lane >> 2);
-        const int m = m_base + r;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / HW, rem = mm - b * HW;
-        const int oy = rem / a.OW, ox = rem - oy * a.OW;
-        piy[p] = ok ? oy * a.stride : -100000;
-        pix[p] = ox * a.stride;
-        pixlin[p] = (b * a.H + oy * a.stride) * a.W + ox * a.stride;
-        vmask[p] = 0ull;
-    }
-    if (tid < a.ntaps) {
-        const int dy = a.dy[tid], dx = a.dx[tid];
-        taptab[tid] = (dy * a.W + dx) * a.C0 * 2;
-        taptab[LWG_MAX_TAPS + tid] = (dy * a.W + dx) * a.C1 * 2;
-        taptab[2 * LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
-    }
-    __syncthreads();
-    for (int tp = 0; tp < a.ntaps; ++tp) {
-        const int packed = taptab[2 * LWG_MAX_TAPS + tp];
-        const int dy = (int)(short)(packed & 0xffff), dx = packed >> 16;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int iy = piy[p] + dy, ix = pix[p] + dx;
-            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            vmask[p] |= (unsigned long long)ok << tp;
-        }
-    }
-
+    const int nchunks = Cin >> 6;
+    const int nsteps = nchunks * a.ntaps;
     const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
     const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 2u;
-    const int nsteps = a.ntaps * (Cin >> 5);
-    const unsigned wbytes = (unsigned)nsteps * (unsigned)a.N * 64u;
+    const unsigned wbytes = (unsigned)nsteps * (unsigned)a.N * 128u;
 
-    int ld_tap = 0, ld_cc = 0, ld_use1 = 0;
-    unsigned ld_soffA = 0, ld_soffB = 0;
-    const void* ld_src = a.x0;
-    unsigned ld_bytes = bytes0;
-    unsigned pixb[PA], vbase[PA], wvoff[PB];
+    // halo DMA: piece q = wid * PAH + p covers halo pixels q*8 .. q*8+7; this lane: pixel q*8 + lane/8, LDS slot lane & 7
+    int hpixlin[PAH];                 // linear input pixel (b*H + gy)*W + gx, or -1 outside the image / beyond the halo
+    unsigned hoct[PAH];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) wvoff[p] = (unsigned)(n_base * 64 + (wid * PB + p) * 1024 + lane * 16);
-    auto source = [&]() {
-        ld_use1 = ld_cc >= a.C0;
-        const int cs = ld_use1 ? a.C1 : a.C0;
-        ld_src = ld_use1 ? (const void*)a.x1 : (const void*)a.x0;
-        ld_bytes = ld_use1 ? bytes1 : bytes0;
-        ld_soffA = (unsigned)(ld_cc - (ld_use1 ? a.C0 : 0)) * 2u;
+    for (int p = 0; p < PAH; ++p) {
+        const int hp = (wid * PAH + p) * 8 + (lane >> 3);
+        const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
+        hoct[p] = (unsigned)((lane & 7) ^ ((hp >> 1) & 7)) * 16u;
+    }
+    unsigned wvoff[PB];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) pixb[p] = (unsigned)pixlin[p] * (unsigned)cs * 2u + chunk16;
-    };
-    auto tap_rows = [&]() {
-        const int toff = taptab[ld_use1 * LWG_MAX_TAPS + ld_tap];
+    for (int p = 0; p < PB; ++p) wvoff[p] = (unsigned)(n_base * 128 + (wid * PB + p) * 1024 + lane * 16);
+
+    auto issue_halo = [&](int chunk, int buf) {
+        const int cc = chunk << 6;
+        const bool use1 = cc >= a.C0;
+        const void* src = use1 ? (const void*)a.x1 : (const void*)a.x0;
+        const unsigned cs = (unsigned)(use1 ? a.C1 : a.C0);
+        const unsigned soff = (unsigned)(cc - (use1 ? a.C0 : 0)) * 2u;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(use1 ? bytes1 : bytes0), 0x00020000);
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const bool ok = (vmask[p] >> ld_tap) & 1ull;
-            vbase[p] = ok ? pixb[p] + (unsigned)toff : LWG_OOB_OFFSET;
+        for (int p = 0; p < PAH; ++p) {
+            const int q = wid * PAH + p;
+            if (q < LWG_HALO_PIECES) {                                   // wave-uniform
+                const unsigned voff = hpixlin[p] >= 0 ? (unsigned)hpixlin[p] * cs * 2u + hoct[p] : LWG_OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LWG_LDS_PTR(Ah + buf * LWG_HALO_BYTES + q * 1024), 16, (int)voff, (int)soff, 0, 0);
+            }
         }
     };
-    auto advance = [&]() {
-        ld_soffB += (unsigned)a.N * 64u;
-        if (++ld_tap == a.ntaps) {
-            ld_tap = 0;
-            ld_cc += 32;
-            ld_soffA += 64u;
-            if (ld_cc == a.C0 && a.C1 > 0) source();
-        }
-        tap_rows();
-    };
-    auto issue = [&](int buf) {
-        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ld_src), 0, (int)ld_bytes, 0x00020000);
+    auto issue_b = [&](int step, int buf) {
         __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
-#pragma unroll
-        for (int p = 0; p < PA; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LWG_LDS_PTR(As + buf * A_STAGE + (wid * PA + p) * 1024), 16, (int)vbase[p],
-                                                     (int)ld_soffA, 0, 0);
+        const unsigned soffB = (unsigned)step * (unsigned)a.N * 128u;
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LWG_LDS_PTR(Bs + buf * B_STAGE + (wid * PB + p) * 1024), 16, (int)wvoff[p],
-                                                     (int)ld_soffB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LWG_LDS_PTR(Bs + buf * B_STAGE + (wid * PB + p) * 1024), 16, (int)wvoff[p], (int)soffB, 0, 0);
     };
 
     floatx16 acc[TM][TN];
@@ -460,64 +474,285 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_kernel4(const LwgConvArg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int khalf = lane >> 5;
-    const int sw = (lane >> 2) & 3;
-    const char* fr_a = As + (wm * TM * 32 + (lane & 31)) * 64;
-    const char* fr_b = Bs + (wn * TN * 32 + (lane & 31)) * 64;
-    int koff[2];
+    // halo pixel of this lane's GEMM row (row r = pixel (r / 16, r % 16) of the block) for tap (0, 0)
+    int hp0[TM];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) koff[ks] = ((2 * ks + khalf) ^ sw) << 4;
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * TM * 32 + i * 32 + (lane & 31);
+        hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
+    }
+    const int swb = (lane >> 1) & 7;
+    const char* fr_b = Bs + (wn * TN * 32 + (lane & 31)) * 128;
+    int koffb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koffb[ks] = ((2 * ks + khalf) ^ swb) << 4;
 
-    // prologue: the DMAs of steps 0, 1, 2 (the loader state always describes the next step to issue)
-    source();
-    tap_rows();
+    issue_halo(0, 0);
+    issue_b(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    int step = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
+        for (int tap = 0; tap < a.ntaps; ++tap, ++step) {
+            if (step + 1 < nsteps) issue_b(step + 1, (step + 1) & 1);
+            if (tap == 0 && chunk + 1 < nchunks) issue_halo(chunk + 1, (chunk + 1) & 1);
+            const int toff = (int)a.dy[tap] * LWG_HALO_W + (int)a.dx[tap];
+            int abase[TM], asw[TM];
 #pragma unroll
-    for (int pre = 0; pre < NST - 1; ++pre) {
-        if (pre < nsteps) {
-            issue(pre);
-            if (pre + 1 < nsteps) advance();
+            for (int i = 0; i < TM; ++i) {
+                const int h = hp0[i] + toff;
+                abase[i] = h << 7;
+                asw[i] = (h >> 1) & 7;
+            }
+            const char* Bcur = fr_b + (step & 1) * B_STAGE;
+            bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + ((khalf ^ asw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bcur + j * 4096 + koffb[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + (((2 * (ks + 1) + khalf) ^ asw[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bcur + j * 4096 + koffb[ks + 1 < 4 ? ks + 1 : 3]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the next step's pieces have landed
+            __syncthreads();
         }
     }
-    for (int t = 0; t < nsteps; ++t) {
-        // my pieces of stage t have landed when at most the pieces of the (up to two) younger issued steps are outstanding
-        const int younger = nsteps - 1 - t;
-        if (younger >= 2) LWG_WAIT_VM_LGKM0(8);
-        else if (younger == 1) LWG_WAIT_VM_LGKM0(4);
-        else LWG_WAIT_VM_LGKM0(0);
-        // past the barrier: stage t is complete for every wave, and every wave has finished reading stage t-1 = (t+3) % 4
-        if (t + NST - 1 < nsteps) {
-            issue((t + NST - 1) & (NST - 1));
-            if (t + NST < nsteps) advance();
-        }
-        const int cur = t & (NST - 1);
-        bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(fr_a + cur * A_STAGE + i * 2048 + koff[ks]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(fr_b + cur * B_STAGE + j * 2048 + koff[ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-    }
-    lwg_bf16_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
+    lwg_bf16_epilogue<TM, TN, EPI, true>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
-static hipError_t launch_cfg_bf16_4(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr size_t lds = (size_t)4 * (BM + BN) * 64 + 3 * LWG_MAX_TAPS * sizeof(int);
-    auto kern = lwg_conv_bf16_kernel4<WAVES_M, WAVES_N, TM, TN, EPI>;
+static hipError_t launch_cfg_bf16_halo(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr int BN = WAVES_N * TN * 32;
+    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES + (size_t)2 * BN * 128;
+    auto kern = lwg_conv_bf16_halo_kernel<WAVES_M, WAVES_N, TM, TN, EPI>;
     static unsigned long long attr_done = 0ull;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a);
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
     return hipGetLastError();
+}
+
+// the halo-tile kernel applies to: stride 1, same input / output grid, every tap within [-1, 1]^2, at least two taps
+static bool lwg_bf16_halo_ok(const LwgConvArgs& a) {
+    static int on = -1;
+    if (on < 0) {
+        const char* ev = getenv("LWG_BF16_HALO");    // lab knob: 0 = always the linear kernel
+        on = ev ? atoi(ev) : 1;
+    }
+    if (!on || a.stride != 1 || a.ntaps < 2 || a.ntaps > 9 || a.H != a.OH || a.W != a.OW) return false;
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.dy[t] < -1 || a.dy[t] > 1 || a.dx[t] < -1 || a.dx[t] > 1) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Halo tile + register-streamed weights.  The two kernels above put a barrier and a "wait for ALL my outstanding loads" into
+// every K-step, and each step's operands are requested one step ahead: the step time then cannot go below one L2 round trip
+// (~1 us under load, measured: res-block launch = 36 steps x 1.1 us whatever the bytes per step) while its 16 MFMAs need
+// 0.25 us - two workgroups per CU hide part of it (matrix pipe 42 % busy).  This kernel removes both:
+//   * activations: the 8 x 16-pixel block's halo (as above), one buffer per 64-channel chunk, double-buffered, staged THROUGH
+//     REGISTERS (global -> VGPR at the top of a chunk, ds_write at its end: nine steps of latency slack) - one barrier per
+//     chunk, none inside it;
+//   * weights: never in LDS.  Four waves split the 128 columns (wave tile 128 rows x 32 columns, TM = 4, TN = 1: every weight
+//     fragment feeds four MFMAs), each wave loads ITS fragment straight from the packed panel (lane-contiguous 1 KB per load)
+//     into a register ring D steps ahead; the compiler's counted vmcnt waits for exactly the oldest ring slot.
+// No LDS-DMA, no per-step barrier: a wave's K loop is MFMAs + ds_read_b128 + 4 loads per step.  LDS = 46 KB -> three workgroups
+// per CU.  Panel layout: [step = chunk*ntaps + tap][ks 4][N][16] (the two k-octets of MFMA k-step ks); SPADE panels interleave
+// gamma | beta in blocks of 16 columns so one 32-column tile carries both for 16 channels.
+template <int NTAPS, int EPI, int D>
+__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvArgs a) {
+    constexpr int TM = 4;
+    static_assert(NTAPS % D == 0, "the weight ring must close at a chunk boundary");
+    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_r[];
+    char* Ah = smem_r;                                       // [2][LWG_HALO_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = a.N >> 7;
+    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % tiles_n;
+    int rest = lid / tiles_n;
+    const int tix = rest % tiles_x;
+    rest /= tiles_x;
+    const int tiy = rest % tiles_y, tb = rest / tiles_y;
+    const int x0 = tix * 16, y0 = tiy * 8;
+    const int n_base = tile_n * 128;
+
+    const int Cin = a.C0 + a.C1;
+    const int nchunks = Cin >> 6;
+    const int nsteps = nchunks * NTAPS;
+    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
+    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 2u;
+    const unsigned wbytes = (unsigned)nsteps * (unsigned)a.N * 128u;
+
+    int hpixlin[PAH];
+    unsigned hoct[PAH];
+#pragma unroll
+    for (int p = 0; p < PAH; ++p) {
+        const int hp = (wid * PAH + p) * 8 + (lane >> 3);
+        const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
+        hoct[p] = (unsigned)((lane & 7) ^ ((hp >> 1) & 7)) * 16u;
+    }
+    uintx4 hreg[PAH];
+    auto load_halo = [&](int chunk) {
+        const int cc = chunk << 6;
+        const bool use1 = cc >= a.C0;
+        const void* src = use1 ? (const void*)a.x1 : (const void*)a.x0;
+        const unsigned cs = (unsigned)(use1 ? a.C1 : a.C0);
+        const unsigned soff = (unsigned)(cc - (use1 ? a.C0 : 0)) * 2u;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(use1 ? bytes1 : bytes0), 0x00020000);
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            const unsigned voff = hpixlin[p] >= 0 ? (unsigned)hpixlin[p] * cs * 2u + hoct[p] : LWG_OOB_OFFSET;
+            hreg[p] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, (int)soff, 0));
+        }
+    };
+    auto store_halo = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            const int q = wid * PAH + p;
+            if (q < LWG_HALO_PIECES) *reinterpret_cast<uintx4*>(Ah + buf * LWG_HALO_BYTES + q * 1024 + lane * 16) = hreg[p];
+        }
+    };
+
+    const int khalf = lane >> 5;
+    // weight fragments: this wave's 32 columns; lane = column (lane & 31), k-octet khalf of MFMA k-step ks
+    const unsigned wv = (unsigned)((n_base + wid * 32 + (lane & 31)) * 32 + khalf * 16);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
+    bf16x8 bq[D][4];
+    auto load_b = [&](int step, int slot) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bq[slot][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wv, (int)((unsigned)(step * 4 + ks) * (unsigned)a.N * 32u), 0));
+    };
+
+    floatx16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    int hp0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = i * 32 + (lane & 31);
+        hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
+    }
+    int toffs[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) toffs[t] = (int)a.dy[t] * LWG_HALO_W + (int)a.dx[t];
+
+    load_halo(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) load_b(d, d);
+    store_halo(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
+        const bool more = chunk + 1 < nchunks;
+        if (more) load_halo(chunk + 1);                    // lands during this chunk's NTAPS steps
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int step = chunk * NTAPS + tap;
+            const int slot = tap % D;
+            int abase[TM], asw[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int h = hp0[i] + toffs[tap];
+                asm volatile("" : "+v"(h));                // opaque: otherwise the 72 (tap, row tile) addresses are hoisted out of the chunk loop and spill
+                abase[i] = h << 7;
+                asw[i] = (h >> 1) & 7;
+            }
+            bf16x8 fa[2][TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + ((khalf ^ asw[i]) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {                                // the four fragments of k-step ks+1 are in flight during the MFMAs of ks
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + (((2 * (ks + 1) + khalf) ^ asw[i]) << 4));
+                }
+                if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);      // DS reads first ...
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot][ks], fa[ks & 1][i], acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                  // ... then the MFMAs of this k-step
+            }
+            if (step + D < nsteps) load_b(step + D, slot);  // refill the slot just consumed: D steps of lookahead
+            __builtin_amdgcn_sched_barrier(0);             // keep the unrolled taps apart: hoisting every fragment read of a chunk spills
+        }
+        if (more) {
+            store_halo((chunk + 1) & 1);                   // the other buffer: every wave left it at the previous chunk's barrier
+            __syncthreads();
+        }
+    }
+    lwg_bf16_epilogue<TM, 1, EPI, true>(a, acc, 0, n_base, 0, wid, lane, tb, y0, x0);
+}
+
+template <int NTAPS, int EPI, int D>
+static hipError_t launch_cfg_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES;
+    auto kern = lwg_conv_bf16_hr_kernel<NTAPS, EPI, D>;
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / 128);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_epi_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
+    if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3>(a, stream);
+    return launch_cfg_bf16_hr<4, EPI, 2>(a, stream);
+}
+
+// args->w = the register-streamed panel [ntaps*Cin/64][4][N][16] (bias / SPADE columns in the matching order, see above);
+// 3x3 (9 taps) or 2x2 (4 taps) within [-1,1]^2, stride 1, same input / output grid, N % 128 == 0, Cin % 64 == 0.
+extern "C" int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    const int Cin = a.C0 + a.C1;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 4)) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16 || a.stride != 1 || a.H != a.OH || a.W != a.OW) return (int)hipErrorInvalidValue;
+    if (a.N % 128 != 0 || Cin % 64 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0) return (int)hipErrorInvalidValue;
+    if (a.C1 != 0 && (a.C0 % 64 != 0 || !a.x1)) return (int)hipErrorInvalidValue;
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.dy[t] < -1 || a.dy[t] > 1 || a.dx[t] < -1 || a.dx[t] > 1) return (int)hipErrorInvalidValue;
+    const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
+    if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 2ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.ntaps * (Cin / 64) * (unsigned long long)a.N * 128ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if (a.epi == LWG_EPI_SPADE) {
+        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return (int)hipErrorInvalidValue;
+        return (int)launch_epi_bf16_hr<LWG_EPI_SPADE>(a, stream);
+    }
+    if (a.epi == LWG_EPI_RESIDUAL) {
+        if (!a.res) return (int)hipErrorInvalidValue;
+        return (int)launch_epi_bf16_hr<LWG_EPI_RESIDUAL>(a, stream);
+    }
+    if (a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
+    return (int)launch_epi_bf16_hr<LWG_EPI_NONE>(a, stream);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool DMA_A>
@@ -528,7 +763,7 @@ static hipError_t launch_cfg_bf16(const LwgConvArgs& a, hipStream_t stream) {
     static unsigned long long attr_done = 0ull;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WAVES_M * WAVES_N * 64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -539,39 +774,33 @@ static hipError_t launch_epi_bf16(const LwgConvArgs& a, hipStream_t stream) {
         const char* ev = getenv("LWG_BF16_DMA_A");   // lab knob: 0 = A through registers (global -> VGPR -> ds_write), 1 = LDS-DMA
         dma_a = ev ? atoi(ev) : 1;
     }
-    static int force64 = -1;
+    static int force64 = -1, cus = 0;
     if (force64 < 0) {
-        const char* ev = getenv("LWG_BF16_TILE64");  // lab knob: 1 = 128 x 64 tiles (48 KB LDS: 3 workgroups per CU) wherever the epilogue allows
-        force64 = ev ? atoi(ev) : 0;
+        const char* ev = getenv("LWG_BF16_TILE64");  // lab knob: 1 = 128 x 64 tiles wherever the epilogue allows, -1 = never
+        force64 = ev ? atoi(ev) + 2 : 2;             // stored + 2: 1 = never, 2 = heuristic, 3 = always
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
-    if (EPI == LWG_EPI_SPADE || (a.N % 128 == 0 && !force64))
+    // a launch with fewer 128 x 128 tiles than two per CU leaves every CU with ONE resident workgroup - nothing to run while it
+    // waits for its DMA / barrier.  Halving the tile (128 x 64: 48 KB of LDS, three per CU) doubles the workgroups; measured on the
+    // 64^2 x 256 -> 128 SPADE convs (256 tiles): 45 -> 3x us.  Larger launches keep 128 x 128 (more flops per staged byte).
+    if (lwg_bf16_halo_ok(a)) {
+        if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg_bf16_halo<2, 2, 2, 2, EPI>(a, stream);
+        return launch_cfg_bf16_halo<4, 1, 1, 2, EPI>(a, stream);
+    }
+    static int big = -1;
+    if (big < 0) {
+        const char* ev = getenv("LWG_BF16_BIG");     // lab knob: 0 = never use the 8-wave 256 x 256 tile
+        big = ev ? atoi(ev) : 1;
+    }
+    // N % 256 == 0 and at least one 256 x 256 tile per CU: eight waves, wave tile 128 x 64 - six fragment reads per eight MFMAs
+    // instead of four per four (the 4-wave kernel's LDS port is as busy as its matrix pipe)
+    if (big && dma_a && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= (long)cus) return launch_cfg_bf16<2, 4, 4, 2, EPI, true>(a, stream);
+    const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    const bool small = a.N % 128 == 0 && tiles128 < 2L * cus;
+    if (EPI == LWG_EPI_SPADE || (a.N % 128 == 0 && force64 != 3 && !(small && force64 == 2)))
         return dma_a ? launch_cfg_bf16<2, 2, 2, 2, EPI, true>(a, stream) : launch_cfg_bf16<2, 2, 2, 2, EPI, false>(a, stream);
     return dma_a ? launch_cfg_bf16<4, 1, 1, 2, EPI, true>(a, stream) : launch_cfg_bf16<4, 1, 1, 2, EPI, false>(a, stream);
-}
-
-// args->w = the [ntaps*Cin/32][N][32] panel of the deep-pipeline variant (see lwg_conv_bf16_kernel4); N % 128 == 0 only.
-extern "C" int lwg_conv2d_nhwc_bf16_p4(const LwgConvArgs* pa, lwg_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!pa) return (int)hipErrorInvalidValue;
-    const LwgConvArgs& a = *pa;
-    const int Cin = a.C0 + a.C1;
-    if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
-    if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16) return (int)hipErrorInvalidValue;
-    if (a.N % 128 != 0 || Cin % 32 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0) return (int)hipErrorInvalidValue;
-    if (a.C1 != 0 && (a.C0 % 32 != 0 || !a.x1)) return (int)hipErrorInvalidValue;
-    const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
-    if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 2ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
-    if ((unsigned long long)a.ntaps * Cin * (unsigned long long)a.N * 2ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
-    if (a.epi == LWG_EPI_SPADE) {
-        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return (int)hipErrorInvalidValue;
-        return (int)launch_cfg_bf16_4<2, 2, 2, 2, LWG_EPI_SPADE>(a, stream);
-    }
-    if (a.epi == LWG_EPI_RESIDUAL) {
-        if (!a.res) return (int)hipErrorInvalidValue;
-        return (int)launch_cfg_bf16_4<2, 2, 2, 2, LWG_EPI_RESIDUAL>(a, stream);
-    }
-    if (a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
-    return (int)launch_cfg_bf16_4<2, 2, 2, 2, LWG_EPI_NONE>(a, stream);
 }
 
 extern "C" int lwg_conv2d_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t stream_) {

@@ -223,6 +223,41 @@ extern "C" int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, s
     return (int)hipGetLastError();
 }
 
+// The same update with the step count on the DEVICE: *t_dev is incremented by a one-thread launch, then the update reads it and
+// forms the bias corrections itself - so a captured (hipGraph) training step replays with the right t (a host-side t would be
+// frozen into the graph at capture time).
+__global__ void lwg_adam_tick_kernel(int* t_dev) { *t_dev += 1; }
+
+__global__ void lwg_adam_dev_kernel(floatx4* __restrict__ p, const floatx4* __restrict__ g, floatx4* __restrict__ m, floatx4* __restrict__ v,
+                                    size_t n4, float lr, float b1, float b2, float eps, const int* __restrict__ t_dev) {
+    const float t = (float)*t_dev;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step = lr / bc1, isq = 1.f / sqrtf(bc2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        floatx4 pp = p[i], mm = m[i], vv = v[i];
+        const floatx4 gg = g[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            pp[k] -= step * mm[k] / (sqrtf(vv[k]) * isq + eps);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+extern "C" int lwg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                     int* t_dev, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!p || !g || !m || !v || !t_dev || n == 0 || (n & 3)) return (int)hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(lwg_adam_tick_kernel, dim3(1), dim3(1), 0, stream, t_dev);
+    hipLaunchKernelGGL(lwg_adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<floatx4*>(p), reinterpret_cast<const floatx4*>(g),
+                       reinterpret_cast<floatx4*>(m), reinterpret_cast<floatx4*>(v), n4, lr, beta1, beta2, eps, t_dev);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Weight panels straight from the parameter tensors (personalization step: every step re-packs every weight - forward panel,
 // data-gradient panel - and un-packs every weight gradient; as chains of torch view / permute / cat / copy kernels that was

@@ -57,7 +57,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16v3", "_w16x3")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -68,7 +68,7 @@ class ConvSpec:
         self.dx = [int(t[1]) for t in taps]
         self.stride, self.omul, self.ooy, self.oox = stride, omul, ooy, oox
         self._w16v2 = None
-        self._w16v3 = None
+        self._w16hr = None
         self._w16x3 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
@@ -96,20 +96,39 @@ def _w16v2(spec):
     return spec._w16v2
 
 
-def _w16v3(spec):
-    """The bf16 panel of lwg_conv2d_nhwc_bf16_p4: [ntaps*Cin/32][N][32] in the fp32 panel's K order, octet slots permuted by
-    (n >> 2) & 3 (include/lwg_hip.h)."""
-    if spec._w16v3 is None or spec._w16v3.device != spec.w.device:
+def _hr_eligible(spec, x0, y, out_hw):
+    """lwg_conv2d_nhwc_bf16_hr applies to the 3x3 / 2x2-tap stride-1 launches on a shared input / output grid, N % 128 == 0."""
+    if not BF16_HR or spec.stride != 1 or spec.ntaps not in (9, 4) or spec.N % 128 != 0 or spec.Cin % 64 != 0:
+        return False
+    if any(abs(d) > 1 for d in spec.dy) or any(abs(d) > 1 for d in spec.dx):
+        return False
+    OH, OW = ((y.shape[1], y.shape[2]) if spec.omul == 1 else (y.shape[1] // spec.omul, y.shape[2] // spec.omul)) if out_hw is None else out_hw
+    return (OH, OW) == (x0.shape[1], x0.shape[2])
+
+
+def _w16hr(spec, spade):
+    """(panel, bias) of lwg_conv2d_nhwc_bf16_hr: [ntaps*Cin/64][4][N][16] bf16, k = ((c/64)*ntaps + tap)*64 + c%64 split as
+    ks*16 + e; for the SPADE epilogue the gamma | beta columns (and the bias) are re-interleaved from blocks of 32 to blocks of 16
+    (include/lwg_hip.h).  Built once per (spec, spade)."""
+    key = bool(spade)
+    if spec._w16hr is None or spec._w16hr[0] != key or spec._w16hr[1].device != spec.w.device:
         K4, N, _ = spec.w.shape
-        rows = spec.w.permute(0, 2, 1).reshape(K4 // 8, 32, N).permute(0, 2, 1).reshape(K4 // 8, N, 4, 8)     # [kstep][n][octet][8]
-        n = torch.arange(N, device=spec.w.device)
-        src = torch.arange(4, device=spec.w.device)[None, :] ^ ((n[:, None] >> 2) & 3)
-        rows = torch.gather(rows, 2, src[None, :, :, None].expand(rows.shape[0], N, 4, 8))
-        spec._w16v3 = rows.reshape(K4 // 8, N, 32).contiguous().to(torch.bfloat16)
-    return spec._w16v3
+        cin, nt = spec.Cin, spec.ntaps
+        wk = spec.w.permute(0, 2, 1).reshape(cin // 64, 2, nt, 32, N).permute(0, 2, 1, 3, 4).reshape(cin // 64 * nt, 64, N)   # [step][k%64][n]
+        bias = spec.bias
+        if spade:
+            j = torch.arange(N, device=spec.w.device)
+            q, r = j // 32, j % 32
+            ch = 16 * q + (r % 16)
+            old = 64 * (ch // 32) + (ch % 32) + 32 * (r // 16)
+            wk = wk[:, :, old]
+            bias = None if bias is None else bias[old].contiguous()
+        panel = wk.reshape(cin // 64 * nt, 4, 16, N).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+        spec._w16hr = (key, panel, bias)
+    return spec._w16hr[1], spec._w16hr[2]
 
 
-BF16_PIPE4 = False      # lab switch: route N % 128 == 0 bf16 convolutions to the four-stage BK = 32 variant
+BF16_HR = True          # lab switch: False routes every bf16 convolution to lwg_conv2d_nhwc_bf16 (LDS-DMA kernels)
 
 
 def _w16x3(spec):
@@ -168,9 +187,10 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
         if y.dtype != torch.bfloat16 or spec.Cin % 64 != 0:
             raise ValueError("bf16 convolutions need bf16 outputs and Cin % 64 == 0")
-        if BF16_PIPE4 and spec.N % 128 == 0:
-            a.w = _ptr(_w16v3(spec), torch.bfloat16)
-            _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16_p4(a, _stream()), "lwg_conv2d_nhwc_bf16_p4")
+        if _hr_eligible(spec, x0, y, out_hw):
+            panel, bias = _w16hr(spec, epi == EPI_SPADE)
+            a.w, a.bias = _ptr(panel, torch.bfloat16), _ptr(bias)
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16_hr(a, _stream()), "lwg_conv2d_nhwc_bf16_hr")
         else:
             a.w = _ptr(_w16v2(spec), torch.bfloat16)
             _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16(a, _stream()), "lwg_conv2d_nhwc_bf16")
@@ -594,6 +614,12 @@ def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=ACT_NONE):
     _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), B, H * W, C, act, ns,
                                                  _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream()), "lwg_norm_bwd_nhwc_f32")
     return dx, dg, db
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, t_dev):
+    """In-place Adam update with the step count on the device: t_dev (1,) int32 is incremented, then used (graph-capturable)."""
+    _lib.check(_lib.lib().lwg_adam_step_dev_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, _ptr(t_dev, torch.int32),
+                                                _stream()), "lwg_adam_step_dev_f32")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, t):

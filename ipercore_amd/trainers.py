@@ -204,6 +204,7 @@ class FlatAdam(object):
         self.flat = torch.zeros(n4, device=dev)
         self.grad = torch.zeros(n4, device=dev)
         self.m, self.v = torch.zeros(n4, device=dev), torch.zeros(n4, device=dev)
+        self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)      # the step count lives on the device: graph replays advance it
         off = 0
         for p in params:
             k = p.numel()
@@ -302,9 +303,9 @@ class FlatAdam(object):
         self.grad.div_(dist.get_world_size(group))
 
     def step(self):
-        self.t += 1
+        self.t += 1                                    # host mirror (not advanced by graph replays: read t_dev for the truth)
         self._gather()
-        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        ops.adam_step_dev(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t_dev)
         if hasattr(self.module, "_packed"):
             self.module._packed = None             # the inference engine's packed panels are stale now
 
@@ -491,6 +492,10 @@ class TrainOpts(object):
     use_face = True
     face_loss_path = "./assets/checkpoints/losses/sphere20a_20171020.pth"
     lambda_face = 5.0
+    # replay the static-shape step as hipGraphs (three segments: G forward / loss / backward, Adam(G) + D loss / backward, Adam(D); the
+    # data-parallel all-reduces run between them): one step is ~2700 kernel launches and the Python / ctypes launch path needs
+    # 26 ms to enqueue what the GPU executes in 33 ms - any kernel-side gain would otherwise be hidden behind the host
+    use_graph = True
     allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
 
     @classmethod
@@ -604,7 +609,7 @@ class LWGTrainer(object):
         tensors that stage leaves on the trainer: input_G_bg (1,nb,4,h,w), input_G_src (1,ns,6,h,w), input_G_tsf (1,nt,6,h,w),
         Tst (1,nt,ns,h,w,2), real_src (1,ns,3,h,w), real_tsf (1,nt,3,h,w), real_bg (nb,3,h,w), body_mask (1,ns+nt,1,h,w)."""
         if "images" not in inputs:
-            self.inp = inputs
+            self._bind_inputs(inputs)
             return
         fc = flow_comp if flow_comp is not None else self.flow_comp
         assert fc is not None, "set_input(sample) needs a FlowCompositionForTrainer (LWGTrainer(..., flow_comp=...))"
@@ -625,10 +630,31 @@ class LWGTrainer(object):
         if not fc.share_bg:
             tsf_img = images[:, ns:]
             g_bg = torch.cat([g_bg, torch.cat([tsf_img * tsf_mask, tsf_mask], dim=2)], dim=1)
-        self.inp = {"input_G_bg": g_bg.contiguous(), "input_G_src": g_src.contiguous(), "input_G_tsf": g_tsf.contiguous(),
-                    "Tst": Tst.contiguous(), "real_src": images[:, :ns].contiguous(), "real_tsf": images[:, ns:].contiguous(),
-                    "real_bg": bg.view(-1, 3, S, S), "body_mask": masks, "uv_img": uv_img, "head_bbox": head_bbox,
-                    "body_bbox": body_bbox}
+        self._bind_inputs({"input_G_bg": g_bg.contiguous(), "input_G_src": g_src.contiguous(), "input_G_tsf": g_tsf.contiguous(),
+                           "Tst": Tst.contiguous(), "real_src": images[:, :ns].contiguous(), "real_tsf": images[:, ns:].contiguous(),
+                           "real_bg": bg.view(-1, 3, S, S), "body_mask": masks, "uv_img": uv_img, "head_bbox": head_bbox,
+                           "body_bbox": body_bbox})
+
+    def _bind_inputs(self, inp):
+        """The captured step reads its inputs from fixed buffers: once graphs exist, a new sample is COPIED into them (same shapes:
+        the personalization loop cycles over samples of one video); a sample of another shape drops the graphs (re-captured)."""
+        st = getattr(self, "_static_inp", None)
+        if getattr(self, "_graphs", None) is None or st is None:
+            self.inp = inp
+            return
+        same = set(inp) == set(st) and all((not torch.is_tensor(st[k])) or (torch.is_tensor(inp[k]) and inp[k].shape == st[k].shape
+                                                                             and inp[k].dtype == st[k].dtype) for k in st)
+        if not same:
+            self._graphs = self._static_inp = None
+            self.inp = inp
+            return
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                if inp[k].data_ptr() != v.data_ptr():
+                    v.copy_(inp[k])
+            else:
+                st[k] = inp[k]
+        self.inp = st
 
     def forward(self):
         """:699-730."""
@@ -687,9 +713,13 @@ class LWGTrainer(object):
     def optimize_parameters(self):
         """:326-352, plus the gradient all-reduce when the step is data parallel."""
         with ops.conv_precision(self.opts.conv_precision):
+            if self._graphable():
+                return self._graph_step()
+            self.step_mode = "eager launches"
             return self._optimize_parameters()
 
-    def _optimize_parameters(self):
+    # ---- the step in three segments (the data-parallel exchanges sit between them) ------------------------------------------------
+    def _seg_G(self):
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
         d_params = [] if self.D is None else list(self.D.parameters())
         for p in d_params:                                  # G's adversarial term needs D's data gradients only (the reference
@@ -698,19 +728,96 @@ class LWGTrainer(object):
         for p in d_params:
             p.requires_grad_(True)
         self.optimizer_G.zero_grad()
+        return loss_G, fake_tsf_imgs
+
+    def _seg_D(self, fake_tsf_imgs):
+        self.optimizer_D.zero_grad()
+        return self.optimize_D(fake_tsf_imgs)
+
+    def _optimize_parameters(self):
+        loss_G, fake_tsf_imgs = self._seg_G()
         self.optimizer_G.arm(self.group)
         loss_G.backward()
         self.optimizer_G.allreduce(self.group)
         self.optimizer_G.step()
         loss_D = None
         if self.D is not None:
-            self.optimizer_D.zero_grad()
-            loss_D = self.optimize_D(fake_tsf_imgs)
+            loss_D = self._seg_D(fake_tsf_imgs)
             self.optimizer_D.arm(self.group, n_buckets=1)
             loss_D.backward()
             self.optimizer_D.allreduce(self.group)
             self.optimizer_D.step()
         return loss_G.detach(), None if loss_D is None else loss_D.detach()
+
+    # ---- hipGraph replay of the step -----------------------------------------------------------------------------------------
+    def _graphable(self):
+        """The step is captured when its shapes are static and nothing in it reads the device from the host: no FaceLoss / crop
+        discriminators (their boxes are host-read integers, as in the reference), CUDA tensors, use_graph on."""
+        if not getattr(self.opts, "use_graph", False) or getattr(self, "_graph_failed", False):
+            return False
+        if not torch.cuda.is_available() or not next(self.G.parameters()).is_cuda or self.crt_face is not None:
+            return False
+        if self.D is not None and getattr(self.D, "CROPS", ()):
+            return False
+        return True
+
+    def _graph_step(self):
+        if getattr(self, "_graphs", None) is None:
+            try:
+                self._capture()
+            except Exception as e:                          # fall back to eager launches, loudly
+                import warnings
+                warnings.warn(f"LWGTrainer: capturing the step as a hipGraph failed ({type(e).__name__}: {e}); running eager launches")
+                self._graph_failed, self._graphs = True, None
+                torch.cuda.synchronize()
+                self.step_mode = "eager launches (graph capture failed)"
+                return self._optimize_parameters()
+        gA, gB, gC = self._graphs
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        gA.replay()
+        if multi:
+            self.optimizer_G.allreduce(self.group)          # one in-place all-reduce of G's flat gradient buffer between the graphs
+        gB.replay()
+        if self.D is not None:
+            if multi:
+                self.optimizer_D.allreduce(self.group)
+            gC.replay()
+        return self._static_losses
+
+    def _capture(self):
+        """Warm up on a side stream (every kernel variant launched once: dynamic-LDS attributes are set outside the capture), then
+        capture the three segments into graphs that share one memory pool."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._optimize_parameters()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.optimizer_G._armed = False                     # no hook-driven collectives inside a capture
+        if self.optimizer_D is not None:
+            self.optimizer_D._armed = False
+        gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gA):
+            loss_G, fake_tsf_imgs = self._seg_G()
+            loss_G.backward()
+            self.optimizer_G._gather()
+        pool = gA.pool()
+        with torch.cuda.graph(gB, pool=pool):
+            self.optimizer_G.step()
+            loss_D = None
+            if self.D is not None:
+                loss_D = self._seg_D(fake_tsf_imgs)
+                loss_D.backward()
+                self.optimizer_D._gather()
+        with torch.cuda.graph(gC, pool=pool):
+            if self.D is not None:
+                self.optimizer_D.step()
+        self._graphs = (gA, gB, gC)
+        self._static_losses = (loss_G.detach(), None if loss_D is None else loss_D.detach())
+        self._static_inp = self.inp
+        self.step_mode = "3 hipGraph segments per step (G fwd/bwd | Adam(G) + D fwd/bwd | Adam(D)), all-reduces between them"
+        torch.cuda.synchronize()
 
 
 def personalize(trainer, samples, n_iters, ckpt_path=None, log_every=0):

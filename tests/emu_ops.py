@@ -320,6 +320,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
     p.addcdiv_(m, (v / (1 - beta2 ** t)).sqrt() + eps, value=-step)
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, t_dev):
+    """lwg_adam_step_dev_f32: the step count lives in a (1,) int32 tensor that the call increments first."""
+    t_dev += 1
+    adam_step(p, g, m, v, lr, beta1, beta2, eps, int(t_dev.item()))
+
+
 def maxpool2_fwd(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
 
@@ -339,7 +345,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd"):
+                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

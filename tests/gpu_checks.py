@@ -500,17 +500,19 @@ def _psnr(a, b):
     return 10 * np.log10(4.0 / max(mse, 1e-20))        # frames are in [-1, 1]: peak-to-peak 2
 
 
-def _precision_rerun(r, mode):
+def _precision_rerun(r, mode, frame_batch=None):
     """The frames of a cached run again with every Cin % 32 == 0 convolution in ``mode`` (source features rebuilt in that mode too);
     the geometry stages are fp32 in every mode, so the oracle frames of the cached run remain the reference."""
     case, im = r["case"], r["im"]
-    prev = im.generator.conv_precision
+    prev, prev_fb = im.generator.conv_precision, im.frame_batch
     im.generator.conv_precision = mode
+    if frame_batch is not None:
+        im.frame_batch = frame_batch
     try:
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
         got = pu.run_hip(case, imitator=im).cpu()
     finally:
-        im.generator.conv_precision = prev
+        im.generator.conv_precision, im.frame_batch = prev, prev_fb
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
     assert torch.isfinite(got).all()
     return got
@@ -518,7 +520,10 @@ def _precision_rerun(r, mode):
 
 def check_bf16_vs_oracle():
     """BASELINE configs[3] precision mode against the fp32 ORACLE (PSNR >= 40 dB), at 512x512 (8 imitation frames) and
-    at 1024x1024 (novel-view poses): bf16 MFMA operands / bf16 activation storage on the HIP side, fp32 torch-CPU on the other."""
+    at 1024x1024 (novel-view poses): bf16 MFMA operands / bf16 activation storage on the HIP side, fp32 torch-CPU on the other.
+    The 1024x1024 clip runs twice - in 2-frame batches (the 4-wave 128 x 128-tile conv kernel) and as ONE 5-frame batch (enough
+    GEMM rows for the 8-wave 256 x 256-tile kernel on the 256- and 512-column layers): both must meet the bound, and since the two
+    kernels accumulate every output element over K in the same order they must agree with each other to the last bit."""
     out = {}
     for key, build in (("full512", lambda: check_pipeline_full_512()), ("novel1024", lambda: check_pipeline_full_1024())):
         if key not in _RUNS:
@@ -531,6 +536,12 @@ def check_bf16_vs_oracle():
                     "vs_fp32_path_psnr_db": _psnr(got, r["got"])}
         assert out[key]["psnr_db_min"] >= 40.0, out
         assert (got - r["got"]).abs().max().item() > 0, "bf16 mode produced the fp32 path's frames bit for bit: the bf16 kernels did not run"
+        if key == "novel1024":
+            big = _precision_rerun(r, "bf16", frame_batch=5)
+            out[key]["one_batch_of_5_psnr_db_min"] = min(_psnr(big[t], r["want"][k]) for k, t in enumerate(r["idx"]))
+            out[key]["one_batch_of_5_vs_batches_of_2_max"] = (big - got).abs().max().item()
+            assert out[key]["one_batch_of_5_psnr_db_min"] >= 40.0, out
+            assert out[key]["one_batch_of_5_vs_batches_of_2_max"] == 0.0, "bf16 frames depend on the frame batch (tile configuration)"
     return out
 
 

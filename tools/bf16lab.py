@@ -24,8 +24,12 @@ def r16(t):
     return t.to(BF).float()
 
 
+BATCH_MUL = 1
+
+
 def build(name):
     B, H, W, C0, C1, N, k, stride, kind = SHAPES[name]
+    B *= BATCH_MUL
     g = torch.Generator(device="cpu").manual_seed(sum(map(ord, name)))
     Cin = C0 + C1
     rnd = lambda *s, sc=1.0: r16((torch.randn(*s, generator=g) * sc)).to(DEV)  # noqa: E731
@@ -79,9 +83,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-f32", action="store_true")
     ap.add_argument("--convs-only", action="store_true")
+    ap.add_argument("--batch-mul", type=int, default=1, help="multiply the batch of every shape (2 = frame batch 4 at 1024^2)")
     args = ap.parse_args()
-    ops.BF16_PIPE4 = os.environ.get("LWG_LAB_PIPE4", "0") == "1"
-    print(f"LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} PIPE4={ops.BF16_PIPE4} TILE64={os.environ.get('LWG_BF16_TILE64', '0')}")
+    global BATCH_MUL
+    BATCH_MUL = args.batch_mul
+    ops.BF16_HR = os.environ.get("LWG_LAB_HR", "1") == "1"
+    print(f"batch x{BATCH_MUL} HR={ops.BF16_HR} HALO={os.environ.get('LWG_BF16_HALO', '(default 1)')} BIG={os.environ.get('LWG_BF16_BIG', '(default 1)')} LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} TILE64={os.environ.get('LWG_BF16_TILE64', '(heuristic)')}")
     tot_f, tot_us = 0.0, 0.0
     for name in args.shapes.split(","):
         x0, x1, yshape, launches = build(name)
