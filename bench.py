@@ -392,7 +392,25 @@ def novel_view_1024_bf16(dev, timer, W, K):
         timer.reset()
 
 
+def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900):
+    """BASELINE configs[4] beside the headline: bench_personalize.py in its OWN process (the step captures hipGraphs and owns
+    its allocator pools; a failure there must not take the headline line with it) -> its JSON line, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench_personalize.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+           "--size", str(size)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"bench_personalize.py exited {r.returncode} without a result line", "stderr_tail": r.stderr[-600:]}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()                    # a crash inside a native library leaves a Python traceback on stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -607,11 +625,7 @@ def main():
                     line["novel_view_1024_bf16"] = novel_view_1024_bf16(dev, timer, 1, 3)
                 except Exception as e:
                     line["novel_view_1024_bf16"] = {"error": f"{type(e).__name__}: {e}"}
-                try:
-                    import bench_personalize
-                    line["personalize_step"] = bench_personalize.measure(dev, steps=10, warmup=4, size=512)
-                except Exception as e:
-                    line["personalize_step"] = {"error": f"{type(e).__name__}: {e}"}
+                line["personalize_step"] = personalize_step_extra()
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)

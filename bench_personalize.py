@@ -28,7 +28,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None):
+def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
+            panel_cache=None, wgrad_side=None):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -64,6 +65,10 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     topts.allow_seeded_loss_nets = True        # the licensed checkpoints are not available offline: seeded weights, same cost per step
     if graph is not None and hasattr(topts, "use_graph"):
         topts.use_graph = bool(graph)
+    if panel_cache is not None:
+        topts.use_panel_cache = bool(panel_cache)
+    if wgrad_side is not None:
+        topts.wgrad_side_stream = bool(wgrad_side)
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
 
@@ -135,7 +140,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
                    "global_batch": world,
                    "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
                                   f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges overlapped with backward",
-                   "step": getattr(tr, "step_mode", "eager launches")},
+                   "step": getattr(tr, "step_mode", "eager launches"),
+                   "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "wgrad_side_stream": bool(getattr(tr.opts, "wgrad_side_stream", False))},
         "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                      "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
@@ -146,6 +152,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -157,6 +165,8 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
                     help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
+    ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
+    ap.add_argument("--wgrad-side", action="store_true", help="weight gradients on a second stream next to the data gradients")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +179,8 @@ def main():
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
     assert args.gpus == world
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
-                  graph=None if args.graph else False)
+                  graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
+                  wgrad_side=True if args.wgrad_side else None)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -85,12 +85,20 @@ int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stre
  * ds_read_b128 on 128-byte rows).  The first layer of a network (fp32 image-like input, Cin < 32) runs lwg_conv2d_nhwc_f32 with
  * ydt = LWG_DT_BF16 (LWG_EPI_NONE only): fp32 in, bf16 out. */
 int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
-/* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches with N % 128 == 0, as the
+/* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches, as the
  * halo-tile kernel with register-streamed weights: args->w = the bf16 panel [ntaps*Cin/64][4][N][16] - element
  * [step][ks][n][e] = weight of GEMM column n at k = step*64 + ks*16 + e (k order as above) - and, for LWG_EPI_SPADE, columns
  * (and args->bias) interleaved gamma | beta in blocks of 16: column 32q + r is gamma of channel 16q + r (r < 16) or beta of
- * channel 16q + r - 16. */
+ * channel 16q + r - 16.  ntaps == 1 (the attention blocks' query projection, attlwb_spade_resunet.py:202-204: 1x1, stride 1,
+ * C -> C with C in {64, 128, 256}, no second input, LWG_EPI_NONE): the weights stay in registers and persistent workgroups
+ * stream the rows - same panel layout with one step per 64-channel chunk. */
 int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* args, lwg_stream_t stream);
+/* First layer of a stream in bf16 mode (attlwb_spade_resunet.py:268-271 Encoder.0 on the 6-channel network input): x0 is the
+ * fp32 NHWC-8 input (xdt = LWG_DT_F32, C0 = 8, C1 = 0), up to 10 taps, any stride, N = 64, bf16 output (ydt = LWG_DT_BF16),
+ * bias + activation epilogue (LWG_EPI_NONE).  The input is rounded to bf16 in registers (one pixel's 8 channels = one MFMA
+ * k-octet, no LDS); args->w = bf16 panel [ceil(ntaps/2)][64][16], element [ks][n][e] = weight of column n at k = 16 ks + e,
+ * k = tap*8 + c, zero past ntaps*8. */
+int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* args, lwg_stream_t stream);
 
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs
@@ -141,6 +149,17 @@ int lwg_pack_panel_f32(const float* w, int D0, int D1, int KH, int KW, int trans
                        int cin_pad, int nout, int n_pad, float* out, lwg_stream_t stream);
 int lwg_unpack_wgrad_f32(const float* dwk, int D0, int D1, int KH, int KW, int transposed, const int* kidx, int ntaps, int cin,
                          int cin_pad, int nout, int n_pad, float* dw, lwg_stream_t stream);
+/* Every panel of a training step in one launch: descs_dev = ndesc LwgPackDesc records in DEVICE memory (built once per network -
+ * the parameters live in flat buffers, their addresses are stable), each the argument list of one lwg_pack_panel_f32 call plus
+ * first_block = the sum of ceil((Kp/4)*n_pad / 256) over the records before it (Kp = ceil32(ntaps*cin_pad)); total_blocks = that
+ * sum over all records.  Same values as ndesc single launches. */
+typedef struct LwgPackDesc {
+    const float* w;    /* (D0, D1, KH, KW) contiguous */
+    float* out;        /* [Kp/4][n_pad][4] */
+    int D1, KHW, transposed, ntaps, cin, cin_pad, nout, n_pad, Kp, first_block;
+    int kidx[LWG_MAX_TAPS];
+} LwgPackDesc;
+int lwg_pack_panels_f32(const LwgPackDesc* descs_dev, int ndesc, int total_blocks, lwg_stream_t stream);
 /* MaxPool2d(2, 2) on NHWC (VGG19 perceptual loss, criterions/vggloss.py): y (B,H/2,W/2,C); the backward writes all of dx
  * (B,H,W,C), each gradient going to the first maximum of its window in scan order.  H, W even; C % 4 == 0. */
 int lwg_maxpool2_fwd_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, lwg_stream_t stream);

@@ -39,6 +39,12 @@ class LwgConvArgs(ctypes.Structure):
     ]
 
 
+class LwgPackDesc(ctypes.Structure):
+    """Mirror of ``struct LwgPackDesc`` (include/lwg_hip.h): one panel of lwg_pack_panels_f32."""
+    _fields_ = [("w", c_f), ("out", c_f)] + [(n, c_i) for n in ("D1", "KHW", "transposed", "ntaps", "cin", "cin_pad", "nout", "n_pad", "Kp",
+                                                               "first_block")] + [("kidx", c_i * LWG_MAX_TAPS)]
+
+
 _SIGS = {
     "lwg_abi_version": (c_i, []),
     "lwg_device_cu_count": (c_i, []),
@@ -47,6 +53,7 @@ _SIGS = {
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
@@ -58,6 +65,7 @@ _SIGS = {
     "lwg_adam_step_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_f]),
     "lwg_adam_step_dev_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "lwg_pack_panel_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),
+    "lwg_pack_panels_f32": (c_i, [c_f, c_i, c_i, c_f]),
     "lwg_unpack_wgrad_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),
     "lwg_maxpool2_fwd_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_maxpool2_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

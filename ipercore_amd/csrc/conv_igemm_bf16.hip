@@ -574,9 +574,11 @@ static bool lwg_bf16_halo_ok(const LwgConvArgs& a) {
 // No LDS-DMA, no per-step barrier: a wave's K loop is MFMAs + ds_read_b128 + 4 loads per step.  LDS = 46 KB -> three workgroups
 // per CU.  Panel layout: [step = chunk*ntaps + tap][ks 4][N][16] (the two k-octets of MFMA k-step ks); SPADE panels interleave
 // gamma | beta in blocks of 16 columns so one 32-column tile carries both for 16 channels.
-template <int NTAPS, int EPI, int D>
-__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvArgs a) {
-    constexpr int TM = 4;
+template <int NTAPS, int EPI, int D, int WAVES_M>
+__global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_kernel(const LwgConvArgs a) {
+    // WAVES_M = 1: four waves side by side, 128 rows x 32 columns each (N % 128 == 0); WAVES_M = 2: two by two, 64 rows x 32
+    // columns each - the 64-column launches (the last up-sampling layer)
+    constexpr int WAVES_N = 4 / WAVES_M, TM = 4 / WAVES_M, BN = WAVES_N * 32;
     static_assert(NTAPS % D == 0, "the weight ring must close at a chunk boundary");
     constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;
 
@@ -585,7 +587,8 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvA
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = a.N >> 7;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int tiles_n = a.N / BN;
     const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
     const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lid % tiles_n;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvA
     rest /= tiles_x;
     const int tiy = rest % tiles_y, tb = rest / tiles_y;
     const int x0 = tix * 16, y0 = tiy * 8;
-    const int n_base = tile_n * 128;
+    const int n_base = tile_n * BN;
 
     const int Cin = a.C0 + a.C1;
     const int nchunks = Cin >> 6;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvA
 
     const int khalf = lane >> 5;
     // weight fragments: this wave's 32 columns; lane = column (lane & 31), k-octet khalf of MFMA k-step ks
-    const unsigned wv = (unsigned)((n_base + wid * 32 + (lane & 31)) * 32 + khalf * 16);
+    const unsigned wv = (unsigned)((n_base + wn * 32 + (lane & 31)) * 32 + khalf * 16);
     __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
     bf16x8 bq[D][4];
     auto load_b = [&](int step, int slot) {
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvA
     int hp0[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int r = i * 32 + (lane & 31);
+        const int r = wm * TM * 32 + i * 32 + (lane & 31);
         hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
     }
     int toffs[NTAPS];
@@ -709,34 +712,243 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_hr_kernel(const LwgConvA
             __syncthreads();
         }
     }
-    lwg_bf16_epilogue<TM, 1, EPI, true>(a, acc, 0, n_base, 0, wid, lane, tb, y0, x0);
+    lwg_bf16_epilogue<TM, 1, EPI, true>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
 }
 
-template <int NTAPS, int EPI, int D>
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pointwise (1 x 1, stride 1, C -> C) kernel: the query projections fq of the attention blocks.  K is one to four 64-channel
+// chunks - the tiled kernels above spend such a launch in prologue / epilogue and one memory round trip per K-step (0.18 of the
+// HBM rate).  Here the whole weight matrix lives in registers (a wave owns 32 columns: K/16 fragments = 16..64 VGPRs), a
+// persistent 8-wave workgroup per CU walks the row tiles, and a tile's activations (rows x K, one contiguous block of the NHWC
+// tensor) come in by LDS-DMA, double-buffered by TILE: the DMA of tile t+1 is in flight for the whole of tile t, one barrier
+// per tile.  HBM-bound: reads M x K, writes M x N bf16 once.
+template <int NCH, int WAVES_N>
+__global__ __launch_bounds__(512, 1) void lwg_conv_bf16_pw_kernel(const LwgConvArgs a) {
+    constexpr int WAVES_M = 8 / WAVES_N, TM = 4, BM = WAVES_M * 128;
+    constexpr int CH_BYTES = BM * 128;                       // one 64-channel chunk of a stage: [row][128 B]
+    constexpr int STAGE = NCH * CH_BYTES;
+    constexpr int PIECES = STAGE / 1024 / 8;                 // 1 KB DMA pieces per wave per stage
+    constexpr int RB = BM / 8;                               // 8-row pieces per chunk
+    constexpr unsigned K2 = NCH * 128u;                      // bytes per pixel
+
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int khalf = lane >> 5;
+    const int ntiles = (a.M + BM - 1) / BM;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0), 0, (int)((unsigned)a.M * K2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(NCH * 4u * (unsigned)a.N * 32u), 0x00020000);
+
+    // byte offset (inside a tile's block of the tensor) this lane fetches for piece p: the LDS image is [chunk][row][8 slots of
+    // 16 B], slot s of row r holds k-octet s ^ ((r >> 1) & 7); rows past M are out of the buffer's range -> the DMA writes zeros
+    unsigned pv[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const int q = wid * PIECES + p;
+        const int chunk = q / RB, row = (q % RB) * 8 + (lane >> 3);
+        pv[p] = (unsigned)row * K2 + (unsigned)chunk * 128u + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    auto issue = [&](int tile, int buf) {
+        const unsigned tb = (unsigned)tile * (unsigned)BM * K2;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LWG_LDS_PTR(smem_p + buf * STAGE + (wid * PIECES + p) * 1024), 16, (int)(tb + pv[p]), 0, 0, 0);
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile, 0);
+
+    // the wave's 32 columns of the whole weight matrix: [chunk][ks][N][16] (the register-streamed panel with one tap)
+    bf16x8 bq[NCH][4];
+    const unsigned wv = (unsigned)((wn * 32 + (lane & 31)) * 32 + khalf * 16);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bq[c][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wv, (int)((unsigned)(c * 4 + ks) * (unsigned)a.N * 32u), 0));
+
+    const int sw = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + khalf) ^ sw) << 4;
+    const int frow = (wm * 128 + (lane & 31)) * 128;
+
+    for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's pieces of the current stage (and its last stores) are done
+        __syncthreads();                           // ... everyone's; and every wave has finished reading the other stage
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) issue(nxt, buf ^ 1);
+        floatx16 acc[TM][1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        const char* S = smem_p + buf * STAGE + frow;
+        bf16x8 fa[2][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(S + i * 4096 + koff[0]);
+#pragma unroll
+        for (int s = 0; s < NCH * 4; ++s) {
+            if (s + 1 < NCH * 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(S + ((s + 1) >> 2) * CH_BYTES + i * 4096 + koff[(s + 1) & 3]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[s >> 2][s & 3], fa[s & 1][i], acc[i][0], 0, 0, 0);
+        }
+        lwg_bf16_epilogue<TM, 1, LWG_EPI_NONE>(a, acc, tile * BM, 0, wm, wn, lane);
+    }
+}
+
+template <int NCH, int WAVES_N>
+static hipError_t launch_cfg_bf16_pw(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr int BM = (8 / WAVES_N) * 128;
+    constexpr size_t lds = (size_t)2 * NCH * BM * 128;
+    auto kern = lwg_conv_bf16_pw_kernel<NCH, WAVES_N>;
+    static unsigned long long attr_done = 0ull;
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    const int ntiles = (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+static bool lwg_bf16_pw_ok(const LwgConvArgs& a) {
+    return a.ntaps == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.stride == 1 && a.C1 == 0 && a.N == a.C0 && a.epi == LWG_EPI_NONE &&
+           (a.N == 64 || a.N == 128 || a.N == 256) && a.H == a.OH && a.W == a.OW;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// First layer of a stream in bf16 mode: fp32 NHWC-8 input (the 6-channel network input, zero-extended), <= 10 taps, any stride,
+// 64 output columns, bf16 output.  8 channels x 4 B = the two 16-byte loads of one lane; converted to bf16 they are exactly one
+// k-octet of the MFMA operand, so a k-step of 16 is two taps (tap = 2 ks + lane / 32) and the A operand needs no LDS at all.
+// The 80 x 64 weight panel sits in 40 VGPRs; a wave produces 64 pixels x 64 channels per pass.  HBM-bound (reads the input
+// once - the shifted re-reads hit L1 / L2 - and writes M x 64 bf16).  Panel: [ceil(ntaps / 2)][64][16] bf16, k = tap * 8 + c.
+__global__ __launch_bounds__(256, 2) void lwg_conv_c8_bf16_kernel(const LwgConvArgs a, const int nks) {
+    constexpr int TM = 2, TN = 2, MAXKS = 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5;
+    const __bf16* wp = reinterpret_cast<const __bf16*>(a.w);
+    bf16x8 bq[MAXKS][TN];
+    int tdy[MAXKS], tdx[MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks) {
+        const int tap = 2 * ks + khalf;
+        const bool ok = ks < nks && tap < a.ntaps;
+        tdy[ks] = ok ? (int)a.dy[tap] : -100000;               // dead taps read out of range: zeros (their weights are zero too)
+        tdx[ks] = ok ? (int)a.dx[tap] : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            bq[ks][j] = ks < nks ? *reinterpret_cast<const bf16x8*>(wp + ((size_t)(ks * 64 + j * 32 + (lane & 31)) * 16 + khalf * 8)) : z;
+        }
+    }
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0), 0, (int)((unsigned)a.B * a.H * a.W * 32u), 0x00020000);
+    const int HW = a.OH * a.OW;
+    const int ngroups = (a.M + 63) >> 6;
+    for (int g = blockIdx.x * 4 + wid; g < ngroups; g += gridDim.x * 4) {
+        floatx16 acc[TM][TN];
+        floatx4 raw[TM][MAXKS][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = g * 64 + i * 32 + (lane & 31);
+            const bool live = m < a.M;
+            const int mm = live ? m : 0;
+            const int b = mm / HW, rem = mm - b * HW;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            const int iy0 = live ? oy * a.stride : -100000, ix0 = ox * a.stride;
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks) {
+                const int iy = iy0 + tdy[ks], ix = ix0 + tdx[ks];
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                const unsigned voff = ok ? (unsigned)((b * a.H + iy) * a.W + ix) * 32u : LWG_OOB_OFFSET;
+                raw[i][ks][0] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, 0, 0));
+                raw[i][ks][1] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, 16, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 fa;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    fa[e] = (__bf16)raw[i][ks][0][e];
+                    fa[4 + e] = (__bf16)raw[i][ks][1][e];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks][j], fa, acc[i][j], 0, 0, 0);
+            }
+        lwg_bf16_epilogue<TM, TN, LWG_EPI_NONE>(a, acc, g * 64, 0, 0, 0, lane);
+    }
+}
+
+// args->x0 fp32 (B,H,W,8), args->w = bf16 panel [ceil(ntaps/2)][64][16] (k = tap*8 + c, zero rows past ntaps*8), N = 64,
+// bf16 output; bias + activation epilogue.
+extern "C" int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps < 1 || a.ntaps > 10) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_BF16 || a.C0 != 8 || a.C1 != 0 || a.N != 64 || a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
+    if ((a.YC & 7) != 0 || (a.ycoff & 7) != 0 || a.stride < 1) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.B * a.H * a.W * 32ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    const int ngroups4 = (a.M + 255) / 256;
+    hipLaunchKernelGGL(lwg_conv_c8_bf16_kernel, dim3((unsigned)(ngroups4 < 2048 ? ngroups4 : 2048)), dim3(256), 0, stream, a, (a.ntaps + 1) / 2);
+    return hipGetLastError();
+}
+
+template <int NTAPS, int EPI, int D, int WAVES_M>
 static hipError_t launch_cfg_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES;
-    auto kern = lwg_conv_bf16_hr_kernel<NTAPS, EPI, D>;
-    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / 128);
+    auto kern = lwg_conv_bf16_hr_kernel<NTAPS, EPI, D, WAVES_M>;
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / (128 / WAVES_M));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int EPI>
 static hipError_t launch_epi_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
-    if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3>(a, stream);
-    return launch_cfg_bf16_hr<4, EPI, 2>(a, stream);
+    if (a.N % 128 == 0) {
+        if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3, 1>(a, stream);
+        return launch_cfg_bf16_hr<4, EPI, 2, 1>(a, stream);
+    }
+    if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3, 2>(a, stream);
+    return launch_cfg_bf16_hr<4, EPI, 2, 2>(a, stream);
 }
 
 // args->w = the register-streamed panel [ntaps*Cin/64][4][N][16] (bias / SPADE columns in the matching order, see above);
-// 3x3 (9 taps) or 2x2 (4 taps) within [-1,1]^2, stride 1, same input / output grid, N % 128 == 0, Cin % 64 == 0.
+// 3x3 (9 taps) or 2x2 (4 taps) within [-1,1]^2, stride 1, same input / output grid, N % 64 == 0, Cin % 64 == 0.
 extern "C" int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* pa, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
     const int Cin = a.C0 + a.C1;
-    if (!a.x0 || !a.w || !a.y || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 4)) return (int)hipErrorInvalidValue;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 4 && a.ntaps != 1)) return (int)hipErrorInvalidValue;
     if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16 || a.stride != 1 || a.H != a.OH || a.W != a.OW) return (int)hipErrorInvalidValue;
-    if (a.N % 128 != 0 || Cin % 64 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0) return (int)hipErrorInvalidValue;
+    if (a.ntaps == 1) {
+        // pointwise C -> C launches: weights resident in registers, persistent workgroups (lwg_conv_bf16_pw_kernel)
+        if (!lwg_bf16_pw_ok(a) || (a.YC & 7) != 0 || (a.ycoff & 7) != 0) return (int)hipErrorInvalidValue;
+        if ((unsigned long long)a.M * (unsigned long long)a.C0 * 2ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+        if (a.N == 64) return (int)launch_cfg_bf16_pw<1, 2>(a, stream);
+        if (a.N == 128) return (int)launch_cfg_bf16_pw<2, 4>(a, stream);
+        return (int)launch_cfg_bf16_pw<4, 8>(a, stream);
+    }
+    if (a.N % 64 != 0 || Cin % 64 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0) return (int)hipErrorInvalidValue;
     if (a.C1 != 0 && (a.C0 % 64 != 0 || !a.x1)) return (int)hipErrorInvalidValue;
     for (int t = 0; t < a.ntaps; ++t)
         if (a.dy[t] < -1 || a.dy[t] > 1 || a.dx[t] < -1 || a.dx[t] > 1) return (int)hipErrorInvalidValue;

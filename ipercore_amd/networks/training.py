@@ -18,6 +18,7 @@ There is no CPU fallback: ``ConvFn`` raises on CPU tensors.
 The module reuses the parameter tree of ``generator.AttentionLWBGenerator`` (same ``state_dict`` keys), so a
 personalized checkpoint saved from here loads into the inference engine unchanged.
 """
+import contextlib
 import math
 
 import torch
@@ -89,12 +90,22 @@ class ConvFn(torch.autograd.Function):
         C0 = x0.shape[3]
         Cin_packed = specs[0].Cin
         want_dw = ctx.needs_input_grad[2]                            # frozen weights (the VGG19 of the perceptual loss): data gradient only
-        db = ops.colsum(dy)[:N] if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-        if cfg.kind == "conv":
-            Nw, Cin, kh, kw = weight.shape
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        # parameter gradients on ops.WGRAD_STREAM when the trainer installed one: forked here (dy is final), joined before returning
+        side = ops.WGRAD_STREAM if (dy.is_cuda and (want_dw or want_db)) else None
+        cur = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(cur)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            db = ops.colsum(dy)[:N] if want_db else None
             dw = None
             if want_dw:
-                dw = packing.wgrad_conv(x0, specs[0], dy, x1, kh, kw, Cin, N)
+                if cfg.kind == "conv":
+                    dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N)
+                else:
+                    dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N)
+        if cfg.kind == "conv":
+            Nw, Cin, kh, kw = weight.shape
             dx = None
             if cfg.need_dx and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                 pad = kh // 2 if cfg.pad is None else cfg.pad            # the dgrad panel sees the padded channel counts
@@ -109,15 +120,14 @@ class ConvFn(torch.autograd.Function):
                         ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
         else:
             Cin, Nw = weight.shape[0], weight.shape[1]
-            dw = None
-            if want_dw:
-                dw = packing.wgrad_conv_transpose(x0, specs, dy, Cin, N)
             dx = None
             if cfg.need_dx and ctx.needs_input_grad[0]:
                 dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
                 ops.conv2d(dy, dspec, dx, splitk=True)
+        if side is not None:
+            cur.wait_stream(side)
         dx0 = dx1 = None
         if dx is not None:
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx

@@ -57,7 +57,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -70,6 +70,7 @@ class ConvSpec:
         self._w16v2 = None
         self._w16hr = None
         self._w16x3 = None
+        self._w16c8 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -97,8 +98,8 @@ def _w16v2(spec):
 
 
 def _hr_eligible(spec, x0, y, out_hw):
-    """lwg_conv2d_nhwc_bf16_hr applies to the 3x3 / 2x2-tap stride-1 launches on a shared input / output grid, N % 128 == 0."""
-    if not BF16_HR or spec.stride != 1 or spec.ntaps not in (9, 4) or spec.N % 128 != 0 or spec.Cin % 64 != 0:
+    """lwg_conv2d_nhwc_bf16_hr applies to the 3x3 / 2x2-tap stride-1 launches on a shared input / output grid."""
+    if not BF16_HR or spec.stride != 1 or spec.ntaps not in (9, 4) or spec.N % 64 != 0 or spec.Cin % 64 != 0:
         return False
     if any(abs(d) > 1 for d in spec.dy) or any(abs(d) > 1 for d in spec.dx):
         return False
@@ -129,6 +130,30 @@ def _w16hr(spec, spade):
 
 
 BF16_HR = True          # lab switch: False routes every bf16 convolution to lwg_conv2d_nhwc_bf16 (LDS-DMA kernels)
+BF16_PW = True          # lab switch: the pointwise (1x1, C -> C) launches on the register-resident-weights kernel
+BF16_C8 = True          # lab switch: the fp32-input first layer on the bf16 MFMA kernel (False: fp32 MFMA kernel, bf16 output)
+
+
+def _pw_eligible(spec, x0, y, x1, epi, out_hw):
+    """The 1x1 / stride-1 / C -> C launches (the attention blocks' query projections) go to lwg_conv2d_nhwc_bf16_hr with ntaps = 1."""
+    if not BF16_PW or spec.ntaps != 1 or spec.stride != 1 or spec.omul != 1 or x1 is not None or epi != EPI_NONE:
+        return False
+    if spec.dy[0] != 0 or spec.dx[0] != 0 or spec.N != spec.Cin or spec.N not in (64, 128, 256):
+        return False
+    OH, OW = (y.shape[1], y.shape[2]) if out_hw is None else out_hw
+    return (OH, OW) == (x0.shape[1], x0.shape[2])
+
+
+def _w16c8(spec):
+    """bf16 panel of lwg_conv2d_nhwc_c8_bf16: [ceil(ntaps/2)][N][16], k = tap*8 + c (the small-Cin K order of the fp32 panel)."""
+    if spec._w16c8 is None or spec._w16c8.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        nks = (spec.ntaps + 1) // 2
+        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
+        if wk.shape[0] < nks * 16:
+            wk = torch.cat([wk, wk.new_zeros(nks * 16 - wk.shape[0], N)], dim=0)
+        spec._w16c8 = wk[:nks * 16].reshape(nks, 16, N).permute(0, 2, 1).contiguous().to(torch.bfloat16)
+    return spec._w16c8
 
 
 def _w16x3(spec):
@@ -187,7 +212,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
         if y.dtype != torch.bfloat16 or spec.Cin % 64 != 0:
             raise ValueError("bf16 convolutions need bf16 outputs and Cin % 64 == 0")
-        if _hr_eligible(spec, x0, y, out_hw):
+        if _hr_eligible(spec, x0, y, out_hw) or _pw_eligible(spec, x0, y, x1, epi, out_hw):
             panel, bias = _w16hr(spec, epi == EPI_SPADE)
             a.w, a.bias = _ptr(panel, torch.bfloat16), _ptr(bias)
             _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16_hr(a, _stream()), "lwg_conv2d_nhwc_bf16_hr")
@@ -195,8 +220,12 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             a.w = _ptr(_w16v2(spec), torch.bfloat16)
             _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16(a, _stream()), "lwg_conv2d_nhwc_bf16")
     elif y.dtype == torch.bfloat16:
-        # the first layer of a network in bf16 mode: fp32 image-like input (Cin < 32) on the fp32 kernel, bf16 output
-        _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+        # the first layer of a network in bf16 mode: fp32 image-like input (Cin < 32), bf16 output
+        if BF16_C8 and spec.Cin == 8 and spec.N == 64 and spec.ntaps <= 10 and x1 is None and epi == EPI_NONE and spec.omul == 1:
+            a.w = _ptr(_w16c8(spec), torch.bfloat16)
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_c8_bf16(a, _stream()), "lwg_conv2d_nhwc_c8_bf16")
+        else:
+            _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
@@ -524,15 +553,70 @@ def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None
     return dw
 
 
+class PanelCache:
+    """The panels of a training step, re-packed by ONE launch per step (lwg_pack_panels_f32) instead of one launch per panel.
+
+    While a cache is installed (``ops.PANEL_CACHE``; trainers.LWGTrainer installs its own for the duration of a step) ``pack_panel``
+    hands out a persistent output buffer per (weight storage, packing arguments): the first request packs it with a single launch
+    and registers it, later requests return the buffer untouched - it was refreshed from the current weights by ``refresh()`` at the
+    start of the step (no weight changes between that point and its last use within a step: Adam(G) runs after G's backward,
+    Adam(D) at the end).  The weights are held by reference, so a registered address is never recycled."""
+
+    def __init__(self):
+        self.out, self.rows, self.keep, self.table, self.blocks = {}, [], [], None, 0
+
+    def get(self, w, transposed, kidx, cin, cin_pad, nout, n_pad):
+        key = (w.data_ptr(), tuple(w.shape), bool(transposed), kidx, cin, cin_pad, nout, n_pad)
+        hit = self.out.get(key)
+        if hit is not None:
+            return hit, False
+        D0, D1, KH, KW = w.shape
+        Kp = (len(kidx) * cin_pad + 31) // 32 * 32
+        out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
+        self.out[key] = out
+        self.keep.append(w)
+        self.rows.append((w.data_ptr(), out.data_ptr(), D1, KH * KW, 1 if transposed else 0, len(kidx), cin, cin_pad, nout, n_pad, Kp, kidx))
+        self.table = None
+        return out, True
+
+    def refresh(self):
+        """Re-pack every registered panel from the current weights (one launch on the current stream)."""
+        if not self.rows:
+            return
+        if self.table is None:
+            descs = (_lib.LwgPackDesc * len(self.rows))()
+            first = 0
+            for d, (wp, op, D1, KHW, tr, nt, cin, cp, nout, npad, Kp, kidx) in zip(descs, self.rows):
+                d.w, d.out = wp, op
+                d.D1, d.KHW, d.transposed, d.ntaps, d.cin, d.cin_pad, d.nout, d.n_pad, d.Kp, d.first_block = D1, KHW, tr, nt, cin, cp, nout, npad, Kp, first
+                for i, k in enumerate(kidx):
+                    d.kidx[i] = k
+                first += ((Kp // 4) * npad + 255) // 256
+            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+            self.table = raw.to(self.keep[0].device)
+            self.blocks = first
+        _lib.check(_lib.lib().lwg_pack_panels_f32(self.table.data_ptr(), len(self.rows), self.blocks, _stream()), "lwg_pack_panels_f32")
+
+
+PANEL_CACHE = None      # a PanelCache while a trainer step runs (trainers.LWGTrainer), else None: every pack_panel call launches
+WGRAD_STREAM = None     # a torch.cuda.Stream while a trainer step wants its weight gradients next to the data gradients, else None
+
+
 def pack_panel(w, transposed, kidx, cin, cin_pad, nout, n_pad):
     """Weight (D0,D1,KH,KW) on the device -> the fp32 GEMM panel [ceil32(ntaps*cin_pad)/4][n_pad][4] in one launch
     (csrc/train_ops.hip lwg_pack_panel_f32; see include/lwg_hip.h for the index convention)."""
     w = w.detach()
     assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
     D0, D1, KH, KW = w.shape
+    kidx = tuple(int(k) for k in kidx)
     ntaps = len(kidx)
     Kp = (ntaps * cin_pad + 31) // 32 * 32
-    out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
+    if PANEL_CACHE is not None:
+        out, fresh = PANEL_CACHE.get(w, transposed, kidx, cin, cin_pad, nout, n_pad)
+        if not fresh:
+            return out
+    else:
+        out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
     arr = (ctypes.c_int * ntaps)(*[int(k) for k in kidx])
     _lib.check(_lib.lib().lwg_pack_panel_f32(_ptr(w), D0, D1, KH, KW, 1 if transposed else 0, arr, ntaps, cin, cin_pad, nout, n_pad,
                                              _ptr(out), _stream()), "lwg_pack_panel_f32")

@@ -496,6 +496,11 @@ class TrainOpts(object):
     # data-parallel all-reduces run between them): one step is ~2700 kernel launches and the Python / ctypes launch path needs
     # 26 ms to enqueue what the GPU executes in 33 ms - any kernel-side gain would otherwise be hidden behind the host
     use_graph = True
+    # one launch re-packs every weight panel of the step (ops.PanelCache / lwg_pack_panels_f32) instead of one launch per panel
+    use_panel_cache = True
+    # weight gradient of a layer on a second stream next to its data gradient (fork / join per layer: graph edges when captured);
+    # one training sample leaves most layers with fewer workgroups than the chip holds, the two launches fill it together
+    wgrad_side_stream = False
     allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
 
     @classmethod
@@ -682,7 +687,12 @@ class LWGTrainer(object):
         fm = fake_masks.view(-1, 1, h, w)
         loss_mask = F.binary_cross_entropy(fm, i["body_mask"].view(-1, 1, h, w)) * o.lambda_mask
         loss_smooth = tv_loss(fm) * o.lambda_mask_smooth
-        self.losses.update(g_rec=loss_rec, g_tsf=loss_tsf, g_face=loss_face, g_adv=loss_adv, g_mask=loss_mask, g_mask_smooth=loss_smooth)
+        # detached: a stored loss that still carries its graph keeps every AccumulateGrad node of the step alive; the next step then
+        # reuses those nodes ON THE STREAM THEY WERE CREATED ON - inside a hipGraph capture that is work on a non-capturing stream
+        # (the capture crashed in hipStreamEndCapture when an eager step had run first)
+        det = lambda v: v.detach() if torch.is_tensor(v) else v            # noqa: E731
+        self.losses.update(g_rec=det(loss_rec), g_tsf=det(loss_tsf), g_face=det(loss_face), g_adv=det(loss_adv), g_mask=det(loss_mask),
+                           g_mask_smooth=det(loss_smooth))
         return loss_rec + loss_tsf + loss_face + loss_adv + loss_mask + loss_smooth
 
     def _d_inputs(self, x):
@@ -712,14 +722,26 @@ class LWGTrainer(object):
 
     def optimize_parameters(self):
         """:326-352, plus the gradient all-reduce when the step is data parallel."""
-        with ops.conv_precision(self.opts.conv_precision):
-            if self._graphable():
-                return self._graph_step()
-            self.step_mode = "eager launches"
-            return self._optimize_parameters()
+        on_gpu = torch.cuda.is_available() and next(self.G.parameters()).is_cuda
+        if on_gpu and getattr(self.opts, "use_panel_cache", False) and getattr(self, "_panel_cache", None) is None:
+            self._panel_cache = ops.PanelCache()
+        if on_gpu and getattr(self.opts, "wgrad_side_stream", False) and getattr(self, "_wgrad_stream", None) is None:
+            self._wgrad_stream = torch.cuda.Stream()
+        prev = ops.PANEL_CACHE, ops.WGRAD_STREAM
+        ops.PANEL_CACHE, ops.WGRAD_STREAM = getattr(self, "_panel_cache", None), getattr(self, "_wgrad_stream", None)
+        try:
+            with ops.conv_precision(self.opts.conv_precision):
+                if self._graphable():
+                    return self._graph_step()
+                self.step_mode = "eager launches"
+                return self._optimize_parameters()
+        finally:
+            ops.PANEL_CACHE, ops.WGRAD_STREAM = prev
 
     # ---- the step in three segments (the data-parallel exchanges sit between them) ------------------------------------------------
     def _seg_G(self):
+        if ops.PANEL_CACHE is not None:
+            ops.PANEL_CACHE.refresh()                       # every weight panel of the step (G, D, the frozen loss networks): one launch
         fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks = self.forward()
         d_params = [] if self.D is None else list(self.D.parameters())
         for p in d_params:                                  # G's adversarial term needs D's data gradients only (the reference
@@ -787,6 +809,9 @@ class LWGTrainer(object):
     def _capture(self):
         """Warm up on a side stream (every kernel variant launched once: dynamic-LDS attributes are set outside the capture), then
         capture the three segments into graphs that share one memory pool."""
+        import gc
+        self.losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in self.losses.items()}
+        gc.collect()                                        # no autograd graph of an earlier (eager) step may outlive this point
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -48,6 +48,12 @@ def build(name):
         yshape = (B, H, W, N)
         launches.append((spec, dict(epi=ops.EPI_SPADE, xn=rnd(B, H, W, N), mean=(torch.randn(B, N, generator=g) * 0.1).to(DEV),
                                     rstd=(torch.randn(B, N, generator=g) * 0.1 + 1.0).to(DEV))))
+    elif kind == "small":
+        w = r16(torch.randn(N, 6, k, k, generator=g) * (6 * k * k) ** -0.5)
+        x0[..., 6:] = 0
+        spec = packing.spec_to(packing.pack_conv(w, 0.1 * torch.randn(N, generator=g), stride=stride, cin_pad=8), DEV)
+        yshape = (B, H // stride, W // stride, N)
+        launches.append((spec, dict(act=ops.ACT_RELU)))
     else:
         w = r16(torch.randn(N, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5)
         spec = packing.spec_to(packing.pack_conv(w, 0.1 * torch.randn(N, generator=g), stride=stride), DEV)
@@ -79,7 +85,7 @@ def timeit(fn, iters, warm_ms=20.0, hint_us=100.0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="res64,resres,gb64,shared64,skip1,skip0,up2,up1,up0,gb256,shared256,gb128,fq64,enc1")
+    ap.add_argument("--shapes", default="res64,resres,gb64,shared64,skip1,skip0,up2,up1,up0,gb256,shared256,gb128,fq64,enc1")   # + fq128, fq256, enc0
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-f32", action="store_true")
     ap.add_argument("--convs-only", action="store_true")
@@ -88,7 +94,9 @@ def main():
     global BATCH_MUL
     BATCH_MUL = args.batch_mul
     ops.BF16_HR = os.environ.get("LWG_LAB_HR", "1") == "1"
-    print(f"batch x{BATCH_MUL} HR={ops.BF16_HR} HALO={os.environ.get('LWG_BF16_HALO', '(default 1)')} BIG={os.environ.get('LWG_BF16_BIG', '(default 1)')} LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} TILE64={os.environ.get('LWG_BF16_TILE64', '(heuristic)')}")
+    ops.BF16_PW = os.environ.get("LWG_LAB_PW", "1") == "1"
+    ops.BF16_C8 = os.environ.get("LWG_LAB_C8", "1") == "1"
+    print(f"batch x{BATCH_MUL} HR={ops.BF16_HR} PW={ops.BF16_PW} C8={ops.BF16_C8} HALO={os.environ.get('LWG_BF16_HALO', '(default 1)')} BIG={os.environ.get('LWG_BF16_BIG', '(default 1)')} LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} TILE64={os.environ.get('LWG_BF16_TILE64', '(heuristic)')}")
     tot_f, tot_us = 0.0, 0.0
     for name in args.shapes.split(","):
         x0, x1, yshape, launches = build(name)
@@ -97,7 +105,7 @@ def main():
         y32 = torch.full(yshape, float("nan"), device=DEV)
         run(x0, x1, y32, launches, torch.float32)
         y16 = torch.full(yshape, float("nan"), device=DEV, dtype=BF)
-        x0b, x1b = x0.to(BF), None if x1 is None else x1.to(BF)
+        x0b, x1b = (x0 if x0.shape[3] == 8 else x0.to(BF)), None if x1 is None else x1.to(BF)      # the first layer takes the fp32 input
         run(x0b, x1b, y16, launches, BF)
         torch.cuda.synchronize()
         ref = y32.abs().max().item()

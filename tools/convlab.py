@@ -37,6 +37,8 @@ SHAPES = {
     "shared256": (8, 256, 256, 64, 0, 128, 3, 1, "conv"),
     "gb128":    (8, 128, 128, 128, 0, 128, 3, 1, "spade"),
     "fq64":     (8, 64, 64, 256, 0, 256, 1, 1, "conv"),       # 1x1
+    "fq128":    (8, 128, 128, 128, 0, 128, 1, 1, "conv"),
+    "fq256":    (8, 256, 256, 64, 0, 64, 1, 1, "conv"),
     "enc1":     (8, 256, 256, 64, 0, 128, 3, 2, "conv"),      # stride-2 encoder
     "enc0":     (8, 512, 512, 8, 0, 64, 3, 2, "small"),       # first layer, Cin 6 -> 8
     "resres":   (8, 64, 64, 256, 0, 256, 3, 1, "res"),        # residual epilogue
