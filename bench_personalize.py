@@ -29,7 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
-            panel_cache=None, wgrad_side=None):
+            panel_cache=None, wgrad_side=None, branch=None, _keep=None):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -69,8 +69,12 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         topts.use_panel_cache = bool(panel_cache)
     if wgrad_side is not None:
         topts.wgrad_side_stream = bool(wgrad_side)
+    if branch is not None:
+        topts.branch_streams = bool(branch)
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
+    if _keep is not None:
+        _keep["trainer"] = tr
 
     flops = [0.0]
 
@@ -141,7 +145,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
                    "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
                                   f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges overlapped with backward",
                    "step": getattr(tr, "step_mode", "eager launches"),
-                   "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "wgrad_side_stream": bool(getattr(tr.opts, "wgrad_side_stream", False))},
+                   "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "wgrad_side_stream": bool(getattr(tr.opts, "wgrad_side_stream", False)),
+                   "branch_streams": bool(getattr(tr.opts, "branch_streams", False))},
         "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                      "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
@@ -149,6 +154,56 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         "allreduce_overlap": getattr(tr.optimizer_G, "overlapped_ranges", None),
         "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
         "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}
+
+
+def breakdown(dev, size=512, steps=3):
+    """Lab view of one eager step: every forward / data-gradient conv launch (ops.CONV_HOOK) and every weight-gradient launch bracketed
+    with events -> per shape: launches per step, ms per step, achieved TFLOP/s.  Written to gpurun_out/personalize_breakdown.json."""
+    from ipercore_amd import ops
+    from ipercore_amd.trainers import LWGTrainer                           # noqa: F401
+    import bench
+    timer, wtimer = bench.ConvTimer(), bench.ConvTimer()
+    hold = {}
+
+    def build():
+        hold["r"] = measure(dev, steps=1, warmup=0, size=size, graph=False, _keep=hold)
+    build()
+    tr = hold["trainer"]
+    ops.CONV_HOOK = lambda b, M, spec, epi=0: timer(b, M, spec, epi, 4)
+    orig_u, orig_w = ops.conv2d_wgrad_unpacked, ops.conv2d_wgrad
+
+    def wrap(fn):
+        def inner(x0, spec, dy, *a, **kw):
+            M = dy.shape[0] * dy.shape[1] * dy.shape[2] // (spec.omul ** 2)
+            wtimer(True, M, spec, 0, 4)
+            out = fn(x0, spec, dy, *a, **kw)
+            wtimer(False, M, spec, 0, 4)
+            return out
+        return inner
+    ops.conv2d_wgrad_unpacked, ops.conv2d_wgrad = wrap(orig_u), wrap(orig_w)
+    try:
+        tr.optimize_parameters()
+        torch.cuda.synchronize()
+        timer.enabled = wtimer.enabled = True
+        for _ in range(steps):
+            tr.optimize_parameters()
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_HOOK, ops.conv2d_wgrad_unpacked, ops.conv2d_wgrad = None, orig_u, orig_w
+    out = {}
+    for name, t in (("forward_dgrad", timer), ("wgrad", wtimer)):
+        rows = t.breakdown()
+        for r in rows:
+            r["launches"] = r["launches"] / steps
+            r["ms"] = round(r["ms"] / steps, 4)
+        out[name] = rows
+        tot = sum(r["ms"] for r in rows)
+        print(f"== {name}: {tot:.2f} ms per step over {sum(r['launches'] for r in rows):.0f} launches")
+        for r in rows[:28]:
+            print(f"  {r['shape']:44s} n={r['launches']:5.1f} ms={r['ms']:7.3f} TF={r['tflops']:7.1f}")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "personalize_breakdown.json"), "w") as fp:
+        json.dump(out, fp, indent=1)
 
 
 def main():
@@ -167,6 +222,8 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
     ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
     ap.add_argument("--wgrad-side", action="store_true", help="weight gradients on a second stream next to the data gradients")
+    ap.add_argument("--branch-streams", action="store_true", help="the background network on a second stream next to the source / transfer networks")
+    ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,9 +235,11 @@ def main():
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
     assert args.gpus == world
+    if args.breakdown:
+        return breakdown(dev, args.size)
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
                   graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
-                  wgrad_side=True if args.wgrad_side else None)
+                  wgrad_side=True if args.wgrad_side else None, branch=True if args.branch_streams else None)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

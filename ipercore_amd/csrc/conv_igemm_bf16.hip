@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_halo_kernel(const LwgCon
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
-        hoct[p] = (unsigned)((lane & 7) ^ ((hp >> 1) & 7)) * 16u;
+        hoct[p] = (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u;    // swizzle keyed on the halo COLUMN (see the fragment reads)
     }
     unsigned wvoff[PB];
 #pragma unroll
@@ -499,12 +499,17 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_bf16_halo_kernel(const LwgCon
             if (step + 1 < nsteps) issue_b(step + 1, (step + 1) & 1);
             if (tap == 0 && chunk + 1 < nchunks) issue_halo(chunk + 1, (chunk + 1) & 1);
             const int toff = (int)a.dy[tap] * LWG_HALO_W + (int)a.dx[tap];
+            // k-octet o of halo pixel (hy, hx) sits at slot o ^ ((hx >> 1) & 7): keyed on the column, so the two image rows of a
+            // 32-lane fragment read use the SAME permutation (keyed on the linear halo index the second row was rotated by one
+            // slot against the first: tools/probes/lds_bank_probe.hip measures +4 cycles per ds_read_b128 for that, PMC 48 % of the
+            // LDS-active cycles in bank conflicts)
+            const int swt = (((lane & 15) + 1 + (int)a.dx[tap]) >> 1) & 7;
             int abase[TM], asw[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int h = hp0[i] + toff;
                 abase[i] = h << 7;
-                asw[i] = (h >> 1) & 7;
+                asw[i] = swt;
             }
             const char* Bcur = fr_b + (step & 1) * B_STAGE;
             bf16x8 fa[2][TM], fb[2][TN];
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_ke
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
-        hoct[p] = (unsigned)((lane & 7) ^ ((hp >> 1) & 7)) * 16u;
+        hoct[p] = (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u;    // swizzle keyed on the halo COLUMN (see the fragment reads)
     }
     uintx4 hreg[PAH];
     auto load_halo = [&](int chunk) {
@@ -662,9 +667,13 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_ke
         const int r = wm * TM * 32 + i * 32 + (lane & 31);
         hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
     }
-    int toffs[NTAPS];
+    int toffs[NTAPS], tdx[NTAPS];                          // wave-uniform: halo offset of a tap, its column shift
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) toffs[t] = (int)a.dy[t] * LWG_HALO_W + (int)a.dx[t];
+    for (int t = 0; t < NTAPS; ++t) {
+        toffs[t] = (int)a.dy[t] * LWG_HALO_W + (int)a.dx[t];
+        tdx[t] = (int)a.dx[t];
+    }
+    const int hx0 = (lane & 15) + 1;                       // halo column of this lane's pixel for a centred tap
 
     load_halo(0);
 #pragma unroll
@@ -682,12 +691,15 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_ke
             const int step = chunk * NTAPS + tap;
             const int slot = tap % D;
             int abase[TM], asw[TM];
+            int swt = hx0 + tdx[tap];                      // slot permutation keyed on the halo column (see the halo-tile kernel above)
+            asm volatile("" : "+v"(swt));                  // opaque, as h below
+            swt = (swt >> 1) & 7;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 int h = hp0[i] + toffs[tap];
                 asm volatile("" : "+v"(h));                // opaque: otherwise the 72 (tap, row tile) addresses are hoisted out of the chunk loop and spill
                 abase[i] = h << 7;
-                asw[i] = (h >> 1) & 7;
+                asw[i] = swt;
             }
             bf16x8 fa[2][TM];
 #pragma unroll

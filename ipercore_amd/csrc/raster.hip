@@ -8,7 +8,7 @@
 //
 // MI355X design: instead of the upstream per-pixel loop over all 13776 faces (3.6 G tests at 512^2):
 //   1. setup (one lane per face): back-face cull, inverse matrix, conservative pixel bounding box, and the face id is
-//      appended to the list of every 64x64-pixel coarse bin its box touches (atomic cursor per bin; the order inside a
+//      appended to the list of every 32x32-pixel coarse bin its box touches (atomic cursor per bin; the order inside a
 //      list is irrelevant: the depth test is order-independent, ties go to the lowest face id);
 //   2. tiles: one workgroup owns a 16x16 pixel tile and streams only ITS BIN's list in chunks of 256; each lane tests
 //      one face's box against the tile, survivors are compacted into LDS with their 80-byte setup record; every pixel
@@ -44,7 +44,8 @@ __global__ void lwg_project_faces_kernel(const float* __restrict__ verts, const 
 }
 
 // ---- per-face setup: inverse matrix + conservative pixel bounding box ----
-#define LWG_BIN 64  // coarse bin edge in pixels
+#define LWG_BIN 32  // coarse bin edge in pixels (64 in round 1: a 16 x 16 tile then scanned a four times longer list - the scan, not the
+                    // arithmetic, was the rasterizer's time on body tiles)
 __global__ __launch_bounds__(256) void lwg_raster_setup_kernel(const float* __restrict__ faces_v, int nf, int S,
                                                               float* __restrict__ rec, short4* __restrict__ bbox, int nbx,
                                                               int* __restrict__ bin_count, int* __restrict__ bin_list) {
@@ -145,6 +146,13 @@ __device__ __forceinline__ bool lwg_raster_eval(const float* f, float xp, float 
 }
 
 #define LWG_RCHUNK 256
+#define LWG_RPAIRS 12288          // (pixel, candidate) hit list; flushed once it holds more than LWG_RPAIRS - 256 * 32 entries
+// float -> unsigned that orders like the float (total order; the depths are positive, this keeps negative near planes honest)
+__device__ __forceinline__ unsigned lwg_ordered_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __restrict__ rec, const short4* __restrict__ bbox,
                                                               int nf, int S, float near, float far, int nbx,
                                                               const int* __restrict__ bin_count,
@@ -152,8 +160,10 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
                                                               int* __restrict__ fim, float* __restrict__ wim) {
     __shared__ __attribute__((aligned(16))) float srec[LWG_RCHUNK][LWG_REC_FLOATS];
     __shared__ int sid[LWG_RCHUNK];
-    __shared__ int scount;
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long skey[256];      // per pixel: min over the hits of (ordered depth bits << 32 | face id)
+    __shared__ unsigned short spair[LWG_RPAIRS];  // pixel | chunk slot << 8
+    __shared__ int scount, spcount;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.z;
     const int xi = blockIdx.x * 16 + (tid & 15);
     const int r = blockIdx.y * 16 + (tid >> 4);
@@ -162,15 +172,47 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     const int ty1 = S - 1 - blockIdx.y * 16, ty0 = ty1 - 15;
     const float xp = (float)((2.0 * xi + 1 - S) / S);
     const float yp = (float)((2.0 * yi + 1 - S) / S);
-    const float fxi = (float)xi, fyi = (float)yi;
     const float* recb = rec + (size_t)b * nf * LWG_REC_FLOATS;
     const short4* bbb = bbox + (size_t)b * nf;
 
-    // nearest depth wins, exact ties go to the lowest face id: the minimum of (depth, id) - independent of the order in
-    // which candidates are visited
-    float zmin = far;
-    int best = -1;
-    float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f;
+    // Nearest depth wins, exact ties go to the lowest face id: the minimum of (depth, id) over the faces covering the pixel -
+    // independent of the order in which candidates are visited.  Three kinds of work, each at full lane utilisation:
+    //   1. coverage: every pixel runs the three edge tests over the tile's candidates (LDS broadcasts, 32 at a time -> bit mask);
+    //   2. depth: the (pixel, candidate) HITS are appended to a list and evaluated 64 per wave pass (7 IEEE divisions each) -
+    //      with the evaluation inside the candidate loop a wave paid it for every candidate covering ANY of its 64 pixels
+    //      (hands / face tiles: ~200 passes per tile for ~12 passes' worth of hits); the minimum is a 64-bit LDS atomic;
+    //   3. weights: one evaluation per pixel for the winner (the same arithmetic on the same record: the same bits).
+    {   // three quarters of the tiles of a frame lie in bins no face touches: background, no LDS, no barrier
+        const int nb2e = nbx * nbx;
+        if (bin_count[b * nb2e + ((blockIdx.y * 16) / LWG_BIN) * nbx + (blockIdx.x * 16) / LWG_BIN] == 0) {
+            if (xi < S && r < S) {
+                const size_t o = ((size_t)b * S + r) * S + xi;
+                fim[o] = -1;
+                wim[3 * o + 0] = 0.f; wim[3 * o + 1] = 0.f; wim[3 * o + 2] = 0.f;
+            }
+            return;
+        }
+    }
+    skey[tid] = ~0ull;
+    if (tid == 0) spcount = 0;
+
+    auto flush = [&]() {           // all threads; leaves the list empty
+        const int cnt = spcount;
+        for (int p = tid; p < cnt; p += 256) {
+            const int pr = spair[p];
+            const int px = pr & 255, e = pr >> 8;
+            const int pxi = blockIdx.x * 16 + (px & 15);
+            const int pyi = S - 1 - (blockIdx.y * 16 + (px >> 4));
+            const float pxp = (float)((2.0 * pxi + 1 - S) / S);
+            const float pyp = (float)((2.0 * pyi + 1 - S) / S);
+            float w0, w1, w2, zp;
+            if (lwg_raster_eval(&srec[e][0], pxp, pyp, (float)pxi, (float)pyi, near, far, w0, w1, w2, zp) && zp == zp)
+                atomicMin(&skey[px], ((unsigned long long)lwg_ordered_bits(zp) << 32) | (unsigned)sid[e]);
+        }
+        __syncthreads();
+        if (tid == 0) spcount = 0;
+        __syncthreads();
+    };
 
     const int nb2 = nbx * nbx;
     const int bin = b * nb2 + ((blockIdx.y * 16) / LWG_BIN) * nbx + (blockIdx.x * 16) / LWG_BIN;
@@ -193,10 +235,6 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
         }
         __syncthreads();
         const int n = scount;
-        // Coverage first, arithmetic second.  A dense tile (hands, face) has hundreds of candidates but a pixel lies inside
-        // only a few of them; if the full evaluation (7 IEEE divisions) sat in the candidate loop, every wave would pay it
-        // for every candidate that covers ANY of its 64 pixels.  So: 32 candidates at a time, the three edge tests only
-        // (LDS broadcasts) into a per-pixel bit mask, then each pixel evaluates just its own hits.
         for (int e0 = 0; e0 < n; e0 += 32) {
             const int m = min(32, n - e0);
             unsigned word = 0u;
@@ -218,18 +256,42 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
                     word |= (unsigned)(!(o0 | o1 | o2) && (j + u < m)) << (j + u);
                 }
             }
+            // append this pixel's hits: wave-level prefix sum of the hit counts, one LDS cursor bump per wave
+            const int c = __popc(word);
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            int wbase = 0;
+            if (lane == 63 && total > 0) wbase = atomicAdd(&spcount, total);
+            wbase = __shfl(wbase, 63);
+            int pos = wbase + incl - c;
             while (word) {
                 const int e = e0 + __ffs(word) - 1;
                 word &= word - 1;
-                float w0, w1, w2, zp;
-                if (!lwg_raster_eval(&srec[e][0], xp, yp, fxi, fyi, near, far, w0, w1, w2, zp)) continue;
-                const int fid = sid[e];
-                if (zp < zmin || (zp == zmin && best >= 0 && fid < best)) {
-                    zmin = zp; best = fid; wb0 = w0; wb1 = w1; wb2 = w2;
-                }
+                spair[pos++] = (unsigned short)(tid | (e << 8));
             }
+            __syncthreads();
+            if (spcount > LWG_RPAIRS - 256 * 32) flush();      // uniform: read after the barrier, written only inside flush
         }
         __syncthreads();
+        flush();                                               // the records of this chunk are about to be replaced
+    }
+    __syncthreads();
+    const unsigned long long key = skey[tid];
+    int best = -1;
+    float wb0 = 0.f, wb1 = 0.f, wb2 = 0.f;
+    if (key != ~0ull) {
+        best = (int)(unsigned)(key & 0xffffffffull);
+        float rf[LWG_REC_FLOATS];
+        const floatx4* src = reinterpret_cast<const floatx4*>(recb + (size_t)best * LWG_REC_FLOATS);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) *reinterpret_cast<floatx4*>(&rf[4 * k]) = src[k];
+        float zp;
+        lwg_raster_eval(rf, xp, yp, (float)xi, (float)yi, near, far, wb0, wb1, wb2, zp);
     }
     if (xi < S && r < S) {
         const size_t o = ((size_t)b * S + r) * S + xi;
@@ -239,8 +301,8 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
 }
 
 // scratch: setup records + boxes, then per-bin cursors and face lists (worst case every face in every bin;
-// S <= LWG_MAX_BINS_EDGE * 64 = 2048).
-#define LWG_MAX_BINS_EDGE 32
+// S <= LWG_MAX_BINS_EDGE * LWG_BIN = 2048).
+#define LWG_MAX_BINS_EDGE 64
 static size_t lwg_raster_rec_bytes(int B, int nf) { return (size_t)B * nf * (LWG_REC_FLOATS * sizeof(float) + sizeof(short4)); }
 extern "C" size_t lwg_rasterize_ws_bytes(int B, int nf, int S) {
     const int nbx = (S + LWG_BIN - 1) / LWG_BIN;

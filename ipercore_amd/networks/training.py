@@ -372,7 +372,19 @@ class TrainableGenerator(object):
         h, w = tsf_inputs.shape[-2:]
         nhwc = lambda t, cp: F.pad(t.reshape(-1, t.shape[2], h, w).permute(0, 2, 3, 1), (0, cp - t.shape[2])).contiguous()   # noqa: E731
         nchw = lambda t, n: t.permute(0, 3, 1, 2).reshape(bs, n, t.shape[3], h, w)                                             # noqa: E731
-        bg = self.forward_bg(nhwc(bg_inputs, 4))
+        # the background network shares nothing with the source / transfer streams until the losses: on ops.BRANCH_STREAM (installed by
+        # the trainer) it runs next to them - one training sample leaves most layers with fewer workgroups than the chip holds.
+        # Autograd replays each node on the stream of its forward, so the two backward chains overlap the same way.
+        side = ops.BRANCH_STREAM if bg_inputs.is_cuda else None
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            bg4 = nhwc(bg_inputs, 4)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                bg4.record_stream(side)
+                bg = self.forward_bg(bg4)
+        else:
+            bg = self.forward_bg(nhwc(bg_inputs, 4))
         enc, res, s_img, s_mask = self.forward_src(nhwc(src_inputs, 8))
         imgs, masks = [], []
         for t in range(nt):
@@ -383,5 +395,8 @@ class TrainableGenerator(object):
             img, mask = self.forward_tsf(nhwc(tsf_inputs[:, t:t + 1], 8), e, r, Tst[:, t].contiguous())
             imgs.append(img)
             masks.append(mask)
+        if side is not None:
+            cur.wait_stream(side)
+            bg.record_stream(cur)
         return (nchw(bg, nb), nchw(s_img, ns), nchw(s_mask, ns),
                 nchw(torch.cat(imgs, dim=0), nt), nchw(torch.cat(masks, dim=0), nt))

@@ -562,14 +562,24 @@ class PanelCache:
     start of the step (no weight changes between that point and its last use within a step: Adam(G) runs after G's backward,
     Adam(D) at the end).  The weights are held by reference, so a registered address is never recycled."""
 
-    def __init__(self):
+    def __init__(self, params=()):
+        """params: the tensors whose STORAGE may be cached from (module parameters / flat optimizer buffers).  A weight assembled per
+        call (e.g. the concatenated image + mask regressors of the fused head's backward) lives in a temporary: its address
+        changes every step, so it is packed by a single launch each time and never registered."""
         self.out, self.rows, self.keep, self.table, self.blocks = {}, [], [], None, 0
+        self.storages = {p.untyped_storage().data_ptr() for p in params}
+
+    def cacheable(self, w):
+        return w.untyped_storage().data_ptr() in self.storages
 
     def get(self, w, transposed, kidx, cin, cin_pad, nout, n_pad):
         key = (w.data_ptr(), tuple(w.shape), bool(transposed), kidx, cin, cin_pad, nout, n_pad)
         hit = self.out.get(key)
         if hit is not None:
             return hit, False
+        if self.table is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PanelCache: a panel was requested for the first time inside a hipGraph capture (the table upload is "
+                               "not capturable): run one eager step before capturing")
         D0, D1, KH, KW = w.shape
         Kp = (len(kidx) * cin_pad + 31) // 32 * 32
         out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
@@ -600,6 +610,7 @@ class PanelCache:
 
 PANEL_CACHE = None      # a PanelCache while a trainer step runs (trainers.LWGTrainer), else None: every pack_panel call launches
 WGRAD_STREAM = None     # a torch.cuda.Stream while a trainer step wants its weight gradients next to the data gradients, else None
+BRANCH_STREAM = None    # a torch.cuda.Stream while a trainer step runs the background network next to the source / transfer streams
 
 
 def pack_panel(w, transposed, kidx, cin, cin_pad, nout, n_pad):
@@ -611,7 +622,7 @@ def pack_panel(w, transposed, kidx, cin, cin_pad, nout, n_pad):
     kidx = tuple(int(k) for k in kidx)
     ntaps = len(kidx)
     Kp = (ntaps * cin_pad + 31) // 32 * 32
-    if PANEL_CACHE is not None:
+    if PANEL_CACHE is not None and PANEL_CACHE.cacheable(w):
         out, fresh = PANEL_CACHE.get(w, transposed, kidx, cin, cin_pad, nout, n_pad)
         if not fresh:
             return out

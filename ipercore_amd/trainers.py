@@ -501,6 +501,9 @@ class TrainOpts(object):
     # weight gradient of a layer on a second stream next to its data gradient (fork / join per layer: graph edges when captured);
     # one training sample leaves most layers with fewer workgroups than the chip holds, the two launches fill it together
     wgrad_side_stream = False
+    # the background network (forward and, through autograd's stream replay, backward) on a second stream next to the source / transfer
+    # networks: independent until the losses
+    branch_streams = False
     allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
 
     @classmethod
@@ -724,11 +727,15 @@ class LWGTrainer(object):
         """:326-352, plus the gradient all-reduce when the step is data parallel."""
         on_gpu = torch.cuda.is_available() and next(self.G.parameters()).is_cuda
         if on_gpu and getattr(self.opts, "use_panel_cache", False) and getattr(self, "_panel_cache", None) is None:
-            self._panel_cache = ops.PanelCache()
+            nets = [self.G, self.D, self.crt_tsf, self.crt_face]               # the loss criteria are nn.Modules holding their frozen networks
+            self._panel_cache = ops.PanelCache([p for n in nets if n is not None for p in list(n.parameters()) + list(n.buffers())])
         if on_gpu and getattr(self.opts, "wgrad_side_stream", False) and getattr(self, "_wgrad_stream", None) is None:
             self._wgrad_stream = torch.cuda.Stream()
-        prev = ops.PANEL_CACHE, ops.WGRAD_STREAM
+        if on_gpu and getattr(self.opts, "branch_streams", False) and getattr(self, "_branch_stream", None) is None:
+            self._branch_stream = torch.cuda.Stream()
+        prev = ops.PANEL_CACHE, ops.WGRAD_STREAM, ops.BRANCH_STREAM
         ops.PANEL_CACHE, ops.WGRAD_STREAM = getattr(self, "_panel_cache", None), getattr(self, "_wgrad_stream", None)
+        ops.BRANCH_STREAM = getattr(self, "_branch_stream", None)
         try:
             with ops.conv_precision(self.opts.conv_precision):
                 if self._graphable():
@@ -736,7 +743,7 @@ class LWGTrainer(object):
                 self.step_mode = "eager launches"
                 return self._optimize_parameters()
         finally:
-            ops.PANEL_CACHE, ops.WGRAD_STREAM = prev
+            ops.PANEL_CACHE, ops.WGRAD_STREAM, ops.BRANCH_STREAM = prev
 
     # ---- the step in three segments (the data-parallel exchanges sit between them) ------------------------------------------------
     def _seg_G(self):
@@ -788,8 +795,11 @@ class LWGTrainer(object):
             try:
                 self._capture()
             except Exception as e:                          # fall back to eager launches, loudly
+                import traceback
                 import warnings
-                warnings.warn(f"LWGTrainer: capturing the step as a hipGraph failed ({type(e).__name__}: {e}); running eager launches")
+                where = "".join(traceback.format_tb(e.__traceback__)[-4:])
+                warnings.warn(f"LWGTrainer: capturing the step as a hipGraph failed ({type(e).__name__}: {e}); running eager launches.  "
+                              f"Raised at:\n{where}")
                 self._graph_failed, self._graphs = True, None
                 torch.cuda.synchronize()
                 self.step_mode = "eager launches (graph capture failed)"
