@@ -29,7 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
-            panel_cache=None, wgrad_side=None, branch=None, _keep=None):
+            panel_cache=None, branch=None, _keep=None):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -67,8 +67,6 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         topts.use_graph = bool(graph)
     if panel_cache is not None:
         topts.use_panel_cache = bool(panel_cache)
-    if wgrad_side is not None:
-        topts.wgrad_side_stream = bool(wgrad_side)
     if branch is not None:
         topts.branch_streams = bool(branch)
     tr = LWGTrainer(G, D, opts=topts)
@@ -145,8 +143,7 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
                    "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
                                   f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges overlapped with backward",
                    "step": getattr(tr, "step_mode", "eager launches"),
-                   "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "wgrad_side_stream": bool(getattr(tr.opts, "wgrad_side_stream", False)),
-                   "branch_streams": bool(getattr(tr.opts, "branch_streams", False))},
+                   "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "branch_streams": bool(getattr(tr.opts, "branch_streams", False))},
         "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                      "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
@@ -221,8 +218,8 @@ def main():
                     help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
     ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
-    ap.add_argument("--wgrad-side", action="store_true", help="weight gradients on a second stream next to the data gradients")
-    ap.add_argument("--branch-streams", action="store_true", help="the background network on a second stream next to the source / transfer networks")
+    ap.add_argument("--no-branch-streams", dest="branch_streams", action="store_false",
+                    help="the background network and the source decoder on the main stream (round-2 default: a second stream)")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +236,7 @@ def main():
         return breakdown(dev, args.size)
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
                   graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
-                  wgrad_side=True if args.wgrad_side else None, branch=True if args.branch_streams else None)
+                  branch=None if args.branch_streams else False)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -43,10 +43,10 @@ __device__ __forceinline__ float lwg_bf16_lo(unsigned u) { return __builtin_bit_
 __device__ __forceinline__ float lwg_bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
 // D^T accumulator tiles -> bf16 NHWC with the fused epilogue (shared by the kernel variants below).
-// SPATIAL = false: GEMM row m_base + r is output position (b, oy, ox) in row-major order.  SPATIAL = true (the halo-tile kernel):
+// SPATIAL = 0: GEMM row m_base + r is output position (b, oy, ox) in row-major order.  SPATIAL = 1 (the halo-tile kernels):
 // the workgroup's 128 rows are the 8 x 16 pixel block whose corner (image tb, row ty0, column tx0) the caller passes; row r is
 // pixel (ty0 + r / 16, tx0 + r % 16) and rows outside the image are dead.
-template <int TM, int TN, int EPI, bool SPATIAL = false>
+template <int TM, int TN, int EPI, int SPATIAL = 0>
 __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
                                                   int lane, int tb = 0, int ty0 = 0, int tx0 = 0) {
     const int khalf = lane >> 5;
@@ -99,7 +99,8 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
         int bimg = 0;
         if (SPATIAL) {
             const int r = wm * TM * 32 + i * 32 + (lane & 31);
-            const int oy = ty0 + (r >> 4), ox = tx0 + (r & 15);
+            // SPATIAL == 2 (the row-renaming kernel): row tile i of a wave = image rows (i, i + TM) of its 2*TM rows
+            const int oy = ty0 + (SPATIAL == 2 ? wm * 2 * TM + i + TM * ((lane >> 4) & 1) : (r >> 4)), ox = tx0 + (r & 15);
             live = oy < a.OH && ox < a.OW;
             bimg = tb;
             opix = live ? ((size_t)tb * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox) : 0;
@@ -728,6 +729,169 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_ke
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Row renaming: the register-streamed-weights kernel above reads ONE 1 KB activation fragment from LDS per MFMA; with eight waves
+// per CU that is 128 B / clock - the LDS port is exactly as busy as the matrix pipe would be at 100 % (PMC: matrix pipe 52 %).
+// Here a wave's row tile i is the image-row PAIR (i, i + TM) of its 2*TM rows instead of (2i, 2i + 1).  A tap's vertical shift then
+// maps row tile i onto row tile i + dy: the fragments E_e = rows (e + dymin, e + dymin + TM), e = 0 .. TM + NDY - 2, are read once
+// per (tap column, k-step) and feed ALL NDY vertical taps by register renaming - TM + NDY - 1 reads for NDY * TM MFMAs (6 for 12 on
+// the 3x3 layers, 5 for 8 on the 2x2-tap up-sampling launches), no shuffles.  Their addresses differ by a constant (one halo row),
+// so a (tap column, k-step) costs one address computation.  Weights: the same panel and a ring of 4 * D fragments refilled one
+// fragment at a time; taps must be an ascending NDY x NDX grid (the host sorts them).
+template <int NDY, int NDX, int EPI, int WAVES_M>
+__global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void lwg_conv_bf16_hr2_kernel(const LwgConvArgs a) {
+    constexpr int NTAPS = NDY * NDX;
+    constexpr int WAVES_N = 4 / WAVES_M, TM = 4 / WAVES_M, BN = WAVES_N * 32;
+    constexpr int NE = TM + NDY - 1;                         // fragments per (tap column, k-step)
+    constexpr int FPC = NDX * 4 * NDY;                       // weight fragments per 64-channel chunk, in consumption order (dx, ks, dy)
+    constexpr int R = NTAPS == 9 ? 12 : 8;                   // ring: the same look-ahead as the kernel above (3 / 2 K-steps)
+    static_assert(FPC % R == 0, "the weight ring must close at a chunk boundary");
+    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;
+    constexpr int ROWB = LWG_HALO_W * 128;                   // bytes between two halo rows
+
+    extern __shared__ __attribute__((aligned(16))) char smem_r2[];
+    char* Ah = smem_r2;                                      // [2][LWG_HALO_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int tiles_n = a.N / BN;
+    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % tiles_n;
+    int rest = lid / tiles_n;
+    const int tix = rest % tiles_x;
+    rest /= tiles_x;
+    const int tiy = rest % tiles_y, tb = rest / tiles_y;
+    const int x0 = tix * 16, y0 = tiy * 8;
+    const int n_base = tile_n * BN;
+
+    const int Cin = a.C0 + a.C1;
+    const int nchunks = Cin >> 6;
+    const int nfrags = nchunks * FPC;
+    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
+    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 2u;
+    const unsigned wbytes = (unsigned)nchunks * NTAPS * (unsigned)a.N * 128u;
+
+    int hpixlin[PAH];
+    unsigned hoct[PAH];
+#pragma unroll
+    for (int p = 0; p < PAH; ++p) {
+        const int hp = (wid * PAH + p) * 8 + (lane >> 3);
+        const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
+        hoct[p] = (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u;
+    }
+    uintx4 hreg[PAH];
+    auto load_halo = [&](int chunk) {
+        const int cc = chunk << 6;
+        const bool use1 = cc >= a.C0;
+        const void* src = use1 ? (const void*)a.x1 : (const void*)a.x0;
+        const unsigned cs = (unsigned)(use1 ? a.C1 : a.C0);
+        const unsigned soff = (unsigned)(cc - (use1 ? a.C0 : 0)) * 2u;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(use1 ? bytes1 : bytes0), 0x00020000);
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            const unsigned voff = hpixlin[p] >= 0 ? (unsigned)hpixlin[p] * cs * 2u + hoct[p] : LWG_OOB_OFFSET;
+            hreg[p] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, (int)soff, 0));
+        }
+    };
+    auto store_halo = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PAH; ++p) {
+            const int q = wid * PAH + p;
+            if (q < LWG_HALO_PIECES) *reinterpret_cast<uintx4*>(Ah + buf * LWG_HALO_BYTES + q * 1024 + lane * 16) = hreg[p];
+        }
+    };
+
+    const int khalf = lane >> 5;
+    const unsigned wv = (unsigned)((n_base + wn * 32 + (lane & 31)) * 32 + khalf * 16);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
+    bf16x8 bq[R];
+    // weight fragment number ql of a chunk (consumption order: tap column, k-step, tap row) -> its place in the panel
+    auto load_w = [&](int chunk, int ql, int slot) {
+        const int dxi = ql / (4 * NDY), ks = (ql / NDY) & 3, dyi = ql % NDY;
+        const int step = chunk * NTAPS + dyi * NDX + dxi;
+        bq[slot] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wv, (int)((unsigned)(step * 4 + ks) * (unsigned)a.N * 32u), 0));
+    };
+
+    floatx16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    const int dymin = (int)a.dy[0], dxmin = (int)a.dx[0];
+    const int hx0 = (lane & 15) + 1;                       // halo column of this lane's pixel for a centred tap
+    // halo pixel of fragment E_0 for the first tap column: image row wm*2*TM + dymin + TM * (second half of the 32 lanes)
+    const int prow0 = (wm * 2 * TM + dymin + TM * ((lane >> 4) & 1) + 1) * LWG_HALO_W + hx0 + dxmin;
+
+    load_halo(0);
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        if (q < nfrags) load_w(0, q, q);
+    store_halo(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
+        const bool more = chunk + 1 < nchunks;
+        if (more) load_halo(chunk + 1);                    // lands during this chunk's MFMAs
+        bf16x8 E[2][NE];
+        auto read_e = [&](int g, int buf) {                // fragments of group g = (tap column, k-step)
+            const int dxi = g >> 2, ks = g & 3;
+            int px = prow0 + dxi;
+            asm volatile("" : "+v"(px));                   // opaque: keeps the per-group addresses out of the chunk-invariant code motion
+            const int sw = ((hx0 + dxmin + dxi) >> 1) & 7;
+            const char* p = Acur + (px << 7) + (((2 * ks + khalf) ^ sw) << 4);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) E[buf][e] = *reinterpret_cast<const bf16x8*>(p + e * ROWB);
+        };
+        read_e(0, 0);
+#pragma unroll
+        for (int g = 0; g < NDX * 4; ++g) {
+            if (g + 1 < NDX * 4) read_e(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NE, 0);                    // the next group's DS reads first ...
+#pragma unroll
+            for (int dyi = 0; dyi < NDY; ++dyi) {
+                const int ql = g * NDY + dyi;
+                const int slot = ql % R;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot], E[g & 1][i + dyi], acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                // ... then the MFMAs of this tap row
+                const int nq = ql + R;                                             // refill the slot just consumed
+                if (nq < FPC) load_w(chunk, nq, slot);
+                else if (more) load_w(chunk + 1, nq - FPC, slot);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            store_halo((chunk + 1) & 1);                   // the other buffer: every wave left it at the previous chunk's barrier
+            __syncthreads();
+        }
+    }
+    lwg_bf16_epilogue<TM, 1, EPI, 2>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
+}
+
+template <int NDY, int NDX, int EPI, int WAVES_M>
+static hipError_t launch_cfg_bf16_hr2(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES;
+    auto kern = lwg_conv_bf16_hr2_kernel<NDY, NDX, EPI, WAVES_M>;
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / (128 / WAVES_M));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+// taps are an ascending row-major NDY x NDX grid of consecutive offsets?
+static bool lwg_bf16_tap_grid(const LwgConvArgs& a, int ndy, int ndx) {
+    if (a.ntaps != ndy * ndx) return false;
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.dy[t] != a.dy[0] + t / ndx || a.dx[t] != a.dx[0] + t % ndx) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Pointwise (1 x 1, stride 1, C -> C) kernel: the query projections fq of the attention blocks.  K is one to four 64-channel
 // chunks - the tiled kernels above spend such a launch in prologue / epilogue and one memory round trip per K-step (0.18 of the
 // HBM rate).  Here the whole weight matrix lives in registers (a wave owns 32 columns: K/16 fragments = 16..64 VGPRs), a
@@ -935,6 +1099,13 @@ static hipError_t launch_cfg_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
 
 template <int EPI>
 static hipError_t launch_epi_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
+    static int hr2 = -1;
+    if (hr2 < 0) {
+        const char* ev = getenv("LWG_BF16_HR2");     // lab knob: 0 = the one-fragment-per-MFMA kernel for every launch
+        hr2 = ev ? atoi(ev) : 1;
+    }
+    if (hr2 && lwg_bf16_tap_grid(a, 3, 3)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<3, 3, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<3, 3, EPI, 2>(a, stream);
+    if (hr2 && lwg_bf16_tap_grid(a, 2, 2)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<2, 2, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<2, 2, EPI, 2>(a, stream);
     if (a.N % 128 == 0) {
         if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3, 1>(a, stream);
         return launch_cfg_bf16_hr<4, EPI, 2, 1>(a, stream);

@@ -91,19 +91,15 @@ class ConvFn(torch.autograd.Function):
         Cin_packed = specs[0].Cin
         want_dw = ctx.needs_input_grad[2]                            # frozen weights (the VGG19 of the perceptual loss): data gradient only
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
-        # parameter gradients on ops.WGRAD_STREAM when the trainer installed one: forked here (dy is final), joined before returning
-        side = ops.WGRAD_STREAM if (dy.is_cuda and (want_dw or want_db)) else None
-        cur = torch.cuda.current_stream() if side is not None else None
-        if side is not None:
-            side.wait_stream(cur)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            db = ops.colsum(dy)[:N] if want_db else None
-            dw = None
-            if want_dw:
-                if cfg.kind == "conv":
-                    dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N)
-                else:
-                    dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N)
+        # (the weight gradient on a second stream next to the data gradient was tried twice - eager launches: 53.6 vs 48.6 ms in round 1,
+        # captured step: 32.4 vs 32.2 ms in round 2 - and removed: both launches already fill the chip)
+        db = ops.colsum(dy)[:N] if want_db else None
+        dw = None
+        if want_dw:
+            if cfg.kind == "conv":
+                dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N)
+            else:
+                dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N)
         if cfg.kind == "conv":
             Nw, Cin, kh, kw = weight.shape
             dx = None
@@ -126,8 +122,6 @@ class ConvFn(torch.autograd.Function):
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
                 ops.conv2d(dy, dspec, dx, splitk=True)
-        if side is not None:
-            cur.wait_stream(side)
         dx0 = dx1 = None
         if dx is not None:
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
@@ -333,8 +327,9 @@ class TrainableGenerator(object):
             i += 3
         return torch.tanh(self.cv(f"bg_net.main.{i}", x, pad=3, n_pad=64))
 
-    def forward_src(self, src8):
-        """(n,S,S,8) -> (enc list, res list, img (n,S,S,3), mask (n,S,S,1))   (:450-478, only_enc=False)."""
+    def forward_src(self, src8, side=None):
+        """(n,S,S,8) -> (enc list, res list, img (n,S,S,3), mask (n,S,S,1))   (:450-478, only_enc=False).  side: a stream for the
+        decoder + regressors (the caller joins it)."""
         x, enc, res = src8, [], []
         for i in range(self.n_down):
             x = self.cv(f"src_net.encoders.layers.{i}.0", x, stride=2, act=_RELU, cin_pad=8 if i == 0 else None, need_dx=i != 0)
@@ -342,9 +337,16 @@ class TrainableGenerator(object):
         for i in range(self.n_res):
             x = self.res_block(f"src_net.res_blocks.{i}", x)
             res.append(x)
-        for i in range(self.n_down):
-            x = self.cv(f"src_net.decoders.layers.{i}.0", x, kind="convT", act=_RELU)
-        img, mask = self.head("src_net.img_reg.0", "src_net.att_reg.0", x)
+        # the source decoder + regressors feed only the reconstruction losses: on the branch stream (behind the background
+        # network) they overlap the transfer stream, which needs just enc / res
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())   # x is final on the main stream
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if side is not None:
+                x.record_stream(side)
+            for i in range(self.n_down):
+                x = self.cv(f"src_net.decoders.layers.{i}.0", x, kind="convT", act=_RELU)
+            img, mask = self.head("src_net.img_reg.0", "src_net.att_reg.0", x)
         return enc, res, img, mask
 
     def forward_tsf(self, tsf8, enc_src, res_src, Tst):
@@ -385,7 +387,7 @@ class TrainableGenerator(object):
                 bg = self.forward_bg(bg4)
         else:
             bg = self.forward_bg(nhwc(bg_inputs, 4))
-        enc, res, s_img, s_mask = self.forward_src(nhwc(src_inputs, 8))
+        enc, res, s_img, s_mask = self.forward_src(nhwc(src_inputs, 8), side=side)
         imgs, masks = [], []
         for t in range(nt):
             if bs == 1:
@@ -397,6 +399,7 @@ class TrainableGenerator(object):
             masks.append(mask)
         if side is not None:
             cur.wait_stream(side)
-            bg.record_stream(cur)
+            for v in (bg, s_img, s_mask):
+                v.record_stream(cur)
         return (nchw(bg, nb), nchw(s_img, ns), nchw(s_mask, ns),
                 nchw(torch.cat(imgs, dim=0), nt), nchw(torch.cat(masks, dim=0), nt))

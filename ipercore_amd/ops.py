@@ -107,6 +107,12 @@ def _hr_eligible(spec, x0, y, out_hw):
     return (OH, OW) == (x0.shape[1], x0.shape[2])
 
 
+def _hr_tap_order(spec):
+    """Tap permutation of the register-streamed panel: ascending in (dy, dx) - the row-renaming kernel wants an NDY x NDX grid in
+    row-major order (a transposed convolution's parity launches list their taps descending)."""
+    return sorted(range(spec.ntaps), key=lambda t: (spec.dy[t], spec.dx[t]))
+
+
 def _w16hr(spec, spade):
     """(panel, bias) of lwg_conv2d_nhwc_bf16_hr: [ntaps*Cin/64][4][N][16] bf16, k = ((c/64)*ntaps + tap)*64 + c%64 split as
     ks*16 + e; for the SPADE epilogue the gamma | beta columns (and the bias) are re-interleaved from blocks of 32 to blocks of 16
@@ -115,7 +121,8 @@ def _w16hr(spec, spade):
     if spec._w16hr is None or spec._w16hr[0] != key or spec._w16hr[1].device != spec.w.device:
         K4, N, _ = spec.w.shape
         cin, nt = spec.Cin, spec.ntaps
-        wk = spec.w.permute(0, 2, 1).reshape(cin // 64, 2, nt, 32, N).permute(0, 2, 1, 3, 4).reshape(cin // 64 * nt, 64, N)   # [step][k%64][n]
+        wk = spec.w.permute(0, 2, 1).reshape(cin // 64, 2, nt, 32, N).permute(0, 2, 1, 3, 4).reshape(cin // 64, nt, 64, N)    # [chunk][tap][k%64][n]
+        wk = wk[:, _hr_tap_order(spec)].reshape(cin // 64 * nt, 64, N)                                                          # taps ascending in (dy, dx)
         bias = spec.bias
         if spade:
             j = torch.arange(N, device=spec.w.device)
@@ -215,6 +222,8 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         if _hr_eligible(spec, x0, y, out_hw) or _pw_eligible(spec, x0, y, x1, epi, out_hw):
             panel, bias = _w16hr(spec, epi == EPI_SPADE)
             a.w, a.bias = _ptr(panel, torch.bfloat16), _ptr(bias)
+            for i, t in enumerate(_hr_tap_order(spec)):              # the panel's tap order
+                a.dy[i], a.dx[i] = spec.dy[t], spec.dx[t]
             _lib.check(_lib.lib().lwg_conv2d_nhwc_bf16_hr(a, _stream()), "lwg_conv2d_nhwc_bf16_hr")
         else:
             a.w = _ptr(_w16v2(spec), torch.bfloat16)
@@ -609,7 +618,6 @@ class PanelCache:
 
 
 PANEL_CACHE = None      # a PanelCache while a trainer step runs (trainers.LWGTrainer), else None: every pack_panel call launches
-WGRAD_STREAM = None     # a torch.cuda.Stream while a trainer step wants its weight gradients next to the data gradients, else None
 BRANCH_STREAM = None    # a torch.cuda.Stream while a trainer step runs the background network next to the source / transfer streams
 
 
