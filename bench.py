@@ -481,6 +481,13 @@ def main():
     if args.precision != "fp32":
         im.generator.conv_precision = args.precision
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    if rank == 0:                                                # what tools/pmc_summary.py stamps the PMC traffic file with
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_last_config.json"), "w") as fp:
+                json.dump({"frame_batch": FB, "image_size": S, "precision": args.precision, "workload": args.workload, "frames": n_clip}, fp)
+        except OSError:
+            pass
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")          # sequence-global pre-pass, every rank identically
     act_bytes = 2 if args.precision == "bf16" else 4
 
@@ -581,7 +588,9 @@ def main():
             if tpath and S == (512 if args.precision == "fp32" else 1024) and args.streams == 1 and os.path.exists(tpath):
                 with open(tpath) as fp:
                     tj = json.load(fp)
-                traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                cfg = tj.get("bench_config") or {}
+                if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload:   # same launches
+                    traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             if args.precision == "split":

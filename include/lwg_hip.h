@@ -99,6 +99,12 @@ int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* args, lwg_stream_t stream);
  * k-octet, no LDS); args->w = bf16 panel [ceil(ntaps/2)][64][16], element [ks][n][e] = weight of column n at k = 16 ks + e,
  * k = tap*8 + c, zero past ntaps*8. */
 int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* args, lwg_stream_t stream);
+/* nn.ConvTranspose2d(kernel 4, stride 2, padding 1) (attlwb_spade_resunet.py:331-340 SkipDecoder upconvs) on bf16 NHWC in ONE
+ * launch: the four output parities read the same input block, staged once.  args = the launch description of the parity-(0,0)
+ * launch (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2H, YW = 2W; dy / dx / ooy / oox ignored: parity (py, px) uses
+ * dy in {py-1, py}, dx in {px-1, px} and writes pixels (2y + py, 2x + px)); args->w = the four register-streamed panels
+ * [parity = 2 py + px][Cin/64 * 4][4][N][16], taps ascending in (dy, dx); C0 = 64 or 128, C1 = 0, N % 64 == 0, LWG_EPI_NONE. */
+int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
 
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs

@@ -892,6 +892,152 @@ static bool lwg_bf16_tap_grid(const LwgConvArgs& a, int ndy, int ndx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(4, 2, 1) as ONE launch: the four output parities (2x2 taps each) of a transposed convolution read the same
+// input block.  As four launches the last up-sampling layer (128 -> 64 channels at full resolution) reads its input four times and is
+// HBM-governed (259 us per parity launch at 1024^2 x 8 frames against a 160 us byte floor).  Here a workgroup stages the halo of its
+// 8 x 16 input pixels ONCE - every 64-channel chunk resident (Cin <= 128: 46 KB) - and walks the parities: per parity the row-renaming
+// K loop above with NDY = NDX = 2 (dy in {py - 1, py}, dx in {px - 1, px}), then the epilogue into the (2y + py, 2x + px) pixels.  No
+// barrier after the staging; the weight ring runs through the four panels without a bubble.
+template <int NCH, int WAVES_M>
+__global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_up4_kernel(const LwgConvArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M, TM = 4 / WAVES_M, BN = WAVES_N * 32;
+    constexpr int NDY = 2, NDX = 2, NTAPS = 4, NE = TM + NDY - 1, FPC = NDX * 4 * NDY, R = 8, FPP = NCH * FPC;   // FPP: fragments per parity
+    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;
+    constexpr int ROWB = LWG_HALO_W * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_u[];
+    char* Ah = smem_u;                                       // [NCH][LWG_HALO_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int tiles_n = a.N / BN;
+    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % tiles_n;
+    int rest = lid / tiles_n;
+    const int tix = rest % tiles_x;
+    rest /= tiles_x;
+    const int tiy = rest % tiles_y, tb = rest / tiles_y;
+    const int x0 = tix * 16, y0 = tiy * 8;
+    const int n_base = tile_n * BN;
+
+    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
+    const unsigned ppanel = (unsigned)NCH * NTAPS * (unsigned)a.N * 128u;           // bytes of one parity's panel
+    {
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0), 0, (int)bytes0, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uintx4 hreg[PAH];
+#pragma unroll
+            for (int p = 0; p < PAH; ++p) {
+                const int hp = (wid * PAH + p) * 8 + (lane >> 3);
+                const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
+                const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+                const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const unsigned voff = ok ? (unsigned)((tb * a.H + gy) * a.W + gx) * (unsigned)a.C0 * 2u + (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u
+                                         : LWG_OOB_OFFSET;
+                hreg[p] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, c * 128, 0));
+            }
+#pragma unroll
+            for (int p = 0; p < PAH; ++p) {
+                const int q = wid * PAH + p;
+                if (q < LWG_HALO_PIECES) *reinterpret_cast<uintx4*>(Ah + c * LWG_HALO_BYTES + q * 1024 + lane * 16) = hreg[p];
+            }
+        }
+    }
+
+    const int khalf = lane >> 5;
+    const unsigned wv = (unsigned)((n_base + wn * 32 + (lane & 31)) * 32 + khalf * 16);
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(4u * ppanel), 0x00020000);
+    bf16x8 bq[R];
+    auto load_w = [&](int parity, int qp, int slot) {      // fragment qp of a parity: (chunk, tap column, k-step, tap row)
+        const int chunk = qp / FPC, ql = qp % FPC;
+        const int dxi = ql / (4 * NDY), ks = (ql / NDY) & 3, dyi = ql % NDY;
+        const int step = chunk * NTAPS + dyi * NDX + dxi;
+        bq[slot] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+            rW, (int)wv, (int)((unsigned)parity * ppanel + (unsigned)(step * 4 + ks) * (unsigned)a.N * 32u), 0));
+    };
+#pragma unroll
+    for (int q = 0; q < R; ++q) load_w(0, q, q);
+    const int hx0 = (lane & 15) + 1;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int parity = 0; parity < 4; ++parity) {
+        const int py = parity >> 1, px = parity & 1;
+        floatx16 acc[TM][1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        const int prow0 = (wm * 2 * TM + (py - 1) + TM * ((lane >> 4) & 1) + 1) * LWG_HALO_W + hx0 + (px - 1);
+#pragma unroll
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const char* Acur = Ah + chunk * LWG_HALO_BYTES;
+            bf16x8 E[2][NE];
+            auto read_e = [&](int g, int buf) {
+                const int dxi = g >> 2, ks = g & 3;
+                int pxl = prow0 + dxi;
+                asm volatile("" : "+v"(pxl));
+                const int sw = ((hx0 + (px - 1) + dxi) >> 1) & 7;
+                const char* p = Acur + (pxl << 7) + (((2 * ks + khalf) ^ sw) << 4);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) E[buf][e] = *reinterpret_cast<const bf16x8*>(p + e * ROWB);
+            };
+            read_e(0, 0);
+#pragma unroll
+            for (int g = 0; g < NDX * 4; ++g) {
+                if (g + 1 < NDX * 4) read_e(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, NE, 0);
+#pragma unroll
+                for (int dyi = 0; dyi < NDY; ++dyi) {
+                    const int qp = chunk * FPC + g * NDY + dyi;
+                    const int slot = qp % R;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot], E[g & 1][i + dyi], acc[i][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                    const int nq = qp + R;                 // refill: this parity's later fragments, then the next parity's first ones
+                    if (nq < FPP) load_w(parity, nq, slot);
+                    else if (parity < 3) load_w(parity + 1, nq - FPP, slot);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        LwgConvArgs ap = a;
+        ap.ooy = py;
+        ap.oox = px;
+        lwg_bf16_epilogue<TM, 1, LWG_EPI_NONE, 2>(ap, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
+    }
+}
+
+template <int NCH, int WAVES_M>
+static hipError_t launch_cfg_bf16_up4(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (size_t)NCH * LWG_HALO_BYTES;
+    auto kern = lwg_conv_bf16_up4_kernel<NCH, WAVES_M>;
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / (128 / WAVES_M));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+// nn.ConvTranspose2d(kernel 4, stride 2, padding 1) on bf16 NHWC in one launch.  args: the launch description of the parity-(0,0)
+// launch (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2H, YW = 2W); args->dy / dx / ooy / oox are ignored (parity (py, px)
+// uses dy in {py-1, py}, dx in {px-1, px} and writes pixels (2y + py, 2x + px)); args->w = the four register-streamed panels
+// [parity = 2 py + px][Cin/64 * 4][4][N][16], each with its taps ascending in (dy, dx).  Cin = 64 or 128, no second input,
+// N % 64 == 0, LWG_EPI_NONE (bias + activation).
+extern "C" int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.C1 != 0 || (a.C0 != 64 && a.C0 != 128)) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16 || a.stride != 1 || a.H != a.OH || a.W != a.OW || a.omul != 2) return (int)hipErrorInvalidValue;
+    if (a.YH != 2 * a.OH || a.YW != 2 * a.OW || a.N % 64 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0 || a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.B * a.H * a.W * (unsigned long long)a.C0 * 2ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if (a.N % 128 == 0) return (int)(a.C0 == 64 ? launch_cfg_bf16_up4<1, 1>(a, stream) : launch_cfg_bf16_up4<2, 1>(a, stream));
+    return (int)(a.C0 == 64 ? launch_cfg_bf16_up4<1, 2>(a, stream) : launch_cfg_bf16_up4<2, 2>(a, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Pointwise (1 x 1, stride 1, C -> C) kernel: the query projections fq of the attention blocks.  K is one to four 64-channel
 // chunks - the tiled kernels above spend such a launch in prologue / epilogue and one memory round trip per K-step (0.18 of the
 // HBM rate).  Here the whole weight matrix lives in registers (a wave owns 32 columns: K/16 fragments = 16..64 VGPRs), a

@@ -255,9 +255,7 @@ class AttentionLWBGenerator(nn.Module):
     def _upconv(x, specs, act):
         B, H, W, _ = x.shape
         y = x.new_empty(B, 2 * H, 2 * W, specs[0].N)
-        for s in specs:
-            ops.conv2d(x, s, y, act=act)
-        return y
+        return ops.conv_transpose2d(x, specs, y, act=act)
 
     @torch.no_grad()
     def _run_tsf_impl(self, tsf8, feats, Tst, bg=None, want_pred=True, want_mask=True, want_img=False):

@@ -57,7 +57,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -71,6 +71,7 @@ class ConvSpec:
         self._w16hr = None
         self._w16x3 = None
         self._w16c8 = None
+        self._w16up = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -247,6 +248,43 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
         CONV_HOOK(False, a.M, spec, epi)
+    return y
+
+
+BF16_UP4 = True         # lab switch: the four parity launches of a bf16 transposed convolution fused into one (Cin <= 128)
+
+
+class _FusedTransposeSpec(object):
+    """What a launch-accounting hook (bench.ConvTimer) sees for the fused transposed convolution: per INPUT pixel 16 taps and 4 N
+    outputs; flops = 2 M algo_kn, bytes = M Cin in + 4 M N out + the four panels."""
+
+    def __init__(self, s0, panel):
+        self.N, self.Cin, self.ntaps, self.stride, self.omul = 4 * s0.N, s0.Cin, 16, 1, 2
+        self.algo_kn, self.w = 4 * s0.algo_kn, panel
+
+
+def conv_transpose2d(x, specs, y, act=ACT_NONE):
+    """y (B,2H,2W,N) <- ConvTranspose2d(4, 2, 1) of x (B,H,W,Cin) given its four parity specs (packing.pack_conv_transpose).
+    bf16 activations with Cin <= 128: ONE launch (lwg_conv_transpose4_nhwc_bf16: the input block is staged once for the four
+    parities); otherwise the four parity launches of ``conv2d``."""
+    s0 = specs[0]
+    if (BF16_UP4 and BF16_HR and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and len(specs) == 4 and s0.Cin in (64, 128)
+            and s0.N % 64 == 0 and all(s.ntaps == 4 and s.omul == 2 and (s.ooy, s.oox) == (i >> 1, i & 1) for i, s in enumerate(specs))):
+        a = conv_args(x, s0, y, act=act)
+        panel = getattr(s0, "_w16up", None)
+        if panel is None or panel.device != s0.w.device:
+            panel = torch.stack([_w16hr(s, False)[0] for s in specs]).contiguous()
+            s0._w16up = panel
+        a.w = _ptr(panel, torch.bfloat16)
+        if CONV_HOOK is not None:                # one launch = the whole transposed convolution: 16 taps, 4 N output values per input pixel
+            whole = _FusedTransposeSpec(s0, panel)
+            CONV_HOOK(True, a.M, whole, EPI_NONE)
+        _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_bf16(a, _stream()), "lwg_conv_transpose4_nhwc_bf16")
+        if CONV_HOOK is not None:
+            CONV_HOOK(False, a.M, whole, EPI_NONE)
+        return y
+    for s in specs:
+        conv2d(x, s, y, act=act)
     return y
 
 

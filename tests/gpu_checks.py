@@ -1392,6 +1392,102 @@ def check_bf16_generator():
     return out
 
 
+def _bf16_kernel_case(name, B, H, W, C0, C1, N, k, stride, kind, seed):
+    """One launch description on bf16 activations vs the SAME launch on the fp32 kernel fed the same bf16-rounded operands (what
+    differs: summation order, bf16 rounding of the output): |d| <= 1.2e-2 of the reference's maximum; once through the
+    register-streamed-weights / pointwise / first-layer kernels (the product default) and once with them switched off (the
+    LDS-DMA kernels)."""
+    g = torch.Generator().manual_seed(seed)
+    r16 = lambda t: t.to(torch.bfloat16).float()                                       # noqa: E731
+    rnd = lambda *sh, sc=1.0: r16(torch.randn(*sh, generator=g) * sc)                    # noqa: E731
+    Cin = C0 + C1
+    x0 = rnd(B, H, W, C0).to(DEV)
+    x1 = rnd(B, H, W, C1).to(DEV) if C1 else None
+    launches = []
+    if kind == "convT":
+        w = rnd(Cin, N, 4, 4, sc=(Cin * 4) ** -0.5)
+        yshape = (B, 2 * H, 2 * W, N)
+        for sp in packing.pack_conv_transpose(w, 0.1 * torch.randn(N, generator=g)):
+            launches.append((_spec_dev(sp), dict(act=ops.ACT_RELU)))
+    elif kind == "spade":
+        wg, wb = rnd(N, Cin, 3, 3, sc=(Cin * 9) ** -0.5), rnd(N, Cin, 3, 3, sc=(Cin * 9) ** -0.5)
+        sp = _spec_dev(packing.pack_spade_gamma_beta(wg, 0.1 * torch.randn(N, generator=g), wb, 0.1 * torch.randn(N, generator=g)))
+        yshape = (B, H, W, N)
+        launches.append((sp, dict(epi=ops.EPI_SPADE, xn=rnd(B, H, W, N).to(DEV), mean=(torch.randn(B, N, generator=g) * 0.1).to(DEV),
+                                  rstd=(torch.randn(B, N, generator=g) * 0.1 + 1.0).to(DEV))))
+    elif kind == "first":
+        w = rnd(N, 6, k, k, sc=(6 * k * k) ** -0.5)
+        x0[..., 6:] = 0
+        launches.append((_spec_dev(packing.pack_conv(w, 0.1 * torch.randn(N, generator=g), stride=stride, cin_pad=8)), dict(act=ops.ACT_RELU)))
+        yshape = (B, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1, N)
+    else:
+        w = rnd(N, Cin, k, k, sc=(Cin * k * k) ** -0.5)
+        sp = _spec_dev(packing.pack_conv(w, 0.1 * torch.randn(N, generator=g), stride=stride))
+        yshape = (B, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1, N)
+        kw = dict(act=ops.ACT_RELU)
+        if kind == "res":
+            kw = dict(epi=ops.EPI_RESIDUAL, res=rnd(*yshape).to(DEV))
+        launches.append((sp, kw))
+
+    def run(a0, a1, y, dt):
+        for sp, kw in launches:
+            ops.conv2d(a0, sp, y, x1=a1, **{k_: (v.to(dt) if k_ in ("res", "xn") else v) for k_, v in kw.items()})
+        return y
+    ref = run(x0, x1, torch.full(yshape, float("nan"), device=DEV), torch.float32)
+    b0 = x0 if kind == "first" else x0.to(torch.bfloat16)
+    b1 = None if x1 is None else x1.to(torch.bfloat16)
+    out = {}
+    flags = (ops.BF16_HR, ops.BF16_PW, ops.BF16_C8)
+    try:
+        for label, on in (("streamed", True), ("lds_dma", False)):
+            ops.BF16_HR = ops.BF16_PW = ops.BF16_C8 = on
+            got = run(b0, b1, torch.full(yshape, float("nan"), device=DEV, dtype=torch.bfloat16), torch.bfloat16).float()
+            torch.cuda.synchronize()
+            assert torch.isfinite(got).all(), (name, label, "non-finite output")
+            rel = (got - ref).abs().max().item() / ref.abs().max().item()
+            assert rel <= 1.2e-2, (name, label, rel)
+            out[label] = rel
+            if kind == "convT" and on:        # the product path: one fused launch for Cin <= 128, the four parity launches otherwise
+                fused = ops.conv_transpose2d(b0, [sp for sp, _ in launches], torch.full(yshape, float("nan"), device=DEV, dtype=torch.bfloat16),
+                                             act=ops.ACT_RELU).float()
+                torch.cuda.synchronize()
+                assert torch.isfinite(fused).all(), (name, "fused", "non-finite output")
+                relf = (fused - ref).abs().max().item() / ref.abs().max().item()
+                assert relf <= 1.2e-2, (name, "fused", relf)
+                out["fused_vs_parity_launches_max"] = (fused - got).abs().max().item()
+    finally:
+        ops.BF16_HR, ops.BF16_PW, ops.BF16_C8 = flags
+    return out
+
+
+def check_bf16_conv_kernels():
+    """Every kernel of csrc/conv_igemm_bf16.hip on its own: 3x3 (row-renaming kernel, 128- and 64-column forms, 1..6 channel chunks,
+    two-pointer concat, partially filled 8x16 blocks), residual / SPADE epilogues, the four parity launches of the transposed convs,
+    pointwise C -> C at the three widths, the fp32-input first layer, and the strided / general launches of the LDS-DMA kernel."""
+    cases = [
+        ("3x3 64->128 partial blocks", 2, 20, 36, 64, 0, 128, 3, 1, "conv"),
+        ("3x3 256->256", 1, 16, 16, 256, 0, 256, 3, 1, "conv"),
+        ("3x3 concat 128+256->256", 1, 24, 24, 128, 256, 256, 3, 1, "conv"),
+        ("3x3 128->64 (64-column form)", 2, 12, 20, 128, 0, 64, 3, 1, "conv"),
+        ("3x3 residual 256", 2, 8, 16, 256, 0, 256, 3, 1, "res"),
+        ("SPADE gamma|beta 64 ch", 2, 16, 16, 128, 0, 64, 3, 1, "spade"),
+        ("SPADE gamma|beta 256 ch", 1, 16, 16, 128, 0, 256, 3, 1, "spade"),
+        ("convT 128->64", 1, 12, 20, 128, 0, 64, 4, 2, "convT"),
+        ("convT 64->128 (one chunk)", 2, 16, 24, 64, 0, 128, 4, 2, "convT"),
+        ("convT 128->128", 1, 20, 16, 128, 0, 128, 4, 2, "convT"),
+        ("convT 256->128", 1, 16, 16, 256, 0, 128, 4, 2, "convT"),
+        ("convT 256->256", 2, 8, 8, 256, 0, 256, 4, 2, "convT"),
+        ("1x1 64->64", 3, 10, 10, 64, 0, 64, 1, 1, "conv"),
+        ("1x1 128->128", 1, 24, 40, 128, 0, 128, 1, 1, "conv"),
+        ("1x1 256->256", 2, 16, 16, 256, 0, 256, 1, 1, "conv"),
+        ("1x1 128->256 (general kernel)", 1, 16, 16, 128, 0, 256, 1, 1, "conv"),
+        ("first layer 6->64 3x3 s2", 2, 40, 56, 8, 0, 64, 3, 2, "first"),
+        ("3x3 s2 64->128", 2, 16, 16, 64, 0, 128, 3, 2, "conv"),
+        ("3x3 s2 128->256", 1, 32, 32, 128, 0, 256, 3, 2, "conv"),
+    ]
+    return {c[0]: _bf16_kernel_case(c[0], *c[1:], seed=1000 + i) for i, c in enumerate(cases)}
+
+
 def check_split_products():
     """The bf16x6 convolution (csrc/conv_igemm_split.hip; ops.conv_precision("split")): fp32 in / out / accumulate with every
     product formed from six bf16 MFMAs over an exact three-way split of both operands.
@@ -1610,6 +1706,6 @@ def check_attention_backward():
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
-       check_pipeline_full_1024, check_bf16_vs_oracle, check_split_vs_oracle, check_source_setup_128,
+       check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
        check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants]

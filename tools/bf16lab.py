@@ -66,6 +66,9 @@ def build(name):
 
 
 def run(x0, x1, y, launches, dt):
+    if dt == BF and len(launches) == 4 and launches[0][0].omul == 2:        # a transposed convolution: the product call (fused when eligible)
+        ops.conv_transpose2d(x0, [sp for sp, _ in launches], y, act=launches[0][1].get("act", ops.ACT_NONE))
+        return
     for spec, kw in launches:
         kw2 = {k_: (v.to(dt) if k_ in ("res", "xn") else v) for k_, v in kw.items()}
         ops.conv2d(x0, spec, y, x1=x1, **kw2)
@@ -96,7 +99,8 @@ def main():
     ops.BF16_HR = os.environ.get("LWG_LAB_HR", "1") == "1"
     ops.BF16_PW = os.environ.get("LWG_LAB_PW", "1") == "1"
     ops.BF16_C8 = os.environ.get("LWG_LAB_C8", "1") == "1"
-    print(f"batch x{BATCH_MUL} HR={ops.BF16_HR} PW={ops.BF16_PW} C8={ops.BF16_C8} HALO={os.environ.get('LWG_BF16_HALO', '(default 1)')} BIG={os.environ.get('LWG_BF16_BIG', '(default 1)')} LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} TILE64={os.environ.get('LWG_BF16_TILE64', '(heuristic)')}")
+    ops.BF16_UP4 = os.environ.get("LWG_LAB_UP4", "1") == "1"
+    print(f"batch x{BATCH_MUL} HR={ops.BF16_HR} PW={ops.BF16_PW} C8={ops.BF16_C8} UP4={ops.BF16_UP4} HALO={os.environ.get('LWG_BF16_HALO', '(default 1)')} BIG={os.environ.get('LWG_BF16_BIG', '(default 1)')} LWG_BF16_DMA_A={os.environ.get('LWG_BF16_DMA_A', '(default 1)')} TILE64={os.environ.get('LWG_BF16_TILE64', '(heuristic)')}")
     tot_f, tot_us = 0.0, 0.0
     for name in args.shapes.split(","):
         x0, x1, yshape, launches = build(name)

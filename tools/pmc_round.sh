@@ -5,11 +5,16 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
-CMD="python $R/bench.py --steps 3 --warmup 2 --cpu-frames 0 --no-conv-events --pipelined-streams 0 --output-frames 0 --no-split-extra"
+# BENCH_ARGS: extra bench.py flags (e.g. "--precision bf16 --size 1024 --workload novel_view"); TAG: suffix of the output names;
+# KERNEL: name substring of the kernel family whose per-launch traffic goes to gpurun_out/pmc_traffic$TAG.json
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-conv-events --no-extras ${BENCH_ARGS:-}"
+TAG="${TAG:-}"
+KERNEL="${KERNEL:-lwg_conv_igemm_kernel}"
+export LWG_PMC_CMD="bench.py --steps 2 --warmup 1 --no-extras ${BENCH_ARGS:-}"
 run() { # name counters...
   local name=$1; shift
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$name" -o pmc -- $CMD > "$R/gpurun_out/pmc_$name.log" 2>&1 )
-  echo "pmc $name exit=$?"; find "$R/gpurun_out/pmc_$name" -name "*.csv" | head -5
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$name$TAG" -o pmc -- $CMD > "$R/gpurun_out/pmc_$name$TAG.log" 2>&1 )
+  echo "pmc $name$TAG exit=$?"
 }
 for p in ${PASSES:-A B C}; do
   case $p in
@@ -20,6 +25,7 @@ for p in ${PASSES:-A B C}; do
   esac
 done
 # per-launch HBM-side traffic of the dominant kernel -> profiles/pmc_traffic.json (read by bench.py) + per-kernel tables
-if [ -d gpurun_out/pmc_fetch ] && [ -d gpurun_out/pmc_write ]; then
-  python tools/pmc_summary.py --traffic gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_traffic.json
+if [ -d gpurun_out/pmc_fetch$TAG ] && [ -d gpurun_out/pmc_write$TAG ]; then
+  python tools/pmc_summary.py --traffic gpurun_out/pmc_fetch$TAG gpurun_out/pmc_write$TAG gpurun_out/pmc_traffic$TAG.json "$KERNEL"
+  find gpurun_out/pmc_fetch$TAG gpurun_out/pmc_write$TAG -type f -size +3M -delete
 fi

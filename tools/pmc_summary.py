@@ -54,7 +54,12 @@ def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_k
 
     fk, nf = mean_kb(fetch_dir, "FETCH_SIZE")
     wk, nw = mean_kb(write_dir, "WRITE_SIZE")
-    out = {"kernel": kernel_substr, "launches_fetch_pass": nf, "launches_write_pass": nw,
+    cfg = None
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_last_config.json")
+    if os.path.exists(cfg_path):          # written by the bench run the counters were collected on (the last one)
+        with open(cfg_path) as fp:
+            cfg = json.load(fp)
+    out = {"kernel": kernel_substr, "command": os.environ.get("LWG_PMC_CMD", ""), "bench_config": cfg, "launches_fetch_pass": nf, "launches_write_pass": nw,
            "fetch_size_kib_per_launch_raw": fk, "write_size_kib_per_launch_raw": wk,
            "fetch_correction": 2.0,
            "traffic_bytes_per_launch": None if fk is None or wk is None else (2.0 * fk + wk) * 1024.0}
@@ -65,6 +70,6 @@ def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_k
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
-        traffic_json(sys.argv[2], sys.argv[3], sys.argv[4])
+        traffic_json(*sys.argv[2:6])            # fetch dir, write dir, out.json[, kernel name substring]
     else:
         main()
