@@ -1,0 +1,106 @@
+"""Host logic of the bf16 convolution family (no GPU): the operand panels ops.py builds for csrc/conv_igemm_bf16.hip must hold, at the
+index the kernel reads, the weight the reference convolution applies (attlwb_spade_resunet.py:14-25 conv / :331-340 ConvTranspose2d).
+The kernels' own arithmetic is checked on the GPU (tests/gpu_checks.py check_bf16_conv_kernels)."""
+import itertools
+
+import numpy as np
+import torch
+
+from ipercore_amd import ops
+from ipercore_amd.networks import packing
+
+
+def _w(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def test_register_streamed_panel_3x3():
+    """[step = chunk * ntaps + tap'][ks][n][e] = W[n][64 chunk + 16 ks + e][tap], taps ascending in (dy, dx)."""
+    N, Cin = 128, 192
+    w = _w((N, Cin, 3, 3), 1)
+    spec = packing.pack_conv(w, None, stride=1)
+    panel, bias = ops._w16hr(spec, False)
+    assert panel.shape == (Cin // 64 * 9, 4, N, 16) and panel.dtype == torch.bfloat16 and bias is None
+    order = ops._hr_tap_order(spec)
+    assert order == list(range(9))                                      # a Conv2d's taps are already an ascending grid
+    p = panel.float().numpy()
+    wq = w.to(torch.bfloat16).float().numpy()
+    for chunk, t, ks, e, n in itertools.product(range(3), range(9), range(4), (0, 7, 15), (0, 31, 127)):
+        assert p[chunk * 9 + t, ks, n, e] == wq[n, 64 * chunk + 16 * ks + e, t // 3, t % 3]
+
+
+def test_register_streamed_panel_transposed_parities_sorted():
+    """The four parity launches of ConvTranspose2d(4, 2, 1): taps re-ordered ascending (the row-renaming kernel's grid), panel rows
+    following; parity (py, px) must use dy in {py-1, py}, dx in {px-1, px} - what the fused launch assumes."""
+    Cin, N = 128, 64
+    w = _w((Cin, N, 4, 4), 2)
+    specs = packing.pack_conv_transpose(w, None)
+    wq = w.to(torch.bfloat16).float().numpy()
+    # out[2a + p] = sum over (kernel index k, input offset d) of _CT_TAPS[p]:  x[a + d] w[k]
+    ct = {0: {0: 1, -1: 3}, 1: {1: 0, 0: 2}}
+    for i, spec in enumerate(specs):
+        py, px = i >> 1, i & 1
+        assert (spec.ooy, spec.oox, spec.omul) == (py, px, 2)
+        order = ops._hr_tap_order(spec)
+        taps = [(spec.dy[t], spec.dx[t]) for t in order]
+        assert taps == [(py - 1, px - 1), (py - 1, px), (py, px - 1), (py, px)]
+        panel = ops._w16hr(spec, False)[0].float().numpy()
+        assert panel.shape == (Cin // 64 * 4, 4, N, 16)
+        for chunk, (ti, (dy, dx)), ks, e, n in itertools.product(range(2), enumerate(taps), range(4), (0, 9), (0, 63)):
+            assert panel[chunk * 4 + ti, ks, n, e] == wq[64 * chunk + 16 * ks + e, n, ct[py][dy], ct[px][dx]]
+
+
+def test_spade_panel_interleaves_gamma_beta_in_blocks_of_16():
+    C, Cin = 64, 128
+    wg, wb = _w((C, Cin, 3, 3), 3), _w((C, Cin, 3, 3), 4)
+    bg, bb = _w((C,), 5), _w((C,), 6)
+    spec = packing.pack_spade_gamma_beta(wg, bg, wb, bb)
+    panel, bias = ops._w16hr(spec, True)
+    p = panel.float().numpy()
+    g16, b16 = wg.to(torch.bfloat16).float().numpy(), wb.to(torch.bfloat16).float().numpy()
+    for col in (0, 15, 16, 31, 32, 47, 100, 127):
+        q, r = col // 32, col % 32
+        ch, src, sb = 16 * q + r % 16, (g16 if r < 16 else b16), (bg if r < 16 else bb)
+        assert float(bias[col]) == float(sb[ch])
+        for t, ks, e in ((0, 0, 0), (4, 2, 5), (8, 3, 15)):
+            assert p[1 * 9 + t, ks, col, e] == src[ch, 64 + 16 * ks + e, t // 3, t % 3]
+
+
+def test_first_layer_panel():
+    """lwg_conv2d_nhwc_c8_bf16: [ceil(ntaps / 2)][64][16], k = 8 tap + c, zero past the taps and for the padded channels 6, 7."""
+    w = _w((64, 6, 3, 3), 7)
+    spec = packing.pack_conv(w, None, stride=2, cin_pad=8)
+    panel = ops._w16c8(spec).float().numpy()
+    assert panel.shape == (5, 64, 16)
+    wq = w.to(torch.bfloat16).float().numpy()
+    for ks, n, e in itertools.product(range(5), (0, 17, 63), range(16)):
+        tap, c = (16 * ks + e) // 8, (16 * ks + e) % 8
+        want = wq[n, c, tap // 3, tap % 3] if (tap < 9 and c < 6) else 0.0
+        assert panel[ks, n, e] == want
+
+
+def test_lds_dma_panel_swizzle():
+    """lwg_conv2d_nhwc_bf16: [step][n][64], the eight 16-byte k-octets of row n stored at slot octet ^ ((n >> 1) & 7)."""
+    N, Cin = 64, 64
+    w = _w((N, Cin, 3, 3), 8)
+    spec = packing.pack_conv(w, None)
+    panel = ops._w16v2(spec).float().numpy()
+    assert panel.shape == (9, N, 64)
+    wq = w.to(torch.bfloat16).float().numpy()
+    for t, n, octet, e in itertools.product((0, 5, 8), (0, 1, 2, 37, 63), range(8), (0, 7)):
+        slot = octet ^ ((n >> 1) & 7)
+        assert panel[t, n, 8 * slot + e] == wq[n, 8 * octet + e, t // 3, t % 3]
+
+
+def test_head_panel_bf16():
+    """csrc/bf16_ops.hip lwg_head_bf16_kernel operand: [ky][pass][channel half][lane][8], MFMA row = 4 * tap + output."""
+    w_img, w_att = _w((3, 64, 5, 5), 9), _w((1, 64, 5, 5), 10)
+    pk = packing.pack_head_bf16(w_img, w_att).float().numpy()
+    assert pk.shape == (5, 2, 2, 64, 8)
+    w4 = torch.cat([w_img, w_att]).to(torch.bfloat16).float().numpy()
+    for ky, half, lane, e in itertools.product(range(5), range(2), (0, 5, 16, 47, 63), (0, 3, 7)):
+        row, koct = lane % 16, lane // 16
+        tap, o, c = row // 4, row % 4, half * 32 + koct * 8 + e
+        assert pk[ky, 0, half, lane, e] == w4[o, c, ky, tap]
+        assert pk[ky, 1, half, lane, e] == (w4[o, c, ky, 4] if tap == 0 else 0.0)
