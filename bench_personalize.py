@@ -29,7 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
-            panel_cache=None, branch=None, _keep=None):
+            panel_cache=None, branch=None, overlap_d=None, _keep=None):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -69,6 +69,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         topts.use_panel_cache = bool(panel_cache)
     if branch is not None:
         topts.branch_streams = bool(branch)
+    if overlap_d is not None:
+        topts.overlap_d_step = bool(overlap_d)
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
     if _keep is not None:
@@ -220,6 +222,7 @@ def main():
     ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
     ap.add_argument("--no-branch-streams", dest="branch_streams", action="store_false",
                     help="the background network and the source decoder on the main stream (round-2 default: a second stream)")
+    ap.add_argument("--no-overlap-d", dest="overlap_d", action="store_false", help="D's forward / backward after Adam(G), not next to G's backward")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +239,7 @@ def main():
         return breakdown(dev, args.size)
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
                   graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
-                  branch=None if args.branch_streams else False)
+                  branch=None if args.branch_streams else False, overlap_d=None if args.overlap_d else False)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

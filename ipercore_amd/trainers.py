@@ -501,6 +501,8 @@ class TrainOpts(object):
     # the background network (forward and, through autograd's stream replay, backward) on a second stream next to the source / transfer
     # networks: independent until the losses (32.2 -> 30.3 ms per step); the source decoder + regressors ride the same stream
     branch_streams = True
+    # captured step only: D's own forward / backward next to G's backward (it needs the fake images and D's weights, not G's update)
+    overlap_d_step = True
     allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
 
     @classmethod
@@ -827,15 +829,31 @@ class LWGTrainer(object):
         if self.optimizer_D is not None:
             self.optimizer_D._armed = False
         gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # The discriminator's own step needs this iteration's fake images (detached) and D's weights - not G's update - so its
+        # forward / backward can run NEXT TO G's backward (which reads D's weights but never writes them or their gradients: they are
+        # frozen while G's adversarial term is built).  Same values as the reference order (lwg_trainer.py:326-352: optimize_G, G step,
+        # optimize_D, D step); the two Adam updates stay where they were.
+        overlap_d = self.D is not None and bool(getattr(self.opts, "overlap_d_step", False))
+        loss_D = None
         with torch.cuda.graph(gA):
             loss_G, fake_tsf_imgs = self._seg_G()
+            if overlap_d:
+                cur = torch.cuda.current_stream()
+                if getattr(self, "_d_stream", None) is None:
+                    self._d_stream = torch.cuda.Stream()
+                self._d_stream.wait_stream(cur)
+                with torch.cuda.stream(self._d_stream):
+                    loss_D = self._seg_D(fake_tsf_imgs)
+                    loss_D.backward()
+                    self.optimizer_D._gather()
             loss_G.backward()
             self.optimizer_G._gather()
+            if overlap_d:
+                cur.wait_stream(self._d_stream)
         pool = gA.pool()
         with torch.cuda.graph(gB, pool=pool):
             self.optimizer_G.step()
-            loss_D = None
-            if self.D is not None:
+            if self.D is not None and not overlap_d:
                 loss_D = self._seg_D(fake_tsf_imgs)
                 loss_D.backward()
                 self.optimizer_D._gather()
@@ -845,7 +863,8 @@ class LWGTrainer(object):
         self._graphs = (gA, gB, gC)
         self._static_losses = (loss_G.detach(), None if loss_D is None else loss_D.detach())
         self._static_inp = self.inp
-        self.step_mode = "3 hipGraph segments per step (G fwd/bwd | Adam(G) + D fwd/bwd | Adam(D)), all-reduces between them"
+        self.step_mode = ("3 hipGraph segments per step (G fwd/bwd with D's own fwd/bwd on a second stream | Adam(G) | Adam(D)), all-reduces between them"
+                          if overlap_d else "3 hipGraph segments per step (G fwd/bwd | Adam(G) + D fwd/bwd | Adam(D)), all-reduces between them")
         torch.cuda.synchronize()
 
 
