@@ -28,7 +28,7 @@ __device__ __forceinline__ unsigned lwg_pack2(float lo, float hi) {
 // ---------------------------------------------------------------------------------------------- Liquid Warping Block (attention)
 // csrc/lwb_attn.hip lwg_lwb_attn_kernel on bf16 q / Ks / Vs / out: one pixel per LPP = C/8 lanes, 16-byte gathers of 8 channels,
 // fp32 flows, fp32 online softmax.
-template <int LPP>
+template <int LPP, bool BUF>      // BUF: as in lwg_lwb_attn_kernel - unconditional zero-filling buffer loads for the eight taps of a source
 __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ Ks,
                                                                const __bf16* __restrict__ Vs, const float* __restrict__ bk,
                                                                const float* __restrict__ bv, const float* __restrict__ T,
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int cl = lane % LPP;
-    const long total = (long)B * h * w;
-    long gp = ((long)blockIdx.x * 4 + wid) * PPW + lane / LPP;
-    const bool live = gp < total;
-    if (!live) gp = total - 1;  // keep all lanes in the shuffles
+    // tile-major, frame-minor work order (lwg_tile_frame_pixel): the frames of a batch share the L2-resident source texels
+    const long L = ((long)lwg_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid) * PPW + lane / LPP;
+    int b, y, x;
+    const bool live = lwg_tile_frame_pixel(L, B, h, w, b, y, x);
+    if (!live) { b = 0; y = 0; x = 0; }  // keep all lanes in the shuffles
     const int hw = h * w;
-    const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
-    const int y = rem / w, x = rem - y * w;
+    const long gp = ((long)b * h + y) * w + x;
 
     float q8[8], bk8[8], bv8[8];
     lwg_unpack8(*reinterpret_cast<const uintx4*>(q + gp * C + 8 * cl), q8);
@@ -88,17 +88,43 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
         float ka[8], va[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) ka[k] = va[k] = 0.f;
+        if (BUF) {
+            const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
+            const int nbytes = (int)(nsrc * (unsigned)hw * (unsigned)C * 2u);
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ks), 0, nbytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vs), 0, nbytes, 0x00020000);
+            const unsigned sbase = ((unsigned)sidx * (unsigned)hw * (unsigned)C + 8u * (unsigned)cl) * 2u;
+            uintx4 kr[4], vr[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
-            const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
-            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
-                const size_t off = ((size_t)ty * w + tx) * C;
+            for (int t = 0; t < 4; ++t) {
+                const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+                const bool ok = ty >= 0 && ty < h && tx >= 0 && tx < w;
+                const unsigned voff = ok ? sbase + (unsigned)(ty * w + tx) * (unsigned)C * 2u : 0xC0000000u;
+                kr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
+                vr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
                 float k8[8], v8[8];
-                lwg_unpack8(*reinterpret_cast<const uintx4*>(Kb + off), k8);
-                lwg_unpack8(*reinterpret_cast<const uintx4*>(Vb + off), v8);
+                lwg_unpack8(kr[t], k8);
+                lwg_unpack8(vr[t], v8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { ka[k] += k8[k] * wt; va[k] += v8[k] * wt; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+                const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+                if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                    const size_t off = ((size_t)ty * w + tx) * C;
+                    float k8[8], v8[8];
+                    lwg_unpack8(*reinterpret_cast<const uintx4*>(Kb + off), k8);
+                    lwg_unpack8(*reinterpret_cast<const uintx4*>(Vb + off), v8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { ka[k] += k8[k] * wt; va[k] += v8[k] * wt; }
+                }
             }
         }
         float dot = 0.f;
@@ -129,13 +155,19 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
                                       void* out, int B, int ns, int h, int w, int C, int S, int src_batched, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!q || !Ks || !Vs || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0) return (int)hipErrorInvalidValue;
-    const long total = (long)B * h * w;
+    const long total = lwg_tile_frame_positions(B, h, w);
+    const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 2ull < 0xC0000000ull;
 #define LWG_ATTN16_LAUNCH(LPP)                                                                                                        \
     {                                                                                                                                 \
         const long per_block = 4 * (64 / LPP);                                                                                        \
-        hipLaunchKernelGGL(lwg_lwb_attn_bf16_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
-                           reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(Ks), reinterpret_cast<const __bf16*>(Vs), \
-                           bk, bv, T, reinterpret_cast<__bf16*>(out), B, ns, h, w, S, src_batched);                                   \
+        if (buf_ok)                                                                                                                   \
+            hipLaunchKernelGGL((lwg_lwb_attn_bf16_kernel<LPP, true>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
+                               reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(Ks), reinterpret_cast<const __bf16*>(Vs), \
+                               bk, bv, T, reinterpret_cast<__bf16*>(out), B, ns, h, w, S, src_batched);                               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((lwg_lwb_attn_bf16_kernel<LPP, false>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
+                               reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(Ks), reinterpret_cast<const __bf16*>(Vs), \
+                               bk, bv, T, reinterpret_cast<__bf16*>(out), B, ns, h, w, S, src_batched);                               \
     }
     switch (C) {
         case 64: LWG_ATTN16_LAUNCH(8) break;
@@ -175,7 +207,11 @@ __global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __r
     typedef float floatx4v __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, x0 = blockIdx.x * H16_TW, y0 = blockIdx.y * H16_TH;
+    // 1-D grid, XCD-aware: a contiguous band of tile rows per XCD - the halo rows of vertically adjacent tiles meet in one L2
+    const int tiles_x = (S + H16_TW - 1) / H16_TW, tiles_y = (S + H16_TH - 1) / H16_TH;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (tiles_x * tiles_y), trem = lid - b * tiles_x * tiles_y;
+    const int x0 = (trem % tiles_x) * H16_TW, y0 = (trem / tiles_x) * H16_TH;
     // ---- stage the halo tile: halo pixel (py, px) = image (y0 + py - 2, x0 + px - 2); piece = 8 consecutive px of one row
     {
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (int)xbytes, 0x00020000);
@@ -264,7 +300,7 @@ extern "C" int lwg_head_compose_bf16(const void* x, const void* wb, const float*
     if (xbytes >= 0xC0000000ull) return (int)hipErrorInvalidValue;
     constexpr size_t lds = (size_t)H16_HROWS * H16_HWID * 128;
     static_assert(lds >= (size_t)H16_TH * 5 * H16_PW * 4 * sizeof(float), "partial sums must fit the halo buffer");
-    hipLaunchKernelGGL(lwg_head_bf16_kernel, dim3((S + H16_TW - 1) / H16_TW, (S + H16_TH - 1) / H16_TH, B), dim3(256), lds, stream,
+    hipLaunchKernelGGL(lwg_head_bf16_kernel, dim3(((S + H16_TW - 1) / H16_TW) * ((S + H16_TH - 1) / H16_TH) * B), dim3(256), lds, stream,
                        reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
     return (int)hipGetLastError();
 }

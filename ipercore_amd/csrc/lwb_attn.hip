@@ -11,7 +11,10 @@
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
-template <int LPP>
+// BUF: the K / V taps through raw buffer loads - an out-of-image tap gets an out-of-range offset and the hardware returns zeros, so the
+// eight gathers of a source are unconditional and in flight together (with per-tap branches each load waited for its own exec mask
+// and its own s_waitcnt); needs the K / V tensors below 3 GB (the launcher picks the pointer form otherwise).
+template <int LPP, bool BUF>
 __global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restrict__ q, const float* __restrict__ Ks,
                                                           const float* __restrict__ Vs, const float* __restrict__ bk,
                                                           const float* __restrict__ bv, const float* __restrict__ T,
@@ -20,13 +23,13 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restri
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int cl = lane % LPP;
-    const long total = (long)B * h * w;
-    long gp = ((long)blockIdx.x * 4 + wid) * PPW + lane / LPP;
-    const bool live = gp < total;
-    if (!live) gp = total - 1;  // keep all lanes in the shuffles
+    // tile-major, frame-minor work order (lwg_tile_frame_pixel): the frames of a batch share the L2-resident source texels
+    const long L = ((long)lwg_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid) * PPW + lane / LPP;
+    int b, y, x;
+    const bool live = lwg_tile_frame_pixel(L, B, h, w, b, y, x);
+    if (!live) { b = 0; y = 0; x = 0; }  // keep all lanes in the shuffles
     const int hw = h * w;
-    const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
-    const int y = rem / w, x = rem - y * w;
+    const long gp = ((long)b * h + y) * w + x;
 
     const floatx4 q4 = *reinterpret_cast<const floatx4*>(q + gp * C + 4 * cl);
     const floatx4 bk4 = *reinterpret_cast<const floatx4*>(bk + 4 * cl);
@@ -68,16 +71,39 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restri
         const float* Kb = Ks + sidx * hw * C + 4 * cl;
         const float* Vb = Vs + sidx * hw * C + 4 * cl;
         floatx4 ka = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+        if (BUF) {
+            const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
+            const int nbytes = (int)(nsrc * (unsigned)hw * (unsigned)C * 4u);
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, nbytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, nbytes, 0x00020000);
+            const unsigned sbase = ((unsigned)sidx * (unsigned)hw * (unsigned)C + 4u * (unsigned)cl) * 4u;
+            floatx4 k4[4], v4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
-            const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
-            if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
-                const size_t off = ((size_t)ty * w + tx) * C;
-                const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
-                const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
+            for (int t = 0; t < 4; ++t) {
+                const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+                const bool ok = ty >= 0 && ty < h && tx >= 0 && tx < w;
+                const unsigned voff = ok ? sbase + (unsigned)(ty * w + tx) * (unsigned)C * 4u : 0xC0000000u;
+                k4[t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
+                v4[t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { ka[k] += k4[k] * wt; va[k] += v4[k] * wt; }
+            for (int t = 0; t < 4; ++t) {
+                const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ka[k] += k4[t][k] * wt; va[k] += v4[t][k] * wt; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
+                const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+                if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
+                    const size_t off = ((size_t)ty * w + tx) * C;
+                    const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
+                    const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { ka[k] += k4[k] * wt; va[k] += v4[k] * wt; }
+                }
             }
         }
         float dot = 0.f;
@@ -112,12 +138,17 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!q || !Ks || !Vs || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0)
         return (int)hipErrorInvalidValue;
-    const long total = (long)B * h * w;
+    const long total = lwg_tile_frame_positions(B, h, w);
+    const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 4ull < 0xC0000000ull;
 #define LWG_ATTN_LAUNCH(LPP)                                                                                      \
     {                                                                                                             \
         const long per_block = 4 * (64 / LPP);                                                                    \
-        hipLaunchKernelGGL(lwg_lwb_attn_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
-                           stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);                                   \
+        if (buf_ok)                                                                                               \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
+                               stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);                           \
+        else                                                                                                      \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, false>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
+                               stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);                           \
     }
     switch (C) {
         case 32: LWG_ATTN_LAUNCH(8) break;

@@ -35,6 +35,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // More than 64 KB of dynamic LDS is an opt-in per kernel AND per device: `done` holds one bit per device ordinal (one process may
 // drive several GPUs even though the runners use one process per GPU).
+// Work order of the per-pixel gather kernels (attention blocks): 8 x 8-pixel tiles, the B frames of a tile back to back, and - through
+// lwg_xcd_remap on the block id - every XCD a contiguous range of that order.  The source texels (K / V) a tile's flows point at are then
+// fetched into ONE XCD's L2 once for all frames of the batch; in frame-major order every frame streamed the whole K / V set (134 MB per
+// site at 1024^2: larger than the L2s) from the Infinity Cache again.  L: position in that order; returns false for padding positions.
+__device__ __forceinline__ bool lwg_tile_frame_pixel(long L, int B, int h, int w, int& b, int& y, int& x) {
+    const int tiles_x = (w + 7) >> 3, tiles_y = (h + 7) >> 3;
+    const long per_tile = (long)B * 64;
+    const long tile = L / per_tile;
+    const int r = (int)(L - tile * per_tile);
+    b = r >> 6;
+    const int p = r & 63;
+    const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long)ty * tiles_x);
+    y = ty * 8 + (p >> 3);
+    x = tx * 8 + (p & 7);
+    return ty < tiles_y && y < h && x < w;
+}
+static inline long lwg_tile_frame_positions(int B, int h, int w) { return (long)((w + 7) >> 3) * ((h + 7) >> 3) * B * 64; }
+
 static inline hipError_t lwg_allow_dynamic_lds(const void* kern, size_t bytes, unsigned long long& done) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;

@@ -164,12 +164,16 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     __shared__ unsigned short spair[LWG_RPAIRS];  // pixel | chunk slot << 8
     __shared__ int scount, spcount;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int b = blockIdx.z;
-    const int xi = blockIdx.x * 16 + (tid & 15);
-    const int r = blockIdx.y * 16 + (tid >> 4);
+    // 1-D grid, XCD-aware: a contiguous band of tile rows per XCD (the 2 x 2 tiles of a bin and neighbouring bins share face records)
+    const int tiles1 = (S + 15) >> 4;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (tiles1 * tiles1), trem = lid - b * tiles1 * tiles1;
+    const int bix = trem % tiles1, biy = trem / tiles1;
+    const int xi = bix * 16 + (tid & 15);
+    const int r = biy * 16 + (tid >> 4);
     const int yi = S - 1 - r;  // row 0 is the top of the image = largest y (vertical flip of the upstream maps)
-    const int tx0 = blockIdx.x * 16, tx1 = tx0 + 15;
-    const int ty1 = S - 1 - blockIdx.y * 16, ty0 = ty1 - 15;
+    const int tx0 = bix * 16, tx1 = tx0 + 15;
+    const int ty1 = S - 1 - biy * 16, ty0 = ty1 - 15;
     const float xp = (float)((2.0 * xi + 1 - S) / S);
     const float yp = (float)((2.0 * yi + 1 - S) / S);
     const float* recb = rec + (size_t)b * nf * LWG_REC_FLOATS;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     //   3. weights: one evaluation per pixel for the winner (the same arithmetic on the same record: the same bits).
     {   // three quarters of the tiles of a frame lie in bins no face touches: background, no LDS, no barrier
         const int nb2e = nbx * nbx;
-        if (bin_count[b * nb2e + ((blockIdx.y * 16) / LWG_BIN) * nbx + (blockIdx.x * 16) / LWG_BIN] == 0) {
+        if (bin_count[b * nb2e + ((biy * 16) / LWG_BIN) * nbx + (bix * 16) / LWG_BIN] == 0) {
             if (xi < S && r < S) {
                 const size_t o = ((size_t)b * S + r) * S + xi;
                 fim[o] = -1;
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
         for (int p = tid; p < cnt; p += 256) {
             const int pr = spair[p];
             const int px = pr & 255, e = pr >> 8;
-            const int pxi = blockIdx.x * 16 + (px & 15);
-            const int pyi = S - 1 - (blockIdx.y * 16 + (px >> 4));
+            const int pxi = bix * 16 + (px & 15);
+            const int pyi = S - 1 - (biy * 16 + (px >> 4));
             const float pxp = (float)((2.0 * pxi + 1 - S) / S);
             const float pyp = (float)((2.0 * pyi + 1 - S) / S);
             float w0, w1, w2, zp;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
     };
 
     const int nb2 = nbx * nbx;
-    const int bin = b * nb2 + ((blockIdx.y * 16) / LWG_BIN) * nbx + (blockIdx.x * 16) / LWG_BIN;
+    const int bin = b * nb2 + ((biy * 16) / LWG_BIN) * nbx + (bix * 16) / LWG_BIN;
     const int nbin = bin_count[bin];
     const int* blist = bin_list + (size_t)bin * nf;
     for (int base = 0; base < nbin; base += LWG_RCHUNK) {
@@ -338,7 +342,7 @@ extern "C" int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, in
     hipLaunchKernelGGL(lwg_raster_setup_kernel, dim3((nf + 255) / 256, B), dim3(256), (size_t)2 * nbx * nbx * sizeof(int), stream,
                        faces_v, nf, S, rec, bbox, nbx, bin_count, bin_list);
     const int tiles = (S + 15) / 16;
-    hipLaunchKernelGGL(lwg_raster_tiles_kernel, dim3(tiles, tiles, B), dim3(256), 0, stream, rec, bbox, nf, S, near, far, nbx,
+    hipLaunchKernelGGL(lwg_raster_tiles_kernel, dim3(tiles * tiles * B), dim3(256), 0, stream, rec, bbox, nf, S, near, far, nbx,
                        bin_count, bin_list, fim, wim);
     return (int)hipGetLastError();
 }
