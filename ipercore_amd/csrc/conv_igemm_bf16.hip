@@ -1043,10 +1043,11 @@ extern "C" int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t
 // HBM rate).  Here the whole weight matrix lives in registers (a wave owns 32 columns: K/16 fragments = 16..64 VGPRs), a
 // persistent 8-wave workgroup per CU walks the row tiles, and a tile's activations (rows x K, one contiguous block of the NHWC
 // tensor) come in by LDS-DMA, double-buffered by TILE: the DMA of tile t+1 is in flight for the whole of tile t, one barrier
-// per tile.  HBM-bound: reads M x K, writes M x N bf16 once.
-template <int NCH, int WAVES_N>
-__global__ __launch_bounds__(512, 1) void lwg_conv_bf16_pw_kernel(const LwgConvArgs a) {
-    constexpr int WAVES_M = 8 / WAVES_N, TM = 4, BM = WAVES_M * 128;
+// per tile.  HBM-bound: reads M x K, writes M x N bf16 once.  Two workgroups per CU (TM = 2: 64-row wave tiles, 2 x 32 KB stages each)
+// stream better than one with 128-row tiles: while one waits for its DMA the other computes and stores (C = 256: 51 -> 39 us).
+template <int NCH, int WAVES_N, int TM>        // TM = 4: 128 rows per wave, one workgroup per CU; TM = 2: 64 rows, two workgroups per CU
+__global__ __launch_bounds__(512, TM == 4 ? 1 : 2) void lwg_conv_bf16_pw_kernel(const LwgConvArgs a) {
+    constexpr int WAVES_M = 8 / WAVES_N, BM = WAVES_M * TM * 32;
     constexpr int CH_BYTES = BM * 128;                       // one 64-channel chunk of a stage: [row][128 B]
     constexpr int STAGE = NCH * CH_BYTES;
     constexpr int PIECES = STAGE / 1024 / 8;                 // 1 KB DMA pieces per wave per stage
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(512, 1) void lwg_conv_bf16_pw_kernel(const LwgConvA
     int koff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + khalf) ^ sw) << 4;
-    const int frow = (wm * 128 + (lane & 31)) * 128;
+    const int frow = (wm * TM * 32 + (lane & 31)) * 128;
 
     for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's pieces of the current stage (and its last stores) are done
@@ -1125,11 +1126,11 @@ __global__ __launch_bounds__(512, 1) void lwg_conv_bf16_pw_kernel(const LwgConvA
     }
 }
 
-template <int NCH, int WAVES_N>
-static hipError_t launch_cfg_bf16_pw(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr int BM = (8 / WAVES_N) * 128;
+template <int NCH, int WAVES_N, int TM>
+static hipError_t launch_cfg_bf16_pw_tm(const LwgConvArgs& a, hipStream_t stream) {
+    constexpr int BM = (8 / WAVES_N) * TM * 32;
     constexpr size_t lds = (size_t)2 * NCH * BM * 128;
-    auto kern = lwg_conv_bf16_pw_kernel<NCH, WAVES_N>;
+    auto kern = lwg_conv_bf16_pw_kernel<NCH, WAVES_N, TM>;
     static unsigned long long attr_done = 0ull;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     static int cus = 0;
@@ -1138,8 +1139,19 @@ static hipError_t launch_cfg_bf16_pw(const LwgConvArgs& a, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
     const int ntiles = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(512), lds, stream, a);
+    const int slots = cus * (TM == 4 ? 1 : 2);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(512), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int NCH, int WAVES_N>
+static hipError_t launch_cfg_bf16_pw(const LwgConvArgs& a, hipStream_t stream) {
+    static int tm = 0;
+    if (tm == 0) {
+        const char* ev = getenv("LWG_BF16_PW_TM");   // lab knob: 4 = one 8-wave workgroup per CU with 128-row wave tiles, 2 = two with 64-row tiles
+        tm = ev ? atoi(ev) : 2;              // measured in the frame loop: C = 256 51 -> 39 us, C = 128 79 -> 65, C = 64 153 -> 123
+    }
+    return tm == 2 ? launch_cfg_bf16_pw_tm<NCH, WAVES_N, 2>(a, stream) : launch_cfg_bf16_pw_tm<NCH, WAVES_N, 4>(a, stream);
 }
 
 static bool lwg_bf16_pw_ok(const LwgConvArgs& a) {
