@@ -2,6 +2,8 @@
 // the attention-form Liquid Warping Block and the output head + compositing (the InstanceNorm statistics live in norm.hip).  Same algorithms and
 // reference citations as their fp32 twins (csrc/norm.hip, csrc/lwb_attn.hip, csrc/head.hip); arithmetic stays fp32, only the
 // tensors in HBM are bf16: half the bytes per launch, 16-byte accesses carry 8 channels.
+#include <stdlib.h>
+
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
@@ -189,21 +191,24 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
 // belongs to output pixel x - kx + 2: the per-tap partials are written to LDS at the shifted position and summed there.
 // Executed MFMA work = 2 / 5 * (16 / 4) = 1.6 x the algorithmic flops (13.4 GFLOP per 1024^2 frame -> 21 executed) on a pipe that
 // delivers > 1 PFLOP/s, instead of a VALU convolution at 60 TFLOP/s (csrc/head.hip).
-// A workgroup (4 waves, one output row each) owns a 4-row x 60-pixel output tile: the 8 x 64-pixel x 64-channel halo tile (64 KB)
+// A workgroup (4 waves, one output row each) owns a 4-row x (16 NCB - 4)-pixel output tile: the 8 x 16 NCB-pixel x 64-channel halo tile (32 / 64 KB)
 // goes global -> LDS by LDS-DMA (16 B per lane, 8 pixels per wave-instruction, out-of-image pixels = out-of-range offsets = zeros),
 // k-octets swizzled by the pixel column (source-side permutation, lane-linear destination) so the ds_read_b128 operand reads are
-// conflict-free; two workgroups per CU overlap one's staging with the other's MFMAs.
-#define H16_TW 60                 // output pixels per tile row (input span 64 = four 16-pixel MFMA column blocks)
+// conflict-free; four (NCB = 2) or two (NCB = 4) workgroups per CU overlap one's staging with the others' MFMAs.
 #define H16_TH 4                  // output rows per tile = waves per workgroup
-#define H16_HWID 64
 #define H16_HROWS (H16_TH + 4)
-#define H16_PW (H16_HWID + 4)     // partial-sum row length: output column c is stored at c + 3 (c ranges over [-3, 64))
 
-__global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wb,
+// NCB: 16-pixel MFMA column blocks per tile row: input span 16 NCB, output 16 NCB - 4.  NCB = 4: 64 KB of LDS, two workgroups per CU;
+// NCB = 2: 32 KB, four per CU (the tile is a short latency chain - DMA, 40 MFMAs, two LDS passes, scattered plane stores - so more
+// resident workgroups stream better; the extra halo columns are L2 hits).
+template <int NCB>
+__global__ __launch_bounds__(256, NCB == 4 ? 2 : 4) void lwg_head_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wb,
                                                               const float* __restrict__ bg, size_t bg_bstride, int S, unsigned xbytes,
                                                               float* __restrict__ pred, float* __restrict__ mask_out,
                                                               float* __restrict__ img_out) {
-    extern __shared__ __attribute__((aligned(16))) char sm[];      // [H16_HROWS][64 px][128 B]; later the partial sums
+    constexpr int H16_HWID = 16 * NCB, H16_TW = H16_HWID - 4;
+    constexpr int H16_PW = H16_HWID + 4;                            // partial-sum row length: output column c is stored at c + 3 (c in [-3, HWID))
+    extern __shared__ __attribute__((aligned(16))) char sm[];      // [H16_HROWS][HWID px][128 B]; later the partial sums
     typedef float floatx4v __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,11 +220,12 @@ __global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __r
     // ---- stage the halo tile: halo pixel (py, px) = image (y0 + py - 2, x0 + px - 2); piece = 8 consecutive px of one row
     {
         __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (int)xbytes, 0x00020000);
-        constexpr int PIECES = H16_HROWS * H16_HWID / 8;           // 64
+        constexpr int PPR = H16_HWID / 8;                          // 8-pixel DMA pieces per halo row
+        constexpr int PIECES = H16_HROWS * PPR;
 #pragma unroll
         for (int q = 0; q < PIECES / 4; ++q) {
             const int piece = wid * (PIECES / 4) + q;
-            const int py = piece >> 3, px = (piece & 7) * 8 + (lane >> 3);
+            const int py = piece / PPR, px = (piece % PPR) * 8 + (lane >> 3);
             const int gy = y0 + py - 2, gx = x0 + px - 2;
             const bool ok = gy >= 0 && gy < S && gx >= 0 && gx < S;
             const unsigned oct = (unsigned)((lane & 7) ^ (px & 7));
@@ -236,9 +242,9 @@ __global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __r
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
                 wf[ky][ps][ch] = *reinterpret_cast<const bf16x8*>(wb + ((((size_t)ky * 2 + ps) * 2 + ch) * 64 + lane) * 8);
-    floatx4v acc[4][2];
+    floatx4v acc[NCB][2];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb][0] = acc[cb][1] = floatx4v{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = floatx4v{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's pieces (and its weight loads) have landed
     __syncthreads();
     const int pxl = lane & 15, koct = lane >> 4;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __r
     for (int ky = 0; ky < 5; ++ky) {
         const int py = wid + ky;                                   // halo row feeding output row wid through kernel row ky
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
             const int px = cb * 16 + pxl;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void lwg_head_bf16_kernel(const __bf16* __r
     // belongs to output column c = cb*16 + j - t (pass 0) / c = cb*16 + j - 4 for the fifth tap (pass 1, held by the t = 0 lanes).
     float* part = reinterpret_cast<float*>(sm);                    // [H16_TH][5][H16_PW][4]
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int j = cb * 16 + pxl;
         *reinterpret_cast<floatx4v*>(part + (((size_t)wid * 5 + koct) * H16_PW + (j - koct + 3)) * 4) = acc[cb][0];
         if (koct == 0 && j >= 1) *reinterpret_cast<floatx4v*>(part + (((size_t)wid * 5 + 4) * H16_PW + (j - 4 + 3)) * 4) = acc[cb][1];
@@ -298,9 +304,19 @@ extern "C" int lwg_head_compose_bf16(const void* x, const void* wb, const float*
     if (!x || !wb || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C != 64 || B > 65535) return (int)hipErrorInvalidValue;
     const unsigned long long xbytes = (unsigned long long)B * S * S * 128ull;
     if (xbytes >= 0xC0000000ull) return (int)hipErrorInvalidValue;
-    constexpr size_t lds = (size_t)H16_HROWS * H16_HWID * 128;
-    static_assert(lds >= (size_t)H16_TH * 5 * H16_PW * 4 * sizeof(float), "partial sums must fit the halo buffer");
-    hipLaunchKernelGGL(lwg_head_bf16_kernel, dim3(((S + H16_TW - 1) / H16_TW) * ((S + H16_TH - 1) / H16_TH) * B), dim3(256), lds, stream,
-                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
+    static int ncb = 0;
+    if (ncb == 0) {
+        const char* ev = getenv("LWG_HEAD16_NCB");      // lab knob: 16-pixel column blocks per tile row (4 or 2)
+        ncb = ev && atoi(ev) == 4 ? 4 : 2;
+    }
+    const int tw = 16 * ncb - 4;
+    const size_t lds = (size_t)H16_HROWS * 16 * ncb * 128;       // >= the partial sums: TH * 5 * (16 NCB + 4) * 16 B
+    const unsigned grid = (unsigned)(((S + tw - 1) / tw) * ((S + H16_TH - 1) / H16_TH) * B);
+    if (ncb == 4)
+        hipLaunchKernelGGL(lwg_head_bf16_kernel<4>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
+                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
+    else
+        hipLaunchKernelGGL(lwg_head_bf16_kernel<2>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
+                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
     return (int)hipGetLastError();
 }
