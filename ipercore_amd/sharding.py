@@ -101,18 +101,10 @@ def chunk_plan(n_frames, world_size, frame_batch):
     [lo_r + off, min(lo_r + off + m, hi_r)) - possibly fewer than m, possibly none."""
     cap = max(shard_counts(n_frames, world_size))
     fb = max(1, int(frame_batch))
-    if cap == 0:
-        return []
-    # as few chunks as the frame batch allows, balanced: 38 frames at frame batch 16 are 13 + 13 + 12, not 16 + 16 + 6 - a short last
-    # chunk runs the 64x64-feature layers with too few GEMM rows to fill the chip, and it is the chunk whose exchange is exposed
-    k = (cap + fb - 1) // fb
-    base, rem = divmod(cap, k)
-    plan, off = [], 0
-    for i in range(k):
-        m = base + (1 if i < rem else 0)
-        plan.append((off, m))
-        off += m
-    return plan
+    # full frame batches first, the remainder last (38 frames at frame batch 16: 16 + 16 + 6).  Balanced chunks (13 + 13 + 12) were tried and
+    # dropped: the 64x64-feature layers have 64 output tiles per frame, so 16 frames are exactly four rounds of the 256 CUs while 13 frames
+    # are 3.25 (a fourth round a quarter full) - and the short last chunk is also the one whose exchange is exposed.
+    return [(off, min(fb, cap - off)) for off in range(0, cap, fb)]
 
 
 def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, group=None, overlap=True, prepared=False, post=None,

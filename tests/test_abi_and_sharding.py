@@ -242,13 +242,12 @@ def test_clip_schedule_gloo_world2_and_3(tmp_path):
 
 
 def test_clip_schedule_gloo_world8_300_frames(tmp_path):
-    """The configuration itself: 8 ranks, 300 frames -> shards of 38/38/38/38/37/37/37/37; at frame batch 8 five balanced chunks of
-    (8, 8, 8, 7, 7) frames, at bench.py's frame batch 16 three of (13, 13, 12); the last one carries one padding frame on the four
+    """The configuration itself: 8 ranks, 300 frames -> shards of 38/38/38/38/37/37/37/37; at frame batch 8 five chunks of
+    (8, 8, 8, 8, 6) frames, at bench.py's frame batch 16 three of (16, 16, 6); the last one carries one padding frame on the four
     short shards."""
     assert sharding.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
-    assert sharding.chunk_plan(300, 8, 8) == [(0, 8), (8, 8), (16, 8), (24, 7), (31, 7)]
-    assert sharding.chunk_plan(300, 8, 16) == [(0, 13), (13, 13), (26, 12)]
-    assert sharding.chunk_plan(300, 1, 16)[-1] == (285, 15) and len(sharding.chunk_plan(300, 1, 16)) == 19      # 15 x 16 + 4 x 15
+    assert sharding.chunk_plan(300, 8, 8) == [(0, 8), (8, 8), (16, 8), (24, 8), (32, 6)]
+    assert sharding.chunk_plan(300, 8, 16) == [(0, 16), (16, 16), (32, 6)]
     assert sharding.chunk_plan(0, 4, 8) == [] and sharding.chunk_plan(3, 8, 8) == [(0, 1)]
     _run_gloo(tmp_path, _CLIP_WORKER, 8, "300:8,5:8")
 
