@@ -104,3 +104,40 @@ def test_head_panel_bf16():
         tap, o, c = row // 4, row % 4, half * 32 + koct * 8 + e
         assert pk[ky, 0, half, lane, e] == w4[o, c, ky, tap]
         assert pk[ky, 1, half, lane, e] == (w4[o, c, ky, 4] if tap == 0 else 0.0)
+
+
+def test_panel_cache_bookkeeping(monkeypatch):
+    """ops.PanelCache (the one-launch-per-step re-packing of the training step): only tensors living in parameter storage are cached,
+    a panel is registered once per (storage address, packing arguments), and refresh() hands the library one descriptor per panel
+    with consecutive block ranges."""
+    import ctypes
+
+    from ipercore_amd import _lib
+    flat = torch.zeros(64 * 32 * 9 + 32 * 64 * 16)                     # a flat parameter buffer with two weight views
+    w1 = flat[:64 * 32 * 9].view(64, 32, 3, 3)
+    w2 = flat[64 * 32 * 9:].view(32, 64, 4, 4)
+    cache = ops.PanelCache([flat])
+    assert cache.cacheable(w1) and cache.cacheable(w2) and not cache.cacheable(torch.cat([w1, w1]))
+    a, fresh_a = cache.get(w1, False, tuple(range(9)), 32, 32, 64, 64)
+    b, fresh_b = cache.get(w1, False, tuple(range(9)), 32, 32, 64, 64)
+    c, fresh_c = cache.get(w1, True, tuple(range(9)), 64, 64, 32, 64)   # the data-gradient panel of the same weight
+    d, fresh_d = cache.get(w2, True, (5, 7, 13, 15), 32, 32, 64, 64)
+    assert fresh_a and not fresh_b and fresh_c and fresh_d and a is b and a is not c
+    assert a.shape == (9 * 32 // 4, 64, 4) and c.shape == (9 * 64 // 4, 64, 4) and d.shape == (4 * 32 // 4, 64, 4)
+    calls = []
+
+    class _Stub:
+        def lwg_pack_panels_f32(self, table, n, blocks, stream):
+            calls.append((table, n, blocks))
+            return 0
+    monkeypatch.setattr(_lib, "lib", lambda: _Stub())
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    cache.refresh()
+    cache.refresh()
+    assert len(calls) == 2 and calls[0][1] == 3 and calls[0] == calls[1]            # the table is built once
+    descs = (_lib.LwgPackDesc * 3).from_buffer_copy(bytes(cache.table.numpy().tobytes()))
+    firsts = [d_.first_block for d_ in descs]
+    sizes = [((d_.Kp // 4) * d_.n_pad + 255) // 256 for d_ in descs]
+    assert firsts == [0, sizes[0], sizes[0] + sizes[1]] and calls[0][2] == sum(sizes)
+    assert descs[0].w == w1.data_ptr() and descs[2].w == w2.data_ptr() and descs[1].transposed == 1 and list(descs[2].kidx[:4]) == [5, 7, 13, 15]
+    assert ctypes.sizeof(_lib.LwgPackDesc) == 264
