@@ -202,11 +202,13 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
 // NCB = 2: 32 KB, four per CU (the tile is a short latency chain - DMA, 40 MFMAs, two LDS passes, scattered plane stores - so more
 // resident workgroups stream better; the extra halo columns are L2 hits).
 template <int NCB>
-__global__ __launch_bounds__(256, NCB == 4 ? 2 : 4) void lwg_head_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wb,
+__global__ __launch_bounds__(256, NCB == 4 ? 2 : (NCB == 3 ? 3 : 4)) void lwg_head_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wb,
                                                               const float* __restrict__ bg, size_t bg_bstride, int S, unsigned xbytes,
                                                               float* __restrict__ pred, float* __restrict__ mask_out,
                                                               float* __restrict__ img_out) {
-    constexpr int H16_HWID = 16 * NCB, H16_TW = H16_HWID - 4;
+    // NCB = 3: 32 output pixels of the 44 the 48-pixel span could give - every plane store / background load of a tile row is then one
+    // aligned 128-byte line (28- or 60-pixel rows straddle lines: the fp32 NCHW planes are written 4 bytes per pixel)
+    constexpr int H16_HWID = 16 * NCB, H16_TW = NCB == 3 ? 32 : H16_HWID - 4;
     constexpr int H16_PW = H16_HWID + 4;                            // partial-sum row length: output column c is stored at c + 3 (c in [-3, HWID))
     extern __shared__ __attribute__((aligned(16))) char sm[];      // [H16_HROWS][HWID px][128 B]; later the partial sums
     typedef float floatx4v __attribute__((ext_vector_type(4)));
@@ -307,13 +309,17 @@ extern "C" int lwg_head_compose_bf16(const void* x, const void* wb, const float*
     static int ncb = 0;
     if (ncb == 0) {
         const char* ev = getenv("LWG_HEAD16_NCB");      // lab knob: 16-pixel column blocks per tile row (4 or 2)
-        ncb = ev && atoi(ev) == 4 ? 4 : 2;
+        ncb = ev ? atoi(ev) : 2;
+        if (ncb != 2 && ncb != 3 && ncb != 4) ncb = 2;
     }
-    const int tw = 16 * ncb - 4;
+    const int tw = ncb == 3 ? 32 : 16 * ncb - 4;
     const size_t lds = (size_t)H16_HROWS * 16 * ncb * 128;       // >= the partial sums: TH * 5 * (16 NCB + 4) * 16 B
     const unsigned grid = (unsigned)(((S + tw - 1) / tw) * ((S + H16_TH - 1) / H16_TH) * B);
     if (ncb == 4)
         hipLaunchKernelGGL(lwg_head_bf16_kernel<4>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
+                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
+    else if (ncb == 3)
+        hipLaunchKernelGGL(lwg_head_bf16_kernel<3>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
                            reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
     else
         hipLaunchKernelGGL(lwg_head_bf16_kernel<2>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
