@@ -29,6 +29,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# multi-process runs: the host driver supports dmabuf IPC only and the HSA runtime reads this when the first HIP call initialises it -
+# so it must be in the environment BEFORE torch touches the device (it is already exported on the GPU boxes; this is the safety net)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -453,10 +458,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":       # the host driver supports dmabuf IPC only (RCCL needs it)
-            if rank == 0:
-                print("[bench] HSA_ENABLE_IPC_MODE_LEGACY was not 0 in the environment: setting it for RCCL", file=sys.stderr)
-            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and rank == 0:
+            print("[bench] HSA_ENABLE_IPC_MODE_LEGACY is not 0: RCCL's IPC handles may fail on this driver", file=sys.stderr)
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
         assert dist.get_world_size() == world
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"

@@ -24,6 +24,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:                  # before the first HIP call (see bench.py)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
