@@ -185,6 +185,10 @@ int lwg_instnorm_stats_nhwc_bf16(const void* x, int B, int HW, int C, float eps,
 int lwg_instnorm_apply_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* res,
                                 float* y, int B, int HW, int C, int act, lwg_stream_t stream);
 
+/* LWB.resize_trans (attlwb_spade_resunet.py:175-181): n flow fields (S,S,2) -> (h,w,2), bilinear, align_corners = True, as its own pass.
+ * The block kernels below resize per pixel when handed full-resolution flows; handed a field already at their resolution (S == h == w)
+ * they read it directly - the engine resizes once per frame batch and resolution. */
+int lwg_flow_resize_f32(const float* T, int n, int S, int h, int w, float* out, lwg_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Liquid Warping Block, attention form (one of 9 sites per frame).
  * Replaces LWB.resize_trans + LWB.transform (attlwb_spade_resunet.py:175-191), the fk/fv 1x1 convs on the

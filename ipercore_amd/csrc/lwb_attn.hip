@@ -131,6 +131,44 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_kernel(const float* __restri
 
 // src_batched = 0: Ks/Vs (ns,h,w,C) shared by all B frames; 1: (B*ns,h,w,C), frame b uses rows b*ns+s.
 // q (B,h,w,C) = fq(tsf_x) incl. bias; Ks/Vs (ns,h,w,C) = Wk x_src / Wv x_src WITHOUT bias; bk/bv (C);
+// The flow resize of LWB.resize_trans (attlwb_spade_resunet.py:175-181: F.interpolate(T, size=(h, w), mode="bilinear", align_corners=True))
+// as its own pass: n = B * ns flow fields (S,S,2) -> (h,w,2).  The attention / fusion kernels do this resize per pixel when handed the
+// full-resolution flows - four 8-byte loads per pixel and source at a stride of S / h pixels, each a trip to HBM at the head of the
+// pixel's dependent chain (flow -> tap addresses -> K / V gathers -> softmax), and the same resize again at every site of the same
+// resolution (seven of the nine sites share one).  Resized once per frame batch and resolution, the block kernels take the (h,w) field
+// with S = h: one coalesced load.  Same formula as the in-kernel resize (results agree to ~1e-6: the compiler contracts the two copies
+// differently); within a run every site uses the same resized field, so a frame stays independent of its batch.
+__global__ void lwg_flow_resize_kernel(const float* __restrict__ T, int n, int S, int h, int w, float* __restrict__ out) {
+    const long total = (long)n * h * w;
+    const float sc_y = h > 1 ? (float)(S - 1) / (float)(h - 1) : 0.f;
+    const float sc_x = w > 1 ? (float)(S - 1) / (float)(w - 1) : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long f = i / ((long)w * h);
+        const float sy = sc_y * (float)y, sx = sc_x * (float)x;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < S - 1 ? 1 : 0), x1 = x0 + (x0 < S - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float2* Tp = reinterpret_cast<const float2*>(T) + (size_t)f * S * S;
+        const float2 t00 = Tp[(size_t)y0 * S + x0], t01 = Tp[(size_t)y0 * S + x1];
+        const float2 t10 = Tp[(size_t)y1 * S + x0], t11 = Tp[(size_t)y1 * S + x1];
+        float2 r;
+        r.x = ly0 * (lx0 * t00.x + lx1 * t01.x) + ly1 * (lx0 * t10.x + lx1 * t11.x);
+        r.y = ly0 * (lx0 * t00.y + lx1 * t01.y) + ly1 * (lx0 * t10.y + lx1 * t11.y);
+        reinterpret_cast<float2*>(out)[i] = r;
+    }
+}
+
+extern "C" int lwg_flow_resize_f32(const float* T, int n, int S, int h, int w, float* out, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!T || !out || n <= 0 || S <= 0 || h <= 0 || w <= 0) return (int)hipErrorInvalidValue;
+    const long total = (long)n * h * w;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(lwg_flow_resize_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, T, n, S, h, w, out);
+    return (int)hipGetLastError();
+}
+
 // T (B,ns,S,S,2) flows in grid_sample coordinates (-2 = background); out (B,h,w,C).
 extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
                                      const float* T, float* out, int B, int ns, int h, int w, int C, int S,

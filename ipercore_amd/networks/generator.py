@@ -233,6 +233,7 @@ class AttentionLWBGenerator(nn.Module):
         B, h, w, C = tsf_x.shape
         if self.lwb_kind != "att":
             ns = Tst.shape[1]
+            Tst = scratch.flow(Tst, h, w)
             if self.lwb_kind == "add":
                 return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), src_batched=batched)
             if self.lwb_kind == "avg":
@@ -242,7 +243,7 @@ class AttentionLWBGenerator(nn.Module):
             return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), gate=g,
                                 scale_w=1.0 if self.lwb_kind == "sg_add" else 1.0 / ns, src_batched=batched)
         q = ops.conv2d(tsf_x, st["fq"], torch.empty_like(tsf_x))
-        att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], Tst, torch.empty_like(tsf_x), src_batched=batched)
+        att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], scratch.flow(Tst, h, w), torch.empty_like(tsf_x), src_batched=batched)
         mean = tsf_x.new_empty(B, C, dtype=torch.float32)
         rstd = tsf_x.new_empty(B, C, dtype=torch.float32)
         nsplit = max(1, min(64, (h * w) // 64))
@@ -484,6 +485,19 @@ class _FeatList(list):
 class _Scratch:
     def __init__(self):
         self.buf = None
+        self.flows = {}
+
+    def flow(self, Tst, h, w):
+        """The (B,ns,S,S,2) flows resized to (h,w) - LWB.resize_trans - once per frame batch and resolution (seven of the nine attention
+        sites share one): the block kernels then read one coalesced value per pixel and source instead of resizing per pixel."""
+        if Tst.shape[2] == h and Tst.shape[3] == w:
+            return Tst
+        if h != w:                                        # the kernels take a square field: fall back to their in-kernel resize
+            return Tst
+        key = (h, w, Tst.data_ptr())
+        if key not in self.flows:
+            self.flows[key] = ops.flow_resize(Tst, h, w)
+        return self.flows[key]
 
     def get(self, n, device):
         if self.buf is None or self.buf.numel() < n or self.buf.device != device:

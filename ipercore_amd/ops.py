@@ -309,6 +309,15 @@ def instnorm_apply(x, mean, rstd, y, act=ACT_NONE, res=None):
     return y
 
 
+def flow_resize(T, h, w):
+    """(B,ns,S,S,2) flows -> (B,ns,h,w,2): F.interpolate(bilinear, align_corners=True) of LWB.resize_trans as its own pass."""
+    B, ns, S = T.shape[0], T.shape[1], T.shape[2]
+    T = T.contiguous()
+    out = torch.empty(B, ns, h, w, 2, device=T.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_flow_resize_f32(_ptr(T), B * ns, S, h, w, _ptr(out), _stream()), "lwg_flow_resize_f32")
+    return out
+
+
 def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     B, h, w, C = q.shape
     ns = T.shape[1]

@@ -128,6 +128,13 @@ def instnorm_apply(x, mean, rstd, y, act=0, res=None):
     return y
 
 
+def flow_resize(T, h, w):
+    """lwg_flow_resize_f32 = LWB.resize_trans: F.interpolate(bilinear, align_corners=True) of every (S,S,2) flow field."""
+    B, ns, S = T.shape[0], T.shape[1], T.shape[2]
+    Tf = F.interpolate(T.reshape(B * ns, S, S, 2).permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True)
+    return Tf.permute(0, 2, 3, 1).reshape(B, ns, h, w, 2).contiguous()
+
+
 def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False, _differentiable=False):
     B, h, w, C = q.shape
     ns, S = T.shape[1], T.shape[2]
@@ -345,7 +352,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd"):
+                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -173,6 +173,18 @@ def check_lwb_attention():
         key = f"C{C}_h{h}_S{S}_b{int(batched)}"
         out[key] = {"max_abs": err.max().item(), "mean_abs": err.mean().item(), "n_gt_2e-5": int((err > 2e-5).sum()),
                     "numel": err.numel(), "ref_max": want.abs().max().item()}
+        if S != h:
+            # the engine's form: the flows resized once (lwg_flow_resize_f32 = LWB.resize_trans), the block kernel on the (h,w) field
+            Tr = ops.flow_resize(T.to(DEV), h, h)
+            torch.cuda.synchronize()
+            werr = (Tr.cpu().double() - emu_ops.flow_resize(T.double(), h, h)).abs().max().item()
+            assert werr <= 4e-6 * S, (key, "flow_resize", werr)            # the fp32 lambda of the align_corners resize: ~S * 2^-24
+            got2 = ops.lwb_attention(q.to(DEV), Ks.to(DEV), Vs.to(DEV), bk.to(DEV), bv.to(DEV), Tr,
+                                     torch.full((B, h, h, C), float("nan"), device=DEV), src_batched=batched)
+            torch.cuda.synchronize()
+            out[key]["pre_resized_vs_in_kernel_max"] = (got2 - got).abs().max().item()
+            # not bitwise: the compiler contracts the two copies of the bilinear formula differently (1-ulp flows, amplified by the taps)
+            assert out[key]["pre_resized_vs_in_kernel_max"] <= 2e-5 * max(1.0, out[key]["ref_max"]), (key, out[key])
     for key, m in out.items():
         assert m["max_abs"] <= 5e-4 * max(1.0, m["ref_max"]) and m["mean_abs"] <= 2e-5, (key, m)
     return out
