@@ -30,8 +30,10 @@ __device__ __forceinline__ unsigned lwg_pack2(float lo, float hi) {
 // ---------------------------------------------------------------------------------------------- Liquid Warping Block (attention)
 // csrc/lwb_attn.hip lwg_lwb_attn_kernel on bf16 q / Ks / Vs / out: one pixel per LPP = C/8 lanes, 16-byte gathers of 8 channels,
 // fp32 flows, fp32 online softmax.
-template <int LPP, bool BUF>      // BUF: as in lwg_lwb_attn_kernel - unconditional zero-filling buffer loads for the eight taps of a source
-__global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ Ks,
+// BUF: as in lwg_lwb_attn_kernel - zero-filling buffer loads for the taps; PAIR: two sources in flight; OCC: resident waves per SIMD the
+// register allocation is held to (the kernel runs on the number of pixel chains in flight)
+template <int LPP, bool BUF, bool PAIR, int OCC>
+__global__ __launch_bounds__(256, OCC) void lwg_lwb_attn_bf16_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ Ks,
                                                                const __bf16* __restrict__ Vs, const float* __restrict__ bk,
                                                                const float* __restrict__ bv, const float* __restrict__ T,
                                                                __bf16* __restrict__ out, int B, int ns, int h, int w, int S, int src_batched) {
@@ -47,10 +49,13 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
     const int hw = h * w;
     const long gp = ((long)b * h + y) * w + x;
 
-    float q8[8], bk8[8], bv8[8];
+    float q8[8];
     lwg_unpack8(*reinterpret_cast<const uintx4*>(q + gp * C + 8 * cl), q8);
+    // the biases leave the loop (registers = resident waves = pixel chains in flight, which is what this kernel runs on):
+    // sum_k (K_k + bk_k) q_k = sum_k K_k q_k + qbk, and sum_s a_s (V_s + bv) = sum_s a_s V_s + bv because the a_s sum to one
+    float qbk = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { bk8[k] = bk[8 * cl + k]; bv8[k] = bv[8 * cl + k]; }
+    for (int k = 0; k < 8; ++k) qbk += bk[8 * cl + k] * q8[k];
 
     // flow resize S x S -> h x w, bilinear, align_corners=True (ATen area_pixel_compute_source_index)
     const float sc_y = h > 1 ? (float)(S - 1) / (float)(h - 1) : 0.f;
@@ -68,7 +73,8 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = 0.f;
 
-    for (int s = 0; s < ns; ++s) {
+    // one source: the flow of this pixel -> sampling position (grid_sample, align_corners=False) -> corner tap + bilinear weights
+    auto position = [&](int s, int& tx0, int& ty0, float& wx0, float& wx1, float& wy0, float& wy1) {
         const float2* Tp = reinterpret_cast<const float2*>(T) + ((size_t)b * ns + s) * S * S;
         float gx, gy;
         if (same) {
@@ -82,39 +88,81 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
         }
         const float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
         const float fx0 = floorf(ix), fy0 = floorf(iy);
-        const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
-        const int tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
-        const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
-        const __bf16* Kb = Ks + sidx * hw * C + 8 * cl;
-        const __bf16* Vb = Vs + sidx * hw * C + 8 * cl;
-        float ka[8], va[8];
+        wx1 = ix - fx0; wy1 = iy - fy0; wx0 = (fx0 + 1.f) - ix; wy0 = (fy0 + 1.f) - iy;
+        tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f); ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+    };
+    // logit of one source from its warped K, online-softmax update with its warped V
+    auto fold = [&](const float (&ka)[8], const float (&va)[8]) {
+        float dot = qbk;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ka[k] = va[k] = 0.f;
-        if (BUF) {
-            const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
-            const int nbytes = (int)(nsrc * (unsigned)hw * (unsigned)C * 2u);
-            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ks), 0, nbytes, 0x00020000);
-            __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vs), 0, nbytes, 0x00020000);
-            const unsigned sbase = ((unsigned)sidx * (unsigned)hw * (unsigned)C + 8u * (unsigned)cl) * 2u;
-            uintx4 kr[4], vr[4];
+        for (int k = 0; k < 8; ++k) dot += ka[k] * q8[k];
+#pragma unroll
+        for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const float logit = dot * inv_sqrt_c;
+        const float mnew = fmaxf(mrun, logit);
+        const float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first source
+        const float pr = expf(logit - mnew);
+        lrun = lrun * corr + pr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = o[k] * corr + pr * va[k];
+        mrun = mnew;
+    };
+    if (BUF) {
+        // sources two at a time: the flow loads and the sixteen K / V gathers of a PAIR are in flight together - the kernel is a latency
+        // chain (flow -> addresses -> gathers -> softmax) with two pixels per wave, so the second source's chain rides under the first's
+        const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
+        const int nbytes = (int)(nsrc * (unsigned)hw * (unsigned)C * 2u);
+        __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ks), 0, nbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vs), 0, nbytes, 0x00020000);
+        struct Taps { uintx4 kr[4], vr[4]; float wx0, wx1, wy0, wy1; };
+        auto issue = [&](int s, Taps& tp) {
+            int tx0, ty0;
+            position(s, tx0, ty0, tp.wx0, tp.wx1, tp.wy0, tp.wy1);
+            const unsigned sidx = (unsigned)(src_batched ? b * ns + s : s);
+            const unsigned sbase = (sidx * (unsigned)hw * (unsigned)C + 8u * (unsigned)cl) * 2u;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
                 const bool ok = ty >= 0 && ty < h && tx >= 0 && tx < w;
                 const unsigned voff = ok ? sbase + (unsigned)(ty * w + tx) * (unsigned)C * 2u : 0xC0000000u;
-                kr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
-                vr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
+                tp.kr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
+                tp.vr[t] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
             }
+        };
+        auto consume = [&](const Taps& tp) {
+            float ka[8], va[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ka[k] = va[k] = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
+                const float wt = ((t >> 1) ? tp.wy1 : tp.wy0) * ((t & 1) ? tp.wx1 : tp.wx0);
                 float k8[8], v8[8];
-                lwg_unpack8(kr[t], k8);
-                lwg_unpack8(vr[t], v8);
+                lwg_unpack8(tp.kr[t], k8);
+                lwg_unpack8(tp.vr[t], v8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { ka[k] += k8[k] * wt; va[k] += v8[k] * wt; }
             }
-        } else {
+            fold(ka, va);
+        };
+        for (int s = 0; s < ns; s += PAIR ? 2 : 1) {
+            Taps t0, t1;
+            const bool two = PAIR && s + 1 < ns;   // wave-uniform
+            issue(s, t0);
+            if (two) issue(s + 1, t1);
+            consume(t0);
+            if (two) consume(t1);
+        }
+    } else {
+        for (int s = 0; s < ns; ++s) {
+            int tx0, ty0;
+            float wx0, wx1, wy0, wy1;
+            position(s, tx0, ty0, wx0, wx1, wy0, wy1);
+            const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
+            const __bf16* Kb = Ks + sidx * hw * C + 8 * cl;
+            const __bf16* Vb = Vs + sidx * hw * C + 8 * cl;
+            float ka[8], va[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ka[k] = va[k] = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
@@ -128,26 +176,14 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bf16_kernel(const __bf16* __
                     for (int k = 0; k < 8; ++k) { ka[k] += k8[k] * wt; va[k] += v8[k] * wt; }
                 }
             }
+            fold(ka, va);
         }
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dot += (ka[k] + bk8[k]) * q8[k];
-#pragma unroll
-        for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-        const float logit = dot * inv_sqrt_c;
-        const float mnew = fmaxf(mrun, logit);
-        const float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first source
-        const float pr = expf(logit - mnew);
-        lrun = lrun * corr + pr;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = o[k] * corr + pr * (va[k] + bv8[k]);
-        mrun = mnew;
     }
     if (live) {
         const float invl = 1.f / lrun;
         uintx4 r;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = lwg_pack2(o[2 * k] * invl, o[2 * k + 1] * invl);
+        for (int k = 0; k < 4; ++k) r[k] = lwg_pack2(o[2 * k] * invl + bv[8 * cl + 2 * k], o[2 * k + 1] * invl + bv[8 * cl + 2 * k + 1]);
         *reinterpret_cast<uintx4*>(out + gp * C + 8 * cl) = r;
     }
 }
@@ -159,17 +195,28 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
     if (!q || !Ks || !Vs || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0) return (int)hipErrorInvalidValue;
     const long total = lwg_tile_frame_positions(B, h, w);
     const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 2ull < 0xC0000000ull;
-#define LWG_ATTN16_LAUNCH(LPP)                                                                                                        \
-    {                                                                                                                                 \
-        const long per_block = 4 * (64 / LPP);                                                                                        \
-        if (buf_ok)                                                                                                                   \
-            hipLaunchKernelGGL((lwg_lwb_attn_bf16_kernel<LPP, true>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
-                               reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(Ks), reinterpret_cast<const __bf16*>(Vs), \
-                               bk, bv, T, reinterpret_cast<__bf16*>(out), B, ns, h, w, S, src_batched);                               \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((lwg_lwb_attn_bf16_kernel<LPP, false>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream, \
-                               reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(Ks), reinterpret_cast<const __bf16*>(Vs), \
-                               bk, bv, T, reinterpret_cast<__bf16*>(out), B, ns, h, w, S, src_batched);                               \
+    static int pair = -1, occ = 0;
+    if (pair < 0) {
+        const char* ev = getenv("LWG_ATTN16_PAIR");      // lab knob: 1 = two sources in flight per wave (159 VGPRs, 3 waves / SIMD) - measured
+        pair = ev ? atoi(ev) : 0;                        // SLOWER (111 vs 97 us at C = 256): the kernel wants more resident pixel chains, not deeper ones
+        const char* eo = getenv("LWG_ATTN16_OCC");       // lab knob: waves per SIMD the registers are held to (4, 5 or 6)
+        occ = eo ? atoi(eo) : 5;
+        if (occ < 4 || occ > 6) occ = 5;
+    }
+    const __bf16* qb = reinterpret_cast<const __bf16*>(q);
+    const __bf16* Kb = reinterpret_cast<const __bf16*>(Ks);
+    const __bf16* Vb = reinterpret_cast<const __bf16*>(Vs);
+    __bf16* ob = reinterpret_cast<__bf16*>(out);
+#define LWG_ATTN16_GO(LPP, BUF, PAIR, OCC)                                                                                              \
+    hipLaunchKernelGGL((lwg_lwb_attn_bf16_kernel<LPP, BUF, PAIR, OCC>), dim3((unsigned)((total + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))), \
+                       dim3(256), 0, stream, qb, Kb, Vb, bk, bv, T, ob, B, ns, h, w, S, src_batched)
+#define LWG_ATTN16_LAUNCH(LPP)                                                          \
+    {                                                                                   \
+        if (!buf_ok) LWG_ATTN16_GO(LPP, false, false, 4);                               \
+        else if (pair) LWG_ATTN16_GO(LPP, true, true, 3);                               \
+        else if (occ == 4) LWG_ATTN16_GO(LPP, true, false, 4);                          \
+        else if (occ == 6) LWG_ATTN16_GO(LPP, true, false, 6);                          \
+        else LWG_ATTN16_GO(LPP, true, false, 5);                                        \
     }
     switch (C) {
         case 64: LWG_ATTN16_LAUNCH(8) break;
@@ -178,6 +225,7 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
         default: return (int)hipErrorInvalidValue;
     }
 #undef LWG_ATTN16_LAUNCH
+#undef LWG_ATTN16_GO
     return (int)hipGetLastError();
 }
 
