@@ -153,6 +153,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                      "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
         "bytes_allreduced_per_step": (nG + nD) * 4 if world > 1 else 0,
+        "exposed_allreduce_ms_per_step": (None if not hasattr(tr, "exposed_allreduce_ms") or tr.exposed_allreduce_ms() is None
+                                          else round(tr.exposed_allreduce_ms(), 3)),
         "allreduce_overlap": getattr(tr.optimizer_G, "overlapped_ranges", None),
         "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
         "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}
