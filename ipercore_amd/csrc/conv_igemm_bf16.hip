@@ -3,19 +3,22 @@
 // ("novel_view 1024x1024 bf16, MFMA bf16 conv tiles").  Replaces the same torch.nn.Conv2d / ConvTranspose2d calls as
 // csrc/conv_igemm.hip (reference generators/attlwb_spade_resunet.py:14-25, :73-93, :202-204, :268-271, :331-340).
 //
-// Same GEMM view as the fp32 kernel (D[M,N] = A[M,K] Wp[K,N], M = B*OH*OW pixels, K = taps*Cin ordered channel-chunk major /
-// tap minor so the shifted re-reads of an activation chunk are L2 hits) with everything that made that kernel the wrong shape
-// for a 16x faster matrix pipe removed:
-//   * activations are STORED as bf16 (half the HBM / L2 bytes of the round-1 kernel, no conversion in the loop); a K-step is
-//     64 channels of one tap = one full 128-byte line per pixel;
-//   * both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no VGPR round trip, no ds_write):
-//     a wave-instruction moves 8 rows x 128 B.  The LDS image is the plain [row][128 B] tile; the eight 16-byte k-octets of a row
-//     sit at slot  octet ^ ((row >> 1) & 7)  - the permutation is applied to the per-lane GLOBAL address of the A gather and
-//     baked into the packed weight panel, the LDS destination stays lane-linear as the DMA requires - which makes every
-//     ds_read_b128 fragment read conflict-free (16 lanes of a read group hit 16 distinct 4-bank groups);
-//   * padding pixels use an out-of-range buffer offset: the DMA writes zeros for them (probed: tools/probes/dma_probe.hip);
-//   * 128 x 128 (or 128 x 64) output tile per 4-wave workgroup, BK = 64: 16 MFMAs per wave between barriers, two LDS stages
-//     (64 KB), two workgroups per CU - one computes while the other waits for its DMA / barrier;
+// The kernels of this file, in the order they were built (DESIGN.md 3.11 has the measurements behind each step):
+//   lwg_conv_bf16_kernel        general launches (strided convs, 1x1 with N != Cin): both operands global -> LDS by LDS-DMA
+//                               (buffer_load_dwordx4 ... lds, 16 B per lane, no VGPR round trip); a K-step = 64 channels of one tap = one
+//                               128-byte line per pixel; 128 x 128 / 128 x 64 tile per 4-wave workgroup or 256 x 256 per 8 waves;
+//   lwg_conv_bf16_halo_kernel   lab variant: the 8 x 16-pixel block's halo staged once per channel chunk, weights still by LDS-DMA;
+//   lwg_conv_bf16_hr_kernel     lab variant: halo tile + weights streamed global -> register ring, one barrier per chunk;
+//   lwg_conv_bf16_hr2_kernel    the 3x3 and 2x2-tap stride-1 launches of the product path: the same with ROW RENAMING - a wave's row
+//                               tile is the image-row pair (i, i + TM), so one fragment read feeds all vertical taps;
+//   lwg_conv_bf16_up4_kernel    ConvTranspose2d(4, 2, 1) with Cin <= 128 as ONE launch (four parities, input block staged once);
+//   lwg_conv_bf16_pw_kernel     1x1 C -> C (query projections): weights resident in registers, persistent workgroups;
+//   lwg_conv_c8_bf16_kernel     first layer: fp32 NHWC-8 input converted in registers, no LDS.
+// Shared by all of them:
+//   * the LDS image of an activation / weight row is [row][128 B] with the eight 16-byte k-octets at slot octet ^ key - key =
+//     ((row >> 1) & 7) for linear tiles, ((halo column >> 1) & 7) for halo tiles - applied to the per-lane GLOBAL address (or baked
+//     into the packed panel), the LDS destination stays lane-linear as the DMA requires: every ds_read_b128 is conflict-free;
+//   * padding pixels use an out-of-range buffer offset: loads / LDS-DMA return zeros (probed: tools/probes/dma_probe.hip);
 //   * D^T accumulators (weights as the row operand): a lane owns one pixel and 4 consecutive channels per 8-channel group; the
 //     two half-waves exchange halves (v_permlane32_swap) so a lane stores 8 consecutive channels = one 16-byte bf16 store.
 // Epilogues: bias, ReLU / tanh / sigmoid, residual add, SPADE's IN(x) * (1 + gamma) + beta - all read / written as bf16.
