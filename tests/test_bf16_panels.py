@@ -141,3 +141,49 @@ def test_panel_cache_bookkeeping(monkeypatch):
     assert firsts == [0, sizes[0], sizes[0] + sizes[1]] and calls[0][2] == sum(sizes)
     assert descs[0].w == w1.data_ptr() and descs[2].w == w2.data_ptr() and descs[1].transposed == 1 and list(descs[2].kidx[:4]) == [5, 7, 13, 15]
     assert ctypes.sizeof(_lib.LwgPackDesc) == 264
+
+
+def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
+    """Host logic around two round-2 kernels (no GPU): ops.conv_transpose2d picks the one-launch form only for bf16 tensors with
+    Cin <= 128 and the four parity specs in order, and hands the accounting hook ONE pseudo-spec for the whole transposed
+    convolution; generator._Scratch.flow resizes the flows once per resolution and passes same-size fields through."""
+    from ipercore_amd import _lib
+    from ipercore_amd.networks import generator
+    calls = []
+
+    class _Stub:
+        def lwg_conv_transpose4_nhwc_bf16(self, a, stream):
+            calls.append(("fused", a.contents.ntaps if hasattr(a, "contents") else a.ntaps))
+            return 0
+    monkeypatch.setattr(_lib, "lib", lambda: _Stub())
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "_ptr", lambda t, dt=None: 0 if t is None else t.data_ptr())
+    monkeypatch.setattr(ops, "conv2d", lambda x, s, y, act=0, **kw: calls.append(("parity", s.ooy, s.oox)))
+    hooked = []
+    monkeypatch.setattr(ops, "CONV_HOOK", lambda begin, M, spec, epi=0: hooked.append((begin, M, spec.N, spec.ntaps, spec.algo_kn)))
+
+    specs128 = packing.pack_conv_transpose(_w((128, 64, 4, 4), 20), torch.zeros(64))
+    x = torch.zeros(1, 8, 16, 128, dtype=torch.bfloat16)
+    y = torch.zeros(1, 16, 32, 64, dtype=torch.bfloat16)
+    ops.conv_transpose2d(x, specs128, y, act=ops.ACT_RELU)
+    assert calls == [("fused", 4)]
+    assert hooked == [(True, 128, 256, 16, 4 * specs128[0].algo_kn), (False, 128, 256, 16, 4 * specs128[0].algo_kn)]
+    assert specs128[0]._w16up.shape == (4, 2 * 4, 4, 64, 16)                   # [parity][Cin/64 * taps][ks][N][16]
+
+    calls.clear()
+    specs256 = packing.pack_conv_transpose(_w((256, 128, 4, 4), 21), torch.zeros(128))
+    ops.conv_transpose2d(torch.zeros(1, 8, 16, 256, dtype=torch.bfloat16), specs256, torch.zeros(1, 16, 32, 128, dtype=torch.bfloat16))
+    assert calls == [("parity", 0, 0), ("parity", 0, 1), ("parity", 1, 0), ("parity", 1, 1)]      # Cin = 256: four launches
+    calls.clear()
+    ops.conv_transpose2d(torch.zeros(1, 8, 16, 128), specs128, torch.zeros(1, 16, 32, 64))         # fp32 tensors: four launches
+    assert [c[0] for c in calls] == ["parity"] * 4
+
+    resized = []
+    monkeypatch.setattr(ops, "flow_resize", lambda T, h, w: resized.append((h, w)) or torch.zeros(T.shape[0], T.shape[1], h, w, 2))
+    sc = generator._Scratch()
+    T = torch.zeros(2, 2, 64, 64, 2)
+    a = sc.flow(T, 16, 16)
+    b = sc.flow(T, 16, 16)
+    c = sc.flow(T, 32, 32)
+    assert a is b and a.shape == (2, 2, 16, 16, 2) and c.shape == (2, 2, 32, 32, 2) and resized == [(16, 16), (32, 32)]
+    assert sc.flow(T, 64, 64) is T and sc.flow(T, 16, 32) is T                # same size / non-square: passed through
