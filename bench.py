@@ -630,7 +630,9 @@ def main():
             if args.split_extra and args.precision == "fp32":
                 line["split_products"] = split_products(im, render, n_clip, 1, Ke, last)
             if args.output_frames > 0:
-                line["with_output"] = with_output(im, tgt, FB, args.output_frames, 0)
+                # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
+                # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)
+                line["with_output"] = with_output(im, tgt, min(FB, 16), args.output_frames, 0)
             if args.precision == "fp32" and S == 512:
                 line["b1_latency"] = b1_latency(im, tgt, timer)
                 ops.CONV_HOOK = hook
