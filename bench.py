@@ -29,6 +29,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+from ipercore_amd.launch import self_launch_if_needed  # noqa: E402  (no torch import: runs before the heavy imports)
+
+if __name__ == "__main__":
+    self_launch_if_needed()
+
 # multi-process runs: the host driver supports dmabuf IPC only and the HSA runtime reads this when the first HIP call initialises it -
 # so it must be in the environment BEFORE torch touches the device (it is already exported on the GPU boxes; this is the safety net)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -382,7 +388,8 @@ def novel_view_1024_bf16(dev, timer, W, K):
             piped = K * n / (time.perf_counter() - t1)
         finally:
             im.streams = prev_streams
-        return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": FB, "image_size": S,
+        return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": im.frame_batch,
+                "frame_batch_requested": FB, "image_size": S,
                 "pipelined_3_streams_frames_per_s": round(piped, 2),
                 "dtype": "bf16 MFMA operands + bf16 activation storage, f32 accumulation / renderer",
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -395,6 +402,46 @@ def novel_view_1024_bf16(dev, timer, W, K):
     finally:
         ops.CONV_HOOK = hook
         timer.reset()
+
+
+def size_extra(dev, timer, S, W=1, K=2):
+    """the metric is quoted "at 256 / 512 / 1024" - the same fp32 per-frame path at another image size in a short loop
+    (W warm-up + K timed clips), with the conv kernel's roofline fraction from HIP events.  Reported beside the headline, never as it."""
+    from ipercore_amd import ops, synthetic as syn
+    n = {256: 300, 1024: 96}.get(S, 96)
+    FB = max(2, min(64, int(round(FB_512["fp32"] * (512.0 / S) ** 2))))
+    case = syn.build_case(image_size=S, n_frames=n, ns=2)
+    im = syn.make_imitator(case, frame_batch=FB, device=dev)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    hook = ops.CONV_HOOK
+    try:
+        ops.CONV_HOOK = None
+        for _ in range(W):
+            im.synthesize(tgt, "smooth")
+        timer.reset()
+        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0: timer(b, M, spec, epi, 4))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            video = im.synthesize(tgt, "smooth")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        assert video.shape[0] == n and torch.isfinite(video).all()
+        conv_ms, conv_flops, n_launch, mean_ms = timer.result()
+        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        return {"value": round(K * n / dt, 2), "unit": "frames/s", "image_size": S, "dtype": "f32", "frames_per_clip": n, "clips": K,
+                "frame_batch": im.frame_batch,
+                "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
+                             "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 2), "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
+    except Exception as e:                       # an extra must never take the headline line with it
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        ops.CONV_HOOK = hook
+        timer.reset()
+        del im
+        torch.cuda.empty_cache()
 
 
 def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900):
@@ -413,7 +460,7 @@ def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def main():
+def main(argv=None):
     import faulthandler
     faulthandler.enable()                    # a crash inside a native library leaves a Python traceback on stderr
     ap = argparse.ArgumentParser()
@@ -430,9 +477,14 @@ def main():
                     help="frames per launch batch; 0 = 32 (fp32) / 48 (bf16) at 512x512 scaled by (512/size)^2, clamped to [2, 64]: "
                          "measured in one process 472 / 476 / 478 frames/s at 16 / 24 / 32 (fp32, 512x512) and 723 / 740 / 739 at "
                          "8 / 12 / 16 (bf16, 1024x1024)")
-    ap.add_argument("--gather-dtype", choices=("f32", "u8"), default="f32",
-                    help="N > 1: exchange the (n,3,S,S) fp32 video the reference returns, or the (n,S,S,3) uint8 video its PNG writer "
-                         "consumes (device-side conversion; a quarter of the bytes on the xGMI ring)")
+    ap.add_argument("--gather-dtype", choices=("auto", "f32", "u8"), default="auto",
+                    help="N > 1: exchange the (n,S,S,3) uint8 video the reference's PNG writer consumes (device-side conversion; a quarter "
+                         "of the bytes on the per-link-bound xGMI ring; the default, 'auto' = u8) or, with f32, the (n,3,S,S) fp32 video "
+                         "Imitator.inference returns")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend; nccl = RCCL (the product)")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
+                    help="cpu: plumbing dry run for the CPU test-suite ONLY (tests/test_bench_launch.py installs the emulated C ABI "
+                         "around main(); without it every op raises on CPU tensors - there is no CPU product path)")
     ap.add_argument("--no-overlap-gather", dest="overlap", action="store_false", help="one all-gather after the frame loop")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=("fp32", "bf16", "split"), default="fp32",
@@ -450,20 +502,38 @@ def main():
     ap.add_argument("--no-split-extra", dest="split_extra", action="store_false")
     ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
-    args = ap.parse_args()
+    ap.add_argument("--tiny-arch", action="store_true", help="reduced-width generator (plumbing tests only; never a reported number)")
+    ap.add_argument("--no-self-check", dest="self_check", action="store_false")
+    ap.add_argument("--no-sizes-extra", dest="sizes_extra", action="store_false")
+    args = ap.parse_args(argv)
+    self_launch_if_needed(sys.argv[1:] if argv is None else argv)      # N > 1 without torchrun: spawn the ranks ourselves
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+    else:
+        dev = torch.device("cpu")
+        args.no_conv_events, args.extras, args.cpu_frames = True, False, 0
+
+        def sync():
+            return None
     if world > 1:
-        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and rank == 0:
+        if on_gpu and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and rank == 0:
             print("[bench] HSA_ENABLE_IPC_MODE_LEGACY is not 0: RCCL's IPC handles may fail on this driver", file=sys.stderr)
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group("gloo", init_method="env://")
         assert dist.get_world_size() == world
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gather_dtype == "auto":
+        args.gather_dtype = "u8"
 
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
@@ -476,7 +546,8 @@ def main():
     clip = args.mode == "clip"
     n_clip = args.frames or (180 if args.workload == "novel_view" else 300)
     n_seq = n_clip if clip else (K + W) * FB * world
-    case = pu.build_case(image_size=S, n_frames=n_seq, ns=2)
+    arch = dict(num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128]) if args.tiny_arch else {}
+    case = pu.build_case(image_size=S, n_frames=n_seq, ns=2, **arch)
     im = pu.make_imitator(case, frame_batch=FB, device=dev)
     im.streams = max(1, args.streams)
     if args.workload == "novel_view":
@@ -485,6 +556,7 @@ def main():
     if args.precision != "fp32":
         im.generator.conv_precision = args.precision
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    FB_requested, FB = FB, im.frame_batch        # what RUNS: the imitator clamps the request to the 3 GiB-per-tensor limit of the conv kernels
     if rank == 0:                                                # what tools/pmc_summary.py stamps the PMC traffic file with
         try:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -500,17 +572,17 @@ def main():
     ops.CONV_HOOK = hook
 
     post = None
-    if args.gather_dtype == "u8":
+    if args.gather_dtype == "u8" and world > 1:      # the exchange format; at N = 1 nothing is exchanged and the fp32 video is the result
         def post(x):
             return ops.frames_to_u8(x) if x.shape[0] else torch.empty((0, S, S, 3), device=x.device, dtype=torch.uint8)
     stats = {}
 
     if clip:
         def step(i):
-            st = {"sync": torch.cuda.synchronize} if world > 1 else {}
+            st = {"sync": sync} if world > 1 else {}
             v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=post, stats=st)
             stats.setdefault("exposed_gather_s", []).append(st.get("exposed_gather_s"))
-            stats.update({k: st[k] for k in ("shard", "bytes_received", "chunks") if k in st})
+            stats.update({k: st[k] for k in ("shard", "bytes_received", "chunks", "chunk_lengths") if k in st})
             return v
         frames_per_step = n_clip
     else:
@@ -529,23 +601,46 @@ def main():
         last = step(i)
     if last is None and world > 1:
         last = step(0)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     stats.pop("exposed_gather_s", None)
     timer.reset()
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(W, W + K):
         last = step(i)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
     assert last.shape[0] == frames_per_step and bool(torch.isfinite(last.float()).all())
+
+    # self-check, outside the timed region: 8 frames spread over the clip rendered again ONE frame per launch (the reference's calling
+    # convention, imitator.py:341) must equal the frames of the timed step bit for bit - every launch shape the timed loop used (full
+    # frame batches, the tail, at N > 1 the other ranks' shards through the exchange) against the B = 1 kernels
+    self_check = None
+    if args.self_check and clip and last.shape[0] == n_clip:
+        idx = sorted(set(int(round(x)) for x in np.linspace(0, n_clip - 1, 8)))
+        prev_fb, prev_streams, prev_hook = im.frame_batch, im.streams, ops.CONV_HOOK
+        im.frame_batch, im.streams, ops.CONV_HOOK = 1, 1, None
+        try:
+            bad = []
+            for t in idx:
+                one = im.synthesize(tgt[t:t + 1], "smooth", t0=t)
+                one = one if post is None else post(one)
+                same = torch.equal(one[0], last[t]) if on_gpu else \
+                    bool((one[0].float() - last[t].float()).abs().max() <= (1.0 if one.dtype == torch.uint8 else 2e-4))
+                if not same:
+                    bad.append(t)
+            sync()
+        finally:
+            im.frame_batch, im.streams, ops.CONV_HOOK = prev_fb, prev_streams, prev_hook
+        assert not bad, f"self-check failed: frames {bad} of the timed step differ from their frame_batch = 1 rendering"
+        self_check = {"result": "bitwise" if on_gpu else "allclose (cpu plumbing run)", "frames": idx, "against": "the same frames rendered one per launch (frame_batch = 1)"}
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -555,7 +650,7 @@ def main():
     if world > 1 and clip:
         mine_stats = {"rank": rank, "shard": list(stats.get("shard", ())), "frames": stats["shard"][1] - stats["shard"][0],
                       "exposed_gather_ms_per_step": round(1e3 * float(np.mean([x for x in stats.get("exposed_gather_s", []) if x is not None] or [0.0])), 3),
-                      "bytes_received_per_step": stats.get("bytes_received")}
+                      "bytes_received_per_step": stats.get("bytes_received"), "chunk_lengths": stats.get("chunk_lengths")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_stats)
 
@@ -569,13 +664,14 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if clip else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split"}[args.precision],
-            "data": "synthetic",
+            "data": "synthetic" + (" (tiny architecture, CPU plumbing run: NOT a measurement)" if (args.tiny_arch or not on_gpu) else ""),
             "config": {"workload": (f"run_imitator {S}x{S} single src/ref pair, {n_clip}-frame reference clip frame-sharded over {world} GPU(s), "
                                     "AttLWB-SPADE generator fp32 (BASELINE configs[1] at N = 1, configs[2] at N = 8)" if clip else
                                     f"run_imitator {S}x{S} single src/ref pair, one {FB}-frame batch per GPU per step (weak scaling)")
                        if args.precision == "fp32" else
                        f"per-frame path {S}x{S}, AttLWB-SPADE generator, precision mode {args.precision}",
-                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frames_per_step": frames_per_step,
+                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frame_batch_requested": FB_requested,
+                       "frames_per_step": frames_per_step,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "parallelism": f"frame-shard x{world}" + (f" + RCCL all-gather of the output video ({args.gather_dtype}), " +
                                                                   ("chunked behind the frame loop" if args.overlap else "one collective")
@@ -585,6 +681,9 @@ def main():
         }
         if per_rank is not None:
             line["config"]["per_rank"] = per_rank
+        line["self_check"] = self_check["result"] if self_check else None
+        if self_check:
+            line["self_check_detail"] = self_check
         if n_launch:
             traffic, traffic_src = None, None
             tname = {"fp32": "pmc_traffic.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
@@ -633,6 +732,8 @@ def main():
                 # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
                 # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)
                 line["with_output"] = with_output(im, tgt, min(FB, 16), args.output_frames, 0)
+            if args.precision == "fp32" and S == 512 and args.sizes_extra:
+                line["sizes"] = {str(S2): size_extra(dev, timer, S2) for S2 in (256, 1024)}
             if args.precision == "fp32" and S == 512:
                 line["b1_latency"] = b1_latency(im, tgt, timer)
                 ops.CONV_HOOK = hook

@@ -27,6 +27,12 @@ sys.path.insert(0, ROOT)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:                  # before the first HIP call (see bench.py)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+from ipercore_amd.launch import self_launch_if_needed  # noqa: E402  (N > 1 without torchrun: spawn the ranks ourselves)
+
+if __name__ == "__main__":
+    self_launch_if_needed()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -230,6 +236,7 @@ def main():
     ap.add_argument("--no-overlap-d", dest="overlap_d", action="store_false", help="D's forward / backward after Adam(G), not next to G's backward")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     args = ap.parse_args()
+    self_launch_if_needed()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -2,7 +2,6 @@
 // the attention-form Liquid Warping Block and the output head + compositing (the InstanceNorm statistics live in norm.hip).  Same algorithms and
 // reference citations as their fp32 twins (csrc/norm.hip, csrc/lwb_attn.hip, csrc/head.hip); arithmetic stays fp32, only the
 // tensors in HBM are bf16: half the bytes per launch, 16-byte accesses carry 8 channels.
-#include <stdlib.h>
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
@@ -195,14 +194,6 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
     if (!q || !Ks || !Vs || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0) return (int)hipErrorInvalidValue;
     const long total = lwg_tile_frame_positions(B, h, w);
     const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 2ull < 0xC0000000ull;
-    static int pair = -1, occ = 0;
-    if (pair < 0) {
-        const char* ev = getenv("LWG_ATTN16_PAIR");      // lab knob: 1 = two sources in flight per wave (159 VGPRs, 3 waves / SIMD) - measured
-        pair = ev ? atoi(ev) : 0;                        // SLOWER (111 vs 97 us at C = 256): the kernel wants more resident pixel chains, not deeper ones
-        const char* eo = getenv("LWG_ATTN16_OCC");       // lab knob: waves per SIMD the registers are held to (4, 5 or 6)
-        occ = eo ? atoi(eo) : 5;
-        if (occ < 4 || occ > 6) occ = 5;
-    }
     const __bf16* qb = reinterpret_cast<const __bf16*>(q);
     const __bf16* Kb = reinterpret_cast<const __bf16*>(Ks);
     const __bf16* Vb = reinterpret_cast<const __bf16*>(Vs);
@@ -213,10 +204,7 @@ extern "C" int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void*
 #define LWG_ATTN16_LAUNCH(LPP)                                                          \
     {                                                                                   \
         if (!buf_ok) LWG_ATTN16_GO(LPP, false, false, 4);                               \
-        else if (pair) LWG_ATTN16_GO(LPP, true, true, 3);                               \
-        else if (occ == 4) LWG_ATTN16_GO(LPP, true, false, 4);                          \
-        else if (occ == 6) LWG_ATTN16_GO(LPP, true, false, 6);                          \
-        else LWG_ATTN16_GO(LPP, true, false, 5);                                        \
+        else LWG_ATTN16_GO(LPP, true, (LWG_ATTN16_PAIR != 0), (LWG_ATTN16_PAIR ? 3 : LWG_ATTN16_OCC)); \
     }
     switch (C) {
         case 64: LWG_ATTN16_LAUNCH(8) break;
@@ -354,23 +342,12 @@ extern "C" int lwg_head_compose_bf16(const void* x, const void* wb, const float*
     if (!x || !wb || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C != 64 || B > 65535) return (int)hipErrorInvalidValue;
     const unsigned long long xbytes = (unsigned long long)B * S * S * 128ull;
     if (xbytes >= 0xC0000000ull) return (int)hipErrorInvalidValue;
-    static int ncb = 0;
-    if (ncb == 0) {
-        const char* ev = getenv("LWG_HEAD16_NCB");      // lab knob: 16-pixel column blocks per tile row (4 or 2)
-        ncb = ev ? atoi(ev) : 2;
-        if (ncb != 2 && ncb != 3 && ncb != 4) ncb = 2;
-    }
+    constexpr int ncb = LWG_HEAD16_NCB;             // 16-pixel column blocks per tile row (compile-time, lwg_common.h)
+    static_assert(ncb == 2 || ncb == 3 || ncb == 4, "LWG_HEAD16_NCB");
     const int tw = ncb == 3 ? 32 : 16 * ncb - 4;
     const size_t lds = (size_t)H16_HROWS * 16 * ncb * 128;       // >= the partial sums: TH * 5 * (16 NCB + 4) * 16 B
     const unsigned grid = (unsigned)(((S + tw - 1) / tw) * ((S + H16_TH - 1) / H16_TH) * B);
-    if (ncb == 4)
-        hipLaunchKernelGGL(lwg_head_bf16_kernel<4>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
-                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
-    else if (ncb == 3)
-        hipLaunchKernelGGL(lwg_head_bf16_kernel<3>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
-                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
-    else
-        hipLaunchKernelGGL(lwg_head_bf16_kernel<2>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
-                           reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
+    hipLaunchKernelGGL(lwg_head_bf16_kernel<ncb>, dim3(grid), dim3(256), lds, stream, reinterpret_cast<const __bf16*>(x),
+                       reinterpret_cast<const __bf16*>(wb), bg, bg_bstride, S, (unsigned)xbytes, pred, mask, img);
     return (int)hipGetLastError();
 }

@@ -28,7 +28,6 @@
 // consecutive channels of each 32x32 tile, so the epilogue issues 16-byte NHWC stores and does the pixel
 // index math once per row tile.
 // Epilogues fuse bias, ReLU/tanh/sigmoid, the residual add, or SPADE's IN(x)*(1+gamma)+beta.
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -389,13 +388,8 @@ __global__ __launch_bounds__(256) void lwg_splitk_finish_kernel(const LwgConvArg
 // workgroup or none, while 3-4 fit (33 KB LDS, ~80 VGPRs).  Slices are whole 32-channel chunks (all taps of a chunk stay
 // together, so the L2-friendly tap-minor K order is kept) with at least 8 K-steps each.
 static int lwg_conv_split_plan(const LwgConvArgs& a, int* chunks_per_slice) {
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* ev = getenv("LWG_CONV_SPLITK");            // tuning knob: 0 disables
-        enabled = ev ? atoi(ev) : 1;
-    }
     const int Cin = a.C0 + a.C1;
-    if (!enabled || a.epi != LWG_EPI_NONE || (Cin % 32) != 0) return 0;
+    if (!LWG_CONV_SPLITK || a.epi != LWG_EPI_NONE || (Cin % 32) != 0) return 0;
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (tiles128 >= 300) return 0;                              // not the 64x64 regime (launch_epi)
     const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
@@ -446,12 +440,7 @@ static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream, float* ws
     // quadruple the workgroup count (each wave then owns one 32x32 MFMA tile: fewer flops per staged byte, but it runs)
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if constexpr (EPI != LWG_EPI_SPADE && !SMALLC) {
-        static long small_thr = -1;
-        if (small_thr < 0) {
-            const char* ev = getenv("LWG_CONV_SMALL_TILES");   // tuning knob
-            small_thr = ev ? atol(ev) : 300;
-        }
-        if (tiles128 < small_thr) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream, ws);  // 64 x 64 (split-K when ws is given)
+        if (tiles128 < (long)LWG_CONV_SMALL_TILES) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream, ws);  // 64 x 64 (split-K when ws is given)
     }
     if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg<2, 2, 2, 2, EPI, SMALLC>(a, stream);  // 128 x 128
     return launch_cfg<4, 1, 1, 2, EPI, SMALLC>(a, stream);                                                // 128 x 64

@@ -7,10 +7,9 @@
 //   lwg_conv_bf16_kernel        general launches (strided convs, 1x1 with N != Cin): both operands global -> LDS by LDS-DMA
 //                               (buffer_load_dwordx4 ... lds, 16 B per lane, no VGPR round trip); a K-step = 64 channels of one tap = one
 //                               128-byte line per pixel; 128 x 128 / 128 x 64 tile per 4-wave workgroup or 256 x 256 per 8 waves;
-//   lwg_conv_bf16_halo_kernel   lab variant: the 8 x 16-pixel block's halo staged once per channel chunk, weights still by LDS-DMA;
-//   lwg_conv_bf16_hr_kernel     lab variant: halo tile + weights streamed global -> register ring, one barrier per chunk;
-//   lwg_conv_bf16_hr2_kernel    the 3x3 and 2x2-tap stride-1 launches of the product path: the same with ROW RENAMING - a wave's row
-//                               tile is the image-row pair (i, i + TM), so one fragment read feeds all vertical taps;
+//   lwg_conv_bf16_hr2_kernel    the 3x3 and 2x2-tap stride-1 launches: the 8 x 16-pixel block's halo staged once per channel chunk,
+//                               weights streamed global -> register ring (one barrier per chunk), ROW RENAMING - a wave's row tile
+//                               is the image-row pair (i, i + TM), so one fragment read feeds all vertical taps;
 //   lwg_conv_bf16_up4_kernel    ConvTranspose2d(4, 2, 1) with Cin <= 128 as ONE launch (four parities, input block staged once);
 //   lwg_conv_bf16_pw_kernel     1x1 C -> C (query projections): weights resident in registers, persistent workgroups;
 //   lwg_conv_c8_bf16_kernel     first layer: fp32 NHWC-8 input converted in registers, no LDS.
@@ -22,8 +21,6 @@
 //   * D^T accumulators (weights as the row operand): a lane owns one pixel and 4 consecutive channels per 8-channel group; the
 //     two half-waves exchange halves (v_permlane32_swap) so a lane stores 8 consecutive channels = one 16-byte bf16 store.
 // Epilogues: bias, ReLU / tanh / sigmoid, residual add, SPADE's IN(x) * (1 + gamma) + beta - all read / written as bf16.
-#include <stdlib.h>
-
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
@@ -381,365 +378,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Halo-tile variant for the stride-1 convolutions whose taps lie in [-1, 1]^2 (every 3x3 conv of the generator and the 2x2-tap
-// parity launches of its transposed convs: > 90 % of the flops).  The linear kernel above re-fetches an activation chunk once per
-// tap (9 x for a 3x3 conv) - all L2 hits, but every one of them travels L2 -> LDS again, and that path (about 55 GB/s per CU
-// here, measured) is what bounds the kernel, not the matrix pipe.  Here a workgroup's 128 GEMM rows are an 8 x 16 PIXEL BLOCK of
-// one image: its (8+2) x (16+2) halo, 64 channels deep, is staged ONCE per channel chunk (23 KB by LDS-DMA, out-of-image pixels
-// = out-of-range offsets = zeros) and all taps read their operand fragments from it at shifted pixel positions; only the weight
-// panel of the (chunk, tap) step streams every step.  L2 -> LDS bytes per 3x3 step: 16 KB + 23.5/9 KB instead of 32 KB.
-// LDS image of the halo: [pixel hp = hy*18 + hx][128 B], k-octet o at slot o ^ ((hp >> 1) & 7) (the same rule as the row tiles:
-// a fragment read's 32 lanes are two runs of 16 consecutive halo pixels).  Two halo buffers (chunk c+1 lands while chunk c
-// computes) + two weight stages = 78 KB: two workgroups per CU.
+// Halo tile + register-streamed weights + row renaming: the 3x3 and 2x2-tap stride-1 launches (every 3x3 conv of the generator and
+// the parity launches of its transposed convs: > 90 % of the flops).
+// The linear kernel above puts a barrier and a "wait for ALL my outstanding loads" into every K-step, and each step's operands are
+// requested one step ahead: the step time cannot go below one L2 round trip (~1 us under load, measured: res-block launch = 36
+// steps x 1.1 us whatever the bytes per step) while its 16 MFMAs need 0.25 us.  It also re-fetches an activation chunk once per tap.
+//   * activations: a workgroup's 128 GEMM rows are an 8 x 16 PIXEL BLOCK of one image; its (8+2) x (16+2) halo, 64 channels deep
+//     (23 KB, out-of-image pixels = out-of-range offsets = zeros), is staged ONCE per channel chunk THROUGH REGISTERS (global -> VGPR
+//     at the top of a chunk, ds_write at its end: nine steps of latency slack), double-buffered - one barrier per chunk, none inside
+//     it; all taps read their operand fragments from it at shifted pixel positions.  LDS image: [pixel hp = hy*18 + hx][128 B],
+//     k-octet o at slot o ^ ((halo column >> 1) & 7);
+//   * weights: never in LDS.  Each wave loads ITS fragments straight from the packed panel (lane-contiguous 1 KB per load) into a
+//     register ring D steps ahead; the compiler's counted vmcnt waits for exactly the oldest ring slot.  Panel layout:
+//     [step = chunk*ntaps + tap][ks 4][N][16] (the two k-octets of MFMA k-step ks); SPADE panels interleave gamma | beta in blocks
+//     of 16 columns so one 32-column tile carries both for 16 channels;
+//   * row renaming: with one 1 KB activation fragment read from LDS per MFMA and eight waves per CU the LDS port is exactly as busy
+//     as the matrix pipe would be at 100 % (PMC on that first form: matrix pipe 52 %).  Here a wave's row tile i is the image-row
+//     PAIR (i, i + TM) of its 2*TM rows instead of (2i, 2i + 1).  A tap's vertical shift then maps row tile i onto row tile i + dy:
+//     the fragments E_e = rows (e + dymin, e + dymin + TM), e = 0 .. TM + NDY - 2, are read once per (tap column, k-step) and feed ALL
+//     NDY vertical taps by register renaming - TM + NDY - 1 reads for NDY * TM MFMAs (6 for 12 on the 3x3 layers, 5 for 8 on the
+//     2x2-tap up-sampling launches), no shuffles.  Their addresses differ by a constant (one halo row), so a (tap column, k-step)
+//     costs one address computation.  The weight ring holds 4 * D fragments refilled one fragment at a time; taps must be an
+//     ascending NDY x NDX grid (the host sorts them).
+// The two earlier forms (halo tile with LDS-DMA weights; one fragment per MFMA) are in the history of this file, DESIGN.md 3.11 has
+// their measurements.
 #define LWG_HALO_W 18
 #define LWG_HALO_PIX 180
 #define LWG_HALO_PIECES 23                 // 8 pixels per DMA piece; the 23rd is half used
 #define LWG_HALO_BYTES (LWG_HALO_PIECES * 1024)
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, 2) void lwg_conv_bf16_halo_kernel(const LwgConvArgs a) {
-    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    static_assert(BM == 128 && WAVES_M * WAVES_N == 4, "an 8 x 16 pixel block per 4-wave workgroup");
-    constexpr int B_STAGE = BN * 128;
-    constexpr int PB = BN / 32;
-    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;           // halo pieces per wave (the last wave has one fewer)
-
-    extern __shared__ __attribute__((aligned(16))) char smem_h[];
-    char* Ah = smem_h;                                       // [2][LWG_HALO_BYTES]
-    char* Bs = smem_h + 2 * LWG_HALO_BYTES;                  // [2][B_STAGE]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int tiles_n = a.N / BN;
-    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
-    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = lid % tiles_n;
-    int rest = lid / tiles_n;
-    const int tix = rest % tiles_x;
-    rest /= tiles_x;
-    const int tiy = rest % tiles_y, tb = rest / tiles_y;
-    const int x0 = tix * 16, y0 = tiy * 8;
-    const int n_base = tile_n * BN;
-
-    const int Cin = a.C0 + a.C1;
-    const int nchunks = Cin >> 6;
-    const int nsteps = nchunks * a.ntaps;
-    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
-    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 2u;
-    const unsigned wbytes = (unsigned)nsteps * (unsigned)a.N * 128u;
-
-    // halo DMA: piece q = wid * PAH + p covers halo pixels q*8 .. q*8+7; this lane: pixel q*8 + lane/8, LDS slot lane & 7
-    int hpixlin[PAH];                 // linear input pixel (b*H + gy)*W + gx, or -1 outside the image / beyond the halo
-    unsigned hoct[PAH];
-#pragma unroll
-    for (int p = 0; p < PAH; ++p) {
-        const int hp = (wid * PAH + p) * 8 + (lane >> 3);
-        const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
-        hoct[p] = (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u;    // swizzle keyed on the halo COLUMN (see the fragment reads)
-    }
-    unsigned wvoff[PB];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) wvoff[p] = (unsigned)(n_base * 128 + (wid * PB + p) * 1024 + lane * 16);
-
-    auto issue_halo = [&](int chunk, int buf) {
-        const int cc = chunk << 6;
-        const bool use1 = cc >= a.C0;
-        const void* src = use1 ? (const void*)a.x1 : (const void*)a.x0;
-        const unsigned cs = (unsigned)(use1 ? a.C1 : a.C0);
-        const unsigned soff = (unsigned)(cc - (use1 ? a.C0 : 0)) * 2u;
-        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(use1 ? bytes1 : bytes0), 0x00020000);
-#pragma unroll
-        for (int p = 0; p < PAH; ++p) {
-            const int q = wid * PAH + p;
-            if (q < LWG_HALO_PIECES) {                                   // wave-uniform
-                const unsigned voff = hpixlin[p] >= 0 ? (unsigned)hpixlin[p] * cs * 2u + hoct[p] : LWG_OOB_OFFSET;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LWG_LDS_PTR(Ah + buf * LWG_HALO_BYTES + q * 1024), 16, (int)voff, (int)soff, 0, 0);
-            }
-        }
-    };
-    auto issue_b = [&](int step, int buf) {
-        __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
-        const unsigned soffB = (unsigned)step * (unsigned)a.N * 128u;
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LWG_LDS_PTR(Bs + buf * B_STAGE + (wid * PB + p) * 1024), 16, (int)wvoff[p], (int)soffB, 0, 0);
-    };
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int khalf = lane >> 5;
-    // halo pixel of this lane's GEMM row (row r = pixel (r / 16, r % 16) of the block) for tap (0, 0)
-    int hp0[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * TM * 32 + i * 32 + (lane & 31);
-        hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
-    }
-    const int swb = (lane >> 1) & 7;
-    const char* fr_b = Bs + (wn * TN * 32 + (lane & 31)) * 128;
-    int koffb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koffb[ks] = ((2 * ks + khalf) ^ swb) << 4;
-
-    issue_halo(0, 0);
-    issue_b(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-
-    int step = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
-        for (int tap = 0; tap < a.ntaps; ++tap, ++step) {
-            if (step + 1 < nsteps) issue_b(step + 1, (step + 1) & 1);
-            if (tap == 0 && chunk + 1 < nchunks) issue_halo(chunk + 1, (chunk + 1) & 1);
-            const int toff = (int)a.dy[tap] * LWG_HALO_W + (int)a.dx[tap];
-            // k-octet o of halo pixel (hy, hx) sits at slot o ^ ((hx >> 1) & 7): keyed on the column, so the two image rows of a
-            // 32-lane fragment read use the SAME permutation (keyed on the linear halo index the second row was rotated by one
-            // slot against the first: tools/probes/lds_bank_probe.hip measures +4 cycles per ds_read_b128 for that, PMC 48 % of the
-            // LDS-active cycles in bank conflicts)
-            const int swt = (((lane & 15) + 1 + (int)a.dx[tap]) >> 1) & 7;
-            int abase[TM], asw[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int h = hp0[i] + toff;
-                abase[i] = h << 7;
-                asw[i] = swt;
-            }
-            const char* Bcur = fr_b + (step & 1) * B_STAGE;
-            bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + ((khalf ^ asw[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bcur + j * 4096 + koffb[0]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + (((2 * (ks + 1) + khalf) ^ asw[i]) << 4));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bcur + j * 4096 + koffb[ks + 1 < 4 ? ks + 1 : 3]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the next step's pieces have landed
-            __syncthreads();
-        }
-    }
-    lwg_bf16_epilogue<TM, TN, EPI, true>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
-}
-
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
-static hipError_t launch_cfg_bf16_halo(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr int BN = WAVES_N * TN * 32;
-    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES + (size_t)2 * BN * 128;
-    auto kern = lwg_conv_bf16_halo_kernel<WAVES_M, WAVES_N, TM, TN, EPI>;
-    static unsigned long long attr_done = 0ull;
-    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
-    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
-    return hipGetLastError();
-}
-
-// the halo-tile kernel applies to: stride 1, same input / output grid, every tap within [-1, 1]^2, at least two taps
-static bool lwg_bf16_halo_ok(const LwgConvArgs& a) {
-    static int on = -1;
-    if (on < 0) {
-        const char* ev = getenv("LWG_BF16_HALO");    // lab knob: 0 = always the linear kernel
-        on = ev ? atoi(ev) : 1;
-    }
-    if (!on || a.stride != 1 || a.ntaps < 2 || a.ntaps > 9 || a.H != a.OH || a.W != a.OW) return false;
-    for (int t = 0; t < a.ntaps; ++t)
-        if (a.dy[t] < -1 || a.dy[t] > 1 || a.dx[t] < -1 || a.dx[t] > 1) return false;
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Halo tile + register-streamed weights.  The two kernels above put a barrier and a "wait for ALL my outstanding loads" into
-// every K-step, and each step's operands are requested one step ahead: the step time then cannot go below one L2 round trip
-// (~1 us under load, measured: res-block launch = 36 steps x 1.1 us whatever the bytes per step) while its 16 MFMAs need
-// 0.25 us - two workgroups per CU hide part of it (matrix pipe 42 % busy).  This kernel removes both:
-//   * activations: the 8 x 16-pixel block's halo (as above), one buffer per 64-channel chunk, double-buffered, staged THROUGH
-//     REGISTERS (global -> VGPR at the top of a chunk, ds_write at its end: nine steps of latency slack) - one barrier per
-//     chunk, none inside it;
-//   * weights: never in LDS.  Four waves split the 128 columns (wave tile 128 rows x 32 columns, TM = 4, TN = 1: every weight
-//     fragment feeds four MFMAs), each wave loads ITS fragment straight from the packed panel (lane-contiguous 1 KB per load)
-//     into a register ring D steps ahead; the compiler's counted vmcnt waits for exactly the oldest ring slot.
-// No LDS-DMA, no per-step barrier: a wave's K loop is MFMAs + ds_read_b128 + 4 loads per step.  LDS = 46 KB -> three workgroups
-// per CU.  Panel layout: [step = chunk*ntaps + tap][ks 4][N][16] (the two k-octets of MFMA k-step ks); SPADE panels interleave
-// gamma | beta in blocks of 16 columns so one 32-column tile carries both for 16 channels.
-template <int NTAPS, int EPI, int D, int WAVES_M>
-__global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_hr_kernel(const LwgConvArgs a) {
-    // WAVES_M = 1: four waves side by side, 128 rows x 32 columns each (N % 128 == 0); WAVES_M = 2: two by two, 64 rows x 32
-    // columns each - the 64-column launches (the last up-sampling layer)
-    constexpr int WAVES_N = 4 / WAVES_M, TM = 4 / WAVES_M, BN = WAVES_N * 32;
-    static_assert(NTAPS % D == 0, "the weight ring must close at a chunk boundary");
-    constexpr int PAH = (LWG_HALO_PIECES + 3) / 4;
-
-    extern __shared__ __attribute__((aligned(16))) char smem_r[];
-    char* Ah = smem_r;                                       // [2][LWG_HALO_BYTES]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int tiles_n = a.N / BN;
-    const int tiles_x = (a.OW + 15) >> 4, tiles_y = (a.OH + 7) >> 3;
-    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = lid % tiles_n;
-    int rest = lid / tiles_n;
-    const int tix = rest % tiles_x;
-    rest /= tiles_x;
-    const int tiy = rest % tiles_y, tb = rest / tiles_y;
-    const int x0 = tix * 16, y0 = tiy * 8;
-    const int n_base = tile_n * BN;
-
-    const int Cin = a.C0 + a.C1;
-    const int nchunks = Cin >> 6;
-    const int nsteps = nchunks * NTAPS;
-    const unsigned bytes0 = (unsigned)a.B * a.H * a.W * a.C0 * 2u;
-    const unsigned bytes1 = (unsigned)a.B * a.H * a.W * a.C1 * 2u;
-    const unsigned wbytes = (unsigned)nsteps * (unsigned)a.N * 128u;
-
-    int hpixlin[PAH];
-    unsigned hoct[PAH];
-#pragma unroll
-    for (int p = 0; p < PAH; ++p) {
-        const int hp = (wid * PAH + p) * 8 + (lane >> 3);
-        const int hy = hp / LWG_HALO_W, hx = hp - hy * LWG_HALO_W;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = hp < LWG_HALO_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        hpixlin[p] = ok ? (tb * a.H + gy) * a.W + gx : -1;
-        hoct[p] = (unsigned)((lane & 7) ^ ((hx >> 1) & 7)) * 16u;    // swizzle keyed on the halo COLUMN (see the fragment reads)
-    }
-    uintx4 hreg[PAH];
-    auto load_halo = [&](int chunk) {
-        const int cc = chunk << 6;
-        const bool use1 = cc >= a.C0;
-        const void* src = use1 ? (const void*)a.x1 : (const void*)a.x0;
-        const unsigned cs = (unsigned)(use1 ? a.C1 : a.C0);
-        const unsigned soff = (unsigned)(cc - (use1 ? a.C0 : 0)) * 2u;
-        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(use1 ? bytes1 : bytes0), 0x00020000);
-#pragma unroll
-        for (int p = 0; p < PAH; ++p) {
-            const unsigned voff = hpixlin[p] >= 0 ? (unsigned)hpixlin[p] * cs * 2u + hoct[p] : LWG_OOB_OFFSET;
-            hreg[p] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff, (int)soff, 0));
-        }
-    };
-    auto store_halo = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < PAH; ++p) {
-            const int q = wid * PAH + p;
-            if (q < LWG_HALO_PIECES) *reinterpret_cast<uintx4*>(Ah + buf * LWG_HALO_BYTES + q * 1024 + lane * 16) = hreg[p];
-        }
-    };
-
-    const int khalf = lane >> 5;
-    // weight fragments: this wave's 32 columns; lane = column (lane & 31), k-octet khalf of MFMA k-step ks
-    const unsigned wv = (unsigned)((n_base + wn * 32 + (lane & 31)) * 32 + khalf * 16);
-    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
-    bf16x8 bq[D][4];
-    auto load_b = [&](int step, int slot) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            bq[slot][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wv, (int)((unsigned)(step * 4 + ks) * (unsigned)a.N * 32u), 0));
-    };
-
-    floatx16 acc[TM][1];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-
-    int hp0[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * TM * 32 + i * 32 + (lane & 31);
-        hp0[i] = ((r >> 4) + 1) * LWG_HALO_W + (r & 15) + 1;
-    }
-    int toffs[NTAPS], tdx[NTAPS];                          // wave-uniform: halo offset of a tap, its column shift
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-        toffs[t] = (int)a.dy[t] * LWG_HALO_W + (int)a.dx[t];
-        tdx[t] = (int)a.dx[t];
-    }
-    const int hx0 = (lane & 15) + 1;                       // halo column of this lane's pixel for a centred tap
-
-    load_halo(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nsteps) load_b(d, d);
-    store_halo(0);
-    __syncthreads();
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
-        const bool more = chunk + 1 < nchunks;
-        if (more) load_halo(chunk + 1);                    // lands during this chunk's NTAPS steps
-#pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int step = chunk * NTAPS + tap;
-            const int slot = tap % D;
-            int abase[TM], asw[TM];
-            int swt = hx0 + tdx[tap];                      // slot permutation keyed on the halo column (see the halo-tile kernel above)
-            asm volatile("" : "+v"(swt));                  // opaque, as h below
-            swt = (swt >> 1) & 7;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int h = hp0[i] + toffs[tap];
-                asm volatile("" : "+v"(h));                // opaque: otherwise the 72 (tap, row tile) addresses are hoisted out of the chunk loop and spill
-                abase[i] = h << 7;
-                asw[i] = swt;
-            }
-            bf16x8 fa[2][TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + ((khalf ^ asw[i]) << 4));
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) {                                // the four fragments of k-step ks+1 are in flight during the MFMAs of ks
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(Acur + abase[i] + (((2 * (ks + 1) + khalf) ^ asw[i]) << 4));
-                }
-                if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);      // DS reads first ...
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot][ks], fa[ks & 1][i], acc[i][0], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                  // ... then the MFMAs of this k-step
-            }
-            if (step + D < nsteps) load_b(step + D, slot);  // refill the slot just consumed: D steps of lookahead
-            __builtin_amdgcn_sched_barrier(0);             // keep the unrolled taps apart: hoisting every fragment read of a chunk spills
-        }
-        if (more) {
-            store_halo((chunk + 1) & 1);                   // the other buffer: every wave left it at the previous chunk's barrier
-            __syncthreads();
-        }
-    }
-    lwg_bf16_epilogue<TM, 1, EPI, true>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Row renaming: the register-streamed-weights kernel above reads ONE 1 KB activation fragment from LDS per MFMA; with eight waves
-// per CU that is 128 B / clock - the LDS port is exactly as busy as the matrix pipe would be at 100 % (PMC: matrix pipe 52 %).
-// Here a wave's row tile i is the image-row PAIR (i, i + TM) of its 2*TM rows instead of (2i, 2i + 1).  A tap's vertical shift then
-// maps row tile i onto row tile i + dy: the fragments E_e = rows (e + dymin, e + dymin + TM), e = 0 .. TM + NDY - 2, are read once
-// per (tap column, k-step) and feed ALL NDY vertical taps by register renaming - TM + NDY - 1 reads for NDY * TM MFMAs (6 for 12 on
-// the 3x3 layers, 5 for 8 on the 2x2-tap up-sampling launches), no shuffles.  Their addresses differ by a constant (one halo row),
-// so a (tap column, k-step) costs one address computation.  Weights: the same panel and a ring of 4 * D fragments refilled one
-// fragment at a time; taps must be an ascending NDY x NDX grid (the host sorts them).
 template <int NDY, int NDX, int EPI, int WAVES_M>
 __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void lwg_conv_bf16_hr2_kernel(const LwgConvArgs a) {
     constexpr int NTAPS = NDY * NDX;
@@ -1149,12 +816,9 @@ static hipError_t launch_cfg_bf16_pw_tm(const LwgConvArgs& a, hipStream_t stream
 
 template <int NCH, int WAVES_N>
 static hipError_t launch_cfg_bf16_pw(const LwgConvArgs& a, hipStream_t stream) {
-    static int tm = 0;
-    if (tm == 0) {
-        const char* ev = getenv("LWG_BF16_PW_TM");   // lab knob: 4 = one 8-wave workgroup per CU with 128-row wave tiles, 2 = two with 64-row tiles
-        tm = ev ? atoi(ev) : 2;              // measured in the frame loop: C = 256 51 -> 39 us, C = 128 79 -> 65, C = 64 153 -> 123
-    }
-    return tm == 2 ? launch_cfg_bf16_pw_tm<NCH, WAVES_N, 2>(a, stream) : launch_cfg_bf16_pw_tm<NCH, WAVES_N, 4>(a, stream);
+    // LWG_BF16_PW_TM (compile-time, tools/labbuild.sh): 4 = one 8-wave workgroup per CU with 128-row wave tiles, 2 = two with 64-row
+    // tiles - measured in the frame loop: C = 256 51 -> 39 us, C = 128 79 -> 65, C = 64 153 -> 123
+    return launch_cfg_bf16_pw_tm<NCH, WAVES_N, LWG_BF16_PW_TM>(a, stream);
 }
 
 static bool lwg_bf16_pw_ok(const LwgConvArgs& a) {
@@ -1249,30 +913,11 @@ extern "C" int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* pa, lwg_stream_t strea
     return hipGetLastError();
 }
 
-template <int NTAPS, int EPI, int D, int WAVES_M>
-static hipError_t launch_cfg_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES;
-    auto kern = lwg_conv_bf16_hr_kernel<NTAPS, EPI, D, WAVES_M>;
-    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / (128 / WAVES_M));
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
-    return hipGetLastError();
-}
-
 template <int EPI>
 static hipError_t launch_epi_bf16_hr(const LwgConvArgs& a, hipStream_t stream) {
-    static int hr2 = -1;
-    if (hr2 < 0) {
-        const char* ev = getenv("LWG_BF16_HR2");     // lab knob: 0 = the one-fragment-per-MFMA kernel for every launch
-        hr2 = ev ? atoi(ev) : 1;
-    }
-    if (hr2 && lwg_bf16_tap_grid(a, 3, 3)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<3, 3, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<3, 3, EPI, 2>(a, stream);
-    if (hr2 && lwg_bf16_tap_grid(a, 2, 2)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<2, 2, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<2, 2, EPI, 2>(a, stream);
-    if (a.N % 128 == 0) {
-        if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3, 1>(a, stream);
-        return launch_cfg_bf16_hr<4, EPI, 2, 1>(a, stream);
-    }
-    if (a.ntaps == 9) return launch_cfg_bf16_hr<9, EPI, 3, 2>(a, stream);
-    return launch_cfg_bf16_hr<4, EPI, 2, 2>(a, stream);
+    if (lwg_bf16_tap_grid(a, 3, 3)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<3, 3, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<3, 3, EPI, 2>(a, stream);
+    if (lwg_bf16_tap_grid(a, 2, 2)) return a.N % 128 == 0 ? launch_cfg_bf16_hr2<2, 2, EPI, 1>(a, stream) : launch_cfg_bf16_hr2<2, 2, EPI, 2>(a, stream);
+    return hipErrorInvalidValue;             // taps must form an ascending 3 x 3 or 2 x 2 grid (packing sorts them)
 }
 
 // args->w = the register-streamed panel [ntaps*Cin/64][4][N][16] (bias / SPADE columns in the matching order, see above);
@@ -1325,38 +970,26 @@ static hipError_t launch_cfg_bf16(const LwgConvArgs& a, hipStream_t stream) {
 
 template <int EPI>
 static hipError_t launch_epi_bf16(const LwgConvArgs& a, hipStream_t stream) {
-    static int dma_a = -1;
-    if (dma_a < 0) {
-        const char* ev = getenv("LWG_BF16_DMA_A");   // lab knob: 0 = A through registers (global -> VGPR -> ds_write), 1 = LDS-DMA
-        dma_a = ev ? atoi(ev) : 1;
-    }
-    static int force64 = -1, cus = 0;
-    if (force64 < 0) {
-        const char* ev = getenv("LWG_BF16_TILE64");  // lab knob: 1 = 128 x 64 tiles wherever the epilogue allows, -1 = never
-        force64 = ev ? atoi(ev) + 2 : 2;             // stored + 2: 1 = never, 2 = heuristic, 3 = always
+    // compile-time tuning constants (tools/labbuild.sh -D...): LWG_BF16_DMA_A 1 = the A operand by LDS-DMA (0: global -> VGPR ->
+    // ds_write); LWG_BF16_TILE64 0 = heuristic below, 1 = 128 x 64 tiles wherever the epilogue allows, -1 = never; LWG_BF16_BIG 1 =
+    // the 8-wave 256 x 256 tile where it applies
+    constexpr bool dma_a = LWG_BF16_DMA_A != 0;
+    static int cus = 0;
+    if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
+    // N % 256 == 0 and at least one 256 x 256 tile per CU: eight waves, wave tile 128 x 64 - six fragment reads per eight MFMAs
+    // instead of four per four (the 4-wave kernel's LDS port is as busy as its matrix pipe)
+    if (LWG_BF16_BIG && dma_a && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= (long)cus) return launch_cfg_bf16<2, 4, 4, 2, EPI, true>(a, stream);
     // a launch with fewer 128 x 128 tiles than two per CU leaves every CU with ONE resident workgroup - nothing to run while it
     // waits for its DMA / barrier.  Halving the tile (128 x 64: 48 KB of LDS, three per CU) doubles the workgroups; measured on the
     // 64^2 x 256 -> 128 SPADE convs (256 tiles): 45 -> 3x us.  Larger launches keep 128 x 128 (more flops per staged byte).
-    if (lwg_bf16_halo_ok(a)) {
-        if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg_bf16_halo<2, 2, 2, 2, EPI>(a, stream);
-        return launch_cfg_bf16_halo<4, 1, 1, 2, EPI>(a, stream);
-    }
-    static int big = -1;
-    if (big < 0) {
-        const char* ev = getenv("LWG_BF16_BIG");     // lab knob: 0 = never use the 8-wave 256 x 256 tile
-        big = ev ? atoi(ev) : 1;
-    }
-    // N % 256 == 0 and at least one 256 x 256 tile per CU: eight waves, wave tile 128 x 64 - six fragment reads per eight MFMAs
-    // instead of four per four (the 4-wave kernel's LDS port is as busy as its matrix pipe)
-    if (big && dma_a && a.N % 256 == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= (long)cus) return launch_cfg_bf16<2, 4, 4, 2, EPI, true>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128);
     const bool small = a.N % 128 == 0 && tiles128 < 2L * cus;
-    if (EPI == LWG_EPI_SPADE || (a.N % 128 == 0 && force64 != 3 && !(small && force64 == 2)))
-        return dma_a ? launch_cfg_bf16<2, 2, 2, 2, EPI, true>(a, stream) : launch_cfg_bf16<2, 2, 2, 2, EPI, false>(a, stream);
-    return dma_a ? launch_cfg_bf16<4, 1, 1, 2, EPI, true>(a, stream) : launch_cfg_bf16<4, 1, 1, 2, EPI, false>(a, stream);
+    if (EPI == LWG_EPI_SPADE || (a.N % 128 == 0 && LWG_BF16_TILE64 != 1 && !(small && LWG_BF16_TILE64 == 0)))
+        return launch_cfg_bf16<2, 2, 2, 2, EPI, dma_a>(a, stream);
+    return launch_cfg_bf16<4, 1, 1, 2, EPI, dma_a>(a, stream);
 }
 
 extern "C" int lwg_conv2d_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t stream_) {

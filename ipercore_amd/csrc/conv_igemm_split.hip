@@ -23,7 +23,6 @@
 // convolution BELOW the native fp32 MFMA kernel's (rms 7.4e-7 vs 8.5e-7 of the output rms on the 3x3 256->256 layer).  What
 // is left is the barrier-per-stage structure (two co-resident workgroups fall into phase and idle together around the
 // barrier).  Launches with N % 128 == 0 and >= 200 256x128 tiles use the 8-wave ping-pong kernel further down (+7-9 %).
-#include <cstdlib>
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
@@ -630,11 +629,7 @@ static hipError_t launch_split_pp(const LwgConvArgs& a, hipStream_t stream) {
 
 // the 256x128 ping-pong kernel needs N % 128 == 0 and enough tiles that one workgroup per CU keeps the chip busy
 static bool lwg_split_use_pp(const LwgConvArgs& a) {
-    static int mode = -1;                                     // LWG_SPLIT_PP=0 never, 1 whenever legal, unset: heuristic
-    if (mode < 0) {
-        const char* e = getenv("LWG_SPLIT_PP");
-        mode = e ? (atoi(e) ? 1 : 0) : 2;
-    }
+    constexpr int mode = LWG_SPLIT_PP;                        // compile-time (lwg_common.h): 0 never, 1 whenever legal, 2 heuristic
     if (mode == 0 || a.N % 128 != 0) return false;
     if (mode == 1) return true;
     const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);

@@ -8,7 +8,6 @@
 // including out-of-range ones where the warp is 0.  Ks = Wk x and Vs = Wv x are therefore computed ONCE per
 // source (they only depend on the cached source features) and this kernel gathers them: an HBM/L2-bound
 // gather with 16-byte loads, one pixel per LPP = C/4 lanes, online softmax over the ns sources.
-#include <stdlib.h>
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
@@ -180,23 +179,14 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
         return (int)hipErrorInvalidValue;
     const long total = lwg_tile_frame_positions(B, h, w);
     const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 4ull < 0xC0000000ull;
-    static int occ = 0;
-    if (occ == 0) {
-        const char* eo = getenv("LWG_ATTN_OCC");         // lab knob: waves per SIMD the registers are held to (5, 6 or 8)
-        occ = eo ? atoi(eo) : 5;
-    }
 #define LWG_ATTN_LAUNCH(LPP)                                                                                      \
     {                                                                                                             \
         const long per_block = 4 * (64 / LPP);                                                                    \
         const dim3 grid((unsigned)((total + per_block - 1) / per_block));                                         \
         if (!buf_ok)                                                                                              \
             hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, false, 5>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched); \
-        else if (occ == 6)                                                                                        \
-            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, 6>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);  \
-        else if (occ == 8)                                                                                        \
-            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, 8>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);  \
         else                                                                                                      \
-            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, 5>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);  \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, LWG_ATTN_OCC>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);  \
     }
     switch (C) {
         case 32: LWG_ATTN_LAUNCH(8) break;

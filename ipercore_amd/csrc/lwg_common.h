@@ -8,6 +8,43 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define LWG_WAVE 64
 
+// Tuning constants.  The product library reads NO environment: every knob is compiled to its measured-best value (DESIGN.md
+// records what the other settings gave); tools/labbuild.sh SRC.hip NAME -DLWG_xxx=v builds a variant library for tools/convlab.py /
+// tools/bf16lab.py A/B runs.
+#ifndef LWG_CONV_SPLITK
+#define LWG_CONV_SPLITK 1          // conv_igemm.hip: split-K of the small-M fp32 launches that hand in a workspace (0 = never)
+#endif
+#ifndef LWG_CONV_SMALL_TILES
+#define LWG_CONV_SMALL_TILES 300   // conv_igemm.hip: launches with fewer 128 x 128 tiles than this use 64 x 64 tiles
+#endif
+#ifndef LWG_BF16_PW_TM
+#define LWG_BF16_PW_TM 2           // conv_igemm_bf16.hip, pointwise kernel: 2 = two 8-wave workgroups per CU with 64-row wave tiles, 4 = one with 128-row tiles
+#endif
+#ifndef LWG_BF16_DMA_A
+#define LWG_BF16_DMA_A 1           // conv_igemm_bf16.hip, linear kernel: the A operand by LDS-DMA (0 = through registers)
+#endif
+#ifndef LWG_BF16_TILE64
+#define LWG_BF16_TILE64 0          // conv_igemm_bf16.hip, linear kernel: 0 = 128 x 64 tiles for launches under two 128 x 128 tiles per CU, 1 = always, -1 = never
+#endif
+#ifndef LWG_BF16_BIG
+#define LWG_BF16_BIG 1             // conv_igemm_bf16.hip, linear kernel: the 8-wave 256 x 256 tile for N % 256 == 0 launches with >= one tile per CU
+#endif
+#ifndef LWG_SPLIT_PP
+#define LWG_SPLIT_PP 2             // conv_igemm_split.hip: the 8-wave ping-pong kernel - 0 never, 1 whenever legal, 2 heuristic
+#endif
+#ifndef LWG_ATTN_OCC
+#define LWG_ATTN_OCC 5             // lwb_attn.hip: waves per SIMD the fp32 attention kernel's registers are held to (5, 6 or 8)
+#endif
+#ifndef LWG_ATTN16_PAIR
+#define LWG_ATTN16_PAIR 0          // bf16_ops.hip: 1 = two sources in flight per wave (159 VGPRs, 3 waves / SIMD): measured SLOWER (111 vs 97 us at C = 256)
+#endif
+#ifndef LWG_ATTN16_OCC
+#define LWG_ATTN16_OCC 5           // bf16_ops.hip: waves per SIMD the bf16 attention kernel's registers are held to (4, 5 or 6)
+#endif
+#ifndef LWG_HEAD16_NCB
+#define LWG_HEAD16_NCB 2           // bf16_ops.hip: 16-pixel column blocks per tile row of the bf16 output head (2, 3 or 4)
+#endif
+
 // Activation codes shared by the C ABI (include/lwg_hip.h) and the kernels.
 enum { LWG_ACT_NONE = 0, LWG_ACT_RELU = 1, LWG_ACT_TANH = 2, LWG_ACT_SIGMOID = 3 };
 

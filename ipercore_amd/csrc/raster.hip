@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void lwg_raster_tiles_kernel(const float* __re
                 spair[pos++] = (unsigned short)(tid | (e << 8));
             }
             __syncthreads();
-            if (spcount > LWG_RPAIRS - 256 * 32) flush();      // uniform: read after the barrier, written only inside flush
+            const int pending = spcount;                       // every thread loads the cursor between two barriers: a fast wave's
+            __syncthreads();                                   // next append (atomicAdd above) cannot slip in before a slow wave's read
+            if (pending > LWG_RPAIRS - 256 * 32) flush();      // block-uniform by construction (flush contains barriers)
         }
         __syncthreads();
         flush();                                               // the records of this chunk are about to be replaced

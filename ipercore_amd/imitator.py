@@ -73,23 +73,43 @@ class Imitator(object):
         self._opt = opt
         self._name = "Imitator"
         self.device = torch.device(device)
-        self.frame_batch = int(frame_batch)
+        self._frame_batch_req = int(frame_batch)   # what the caller asked for; ``frame_batch`` (property) is what runs
+        self._fb_warned = None
         self.streams = max(1, int(streams))       # independent frame batches in flight on separate HIP streams
         self._side_streams = None
         self.src_info = None
         self.first_cam = None
         self.image_size = int(_opt_get(opt, "image_size", 512))
-        # the conv kernels address activations with 32-bit buffer offsets (< 3 GiB per tensor, include/lwg_hip.h); the largest
-        # NHWC tensor of a frame batch is the last decoder output (B, S, S, 64) fp32
-        max_fb = max(1, int((3 << 30) // (self.image_size * self.image_size * 64 * 4)) - 1)
-        if self.frame_batch > max_fb:
-            print(f"[ipercore_amd] frame_batch {self.frame_batch} -> {max_fb} at {self.image_size}x{self.image_size} (3 GiB per-tensor limit of the conv kernels)")
-            self.frame_batch = max_fb
+        self.generator = None
         self.temporal = bool(_opt_get(opt, "temporal", False))
         self.time_step = int(_opt_get(opt, "time_step", 1))
         self.temporal_fifo = None
         self.primary_ids = 0                      # which source's camera / shape drives the target (Swapper sets it)
         self._create_networks()
+
+    # ------------------------------------------------------------------ frame batch actually launched
+    def max_frame_batch(self):
+        """The conv kernels address activations with 32-bit buffer offsets (< 3 GiB per tensor, include/lwg_hip.h).  The largest NHWC
+        tensor of a frame batch is the last decoder output (B, S, S, 64) in the ACTIVATION dtype of the current precision mode: fp32
+        (4 bytes) or, with ``generator.conv_precision == "bf16"``, bf16 (2 bytes: twice the frames fit)."""
+        gen = getattr(self, "generator", None)
+        act_bytes = 2 if (gen is not None and getattr(gen, "conv_precision", "fp32") == "bf16") else 4
+        return max(1, int((3 << 30) // (self.image_size * self.image_size * 64 * act_bytes)) - 1)
+
+    @property
+    def frame_batch(self):
+        """Frames per launch batch as they RUN: the requested value clamped by ``max_frame_batch()`` for the current precision mode."""
+        fb, cap = self._frame_batch_req, self.max_frame_batch()
+        if fb > cap:
+            if self._fb_warned != (fb, cap):
+                self._fb_warned = (fb, cap)
+                print(f"[ipercore_amd] frame_batch {fb} -> {cap} at {self.image_size}x{self.image_size} (3 GiB per-tensor limit of the conv kernels)")
+            return cap
+        return fb
+
+    @frame_batch.setter
+    def frame_batch(self, value):
+        self._frame_batch_req = max(1, int(value))
 
     def _create_networks(self):
         self.body_rec = SMPLH(model_path=_opt_get(self._opt, "smpl_model_hand")).to(self.device)

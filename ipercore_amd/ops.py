@@ -580,6 +580,8 @@ def frames_to_u8(pred, bgr=False):
     B, C, S, S2 = pred.shape
     assert C == 3 and S == S2
     out = torch.empty(B, S, S, 3, device=pred.device, dtype=torch.uint8)
+    if B == 0:               # an empty shard / all-padding chunk (sharding.sharded_synthesize): nothing to launch (a zero-size grid is invalid)
+        return out
     _lib.check(_lib.lib().lwg_frames_to_u8(_ptr(pred), B, S, 1 if bgr else 0, _ptr(out, torch.uint8), _stream()), "lwg_frames_to_u8")
     return out
 

@@ -22,11 +22,11 @@ def shard_counts(n_frames, world_size):
     return [shard_range(n_frames, r, world_size)[1] - shard_range(n_frames, r, world_size)[0] for r in range(world_size)]
 
 
-def all_gather_frames(local, n_frames, group=None):
+def all_gather_frames(local, n_frames, group=None, force=False):
     """local: (n_local, ...) block of this rank (as given by shard_range) -> (n_frames, ...) on every rank.
 
     Blocks are padded to the largest shard so a single ``all_gather_into_tensor`` moves everything."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     counts = shard_counts(n_frames, world)
@@ -95,26 +95,48 @@ class OverlappedGather(object):
         return video
 
 
-def chunk_plan(n_frames, world_size, frame_batch):
+def chunk_plan(n_frames, world_size, frame_batch, round_frames=1):
     """The chunk schedule every rank follows for a clip of ``n_frames``: [(offset in the shard, chunk length)], the same list on
     all ranks (collectives must match), sized by the LONGEST shard; rank r's frames of a chunk are
-    [lo_r + off, min(lo_r + off + m, hi_r)) - possibly fewer than m, possibly none."""
+    [lo_r + off, min(lo_r + off + m, hi_r)) - possibly fewer than m, possibly none.
+
+    Full frame batches first, the remainder last (the last chunk is the one whose exchange is exposed, so it should be the short
+    one).  ``round_frames``: the number of frames that fill the chip once on the coarsest layers (8 at 512x512: the 64x64-feature
+    layers have 64 128x128 output tiles per frame against 256 CUs x 2 workgroups).  A remainder SHORTER than one such round would be
+    a launch set that never fills the machine; when the shard allows it, the last full batch gives up whole rounds so that the tail
+    holds at least one: 38 frames at frame batch 32 -> 24 + 14 instead of 32 + 6 (same number of tile rounds in total - ceil(4.75)
+    - but no sub-round launch set; the exposed exchange grows from 6 to 14 frames, ~0.3 ms on the uint8 video at 8 ranks).
+    Balanced chunks (13 + 13 + 12) were tried in round 2 and dropped: 13 frames are 3.25 rounds."""
     cap = max(shard_counts(n_frames, world_size))
     fb = max(1, int(frame_batch))
-    # full frame batches first, the remainder last (38 frames at frame batch 16: 16 + 16 + 6).  Balanced chunks (13 + 13 + 12) were tried and
-    # dropped: the 64x64-feature layers have 64 output tiles per frame, so 16 frames are exactly four rounds of the 256 CUs while 13 frames
-    # are 3.25 (a fourth round a quarter full) - and the short last chunk is also the one whose exchange is exposed.
-    return [(off, min(fb, cap - off)) for off in range(0, cap, fb)]
+    rf = max(1, int(round_frames))
+    plan = [(off, min(fb, cap - off)) for off in range(0, cap, fb)]
+    if len(plan) >= 2 and plan[-1][1] < rf and fb > rf:
+        off, m = plan[-2]
+        tail = plan[-1][1]
+        give = -(-(rf - tail) // rf) * rf                  # whole rounds moved from the last full batch into the tail
+        if m - give >= rf:
+            plan[-2] = (off, m - give)
+            plan[-1] = (off + m - give, tail + give)
+    return plan
+
+
+def round_frames_of(imitator):
+    """Frames per full tile round of the coarsest, (S/8)^2 x 256-channel layers: (S/8)^2 / 128 row tiles x 2 column tiles of 128 x 128
+    per frame against 512 workgroup slots (256 CUs x 2) -> 8 at 512x512, 32 at 256x256, 2 at 1024x1024."""
+    S = int(getattr(imitator, "image_size", 512))
+    return max(1, (512 * 64) // max(1, (S // 8) ** 2))
 
 
 def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, group=None, overlap=True, prepared=False, post=None,
-                       stats=None):
+                       stats=None, force_collective=False):
     """Every rank: prepare the whole sequence, synthesize its block, all-gather the video tensor
     (``overlap``: chunk by chunk behind the frame loop, see OverlappedGather; False: one collective at the end).
     prepared: ``tgt_smpls`` is already the output of ``imitator.prepare_sequence`` (the sequence-global pre-pass, identical on every
     rank).  post: a per-chunk transform applied before the exchange - ``ops.frames_to_u8`` turns the (n,3,S,S) fp32 video into the
     (n,S,S,3) uint8 one the PNG writer consumes: a quarter of the bytes on the xGMI ring.  stats: a dict that receives this rank's
-    shard, the bytes it received and (when ``stats["sync"]`` is a callable) the exposed gather time."""
+    shard, the bytes it received and (when ``stats["sync"]`` is a callable) the exposed gather time.  force_collective: issue the
+    collectives even in a one-rank group (the RCCL check on a single GPU)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     tgt = tgt_smpls if prepared else imitator.prepare_sequence(tgt_smpls, cam_strategy)
@@ -123,11 +145,13 @@ def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, 
     fin = (lambda x: x) if post is None else post
     if stats is not None:
         stats.update(rank=rank, world=world, shard=(lo, hi))
-    if not (gather and overlap and world > 1):
+    multi = world > 1 or (force_collective and dist.is_initialized())
+    if not (gather and overlap and multi):
         local = fin(imitator.synthesize(tgt[lo:hi], cam_strategy, t0=lo))
-        return all_gather_frames(local, n, group) if gather else local
+        return all_gather_frames(local, n, group, force=force_collective) if gather else local
     og = OverlappedGather(n, group)
-    for off, m in chunk_plan(n, world, getattr(imitator, "frame_batch", 8)):
+    plan = chunk_plan(n, world, getattr(imitator, "frame_batch", 8), round_frames_of(imitator))
+    for off, m in plan:
         a = min(lo + off, hi)
         b = min(lo + off + m, hi)
         # an empty slice (this shard ended before the longest one, or holds no frame at all) still yields a correctly shaped
@@ -135,6 +159,6 @@ def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, 
         og.submit(fin(imitator.synthesize(tgt[a:b], cam_strategy, t0=a)), off, length=m)
     video = og.finish(sync=None if stats is None else stats.get("sync"))
     if stats is not None:
-        stats.update(bytes_received=og.bytes_received, exposed_gather_s=og.exposed_s, chunks=len(chunk_plan(n, world, getattr(imitator, "frame_batch", 8))))
+        stats.update(bytes_received=og.bytes_received, exposed_gather_s=og.exposed_s, chunks=len(plan), chunk_lengths=[m for _, m in plan])
         stats.pop("sync", None)
     return video

@@ -241,7 +241,7 @@ class FlatAdam(object):
             torch._foreach_copy_(dst, src)
 
     # ---- data-parallel exchange, overlapped with backward ---------------------------------------------------------------
-    def arm(self, group=None, n_buckets=4):
+    def arm(self, group=None, n_buckets=4, force=False):
         """Call before the backward whose gradients this optimizer will apply.  The flat gradient buffer is cut into
         ``n_buckets`` contiguous ranges (a few large collectives: xGMI rings are per-link bound, so 145 MB of G gradients go
         out as ~36 MB pieces, not DDP's 25 MB x many); a post-accumulate hook per parameter counts the range down and hands it to
@@ -249,7 +249,7 @@ class FlatAdam(object):
         on RCCL's stream while backward is still computing the early ones.  ``allreduce()`` afterwards only finishes the job."""
         self._works, self._issued = [], set()
         self._group = group
-        self._armed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._armed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)   # force: one-rank RCCL check
         if not self._armed:
             return
         if not hasattr(self, "_bucket_of"):
@@ -284,10 +284,10 @@ class FlatAdam(object):
         self._issued.add(b)
         self._works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
 
-    def allreduce(self, group=None):
+    def allreduce(self, group=None, force=False):
         """Average the flat gradient buffer over the ranks.  After ``arm()``: wait for the ranges already in flight and send the
         ones whose parameters received no gradient in this backward; without ``arm()``: one all-reduce of the whole buffer."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
             return
         self._gather()
         if getattr(self, "_armed", False):
@@ -302,8 +302,27 @@ class FlatAdam(object):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         self.grad.div_(dist.get_world_size(group))
 
+    def snapshot(self):
+        """Parameters, both moments and the step count (device + host mirror): what a throw-away step must not leave changed."""
+        return (self.flat.clone(), self.m.clone(), self.v.clone(), self.t_dev.clone(), self.t)
+
+    def restore(self, snap):
+        flat, m, v, t_dev, t = snap
+        self.flat.copy_(flat)
+        self.m.copy_(m)
+        self.v.copy_(v)
+        self.t_dev.copy_(t_dev)
+        self.t = t
+
+    def note_replayed(self, n=1):
+        """A captured ``step()`` was replayed ``n`` times: the device did the update (raw pointers - no tensor version counter moved),
+        so advance the host mirror of the step count and drop the module's packed inference panels here."""
+        self.t += n
+        if hasattr(self.module, "_packed"):
+            self.module._packed = None
+
     def step(self):
-        self.t += 1                                    # host mirror (not advanced by graph replays: read t_dev for the truth)
+        self.t += 1                                    # host mirror; graph replays advance it through note_replayed()
         self._gather()
         ops.adam_step_dev(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t_dev)
         if hasattr(self.module, "_packed"):
@@ -719,7 +738,7 @@ class LWGTrainer(object):
         outs = self.D(both)
         d_real, d_fake = [o[:o.shape[0] // 2] for o in outs], [o[o.shape[0] // 2:] for o in outs]
         assert outs[0].shape[0] == 2 * n
-        self.losses.update(d_real=_reduce_outs(d_real), d_fake=_reduce_outs(d_fake))           # reduce_tensor, multi_scale_dis.py:9-18
+        self.losses.update(d_real=_reduce_outs(d_real).detach(), d_fake=_reduce_outs(d_fake).detach())   # reduce_tensor, multi_scale_dis.py:9-18
         return lsgan_loss(d_real, 1) + lsgan_loss(d_fake, -1)
 
     def optimize_parameters(self):
@@ -800,6 +819,10 @@ class LWGTrainer(object):
                 torch.cuda.synchronize()
                 self.step_mode = "eager launches (graph capture failed)"
                 return self._optimize_parameters()
+        if self._captured_lr != (self.optimizer_G.lr, None if self.optimizer_D is None else self.optimizer_D.lr):
+            # the learning rate is a kernel argument frozen into the graph: a changed lr needs a new capture
+            self._graphs = None
+            return self._graph_step()
         gA, gB, gC = self._graphs
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         gA.replay()
@@ -819,7 +842,13 @@ class LWGTrainer(object):
             gC.replay()
         if multi:
             self._allreduce_events = ev if self.D is not None else ev[:2]
-        return self._static_losses
+        # the replay updated the weights through raw pointers: host-side mirrors follow here (stale inference panels, step counts)
+        self.optimizer_G.note_replayed()
+        if self.D is not None:
+            self.optimizer_D.note_replayed()
+        # the static loss tensors are overwritten by the next replay: hand out copies (a caller may keep a history, as eager mode allows)
+        lg, ld = self._static_losses
+        return lg.clone(), None if ld is None else ld.clone()
 
     def exposed_allreduce_ms(self):
         """Device time of the gradient all-reduces of the LAST captured step (data-parallel runs; synchronizes), else None."""
@@ -835,12 +864,19 @@ class LWGTrainer(object):
         import gc
         self.losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in self.losses.items()}
         gc.collect()                                        # no autograd graph of an earlier (eager) step may outlive this point
+        # the warm-up steps are throw-away: the reference does exactly n_iters updates (services/personalization.py:95-151), so the
+        # parameters, Adam moments and step counts of G and D are put back afterwards - capture + first replay = ONE update
+        opts_ = [o for o in (self.optimizer_G, self.optimizer_D) if o is not None]
+        snaps = [o.snapshot() for o in opts_]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 self._optimize_parameters()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for o, sn in zip(opts_, snaps):
+            o.restore(sn)
         torch.cuda.synchronize()
         self.optimizer_G._armed = False                     # no hook-driven collectives inside a capture
         if self.optimizer_D is not None:
@@ -877,7 +913,10 @@ class LWGTrainer(object):
         with torch.cuda.graph(gC, pool=pool):
             if self.D is not None:
                 self.optimizer_D.step()
+        for o, sn in zip(opts_, snaps):                     # capturing step() advanced the host mirrors only; nothing ran on the device
+            o.t = sn[4]
         self._graphs = (gA, gB, gC)
+        self._captured_lr = (self.optimizer_G.lr, None if self.optimizer_D is None else self.optimizer_D.lr)
         self._static_losses = (loss_G.detach(), None if loss_D is None else loss_D.detach())
         self._static_inp = self.inp
         self.step_mode = ("3 hipGraph segments per step (G fwd/bwd with D's own fwd/bwd on a second stream | Adam(G) | Adam(D)), all-reduces between them"

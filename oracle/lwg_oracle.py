@@ -432,7 +432,7 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     cam = cam_swap(src_info["cam"][0:1], tgt[:, 0:3], first_cam, cam_strategy)
     ref_smpl = torch.cat([cam, tgt[:, 3:-10], src_info["shape"][0:1]], dim=1)
     ref = smplh_get_details(model, ref_smpl, src_info.get("offsets", 0), src_info.get("links_ids"))
-    own_verts = ref["verts"]
+    own_verts, own_cam = ref["verts"], ref["cam"]
     if ref_override is not None:          # tests: rasterize the caller's (bit-identical) vertices, see parity_utils
         ref["cam"], ref["verts"] = ref_override
     f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
@@ -443,7 +443,7 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(enc), n_res=len(res))
     pred = compose(img, mask, src_info["bg"])
     return {"pred": pred, "mask": mask, "img": img, "tsf_inputs": tsf_inputs, "Tst": Tst, "fim": fim, "wim": wim,
-            "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t, "own_verts": own_verts,
+            "cond": cond, "verts": ref["verts"], "f2pts": f2pts, "cam": ref["cam"], "Tuv2t": Tuv2t, "own_verts": own_verts, "own_cam": own_cam,
             "src_own_verts": src_info.get("own_verts"), "src_fim": src_info.get("fim")}
 
 

@@ -347,12 +347,20 @@ def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None
     return unpack_wgrad(conv2d_wgrad(x0, spec, dy, x1=x1, out_hw=out_hw, ycoff=ycoff), dw, transposed, kidx, cin, spec.Cin, nout)
 
 
+def frames_to_u8(pred, bgr=False):
+    """lwg_frames_to_u8's contract: save_cv2_img(normalize=True) arithmetic (cv_utils.py:111-113) -> (B,S,S,3) uint8."""
+    import numpy as np
+    a = np.transpose(pred.detach().cpu().numpy().astype(np.float32), (0, 2, 3, 1))
+    u8 = ((a + np.float32(1)) / np.float32(2.0) * np.float32(255)).astype(np.uint8)
+    return torch.from_numpy(np.ascontiguousarray(u8[..., ::-1] if bgr else u8))
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize"):
+                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

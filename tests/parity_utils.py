@@ -69,25 +69,32 @@ def run_oracle(case, cam_strategy="smooth", frames=None, return_all=False, src_o
     return (pred, extra) if return_all else pred
 
 
-def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, device="cuda:0", imitator=None, return_want=False):
+def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, device="cuda:0", imitator=None, return_want=False,
+                  e2e_fim=True):
     """HIP path vs oracle, stage by stage (the end-to-end map is discontinuous at silhouette pixels, so each stage
     is compared on identical inputs): (1) skinned vertices HIP vs oracle; (2) fim/wim exact given the HIP vertices;
-    (3) generator input / flows; (4) final frames.  Returns a metrics dict; the caller asserts."""
+    (3) generator input / flows; (4) final frames.  Returns a metrics dict; the caller asserts.
+    ``frames``: the frame indices the oracle renders (default all).  ``e2e_fim``: additionally REPORT the un-overridden end-to-end
+    agreement (expect >= 99.9 %): the oracle rasterizes ITS OWN skinned vertices (which differ from the HIP ones by
+    <= 1e-5) and the face-index map is compared with the HIP one pixel by pixel -> ``fim_agree_e2e_min`` / ``_mean``."""
     im = imitator or make_imitator(case, frame_batch, device=device)
     tgt = im.prepare_sequence(case.tgt_smpls, cam_strategy)
+    idx = list(range(tgt.shape[0])) if frames is None else list(frames)
+    keep = set(idx)
     preds, refs = [], {}
-    for s in range(0, tgt.shape[0], im.frame_batch):
-        tsf8, Tst, ref = im.make_inputs_for_tsf(im.src_info, tgt[s:s + im.frame_batch], cam_strategy, t=s, want_aux=True)
+    fb = im.frame_batch
+    for s in range(0, tgt.shape[0], fb):
+        tsf8, Tst, ref = im.make_inputs_for_tsf(im.src_info, tgt[s:s + fb], cam_strategy, t=s, want_aux=True)
         preds.append(im.forward(tsf8, Tst)[0])
         for i in range(ref["verts"].shape[0]):
-            refs[s + i] = {"cam": ref["cam"][i:i + 1].cpu(), "verts": ref["verts"][i:i + 1].cpu(), "fim": ref["fim"][i].cpu(),
-                           "wim": ref["wim"][i].cpu(), "Tst": Tst[i].cpu(), "tsf8": tsf8[i].cpu()}
+            if s + i in keep:
+                refs[s + i] = {"cam": ref["cam"][i:i + 1].cpu(), "verts": ref["verts"][i:i + 1].cpu(), "fim": ref["fim"][i].cpu(),
+                               "wim": ref["wim"][i].cpu(), "Tst": Tst[i].cpu(), "tsf8": tsf8[i].cpu()}
     got = torch.cat(preds, dim=0).cpu()
-    idx = list(range(tgt.shape[0])) if frames is None else list(frames)
     src_ov = (im.src_info["cam"].cpu(), im.src_info["verts"].cpu())
     want, extra = run_oracle(case, cam_strategy, frames=idx, return_all=True, src_override=src_ov,
                              ref_override={t: (refs[t]["cam"], refs[t]["verts"]) for t in idx})
-    m = {"frames": idx}
+    m = {"frames": idx, "frame_batch": fb}
     m["src_verts_max"] = (extra[0]["src_own_verts"] - src_ov[1]).abs().max().item()
     m["src_fim_equal"] = bool(torch.equal(im.src_info["fim"].cpu(), extra[0]["src_fim"]))
     m["verts_max"] = max((extra[k]["own_verts"] - refs[t]["verts"]).abs().max().item() for k, t in enumerate(idx))
@@ -99,6 +106,14 @@ def staged_parity(case, frame_batch=8, cam_strategy="smooth", frames=None, devic
     d = (got[idx] - want).abs()
     m["pred_max"], m["pred_mean"] = d.max().item(), d.mean().item()
     m["pred_finite"] = bool(torch.isfinite(got).all())
+    if e2e_fim:
+        from oracle import lwg_oracle as orc
+        tables = oracle_tables()
+        rates = []
+        for k, t in enumerate(idx):
+            _, fim_own, _ = orc.render_fim_wim(extra[k]["own_cam"], extra[k]["own_verts"], tables["smpl_faces"], case.S)
+            rates.append((fim_own[0] == refs[t]["fim"]).float().mean().item())
+        m["fim_agree_e2e_min"], m["fim_agree_e2e_mean"] = min(rates), float(np.mean(rates))
     if return_want:
         m["want"] = want
     return m, got, im

@@ -249,6 +249,24 @@ def test_clip_schedule_gloo_world8_300_frames(tmp_path):
     assert sharding.chunk_plan(300, 8, 8) == [(0, 8), (8, 8), (16, 8), (24, 8), (32, 6)]
     assert sharding.chunk_plan(300, 8, 16) == [(0, 16), (16, 16), (32, 6)]
     assert sharding.chunk_plan(0, 4, 8) == [] and sharding.chunk_plan(3, 8, 8) == [(0, 1)]
+    # round-aware plan (what sharded_synthesize uses: 8 frames fill the chip once on the 64x64-feature layers at 512x512): a remainder
+    # shorter than one round takes whole rounds from the last full batch - no launch set that never fills the machine
+    assert sharding.chunk_plan(300, 8, 32, 8) == [(0, 24), (24, 14)]
+    assert sharding.chunk_plan(300, 8, 16, 8) == [(0, 16), (16, 8), (24, 14)]
+    assert sharding.chunk_plan(300, 8, 8, 8) == [(0, 8), (8, 8), (16, 8), (24, 8), (32, 6)]          # nothing to give: batches ARE one round
+    assert sharding.chunk_plan(300, 4, 32, 8) == [(0, 32), (32, 32), (64, 11)]                          # tail >= one round: untouched
+    assert sharding.chunk_plan(300, 2, 32, 8)[-1] == (128, 22)
+    for n, w, fb, rf in [(300, 8, 32, 8), (301, 7, 16, 8), (37, 3, 12, 8), (9, 1, 8, 8), (300, 8, 64, 32)]:
+        plan = sharding.chunk_plan(n, w, fb, rf)
+        assert sum(m for _, m in plan) == max(sharding.shard_counts(n, w)) and all(0 < m <= fb for _, m in plan)
+        assert [o for o, _ in plan] == [sum(m for _, m in plan[:i]) for i in range(len(plan))]
+    class _Im:
+        image_size = 512
+    assert sharding.round_frames_of(_Im()) == 8
+    _Im.image_size = 1024
+    assert sharding.round_frames_of(_Im()) == 2
+    _Im.image_size = 256
+    assert sharding.round_frames_of(_Im()) == 32
     _run_gloo(tmp_path, _CLIP_WORKER, 8, "300:8,5:8")
 
 

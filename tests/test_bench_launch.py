@@ -1,0 +1,78 @@
+"""bench.py as the driver starts it: ``python bench.py --gpus N`` with no WORLD_SIZE must spawn its own ranks (torch.distributed.run)
+and print ONE parsable JSON line from rank 0; under torchrun it must still run in-process.  Exercised on CPU with the gloo backend
+and the emulated C ABI (tests/emu_ops.py) installed AROUND bench.main() by a wrapper script - bench.py itself has no CPU path: with
+``--device cpu`` and no emulation every op raises.  Reference launcher being matched: scripts/train/dist_train.py:97-109."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WRAPPER = r'''
+import sys
+sys.path.insert(0, {root!r})
+import bench
+bench.self_launch_if_needed()            # N > 1 and no WORLD_SIZE: re-executes THIS wrapper under torch.distributed.run
+from tests import emu_ops
+
+
+class _Patch:                             # the two monkeypatch methods emu_ops.install uses
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+emu_ops.install(_Patch())
+bench.main()
+'''
+
+_ARGS = ["--device", "cpu", "--backend", "gloo", "--tiny-arch", "--size", "64", "--frames", "7", "--frame-batch", "2", "--steps", "1",
+         "--warmup", "0"]
+
+
+def _run(tmp_path, extra, env_extra=None, launcher=None):
+    script = tmp_path / "bench_wrapper.py"
+    script.write_text(_WRAPPER.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", **(env_extra or {}))
+    cmd = (launcher or [sys.executable]) + [str(script)] + _ARGS + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_gloo(tmp_path):
+    """Plain ``python <bench> --gpus 2`` (WORLD_SIZE unset): two ranks, a 7-frame clip in shards of 4 + 3, uint8 exchange by default."""
+    line = _run(tmp_path, ["--gpus", "2"])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["unit"] == "frames/s" and line["config"]["frames_per_step"] == 7
+    per_rank = line["config"]["per_rank"]
+    assert [p["rank"] for p in per_rank] == [0, 1] and [p["frames"] for p in per_rank] == [4, 3]
+    assert per_rank[0]["shard"] == [0, 4] and per_rank[1]["shard"] == [4, 7]
+    assert per_rank[0]["chunk_lengths"] == [2, 2]                     # frame batch 2 over the longest shard (4)
+    # (S,S,3) uint8 blocks of 2 frames from 2 ranks, two chunks
+    assert per_rank[0]["bytes_received_per_step"] == 2 * 2 * 2 * 64 * 64 * 3
+    assert "(u8)" in line["config"]["parallelism"]
+    assert line["self_check"] is not None and "NOT a measurement" in line["data"]
+
+
+def test_bench_under_torchrun_and_f32_gather(tmp_path):
+    """The documented multi-GPU launch (``python -m torch.distributed.run ... bench.py --gpus 2``) keeps working; fp32 exchange on request."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    line = _run(tmp_path, ["--gpus", "2", "--gather-dtype", "f32"], launcher=launcher)
+    assert line["n_gpus"] == 2 and "(f32)" in line["config"]["parallelism"]
+    assert line["config"]["per_rank"][1]["bytes_received_per_step"] == 2 * 2 * 2 * 3 * 64 * 64 * 4
+
+
+def test_bench_single_process_line(tmp_path):
+    """N = 1: no process group, no exchange format applied, the fp32 video is the result."""
+    line = _run(tmp_path, ["--gpus", "1"])
+    assert line["n_gpus"] == 1 and line["config"]["world_size"] == 1 and "per_rank" not in line["config"]
+    assert line["config"]["frame_batch"] == 2 and line["config"]["frame_batch_requested"] == 2

@@ -106,3 +106,36 @@ def test_novel_view_smpls_and_viewer(monkeypatch):
     out72 = v.inference(smpls[:3], cam_strategy="smooth")
     assert len(out156) == 3 and out156[0].shape == (3, 64, 64)
     assert all(np.abs(a - b).max() <= 1e-5 for a, b in zip(out156, out72))          # hands_mean = 0 in the synthetic model
+
+
+def test_configs0_motion_imitate_256_cpu_plumbing(monkeypatch):
+    """BASELINE configs[0] as stated (demo/motion_imitate.py:120-133 -> run_imitator): 256x256, ONE source image, an 8-frame reference
+    clip, the whole path on CPU tensors - the runner's host logic over the emulated C ABI against the oracle's frame-by-frame result
+    (full AttLWB-SPADE architecture; plumbing + parity, no GPU, no timing)."""
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=256, n_frames=8, ns=1)
+    im = pu.make_imitator(case, frame_batch=8, device="cpu")
+    outs = im.inference(case.tgt_smpls, cam_strategy="smooth", output_dir="", verbose=False)
+    assert len(outs) == 8 and outs[0].shape == (3, 256, 256)
+    want = pu.run_oracle(case)
+    d = np.abs(np.stack(outs) - want.numpy())
+    assert np.isfinite(d).all() and d.max() <= 2e-3 and d.mean() <= 1e-4, (d.max(), d.mean())     # SURVEY 8c generator tolerance
+
+
+def test_frame_batch_clamp_follows_the_activation_dtype(monkeypatch):
+    """The per-tensor 3 GiB limit of the conv kernels is counted in the activation dtype of the precision mode: at 1024x1024 a request
+    of 12 runs as 11 in fp32 (12 x 1024^2 x 64 x 4 B IS 3 GiB) and as 12 in bf16 mode; ``frame_batch`` reports what runs."""
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=1, ns=1)
+    im = pu.make_imitator(case, frame_batch=12, device="cpu")
+    assert im.frame_batch == 12 and im.max_frame_batch() > 1000
+    im.image_size = 1024                       # the clamp only reads the size and the generator's precision mode
+    assert im.max_frame_batch() == 11 and im.frame_batch == 11
+    im.generator.conv_precision = "bf16"
+    assert im.max_frame_batch() == 23 and im.frame_batch == 12
+    im.frame_batch = 40
+    assert im.frame_batch == 23
+    im.generator.conv_precision = "fp32"
+    im.image_size = 512
+    im.frame_batch = 32
+    assert im.frame_batch == 32 and im.max_frame_batch() == 47
