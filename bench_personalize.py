@@ -152,16 +152,20 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if use_vgg else "L1") + " tsf" + (" + Sphere20a face" if use_face else "") + " + BCE mask + TV",
                    "global_batch": world,
                    "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
-                                  f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges overlapped with backward",
+                                  f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges behind D's forward / backward segment",
                    "step": getattr(tr, "step_mode", "eager launches"),
                    "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "branch_streams": bool(getattr(tr.opts, "branch_streams", False))},
         "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                      "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
         "bytes_allreduced_per_step": (nG + nD) * 4 if world > 1 else 0,
-        "exposed_allreduce_ms_per_step": (None if not hasattr(tr, "exposed_allreduce_ms") or tr.exposed_allreduce_ms() is None
-                                          else round(tr.exposed_allreduce_ms(), 3)),
-        "allreduce_overlap": getattr(tr.optimizer_G, "overlapped_ranges", None),
+        # N > 1: time the compute stream waited for RCCL in the last step (G's exchange runs behind D's forward / backward segment, D's
+        # behind Adam(G): trainers.LWGTrainer._run_dp_schedule); N = 1: nothing is exchanged
+        "exposed_allreduce_ms_per_step": (0.0 if world == 1 else (None if tr.exposed_allreduce_ms() is None else round(tr.exposed_allreduce_ms(), 3))),
+        "allreduce_overlap": (getattr(tr, "allreduce_overlap", None) or
+                              ("no collective at N = 1; at N > 1 the captured step runs G's gradient all-reduce (4 ranges, RCCL's stream) "
+                               "behind D's forward / backward graph and D's behind Adam(G)" if world == 1 else
+                               f"hook-driven: {getattr(tr.optimizer_G, 'overlapped_ranges', None)} ranges of G issued during backward")),
         "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
         "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}
 

@@ -131,7 +131,7 @@ int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* w
  * lwg_act_bwd_f32:        out = dy * act'(y)  (ReLU after the convs, tanh / sigmoid of the regressors), n % 4 == 0.
  * lwg_norm_fwd_nhwc_f32:  y = act((x - mean) rstd (1 + gamma) + beta); gamma = beta = NULL: InstanceNorm + activation
  *                         (bg_inpaintor.py:31-57); with gamma / beta (B,HW,C): SPADE (attlwb_spade_resunet.py:92).
- * lwg_norm_bwd_nhwc_f32:  the backward of the above: dx (and dgamma, dbeta); ws: B*nsplit*C*2 floats.
+ * lwg_norm_bwd_nhwc_f32:  the backward of the above: dx (and dgamma, dbeta); ws: B*(nsplit+1)*C*2 floats (split records + their fold).
  * lwg_adam_step_f32:      torch.optim.Adam update (lwg_trainer.py:140-146) of a flat parameter buffer, step count t >= 1. */
 int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int act, float* out, lwg_stream_t stream);
 int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B,
@@ -280,6 +280,11 @@ int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float* beta, int 
  * ------------------------------------------------------------------------------------------------ */
 int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
                          float* pred, float* mask, float* img, lwg_stream_t stream);
+/* Thin regressor forward: a stride-1 ks x ks convolution (ks = 5 or 7, pad ks/2, no bias, no activation) with <= 4 output channels at
+ * full resolution on the vector ALUs - the 7x7 image head of the background network, bg_inpaintor.py:53 (Conv2d(64, 3, 7, 1, 3,
+ * bias=False), the Tanh that follows is the caller's).  x (B,S,S,C) NHWC, C % 8 == 0; wpk [ks*ks][C][4] (tap = ky*ks + kx, unused
+ * output columns zero) -> y (B,S,S,4) NHWC, pre-activation. */
+int lwg_thin_conv_f32(const float* x, const float* wpk, int B, int S, int C, int ks, float* y, lwg_stream_t stream);
 /* The same head on a bf16 NHWC input (B,S,S,64) with the regressors on the matrix cores (v_mfma_f32_16x16x32_bf16): wb is the bf16
  * operand panel [ky 5][pass 2][channel half 2][lane 64][8]: lane l of a block holds row (l % 16) = 4 * tap + output and the
  * k-octet (l / 16) of the 32 channels; pass 0 carries the taps kx = 0..3, pass 1 the tap kx = 4 in its rows 0..3 (rows 4..15 zero).

@@ -90,6 +90,7 @@ _SIGS = {
     "lwg_smpl_lbs_f32": (c_i, [c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i,
                                c_i, c_f, c_f, c_f, c_f, c_f]),
     "lwg_head_compose_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "lwg_thin_conv_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_nchw_to_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_nhwc_to_nchw_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_frames_to_u8": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f]),

@@ -49,8 +49,14 @@ __device__ __forceinline__ floatx4 lwg_buf_load(const float* base, unsigned byte
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
+// DEEP: the global loads run TWO K-steps ahead of the MFMAs (two register sets) instead of one.  A wave tile of one or two 32 x 32
+// MFMA tiles spends 1024 / 2048 cycles per K-step; with the loads of step t + 1 issued at the top of step t and stored to LDS at its
+// end they have ~700 cycles to return - less than an L2 round trip under load, and the small-tile launches (one frame, one training
+// sample) have ONE workgroup per CU, nobody to cover the stall (measured: 57 us for a 4096 x 256 x 2304 launch whose MFMAs need 33).
+// Same MFMA order, same results.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC, bool DEEP = false>
 __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArgs a, const int split_chunks, float* __restrict__ slabs) {
+    static_assert(!DEEP || !LWG_CONV_DMA_B, "the two-steps-ahead loader stages both operands through registers");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_ROW = (BM + 1) * 4;  // floats per k-quad row; +1 float4 pad => conflict-free b128 stores
     constexpr int B_ROW = BN * 4;
@@ -166,11 +172,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         return SMALLC ? 0 : taptab[ld_use1 * LWG_MAX_TAPS + ld_tap];
     };
 
-    floatx4 ra[PA], rb[PB];
-    auto load_a = [&](int tstep) {
+    constexpr int NSET = DEEP ? 2 : 1;
+    floatx4 ra[NSET][PA], rb[NSET][PB];
+    auto load_a = [&](int tstep, int set = 0) {
         if (!SMALLC) {
 #pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = lwg_buf_load(ld_src, ld_bytes, vbase[p], ld_soffA);
+            for (int p = 0; p < PA; ++p) ra[set][p] = lwg_buf_load(ld_src, ld_bytes, vbase[p], ld_soffA);
         } else {
             const int k4 = tstep * 8 + kq;
             const int tap = k4 >> a.cshift;
@@ -183,13 +190,13 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
                 const int iy = piy[p] + dy, ix = pix[p] + dx;
                 const bool ok = tap_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 const unsigned off = ((unsigned)(pixlin[p] + dy * a.W + dx) * (unsigned)Cin + (unsigned)c) * 4u;
-                ra[p] = lwg_buf_load(a.x0, bytes0, ok ? off : LWG_OOB_OFFSET, 0u);
+                ra[set][p] = lwg_buf_load(a.x0, bytes0, ok ? off : LWG_OOB_OFFSET, 0u);
             }
         }
     };
-    auto load_b = [&]() {
+    auto load_b = [&](int set = 0) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = lwg_buf_load(a.w, wbytes, wvoff[p], ld_soffB);
+        for (int p = 0; p < PB; ++p) rb[set][p] = lwg_buf_load(a.w, wbytes, wvoff[p], ld_soffB);
     };
     // LDS-DMA form: lane i of a wave lands at (M0 base) + 16 * i, i.e. the wave's 1 KB slice of the lane-linear B stage
     const int wave_b = __builtin_amdgcn_readfirstlane(tid >> 6) * 256;          // floats
@@ -203,19 +210,19 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
 
     const int st_a = kq * A_ROW + mrow * 4;  // + 128 * p
     const int st_b = tid * 4;                // + 1024 * p   ([kq][n] is linear in idx)
-    auto lstore_a = [&](int buf) {
+    auto lstore_a = [&](int buf, int set = 0) {
         float* Ab = As + buf * A_STAGE + st_a;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[p];
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<floatx4*>(Ab + 128 * p) = ra[set][p];
     };
-    auto lstore_b = [&](int buf) {
+    auto lstore_b = [&](int buf, int set = 0) {
         float* Bb = Bs + buf * B_STAGE + st_b;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<floatx4*>(Bb + 1024 * p) = rb[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<floatx4*>(Bb + 1024 * p) = rb[set][p];
     };
-    auto lstore = [&](int buf) {
-        lstore_a(buf);
-        lstore_b(buf);
+    auto lstore = [&](int buf, int set = 0) {
+        lstore_a(buf, set);
+        lstore_b(buf, set);
     };
 
     floatx16 acc[TM][TN];
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][e], fa[set][i][e], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: stage 0 ----
+    // ---- prologue: stage 0 (DEEP: the loads of step 1 are in flight as well, the loader state describes step 2) ----
     if (!SMALLC) {
         source();
         const int toff0 = taptab[ld_use1 * LWG_MAX_TAPS];      // a split-K slice may start inside x1
@@ -262,6 +269,17 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
             for (int p = 0; p < PA; ++p) tap_row(p, toff1);
         }
     }
+    if (DEEP) {
+        if (nsteps > 1) {
+            load_a(1, NSET - 1);
+            load_b(NSET - 1);
+        }
+        const int toff2 = advance_scalar();                    // loader state -> step 2
+        if (!SMALLC) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) tap_row(p, toff2);
+        }
+    }
     if (LWG_CONV_DMA_B) {
         lstore_a(0);
         __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the DMA of stage 0 has landed
@@ -271,36 +289,42 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     __syncthreads();
     read_frags(0, 0, 0);
 
-    auto step = [&](auto cur_c, auto next_c, int t) {
+    // NEXT: step t + 1 exists (its stage is stored + published here).  LOAD: the loads this step issues exist - step t + 1's
+    // (= NEXT) in the one-step-ahead form, step t + 2's in the DEEP form (register set CUR: it held step t's operands, stored to LDS
+    // one step ago; step t + 1's operands, loaded one step ago, sit in set CUR ^ 1 until this step's phase 3 stores them).
+    auto step = [&](auto cur_c, auto next_c, auto load_c, int t) {
         constexpr int CUR = decltype(cur_c)::value;
         constexpr bool NEXT = decltype(next_c)::value;
-        // phase 0: fragments of g=1 in flight, loads of step t+1 issued between the MFMAs
+        constexpr bool LOAD = decltype(load_c)::value;
+        constexpr int LSET = DEEP ? CUR : 0;            // set the loads of this step go to
+        constexpr int SSET = DEEP ? (CUR ^ 1) : 0;      // set phase 3 stores to LDS
+        // phase 0: fragments of g=1 in flight, loads issued between the MFMAs
         read_frags(CUR, 1, 1);
         LWG_SB();
         mfma_e(0, 0);
         LWG_SB();
-        if (NEXT) load_a(t + 1);
+        if (LOAD) load_a(t + (DEEP ? 2 : 1), LSET);
         LWG_SB();
         mfma_e(0, 1);
         LWG_SB();
-        if (NEXT) {
-            if (LWG_CONV_DMA_B) dma_b(CUR ^ 1); else load_b();
+        if (LOAD) {
+            if (LWG_CONV_DMA_B) dma_b(CUR ^ 1); else load_b(LSET);
         }
         LWG_SB();
         mfma_e(0, 2);
         mfma_e(0, 3);
         LWG_SB();
-        // phase 1: the loader state moves on to step t+2 (the offsets of its tap: one row per MFMA group)
+        // phase 1: the loader state moves on by one step (the offsets of its tap: one row per MFMA group)
         read_frags(CUR, 2, 0);
         LWG_SB();
         int toff = 0;
-        if (NEXT) toff = advance_scalar();
+        if (LOAD) toff = advance_scalar();
         LWG_SB();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             mfma_e(1, e);
             LWG_SB();
-            if (NEXT && !SMALLC) {
+            if (LOAD && !SMALLC) {
 #pragma unroll
                 for (int p = e * PA / 4; p < (e + 1) * PA / 4; ++p) tap_row(p, toff);
             }
@@ -317,11 +341,11 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         // phase 3: the stores of step t+1 ride in the shadow of MFMAs 1..8, the barrier sits before the last 4
         mfma_e(1, 0);
         LWG_SB();
-        if (NEXT) lstore_a(CUR ^ 1);
+        if (NEXT) lstore_a(CUR ^ 1, SSET);
         LWG_SB();
         mfma_e(1, 1);
         LWG_SB();
-        if (NEXT && !LWG_CONV_DMA_B) lstore_b(CUR ^ 1);
+        if (NEXT && !LWG_CONV_DMA_B) lstore_b(CUR ^ 1, SSET);
         LWG_SB();
         mfma_e(1, 2);
         LWG_SB();
@@ -336,16 +360,36 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     };
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     int t = 0;
-    for (; t + 2 < nsteps; t += 2) {
-        step(c0{}, std::true_type{}, t);
-        step(c1{}, std::true_type{}, t + 1);
-    }
-    if (nsteps - t == 2) {
-        step(c0{}, std::true_type{}, t);
-        step(c1{}, std::false_type{}, t + 1);
+    if (DEEP) {
+        for (; t + 3 < nsteps; t += 2) {                   // steps t + 2 and t + 3 exist: both steps load
+            step(c0{}, T_{}, T_{}, t);
+            step(c1{}, T_{}, T_{}, t + 1);
+        }
+        const int left = nsteps - t;                       // 1, 2 or 3
+        if (left == 3) {
+            step(c0{}, T_{}, T_{}, t);
+            step(c1{}, T_{}, F_{}, t + 1);
+            step(c0{}, F_{}, F_{}, t + 2);
+        } else if (left == 2) {
+            step(c0{}, T_{}, F_{}, t);
+            step(c1{}, F_{}, F_{}, t + 1);
+        } else {
+            step(c0{}, F_{}, F_{}, t);
+        }
     } else {
-        step(c0{}, std::false_type{}, t);
+        for (; t + 2 < nsteps; t += 2) {
+            step(c0{}, T_{}, T_{}, t);
+            step(c1{}, T_{}, T_{}, t + 1);
+        }
+        if (nsteps - t == 2) {
+            step(c0{}, T_{}, T_{}, t);
+            step(c1{}, F_{}, F_{}, t + 1);
+        } else {
+            step(c0{}, F_{}, F_{}, t);
+        }
     }
 
     if (EPI == LWG_EPI_NONE && !SMALLC && split_chunks > 0) {
@@ -411,11 +455,11 @@ extern "C" size_t lwg_conv2d_ws_floats(const LwgConvArgs* pa) {
     return (size_t)lwg_conv_split_plan(*pa, &cps) * (size_t)pa->M * (size_t)pa->N;
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC, bool DEEP = false>
 static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream, float* ws = nullptr) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t lds = (size_t)2 * 8 * ((BM + 1) * 4 + BN * 4) * sizeof(float) + 3 * LWG_MAX_TAPS * sizeof(int);
-    auto kern = lwg_conv_igemm_kernel<WAVES_M, WAVES_N, TM, TN, EPI, SMALLC>;
+    auto kern = lwg_conv_igemm_kernel<WAVES_M, WAVES_N, TM, TN, EPI, SMALLC, DEEP>;
     static unsigned long long attr_done = 0ull;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
@@ -440,7 +484,13 @@ static hipError_t launch_epi(const LwgConvArgs& a, hipStream_t stream, float* ws
     // quadruple the workgroup count (each wave then owns one 32x32 MFMA tile: fewer flops per staged byte, but it runs)
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if constexpr (EPI != LWG_EPI_SPADE && !SMALLC) {
-        if (tiles128 < (long)LWG_CONV_SMALL_TILES) return launch_cfg<2, 2, 1, 1, EPI, SMALLC>(a, stream, ws);  // 64 x 64 (split-K when ws is given)
+        if (tiles128 < (long)LWG_CONV_SMALL_TILES) return launch_cfg<2, 2, 1, 1, EPI, SMALLC, LWG_CONV_DEEP != 0>(a, stream, ws);  // 64 x 64 (split-K when ws is given)
+    }
+    if constexpr (EPI == LWG_EPI_SPADE && !SMALLC) {
+        // SPADE needs gamma | beta of the same channels in one wave (TN = 2): a small launch takes 128 x 64 tiles - four waves stacked
+        // in M, each 32 rows x (32 gamma | 32 beta) - instead of 128 x 128: twice the workgroups (a 4096-row frame at N = 512: 256
+        // instead of 128, one per CU)
+        if (LWG_CONV_SPADE_SMALL && tiles128 < (long)LWG_CONV_SMALL_TILES) return launch_cfg<4, 1, 1, 2, EPI, SMALLC, LWG_CONV_DEEP != 0>(a, stream);
     }
     if (EPI == LWG_EPI_SPADE || a.N % 128 == 0) return launch_cfg<2, 2, 2, 2, EPI, SMALLC>(a, stream);  // 128 x 128
     return launch_cfg<4, 1, 1, 2, EPI, SMALLC>(a, stream);                                                // 128 x 64

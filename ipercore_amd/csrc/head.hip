@@ -98,6 +98,77 @@ __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __re
     }
 }
 
+// Thin regressor forward: a stride-1 KS x KS convolution (pad KS / 2, no bias) with <= 4 output channels at full resolution - the
+// 7x7 image head of the background network (bg_inpaintor.py:53: Conv2d(64, 3, 7, 1, 3, bias=False) before the Tanh).  As an MFMA
+// launch its 3 outputs are zero-extended to 64 GEMM columns: 21x the useful flops (0.78 ms per personalization step at 512x512).
+// Same register-blocked VALU form as the compose kernel above (32 x 32 pixel tile, 4 pixels x 4 outputs per thread, halo tile staged
+// 8 channels at a time as channel quads); writes the PRE-activation NHWC-4 tensor (the layout the thin backward consumes), channels
+// beyond the real outputs are zero because their weight columns are.
+template <int KS>
+__global__ __launch_bounds__(256) void lwg_thin_conv_kernel(const float* __restrict__ x, const float* __restrict__ wpk, int S, int C,
+                                                           float* __restrict__ y) {
+    constexpr int PAD = KS / 2, HHK = HT + KS - 1;
+    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HHK][HHK][4];
+    __shared__ __attribute__((aligned(16))) float sw[KS * KS][HCH][4];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int tiles1 = (S + HT - 1) / HT;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (tiles1 * tiles1), trem = lid - b * tiles1 * tiles1;
+    const int x0 = (trem % tiles1) * HT, y0 = (trem / tiles1) * HT;
+    const float* xb = x + (size_t)b * S * S * C;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += HCH) {
+        for (int i = tid; i < HHK * HHK * (HCH / 4); i += 256) {
+            const int cq = i & 1, p = i >> 1;
+            const int py = p / HHK, px = p - py * HHK;
+            const int gy = y0 + py - PAD, gx = x0 + px - PAD;
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < S && gx >= 0 && gx < S)
+                v = *reinterpret_cast<const floatx4*>(xb + ((size_t)gy * S + gx) * C + c0 + cq * 4);
+            *reinterpret_cast<floatx4*>(&sx[cq][py][px][0]) = v;
+        }
+        for (int i = tid; i < KS * KS * HCH; i += 256) {
+            const int tap = i / HCH, c = i - tap * HCH;
+            *reinterpret_cast<floatx4*>(&sw[tap][c][0]) = *reinterpret_cast<const floatx4*>(wpk + ((size_t)tap * C + c0 + c) * 4);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int cq = 0; cq < HCH / 4; ++cq) {
+                    floatx4 w4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w4[c] = *reinterpret_cast<const floatx4*>(&sw[ky * KS + kx][cq * 4 + c][0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const floatx4 xv = *reinterpret_cast<const floatx4*>(&sx[cq][ty + 8 * j + ky][tx + kx][0]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[j][o] += xv[c] * w4[c][o];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int gx = x0 + tx;
+    if (gx >= S) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gy = y0 + ty + 8 * j;
+        if (gy >= S) continue;
+        floatx4 o = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        *reinterpret_cast<floatx4*>(y + (((size_t)b * S + gy) * S + gx) * 4) = o;
+    }
+}
+
 // (B,C,P) -> (B,P,Cp), channels >= C zero-filled.  32x32 LDS tile transpose.
 __global__ __launch_bounds__(256) void lwg_nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
                                                               int Cp, int P) {
@@ -143,6 +214,19 @@ extern "C" int lwg_head_compose_f32(const float* x, const float* wpk, const floa
     const int tiles = (S + HT - 1) / HT;
     hipLaunchKernelGGL(lwg_head_compose_kernel, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred,
                        mask, img);
+    return (int)hipGetLastError();
+}
+
+// x (B,S,S,C) NHWC, C % 8 == 0; wpk [ks*ks][C][4] (tap = ky*ks + kx; unused output columns zero); ks = 5 or 7, stride 1, pad ks/2,
+// no bias, no activation -> y (B,S,S,4) NHWC.
+extern "C" int lwg_thin_conv_f32(const float* x, const float* wpk, int B, int S, int C, int ks, float* y, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !wpk || !y || B <= 0 || S <= 0 || C <= 0 || (C % HCH) != 0 || B > 65535 || (ks != 5 && ks != 7)) return (int)hipErrorInvalidValue;
+    const int tiles = (S + HT - 1) / HT;
+    if (ks == 7)
+        hipLaunchKernelGGL(lwg_thin_conv_kernel<7>, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, S, C, y);
+    else
+        hipLaunchKernelGGL(lwg_thin_conv_kernel<5>, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, S, C, y);
     return (int)hipGetLastError();
 }
 

@@ -204,6 +204,11 @@ __global__ __launch_bounds__(256) void lwg_lbs_blend_kernel(const float* __restr
     o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
 }
 
+__global__ void lwg_lbs_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // linked[b, ids[i,0]] = verts[b, ids[i,1]]  (dst must already hold a copy of verts)
 __global__ void lwg_lbs_link_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ ids,
                                     int nlinks, int nv, int B) {
@@ -251,8 +256,9 @@ extern "C" int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float*
     hipLaunchKernelGGL(lwg_lbs_blend_kernel, dim3((nv + 255) / 256, B), dim3(256), (size_t)nj * 12 * sizeof(float), stream,
                        v_posed, lbs_weights, A, nj, nv, skin_out);
     if (links && nlinks > 0) {
-        hipError_t e = hipMemcpyAsync(verts, vraw, (size_t)B * nv3 * sizeof(float), hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return (int)e;
+        // a copy kernel, not hipMemcpyAsync: the per-frame path is replayed as a hipGraph of kernel nodes only
+        const size_t ncopy = (size_t)B * nv3;
+        hipLaunchKernelGGL(lwg_lbs_copy_kernel, dim3((unsigned)((ncopy + 255) / 256)), dim3(256), 0, stream, vraw, verts, ncopy);
         hipLaunchKernelGGL(lwg_lbs_link_kernel, dim3((B * nlinks + 255) / 256), dim3(256), 0, stream, vraw, verts, links, nlinks, nv, B);
     }
     return (int)hipGetLastError();

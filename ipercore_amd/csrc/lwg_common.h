@@ -17,6 +17,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef LWG_CONV_SMALL_TILES
 #define LWG_CONV_SMALL_TILES 300   // conv_igemm.hip: launches with fewer 128 x 128 tiles than this use 64 x 64 tiles
 #endif
+#ifndef LWG_CONV_DEEP
+#define LWG_CONV_DEEP 1            // conv_igemm.hip: the small-tile launches load two K-steps ahead (0 = one, as the large tiles)
+#endif
+#ifndef LWG_CONV_SPADE_SMALL
+#define LWG_CONV_SPADE_SMALL 1     // conv_igemm.hip: small SPADE launches on 128 x 64 tiles (0 = 128 x 128 always)
+#endif
 #ifndef LWG_BF16_PW_TM
 #define LWG_BF16_PW_TM 2           // conv_igemm_bf16.hip, pointwise kernel: 2 = two 8-wave workgroups per CU with 64-row wave tiles, 4 = one with 128-row tiles
 #endif

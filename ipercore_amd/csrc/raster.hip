@@ -124,6 +124,11 @@ __global__ __launch_bounds__(256) void lwg_raster_setup_kernel(const float* __re
         }
 }
 
+__global__ void lwg_zero_i32_kernel(int* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 __device__ __forceinline__ float lwg_clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
 // One candidate face at one pixel: the oracle's arithmetic in the oracle's order.  Returns false if the pixel centre is
@@ -339,8 +344,9 @@ extern "C" int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, in
     const size_t bins = (size_t)B * nbx * nbx;
     int* bin_count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + lwg_raster_rec_bytes(B, nf));
     int* bin_list = bin_count + bins;
-    hipError_t e = hipMemsetAsync(bin_count, 0, bins * sizeof(int), stream);
-    if (e != hipSuccess) return (int)e;
+    // a kernel, not hipMemsetAsync: the per-frame path is replayed as a hipGraph (Imitator.graph_single_frame) and stays a pure chain
+    // of kernel nodes (no memset / memcpy nodes whose blit arguments the runtime owns)
+    hipLaunchKernelGGL(lwg_zero_i32_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, stream, bin_count, bins);
     hipLaunchKernelGGL(lwg_raster_setup_kernel, dim3((nf + 255) / 256, B), dim3(256), (size_t)2 * nbx * nbx * sizeof(int), stream,
                        faces_v, nf, S, rec, bbox, nbx, bin_count, bin_list);
     const int tiles = (S + 15) / 16;

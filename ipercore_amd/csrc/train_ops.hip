@@ -142,38 +142,51 @@ __global__ __launch_bounds__(256) void lwg_norm_bwd_partial_kernel(const float* 
     }
 }
 
+// Pass 1b (fold): the nsplit records of a (b, c) added in split order -> one pair per (b, c).  (The first version left this to the
+// apply kernel: every thread of it walked all nsplit records - 2 KB of L2 reads per 48 bytes of tensor data at nsplit = 64.)
+__global__ void lwg_norm_bwd_fold_kernel(const float* __restrict__ ws, int nsplit, int C, int total, float* __restrict__ fold) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (b, c)
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float m1 = 0.f, m2 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* o = ws + (((size_t)b * nsplit + s) * C + c) * 2;
+        m1 += o[0];
+        m2 += o[1];
+    }
+    fold[2 * (size_t)i] = m1;
+    fold[2 * (size_t)i + 1] = m2;
+}
+
 __global__ void lwg_norm_bwd_apply_kernel(const floatx4* __restrict__ dy, const floatx4* __restrict__ y, const floatx4* __restrict__ x,
                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                          const floatx4* __restrict__ gamma, const float* __restrict__ ws, int HW, int C4, int nsplit,
+                                          const floatx4* __restrict__ gamma, const float* __restrict__ fold, int HW, int C4,
                                           size_t total4, int act, floatx4* __restrict__ dx) {
     const float inv_hw = 1.f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const int b = (int)(i / ((size_t)HW * C4));
-        floatx4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = m1;
-        for (int s = 0; s < nsplit; ++s) {                         // a few L2-resident floats per element
-            const float* o = ws + (((size_t)b * nsplit + s) * C4 + c4) * 8;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { m1[k] += o[2 * k]; m2[k] += o[2 * k + 1]; }
-        }
+        const float* o = fold + ((size_t)b * C4 + c4) * 8;         // [m1, m2] of four channels
+        const floatx4 f0 = *reinterpret_cast<const floatx4*>(o), f1 = *reinterpret_cast<const floatx4*>(o + 4);
+        const floatx4 m1 = {f0[0], f0[2], f1[0], f1[2]}, m2 = {f0[1], f0[3], f1[1], f1[3]};
         const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + ((size_t)b * C4 + c4) * 4);
         const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + ((size_t)b * C4 + c4) * 4);
         const floatx4 g0 = dy[i], yv = y[i], xv = x[i];
         floatx4 gm = {0.f, 0.f, 0.f, 0.f};
         if (gamma) gm = gamma[i];
-        floatx4 o;
+        floatx4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = (xv[k] - mu[k]) * rs[k];
             const float dxh = g0[k] * lwg_dact_from_y(yv[k], act) * (1.f + gm[k]);
-            o[k] = rs[k] * (dxh - m1[k] * inv_hw - xh * (m2[k] * inv_hw));
+            out[k] = rs[k] * (dxh - m1[k] * inv_hw - xh * (m2[k] * inv_hw));
         }
-        dx[i] = o;
+        dx[i] = out;
     }
 }
 
 // dy, y, x (B,HW,C); mean, rstd (B,C); gamma (B,HW,C) or NULL.  Outputs dx, and dgamma / dbeta when gamma is given.
-// ws: B * nsplit * C * 2 floats, nsplit <= 64.
+// ws: B * (nsplit + 1) * C * 2 floats (the split records, then their fold); nsplit: enough splits to fill the chip (ops._nsplit_bwd).
 extern "C" int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                                      const float* gamma, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma,
                                      float* dbeta, float* ws, lwg_stream_t stream_) {
@@ -184,11 +197,13 @@ extern "C" int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const floa
     const int C4 = C / 4;
     hipLaunchKernelGGL(lwg_norm_bwd_partial_kernel, dim3((C4 + 63) / 64, nsplit, B), dim3(256), 0, stream, dy, y, x, mean, rstd, gamma,
                        HW, C, nsplit, act, dgamma, dbeta, ws);
+    float* fold = ws + (size_t)B * nsplit * C * 2;
+    hipLaunchKernelGGL(lwg_norm_bwd_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, ws, nsplit, C, B * C, fold);
     const size_t total4 = (size_t)B * HW * C4;
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(lwg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(dy),
                        reinterpret_cast<const floatx4*>(y), reinterpret_cast<const floatx4*>(x), mean, rstd,
-                       reinterpret_cast<const floatx4*>(gamma), ws, HW, C4, nsplit, total4, act, reinterpret_cast<floatx4*>(dx));
+                       reinterpret_cast<const floatx4*>(gamma), fold, HW, C4, total4, act, reinterpret_cast<floatx4*>(dx));
     return (int)hipGetLastError();
 }
 

@@ -104,6 +104,15 @@ def pack_head(w_img, w_att):
     return w.permute(2, 3, 1, 0).reshape(25, w.shape[1], 4).contiguous()
 
 
+def pack_thin(w):
+    """A thin regressor (N <= 4, Cin, ks, ks) -> (ks*ks, Cin, 4) fp32 for csrc/head.hip lwg_thin_conv_f32 (unused columns zero)."""
+    N, C, kh, kw = w.shape
+    assert N <= 4 and kh == kw
+    out = w.new_zeros(kh * kw, C, 4, dtype=torch.float32)
+    out[:, :, :N] = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, C, N)
+    return out.contiguous()
+
+
 def pack_head_bf16(w_img, w_att):
     """tsf_img_reg (3,64,5,5) + tsf_att_reg (1,64,5,5) -> the bf16 MFMA operand panel of csrc/bf16_ops.hip lwg_head_bf16_kernel:
     [ky 5][pass 2][channel half 2][lane 64][8]; lane l holds row (l % 16) = 4 * tap + output and channels half*32 + 8*(l // 16) + e;

@@ -166,6 +166,30 @@ def conv(x0, weight, bias=None, x1=None, **kw):
     return ConvFn.apply(x0, x1, weight, bias, ConvCfg(**kw))
 
 
+class ThinConvFn(torch.autograd.Function):
+    """y = conv_ks(x, weight) for a bias-free stride-1 regressor with N <= 4 outputs and ks in {5, 7} (the 7x7 image head of the
+    background network, bg_inpaintor.py:53) on the vector-ALU kernel (csrc/head.hip lwg_thin_conv_f32) instead of an MFMA launch
+    zero-extended to 64 columns (21x the useful flops); backward = ``thin_backward``.  x (B,S,S,C) NHWC -> (B,S,S,N)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        if not x.is_cuda:
+            raise RuntimeError("ipercore_amd training ops run on the MI355X only (no CPU fallback)")
+        x = x.contiguous()
+        N, _, ks, _ = weight.shape
+        y = ops.thin_conv(x, packing.pack_thin(weight).to(x.device), ks)
+        ctx.save_for_backward(x, weight)
+        return y[..., :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, _, ks, _ = weight.shape
+        dy = F.pad(dy, (0, 4 - N)).contiguous() if N != 4 else dy.contiguous()
+        dx, dw = thin_backward(x, weight.detach(), dy, ks // 2, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw
+
+
 class HeadFn(torch.autograd.Function):
     """img = tanh(conv5x5(x, w_img)), mask = sigmoid(conv5x5(x, w_att)) (attlwb_spade_resunet.py:375-384, 604-613; no bias) on
     the inference path's fused regressor kernel (csrc/head.hip: 4 output channels per pixel on the vector ALUs instead of an
@@ -325,6 +349,9 @@ class TrainableGenerator(object):
         for _ in range(self.n_bg - 1):
             x = instance_norm(self.cv(f"bg_net.main.{i}", x, kind="convT"), _RELU)
             i += 3
+        w = self.p(f"bg_net.main.{i}").weight            # Conv2d(nf, 3, 7, 1, 3, bias=False) + Tanh (bg_inpaintor.py:53-54)
+        if w.shape[0] <= 4 and w.shape[2] in (5, 7) and x.shape[3] % 8 == 0 and x.shape[1] == x.shape[2]:
+            return torch.tanh(ThinConvFn.apply(x, w))
         return torch.tanh(self.cv(f"bg_net.main.{i}", x, pad=3, n_pad=64))
 
     def forward_src(self, src8, side=None):

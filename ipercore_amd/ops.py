@@ -446,6 +446,16 @@ def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
     return pred, mask, img
 
 
+def thin_conv(x, wpk, ks):
+    """Stride-1 ks x ks convolution (pad ks // 2, no bias) with <= 4 outputs: x (B,S,S,C) NHWC, wpk (ks*ks, C, 4) -> (B,S,S,4)
+    pre-activation (csrc/head.hip lwg_thin_conv_f32)."""
+    B, S, S2, C = x.shape
+    assert S == S2 and tuple(wpk.shape) == (ks * ks, C, 4), (x.shape, wpk.shape, ks)
+    y = torch.empty(B, S, S, 4, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().lwg_thin_conv_f32(_ptr(x), _ptr(wpk), B, S, C, ks, _ptr(y), _stream()), "lwg_thin_conv_f32")
+    return y
+
+
 def nchw_to_nhwc(x, c_pad=None):
     B, C = x.shape[0], x.shape[1]
     H, W = x.shape[2], x.shape[3]
@@ -754,15 +764,22 @@ def norm_fwd(x, gamma=None, beta=None, act=ACT_NONE, eps=1e-5):
     return y, mean, rstd
 
 
+def _nsplit_bwd(hw, B, C):
+    """Splits of the reduction pass of norm_bwd: ~512 workgroups per launch (one training sample is B = 1: the statistics' 64 splits
+    leave three quarters of the CUs idle), at least 32 pixels per split."""
+    per_image = max(1, 512 // max(1, B * ((C // 4 + 63) // 64)))
+    return max(1, min(per_image, hw // 32, 512))
+
+
 def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=ACT_NONE):
     """Backward of norm_fwd -> (dx, dgamma, dbeta)."""
     B, H, W, C = x.shape
     dy = dy.contiguous()
-    ns = _nsplit(H * W)
+    ns = _nsplit_bwd(H * W, B, C)
     dx = torch.empty_like(x)
     dg = torch.empty_like(x) if gamma is not None else None
     db = torch.empty_like(x) if gamma is not None else None
-    ws = x.new_empty(B * ns * C * 2)
+    ws = x.new_empty(B * (ns + 1) * C * 2)          # the split records + their fold
     _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), B, H * W, C, act, ns,
                                                  _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream()), "lwg_norm_bwd_nhwc_f32")
     return dx, dg, db

@@ -302,6 +302,25 @@ class FlatAdam(object):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         self.grad.div_(dist.get_world_size(group))
 
+    def allreduce_async(self, group=None, n_ranges=1, force=False):
+        """Hand the (already complete) flat gradient buffer to RCCL as ``n_ranges`` async all-reduces and return the work handles
+        (None when there is nothing to exchange): the collectives run on RCCL's stream from this point of the current stream on,
+        next to whatever the caller launches afterwards on OTHER streams.  ``allreduce_finish`` waits and applies the 1/N."""
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+            return None
+        self._gather()
+        total = self.grad.numel()
+        bounds = [(total * b // n_ranges) // 4 * 4 for b in range(n_ranges)] + [total]
+        return [dist.all_reduce(self.grad[bounds[b]:bounds[b + 1]], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                for b in range(n_ranges) if bounds[b + 1] > bounds[b]]
+
+    def allreduce_finish(self, works, group=None):
+        if works is None:
+            return
+        for w in works:
+            w.wait()                                   # the current stream waits for RCCL's stream
+        self.grad.div_(dist.get_world_size(group))
+
     def snapshot(self):
         """Parameters, both moments and the step count (device + host mirror): what a throw-away step must not leave changed."""
         return (self.flat.clone(), self.m.clone(), self.v.clone(), self.t_dev.clone(), self.t)
@@ -522,6 +541,10 @@ class TrainOpts(object):
     branch_streams = True
     # captured step only: D's own forward / backward next to G's backward (it needs the fake images and D's weights, not G's update)
     overlap_d_step = True
+    # data-parallel runs (N > 1): "segmented" = the step as segments [G fwd/bwd | D fwd/bwd | Adam(G) | Adam(D)] with G's gradient
+    # all-reduce on RCCL's stream WHILE D's segment computes and D's all-reduce while Adam(G) runs (the captured step always has this
+    # form at N > 1); "hooks" = the eager step with hook-driven range all-reduces during backward (FlatAdam.arm)
+    dp_schedule = "hooks"
     allow_seeded_loss_nets = False                  # True: seeded VGG19 / Sphere20a weights when a checkpoint is absent (NOT a trained metric)
 
     @classmethod
@@ -755,10 +778,89 @@ class LWGTrainer(object):
             with ops.conv_precision(self.opts.conv_precision):
                 if self._graphable():
                     return self._graph_step()
+                if getattr(self.opts, "dp_schedule", "hooks") == "segmented" and self._multi():
+                    self.step_mode = "eager launches, segmented data-parallel schedule"
+                    seg, st = self._eager_segments()
+                    self._run_dp_schedule(seg)
+                    return st["lg"], st.get("ld")
                 self.step_mode = "eager launches"
                 return self._optimize_parameters()
         finally:
             ops.PANEL_CACHE, ops.BRANCH_STREAM = prev
+
+    def _multi(self):
+        """Is this step data parallel?  ``force_dp`` (tests): run the data-parallel schedule in a one-rank group too, so the RCCL calls
+        and the stream hand-offs of the N > 1 form execute on a single GPU."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or bool(getattr(self, "force_dp", False))
+
+    # ---- the data-parallel schedule of the segmented step (graph replays on the GPU, eager closures in the CPU / gloo test) -------
+    def _eager_segments(self):
+        st = {}
+
+        def seg_A():
+            lg, fake = self._seg_G()
+            lg.backward()
+            self.optimizer_G._gather()
+            st.update(lg=lg.detach(), fake=fake)
+
+        def seg_D():
+            ld = self._seg_D(st["fake"])
+            ld.backward()
+            self.optimizer_D._gather()
+            st["ld"] = ld.detach()
+        return {"A": seg_A, "D": seg_D, "adamG": self.optimizer_G.step,
+                "adamD": None if self.D is None else self.optimizer_D.step}, st
+
+    def _run_dp_schedule(self, seg):
+        """N > 1.  A: G forward / losses / backward (gradients complete).  Then, concurrently: G's flat gradient buffer (145 MB) goes to
+        RCCL (async: its stream starts where the compute stream stands) and D's own forward / backward runs on a second stream - the
+        reference's DDP overlaps its bucketed all-reduce with backward (services/train.py:89-95); here the exchange hides behind the
+        discriminator's step, which needs the fake images and D's weights, not G's update.  Adam(G) follows the exchange; D's buffer
+        (28 MB) is exchanged while Adam(G) runs; Adam(D) last.  Same values as the reference order (lwg_trainer.py:326-352).
+        Exposed exchange time (compute stream idle, waiting for RCCL) is kept as events -> exposed_allreduce_ms()."""
+        on_gpu = torch.cuda.is_available() and next(self.G.parameters()).is_cuda
+        oG, oD = self.optimizer_G, self.optimizer_D
+        ev = {}
+
+        def rec(name, stream=None):
+            if on_gpu:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream if stream is not None else torch.cuda.current_stream())
+                ev[name] = e
+        seg["A"]()
+        rec("A_done")
+        force = bool(getattr(self, "force_dp", False))
+        wG = oG.allreduce_async(self.group, n_ranges=4, force=force)
+        ds = None
+        if self.D is not None:
+            if on_gpu:
+                if getattr(self, "_d_stream", None) is None:
+                    self._d_stream = torch.cuda.Stream()
+                ds = self._d_stream
+                ds.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(ds):
+                    seg["D"]()
+                rec("D_done", ds)
+            else:
+                seg["D"]()
+        oG.allreduce_finish(wG, self.group)
+        rec("G_reduced")
+        wD = None
+        if self.D is not None:
+            if ds is not None:
+                torch.cuda.current_stream().wait_stream(ds)
+            wD = oD.allreduce_async(self.group, force=force)
+        seg["adamG"]()
+        rec("adamG_done")
+        if self.D is not None:
+            oD.allreduce_finish(wD, self.group)
+            rec("D_reduced")
+            seg["adamD"]()
+        self._dp_events = ev
+        self.allreduce_overlap = ("G's gradient all-reduce (4 ranges) behind D's forward / backward, D's behind Adam(G)"
+                                  if self.D is not None else "G's gradient all-reduce exposed (no discriminator step to hide it behind)")
 
     # ---- the step in three segments (the data-parallel exchanges sit between them) ------------------------------------------------
     def _seg_G(self):
@@ -823,25 +925,21 @@ class LWGTrainer(object):
             # the learning rate is a kernel argument frozen into the graph: a changed lr needs a new capture
             self._graphs = None
             return self._graph_step()
-        gA, gB, gC = self._graphs
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        gA.replay()
+        multi = self._multi()
+        if self._graphs["dp"] != multi:                      # captured for the other form (a process group appeared / went away)
+            self._graphs = None
+            return self._graph_step()
+        gr = self._graphs
         if multi:
-            # the collectives sit between the graphs, on the compute stream: their time is exposed, so it is measured (events; read
-            # through exposed_allreduce_ms()) - 145 MB for G, 28 MB for D per step and rank
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            ev[0].record()
-            self.optimizer_G.allreduce(self.group)          # one in-place all-reduce of G's flat gradient buffer between the graphs
-            ev[1].record()
-        gB.replay()
-        if self.D is not None:
-            if multi:
-                ev[2].record()
-                self.optimizer_D.allreduce(self.group)
-                ev[3].record()
-            gC.replay()
-        if multi:
-            self._allreduce_events = ev if self.D is not None else ev[:2]
+            # [A: G fwd / bwd] -> {G's all-reduce on RCCL's stream || [D: D fwd / bwd on the second stream]} -> {Adam(G) || D's all-reduce}
+            # -> Adam(D): _run_dp_schedule
+            self._run_dp_schedule({"A": gr["A"].replay, "D": None if gr["D"] is None else gr["D"].replay, "adamG": gr["B"].replay,
+                                   "adamD": gr["C"].replay})
+        else:
+            gr["A"].replay()
+            gr["B"].replay()
+            if self.D is not None:
+                gr["C"].replay()
         # the replay updated the weights through raw pointers: host-side mirrors follow here (stale inference panels, step counts)
         self.optimizer_G.note_replayed()
         if self.D is not None:
@@ -851,12 +949,16 @@ class LWGTrainer(object):
         return lg.clone(), None if ld is None else ld.clone()
 
     def exposed_allreduce_ms(self):
-        """Device time of the gradient all-reduces of the LAST captured step (data-parallel runs; synchronizes), else None."""
-        ev = getattr(self, "_allreduce_events", None)
-        if not ev:
+        """Time the compute stream of the LAST data-parallel step spent waiting for RCCL (synchronizes): G's exchange beyond the end of
+        D's forward / backward segment, D's beyond Adam(G).  None when the last step exchanged nothing (one GPU)."""
+        dp = getattr(self, "_dp_events", None)
+        if not dp:
             return None
         torch.cuda.synchronize()
-        return sum(ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev), 2))
+        t = lambda a, b: dp[a].elapsed_time(dp[b])                                       # noqa: E731  (ms from a to b)
+        g_exposed = t("A_done", "G_reduced") if "D_done" not in dp else min(t("A_done", "G_reduced"), t("D_done", "G_reduced"))
+        d_exposed = t("adamG_done", "D_reduced") if "D_reduced" in dp else 0.0
+        return max(0.0, g_exposed) + max(0.0, d_exposed)
 
     def _capture(self):
         """Warm up on a side stream (every kernel variant launched once: dynamic-LDS attributes are set outside the capture), then
@@ -882,18 +984,22 @@ class LWGTrainer(object):
         if self.optimizer_D is not None:
             self.optimizer_D._armed = False
         gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        # The discriminator's own step needs this iteration's fake images (detached) and D's weights - not G's update - so its
-        # forward / backward can run NEXT TO G's backward (which reads D's weights but never writes them or their gradients: they are
-        # frozen while G's adversarial term is built).  Same values as the reference order (lwg_trainer.py:326-352: optimize_G, G step,
-        # optimize_D, D step); the two Adam updates stay where they were.
-        overlap_d = self.D is not None and bool(getattr(self.opts, "overlap_d_step", False))
+        gD = None
+        multi = self._multi()
+        # The discriminator's own step needs this iteration's fake images (detached) and D's weights - not G's update.  Same values as
+        # the reference order (lwg_trainer.py:326-352: optimize_G, G step, optimize_D, D step) in both forms:
+        #  * one GPU: D's forward / backward runs NEXT TO G's backward inside graph A (which reads D's weights but never writes them or
+        #    their gradients: they are frozen while G's adversarial term is built);
+        #  * data parallel: D's forward / backward is its OWN graph, replayed on the second stream while RCCL all-reduces G's gradient
+        #    buffer (_run_dp_schedule) - the exchange hides behind it instead of sitting exposed between the graphs.
+        overlap_d = self.D is not None and bool(getattr(self.opts, "overlap_d_step", False)) and not multi
         loss_D = None
+        if self.D is not None and getattr(self, "_d_stream", None) is None:
+            self._d_stream = torch.cuda.Stream()
         with torch.cuda.graph(gA):
             loss_G, fake_tsf_imgs = self._seg_G()
             if overlap_d:
                 cur = torch.cuda.current_stream()
-                if getattr(self, "_d_stream", None) is None:
-                    self._d_stream = torch.cuda.Stream()
                 self._d_stream.wait_stream(cur)
                 with torch.cuda.stream(self._d_stream):
                     loss_D = self._seg_D(fake_tsf_imgs)
@@ -904,9 +1010,15 @@ class LWGTrainer(object):
             if overlap_d:
                 cur.wait_stream(self._d_stream)
         pool = gA.pool()
+        if multi and self.D is not None:
+            gD = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gD, pool=pool, stream=self._d_stream):
+                loss_D = self._seg_D(fake_tsf_imgs)
+                loss_D.backward()
+                self.optimizer_D._gather()
         with torch.cuda.graph(gB, pool=pool):
             self.optimizer_G.step()
-            if self.D is not None and not overlap_d:
+            if self.D is not None and not overlap_d and not multi:
                 loss_D = self._seg_D(fake_tsf_imgs)
                 loss_D.backward()
                 self.optimizer_D._gather()
@@ -915,12 +1027,16 @@ class LWGTrainer(object):
                 self.optimizer_D.step()
         for o, sn in zip(opts_, snaps):                     # capturing step() advanced the host mirrors only; nothing ran on the device
             o.t = sn[4]
-        self._graphs = (gA, gB, gC)
+        self._graphs = {"A": gA, "D": gD, "B": gB, "C": gC, "dp": multi}
         self._captured_lr = (self.optimizer_G.lr, None if self.optimizer_D is None else self.optimizer_D.lr)
         self._static_losses = (loss_G.detach(), None if loss_D is None else loss_D.detach())
         self._static_inp = self.inp
-        self.step_mode = ("3 hipGraph segments per step (G fwd/bwd with D's own fwd/bwd on a second stream | Adam(G) | Adam(D)), all-reduces between them"
-                          if overlap_d else "3 hipGraph segments per step (G fwd/bwd | Adam(G) + D fwd/bwd | Adam(D)), all-reduces between them")
+        if multi:
+            self.step_mode = ("4 hipGraph segments per step (G fwd/bwd | D fwd/bwd on a second stream next to G's gradient all-reduce | Adam(G) "
+                              "next to D's all-reduce | Adam(D))")
+        else:
+            self.step_mode = ("3 hipGraph segments per step (G fwd/bwd with D's own fwd/bwd on a second stream | Adam(G) | Adam(D))"
+                              if overlap_d else "3 hipGraph segments per step (G fwd/bwd | Adam(G) + D fwd/bwd | Adam(D))")
         torch.cuda.synchronize()
 
 

@@ -180,6 +180,14 @@ def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
     return pred, (mask if want_mask else None), (img if want_img else None)
 
 
+def thin_conv(x, wpk, ks):
+    """lwg_thin_conv_f32's contract: x (B,S,S,C), wpk (ks*ks, C, 4) -> (B,S,S,4), stride 1, pad ks // 2, no bias."""
+    B, S, _, C = x.shape
+    assert ks in (5, 7) and C % 8 == 0 and tuple(wpk.shape) == (ks * ks, C, 4)
+    w = wpk.view(ks, ks, C, 4).permute(3, 2, 0, 1)
+    return F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=ks // 2).permute(0, 2, 3, 1).contiguous()
+
+
 def nchw_to_nhwc(x, c_pad=None):
     B, C, H, W = x.shape
     Cp = C if c_pad is None else c_pad
@@ -360,7 +368,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8"):
+                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -201,6 +201,23 @@ def check_head_and_layout():
     gp, gm, gi = ops.head_compose(x.to(DEV), wpk.to(DEV), bg.to(DEV), want_pred=True, want_mask=True, want_img=True)
     torch.cuda.synchronize()
     out["pred"], out["mask"], out["img"] = _cmp(gp, wp, 2e-5, "head pred"), _cmp(gm, wm, 2e-5, "head mask"), _cmp(gi, wim_, 2e-5, "head img")
+    # the thin regressor forward (7x7 image head of the background network, bg_inpaintor.py:53) vs torch conv2d, and its autograd
+    # form (forward on the vector-ALU kernel, backward on the thin MFMA forms) vs torch autograd
+    from ipercore_amd.networks.training import ThinConvFn
+    for ks, N in ((7, 3), (5, 4)):
+        w = _rand((N, C, ks, ks), 156 + ks, 0.03)
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None, padding=ks // 2).permute(0, 2, 3, 1).float()
+        got = ops.thin_conv(x.to(DEV), packing.pack_thin(w).to(DEV), ks)
+        torch.cuda.synchronize()
+        out[f"thin_conv_{ks}x{ks}"] = _cmp(got[..., :N], want, 2e-5, f"thin conv {ks}x{ks}")
+        assert N == 4 or float(got[..., N:].abs().max()) == 0.0
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        (F.conv2d(xr.permute(0, 3, 1, 2), wr, None, padding=ks // 2).tanh() ** 2).sum().backward()
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        (torch.tanh(ThinConvFn.apply(xd, wd)) ** 2).sum().backward()
+        torch.cuda.synchronize()
+        out[f"thin_conv_{ks}x{ks}_dx"] = _cmp(xd.grad, xr.grad, 2e-4, "thin conv dx")
+        out[f"thin_conv_{ks}x{ks}_dw"] = _cmp(wd.grad, wr.grad, 2e-4, "thin conv dw")
     t = _rand((3, 6, 20, 28), 154)
     nh = ops.nchw_to_nhwc(t.to(DEV), c_pad=8)
     assert torch.equal(nh.cpu(), emu_ops.nchw_to_nhwc(t, c_pad=8)), "nchw_to_nhwc"
@@ -1542,6 +1559,41 @@ def check_rccl_world1():
         torch.cuda.synchronize()
         assert (opt.flat - before).abs().max().item() > 0
         m["allreduce"] = {"ranges": opt.overlapped_ranges, "issued_during_backward": in_flight}
+        # the captured personalization step in its data-parallel form (4 graphs; G's all-reduce on RCCL's stream next to D's graph on a
+        # second stream, D's next to Adam(G)) forced in this one-rank group, against the one-GPU form of the captured step
+        from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+        from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
+        S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
+        sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+        u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed, name), device=DEV)      # noqa: E731
+        inp = {"input_G_bg": u((1, 1, 4, S, S), 10, "bg_inputs"), "input_G_src": u((1, ns, 6, S, S), 8, "src_inputs"),
+               "input_G_tsf": u((1, 1, 6, S, S), 9, "tsf_inputs"), "Tst": torch.tensor(g["render/Tst"], device=DEV).view(1, 1, ns, S, S, 2),
+               "real_src": u((1, ns, 3, S, S), 700, "real_src"), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
+               "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
+        flats = {}
+        for form in ("one_gpu", "dp"):
+            G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
+            G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+            G.to(DEV).train()
+            torch.manual_seed(0)
+            D = PatchGlobalDiscriminator().to(DEV)
+            tr = LWGTrainer(G, D, opts=TrainOpts.l1_transfer())
+            tr.force_dp = form == "dp"
+            tr.set_input({k: v.clone() for k, v in inp.items()})
+            losses = [tuple(float(x) for x in tr.optimize_parameters()) for _ in range(3)]
+            torch.cuda.synchronize()
+            flats[form] = (tr.optimizer_G.flat.clone(), tr.optimizer_D.flat.clone(), losses, tr.step_mode, tr.exposed_allreduce_ms(),
+                           int(tr.optimizer_G.t_dev.item()))
+        assert "4 hipGraph" in flats["dp"][3] and "3 hipGraph" in flats["one_gpu"][3], (flats["dp"][3], flats["one_gpu"][3])
+        assert flats["dp"][5] == flats["one_gpu"][5] == 3
+        assert flats["dp"][4] is not None and flats["one_gpu"][4] is None
+        for (a0, b0), (a1, b1) in zip(flats["one_gpu"][2], flats["dp"][2]):
+            assert abs(a0 - a1) <= 2e-3 * max(1.0, abs(a0)) and abs(b0 - b1) <= 2e-3 * max(1.0, abs(b0)), (flats["one_gpu"][2], flats["dp"][2])
+        for k in (0, 1):
+            d = (flats["one_gpu"][k] - flats["dp"][k]).abs()
+            assert d.max().item() <= 6e-4 and d.mean().item() <= 1e-5, (k, d.max().item(), d.mean().item())
+        m["dp_graph_step"] = {"step_mode": flats["dp"][3], "exposed_allreduce_ms_world1": flats["dp"][4], "losses": flats["dp"][2]}
     finally:
         dist.destroy_process_group()
     return m

@@ -86,6 +86,8 @@ def test_invalid_arguments_are_rejected_on_the_host():
     assert L.lwg_lwb_fuse_f32(bad, None, None, bad, bad, 1, 2, 8, 8, 64, 8, 0, 1.0, 1.0, None) == 1       # NULL sources
     assert L.lwg_rasterize_fim_wim_f32(bad, 1, 16, 4096, 0.1, 100.0, bad, bad, bad, None) == 1            # S > 2048
     assert L.lwg_head_compose_f32(bad, bad, None, 0, 1, 64, 60, bad, None, None, None) == 1               # C % 8 != 0 / pred without bg
+    assert L.lwg_thin_conv_f32(bad, bad, 1, 64, 64, 3, bad, None) == 1                                    # ks not in {5, 7}
+    assert L.lwg_thin_conv_f32(bad, bad, 1, 64, 60, 7, bad, None) == 1                                    # C % 8 != 0
     kidx = (ctypes.c_int * 2)(0, 99)
     assert L.lwg_pack_panel_f32(bad, 64, 64, 3, 3, 0, kidx, 2, 64, 64, 64, 64, bad, None) == 1            # tap index outside the kernel
     with pytest.raises(RuntimeError):
@@ -354,3 +356,73 @@ def test_flat_adam_overlapped_allreduce_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+_DP_SCHEDULE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+import unittest.mock as um
+sys.path.insert(0, sys.argv[1])
+from ipercore_amd import synthetic
+from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
+from tests import emu_ops
+
+
+class _Patch:
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+emu_ops.install(_Patch())
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+S_, ns, nf, nres, bgf = 32, 2, [64, 64, 128], 1, [64, 64, 128]
+sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed + 1000 * rank, name))      # a different sample per rank
+inp = {"input_G_bg": u((1, 1, 4, S_, S_), 10, "bg_inputs"), "input_G_src": u((1, ns, 6, S_, S_), 8, "src_inputs"),
+       "input_G_tsf": u((1, 1, 6, S_, S_), 9, "tsf_inputs"), "Tst": u((1, 1, ns, S_, S_, 2), 11, "Tst"),
+       "real_src": u((1, ns, 3, S_, S_), 700, "real_src"), "real_tsf": u((1, 1, 3, S_, S_), 701, "real_tsf"),
+       "real_bg": u((1, 3, S_, S_), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S_, S_), 703, "mask") > 0).float()}
+
+
+def run(schedule, steps=2):
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=synthetic.gen_cfg(nf, nres, bgf), temporal=False)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
+    G.train()
+    torch.manual_seed(2)
+    D = PatchGlobalDiscriminator(ndf=32, n_layers=3)
+    o = TrainOpts.l1_transfer()
+    o.use_graph, o.dp_schedule = False, schedule
+    tr = LWGTrainer(G, D, opts=o)
+    tr.set_input({k: v.clone() for k, v in inp.items()})
+    losses = []
+    with um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True), \
+            um.patch.object(torch.cuda, "is_available", return_value=False):
+        for _ in range(steps):
+            lg, ld = tr.optimize_parameters()
+            losses.append((float(lg), float(ld)))
+    return tr, losses
+
+
+tr_h, l_h = run("hooks")             # the eager step: hook-driven range all-reduces during backward
+tr_s, l_s = run("segmented")         # the captured step's schedule, its segments as eager closures
+assert "segmented" in tr_s.step_mode and tr_s.allreduce_overlap, tr_s.step_mode
+for a, b in zip(l_h, l_s):
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(a[1]), (l_h, l_s)
+for oa, ob in ((tr_h.optimizer_G, tr_s.optimizer_G), (tr_h.optimizer_D, tr_s.optimizer_D)):
+    assert torch.allclose(oa.flat, ob.flat, atol=1e-6), (oa.flat - ob.flat).abs().max()       # same averaged gradients, same updates
+    assert oa.t == ob.t == 2
+    both = [torch.zeros_like(ob.flat) for _ in range(world)]
+    dist.all_gather(both, ob.flat)
+    assert torch.equal(both[0], both[1]), "ranks diverged"                                  # every rank applied the SAME mean gradient
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_segmented_dp_schedule_gloo_world2(tmp_path):
+    """The data-parallel schedule of the captured personalization step (LWGTrainer._run_dp_schedule: G's gradient all-reduce issued async
+    behind D's forward / backward segment, D's behind Adam(G)) with its segments as eager closures over the emulated C ABI, two gloo
+    ranks with different samples: same losses and weights as the hook-driven eager step, ranks stay identical.  Reference behaviour
+    being matched: DistributedDataParallel's overlapped all-reduce, iPERCore/services/train.py:89-95."""
+    _run_gloo(tmp_path, _DP_SCHEDULE_WORKER, 2)
