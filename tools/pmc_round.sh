@@ -22,6 +22,9 @@ for p in ${PASSES:-A B C}; do
     B) run fetch FETCH_SIZE ;;
     C) run write WRITE_SIZE ;;
     D) run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS ;;
+    E) run l2 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE ;;
+    F) run l1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE ;;
+    G) run l2b TCC_READ_sum TCC_WRITE_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum ;;
   esac
 done
 # per-launch HBM-side traffic of the dominant kernel -> profiles/pmc_traffic.json (read by bench.py) + per-kernel tables
