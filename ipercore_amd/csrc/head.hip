@@ -15,30 +15,35 @@
 #define HH (HT + 4)    // halo edge (5x5, pad 2)
 #define HCH 8          // channels per stage
 
+// J: pixels per thread = tile height / 8.  J = 4: 32 x 32 tiles (frame batches); J = 2: 32 x 16 tiles for launches that would otherwise
+// leave CUs without a workgroup (one frame at 512x512 is 256 tiles of 32 x 32: one 4-wave workgroup per CU - 150 us per image against
+// 54 us per image inside an 8-frame batch); the arithmetic per output pixel is the same in both forms.
+template <int J>
 __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                               const float* __restrict__ bg, size_t bg_bstride, int S, int C,
                                                               float* __restrict__ pred, float* __restrict__ mask_out,
                                                               float* __restrict__ img_out) {
-    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HH][HH][4];
+    constexpr int HTY = 8 * J, HHY = HTY + 4;
+    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HHY][HH][4];
     __shared__ __attribute__((aligned(16))) float sw[25][HCH][4];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     // 1-D grid, XCD-aware: every XCD walks a contiguous band of tile rows, so the halo rows two vertically adjacent tiles share are
     // fetched into ONE L2 (with the 3-D grid the hardware dealt neighbouring tiles to different XCDs: PMC showed 2.4 GB fetched per
     // launch for a 0.54 GB input)
-    const int tiles1 = (S + HT - 1) / HT;
+    const int tiles1 = (S + HT - 1) / HT, tilesy = (S + HTY - 1) / HTY;
     const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / (tiles1 * tiles1), trem = lid - b * tiles1 * tiles1;
-    const int x0 = (trem % tiles1) * HT, y0 = (trem / tiles1) * HT;
+    const int b = lid / (tiles1 * tilesy), trem = lid - b * tiles1 * tilesy;
+    const int x0 = (trem % tiles1) * HT, y0 = (trem / tiles1) * HTY;
     const float* xb = x + (size_t)b * S * S * C;
-    float acc[4][4];
+    float acc[J][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
 
     for (int c0 = 0; c0 < C; c0 += HCH) {
         // stage input halo: HH*HH pixels x 2 channel quads
-        for (int i = tid; i < HH * HH * (HCH / 4); i += 256) {
+        for (int i = tid; i < HHY * HH * (HCH / 4); i += 256) {
             const int cq = i & 1, p = i >> 1;
             const int py = p / HH, px = p - py * HH;
             const int gy = y0 + py - 2, gx = x0 + px - 2;
@@ -64,12 +69,12 @@ __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __re
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w4[c] = *reinterpret_cast<const floatx4*>(&sw[ky * 5 + kx][cq * 4 + c][0]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < J; ++j) {
                         const floatx4 xv = *reinterpret_cast<const floatx4*>(&sx[cq][ty + 8 * j + ky][tx + kx][0]);
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
 #pragma unroll
-                            for (int o = 0; o < 4; ++o) acc[j][o] += xv[c] * w4[c][o];
+                            for (int o = 0; o < 4; ++o) acc[j][o] = __builtin_fmaf(xv[c], w4[c][o], acc[j][o]);   // explicit: every tile form contracts alike
                     }
                 }
             }
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __re
     if (gx >= S) return;
     const size_t plane = (size_t)S * S;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < J; ++j) {
         const int gy = y0 + ty + 8 * j;
         if (gy >= S) continue;
         const size_t pix = (size_t)gy * S + gx;
@@ -104,25 +109,25 @@ __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __re
 // Same register-blocked VALU form as the compose kernel above (32 x 32 pixel tile, 4 pixels x 4 outputs per thread, halo tile staged
 // 8 channels at a time as channel quads); writes the PRE-activation NHWC-4 tensor (the layout the thin backward consumes), channels
 // beyond the real outputs are zero because their weight columns are.
-template <int KS>
+template <int KS, int J>
 __global__ __launch_bounds__(256) void lwg_thin_conv_kernel(const float* __restrict__ x, const float* __restrict__ wpk, int S, int C,
                                                            float* __restrict__ y) {
-    constexpr int PAD = KS / 2, HHK = HT + KS - 1;
-    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HHK][HHK][4];
+    constexpr int PAD = KS / 2, HHK = HT + KS - 1, HTY = 8 * J, HHKY = HTY + KS - 1;
+    __shared__ __attribute__((aligned(16))) float sx[HCH / 4][HHKY][HHK][4];
     __shared__ __attribute__((aligned(16))) float sw[KS * KS][HCH][4];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    const int tiles1 = (S + HT - 1) / HT;
+    const int tiles1 = (S + HT - 1) / HT, tilesy = (S + HTY - 1) / HTY;
     const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / (tiles1 * tiles1), trem = lid - b * tiles1 * tiles1;
-    const int x0 = (trem % tiles1) * HT, y0 = (trem / tiles1) * HT;
+    const int b = lid / (tiles1 * tilesy), trem = lid - b * tiles1 * tilesy;
+    const int x0 = (trem % tiles1) * HT, y0 = (trem / tiles1) * HTY;
     const float* xb = x + (size_t)b * S * S * C;
-    float acc[4][4];
+    float acc[J][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
     for (int c0 = 0; c0 < C; c0 += HCH) {
-        for (int i = tid; i < HHK * HHK * (HCH / 4); i += 256) {
+        for (int i = tid; i < HHKY * HHK * (HCH / 4); i += 256) {
             const int cq = i & 1, p = i >> 1;
             const int py = p / HHK, px = p - py * HHK;
             const int gy = y0 + py - PAD, gx = x0 + px - PAD;
@@ -146,12 +151,12 @@ __global__ __launch_bounds__(256) void lwg_thin_conv_kernel(const float* __restr
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w4[c] = *reinterpret_cast<const floatx4*>(&sw[ky * KS + kx][cq * 4 + c][0]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < J; ++j) {
                         const floatx4 xv = *reinterpret_cast<const floatx4*>(&sx[cq][ty + 8 * j + ky][tx + kx][0]);
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
 #pragma unroll
-                            for (int o = 0; o < 4; ++o) acc[j][o] += xv[c] * w4[c][o];
+                            for (int o = 0; o < 4; ++o) acc[j][o] = __builtin_fmaf(xv[c], w4[c][o], acc[j][o]);   // explicit: every tile form contracts alike
                     }
                 }
             }
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void lwg_thin_conv_kernel(const float* __restr
     const int gx = x0 + tx;
     if (gx >= S) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < J; ++j) {
         const int gy = y0 + ty + 8 * j;
         if (gy >= S) continue;
         floatx4 o = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
@@ -212,8 +217,12 @@ extern "C" int lwg_head_compose_f32(const float* x, const float* wpk, const floa
     if (!x || !wpk || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C <= 0 || (C % HCH) != 0 || B > 65535)
         return (int)hipErrorInvalidValue;
     const int tiles = (S + HT - 1) / HT;
-    hipLaunchKernelGGL(lwg_head_compose_kernel, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred,
-                       mask, img);
+    if ((long)tiles * tiles * B < 512) {          // fewer 32 x 32 tiles than two per CU: 32 x 16 tiles
+        const int ty2 = (S + 15) / 16;
+        hipLaunchKernelGGL(lwg_head_compose_kernel<2>, dim3(tiles * ty2 * B), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred, mask, img);
+    } else {
+        hipLaunchKernelGGL(lwg_head_compose_kernel<4>, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred, mask, img);
+    }
     return (int)hipGetLastError();
 }
 
@@ -222,11 +231,16 @@ extern "C" int lwg_head_compose_f32(const float* x, const float* wpk, const floa
 extern "C" int lwg_thin_conv_f32(const float* x, const float* wpk, int B, int S, int C, int ks, float* y, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !wpk || !y || B <= 0 || S <= 0 || C <= 0 || (C % HCH) != 0 || B > 65535 || (ks != 5 && ks != 7)) return (int)hipErrorInvalidValue;
-    const int tiles = (S + HT - 1) / HT;
-    if (ks == 7)
-        hipLaunchKernelGGL(lwg_thin_conv_kernel<7>, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, S, C, y);
-    else
-        hipLaunchKernelGGL(lwg_thin_conv_kernel<5>, dim3(tiles * tiles * B), dim3(256), 0, stream, x, wpk, S, C, y);
+    const int tiles = (S + HT - 1) / HT, ty2 = (S + 15) / 16;
+    const bool small = (long)tiles * tiles * B < 512;      // as lwg_head_compose_f32: 32 x 16 tiles when 32 x 32 ones leave CUs idle
+    const dim3 grid(small ? tiles * ty2 * B : tiles * tiles * B);
+    if (ks == 7) {
+        if (small) hipLaunchKernelGGL((lwg_thin_conv_kernel<7, 2>), grid, dim3(256), 0, stream, x, wpk, S, C, y);
+        else hipLaunchKernelGGL((lwg_thin_conv_kernel<7, 4>), grid, dim3(256), 0, stream, x, wpk, S, C, y);
+    } else {
+        if (small) hipLaunchKernelGGL((lwg_thin_conv_kernel<5, 2>), grid, dim3(256), 0, stream, x, wpk, S, C, y);
+        else hipLaunchKernelGGL((lwg_thin_conv_kernel<5, 4>), grid, dim3(256), 0, stream, x, wpk, S, C, y);
+    }
     return (int)hipGetLastError();
 }
 

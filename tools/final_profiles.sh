@@ -1,18 +1,31 @@
 #!/bin/bash
-# End-of-round evidence: rocprofv3 kernel stats of the default bench command, the PMC traffic passes, the per-kernel table,
-# and bench lines at 256 / 1024 / split / bf16.  Everything lands in gpurun_out/; copy what is judged into profiles/.
+# End-of-round evidence on the final code (run through gpurun; everything lands in gpurun_out/, copy what is judged into profiles/):
+#   1. pytest -m gpu (the parity suite, through the C ABI)        2. the driver's bench command
+#   3. rocprofv3 --kernel-trace --stats of that command (fp32 512^2) and of the bf16 1024^2 novel-view run
+#   4. PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs) for both -> pmc_traffic.json / pmc_traffic_bf16.json
+# usage: tools/final_profiles.sh [pytest] [bench] [prof] [pmc]   (default: all)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma
-tools/gpu_round.sh prof > gpurun_out/final_prof.log 2>&1
-PASSES="A B C" tools/pmc_round.sh > gpurun_out/final_pmc.log 2>&1
-f=$(find gpurun_out/prof -name "*kernel_stats*" | head -1)
-python tools/kernel_table.py "$f" gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/kernel_table.md > /dev/null 2>&1
-python tools/prof_summary.py "$f" 6 30 > gpurun_out/prof_summary.txt 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_mfma gpurun_out/pmc_mfma.md > /dev/null 2>&1
-for cfg in "256 --size 256" "1024 --size 1024" "512_split --precision split" "512_bf16 --precision bf16" "1024_bf16_novelview --size 1024 --precision bf16 --workload novel_view"; do
-  set -- $cfg; name=$1; shift
-  timeout 400 python bench.py "$@" --cpu-frames 0 --output-frames 0 --no-split-extra > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
-  echo "$name: $(tail -1 gpurun_out/bench_$name.json | cut -c1-160)"
-done
-head -12 gpurun_out/prof_summary.txt; cat gpurun_out/pmc_traffic.json 2>/dev/null | head -c 600
+R=$PWD; O=gpurun_out; mkdir -p $O
+WHAT="${*:-pytest bench prof pmc}"
+if [[ " $WHAT " == *" pytest "* ]]; then
+  timeout 1500 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -30 > $O/pytest_gpu.log; echo "pytest exit=${PIPESTATUS[0]}"; tail -4 $O/pytest_gpu.log
+fi
+if [[ " $WHAT " == *" bench "* ]]; then
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err; echo "bench exit=$?"; head -c 300 $O/bench_final.json; echo
+fi
+if [[ " $WHAT " == *" prof "* ]]; then
+  rm -rf $O/prof $O/prof_bf16
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o lwg -- python $R/bench.py --steps 4 --warmup 2 --cpu-frames 0 --no-conv-events --no-extras --no-self-check > $R/$O/prof_f32.log 2>&1 ); echo "prof f32 exit=$?"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bf16 -o lwg -- python $R/bench.py --precision bf16 --size 1024 --workload novel_view --steps 3 --warmup 1 --cpu-frames 0 --no-conv-events --no-extras --no-self-check > $R/$O/prof_bf16.log 2>&1 ); echo "prof bf16 exit=$?"
+  for d in prof prof_bf16; do f=$(find $O/$d -name "*kernel_stats*" | head -1); [ -n "$f" ] && cp "$f" $O/${d}_kernel_stats.csv && python tools/prof_summary.py "$f" 6 30 > $O/${d}_summary.txt 2>&1; done
+  find $O/prof $O/prof_bf16 -name "*.csv" -size +3M -delete
+fi
+if [[ " $WHAT " == *" pmc "* ]]; then
+  rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_fetch_bf16 $O/pmc_write_bf16 $O/pmc_mfma_bf16
+  PASSES="A B C" bash tools/pmc_round.sh > $O/final_pmc.log 2>&1
+  BENCH_ARGS="--precision bf16 --size 1024 --workload novel_view" TAG=_bf16 KERNEL=lwg_conv_bf16 PASSES="A B C" bash tools/pmc_round.sh > $O/final_pmc_bf16.log 2>&1
+  python tools/pmc_summary.py $O/pmc_mfma $O/pmc_mfma.md > /dev/null 2>&1
+  python tools/pmc_summary.py $O/pmc_mfma_bf16 $O/pmc_mfma_bf16.md > /dev/null 2>&1
+  cat $O/pmc_traffic.json 2>/dev/null | head -c 500; echo; cat $O/pmc_traffic_bf16.json 2>/dev/null | head -c 500; echo
+fi
