@@ -7,10 +7,10 @@ export TMPDIR=/tmp
 R="$PWD"
 # BENCH_ARGS: extra bench.py flags (e.g. "--precision bf16 --size 1024 --workload novel_view"); TAG: suffix of the output names;
 # KERNEL: name substring of the kernel family whose per-launch traffic goes to gpurun_out/pmc_traffic$TAG.json
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-conv-events --no-extras ${BENCH_ARGS:-}"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-conv-events --no-extras --no-self-check ${BENCH_ARGS:-}"
 TAG="${TAG:-}"
 KERNEL="${KERNEL:-lwg_conv_igemm_kernel}"
-export LWG_PMC_CMD="bench.py --steps 2 --warmup 1 --no-extras ${BENCH_ARGS:-}"
+export LWG_PMC_CMD="bench.py --steps 2 --warmup 1 --no-extras --no-self-check ${BENCH_ARGS:-}"
 run() { # name counters...
   local name=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$name$TAG" -o pmc -- $CMD > "$R/gpurun_out/pmc_$name$TAG.log" 2>&1 )
