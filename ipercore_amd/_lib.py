@@ -122,6 +122,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP kernels are not built (run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C ipercore_amd/csrc`).  There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so) while this library is linked against /opt/rocm's: the
+        # first one loaded serves every later request for that SONAME.  torch must win - its streams and allocations are what the
+        # kernels run on; loaded the other way round (build() then smoke() in one process) every launch fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
