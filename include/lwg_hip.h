@@ -105,6 +105,14 @@ int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* args, lwg_stream_t stream);
  * dy in {py-1, py}, dx in {px-1, px} and writes pixels (2y + py, 2x + px)); args->w = the four register-streamed panels
  * [parity = 2 py + px][Cin/64 * 4][4][N][16], taps ascending in (dy, dx); C0 = 64 or 128, C1 = 0, N % 64 == 0, LWG_EPI_NONE. */
 int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
+/* The same call on fp32 NHWC (nn.ConvTranspose2d(4, 2, 1) of the decoders, attlwb_spade_resunet.py:331-340, bg_inpaintor.py:49-50): args =
+ * the parity-(0,0) launch description of lwg_conv2d_nhwc_f32 (ntaps = 4 with dy, dx in {-1, 0}, stride = 1, omul = 2, ooy = oox = 0, OH = H,
+ * OW = W, YH = 2H, YW = 2W, LWG_EPI_NONE, one input, Cin % 32 == 0); args->w = the four parity panels stacked [2 py + px][4 Cin][N].  Small
+ * launches (a frame or two) run as ONE grid of four times the workgroups, large ones as the four lwg_conv2d_nhwc_f32 launches; every
+ * output element is computed exactly as by four separate calls. */
+int lwg_conv_transpose4_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
+/* 1 if the call above runs this description as one grid, 0 if as four launches (for callers that bracket launches with events). */
+int lwg_conv_transpose4_is_one_grid(const LwgConvArgs* args);
 
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs

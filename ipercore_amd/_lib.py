@@ -55,6 +55,8 @@ _SIGS = {
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv_transpose4_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv_transpose4_is_one_grid": (c_i, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),

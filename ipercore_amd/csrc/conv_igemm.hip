@@ -55,8 +55,14 @@ __device__ __forceinline__ floatx4 lwg_buf_load(const float* base, unsigned byte
 // sample) have ONE workgroup per CU, nobody to cover the stall (measured: 57 us for a 4096 x 256 x 2304 launch whose MFMAs need 33).
 // Same MFMA order, same results.
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool SMALLC, bool DEEP = false>
-__global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArgs a, const int split_chunks, float* __restrict__ slabs) {
+__global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArgs a, const int split_chunks, float* __restrict__ slabs,
+                                                               const unsigned parity_panel_floats) {
     static_assert(!DEEP || !LWG_CONV_DMA_B, "the two-steps-ahead loader stages both operands through registers");
+    // parity_panel_floats > 0: the FOUR output parities of a ConvTranspose2d(4, 2, 1) in one grid (lwg_conv_transpose4_nhwc_f32):
+    // a describes parity (0, 0); workgroups with blockIdx.z = 2 py + px read the panel a.w + z * parity_panel_floats, shift every tap
+    // by (py, px) (packing._CT_TAPS: parity p's input offsets are parity 0's + p) and write the pixels (2y + py, 2x + px)
+    const int ppy = parity_panel_floats ? (int)(blockIdx.z >> 1) : 0, ppx = parity_panel_floats ? (int)(blockIdx.z & 1) : 0;
+    const float* const wbase = a.w + (size_t)blockIdx.z * parity_panel_floats;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_ROW = (BM + 1) * 4;  // floats per k-quad row; +1 float4 pad => conflict-free b128 stores
     constexpr int B_ROW = BN * 4;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         vmask[p] = 0ull;
     }
     if (tid < a.ntaps) {
-        const int dy = a.dy[tid], dx = a.dx[tid];
+        const int dy = a.dy[tid] + ppy, dx = a.dx[tid] + ppx;
         taptab[tid] = (dy * a.W + dx) * a.C0 * 4;
         taptab[LWG_MAX_TAPS + tid] = (dy * a.W + dx) * a.C1 * 4;
         taptab[2 * LWG_MAX_TAPS + tid] = (dy & 0xffff) | (dx << 16);
@@ -196,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
     };
     auto load_b = [&](int set = 0) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[set][p] = lwg_buf_load(a.w, wbytes, wvoff[p], ld_soffB);
+        for (int p = 0; p < PB; ++p) rb[set][p] = lwg_buf_load(wbase, wbytes, wvoff[p], ld_soffB);
     };
     // LDS-DMA form: lane i of a wave lands at (M0 base) + 16 * i, i.e. the wave's 1 KB slice of the lane-linear B stage
     const int wave_b = __builtin_amdgcn_readfirstlane(tid >> 6) * 256;          // floats
     auto dma_b = [&](int buf) {
-        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)wbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, (int)wbytes, 0x00020000);
 #pragma unroll
         for (int p = 0; p < PB; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(Bs + buf * B_STAGE + wave_b + 1024 * p), 16,
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_igemm_kernel(const LwgConvArg
         lwg_conv_epilogue_slab<TM, TN>(slabs + (size_t)blockIdx.y * a.M * a.N, a.M, a.N, acc, m_base, n_base, wm, wn, lane);
         return;
     }
-    lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane);
+    lwg_conv_epilogue<TM, TN, EPI>(a, acc, m_base, n_base, wm, wn, lane, ppy, ppx);
 }
 
 // y[row m -> output pixel][ycoff + n] = act(sum_s slab[s][m][n] + bias[n]): the epilogue of a split-K launch (slices added in
@@ -467,14 +473,26 @@ static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream, float* ws
         int cps = 0;
         const int slices = ws ? lwg_conv_split_plan(a, &cps) : 0;
         if (slices > 1) {
-            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, slices), dim3(256), lds, stream, a, cps, ws);
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, slices), dim3(256), lds, stream, a, cps, ws, 0u);
             const size_t total4 = (size_t)a.M * (a.N / 4);
             const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
             hipLaunchKernelGGL(lwg_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, slices);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, 0, (float*)nullptr);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, 0, (float*)nullptr, 0u);
+    return hipGetLastError();
+}
+
+// The four parity launches of a transposed convolution as ONE grid (blockIdx.z = parity) on the small-launch tile configuration.
+template <int EPI>
+static hipError_t launch_parity4(const LwgConvArgs& a, hipStream_t stream, unsigned panel_floats) {
+    constexpr size_t lds = (size_t)2 * 8 * ((64 + 1) * 4 + 64 * 4) * sizeof(float) + 3 * LWG_MAX_TAPS * sizeof(int);
+    auto kern = lwg_conv_igemm_kernel<2, 2, 1, 1, EPI, false, LWG_CONV_DEEP != 0>;
+    static unsigned long long attr_done = 0ull;
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done); e != hipSuccess) return e;
+    const int tiles_m = (a.M + 63) / 64, tiles_n = a.N / 64;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1, 4), dim3(256), lds, stream, a, 0, (float*)nullptr, panel_floats);
     return hipGetLastError();
 }
 
@@ -528,4 +546,47 @@ extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stre
     }
     if (a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
     return smallc ? (int)launch_epi<LWG_EPI_NONE, true>(a, stream) : (int)launch_epi<LWG_EPI_NONE, false>(a, stream, ws);
+}
+
+// nn.ConvTranspose2d(kernel 4, stride 2, padding 1) on fp32 NHWC as ONE call (decoder up-sampling, attlwb_spade_resunet.py:331-340;
+// bg_inpaintor.py:49-50).  args: the launch description of the parity-(0, 0) launch (ntaps = 4 with dy, dx in {-1, 0}, stride = 1,
+// omul = 2, ooy = oox = 0, OH = H, OW = W, YH = 2H, YW = 2W, LWG_EPI_NONE); args->w = the four parity panels stacked [2 py + px][4 Cin][N]
+// (each as lwg_conv2d_nhwc_f32 takes it); parity (py, px) reads the taps shifted by (py, px) and writes the pixels (2y + py, 2x + px).
+// Small launches (one frame: a parity is 64..256 tiles of 64 x 64, a workgroup per CU or less) run as ONE grid of four times the
+// workgroups; large ones as the four launches of lwg_conv2d_nhwc_f32.  Either way every output element is computed exactly as by four
+// separate lwg_conv2d_nhwc_f32 calls (same tile, same K order).
+// 1 if lwg_conv_transpose4_nhwc_f32 runs this description as ONE grid (a parity has fewer 128 x 128 tiles than the small-launch
+// threshold), 0 if as four launches - so that a caller bracketing launches with events (bench.py) brackets what really runs.
+extern "C" int lwg_conv_transpose4_is_one_grid(const LwgConvArgs* pa) {
+    if (!pa || pa->M <= 0 || pa->N <= 0) return 0;
+    const long tiles128 = (long)((pa->M + 127) / 128) * ((pa->N + 127) / 128);
+    return tiles128 < (long)LWG_CONV_SMALL_TILES ? 1 : 0;
+}
+
+extern "C" int lwg_conv_transpose4_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.stride != 1 || a.omul != 2 || a.ooy != 0 || a.oox != 0 || a.C1 != 0 ||
+        a.epi != LWG_EPI_NONE || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.C0 % 32 != 0 || a.N % 64 != 0 || (a.YC & 3) != 0 ||
+        (a.ycoff & 3) != 0 || a.OH != a.H || a.OW != a.W || a.YH != 2 * a.H || a.YW != 2 * a.W)
+        return (int)hipErrorInvalidValue;
+    for (int t = 0; t < 4; ++t)
+        if (a.dy[t] < -1 || a.dy[t] > 0 || a.dx[t] < -1 || a.dx[t] > 0) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.B * a.H * a.W * (unsigned long long)a.C0 * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    const unsigned panel_floats = 4u * (unsigned)a.C0 * (unsigned)a.N;
+    if (lwg_conv_transpose4_is_one_grid(pa)) return (int)launch_parity4<LWG_EPI_NONE>(a, stream, panel_floats);
+    for (int p = 0; p < 4; ++p) {
+        LwgConvArgs ap = a;
+        ap.w = a.w + (size_t)p * panel_floats;
+        ap.ooy = p >> 1;
+        ap.oox = p & 1;
+        for (int t = 0; t < 4; ++t) {
+            ap.dy[t] = (signed char)(a.dy[t] + (p >> 1));
+            ap.dx[t] = (signed char)(a.dx[t] + (p & 1));
+        }
+        const int e = lwg_conv2d_nhwc_f32_ws(&ap, nullptr, stream_);
+        if (e != 0) return e;
+    }
+    return 0;
 }

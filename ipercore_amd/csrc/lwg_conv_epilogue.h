@@ -6,7 +6,7 @@
 // acc[i][j] are 32x32 D^T tiles: rows = output channels, columns = output pixels (see conv_igemm.hip).
 template <int TM, int TN, int EPI>
 __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base,
-                                                  int wm, int wn, int lane) {
+                                                  int wm, int wn, int lane, int ooy_add = 0, int oox_add = 0) {
     const int khalf = lane >> 5;
     const int HW = a.OH * a.OW;
     // ---- epilogue.  The MFMAs computed D^T (weights as the row operand), so a lane owns ONE output pixel
@@ -34,7 +34,7 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
             if (!direct) {
                 const int rem = m - b * HW;
                 const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+                opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy + ooy_add)) * a.YW + (ox * a.omul + a.oox + oox_add);
             }
         }
         if (EPI == LWG_EPI_SPADE) {

@@ -57,7 +57,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -72,6 +72,7 @@ class ConvSpec:
         self._w16x3 = None
         self._w16c8 = None
         self._w16up = None
+        self._w32up = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -251,6 +252,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     return y
 
 
+F32_UP4 = True          # lab switch: fp32 transposed convolutions through lwg_conv_transpose4_nhwc_f32 (False: four conv2d calls)
 BF16_UP4 = True         # lab switch: the four parity launches of a bf16 transposed convolution fused into one (Cin <= 128)
 
 
@@ -283,6 +285,26 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE):
         if CONV_HOOK is not None:
             CONV_HOOK(False, a.M, whole, EPI_NONE)
         return y
+    if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION == "fp32" and len(specs) == 4 and s0.Cin % 32 == 0
+            and all(s.ntaps == 4 and s.omul == 2 and s.stride == 1 and (s.ooy, s.oox) == (i >> 1, i & 1) and s.N == s0.N and s.Cin == s0.Cin
+                    and [(dy - (i >> 1), dx - (i & 1)) for dy, dx in zip(s.dy, s.dx)] == list(zip(s0.dy, s0.dx)) for i, s in enumerate(specs))):
+        # fp32, small launch (one frame: a parity is a workgroup per CU or less): ONE grid of four times the workgroups
+        # (lwg_conv_transpose4_nhwc_f32); large launches stay four conv2d calls (the library would issue the same four launches). The
+        # values are those of the four conv2d calls bit for bit (same tiles, same K order).
+        a = conv_args(x, s0, y, act=act)
+        if _lib.lib().lwg_conv_transpose4_is_one_grid(a):
+            panel = getattr(s0, "_w32up", None)
+            if panel is None or panel.device != s0.w.device:
+                panel = torch.stack([s.w.reshape(-1) for s in specs]).contiguous()
+                s0._w32up = panel
+            a.w = _ptr(panel)
+            if CONV_HOOK is not None:
+                whole = _FusedTransposeSpec(s0, panel)
+                CONV_HOOK(True, a.M, whole, EPI_NONE)
+            _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_f32(a, _stream()), "lwg_conv_transpose4_nhwc_f32")
+            if CONV_HOOK is not None:
+                CONV_HOOK(False, a.M, whole, EPI_NONE)
+            return y
     for s in specs:
         conv2d(x, s, y, act=act)
     return y

@@ -100,16 +100,29 @@ def check_conv_variants():
 
 
 def check_conv_transpose():
-    B, H, W, Cin, N = 2, 8, 8, 128, 64
-    w = _rand((Cin, N, 4, 4), 100, 1.0 / np.sqrt(Cin * 4))
-    b = _rand((N,), 101, 0.1)
-    x = _rand((B, H, W, Cin), 102)
-    want = torch.nn.functional.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1).relu().permute(0, 2, 3, 1)
-    y = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
-    for s in packing.pack_conv_transpose(w, b):
-        ops.conv2d(x.to(DEV), _spec_dev(s), y, act=ops.ACT_RELU)
-    torch.cuda.synchronize()
-    return _cmp(y, want, 2e-5, "convT 4x4 s2")
+    """ConvTranspose2d(4, 2, 1) as four parity launches of the conv kernel vs torch, and the one-call form
+    (lwg_conv_transpose4_nhwc_f32: ONE grid of four times the workgroups for small launches, four launches for large ones) against
+    the four separate launches BITWISE, at a small shape (one grid) and at a shape past the small-launch threshold."""
+    out = {}
+    for tag, (B, H, W, Cin, N) in (("small", (2, 8, 8, 128, 64)), ("odd", (1, 12, 20, 256, 128)), ("large", (3, 128, 128, 64, 128))):
+        w = _rand((Cin, N, 4, 4), 100, 1.0 / np.sqrt(Cin * 4))
+        b = _rand((N,), 101, 0.1)
+        x = _rand((B, H, W, Cin), 102)
+        want = torch.nn.functional.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1).relu().permute(0, 2, 3, 1)
+        specs = [_spec_dev(s) for s in packing.pack_conv_transpose(w, b)]
+        y = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        for s in specs:
+            ops.conv2d(x.to(DEV), s, y, act=ops.ACT_RELU)
+        torch.cuda.synchronize()
+        out[tag] = _cmp(y, want, 2e-5, "convT 4x4 s2 " + tag)
+        y1 = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        ops.conv_transpose2d(x.to(DEV), specs, y1, act=ops.ACT_RELU)
+        torch.cuda.synchronize()
+        a = ops.conv_args(x.to(DEV), specs[0], y1, act=ops.ACT_RELU)
+        out[tag]["one_grid"] = int(_lib.lib().lwg_conv_transpose4_is_one_grid(a))
+        assert torch.equal(y1, y), f"one-call transposed convolution differs from the four parity launches ({tag})"
+    assert out["small"]["one_grid"] == 1 and out["large"]["one_grid"] == 0, out
+    return out
 
 
 def check_spade_epilogue():

@@ -86,6 +86,9 @@ def test_invalid_arguments_are_rejected_on_the_host():
     assert L.lwg_lwb_fuse_f32(bad, None, None, bad, bad, 1, 2, 8, 8, 64, 8, 0, 1.0, 1.0, None) == 1       # NULL sources
     assert L.lwg_rasterize_fim_wim_f32(bad, 1, 16, 4096, 0.1, 100.0, bad, bad, bad, None) == 1            # S > 2048
     assert L.lwg_head_compose_f32(bad, bad, None, 0, 1, 64, 60, bad, None, None, None) == 1               # C % 8 != 0 / pred without bg
+    a.xdt = a.ydt = _lib.DT_F32
+    a.C0, a.C1, a.N, a.YC, a.ntaps, a.stride, a.omul, a.epi, a.res = 64, 0, 64, 64, 4, 1, 1, 0, None
+    assert L.lwg_conv_transpose4_nhwc_f32(a, None) == 1                                                 # omul != 2: not a parity-(0,0) description
     assert L.lwg_thin_conv_f32(bad, bad, 1, 64, 64, 3, bad, None) == 1                                    # ks not in {5, 7}
     assert L.lwg_thin_conv_f32(bad, bad, 1, 64, 60, 7, bad, None) == 1                                    # C % 8 != 0
     kidx = (ctypes.c_int * 2)(0, 99)
