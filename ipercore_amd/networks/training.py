@@ -38,6 +38,9 @@ class ConvCfg(object):
         self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
 
 
+FUSED_CONVT_FWD = True      # lab switch: False = four parity launches (split-K where the library plans it)
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(cat[x0, x1], weight) + bias) on NHWC tensors, all three passes on the MFMA kernels."""
 
@@ -62,8 +65,11 @@ class ConvFn(torch.autograd.Function):
             N = weight.shape[1]
             specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(weight, bias, cfg.n_pad)]
             y = torch.empty(B, 2 * H, 2 * W, specs[0].N, device=dev, dtype=torch.float32)
-            for s in specs:
-                ops.conv2d(x0, s, y, act=cfg.act, splitk=True)
+            if FUSED_CONVT_FWD:
+                ops.conv_transpose2d(x0, specs, y, act=cfg.act)     # small launches: the four parities as one grid (lwg_conv_transpose4_nhwc_f32)
+            else:
+                for s in specs:
+                    ops.conv2d(x0, s, y, act=cfg.act, splitk=True)
         ctx.cfg, ctx.specs, ctx.N, ctx.has_bias = cfg, specs, N, bias is not None
         ctx.has_x1 = x1 is not None
         # a regressor (3 / 4 / 1 output channels zero-extended to 64): its backward runs on the thin forms below

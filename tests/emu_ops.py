@@ -70,6 +70,13 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
     return y
 
 
+def conv_transpose2d(x, specs, y, act=0):
+    """ops.conv_transpose2d's contract: ConvTranspose2d(4, 2, 1) given its four parity specs = the four parity launches."""
+    for s in specs:
+        conv2d(x, s, y, act=act)
+    return y
+
+
 def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
     """CPU emulation of lwg_conv2d_wgrad_nhwc_f32: dW (ntaps*Cin, N) in the panel's K order (include/lwg_hip.h)."""
     x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
@@ -368,7 +375,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv"):
+                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)
