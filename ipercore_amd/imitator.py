@@ -243,6 +243,12 @@ class Imitator(object):
         return (cam_strategy, sel["primary_ids"], sel["use_selected_f2pts"], id(self.src_info), id(gen.packed()), gen.conv_precision,
                 tuple(row.shape), self.image_size)
 
+    def reset_frame_graph(self):
+        """Drop the captured single-frame graph.  It is keyed on the IDENTITY of ``src_info`` and of the packed weight panels: call this
+        after mutating ``src_info``'s tensors in place (``set_source`` / ``source_setup`` / ``swap_source_setup`` build a new dict and need
+        nothing)."""
+        self._frame_graph = None
+
     def _graphed_frame(self, row, cam_strategy, sel):
         """row (1, 85 | 156) on the device -> pred (1,3,S,S): the per-frame path captured once (per source state / weight version /
         precision mode) and replayed.  Returns None when the frame must run eager (first_cam not fixed yet, capture unavailable)."""
