@@ -520,7 +520,7 @@ def main(argv=None):
                     help="skip every separately reported measurement (pipelined, split_products, with_output, b1_latency, "
                          "novel_view_1024_bf16, personalize_step)")
     ap.add_argument("--no-split-extra", dest="split_extra", action="store_false")
-    ap.add_argument("--output-frames", type=int, default=160, help="frames of the with-output measurement (0 = skip)")
+    ap.add_argument("--output-frames", type=int, default=300, help="frames of the with-output measurement (0 = skip; 300 = the whole clip)")
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     ap.add_argument("--tiny-arch", action="store_true", help="reduced-width generator (plumbing tests only; never a reported number)")
     ap.add_argument("--no-self-check", dest="self_check", action="store_false")
