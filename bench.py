@@ -480,6 +480,18 @@ def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def _extra(fn, *a, **kw):
+    """A separately reported measurement must never take the headline line with it: an exception becomes {"error": ...}."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:       # noqa: BLE001
+        try:
+            torch.cuda.synchronize()
+        except Exception:        # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"[:500]}
+
+
 def main(argv=None):
     import faulthandler
     faulthandler.enable()                    # a crash inside a native library leaves a Python traceback on stderr
@@ -745,17 +757,17 @@ def main(argv=None):
             def render():
                 return im.synthesize(tgt, "smooth")
             if args.pipelined_streams > 1:
-                line["pipelined"] = pipelined(im, render, n_clip, 1, Ke, args.pipelined_streams)
+                line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams)
             if args.split_extra and args.precision == "fp32":
-                line["split_products"] = split_products(im, render, n_clip, 1, Ke, last)
+                line["split_products"] = _extra(split_products, im, render, n_clip, 1, Ke, last)
             if args.output_frames > 0:
                 # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
                 # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)
-                line["with_output"] = with_output(im, tgt, min(FB, 16), args.output_frames, 0)
+                line["with_output"] = _extra(with_output, im, tgt, min(FB, 16), args.output_frames, 0)
             if args.precision == "fp32" and S == 512 and args.sizes_extra:
                 line["sizes"] = {str(S2): size_extra(dev, timer, S2) for S2 in (256, 1024)}
             if args.precision == "fp32" and S == 512:
-                line["b1_latency"] = b1_latency(im, tgt, timer)
+                line["b1_latency"] = _extra(b1_latency, im, tgt, timer)
                 ops.CONV_HOOK = hook
                 try:
                     line["novel_view_1024_bf16"] = novel_view_1024_bf16(dev, timer, 1, 3)
@@ -764,7 +776,7 @@ def main(argv=None):
                 line["personalize_step"] = personalize_step_extra()
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
-            line["cpu_baseline"] = cpu_baseline(small, args.cpu_frames)
+            line["cpu_baseline"] = _extra(cpu_baseline, small, args.cpu_frames)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
