@@ -339,8 +339,43 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack_kernel(const float
     }
 }
 
+// The large-tensor form (G = 1 above keeps ONE 4-byte load in flight per thread while it walks the slabs: 17 us for a 33 MB slab set that
+// HBM streams in 7).  Here a thread owns FOUR consecutive n of one (tap, c) - their slab entries are 16 contiguous bytes - and the slab
+// loop is unrolled by four (independent loads in flight; the sums are still added in slab order: deterministic).
+__global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4_kernel(const float* __restrict__ part, int nsplit, size_t slab, size_t total4,
+                                                                      const LwgUnpackMap u, float* __restrict__ out) {
+    const int nq = u.nout >> 2;
+    for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i4 % nq) * 4, r = (int)(i4 / nq);
+        const int c = r % u.cin, tap = r / u.cin;
+        const int k = (u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c;
+        const float* src = part + (size_t)k * u.n_pad + n;
+        floatx4 s = {0.f, 0.f, 0.f, 0.f};
+        int kk = 0;
+        for (; kk + 4 <= nsplit; kk += 4) {
+            const floatx4 v0 = *reinterpret_cast<const floatx4*>(src + (size_t)kk * slab);
+            const floatx4 v1 = *reinterpret_cast<const floatx4*>(src + (size_t)(kk + 1) * slab);
+            const floatx4 v2 = *reinterpret_cast<const floatx4*>(src + (size_t)(kk + 2) * slab);
+            const floatx4 v3 = *reinterpret_cast<const floatx4*>(src + (size_t)(kk + 3) * slab);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; kk < nsplit; ++kk) s += *reinterpret_cast<const floatx4*>(src + (size_t)kk * slab);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t dst = ((size_t)(u.transposed ? c : n + j) * u.D1 + (u.transposed ? n + j : c)) * u.KHW + u.kidx[tap];
+            out[dst] = s[j];
+        }
+    }
+}
+
 static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t slab, size_t total, const LwgUnpackMap& u, float* out,
                                           hipStream_t stream) {
+    if (total >= 65536 && (u.nout & 3) == 0 && (u.n_pad & 3) == 0 && (slab & 3) == 0) {
+        const size_t total4 = total / 4;
+        const unsigned blocks = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack4_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total4, u, out);
+        return;
+    }
     if (total < 65536 && nsplit >= 64) {
         hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
     } else if (total < 65536 && nsplit >= 16) {
