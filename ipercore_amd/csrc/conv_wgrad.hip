@@ -30,10 +30,15 @@ __device__ __forceinline__ floatx4 lwg_wg_buf_load(const float* base, unsigned b
 
 // a: the FORWARD geometry (x0/x1, taps, stride, OH/OW/M, N, output mapping YH/YW/YC/ycoff/omul/ooy/oox); a.y is unused.
 // dy_: gradient of the forward output, laid out like the forward y.  part: [gridDim.y][Ktot][N] partial sums.
-template <bool SMALLC>
+// BN: columns of the output tile.  128: wave tile 64 (k) x 64 (n) = 2 x 2 MFMA tiles.  64: wave tile 64 (k) x 32 (n) = 2 x 1 - for
+// the N = 64 layers (last up-sampling layer, first discriminator / encoder layers), where a 128-column tile spends half of its MFMAs on
+// columns that do not exist (33 - 53 TFLOP/s on those launches).
+template <bool SMALLC, int BN>
 __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArgs a, const float* __restrict__ dy_, int Ktot,
                                                                int chunks_per_split, float* __restrict__ part) {
-    constexpr int BK = 128, BN = 128, BR = 32;           // output tile and reduction chunk
+    constexpr int BK = 128, BR = 32;                     // output tile rows and reduction chunk
+    constexpr int NT = BN / 64;                          // 32-column MFMA tiles per wave
+    constexpr int NYP = BN / 32;                         // 16-byte dY pieces per thread and chunk
     constexpr int ROW = 128;                             // floats per staged row (no pad: see header)
     constexpr int STAGE = BR * ROW;                      // one operand, one stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
         roy = rem / a.OW;
         rox = rem - roy * a.OW;
     }
-    floatx4 rx[4], ry[4];
+    floatx4 rx[4], ry[NYP];
     // The eight loads of a chunk are issued as eight separate pieces between the MFMAs of the current chunk.
     // row_setup(): per-chunk base offsets of this thread's row; load_piece(i): i < 4 activation group i, else dY quad i-4.
     const unsigned tapb[4] = {   // (tap offset in pixels) * channels of the group's source * 4 + channel offset * 4  (constants)
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
             const bool ok = r_ok && gok[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const unsigned off = r_pix * (unsigned)(gcs[i] * 4) + tapb[i];
             rx[i] = lwg_wg_buf_load(gsrc[i], gbytes[i], ok ? off : LWG_OOB_OFFSET);
-        } else {
+        } else if (i - 4 < NYP) {
             const int j = i - 4;
             const bool ok = r_ok && n_base + (kq + 8 * j) * 4 < a.N;
             ry[j] = lwg_wg_buf_load(dy_, ybytes, ok ? r_yoff + 128u * j : LWG_OOB_OFFSET);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
     };
     auto store_piece = [&](int buf, int i) {
         if (i < 4) *reinterpret_cast<floatx4*>(Xs + buf * STAGE + mrow * ROW + kq * 4 + i * 32) = rx[i];
-        else *reinterpret_cast<floatx4*>(Ys + buf * STAGE + mrow * ROW + kq * 4 + (i - 4) * 32) = ry[i - 4];
+        else if (i - 4 < NYP) *reinterpret_cast<floatx4*>(Ys + buf * STAGE + mrow * ROW + kq * 4 + (i - 4) * 32) = ry[i - 4 < NYP ? i - 4 : 0];
     };
     auto lstore = [&](int buf) {
         float* xb = Xs + buf * STAGE + mrow * ROW + kq * 4;
@@ -153,33 +158,33 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(xb + g * 32) = rx[g];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(yb + j * 32) = ry[j];
+        for (int j = 0; j < NYP; ++j) *reinterpret_cast<floatx4*>(yb + j * 32) = ry[j];
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int khalf = lane >> 5;
     const float* fx = Xs + khalf * ROW + wk * 64 + (lane & 31);
-    const float* fy = Ys + khalf * ROW + wn * 64 + (lane & 31);
+    const float* fy = Ys + khalf * ROW + wn * (BN / 2) + (lane & 31);
     // fragments of reduction step s: one scalar per operand tile (lanes 0-31: row 2s, lanes 32-63: row 2s+1)
-    float fa[2][2], fb[2][2];
+    float fa[2][2], fb[2][NT];
     auto read_frags = [&](int buf, int s_, int set) {
         fa[set][0] = fx[buf * STAGE + 2 * s_ * ROW];
         fa[set][1] = fx[buf * STAGE + 2 * s_ * ROW + 32];
-        fb[set][0] = fy[buf * STAGE + 2 * s_ * ROW];
-        fb[set][1] = fy[buf * STAGE + 2 * s_ * ROW + 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[set][j] = fy[buf * STAGE + 2 * s_ * ROW + 32 * j];
     };
     auto mfma4 = [&](int set) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0], fb[set][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1], fb[set][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
     };
 
     if (c_begin < c_end) {
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
             const int k = k_base + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             if (k >= Ktot) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n_base + wn * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < NT; ++j) {
+                const int n = n_base + wn * (BN / 2) + j * 32 + (lane & 31);
                 if (n < a.N) slab[(size_t)k * a.N + n] = acc[i][j][r];
             }
         }
@@ -431,8 +436,11 @@ __global__ __launch_bounds__(256) void lwg_colsum_partial_kernel(const float* __
 
 // Reduction splits: enough workgroups to fill the 256 CUs twice (2 workgroups/CU), at most 48 MB of slabs (every slab is
 // written and read once more by the reduction), at least 4 chunks of 32 rows per workgroup.
+static int lwg_wgrad_bn(int N) { return (N % 128 != 0 && N % 128 <= 64) ? 64 : 128; }    // 64-column tiles when the last 128 would be half empty
+
 static int lwg_wgrad_splits(int Ktot, int N, int M) {
-    const int tiles = ((Ktot + 127) / 128) * ((N + 127) / 128);
+    const int bn = lwg_wgrad_bn(N);
+    const int tiles = ((Ktot + 127) / 128) * ((N + bn - 1) / bn);
     const int nchunks = (M + 31) / 32;
     int splits = 512 / tiles;          // tiles * splits <= 512 = one full wave of workgroups at 2 per CU (no ragged second wave)
     const long slab = (long)Ktot * N * 4;
@@ -460,14 +468,16 @@ static int lwg_wgrad_launch(const LwgConvArgs* pa, const float* dy, float* ws, h
     if (smallc && (a.C1 != 0 || Cin > 16 || (Cin & (Cin - 1)) != 0 || (1 << a.cshift) != (Cin >> 2))) return (int)hipErrorInvalidValue;
     if (!smallc && a.C1 != 0 && (a.C0 % 32 != 0 || !a.x1)) return (int)hipErrorInvalidValue;
     const int Ktot = a.ntaps * Cin;
-    const int tiles = ((Ktot + 127) / 128) * ((a.N + 127) / 128);
+    const int bn = lwg_wgrad_bn(a.N);
+    const int tiles = ((Ktot + 127) / 128) * ((a.N + bn - 1) / bn);
     const int nchunks = (a.M + 31) / 32;
     const int splits = lwg_wgrad_splits(Ktot, a.N, a.M);
     const int cps = (nchunks + splits - 1) / splits;
     const size_t lds = (size_t)4 * 32 * 128 * sizeof(float) + LWG_MAX_TAPS * sizeof(int);
-    auto kern = smallc ? lwg_conv_wgrad_kernel<true> : lwg_conv_wgrad_kernel<false>;
-    static unsigned long long attr_done[2] = {0ull, 0ull};
-    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[smallc]); e != hipSuccess) return (int)e;
+    auto kern = bn == 64 ? (smallc ? lwg_conv_wgrad_kernel<true, 64> : lwg_conv_wgrad_kernel<false, 64>)
+                         : (smallc ? lwg_conv_wgrad_kernel<true, 128> : lwg_conv_wgrad_kernel<false, 128>);
+    static unsigned long long attr_done[4] = {0ull, 0ull, 0ull, 0ull};
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[(bn == 64 ? 2 : 0) + (smallc ? 1 : 0)]); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
     *splits_out = splits;
     return 0;
