@@ -129,9 +129,12 @@ int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* args, lwg_stream_t stream);
 size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M);
 int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* args, const float* dy, float* dw, float* ws, lwg_stream_t stream);
 /* The same weight gradient written straight into the parameter's gradient tensor dw (D0,D1,KH,KW) - the slab reduction and
- * lwg_unpack_wgrad_f32 (below; same transposed / kidx / cin / nout convention, cin_pad = C0 + C1, n_pad = N) in one launch. */
+ * lwg_unpack_wgrad_f32 (below; same transposed / kidx / cin / nout convention, cin_pad = C0 + C1, n_pad = N) in one launch.
+ * db: NULL, or nout floats receiving the bias gradient db[n] = sum over the launch's M rows of dy[m, n] (torch's
+ *   grad_bias of nn.Conv2d): the column sums are accumulated by the workgroups that stage dy anyway and reduced by the same
+ *   launch - no separate pass over dy (lwg_colsum_nhwc_f32 remains for tensors that have no weight gradient next to them). */
 int lwg_conv2d_wgrad_unpacked_f32(const LwgConvArgs* args, const float* dy, float* ws, float* dw, int D0, int D1, int KH, int KW,
-                                  int transposed, const int* kidx, int cin, int nout, lwg_stream_t stream);
+                                  int transposed, const int* kidx, int cin, int nout, float* db, lwg_stream_t stream);
 int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* ws, lwg_stream_t stream);
 
 /* Elementwise / normalisation pieces of the personalization step and their backward (csrc/train_ops.hip); NHWC fp32.

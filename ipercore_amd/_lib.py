@@ -60,7 +60,7 @@ _SIGS = {
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
-    "lwg_conv2d_wgrad_unpacked_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int), c_i, c_i, c_f]),
+    "lwg_conv2d_wgrad_unpacked_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int), c_i, c_i, c_f, c_f]),
     "lwg_colsum_nhwc_f32": (c_i, [c_f, ctypes.c_size_t, c_i, c_f, c_f, c_f]),
     "lwg_act_bwd_f32": (c_i, [c_f, c_f, ctypes.c_size_t, c_i, c_f, c_f]),
     "lwg_norm_fwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -35,7 +35,7 @@ __device__ __forceinline__ floatx4 lwg_wg_buf_load(const float* base, unsigned b
 // columns that do not exist (33 - 53 TFLOP/s on those launches).
 template <bool SMALLC, int BN>
 __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArgs a, const float* __restrict__ dy_, int Ktot,
-                                                               int chunks_per_split, float* __restrict__ part) {
+                                                               int chunks_per_split, float* __restrict__ part, int want_bias) {
     constexpr int BK = 128, BR = 32;                     // output tile rows and reduction chunk
     constexpr int NT = BN / 64;                          // 32-column MFMA tiles per wave
     constexpr int NYP = BN / 32;                         // 16-byte dY pieces per thread and chunk
@@ -109,6 +109,12 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
         rox = rem - roy * a.OW;
     }
     floatx4 rx[4], ry[NYP];
+    // Bias gradient (column sums of dY) as row Ktot of the slab: the workgroups of k-tile 0 add up the dY quads they stage anyway
+    // (NYP vector adds per chunk) - no separate pass over dY (lwg_colsum_nhwc_f32: 102 launch pairs per training step).
+    const bool do_bias = want_bias != 0 && tile_k == 0;
+    floatx4 cs[NYP];
+#pragma unroll
+    for (int j = 0; j < NYP; ++j) cs[j] = floatx4{0.f, 0.f, 0.f, 0.f};
     // The eight loads of a chunk are issued as eight separate pieces between the MFMAs of the current chunk.
     // row_setup(): per-chunk base offsets of this thread's row; load_piece(i): i < 4 activation group i, else dY quad i-4.
     const unsigned tapb[4] = {   // (tap offset in pixels) * channels of the group's source * 4 + channel offset * 4  (constants)
@@ -150,7 +156,11 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
     };
     auto store_piece = [&](int buf, int i) {
         if (i < 4) *reinterpret_cast<floatx4*>(Xs + buf * STAGE + mrow * ROW + kq * 4 + i * 32) = rx[i];
-        else if (i - 4 < NYP) *reinterpret_cast<floatx4*>(Ys + buf * STAGE + mrow * ROW + kq * 4 + (i - 4) * 32) = ry[i - 4 < NYP ? i - 4 : 0];
+        else if (i - 4 < NYP) {
+            const int j = i - 4 < NYP ? i - 4 : 0;
+            *reinterpret_cast<floatx4*>(Ys + buf * STAGE + mrow * ROW + kq * 4 + j * 32) = ry[j];
+            if (do_bias) cs[j] += ry[j];
+        }
     };
     auto lstore = [&](int buf) {
         float* xb = Xs + buf * STAGE + mrow * ROW + kq * 4;
@@ -158,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(xb + g * 32) = rx[g];
 #pragma unroll
-        for (int j = 0; j < NYP; ++j) *reinterpret_cast<floatx4*>(yb + j * 32) = ry[j];
+        for (int j = 0; j < NYP; ++j) {
+            *reinterpret_cast<floatx4*>(yb + j * 32) = ry[j];
+            if (do_bias) cs[j] += ry[j];
+        }
     };
 
     floatx16 acc[2][NT];
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
         }
     }
     // ---- partial tile -> workspace slab blockIdx.y.  Lane owns column n = lane&31, rows k = (r&3) + 8*(r>>2) + 4*khalf ----
-    float* slab = part + (size_t)blockIdx.y * Ktot * a.N;
+    float* slab = part + (size_t)blockIdx.y * (Ktot + 1) * a.N;     // a slab = Ktot weight rows + the bias-gradient row
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -250,14 +263,26 @@ __global__ __launch_bounds__(256, 2) void lwg_conv_wgrad_kernel(const LwgConvArg
                 if (n < a.N) slab[(size_t)k * a.N + n] = acc[i][j][r];
             }
         }
+    if (do_bias) {   // the 32 rows' partial column sums through LDS, added in row order (deterministic)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) *reinterpret_cast<floatx4*>(Ys + mrow * ROW + kq * 4 + j * 32) = cs[j];
+        __syncthreads();
+        if (tid < BN && n_base + tid < a.N) {
+            float t = Ys[tid];
+#pragma unroll 8
+            for (int r = 1; r < BR; ++r) t += Ys[r * ROW + tid];
+            slab[(size_t)Ktot * a.N + n_base + tid] = t;
+        }
+    }
 }
 
 // dW[i] = sum_s part[s][i] in slab order; optionally also the bias gradient db[n] = sum_m dY[m, n] is NOT computed here
 // (it is a plain column sum, done by lwg_colsum_nhwc_f32).
-__global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t total, float* __restrict__ dw) {
+__global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t total, size_t stride, float* __restrict__ dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * stride + i];
         dw[i] = s;
     }
 }
@@ -267,7 +292,7 @@ __global__ void lwg_wgrad_reduce_kernel(const float* __restrict__ part, int nspl
 // 512 slabs).  G lanes share an element - lane g adds slabs g, g + G, ... - and a fixed-order LDS pass adds the G partial sums
 // (deterministic: the association depends only on (nsplit, G)).
 template <int G>
-__global__ __launch_bounds__(256) void lwg_slab_reduce_g_kernel(const float* __restrict__ part, int nsplit, size_t total,
+__global__ __launch_bounds__(256) void lwg_slab_reduce_g_kernel(const float* __restrict__ part, int nsplit, size_t total, size_t stride,
                                                                 float* __restrict__ out) {
     constexpr int EPB = 256 / G;                                   // elements per block
     __shared__ float sh[256];
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_g_kernel(const float* __r
     const size_t i = (size_t)blockIdx.x * EPB + e;
     float s = 0.f;
     if (i < total)
-        for (int k = g; k < nsplit; k += G) s += part[(size_t)k * total + i];
+        for (int k = g; k < nsplit; k += G) s += part[(size_t)k * stride + i];
     sh[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < total) {
@@ -286,14 +311,15 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_g_kernel(const float* __r
     }
 }
 
-static void lwg_launch_slab_reduce(const float* part, int nsplit, size_t total, float* out, hipStream_t stream) {
+// out[i] = sum_k part[k * stride + i], i < total (stride = total for dense slab sets; a weight-gradient slab carries one more row)
+static void lwg_launch_slab_reduce(const float* part, int nsplit, size_t total, size_t stride, float* out, hipStream_t stream) {
     if (total < 65536 && nsplit >= 64) {
-        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, total, out);
+        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, total, stride, out);
     } else if (total < 65536 && nsplit >= 16) {
-        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, total, out);
+        hipLaunchKernelGGL(lwg_slab_reduce_g_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, total, stride, out);
     } else {
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, total, out);
+        hipLaunchKernelGGL(lwg_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, total, stride, out);
     }
 }
 
@@ -306,8 +332,16 @@ struct LwgUnpackMap {
     int kidx[LWG_MAX_TAPS];
 };
 
-__device__ __forceinline__ void lwg_unpack_map(const LwgUnpackMap& u, size_t i, size_t& src, size_t& dst) {
+// element i of the output -> its slab offset (src) and parameter-tensor offset (dst).  Elements [total_w, total_w + nout) are the bias
+// gradient (slab row ntaps * cin_pad, returned with bias = true and dst = n) when the launch carries one.
+__device__ __forceinline__ void lwg_unpack_map(const LwgUnpackMap& u, size_t i, size_t& src, size_t& dst, bool& bias) {
     const int n = (int)(i % u.nout), r = (int)(i / u.nout);
+    bias = r >= u.ntaps * u.cin;
+    if (bias) {
+        src = (size_t)u.ntaps * u.cin_pad * u.n_pad + n;
+        dst = (size_t)n;
+        return;
+    }
     const int c = r % u.cin, tap = r / u.cin;
     const int k = (u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c;
     src = (size_t)k * u.n_pad + n;
@@ -316,20 +350,22 @@ __device__ __forceinline__ void lwg_unpack_map(const LwgUnpackMap& u, size_t i, 
 
 template <int G>
 __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack_kernel(const float* __restrict__ part, int nsplit, size_t slab, size_t total,
-                                                                     const LwgUnpackMap u, float* __restrict__ out) {
+                                                                     const LwgUnpackMap u, float* __restrict__ out, float* __restrict__ db) {
     constexpr int EPB = 256 / G;
     __shared__ float sh[256];
     const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
     for (size_t i0 = (size_t)blockIdx.x * EPB; i0 < total; i0 += (size_t)gridDim.x * EPB) {
         const size_t i = i0 + e;
         size_t src = 0, dst = 0;
+        bool bias = false;
         float s = 0.f;
         if (i < total) {
-            lwg_unpack_map(u, i, src, dst);
+            lwg_unpack_map(u, i, src, dst, bias);
             for (int k = g; k < nsplit; k += G) s += part[(size_t)k * slab + src];
         }
+        float* o = bias ? db : out;
         if (G == 1) {
-            if (i < total) out[dst] = s;
+            if (i < total) o[dst] = s;
         } else {
             __syncthreads();
             sh[threadIdx.x] = s;
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack_kernel(const float
                 float t = sh[e];
 #pragma unroll
                 for (int j = 1; j < G; ++j) t += sh[j * EPB + e];
-                out[dst] = t;
+                o[dst] = t;
             }
         }
     }
@@ -348,12 +384,13 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack_kernel(const float
 // HBM streams in 7).  Here a thread owns FOUR consecutive n of one (tap, c) - their slab entries are 16 contiguous bytes - and the slab
 // loop is unrolled by four (independent loads in flight; the sums are still added in slab order: deterministic).
 __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4_kernel(const float* __restrict__ part, int nsplit, size_t slab, size_t total4,
-                                                                      const LwgUnpackMap u, float* __restrict__ out) {
+                                                                      const LwgUnpackMap u, float* __restrict__ out, float* __restrict__ db) {
     const int nq = u.nout >> 2;
     for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i4 % nq) * 4, r = (int)(i4 / nq);
-        const int c = r % u.cin, tap = r / u.cin;
-        const int k = (u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c;
+        const bool bias = r >= u.ntaps * u.cin;              // the quads past the weight elements: the bias-gradient row of the slabs
+        const int c = r % u.cin, tap = bias ? 0 : r / u.cin;
+        const int k = bias ? u.ntaps * u.cin_pad : ((u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c);
         const float* src = part + (size_t)k * u.n_pad + n;
         floatx4 s = {0.f, 0.f, 0.f, 0.f};
         int kk = 0;
@@ -365,6 +402,10 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4_kernel(const floa
             s += v0; s += v1; s += v2; s += v3;
         }
         for (; kk < nsplit; ++kk) s += *reinterpret_cast<const floatx4*>(src + (size_t)kk * slab);
+        if (bias) {
+            *reinterpret_cast<floatx4*>(db + n) = s;
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const size_t dst = ((size_t)(u.transposed ? c : n + j) * u.D1 + (u.transposed ? n + j : c)) * u.KHW + u.kidx[tap];
@@ -373,21 +414,24 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4_kernel(const floa
     }
 }
 
-static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t slab, size_t total, const LwgUnpackMap& u, float* out,
+// total: weight elements (ntaps * cin * nout); db != NULL appends the nout bias-gradient elements (slab row Ktot) to the same launch
+static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t slab, size_t total, const LwgUnpackMap& u, float* out, float* db,
                                           hipStream_t stream) {
-    if (total >= 65536 && (u.nout & 3) == 0 && (u.n_pad & 3) == 0 && (slab & 3) == 0) {
+    const size_t weights = total;
+    if (db) total += (size_t)u.nout;
+    if (weights >= 65536 && (u.nout & 3) == 0 && (u.n_pad & 3) == 0 && (slab & 3) == 0) {
         const size_t total4 = total / 4;
         const unsigned blocks = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(lwg_slab_reduce_unpack4_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total4, u, out);
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack4_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total4, u, out, db);
         return;
     }
-    if (total < 65536 && nsplit >= 64) {
-        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
-    } else if (total < 65536 && nsplit >= 16) {
-        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
+    if (weights < 65536 && nsplit >= 64) {
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, part, nsplit, slab, total, u, out, db);
+    } else if (weights < 65536 && nsplit >= 16) {
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, part, nsplit, slab, total, u, out, db);
     } else {
         const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<1>, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total, u, out);
+        hipLaunchKernelGGL(lwg_slab_reduce_unpack_kernel<1>, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total, u, out, db);
     }
 }
 
@@ -443,7 +487,7 @@ static int lwg_wgrad_splits(int Ktot, int N, int M) {
     const int tiles = ((Ktot + 127) / 128) * ((N + bn - 1) / bn);
     const int nchunks = (M + 31) / 32;
     int splits = 512 / tiles;          // tiles * splits <= 512 = one full wave of workgroups at 2 per CU (no ragged second wave)
-    const long slab = (long)Ktot * N * 4;
+    const long slab = (long)(Ktot + 1) * N * 4;
     if ((long)splits * slab > (48l << 20)) splits = (int)((48l << 20) / slab);     // <= 48 MB of slabs per launch
     if (splits > nchunks / 4) splits = nchunks / 4;
     if (splits < 1) splits = 1;
@@ -451,11 +495,11 @@ static int lwg_wgrad_splits(int Ktot, int N, int M) {
 }
 
 extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
-    return (size_t)lwg_wgrad_splits(Ktot, N, M) * Ktot * N;
+    return (size_t)lwg_wgrad_splits(Ktot, N, M) * (size_t)(Ktot + 1) * N;     // a slab = Ktot weight rows + the bias-gradient row
 }
 
 // Validation + the slab launch shared by the two entry points; *splits_out slices of (Ktot, N) land in ws.
-static int lwg_wgrad_launch(const LwgConvArgs* pa, const float* dy, float* ws, hipStream_t stream, int* splits_out) {
+static int lwg_wgrad_launch(const LwgConvArgs* pa, const float* dy, float* ws, hipStream_t stream, int* splits_out, int want_bias = 0) {
     if (!pa || !dy || !ws) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
     const int Cin = a.C0 + a.C1;
@@ -478,7 +522,7 @@ static int lwg_wgrad_launch(const LwgConvArgs* pa, const float* dy, float* ws, h
                          : (smallc ? lwg_conv_wgrad_kernel<true, 128> : lwg_conv_wgrad_kernel<false, 128>);
     static unsigned long long attr_done[4] = {0ull, 0ull, 0ull, 0ull};
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[(bn == 64 ? 2 : 0) + (smallc ? 1 : 0)]); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws);
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), lds, stream, a, dy, Ktot, cps, ws, want_bias);
     *splits_out = splits;
     return 0;
 }
@@ -490,7 +534,8 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
     if (!dw) return (int)hipErrorInvalidValue;
     int splits = 0;
     if (int e = lwg_wgrad_launch(pa, dy, ws, stream, &splits); e != 0) return e;
-    lwg_launch_slab_reduce(ws, splits, (size_t)pa->ntaps * (pa->C0 + pa->C1) * pa->N, dw, stream);
+    const size_t total = (size_t)pa->ntaps * (pa->C0 + pa->C1) * pa->N;
+    lwg_launch_slab_reduce(ws, splits, total, total + (size_t)pa->N, dw, stream);
     return (int)hipGetLastError();
 }
 
@@ -498,8 +543,10 @@ extern "C" int lwg_conv2d_wgrad_nhwc_f32(const LwgConvArgs* pa, const float* dy,
 // nn.Conv2d (transposed = 0: (N, Cin, KH, KW)) or of the GEMM-transposed forms (transposed = 1: (Cin-of-the-GEMM, N, KH, KW)),
 // tap t of the launch goes to kernel position kidx[t]; cin <= C0 + C1 and nout <= N drop the zero-extended channels.  Positions no
 // tap maps to are left untouched (the four parity launches of a transposed convolution fill one tensor).
+// db: NULL, or nout floats that receive the bias gradient sum_m dY[m, n] of THIS launch's rows (the column sums ride along in the
+// workgroups of k-tile 0 and the same reduction launch; nout % 4 == 0 is not required).
 extern "C" int lwg_conv2d_wgrad_unpacked_f32(const LwgConvArgs* pa, const float* dy, float* ws, float* dw, int D0, int D1, int KH, int KW,
-                                             int transposed, const int* kidx, int cin, int nout, lwg_stream_t stream_) {
+                                             int transposed, const int* kidx, int cin, int nout, float* db, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa || !dw || !kidx || cin < 1 || nout < 1 || cin > pa->C0 + pa->C1 || nout > pa->N) return (int)hipErrorInvalidValue;
     if ((transposed ? cin : nout) > D0 || (transposed ? nout : cin) > D1 || pa->ntaps < 1 || pa->ntaps > LWG_MAX_TAPS) return (int)hipErrorInvalidValue;
@@ -511,8 +558,8 @@ extern "C" int lwg_conv2d_wgrad_unpacked_f32(const LwgConvArgs* pa, const float*
         u.kidx[i] = kidx[i];
     }
     int splits = 0;
-    if (int e = lwg_wgrad_launch(pa, dy, ws, stream, &splits); e != 0) return e;
-    lwg_launch_slab_reduce_unpack(ws, splits, (size_t)u.ntaps * u.cin_pad * u.n_pad, (size_t)u.ntaps * cin * nout, u, dw, stream);
+    if (int e = lwg_wgrad_launch(pa, dy, ws, stream, &splits, db ? 1 : 0); e != 0) return e;
+    lwg_launch_slab_reduce_unpack(ws, splits, ((size_t)u.ntaps * u.cin_pad + 1) * u.n_pad, (size_t)u.ntaps * cin * nout, u, dw, db, stream);
     return (int)hipGetLastError();
 }
 
@@ -524,12 +571,12 @@ extern "C" int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* ou
         const int nblk = rows >= 512 * 64 ? 512 : (int)((rows + 63) / 64);      // ws holds nblk * C floats (callers size it 512 * C)
         const int rpb = (int)((rows + nblk - 1) / nblk);
         hipLaunchKernelGGL(lwg_colsum_partial4_kernel, dim3(nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
-        lwg_launch_slab_reduce(ws, nblk, (size_t)C, out, stream);
+        lwg_launch_slab_reduce(ws, nblk, (size_t)C, (size_t)C, out, stream);
         return (int)hipGetLastError();
     }
     const int nblk = rows >= 64 * 64 ? 64 : (int)((rows + 63) / 64);
     const int rpb = (int)((rows + nblk - 1) / nblk);
     hipLaunchKernelGGL(lwg_colsum_partial_kernel, dim3((C + 63) / 64, nblk), dim3(256), 0, stream, x, rows, C, rpb, ws);
-    lwg_launch_slab_reduce(ws, nblk, (size_t)C, out, stream);
+    lwg_launch_slab_reduce(ws, nblk, (size_t)C, (size_t)C, out, stream);
     return (int)hipGetLastError();
 }

@@ -220,12 +220,14 @@ def wgrad_to_conv(dwk, ntaps, cin_packed, cin, n, kh, kw):
     return unpack_wgrad(dwk, ntaps, cin_packed)[:, :cin, :n].reshape(kh, kw, cin, n).permute(3, 2, 0, 1).contiguous()
 
 
-def wgrad_conv(x0, spec, dy, x1, kh, kw, cin, n):
+def wgrad_conv(x0, spec, dy, x1, kh, kw, cin, n, db=None):
     """nn.Conv2d weight gradient (N, Cin, kh, kw) of the launch ``spec``: on the device ONE reduction launch writes it in place
-    (ops.conv2d_wgrad_unpacked); the host-logic tests take the two-step form."""
+    (ops.conv2d_wgrad_unpacked) - and the bias gradient into ``db`` (n,) when given; the host-logic tests take the two-step form."""
     if dy.is_cuda:
         return ops.conv2d_wgrad_unpacked(x0, spec, dy, torch.empty(n, cin, kh, kw, device=dy.device, dtype=torch.float32), False,
-                                         range(kh * kw), cin, n, x1=x1)
+                                         range(kh * kw), cin, n, x1=x1, db=db)
+    if db is not None:
+        db.copy_(ops.colsum(dy)[:n])
     return wgrad_to_conv(ops.conv2d_wgrad(x0, spec, dy, x1=x1), kh * kw, spec.Cin, cin, n, kh, kw)
 
 

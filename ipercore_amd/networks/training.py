@@ -38,6 +38,7 @@ class ConvCfg(object):
         self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
 
 
+FUSED_BIAS_GRAD = True      # lab switch: False = bias gradients by the separate column-sum kernel
 FUSED_CONVT_FWD = True      # lab switch: False = four parity launches (split-K where the library plans it)
 
 
@@ -99,11 +100,16 @@ class ConvFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         # (the weight gradient on a second stream next to the data gradient was tried twice - eager launches: 53.6 vs 48.6 ms in round 1,
         # captured step: 32.4 vs 32.2 ms in round 2 - and removed: both launches already fill the chip)
-        db = ops.colsum(dy)[:N] if want_db else None
+        # the bias gradient of a convolution rides along with its weight gradient (the column sums of dy in the launch that stages dy
+        # anyway: FUSED_BIAS_GRAD); a transposed convolution's four parity launches each see a quarter of dy -> the column-sum kernel
+        fused_db = FUSED_BIAS_GRAD and want_db and want_dw and cfg.kind == "conv"
+        db = None
+        if want_db:
+            db = torch.empty(N, device=dev, dtype=torch.float32) if fused_db else ops.colsum(dy)[:N]
         dw = None
         if want_dw:
             if cfg.kind == "conv":
-                dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N)
+                dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N, db=db if fused_db else None)
             else:
                 dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N)
         if cfg.kind == "conv":

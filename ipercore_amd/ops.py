@@ -630,16 +630,19 @@ def conv2d_wgrad(x0, spec, dy, x1=None, out_hw=None, ycoff=0):
     return dw
 
 
-def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None, out_hw=None, ycoff=0):
-    """``conv2d_wgrad`` + ``unpack_wgrad`` in one reduction launch: the weight gradient lands at positions kidx of dw (D0,D1,KH,KW)."""
+def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None, out_hw=None, ycoff=0, db=None):
+    """``conv2d_wgrad`` + ``unpack_wgrad`` in one reduction launch: the weight gradient lands at positions kidx of dw (D0,D1,KH,KW).
+    db: optional (nout,) tensor that receives the bias gradient (column sums of dy) from the same two launches."""
     a = conv_args(x0, spec, dy, x1=x1, out_hw=out_hw, ycoff=ycoff)
     Ktot = spec.ntaps * spec.Cin
     D0, D1, KH, KW = dw.shape
     assert dw.is_contiguous() and len(kidx) == spec.ntaps
     ws = torch.empty(_lib.lib().lwg_conv2d_wgrad_ws_floats(Ktot, spec.N, a.M), device=x0.device, dtype=torch.float32)
     arr = (ctypes.c_int * spec.ntaps)(*[int(k) for k in kidx])
+    if db is not None:
+        assert db.is_contiguous() and db.dtype == torch.float32 and db.numel() == nout
     _lib.check(_lib.lib().lwg_conv2d_wgrad_unpacked_f32(a, _ptr(dy), _ptr(ws), _ptr(dw), D0, D1, KH, KW, 1 if transposed else 0, arr, cin, nout,
-                                                        _stream()), "lwg_conv2d_wgrad_unpacked_f32")
+                                                        None if db is None else _ptr(db), _stream()), "lwg_conv2d_wgrad_unpacked_f32")
     return dw
 
 

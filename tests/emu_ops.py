@@ -358,7 +358,10 @@ def maxpool2_bwd(x, dy):
         return torch.autograd.grad(F.max_pool2d(xr.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1), xr, dy)[0]
 
 
-def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None, out_hw=None, ycoff=0):
+def conv2d_wgrad_unpacked(x0, spec, dy, dw, transposed, kidx, cin, nout, x1=None, out_hw=None, ycoff=0, db=None):
+    if db is not None:      # the launch's own rows only (out_hw / ycoff select them); dense launches: every row of dy
+        assert out_hw is None and ycoff == 0
+        db.copy_(colsum(dy)[:nout])
     return unpack_wgrad(conv2d_wgrad(x0, spec, dy, x1=x1, out_hw=out_hw, ycoff=ycoff), dw, transposed, kidx, cin, spec.Cin, nout)
 
 

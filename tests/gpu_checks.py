@@ -1306,6 +1306,7 @@ def check_conv_backward():
     run("4x4_s2_odd", "4x4 s2 64->64, odd 11x13 input (D's kernel)", 1, 11, 13, 64, 64, 4, 2, 1, 427)
     run("1x1", "1x1 256->256", 1, 8, 8, 256, 256, 1, 1, 0, 430)
     run("concat", "3x3 concat 128+256", 1, 16, 16, 384, 256, 3, 1, 1, 440, C1=256, act=1)
+    run("3x3_n192", "3x3 s1 64->192 (64-column tiles, 8 splits, fused bias gradient)", 1, 32, 32, 64, 192, 3, 1, 1, 445)
     run("convT", "convT 128->64", 2, 8, 8, 128, 64, 4, 2, 1, 450, kind="convT", act=1)
     run("head5x5", "5x5 64->4 (n_pad)", 1, 16, 16, 64, 4, 5, 1, 2, 460, bias=False, n_pad=64)
     run("first_layer", "3x3 s2 6->64 (cin_pad 8)", 1, 32, 32, 6, 64, 3, 2, 1, 470, cin_pad=8, bias=False, act=1, need_dx=False)
