@@ -143,13 +143,16 @@ int lwg_colsum_nhwc_f32(const float* x, size_t rows, int C, float* out, float* w
  * lwg_norm_fwd_nhwc_f32:  y = act((x - mean) rstd (1 + gamma) + beta); gamma = beta = NULL: InstanceNorm + activation
  *                         (bg_inpaintor.py:31-57); with gamma / beta (B,HW,C): SPADE (attlwb_spade_resunet.py:92).
  * lwg_norm_bwd_nhwc_f32:  the backward of the above: dx (and dgamma, dbeta); ws: B*(nsplit+1)*C*2 floats (split records + their fold).
+ *   gstride (both): floats per pixel row of gamma / beta (and dgamma / dbeta): 0 or C for dense (B,HW,C) tensors; 2C with
+ *   beta = gamma + C (dbeta = dgamma + C) when the two are the halves of ONE (B,HW,2C) tensor - the training step runs SPADE's
+ *   mlp_gamma | mlp_beta convolutions (attlwb_spade_resunet.py:66-67, 88-89) as a single launch of 2C columns.
  * lwg_adam_step_f32:      torch.optim.Adam update (lwg_trainer.py:140-146) of a flat parameter buffer, step count t >= 1. */
 int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int act, float* out, lwg_stream_t stream);
-int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B,
-                          int HW, int C, int act, float* y, lwg_stream_t stream);
+int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int gstride,
+                          int B, int HW, int C, int act, float* y, lwg_stream_t stream);
 int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
-                          const float* gamma, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma, float* dbeta,
-                          float* ws, lwg_stream_t stream);
+                          const float* gamma, int gstride, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma,
+                          float* dbeta, float* ws, lwg_stream_t stream);
 int lwg_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t,
                       lwg_stream_t stream);
 /* The same update with the step count kept on the device (*t_dev is incremented, then read): what a captured (hipGraph) training step

@@ -63,8 +63,8 @@ _SIGS = {
     "lwg_conv2d_wgrad_unpacked_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int), c_i, c_i, c_f, c_f]),
     "lwg_colsum_nhwc_f32": (c_i, [c_f, ctypes.c_size_t, c_i, c_f, c_f, c_f]),
     "lwg_act_bwd_f32": (c_i, [c_f, c_f, ctypes.c_size_t, c_i, c_f, c_f]),
-    "lwg_norm_fwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
-    "lwg_norm_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "lwg_norm_fwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "lwg_norm_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
     "lwg_adam_step_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_f]),
     "lwg_adam_step_dev_f32": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "lwg_pack_panel_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),

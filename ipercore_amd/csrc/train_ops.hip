@@ -46,12 +46,14 @@ extern "C" int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int ac
 
 // ---------------------------------------------------------------------------------------------- normalise (+ modulate) forward
 // y = act( (x - mean) * rstd * (1 + gamma) + beta )   gamma / beta optional (NULL: plain InstanceNorm + activation)
+// gs4: float4s per pixel row of gamma / beta (C4 for dense tensors; 2 * C4 when both are halves of ONE (B,HW,2C) convolution output)
 __global__ void lwg_norm_fwd_kernel(const floatx4* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const floatx4* __restrict__ gamma, const floatx4* __restrict__ beta, int HW, int C4,
+                                    const floatx4* __restrict__ gamma, const floatx4* __restrict__ beta, int gs4, int HW, int C4,
                                     size_t total4, int act, floatx4* __restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
-        const int b = (int)(i / ((size_t)HW * C4));
+        const size_t pix = i / C4;
+        const int b = (int)(pix / (size_t)HW);
         const floatx4 v = x[i];
         const floatx4 mu = *reinterpret_cast<const floatx4*>(mean + ((size_t)b * C4 + c4) * 4);
         const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + ((size_t)b * C4 + c4) * 4);
@@ -59,7 +61,7 @@ __global__ void lwg_norm_fwd_kernel(const floatx4* __restrict__ x, const float* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (v[k] - mu[k]) * rs[k];
         if (gamma) {
-            const floatx4 g = gamma[i], bt = beta[i];
+            const floatx4 g = gamma[pix * gs4 + c4], bt = beta[pix * gs4 + c4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = o[k] * (1.f + g[k]) + bt[k];
         }
@@ -69,14 +71,18 @@ __global__ void lwg_norm_fwd_kernel(const floatx4* __restrict__ x, const float* 
     }
 }
 
-extern "C" int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+// gstride: floats per pixel row of gamma / beta (0 or C: dense (B,HW,C) tensors; 2C with beta = gamma + C: the two halves of one
+// (B,HW,2C) tensor - SPADE's gamma | beta convolutions run as ONE launch in the training step)
+extern "C" int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int gstride,
                                      int B, int HW, int C, int act, float* y, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !mean || !rstd || !y || (C & 3) || B <= 0 || HW <= 0 || ((gamma == nullptr) != (beta == nullptr))) return (int)hipErrorInvalidValue;
+    if (gstride == 0) gstride = C;
+    if (gstride < C || (gstride & 3)) return (int)hipErrorInvalidValue;
     const size_t total4 = (size_t)B * HW * (C / 4);
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(lwg_norm_fwd_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(x), mean, rstd,
-                       reinterpret_cast<const floatx4*>(gamma), reinterpret_cast<const floatx4*>(beta), HW, C / 4, total4, act,
+                       reinterpret_cast<const floatx4*>(gamma), reinterpret_cast<const floatx4*>(beta), gstride / 4, HW, C / 4, total4, act,
                        reinterpret_cast<floatx4*>(y));
     return (int)hipGetLastError();
 }
@@ -90,7 +96,7 @@ extern "C" int lwg_norm_fwd_nhwc_f32(const float* x, const float* mean, const fl
 __global__ __launch_bounds__(256) void lwg_norm_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                   const float* __restrict__ x, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                  int HW, int C, int nsplit, int act, float* __restrict__ dgamma,
+                                                                  int gstride, int HW, int C, int nsplit, int act, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, float* __restrict__ ws) {
     const int C4 = C >> 2;
     const int lpp = C4 < 64 ? C4 : 64;                 // lanes per pixel (channel quads handled by this block)
@@ -110,7 +116,8 @@ __global__ __launch_bounds__(256) void lwg_norm_bwd_partial_kernel(const float* 
             const floatx4 g0 = *reinterpret_cast<const floatx4*>(dy + o), yv = *reinterpret_cast<const floatx4*>(y + o);
             const floatx4 xv = *reinterpret_cast<const floatx4*>(x + o);
             floatx4 gm = {0.f, 0.f, 0.f, 0.f};
-            if (gamma) gm = *reinterpret_cast<const floatx4*>(gamma + o);
+            const size_t og = ((size_t)b * HW + p) * gstride + cq * 4;     // gamma / dgamma / dbeta rows (gstride floats apart)
+            if (gamma) gm = *reinterpret_cast<const floatx4*>(gamma + og);
             floatx4 g, xh, dxh;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(256) void lwg_norm_bwd_partial_kernel(const float* 
                 floatx4 dg;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dg[k] = g[k] * xh[k];
-                *reinterpret_cast<floatx4*>(dgamma + o) = dg;
-                *reinterpret_cast<floatx4*>(dbeta + o) = g;
+                *reinterpret_cast<floatx4*>(dgamma + og) = dg;
+                *reinterpret_cast<floatx4*>(dbeta + og) = g;
             }
         }
     }
@@ -171,12 +178,13 @@ __global__ __launch_bounds__(256) void lwg_norm_bwd_fold_kernel(const float* __r
 
 __global__ void lwg_norm_bwd_apply_kernel(const floatx4* __restrict__ dy, const floatx4* __restrict__ y, const floatx4* __restrict__ x,
                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                          const floatx4* __restrict__ gamma, const float* __restrict__ fold, int HW, int C4,
+                                          const floatx4* __restrict__ gamma, int gs4, const float* __restrict__ fold, int HW, int C4,
                                           size_t total4, int act, floatx4* __restrict__ dx) {
     const float inv_hw = 1.f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
-        const int b = (int)(i / ((size_t)HW * C4));
+        const size_t pix = i / C4;
+        const int b = (int)(pix / (size_t)HW);
         const float* o = fold + ((size_t)b * C4 + c4) * 8;         // [m1, m2] of four channels
         const floatx4 f0 = *reinterpret_cast<const floatx4*>(o), f1 = *reinterpret_cast<const floatx4*>(o + 4);
         const floatx4 m1 = {f0[0], f0[2], f1[0], f1[2]}, m2 = {f0[1], f0[3], f1[1], f1[3]};
@@ -184,7 +192,7 @@ __global__ void lwg_norm_bwd_apply_kernel(const floatx4* __restrict__ dy, const 
         const floatx4 rs = *reinterpret_cast<const floatx4*>(rstd + ((size_t)b * C4 + c4) * 4);
         const floatx4 g0 = dy[i], yv = y[i], xv = x[i];
         floatx4 gm = {0.f, 0.f, 0.f, 0.f};
-        if (gamma) gm = gamma[i];
+        if (gamma) gm = gamma[pix * gs4 + c4];
         floatx4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -197,24 +205,28 @@ __global__ void lwg_norm_bwd_apply_kernel(const floatx4* __restrict__ dy, const 
 }
 
 // dy, y, x (B,HW,C); mean, rstd (B,C); gamma (B,HW,C) or NULL.  Outputs dx, and dgamma / dbeta when gamma is given.
+// gstride: floats per pixel row of gamma, dgamma and dbeta (0 or C: dense; 2C: halves of (B,HW,2C) tensors, dbeta = dgamma + C - the
+//   gradient of a fused gamma | beta convolution output is written in place, no concatenation).
 // ws: B * (nsplit + 1) * C * 2 floats (the split records, then their fold); nsplit: enough splits to fill the chip (ops._nsplit_bwd).
 extern "C" int lwg_norm_bwd_nhwc_f32(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
-                                     const float* gamma, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma,
+                                     const float* gamma, int gstride, int B, int HW, int C, int act, int nsplit, float* dx, float* dgamma,
                                      float* dbeta, float* ws, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!dy || !y || !x || !mean || !rstd || !dx || !ws || (C & 3) || B <= 0 || HW <= 0 || nsplit < 1 || nsplit > 65535 ||
         (gamma && (!dgamma || !dbeta)))
         return (int)hipErrorInvalidValue;
+    if (gstride == 0) gstride = C;
+    if (gstride < C || (gstride & 3)) return (int)hipErrorInvalidValue;
     const int C4 = C / 4;
     hipLaunchKernelGGL(lwg_norm_bwd_partial_kernel, dim3((C4 + 63) / 64, nsplit, B), dim3(256), 0, stream, dy, y, x, mean, rstd, gamma,
-                       HW, C, nsplit, act, dgamma, dbeta, ws);
+                       gstride, HW, C, nsplit, act, dgamma, dbeta, ws);
     float* fold = ws + (size_t)B * nsplit * C * 2;
     hipLaunchKernelGGL(lwg_norm_bwd_fold_kernel, dim3((C + 31) / 32, B), dim3(256), 0, stream, ws, nsplit, C, fold);
     const size_t total4 = (size_t)B * HW * C4;
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(lwg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const floatx4*>(dy),
                        reinterpret_cast<const floatx4*>(y), reinterpret_cast<const floatx4*>(x), mean, rstd,
-                       reinterpret_cast<const floatx4*>(gamma), fold, HW, C4, total4, act, reinterpret_cast<floatx4*>(dx));
+                       reinterpret_cast<const floatx4*>(gamma), gstride / 4, fold, HW, C4, total4, act, reinterpret_cast<floatx4*>(dx));
     return (int)hipGetLastError();
 }
 

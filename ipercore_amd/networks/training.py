@@ -38,17 +38,38 @@ class ConvCfg(object):
         self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
 
 
+FUSED_SPADE_PAIR = True     # lab switch: False = SPADE's mlp_gamma / mlp_beta as two convolutions (two launches per pass + gradient add)
 FUSED_BIAS_GRAD = True      # lab switch: False = bias gradients by the separate column-sum kernel
 FUSED_CONVT_FWD = True      # lab switch: False = four parity launches (split-K where the library plans it)
 
 
+def _stacked(a, b):
+    """cat([a, b], dim 0) of two parameters WITHOUT a copy when b starts where a ends in the same storage (``trainers.FlatAdam``
+    lays paired parameters out that way) - else a concatenation (modules outside a trainer, the host-logic tests)."""
+    a, b = a.detach(), b.detach()
+    if (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:] and a.dtype == b.dtype
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        shape = (a.shape[0] + b.shape[0],) + tuple(a.shape[1:])
+        return torch.as_strided(a, shape, a.stride())
+    return torch.cat([a, b], dim=0)
+
+
 class ConvFn(torch.autograd.Function):
-    """y = act(conv(cat[x0, x1], weight) + bias) on NHWC tensors, all three passes on the MFMA kernels."""
+    """y = act(conv(cat[x0, x1], weight) + bias) on NHWC tensors, all three passes on the MFMA kernels.
+    weight2 / bias2: a second nn.Conv2d of the same geometry on the same input - the two run as ONE launch of N + N2 output columns
+    (y = [conv(x, weight) | conv(x, weight2)] along the channels): SPADE's mlp_gamma | mlp_beta (attlwb_spade_resunet.py:66-67)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, cfg):
+    def forward(ctx, x0, x1, weight, bias, cfg, weight2=None, bias2=None):
         if not x0.is_cuda:
             raise RuntimeError("ipercore_amd training convs run on the MI355X only (no CPU fallback)")
+        ctx.n_first = None
+        if weight2 is not None:
+            assert cfg.kind == "conv" and (bias is None) == (bias2 is None)
+            ctx.n_first = weight.shape[0]
+            weight = _stacked(weight, weight2)
+            bias = None if bias is None else _stacked(bias, bias2)
         x0 = x0.contiguous()
         x1 = None if x1 is None else x1.contiguous()
         B, H, W, _ = x0.shape
@@ -139,7 +160,11 @@ class ConvFn(torch.autograd.Function):
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
             if ctx.has_x1:
                 dx1 = dx[..., C0:C0 + x1.shape[3]]
-        return dx0, dx1, dw, db, None
+        if ctx.n_first is not None:          # the pair's gradients: views of the stacked ones
+            k = ctx.n_first
+            return (dx0, dx1, None if dw is None else dw[:k], None if db is None else db[:k], None,
+                    None if dw is None else dw[k:], None if db is None else db[k:])
+        return dx0, dx1, dw, db, None, None, None
 
     @staticmethod
     def _backward_thin(ctx, x0, weight, dy):
@@ -152,7 +177,7 @@ class ConvFn(torch.autograd.Function):
         kh = weight.shape[2]
         dx, dw = thin_backward(x0, weight, dy, kh // 2 if cfg.pad is None else cfg.pad, cfg.need_dx and ctx.needs_input_grad[0],
                                ctx.needs_input_grad[2])
-        return dx, None, dw, db, None
+        return dx, None, dw, db, None, None, None
 
 
 def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
@@ -176,6 +201,11 @@ def thin_backward(x0, weight, dy, pad, want_dx, want_dw):
 
 def conv(x0, weight, bias=None, x1=None, **kw):
     return ConvFn.apply(x0, x1, weight, bias, ConvCfg(**kw))
+
+
+def conv_pair(x0, weight, bias, weight2, bias2, **kw):
+    """[conv(x0, weight, bias) | conv(x0, weight2, bias2)] along the channels as one launch per pass."""
+    return ConvFn.apply(x0, None, weight, bias, ConvCfg(**kw), weight2, bias2)
 
 
 class ThinConvFn(torch.autograd.Function):
@@ -244,6 +274,25 @@ class NormAct(torch.autograd.Function):
         x, mean, rstd, gamma, y = ctx.saved_tensors
         dx, dg, db = ops.norm_bwd(dy, y, x, mean, rstd, gamma, ctx.act)
         return dx, dg, db, None
+
+
+class SpadeNormFn(torch.autograd.Function):
+    """y = act(InstanceNorm2d(x) * (1 + gamma) + beta) with gb = gamma | beta (B,H,W,2C) as ONE tensor: the kernels read the halves in
+    place and the backward writes d(gamma | beta) in place - no slicing / concatenation kernels around the fused SPADE convolution."""
+
+    @staticmethod
+    def forward(ctx, x, gb, act):
+        gb = gb.contiguous()
+        y, mean, rstd = ops.norm_fwd(x, act=act, gb=gb)
+        ctx.act = act
+        ctx.save_for_backward(x.contiguous(), mean, rstd, gb, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gb, y = ctx.saved_tensors
+        dx, dgb, _ = ops.norm_bwd(dy, y, x, mean, rstd, act=ctx.act, gb=gb)
+        return dx, dgb, None
 
 
 def instance_norm(x, act=_NONE):
@@ -333,6 +382,9 @@ class TrainableGenerator(object):
             logits = (K * q.unsqueeze(1)).sum(dim=4, keepdim=True) / math.sqrt(C)
             x = (torch.softmax(logits, dim=1) * V).sum(dim=1)
         actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
+        if FUSED_SPADE_PAIR:
+            g, b = self.p(pfx + ".spade.mlp_gamma"), self.p(pfx + ".spade.mlp_beta")
+            return SpadeNormFn.apply(tsf_x, conv_pair(actv, g.weight, g.bias, b.weight, b.bias), _NONE)
         gamma = self.cv(pfx + ".spade.mlp_gamma", actv)
         beta = self.cv(pfx + ".spade.mlp_beta", actv)
         return NormAct.apply(tsf_x, gamma, beta, _NONE)

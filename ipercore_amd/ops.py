@@ -775,16 +775,26 @@ def _nsplit(hw):
     return max(1, min(64, hw // 64))
 
 
-def norm_fwd(x, gamma=None, beta=None, act=ACT_NONE, eps=1e-5):
-    """y = act(InstanceNorm(x) * (1 + gamma) + beta) on NHWC -> (y, mean, rstd)."""
+def _elem_ptr(t, off):
+    """Device address of element ``off`` of a contiguous fp32 tensor (the beta / dbeta half of a fused gamma | beta tensor)."""
+    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+
+
+def norm_fwd(x, gamma=None, beta=None, act=ACT_NONE, eps=1e-5, gb=None):
+    """y = act(InstanceNorm(x) * (1 + gamma) + beta) on NHWC -> (y, mean, rstd).
+    gb: (B,H,W,2C) = gamma | beta as ONE tensor (the output of the fused mlp_gamma | mlp_beta convolution) instead of gamma, beta."""
     B, H, W, C = x.shape
     x = x.contiguous()
     mean, rstd = x.new_empty(B, C), x.new_empty(B, C)
     ns = _nsplit(H * W)
     instnorm_stats(x, mean, rstd, x.new_empty(B * C * ns * 3), eps=eps, nsplit=ns)
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().lwg_norm_fwd_nhwc_f32(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(None if gamma is None else gamma.contiguous()),
-                                                 _ptr(None if beta is None else beta.contiguous()), B, H * W, C, act, _ptr(y),
+    if gb is not None:
+        assert gamma is None and beta is None and gb.is_contiguous() and gb.shape == (B, H, W, 2 * C)
+        gp, bp, gs = _ptr(gb), _elem_ptr(gb, C), 2 * C
+    else:
+        gp, bp, gs = _ptr(None if gamma is None else gamma.contiguous()), _ptr(None if beta is None else beta.contiguous()), 0
+    _lib.check(_lib.lib().lwg_norm_fwd_nhwc_f32(_ptr(x), _ptr(mean), _ptr(rstd), gp, bp, gs, B, H * W, C, act, _ptr(y),
                                                  _stream()), "lwg_norm_fwd_nhwc_f32")
     return y, mean, rstd
 
@@ -796,16 +806,21 @@ def _nsplit_bwd(hw, B, C):
     return max(1, min(per_image, hw // 32, 512))
 
 
-def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=ACT_NONE):
-    """Backward of norm_fwd -> (dx, dgamma, dbeta)."""
+def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=ACT_NONE, gb=None):
+    """Backward of norm_fwd -> (dx, dgamma, dbeta); with gb (the fused gamma | beta tensor) -> (dx, dgb (B,H,W,2C), None)."""
     B, H, W, C = x.shape
     dy = dy.contiguous()
     ns = _nsplit_bwd(H * W, B, C)
     dx = torch.empty_like(x)
+    ws = x.new_empty(B * (ns + 1) * C * 2)          # the split records + their fold
+    if gb is not None:
+        dgb = torch.empty_like(gb)
+        _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gb), 2 * C, B, H * W, C, act, ns,
+                                                     _ptr(dx), _ptr(dgb), _elem_ptr(dgb, C), _ptr(ws), _stream()), "lwg_norm_bwd_nhwc_f32")
+        return dx, dgb, None
     dg = torch.empty_like(x) if gamma is not None else None
     db = torch.empty_like(x) if gamma is not None else None
-    ws = x.new_empty(B * (ns + 1) * C * 2)          # the split records + their fold
-    _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), B, H * W, C, act, ns,
+    _lib.check(_lib.lib().lwg_norm_bwd_nhwc_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), 0, B, H * W, C, act, ns,
                                                  _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream()), "lwg_norm_bwd_nhwc_f32")
     return dx, dg, db
 

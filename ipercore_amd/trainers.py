@@ -195,9 +195,31 @@ class FlatAdam(object):
     buffer, so (a) the update is one HIP kernel (lwg_adam_step_f32) instead of a multi-tensor loop and (b) the data-parallel
     exchange all-reduces the gradient buffer in place - no flatten / unflatten copies."""
 
+    # parameters that run as ONE stacked convolution in the training step (training.conv_pair): the second one is placed right behind
+    # the first in the flat buffer, so cat([first, second]) is a VIEW of it (no per-step concatenation / panel re-registration)
+    PAIRS = ((".mlp_gamma.weight", ".mlp_beta.weight"), (".mlp_gamma.bias", ".mlp_beta.bias"))
+
+    @classmethod
+    def _ordered(cls, module):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        by_name = dict(named)
+        follower = {}                                    # first name -> second name
+        for a, b in cls.PAIRS:
+            for n, _ in named:
+                if n.endswith(a) and n[:-len(a)] + b in by_name:
+                    follower[n] = n[:-len(a)] + b
+        placed, out = set(follower.values()), []
+        for n, p in named:
+            if n in placed:
+                continue
+            out.append(p)
+            if n in follower:
+                out.append(by_name[follower[n]])
+        return out
+
     def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8):
         self.module, self.lr, self.betas, self.eps, self.t = module, lr, betas, eps, 0
-        params = [p for p in module.parameters() if p.requires_grad]
+        params = self._ordered(module)
         n = sum(p.numel() for p in params)
         n4 = (n + 3) // 4 * 4
         dev = params[0].device

@@ -306,15 +306,22 @@ def _norm_ref(x, mean, rstd, gamma, beta, act):
     return ACT[act](xn)
 
 
-def norm_fwd(x, gamma=None, beta=None, act=0, eps=1e-5):
-    """lwg_instnorm_stats + lwg_norm_fwd_nhwc_f32: y = act(IN(x) * (1 + gamma) + beta), biased variance."""
+def norm_fwd(x, gamma=None, beta=None, act=0, eps=1e-5, gb=None):
+    """lwg_instnorm_stats + lwg_norm_fwd_nhwc_f32: y = act(IN(x) * (1 + gamma) + beta), biased variance.  gb = gamma | beta fused."""
+    if gb is not None:
+        C = x.shape[3]
+        gamma, beta = gb[..., :C], gb[..., C:]
     v = x.reshape(x.shape[0], -1, x.shape[3])
     mean, rstd = v.mean(1), 1.0 / torch.sqrt(v.var(1, unbiased=False) + eps)
     return _norm_ref(x, mean, rstd, gamma, beta, act), mean, rstd
 
 
-def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=0):
+def norm_bwd(dy, y, x, mean, rstd, gamma=None, act=0, gb=None):
     """lwg_norm_bwd_nhwc_f32 by torch autograd through the same formula (statistics are functions of x)."""
+    if gb is not None:
+        C = x.shape[3]
+        dx, dg, db = norm_bwd(dy, y, x, mean, rstd, gb[..., :C].contiguous(), act)
+        return dx, torch.cat([dg, db], dim=3), None
     with torch.enable_grad():
         xr = x.detach().clone().requires_grad_(True)
         gr = None if gamma is None else gamma.detach().clone().requires_grad_(True)

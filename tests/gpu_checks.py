@@ -1911,6 +1911,16 @@ def check_train_ops():
         if spade:
             out[name]["dgamma"] = _cmp(gd.grad, gr.grad, 2e-5, "dgamma")
             out[name]["dbeta"] = _cmp(bd.grad, br.grad, 2e-5, "dbeta")
+            # the fused form (gamma | beta as ONE (B,H,W,2C) tensor, read / written in place): bitwise the two-tensor form
+            from ipercore_amd.networks.training import SpadeNormFn
+            x2 = x.to(DEV).requires_grad_(True)
+            gb = torch.cat([gm, bt], dim=3).to(DEV).requires_grad_(True)
+            y2 = SpadeNormFn.apply(x2, gb, act)
+            (y2 * g.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            assert torch.equal(y2, y) and torch.equal(x2.grad, xd.grad), "fused gamma | beta: y / dx differ from the two-tensor form"
+            assert torch.equal(gb.grad[..., :C], gd.grad) and torch.equal(gb.grad[..., C:], bd.grad), "fused gamma | beta: d(gamma | beta)"
+            out[name]["fused_gb"] = "bitwise"
     yv, dv = _rand((3, 5, 8), 910), _rand((3, 5, 8), 911)
     for act, f in ((ops.ACT_TANH, torch.tanh), (ops.ACT_SIGMOID, torch.sigmoid)):
         a = yv.clone().requires_grad_(True)
