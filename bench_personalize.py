@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--no-overlap-d", dest="overlap_d", action="store_false", help="D's forward / backward after Adam(G), not next to G's backward")
     ap.add_argument("--no-fused-convt", dest="fused_convt", action="store_false", help="lab: transposed-conv forwards as four parity launches")
     ap.add_argument("--no-fused-bias", dest="fused_bias", action="store_false", help="lab: bias gradients by the separate column-sum kernel")
+    ap.add_argument("--no-kv-pair", dest="kv_pair", action="store_false", help="lab: the fk / fv projections as two 1x1 convolutions")
     ap.add_argument("--no-spade-pair", dest="spade_pair", action="store_false", help="lab: SPADE's gamma / beta convolutions as two launches per pass")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     args = ap.parse_args()
@@ -263,6 +264,9 @@ def main():
     if not args.spade_pair:
         from ipercore_amd.networks import training as _tr
         _tr.FUSED_SPADE_PAIR = False
+    if not args.kv_pair:
+        from ipercore_amd.networks import training as _tr
+        _tr.FUSED_KV_PAIR = False
     if args.breakdown:
         return breakdown(dev, args.size)
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,

@@ -223,6 +223,14 @@ int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void* Vs, const 
 int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const float* Vs, const float* bk, const float* bv,
                               const float* T, const float* dout, float* dq, float* dKs, float* dVs, int B, int ns,
                               int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
+/* The fp32 block and its backward with K | V as ONE tensor kv (nsrc,h,w,2C), K = kv[..., :C], V = kv[..., C:]: the training step
+ * projects the source features with a single stacked fk | fv 1x1 convolution (attlwb_spade_resunet.py:226-227 are two) and these
+ * entry points read / accumulate the halves in place.  dkv (same shape) must be zero on entry. */
+int lwg_lwb_attention_kv_f32(const float* q, const float* kv, const float* bk, const float* bv, const float* T, float* out,
+                             int B, int ns, int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
+int lwg_lwb_attention_kv_bwd_f32(const float* q, const float* kv, const float* bk, const float* bv, const float* T,
+                                 const float* dout, float* dq, float* dkv, int B, int ns, int h, int w, int C, int S,
+                                 int src_batched, lwg_stream_t stream);
 /* The non-attention Liquid Warping Blocks (AddLWB / AvgLWB: generators/lwb_resunet.py:77-152; SoftGateLWB:
  * generators/lwb_softgate_resunet.py:77-123) as one gather kernel:
  *   out = (tsf_x + gate * scale_w * sum_s warp_s(src_x)) * scale_o        gate == NULL: 1

@@ -15,12 +15,16 @@
 // BUF: the K / V taps through raw buffer loads - an out-of-image tap gets an out-of-range offset and the hardware returns zeros, so the
 // eight gathers of a source are unconditional and in flight together (with per-tap branches each load waited for its own exec mask
 // and its own s_waitcnt); needs the K / V tensors below 3 GB (the launcher picks the pointer form otherwise).
-template <int LPP, bool BUF, int OCC>       // OCC: resident waves per SIMD the register allocation is held to (see csrc/bf16_ops.hip)
+// KVS: Ks / Vs rows are ``kvs`` floats apart instead of C (the two halves of ONE (nsrc,h,w,2C) tensor: the training step projects K | V
+// with a single stacked 1x1 convolution, lwg_lwb_attention_kv_f32); false: dense tensors, the stride a compile-time constant.
+template <int LPP, bool BUF, int OCC, bool KVS = false>       // OCC: resident waves per SIMD the register allocation is held to (see csrc/bf16_ops.hip)
 __global__ __launch_bounds__(256, OCC) void lwg_lwb_attn_kernel(const float* __restrict__ q, const float* __restrict__ Ks,
                                                           const float* __restrict__ Vs, const float* __restrict__ bk,
                                                           const float* __restrict__ bv, const float* __restrict__ T,
-                                                          float* __restrict__ out, int B, int ns, int h, int w, int S, int src_batched) {
+                                                          float* __restrict__ out, int B, int ns, int h, int w, int S, int src_batched,
+                                                          int kvs) {
     constexpr int C = 4 * LPP;
+    const int PS = KVS ? kvs : C;                // floats between consecutive pixels of Ks / Vs
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int cl = lane % LPP;
@@ -69,21 +73,21 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attn_kernel(const float* __r
         // clamp before the int conversion so wild flows cannot overflow; out-of-range taps are skipped anyway
         const int tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
         const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
-        const float* Kb = Ks + sidx * hw * C + 4 * cl;
-        const float* Vb = Vs + sidx * hw * C + 4 * cl;
+        const float* Kb = Ks + sidx * hw * PS + 4 * cl;
+        const float* Vb = Vs + sidx * hw * PS + 4 * cl;
         floatx4 ka = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
         if (BUF) {
             const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
-            const int nbytes = (int)(nsrc * (unsigned)hw * (unsigned)C * 4u);
+            const int nbytes = (int)(((nsrc * (unsigned)hw - 1u) * (unsigned)PS + (unsigned)C) * 4u);     // up to the last pixel's C channels
             __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, nbytes, 0x00020000);
             __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, nbytes, 0x00020000);
-            const unsigned sbase = ((unsigned)sidx * (unsigned)hw * (unsigned)C + 4u * (unsigned)cl) * 4u;
+            const unsigned sbase = ((unsigned)sidx * (unsigned)hw * (unsigned)PS + 4u * (unsigned)cl) * 4u;
             floatx4 k4[4], v4[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
                 const bool ok = ty >= 0 && ty < h && tx >= 0 && tx < w;
-                const unsigned voff = ok ? sbase + (unsigned)(ty * w + tx) * (unsigned)C * 4u : 0xC0000000u;
+                const unsigned voff = ok ? sbase + (unsigned)(ty * w + tx) * (unsigned)PS * 4u : 0xC0000000u;
                 k4[t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
                 v4[t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
             }
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attn_kernel(const float* __r
                 const int ty = ty0 + (t >> 1), tx = tx0 + (t & 1);
                 const float wt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);
                 if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
-                    const size_t off = ((size_t)ty * w + tx) * C;
+                    const size_t off = ((size_t)ty * w + tx) * PS;
                     const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
                     const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
 #pragma unroll
@@ -184,9 +188,9 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
         const long per_block = 4 * (64 / LPP);                                                                    \
         const dim3 grid((unsigned)((total + per_block - 1) / per_block));                                         \
         if (!buf_ok)                                                                                              \
-            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, false, 5>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched); \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, false, 5>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched, 0); \
         else                                                                                                      \
-            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, LWG_ATTN_OCC>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched);  \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, LWG_ATTN_OCC>), grid, dim3(256), 0, stream, q, Ks, Vs, bk, bv, T, out, B, ns, h, w, S, src_batched, 0);  \
     }
     switch (C) {
         case 32: LWG_ATTN_LAUNCH(8) break;
@@ -200,6 +204,34 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same block with K | V as ONE tensor kv (nsrc,h,w,2C): K = kv[..., :C], V = kv[..., C:] (the training step's stacked fk | fv
+// projection, networks/training.py attlwb): no slicing copies in front of the kernel.
+extern "C" int lwg_lwb_attention_kv_f32(const float* q, const float* kv, const float* bk, const float* bv, const float* T, float* out,
+                                        int B, int ns, int h, int w, int C, int S, int src_batched, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!q || !kv || !bk || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0 || S <= 0) return (int)hipErrorInvalidValue;
+    const long total = lwg_tile_frame_positions(B, h, w);
+    const bool buf_ok = (unsigned long long)(src_batched ? B * ns : ns) * (unsigned long long)h * w * (unsigned long long)C * 8ull < 0xC0000000ull;
+#define LWG_ATTN_KV_LAUNCH(LPP)                                                                                   \
+    {                                                                                                             \
+        const long per_block = 4 * (64 / LPP);                                                                    \
+        const dim3 grid((unsigned)((total + per_block - 1) / per_block));                                         \
+        if (!buf_ok)                                                                                              \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, false, 5, true>), grid, dim3(256), 0, stream, q, kv, kv + C, bk, bv, T, out, B, ns, h, w, S, src_batched, 2 * C); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((lwg_lwb_attn_kernel<LPP, true, LWG_ATTN_OCC, true>), grid, dim3(256), 0, stream, q, kv, kv + C, bk, bv, T, out, B, ns, h, w, S, src_batched, 2 * C);  \
+    }
+    switch (C) {
+        case 32: LWG_ATTN_KV_LAUNCH(8) break;
+        case 64: LWG_ATTN_KV_LAUNCH(16) break;
+        case 128: LWG_ATTN_KV_LAUNCH(32) break;
+        case 256: LWG_ATTN_KV_LAUNCH(64) break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LWG_ATTN_KV_LAUNCH
+    return (int)hipGetLastError();
+}
+
 // Backward of the attention-form Liquid Warping Block (personalization step).  Per pixel, with K_s = warp_s(Ks) + bk,
 // V_s = warp_s(Vs) + bv, l_s = K_s.q / sqrt(C), a = softmax_s(l), out = sum_s a_s V_s and upstream gradient g = dout:
 //   dV_s = a_s g                      da_s = g . V_s            dl_s = a_s (da_s - sum_j a_j da_j)
@@ -208,14 +240,15 @@ extern "C" int lwg_lwb_attention_f32(const float* q, const float* Ks, const floa
 //   dbv = sum_pixels g  (sum_s a_s = 1);   dbk = 0 exactly (a bias on every K shifts all logits of a pixel equally)
 // The flows are not differentiated (the reference computes them under no_grad, lwg_trainer.py:649-697).
 // One pixel per LPP = C/4 lanes, the gathers are recomputed instead of stored.  dKs / dVs must be zero on entry.
-template <int LPP>
+template <int LPP, bool KVS = false>
 __global__ __launch_bounds__(256) void lwg_lwb_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ Ks,
                                                               const float* __restrict__ Vs, const float* __restrict__ bk,
                                                               const float* __restrict__ bv, const float* __restrict__ T,
                                                               const float* __restrict__ dout, float* __restrict__ dq,
                                                               float* __restrict__ dKs, float* __restrict__ dVs, int B, int ns, int h,
-                                                              int w, int S, int src_batched) {
+                                                              int w, int S, int src_batched, int kvs) {
     constexpr int C = 4 * LPP;
+    const int PS = KVS ? kvs : C;                // floats between consecutive pixels of Ks / Vs / dKs / dVs
     constexpr int PPW = 64 / LPP;
     constexpr int MAXS = 8;   // sources + temporal frames per pixel kept in registers
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -266,15 +299,15 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bwd_kernel(const float* __re
         tx0s[s] = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
         ty0s[s] = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
         const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
-        const float* Kb = Ks + sidx * hw * C + 4 * cl;
-        const float* Vb = Vs + sidx * hw * C + 4 * cl;
+        const float* Kb = Ks + sidx * hw * PS + 4 * cl;
+        const float* Vb = Vs + sidx * hw * PS + 4 * cl;
         floatx4 ka = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ty = ty0s[s] + (t >> 1), tx = tx0s[s] + (t & 1);
             const float wt = ((t >> 1) ? wy1s[s] : wy0s[s]) * ((t & 1) ? wx1s[s] : wx0s[s]);
             if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
-                const size_t off = ((size_t)ty * w + tx) * C;
+                const size_t off = ((size_t)ty * w + tx) * PS;
                 const floatx4 k4 = *reinterpret_cast<const floatx4*>(Kb + off);
                 const floatx4 v4 = *reinterpret_cast<const floatx4*>(Vb + off);
 #pragma unroll
@@ -309,14 +342,14 @@ __global__ __launch_bounds__(256) void lwg_lwb_attn_bwd_kernel(const float* __re
         for (int k = 0; k < 4; ++k) dq4[k] += dl * kf[s][k];
         if (!live) continue;
         const size_t sidx = src_batched ? (size_t)b * ns + s : (size_t)s;
-        float* dKb = dKs + sidx * hw * C + 4 * cl;
-        float* dVb = dVs + sidx * hw * C + 4 * cl;
+        float* dKb = dKs + sidx * hw * PS + 4 * cl;
+        float* dVb = dVs + sidx * hw * PS + 4 * cl;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ty = ty0s[s] + (t >> 1), tx = tx0s[s] + (t & 1);
             const float wt = ((t >> 1) ? wy1s[s] : wy0s[s]) * ((t & 1) ? wx1s[s] : wx0s[s]);
             if (ty >= 0 && ty < h && tx >= 0 && tx < w) {
-                const size_t off = ((size_t)ty * w + tx) * C;
+                const size_t off = ((size_t)ty * w + tx) * PS;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     atomicAdd(dKb + off + k, wt * dl * q4[k]);
@@ -340,7 +373,7 @@ extern "C" int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const 
     {                                                                                                                 \
         const long per_block = 4 * (64 / LPP);                                                                        \
         hipLaunchKernelGGL(lwg_lwb_attn_bwd_kernel<LPP>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
-                           stream, q, Ks, Vs, bk, bv, T, dout, dq, dKs, dVs, B, ns, h, w, S, src_batched);                    \
+                           stream, q, Ks, Vs, bk, bv, T, dout, dq, dKs, dVs, B, ns, h, w, S, src_batched, 0);                    \
     }
     switch (C) {
         case 32: LWG_ATTN_BWD_LAUNCH(8) break;
@@ -350,6 +383,31 @@ extern "C" int lwg_lwb_attention_bwd_f32(const float* q, const float* Ks, const 
         default: return (int)hipErrorInvalidValue;
     }
 #undef LWG_ATTN_BWD_LAUNCH
+    return (int)hipGetLastError();
+}
+
+// Backward with K | V as one tensor kv (nsrc,h,w,2C): d(kv) is ACCUMULATED into dkv of the same shape (zero it first).
+extern "C" int lwg_lwb_attention_kv_bwd_f32(const float* q, const float* kv, const float* bk, const float* bv, const float* T,
+                                            const float* dout, float* dq, float* dkv, int B, int ns, int h, int w, int C, int S,
+                                            int src_batched, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!q || !kv || !bk || !bv || !T || !dout || !dq || !dkv || B <= 0 || ns <= 0 || ns > 8 || h <= 0 || w <= 0 || S <= 0)
+        return (int)hipErrorInvalidValue;
+    const long total = (long)B * h * w;
+#define LWG_ATTN_KV_BWD_LAUNCH(LPP)                                                                                   \
+    {                                                                                                                 \
+        const long per_block = 4 * (64 / LPP);                                                                        \
+        hipLaunchKernelGGL((lwg_lwb_attn_bwd_kernel<LPP, true>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, \
+                           stream, q, kv, kv + C, bk, bv, T, dout, dq, dkv, dkv + C, B, ns, h, w, S, src_batched, 2 * C);             \
+    }
+    switch (C) {
+        case 32: LWG_ATTN_KV_BWD_LAUNCH(8) break;
+        case 64: LWG_ATTN_KV_BWD_LAUNCH(16) break;
+        case 128: LWG_ATTN_KV_BWD_LAUNCH(32) break;
+        case 256: LWG_ATTN_KV_BWD_LAUNCH(64) break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef LWG_ATTN_KV_BWD_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ class ConvCfg(object):
         self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
 
 
+FUSED_KV_PAIR = True        # lab switch: False = the fk / fv projections of an attention site as two 1x1 convolutions
 FUSED_SPADE_PAIR = True     # lab switch: False = SPADE's mlp_gamma / mlp_beta as two convolutions (two launches per pass + gradient add)
 FUSED_BIAS_GRAD = True      # lab switch: False = bias gradients by the separate column-sum kernel
 FUSED_CONVT_FWD = True      # lab switch: False = four parity launches (split-K where the library plans it)
@@ -320,6 +321,26 @@ class AttnFn(torch.autograd.Function):
         return dq, dKs, dVs, dbk, dbv, None
 
 
+class AttnKVFn(torch.autograd.Function):
+    """``AttnFn`` with K | V as ONE tensor kv (B*ns,h,w,2C) - the output of the stacked fk | fv projection (``conv_pair``) - read and
+    differentiated in place (lwg_lwb_attention_kv_f32 / _kv_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, bk, bv, T):
+        q, kv, T = q.contiguous(), kv.contiguous(), T.contiguous()
+        out = ops.lwb_attention_kv(q, kv, bk, bv, T, torch.empty_like(q), src_batched=True)
+        ctx.save_for_backward(q, kv, bk, bv, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, bk, bv, T = ctx.saved_tensors
+        dq, dkv = ops.lwb_attention_kv_bwd(q, kv, bk, bv, T, dout, src_batched=True)
+        dbv = ops.colsum(dout) if ctx.needs_input_grad[3] else None
+        dbk = torch.zeros_like(bk) if ctx.needs_input_grad[2] else None
+        return dq, dkv, dbk, dbv, None
+
+
 class MaxPool2Fn(torch.autograd.Function):
     """nn.MaxPool2d(2, 2) on NHWC (csrc/train_ops.hip)."""
 
@@ -370,7 +391,10 @@ class TrainableGenerator(object):
         h, w, C = tsf_x.shape[1:]
         fk, fv = self.p(pfx + ".fk"), self.p(pfx + ".fv")
         q = self.cv(pfx + ".fq", tsf_x, pad=0)
-        if self.fused_attention:
+        if self.fused_attention and FUSED_KV_PAIR:
+            # ... and the two projections are ONE stacked 1x1 convolution (K | V along the channels), gathered in place by the kernel
+            x = AttnKVFn.apply(q, conv_pair(src_x, fk.weight, None, fv.weight, None, pad=0), fk.bias, fv.bias, Tst)
+        elif self.fused_attention:
             # a 1x1 conv commutes with the zero-padded warp: project the source features, warp inside the kernel
             Ks = conv(src_x, fk.weight, None, pad=0)
             Vs = conv(src_x, fv.weight, None, pad=0)

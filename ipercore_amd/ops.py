@@ -379,6 +379,28 @@ def lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=False):
     return dq, dKs, dVs
 
 
+def lwb_attention_kv(q, kv, bk, bv, T, out, src_batched=False):
+    """``lwb_attention`` with K | V as one tensor kv (nsrc,h,w,2C) (the stacked fk | fv projection of the training step)."""
+    B, h, w, C = q.shape
+    ns, S = T.shape[1], T.shape[2]
+    assert T.shape[0] == B and kv.shape[0] == (B * ns if src_batched else ns) and tuple(kv.shape[1:]) == (h, w, 2 * C)
+    _lib.check(_lib.lib().lwg_lwb_attention_kv_f32(_ptr(q), _ptr(kv), _ptr(bk), _ptr(bv), _ptr(T), _ptr(out), B, ns, h, w, C, S,
+                                                    1 if src_batched else 0, _stream()), "lwg_lwb_attention_kv_f32")
+    return out
+
+
+def lwb_attention_kv_bwd(q, kv, bk, bv, T, dout, src_batched=False):
+    """Gradients of ``lwb_attention_kv`` w.r.t. q and kv -> (dq, dkv)."""
+    B, h, w, C = q.shape
+    ns, S = T.shape[1], T.shape[2]
+    dout = dout.contiguous()
+    dq = torch.empty_like(q)
+    dkv = torch.zeros_like(kv)
+    _lib.check(_lib.lib().lwg_lwb_attention_kv_bwd_f32(_ptr(q), _ptr(kv), _ptr(bk), _ptr(bv), _ptr(T), _ptr(dout), _ptr(dq), _ptr(dkv),
+                                                        B, ns, h, w, C, S, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_kv_bwd_f32")
+    return dq, dkv
+
+
 def project_faces(verts, cam, faces, want_faces_v=True, want_f2pts=True):
     B, nv, _ = verts.shape
     nf = faces.shape[0]

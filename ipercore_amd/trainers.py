@@ -197,7 +197,7 @@ class FlatAdam(object):
 
     # parameters that run as ONE stacked convolution in the training step (training.conv_pair): the second one is placed right behind
     # the first in the flat buffer, so cat([first, second]) is a VIEW of it (no per-step concatenation / panel re-registration)
-    PAIRS = ((".mlp_gamma.weight", ".mlp_beta.weight"), (".mlp_gamma.bias", ".mlp_beta.bias"))
+    PAIRS = ((".mlp_gamma.weight", ".mlp_beta.weight"), (".mlp_gamma.bias", ".mlp_beta.bias"), (".fk.weight", ".fv.weight"))
 
     @classmethod
     def _ordered(cls, module):

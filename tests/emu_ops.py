@@ -341,6 +341,17 @@ def lwb_attention_bwd(q, Ks, Vs, bk, bv, T, dout, src_batched=False):
         return torch.autograd.grad(out, [qr, kr, vr], dout)
 
 
+def lwb_attention_kv(q, kv, bk, bv, T, out, src_batched=False):
+    C = q.shape[3]
+    return lwb_attention(q, kv[..., :C].contiguous(), kv[..., C:].contiguous(), bk, bv, T, out, src_batched=src_batched)
+
+
+def lwb_attention_kv_bwd(q, kv, bk, bv, T, dout, src_batched=False):
+    C = q.shape[3]
+    dq, dk, dv = lwb_attention_bwd(q, kv[..., :C].contiguous(), kv[..., C:].contiguous(), bk, bv, T, dout, src_batched=src_batched)
+    return dq, torch.cat([dk, dv], dim=3)
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
     """lwg_adam_step_f32 = torch.optim.Adam's update (no weight decay, no amsgrad)."""
     m.mul_(beta1).add_(g, alpha=1 - beta1)
@@ -385,7 +396,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

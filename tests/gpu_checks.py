@@ -1968,6 +1968,22 @@ def check_attention_backward():
         y = AttnFn.apply(txd @ Wqd.t() + bqd, xd @ Wkd.t(), xd @ Wvd.t(), bkd, bvd, T.to(DEV))
         (y * g.to(DEV)).sum().backward()
         torch.cuda.synchronize()
+        # the K | V-in-one-tensor form of the training step (AttnKVFn): same gathers at a 2C pixel stride -> the forward bitwise, the
+        # backward up to the order of the scatter atomics
+        from ipercore_amd.networks.training import AttnKVFn
+        with torch.no_grad():
+            q0, k0, v0 = (txd @ Wqd.t() + bqd), xd @ Wkd.t(), xd @ Wvd.t()
+        q1, kv1 = q0.clone().requires_grad_(True), torch.cat([k0, v0], dim=3).requires_grad_(True)
+        q2, k2, v2 = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+        y1 = AttnKVFn.apply(q1, kv1, bkd.detach(), bvd.detach(), T.to(DEV))
+        y2 = AttnFn.apply(q2, k2, v2, bkd.detach(), bvd.detach(), T.to(DEV))
+        (y1 * g.to(DEV)).sum().backward()
+        (y2 * g.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2), name + ": K | V form forward differs"
+        sc = max(k2.grad.abs().max().item(), v2.grad.abs().max().item())
+        for a_, b_ in ((q1.grad, q2.grad), (kv1.grad[..., :C], k2.grad), (kv1.grad[..., C:], v2.grad)):
+            assert (a_ - b_).abs().max().item() <= 1e-5 * max(sc, b_.abs().max().item()), name + ": K | V form backward differs"
         m = {"y": _cmp(y, yr, 3e-4, name + " y")}   # q / Ks / Vs come from GPU matmuls here
         gmax = max(t.grad.abs().max().item() for t in leaves)
         for nm, a_, b_ in zip(("x", "tx", "Wq", "Wk", "Wv", "bq", "bk", "bv"), dl, leaves):
