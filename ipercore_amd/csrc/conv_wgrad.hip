@@ -414,6 +414,50 @@ __global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4_kernel(const floa
     }
 }
 
+// The same with G lanes per quad (lane g adds slabs g, g + G, ...; fixed-order LDS pass over the G partial sums): medium-sized gradients
+// reduced over many slabs (a transposed convolution's parity launch: 32 K quads x 64 - 128 slabs) gave the one-lane form 64 - 128
+// workgroups, each thread walking every slab (8 us); G = 4 / 8 puts 4 - 8x the loads in flight.
+template <int G>
+__global__ __launch_bounds__(256) void lwg_slab_reduce_unpack4g_kernel(const float* __restrict__ part, int nsplit, size_t slab, size_t total4,
+                                                                       const LwgUnpackMap u, float* __restrict__ out, float* __restrict__ db) {
+    constexpr int EPB = 256 / G;
+    __shared__ floatx4 sh[256];
+    const int e = threadIdx.x % EPB, g = threadIdx.x / EPB;
+    const int nq = u.nout >> 2;
+    const size_t i4 = (size_t)blockIdx.x * EPB + e;
+    const bool live = i4 < total4;
+    const int n = live ? (int)(i4 % nq) * 4 : 0, r = live ? (int)(i4 / nq) : 0;
+    const bool bias = r >= u.ntaps * u.cin;
+    const int c = r % u.cin, tap = bias ? 0 : r / u.cin;
+    const int k = bias ? u.ntaps * u.cin_pad : ((u.cin_pad & 31) == 0 ? ((c >> 5) * u.ntaps + tap) * 32 + (c & 31) : tap * u.cin_pad + c);
+    const float* src = part + (size_t)k * u.n_pad + n;
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        int kk = g;
+        for (; kk + G < nsplit; kk += 2 * G) {
+            const floatx4 v0 = *reinterpret_cast<const floatx4*>(src + (size_t)kk * slab);
+            const floatx4 v1 = *reinterpret_cast<const floatx4*>(src + (size_t)(kk + G) * slab);
+            s += v0; s += v1;
+        }
+        if (kk < nsplit) s += *reinterpret_cast<const floatx4*>(src + (size_t)kk * slab);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (g != 0 || !live) return;
+    floatx4 t = sh[e];
+#pragma unroll
+    for (int j = 1; j < G; ++j) t += sh[j * EPB + e];
+    if (bias) {
+        *reinterpret_cast<floatx4*>(db + n) = t;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t dst = ((size_t)(u.transposed ? c : n + j) * u.D1 + (u.transposed ? n + j : c)) * u.KHW + u.kidx[tap];
+        out[dst] = t[j];
+    }
+}
+
 // total: weight elements (ntaps * cin * nout); db != NULL appends the nout bias-gradient elements (slab row Ktot) to the same launch
 static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t slab, size_t total, const LwgUnpackMap& u, float* out, float* db,
                                           hipStream_t stream) {
@@ -421,6 +465,13 @@ static void lwg_launch_slab_reduce_unpack(const float* part, int nsplit, size_t 
     if (db) total += (size_t)u.nout;
     if (weights >= 65536 && (u.nout & 3) == 0 && (u.n_pad & 3) == 0 && (slab & 3) == 0) {
         const size_t total4 = total / 4;
+        if (total4 < 65536 && nsplit >= 32) {        // few quads, many slabs: several lanes per quad
+            if (nsplit >= 64)
+                hipLaunchKernelGGL(lwg_slab_reduce_unpack4g_kernel<8>, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, stream, part, nsplit, slab, total4, u, out, db);
+            else
+                hipLaunchKernelGGL(lwg_slab_reduce_unpack4g_kernel<4>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, stream, part, nsplit, slab, total4, u, out, db);
+            return;
+        }
         const unsigned blocks = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(lwg_slab_reduce_unpack4_kernel, dim3(blocks), dim3(256), 0, stream, part, nsplit, slab, total4, u, out, db);
         return;
@@ -491,7 +542,8 @@ static int lwg_wgrad_splits(int Ktot, int N, int M) {
     if ((long)splits * slab > (48l << 20)) splits = (int)((48l << 20) / slab);     // <= 48 MB of slabs per launch
     if (splits > nchunks / 4) splits = nchunks / 4;
     if (splits < 1) splits = 1;
-    return splits;
+    const int cps = (nchunks + splits - 1) / splits;          // chunks per workgroup; drop the splits that would get none
+    return (nchunks + cps - 1) / cps;                          // (128 chunks over 14 splits: 10 each -> 13 workgroups have work)
 }
 
 extern "C" size_t lwg_conv2d_wgrad_ws_floats(int Ktot, int N, int M) {
