@@ -38,6 +38,10 @@ int lwg_abi_version(void);
 #define LWG_MAX_TAPS 52
 enum { LWG_EPI_NONE = 0, LWG_EPI_RESIDUAL = 1, LWG_EPI_SPADE = 2 };
 enum { LWG_ACTIVATION_NONE = 0, LWG_ACTIVATION_RELU = 1, LWG_ACTIVATION_TANH = 2, LWG_ACTIVATION_SIGMOID = 3 };
+/* fp32 launches with LWG_EPI_RESIDUAL only: y = res > 0 ? acc + bias : 0.  The data gradient of a convolution whose forward input was
+ * relu(...) (res = that input): the ReLU backward of the producing layer rides in the epilogue that writes its output gradient
+ * (torch autograd runs it as a separate threshold_backward pass, lwg_trainer.py:326-352 loss.backward()). */
+#define LWG_ACTIVATION_RELU_MASK 5
 enum { LWG_DT_F32 = 0, LWG_DT_BF16 = 1 };   /* activation storage type (BASELINE configs[3]: bf16 activations end to end) */
 
 typedef struct LwgConvArgs {
@@ -59,7 +63,7 @@ typedef struct LwgConvArgs {
     int omul, ooy, oox;
     int epi;           /* LWG_EPI_* */
     int act;           /* LWG_ACTIVATION_* applied last */
-    const float* res;  /* LWG_EPI_RESIDUAL: tensor shaped like y, added before the activation */
+    const float* res;  /* LWG_EPI_RESIDUAL: tensor shaped like y, added before the activation (LWG_ACTIVATION_RELU_MASK: the mask source) */
     const float* xn;   /* LWG_EPI_SPADE: tensor to normalise (B,YH,YW,YC) */
     const float* mean; /* LWG_EPI_SPADE: (B,YC) instance mean   */
     const float* rstd; /* LWG_EPI_SPADE: (B,YC) 1/sqrt(var+eps) */

@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg_hip.h")
 LWG_MAX_TAPS = 52
 EPI_NONE, EPI_RESIDUAL, EPI_SPADE = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_LRELU = 0, 1, 2, 3, 4
+ACT_RELU_MASK = 5       # conv launches with EPI_RESIDUAL only: y = res > 0 ? acc + bias : 0 (include/lwg_hip.h)
 DT_F32, DT_BF16 = 0, 1
 
 c_f = ctypes.c_void_p  # device pointers travel as void*

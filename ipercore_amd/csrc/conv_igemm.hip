@@ -424,11 +424,17 @@ __global__ __launch_bounds__(256) void lwg_splitk_finish_kernel(const LwgConvArg
 #pragma unroll
             for (int c = 0; c < 4; ++c) s[c] += b4[c];
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] = lwg_act(s[c], a.act);
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / a.OW, ox = rem - oy * a.OW;
         const size_t opix = ((size_t)b * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox);
+        if (a.act == LWG_ACT_RELU_MASK) {            // ReLU backward of the producer of the forward input (see lwg_common.h)
+            const floatx4 rv = *reinterpret_cast<const floatx4*>(a.res + opix * a.YC + a.ycoff + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] = rv[c] > 0.f ? s[c] : 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] = lwg_act(s[c], a.act);
+        }
         *reinterpret_cast<floatx4*>(a.y + opix * a.YC + a.ycoff + n) = s;
     }
 }
@@ -439,7 +445,8 @@ __global__ __launch_bounds__(256) void lwg_splitk_finish_kernel(const LwgConvArg
 // together, so the L2-friendly tap-minor K order is kept) with at least 8 K-steps each.
 static int lwg_conv_split_plan(const LwgConvArgs& a, int* chunks_per_slice) {
     const int Cin = a.C0 + a.C1;
-    if (!LWG_CONV_SPLITK || a.epi != LWG_EPI_NONE || (Cin % 32) != 0) return 0;
+    const bool mask = a.epi == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK;     // finished by lwg_splitk_finish_kernel like LWG_EPI_NONE
+    if (!LWG_CONV_SPLITK || (a.epi != LWG_EPI_NONE && !mask) || (Cin % 32) != 0) return 0;
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (tiles128 >= 300) return 0;                              // not the 64x64 regime (launch_epi)
     const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
@@ -542,8 +549,13 @@ extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stre
     }
     if (a.epi == LWG_EPI_RESIDUAL) {
         if (!a.res || smallc) return (int)hipErrorInvalidValue;
+        if (a.act == LWG_ACT_RELU_MASK && ws) {
+            int cps = 0;
+            if (lwg_conv_split_plan(a, &cps) > 1) return (int)launch_epi<LWG_EPI_NONE, false>(a, stream, ws);   // slabs + the masking finish kernel
+        }
         return (int)launch_epi<LWG_EPI_RESIDUAL, false>(a, stream);
     }
+    if (a.act == LWG_ACT_RELU_MASK) return (int)hipErrorInvalidValue;
     if (a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
     return smallc ? (int)launch_epi<LWG_EPI_NONE, true>(a, stream) : (int)launch_epi<LWG_EPI_NONE, false>(a, stream, ws);
 }

@@ -53,6 +53,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // Activation codes shared by the C ABI (include/lwg_hip.h) and the kernels.
 enum { LWG_ACT_NONE = 0, LWG_ACT_RELU = 1, LWG_ACT_TANH = 2, LWG_ACT_SIGMOID = 3 };
+// With LWG_EPI_RESIDUAL only: y = res > 0 ? acc + bias : 0 - the ReLU backward of the layer that PRODUCED the conv's forward input,
+// applied where a data gradient is written (training step: dX of a conv whose input was relu(...); res = that forward input).
+#define LWG_ACT_RELU_MASK 5
 
 __device__ __forceinline__ float lwg_act(float v, int act) {
     if (act == LWG_ACT_RELU) return v > 0.f ? v : 0.f;

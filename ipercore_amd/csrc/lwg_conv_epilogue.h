@@ -70,7 +70,10 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                     floatx4 rv = floatx4{0.f, 0.f, 0.f, 0.f};
                     if (EPI == LWG_EPI_RESIDUAL) rv = *reinterpret_cast<const floatx4*>(rr + 32 * j + 8 * g);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c] + rv[c], a.act);
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = acc[i][j][4 * g + c] + bias4[j][g][c];
+                        o[c] = (EPI == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK) ? (rv[c] > 0.f ? v : 0.f) : lwg_act(v + rv[c], a.act);
+                    }
                     if (EPI == LWG_EPI_NONE && a.ydt == LWG_DT_BF16) {      // first layer of the bf16 mode: fp32 in, bf16 NHWC out
                         typedef __bf16 lwg_bf16x4 __attribute__((ext_vector_type(4)));
                         lwg_bf16x4 ob;

@@ -34,10 +34,15 @@ class ConvCfg(object):
     """Static description of one layer: kind ('conv' | 'convT'), stride, pad, fused act (0 none, 1 relu),
     zero-extension of input channels (cin_pad) / output channels (n_pad) to what the kernels need."""
 
-    def __init__(self, kind="conv", stride=1, pad=None, act=_NONE, cin_pad=None, n_pad=None, need_dx=True):
+    def __init__(self, kind="conv", stride=1, pad=None, act=_NONE, cin_pad=None, n_pad=None, need_dx=True, mask_dx=False, premasked=False):
         self.kind, self.stride, self.pad, self.act, self.cin_pad, self.n_pad, self.need_dx = kind, stride, pad, act, cin_pad, n_pad, need_dx
+        # A ReLU layer whose output feeds exactly ONE convolution: that convolution (mask_dx=True) applies the ReLU backward where it
+        # writes its data gradient (dX = x0 > 0 ? ... : 0 in the launch's epilogue), and the ReLU layer (premasked=True) skips its own
+        # act_bwd pass.  The two flags are set together by the wiring (TrainableGenerator); check_generator_training_grads pins them.
+        self.mask_dx, self.premasked = mask_dx and FUSED_RELU_MASK, premasked and FUSED_RELU_MASK
 
 
+FUSED_RELU_MASK = True      # lab switch: False = every ReLU convolution runs its own act_bwd pass
 FUSED_KV_PAIR = True        # lab switch: False = the fk / fv projections of an attention site as two 1x1 convolutions
 FUSED_SPADE_PAIR = True     # lab switch: False = SPADE's mlp_gamma / mlp_beta as two convolutions (two launches per pass + gradient add)
 FUSED_BIAS_GRAD = True      # lab switch: False = bias gradients by the separate column-sum kernel
@@ -113,7 +118,7 @@ class ConvFn(torch.autograd.Function):
             full = dy.new_zeros(dy.shape[0], dy.shape[1], dy.shape[2], Np)
             full[..., :N] = dy
             dy = full
-        if cfg.act == _RELU:
+        if cfg.act == _RELU and not cfg.premasked:
             dy = ops.act_bwd(dy, y, ops.ACT_RELU)
         dev = dy.device
         C0 = x0.shape[3]
@@ -143,9 +148,13 @@ class ConvFn(torch.autograd.Function):
                 dspecs = [packing.spec_to(s, dev) for s in packing.pack_dgrad_conv(weight, cfg.stride, pad, n_pad=Np, cin_pad=Cd)]
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cd, device=dev, dtype=torch.float32)
-                if cfg.stride == 1:
+                if cfg.stride == 1 and cfg.mask_dx:
+                    assert Cd == C0 and x1 is None, "mask_dx: the data gradient must have exactly the forward input's channels"
+                    ops.conv2d(dy, dspecs[0], dx, epi=ops.EPI_RESIDUAL, act=ops.ACT_RELU_MASK, res=x0, splitk=True)
+                elif cfg.stride == 1:
                     ops.conv2d(dy, dspecs[0], dx, splitk=True)
                 else:
+                    assert not cfg.mask_dx
                     for s in dspecs:             # one launch per input parity (py, px): rows py, py + 2, .. < H - ceil for odd sizes
                         ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
         else:
@@ -155,7 +164,10 @@ class ConvFn(torch.autograd.Function):
                 dspec = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev)
                 B, H, W, _ = x0.shape
                 dx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
-                ops.conv2d(dy, dspec, dx, splitk=True)
+                if cfg.mask_dx:
+                    ops.conv2d(dy, dspec, dx, epi=ops.EPI_RESIDUAL, act=ops.ACT_RELU_MASK, res=x0, splitk=True)
+                else:
+                    ops.conv2d(dy, dspec, dx, splitk=True)
         dx0 = dx1 = None
         if dx is not None:
             dx0 = dx[..., :C0] if (ctx.has_x1 or dx.shape[3] != C0) else dx
@@ -405,16 +417,17 @@ class TrainableGenerator(object):
             V = self.cv(pfx + ".fv", warp, pad=0).view(bs, ns, h, w, C)
             logits = (K * q.unsqueeze(1)).sum(dim=4, keepdim=True) / math.sqrt(C)
             x = (torch.softmax(logits, dim=1) * V).sum(dim=1)
-        actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
-        if FUSED_SPADE_PAIR:
+        if FUSED_SPADE_PAIR:         # mlp_shared's ReLU output feeds only the stacked gamma | beta convolution: its mask rides in that dgrad
+            actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU, premasked=True)
             g, b = self.p(pfx + ".spade.mlp_gamma"), self.p(pfx + ".spade.mlp_beta")
-            return SpadeNormFn.apply(tsf_x, conv_pair(actv, g.weight, g.bias, b.weight, b.bias), _NONE)
+            return SpadeNormFn.apply(tsf_x, conv_pair(actv, g.weight, g.bias, b.weight, b.bias, mask_dx=True), _NONE)
+        actv = self.cv(pfx + ".spade.mlp_shared.0", x, act=_RELU)
         gamma = self.cv(pfx + ".spade.mlp_gamma", actv)
         beta = self.cv(pfx + ".spade.mlp_beta", actv)
         return NormAct.apply(tsf_x, gamma, beta, _NONE)
 
     def res_block(self, pfx, x):
-        return x + self.cv(pfx + ".main.2", self.cv(pfx + ".main.0", x, act=_RELU))
+        return x + self.cv(pfx + ".main.2", self.cv(pfx + ".main.0", x, act=_RELU, premasked=True), mask_dx=True)
 
     def head(self, img_name, att_name, x):
         """The two 5x5 regressors with their tanh / sigmoid: one fused launch (``HeadFn``); NHWC views of its NCHW outputs."""
@@ -460,7 +473,8 @@ class TrainableGenerator(object):
             if side is not None:
                 x.record_stream(side)
             for i in range(self.n_down):
-                x = self.cv(f"src_net.decoders.layers.{i}.0", x, kind="convT", act=_RELU)
+                # a decoder layer's ReLU output feeds only the next layer: that layer's data gradient carries the mask
+                x = self.cv(f"src_net.decoders.layers.{i}.0", x, kind="convT", act=_RELU, mask_dx=i > 0, premasked=i < self.n_down - 1)
             img, mask = self.head("src_net.img_reg.0", "src_net.att_reg.0", x)
         return enc, res, img, mask
 
@@ -475,9 +489,9 @@ class TrainableGenerator(object):
             x = self.res_block(f"res_blocks.{i}", x)
             x = self.attlwb(f"res_attlwbs.{i}", x, res_src[i], Tst)
         for i in range(self.n_down):
-            x = self.cv(f"tsf_net_dec.upconvs.{i}.0", x, kind="convT", act=_RELU)
+            x = self.cv(f"tsf_net_dec.upconvs.{i}.0", x, kind="convT", act=_RELU, mask_dx=i > 0)      # input: the skipper's ReLU output
             if i != self.n_down - 1:
-                x = self.cv(f"tsf_net_dec.skippers.{i}.0", enc[self.n_down - 2 - i], x1=x, act=_RELU)
+                x = self.cv(f"tsf_net_dec.skippers.{i}.0", enc[self.n_down - 2 - i], x1=x, act=_RELU, premasked=True)
         return self.head("tsf_img_reg.0", "tsf_att_reg.0", x)
 
     def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst):

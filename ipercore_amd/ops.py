@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EPI_NONE, EPI_RESIDUAL, EPI_SPADE  # noqa: F401
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU_MASK, ACT_SIGMOID, ACT_TANH, EPI_NONE, EPI_RESIDUAL, EPI_SPADE  # noqa: F401
 
 EYE_DIST = 2.7320508075688776   # 1/tan(30 deg) + 1 (reference renders/nmr.py:225)
 

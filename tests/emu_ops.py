@@ -64,6 +64,9 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
         return y
     if spec.bias is not None:
         acc = acc + spec.bias
+    if epi == real_ops.EPI_RESIDUAL and act == real_ops.ACT_RELU_MASK:       # the ReLU backward of the producer of the forward input
+        y[:, ys, xs, ycoff:ycoff + spec.N] = acc * (res[:, ys, xs, ycoff:ycoff + spec.N] > 0).float()
+        return y
     if epi == real_ops.EPI_RESIDUAL:
         acc = acc + res[:, ys, xs, ycoff:ycoff + spec.N]
     y[:, ys, xs, ycoff:ycoff + spec.N] = ACT[act](acc)

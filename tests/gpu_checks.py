@@ -96,6 +96,21 @@ def check_conv_variants():
     assert out["4x4_s2_256_512_D"]["splitk_slices"] == 8 and out["4x4_s1_512_512_D"]["splitk_slices"] == 8, out
     assert out["3x3_res_256"]["splitk_slices"] == 4 and out["3x3_concat"]["splitk_slices"] == 6, out      # the concat case crosses x0 | x1
     assert out["3x3_unsplit_64x64_tiles"]["splitk_slices"] == 0 and out["3x3_residual"]["splitk_slices"] == 0, out
+    # ACT_RELU_MASK (y = res > 0 ? acc + bias : 0, the fused ReLU backward of the training step's data gradients): bitwise the plain
+    # launch times the mask, on the split-K path (finish kernel), the 64x64-tile epilogue and the 128x128-tile epilogue
+    for tag, (B, H, W, Cin, N, splitk) in (("mask_splitk", (1, 64, 64, 256, 256, True)), ("mask_64", (1, 64, 64, 128, 512, True)),
+                                           ("mask_128", (6, 64, 64, 64, 128, False)), ("mask_tail", (3, 9, 7, 64, 64, True))):
+        w = _rand((N, Cin, 3, 3), 110, 1.0 / np.sqrt(9 * Cin))
+        spec = _spec_dev(packing.pack_conv(w, _rand((N,), 111, 0.1)))
+        x, res = _rand((B, H, W, Cin), 112).to(DEV), _rand((B, H, W, N), 113).to(DEV)
+        y0, y1 = torch.empty(B, H, W, N, device=DEV), torch.empty(B, H, W, N, device=DEV)
+        ops.conv2d(x, spec, y0, splitk=splitk)
+        ops.conv2d(x, spec, y1, epi=ops.EPI_RESIDUAL, act=ops.ACT_RELU_MASK, res=res, splitk=splitk)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0 * (res > 0).float()), tag
+        a = ops.conv_args(x, spec, y1, epi=ops.EPI_RESIDUAL, act=ops.ACT_RELU_MASK, res=res)
+        out[tag] = {"splitk_ws_floats": int(_lib.lib().lwg_conv2d_ws_floats(a)) if splitk else 0}
+    assert out["mask_splitk"]["splitk_ws_floats"] > 0 and out["mask_64"]["splitk_ws_floats"] == 0, out
     return out
 
 
