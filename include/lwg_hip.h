@@ -26,7 +26,8 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-#define LWG_ABI_VERSION 2
+/* 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
+#define LWG_ABI_VERSION 3
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
