@@ -451,7 +451,7 @@ static int lwg_conv_split_plan(const LwgConvArgs& a, int* chunks_per_slice) {
     if (tiles128 >= 300) return 0;                              // not the 64x64 regime (launch_epi)
     const long tiles = (long)((a.M + 63) / 64) * (a.N / 64);
     const int chunks = Cin / 32;
-    if (tiles >= 512 || chunks < 2) return 0;                   // (splitting 512-tile launches in two measured slower: 35.0 vs 34.0 ms / step)
+    if (tiles >= LWG_CONV_SPLIT_MAX_TILES || chunks < 2) return 0;   // (512-tile launches split in two measured slower: 35.0 vs 34.0 ms / step in round 1, 24.4 vs 24.1 in round 3)
     int want = (int)((1024 + tiles - 1) / tiles);               // aim at ~1024 workgroups = 4 per CU
     if (want > 8) want = 8;
     int cps = (chunks + want - 1) / want;

@@ -11,6 +11,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // Tuning constants.  The product library reads NO environment: every knob is compiled to its measured-best value (DESIGN.md
 // records what the other settings gave); tools/labbuild.sh SRC.hip NAME -DLWG_xxx=v builds a variant library for tools/convlab.py /
 // tools/bf16lab.py A/B runs.
+#ifndef LWG_CONV_SPLIT_MAX_TILES
+#define LWG_CONV_SPLIT_MAX_TILES 512   // conv_igemm.hip: launches with at least this many 64x64 tiles are never split over K
+#endif
 #ifndef LWG_CONV_SPLITK
 #define LWG_CONV_SPLITK 1          // conv_igemm.hip: split-K of the small-M fp32 launches that hand in a workspace (0 = never)
 #endif
