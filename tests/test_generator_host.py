@@ -329,6 +329,21 @@ def test_trainer_step_host_logic_cpu(monkeypatch):
     gD = torch.autograd.grad(loss_d, list(sdD.values()))
     # ---- the product's step
     tr = LWGTrainer(G, D, opts=o)
+    # FlatAdam lays the parameter pairs that run as ONE stacked convolution out back to back: their concatenation is a VIEW of the flat
+    # buffer (no copy), for SPADE's gamma | beta weights and biases and the attention's fk | fv weights of every site
+    from ipercore_amd.networks.training import _stacked
+    n_pairs = 0
+    for name, mod in G.named_modules():
+        pairs = []
+        if name.endswith(".spade"):
+            pairs = [(mod.mlp_gamma.weight, mod.mlp_beta.weight), (mod.mlp_gamma.bias, mod.mlp_beta.bias)]
+        elif hasattr(mod, "fk") and hasattr(mod, "fv"):
+            pairs = [(mod.fk.weight, mod.fv.weight)]
+        for a_, b_ in pairs:
+            st = _stacked(a_, b_)
+            assert st.data_ptr() == a_.data_ptr() and torch.equal(st, torch.cat([a_.detach(), b_.detach()], dim=0))
+            n_pairs += 1
+    assert n_pairs == 3 * (len(nf) + nres), n_pairs
     tr.set_input(inp)
     w0 = {k: v.detach().clone() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
     lg, ld = _as_device(tr.optimize_parameters)
