@@ -1,3 +1,7 @@
+#!/bin/bash
+# lab: whole-library A/B under the personalization bench inside ONE gpurun call on ONE box (boxes differ by a few per cent):
+#   tools/lab/liblwg_head.so and tools/lab/liblwg_new.so (variant builds, e.g. -DLWG_CONV_SPLIT_MAX_TILES=1024) are swapped under
+#   bench_personalize.py, A/B/A/B; a few training checks run first on the library in the tree.  Results: gpurun_out/ab_pers.log
 cd /root/repo
 mkdir -p gpurun_out
 L=ipercore_amd/liblwg_hip.so
