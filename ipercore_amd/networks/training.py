@@ -42,6 +42,7 @@ class ConvCfg(object):
         self.mask_dx, self.premasked = mask_dx and FUSED_RELU_MASK, premasked and FUSED_RELU_MASK
 
 
+FUSED_S2_DGRAD = True       # lab switch: False = the data gradient of a 4x4 stride-2 convolution as four parity launches
 FUSED_RELU_MASK = True      # lab switch: False = every ReLU convolution runs its own act_bwd pass
 FUSED_KV_PAIR = True        # lab switch: False = the fk / fv projections of an attention site as two 1x1 convolutions
 FUSED_SPADE_PAIR = True     # lab switch: False = SPADE's mlp_gamma / mlp_beta as two convolutions (two launches per pass + gradient add)
@@ -155,8 +156,14 @@ class ConvFn(torch.autograd.Function):
                     ops.conv2d(dy, dspecs[0], dx, splitk=True)
                 else:
                     assert not cfg.mask_dx
-                    for s in dspecs:             # one launch per input parity (py, px): rows py, py + 2, .. < H - ceil for odd sizes
-                        ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
+                    if FUSED_S2_DGRAD and kh == 4 and kw == 4 and pad == 1 and H % 2 == 0 and W % 2 == 0 and dy.shape[1] * 2 == H and dy.shape[2] * 2 == W:
+                        # the data gradient of Conv2d(4, 2, 1) IS ConvTranspose2d(4, 2, 1) with the same weight: its four input-parity
+                        # launches have four taps each, parity p's shifted by p - the one-grid form of the decoder's up-sampling layers
+                        # (lwg_conv_transpose4_nhwc_f32) runs them as ONE launch when a parity is small (the discriminator's layers)
+                        ops.conv_transpose2d(dy, dspecs, dx)
+                    else:
+                        for s in dspecs:         # one launch per input parity (py, px): rows py, py + 2, .. < H - ceil for odd sizes
+                            ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
         else:
             Cin, Nw = weight.shape[0], weight.shape[1]
             dx = None
