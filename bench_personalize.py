@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--no-overlap-d", dest="overlap_d", action="store_false", help="D's forward / backward after Adam(G), not next to G's backward")
     ap.add_argument("--no-fused-convt", dest="fused_convt", action="store_false", help="lab: transposed-conv forwards as four parity launches")
     ap.add_argument("--no-fused-bias", dest="fused_bias", action="store_false", help="lab: bias gradients by the separate column-sum kernel")
+    ap.add_argument("--no-convt-wgrad", dest="convt_wgrad", action="store_false", help="lab: transposed-convolution weight gradients as four parity launches")
     ap.add_argument("--no-s2-dgrad", dest="s2_dgrad", action="store_false", help="lab: 4x4 stride-2 data gradients as four parity launches")
     ap.add_argument("--no-relu-mask", dest="relu_mask", action="store_false", help="lab: every ReLU convolution runs its own act_bwd pass")
     ap.add_argument("--no-kv-pair", dest="kv_pair", action="store_false", help="lab: the fk / fv projections as two 1x1 convolutions")
@@ -266,6 +267,9 @@ def main():
     if not args.spade_pair:
         from ipercore_amd.networks import training as _tr
         _tr.FUSED_SPADE_PAIR = False
+    if not args.convt_wgrad:
+        from ipercore_amd.networks import training as _tr
+        _tr.FUSED_CONVT_WGRAD = False
     if not args.s2_dgrad:
         from ipercore_amd.networks import training as _tr
         _tr.FUSED_S2_DGRAD = False

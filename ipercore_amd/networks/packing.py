@@ -231,10 +231,16 @@ def wgrad_conv(x0, spec, dy, x1, kh, kw, cin, n, db=None):
     return wgrad_to_conv(ops.conv2d_wgrad(x0, spec, dy, x1=x1), kh * kw, spec.Cin, cin, n, kh, kw)
 
 
-def wgrad_conv_transpose(x0, specs, dy, cin, n):
-    """nn.ConvTranspose2d(4, 2, 1) weight gradient (Cin, N, 4, 4) from its four parity launches."""
+def wgrad_conv_transpose(x0, specs, dy, cin, n, adj_spec=None):
+    """nn.ConvTranspose2d(4, 2, 1) weight gradient (Cin, N, 4, 4).  With ``adj_spec`` (pack_dgrad_conv_transpose: the adjoint convolution
+    dY -> dX, stride 2, 16 taps) ONE launch: that convolution's weight gradient with the roles swapped - input dY (B,2H,2W,N), "output
+    gradient" x (B,H,W,Cin): dW'[(tap, n)][c] = sum_a dY[2a + off(tap)][n] x[a][c] = dW[c][n][tap] - instead of four parity launches
+    (and four slab reductions)."""
     if dy.is_cuda:
-        g = torch.empty(cin, n, 4, 4, device=dy.device, dtype=torch.float32)           # the four parities cover all 16 positions
+        g = torch.empty(cin, n, 4, 4, device=dy.device, dtype=torch.float32)           # all 16 positions are covered either way
+        if adj_spec is not None:
+            kidx = [ky * 4 + kx for py in (0, 1) for px in (0, 1) for ky, _ in _CT_TAPS[py] for kx, _ in _CT_TAPS[px]]   # pack_dgrad_conv_transpose's tap order
+            return ops.conv2d_wgrad_unpacked(dy, adj_spec, x0, g, False, kidx, n, cin)
         i = 0
         for py in (0, 1):
             for px in (0, 1):

@@ -42,6 +42,7 @@ class ConvCfg(object):
         self.mask_dx, self.premasked = mask_dx and FUSED_RELU_MASK, premasked and FUSED_RELU_MASK
 
 
+FUSED_CONVT_WGRAD = True    # lab switch: False = a transposed convolution's weight gradient as four parity launches
 FUSED_S2_DGRAD = True       # lab switch: False = the data gradient of a 4x4 stride-2 convolution as four parity launches
 FUSED_RELU_MASK = True      # lab switch: False = every ReLU convolution runs its own act_bwd pass
 FUSED_KV_PAIR = True        # lab switch: False = the fk / fv projections of an attention site as two 1x1 convolutions
@@ -139,7 +140,8 @@ class ConvFn(torch.autograd.Function):
             if cfg.kind == "conv":
                 dw = packing.wgrad_conv(x0, specs[0], dy, x1, weight.shape[2], weight.shape[3], weight.shape[1], N, db=db if fused_db else None)
             else:
-                dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N)
+                adj = packing.spec_to(packing.pack_dgrad_conv_transpose(weight, n_pad=Np)[0], dev) if FUSED_CONVT_WGRAD else None
+                dw = packing.wgrad_conv_transpose(x0, specs, dy, weight.shape[0], N, adj_spec=adj)
         if cfg.kind == "conv":
             Nw, Cin, kh, kw = weight.shape
             dx = None
