@@ -1323,8 +1323,10 @@ def check_conv_backward():
     run("concat", "3x3 concat 128+256", 1, 16, 16, 384, 256, 3, 1, 1, 440, C1=256, act=1)
     run("3x3_n192", "3x3 s1 64->192 (64-column tiles, 8 splits, fused bias gradient)", 1, 32, 32, 64, 192, 3, 1, 1, 445)
     run("convT", "convT 128->64", 2, 8, 8, 128, 64, 4, 2, 1, 450, kind="convT", act=1)
-    run("convT_g4", "convT 128->128, 32 reduction slabs (4 lanes per gradient quad)", 4, 32, 32, 128, 128, 4, 2, 1, 452, kind="convT")
-    run("convT_g8", "convT 128->128, 64 reduction slabs (8 lanes per gradient quad)", 8, 32, 32, 128, 128, 4, 2, 1, 454, kind="convT")
+    run("convT_m4096", "convT 128->128, M = 4096 (one-launch weight gradient: K = 16 x 128, 32 slabs)", 4, 32, 32, 128, 128, 4, 2, 1, 452, kind="convT")
+    # medium gradients over many slabs: lwg_slab_reduce_unpack4g_kernel<4> (56 slabs) and <8> (128 slabs)
+    run("3x3_g4", "3x3 s1 128->128 at 128x128 (147 K gradient elements over 56 slabs: 4 lanes per quad)", 1, 128, 128, 128, 128, 3, 1, 1, 456)
+    run("1x1_g8", "1x1 256->256 at 128x128 (65 K gradient elements over 128 slabs: 8 lanes per quad)", 1, 128, 128, 256, 256, 1, 1, 0, 458)
     run("head5x5", "5x5 64->4 (n_pad)", 1, 16, 16, 64, 4, 5, 1, 2, 460, bias=False, n_pad=64)
     run("first_layer", "3x3 s2 6->64 (cin_pad 8)", 1, 32, 32, 6, 64, 3, 2, 1, 470, cin_pad=8, bias=False, act=1, need_dx=False)
     run("bg_first", "7x7 4->64", 1, 16, 16, 4, 64, 7, 1, 3, 480, cin_pad=4, need_dx=False)   # network inputs: no dX
