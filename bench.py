@@ -248,6 +248,29 @@ def with_output(im, smpls, FB, n_frames, t_base):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def rerender_check(im, tgt, video, small_fb=1, n_pick=6, cam="smooth"):
+    """Self-check of a separately reported measurement, outside its timed loop: ``n_pick`` frames spread over the clip are rendered
+    again in launches of ``small_fb`` frames (1 = the reference's calling convention, imitator.py:341) on ONE stream and must equal
+    the measured loop's frames bit for bit - every launch shape the loop used against the small-batch kernels."""
+    from ipercore_amd import ops
+    n = video.shape[0]
+    idx = sorted(set(int(round(x)) for x in np.linspace(0, n - 1, n_pick)))
+    prev = im.frame_batch, im.streams, ops.CONV_HOOK
+    im.frame_batch, im.streams, ops.CONV_HOOK = small_fb, 1, None
+    try:
+        bad = []
+        for t in idx:
+            lo = min(t, n - small_fb)
+            blk = im.synthesize(tgt[lo:lo + small_fb], cam, t0=lo)
+            if not torch.equal(blk[t - lo], video[t]):
+                bad.append(t)
+        torch.cuda.synchronize()
+    finally:
+        im.frame_batch, im.streams, ops.CONV_HOOK = prev
+    return {"result": "bitwise" if not bad else f"MISMATCH at frames {bad}", "frames": idx,
+            "against": f"the same frames rendered in launches of {small_fb} (frame_batch = {small_fb}), one stream"}
+
+
 def _timed_clips(render, W, K):
     for _ in range(W):
         render()
@@ -272,6 +295,7 @@ def split_products(im, render, n, W, K, ref_video):
         dt, video = _timed_clips(render, W, K)
         diff = (video - ref_video).abs().max().item()
         return {"value": round(K * n / dt, 3), "unit": "frames/s", "ms_per_clip": round(dt / K * 1e3, 3), "clips": K,
+                "self_check": "allclose (max |d| <= 2e-3 vs the fp32 path's frames of the same clip)" if diff <= 2e-3 else f"MISMATCH: max |d| = {diff:.3e}",
                 "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
                 "what": "bf16x6: exact 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per product, fp32 accumulation"}
     finally:
@@ -279,7 +303,7 @@ def split_products(im, render, n, W, K, ref_video):
         ops.CONV_HOOK = hook
 
 
-def pipelined(im, render, n, W, K, n_streams):
+def pipelined(im, render, n, W, K, n_streams, tgt=None):
     """Reported separately: the same clip with independent frame batches in flight on several HIP streams (Imitator(streams=n)), so
     that one batch's launch gaps, kernel tails and HBM-bound kernels overlap another batch's MFMA work.  Not the headline value (the
     per-kernel roofline accounting needs launches that own the machine)."""
@@ -290,7 +314,11 @@ def pipelined(im, render, n, W, K, n_streams):
     try:
         dt, video = _timed_clips(render, W, K)
         assert torch.isfinite(video).all()
-        return {"value": round(K * n / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_clip": round(dt / K * 1e3, 3), "clips": K}
+        out = {"value": round(K * n / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_clip": round(dt / K * 1e3, 3), "clips": K}
+        if tgt is not None:
+            chk = rerender_check(im, tgt, video)
+            out["self_check"], out["self_check_detail"] = chk["result"], chk
+        return out
     finally:
         im.streams = prev
         ops.CONV_HOOK = hook
@@ -392,6 +420,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
         dt = time.perf_counter() - t0
         timer.enabled = False
         assert torch.isfinite(video).all()
+        chk = rerender_check(im, tgt, video, small_fb=2)         # 1024x1024 bf16: against batches of 2 (check_benched_shapes_1024_bf16's form)
         conv_ms, conv_flops, n_launch, mean_ms = timer.result()
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         gov, hbm_share = timer.governing(PEAK_BF16_MFMA_TFLOPS)
@@ -409,7 +438,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
         finally:
             im.streams = prev_streams
         return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": im.frame_batch,
-                "frame_batch_requested": FB, "image_size": S,
+                "frame_batch_requested": FB, "image_size": S, "self_check": chk["result"], "self_check_detail": chk,
                 "pipelined_3_streams_frames_per_s": round(piped, 2),
                 "dtype": "bf16 MFMA operands + bf16 activation storage, f32 accumulation / renderer",
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -449,9 +478,10 @@ def size_extra(dev, timer, S, W=1, K=2):
         timer.enabled = False
         assert video.shape[0] == n and torch.isfinite(video).all()
         conv_ms, conv_flops, n_launch, mean_ms = timer.result()
+        chk = rerender_check(im, tgt, video)
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         return {"value": round(K * n / dt, 2), "unit": "frames/s", "image_size": S, "dtype": "f32", "frames_per_clip": n, "clips": K,
-                "frame_batch": im.frame_batch,
+                "frame_batch": im.frame_batch, "self_check": chk["result"], "self_check_detail": chk,
                 "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
                              "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 2), "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
@@ -510,9 +540,10 @@ def main(argv=None):
                          "measured in one process 472 / 476 / 478 frames/s at 16 / 24 / 32 (fp32, 512x512) and 723 / 740 / 739 at "
                          "12 / 16 / 20 -> 746 / 754 / 757 (bf16, 1024x1024)")
     ap.add_argument("--gather-dtype", choices=("auto", "f32", "u8"), default="auto",
-                    help="N > 1: exchange the (n,S,S,3) uint8 video the reference's PNG writer consumes (device-side conversion; a quarter "
-                         "of the bytes on the per-link-bound xGMI ring; the default, 'auto' = u8) or, with f32, the (n,3,S,S) fp32 video "
-                         "Imitator.inference returns")
+                    help="N > 1: what the all-gather exchanges.  f32 (the default, 'auto' = f32): the (n,3,S,S) fp32 video Imitator.inference "
+                         "returns - the same result tensor as at N = 1 and as the reference's; u8: the (n,S,S,3) uint8 video its PNG writer "
+                         "consumes (device-side conversion, a quarter of the bytes on the per-link-bound xGMI ring).  With f32 the u8 form "
+                         "is measured too, in its own short loop, and reported as `exchange_u8` - never as `value`")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend; nccl = RCCL (the product)")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
                     help="cpu: plumbing dry run for the CPU test-suite ONLY (tests/test_bench_launch.py installs the emulated C ABI "
@@ -537,6 +568,7 @@ def main(argv=None):
     ap.add_argument("--tiny-arch", action="store_true", help="reduced-width generator (plumbing tests only; never a reported number)")
     ap.add_argument("--no-self-check", dest="self_check", action="store_false")
     ap.add_argument("--no-sizes-extra", dest="sizes_extra", action="store_false")
+    ap.add_argument("--no-exchange-u8", dest="exchange_u8", action="store_false", help="N > 1 with the f32 exchange: skip the extra uint8-exchange loop")
     args = ap.parse_args(argv)
     self_launch_if_needed(sys.argv[1:] if argv is None else argv)      # N > 1 without torchrun: spawn the ranks ourselves
 
@@ -565,7 +597,7 @@ def main(argv=None):
         assert dist.get_world_size() == world
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.gather_dtype == "auto":
-        args.gather_dtype = "u8"
+        args.gather_dtype = "f32"
 
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
@@ -603,16 +635,17 @@ def main(argv=None):
     hook = None if args.no_conv_events else (lambda b, M, spec, epi=0: timer(b, M, spec, epi, act_bytes))
     ops.CONV_HOOK = hook
 
-    post = None
-    if args.gather_dtype == "u8" and world > 1:      # the exchange format; at N = 1 nothing is exchanged and the fp32 video is the result
-        def post(x):
-            return ops.frames_to_u8(x) if x.shape[0] else torch.empty((0, S, S, 3), device=x.device, dtype=torch.uint8)
+    def to_u8(x):
+        return ops.frames_to_u8(x) if x.shape[0] else torch.empty((0, S, S, 3), device=x.device, dtype=torch.uint8)
+    # the exchange format; at N = 1 nothing is exchanged and the fp32 video is the result
+    post = to_u8 if (args.gather_dtype == "u8" and world > 1) else None
+    fmt = {"post": post}
     stats = {}
 
     if clip:
         def step(i):
             st = {"sync": sync} if world > 1 else {}
-            v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=post, stats=st)
+            v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=fmt["post"], stats=st)
             stats.setdefault("exposed_gather_s", []).append(st.get("exposed_gather_s"))
             stats.update({k: st[k] for k in ("shard", "bytes_received", "chunks", "chunk_lengths") if k in st})
             return v
@@ -678,6 +711,7 @@ def main(argv=None):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
     per_rank = None
     if world > 1 and clip:
         mine_stats = {"rank": rank, "shard": list(stats.get("shard", ())), "frames": stats["shard"][1] - stats["shard"][0],
@@ -685,6 +719,31 @@ def main(argv=None):
                       "bytes_received_per_step": stats.get("bytes_received"), "chunk_lengths": stats.get("chunk_lengths")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_stats)
+
+    # N > 1, fp32 exchange in the headline: the uint8 exchange (what a PNG-writing consumer needs) in its own short loop, same protocol
+    exchange_u8 = None
+    if world > 1 and clip and args.gather_dtype == "f32" and args.exchange_u8:
+        fmt["post"], prev_hook, ops.CONV_HOOK = to_u8, ops.CONV_HOOK, None
+        try:
+            Ku = max(2, K // 5)
+            v8 = step(0)
+            sync()
+            dist.barrier()
+            sync()
+            t1 = time.perf_counter()
+            for i in range(Ku):
+                v8 = step(i)
+            sync()
+            dist.barrier()
+            sync()
+            tu = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tu, op=dist.ReduceOp.MAX)
+            same = bool(torch.equal(v8, to_u8(last))) if last.dtype == torch.float32 else None
+            exchange_u8 = {"value": round(Ku * frames_per_step / float(tu.item()), 3), "unit": "frames/s", "steps": Ku,
+                           "ms_per_step": round(float(tu.item()) / Ku * 1e3, 3), "exchanged": "(n,S,S,3) uint8 video",
+                           "equals_u8_of_the_f32_video": same}
+        finally:
+            fmt["post"], ops.CONV_HOOK = post, prev_hook
 
     if rank == 0:
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
@@ -697,6 +756,8 @@ def main(argv=None):
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split"}[args.precision],
             "data": "synthetic" + (" (tiny architecture, CPU plumbing run: NOT a measurement)" if (args.tiny_arch or not on_gpu) else ""),
+            "result_tensor": ("(n,3,S,S) f32 video" if (world == 1 or args.gather_dtype == "f32") else "(n,S,S,3) uint8 video") +
+                             (f", all-gathered as {args.gather_dtype}" if world > 1 else ""),
             "config": {"workload": (f"run_imitator {S}x{S} single src/ref pair, {n_clip}-frame reference clip frame-sharded over {world} GPU(s), "
                                     "AttLWB-SPADE generator fp32 (BASELINE configs[1] at N = 1, configs[2] at N = 8)" if clip else
                                     f"run_imitator {S}x{S} single src/ref pair, one {FB}-frame batch per GPU per step (weak scaling)")
@@ -713,6 +774,8 @@ def main(argv=None):
         }
         if per_rank is not None:
             line["config"]["per_rank"] = per_rank
+        if exchange_u8 is not None:
+            line["exchange_u8"] = exchange_u8
         line["self_check"] = self_check["result"] if self_check else None
         if self_check:
             line["self_check_detail"] = self_check
@@ -757,7 +820,7 @@ def main(argv=None):
             def render():
                 return im.synthesize(tgt, "smooth")
             if args.pipelined_streams > 1:
-                line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams)
+                line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams, tgt if args.self_check else None)
             if args.split_extra and args.precision == "fp32":
                 line["split_products"] = _extra(split_products, im, render, n_clip, 1, Ke, last)
             if args.output_frames > 0:

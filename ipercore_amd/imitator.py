@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .bodynets import SMPLH
-from .flowcomposition import FlowComposition
+from .flowcomposition import FlowComposition, _force
 from .geometry import cam_pose_utils
 from .networks import NetworksFactory
 
@@ -223,9 +223,10 @@ class Imitator(object):
         ref_smpl = self.swap_params(src_info["cam"][primary_ids:primary_ids + 1],
                                     src_info["shape"][primary_ids:primary_ids + 1], tgt_smpl, cam_strategy)
         ref_info = self.body_rec.get_details(ref_smpl.contiguous(), src_info["offsets"], links_ids=src_info["links_ids"])
-        key = "selected_f2pts" if use_selected_f2pts else "f2pts"
+        # flowcomposition.py:556-562: selected faces (Swapper) > visible faces only (opt.only_vis) > all projected source faces
+        key = "selected_f2pts" if use_selected_f2pts else ("only_vis_f2pts" if self.flow_comp.only_vis else "f2pts")
         tsf8, Tst, aux = self.flow_comp.frame_inputs(ref_info["cam"].contiguous(), ref_info["verts"], src_info["uv_img4"],
-                                                     src_info[key].contiguous(), want_aux=want_aux)
+                                                     _force(src_info[key]).contiguous(), want_aux=want_aux)
         if aux is not None:
             ref_info.update(aux)
         return tsf8, Tst, ref_info
@@ -240,8 +241,12 @@ class Imitator(object):
     # ------------------------------------------------------------------ frame_batch = 1: one hipGraph replay per frame
     def _frame_graph_key(self, row, cam_strategy, sel):
         gen = self.generator
-        return (cam_strategy, sel["primary_ids"], sel["use_selected_f2pts"], id(self.src_info), id(gen.packed()), gen.conv_precision,
-                tuple(row.shape), self.image_size)
+        return (cam_strategy, sel["primary_ids"], sel["use_selected_f2pts"], gen.conv_precision, tuple(row.shape), self.image_size)
+
+    def _frame_graph_current(self, fg, key):
+        """The captured graph reads THESE source tensors and THESE weight panels: besides the value key, the identities must match - the
+        graph dict holds both objects (a freed panel set's address can be handed to its successor, so ``id()`` alone proves nothing)."""
+        return fg is not None and fg.get("key") == key and fg.get("src_info") is self.src_info and fg.get("packed") is self.generator.packed()
 
     def reset_frame_graph(self):
         """Drop the captured single-frame graph.  It is keyed on the IDENTITY of ``src_info`` and of the packed weight panels: call this
@@ -256,8 +261,9 @@ class Imitator(object):
             return None                                   # frame 0 of an un-prepared sequence fixes first_cam on the host path
         key = self._frame_graph_key(row, cam_strategy, sel)
         fg = self._frame_graph
-        if fg is None or fg["key"] != key:
-            if fg is not None and fg.get("failed") == key:
+        if not self._frame_graph_current(fg, key):
+            if (fg is not None and fg.get("failed") == key and fg.get("failed_src") is self.src_info
+                    and fg.get("failed_packed") is self.generator.packed()):
                 return None
             try:
                 fg = self._capture_frame(row, cam_strategy, sel, key)
@@ -265,7 +271,7 @@ class Imitator(object):
                 import warnings
                 warnings.warn(f"Imitator: capturing the single-frame path as a hipGraph failed ({type(e).__name__}: {e}); eager launches")
                 torch.cuda.synchronize()
-                self._frame_graph = {"key": None, "failed": key}
+                self._frame_graph = {"key": None, "failed": key, "failed_src": self.src_info, "failed_packed": self.generator.packed()}
                 return None
             self._frame_graph = fg
         fc = self.first_cam
@@ -291,13 +297,15 @@ class Imitator(object):
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: HIP calls of OTHER threads (the FrameWriter's event waits / D2H copies, the RCCL watchdog) while this thread
+            # captures are legal and must not fail the capture - or surface as an error in that other thread
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, static_row, cam_strategy, t=1, **sel)
                 out = self.forward(tsf8, Tst)[0]
         finally:
             self.first_cam = prev_fc
         return {"key": key, "graph": g, "row": static_row, "first_cam": static_fc, "out": out, "fc_id": None, "fc_ver": None,
-                "src_info": self.src_info}                # keeps the captured source state alive
+                "src_info": self.src_info, "packed": self.generator.packed()}      # keeps the captured source state and weight panels alive
 
     @torch.no_grad()
     def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0, use_selected_f2pts=False):
@@ -345,8 +353,8 @@ class Imitator(object):
         """temporal=True (imitator.py:341-366): a recurrence - frame t attends to the sources and to the last ``time_step``
         synthesized frames, so frames are produced one at a time (this mode does not shard over frames: replicas only)."""
         src = self.src_info
-        key = "selected_f2pts" if use_selected_f2pts else "f2pts"
-        self.temporal_fifo = fifo = TemporalFIFO(self.time_step, src["feats_nhwc"], src[key].contiguous())
+        key = "selected_f2pts" if use_selected_f2pts else ("only_vis_f2pts" if self.flow_comp.only_vis else "f2pts")
+        self.temporal_fifo = fifo = TemporalFIFO(self.time_step, src["feats_nhwc"], _force(src[key]).contiguous())
         outs = []
         for t in range(tgt_smpls.shape[0]):
             if t == 0 and cam_strategy == "smooth" and self.first_cam is None:

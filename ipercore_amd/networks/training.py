@@ -96,7 +96,7 @@ class ConvFn(torch.autograd.Function):
             specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(weight, bias, cfg.n_pad)]
             y = torch.empty(B, 2 * H, 2 * W, specs[0].N, device=dev, dtype=torch.float32)
             if FUSED_CONVT_FWD:
-                ops.conv_transpose2d(x0, specs, y, act=cfg.act)     # small launches: the four parities as one grid (lwg_conv_transpose4_nhwc_f32)
+                ops.conv_transpose2d(x0, specs, y, act=cfg.act, splitk=True)     # small launches: the four parities as one grid (lwg_conv_transpose4_nhwc_f32)
             else:
                 for s in specs:
                     ops.conv2d(x0, s, y, act=cfg.act, splitk=True)
@@ -162,7 +162,7 @@ class ConvFn(torch.autograd.Function):
                         # the data gradient of Conv2d(4, 2, 1) IS ConvTranspose2d(4, 2, 1) with the same weight: its four input-parity
                         # launches have four taps each, parity p's shifted by p - the one-grid form of the decoder's up-sampling layers
                         # (lwg_conv_transpose4_nhwc_f32) runs them as ONE launch when a parity is small (the discriminator's layers)
-                        ops.conv_transpose2d(dy, dspecs, dx)
+                        ops.conv_transpose2d(dy, dspecs, dx, splitk=True, out_hw=lambda s_: ((H - s_.ooy + 1) // 2, (W - s_.oox + 1) // 2))
                     else:
                         for s in dspecs:         # one launch per input parity (py, px): rows py, py + 2, .. < H - ceil for odd sizes
                             ops.conv2d(dy, s, dx, out_hw=((H - s.ooy + 1) // 2, (W - s.oox + 1) // 2), splitk=True)
@@ -460,7 +460,8 @@ class TrainableGenerator(object):
             x = instance_norm(self.cv(f"bg_net.main.{i}", x, kind="convT"), _RELU)
             i += 3
         w = self.p(f"bg_net.main.{i}").weight            # Conv2d(nf, 3, 7, 1, 3, bias=False) + Tanh (bg_inpaintor.py:53-54)
-        if w.shape[0] <= 4 and w.shape[2] in (5, 7) and x.shape[3] % 8 == 0 and x.shape[1] == x.shape[2]:
+        # ThinConvFn's backward is the thin MFMA form (dX = a conv with N = Cin columns: the kernel's granularity is 64 - ConvFn's ctx.thin rule)
+        if w.shape[0] <= 4 and w.shape[2] in (5, 7) and x.shape[3] % 64 == 0 and x.shape[1] == x.shape[2]:
             return torch.tanh(ThinConvFn.apply(x, w))
         return torch.tanh(self.cv(f"bg_net.main.{i}", x, pad=3, n_pad=64))
 

@@ -265,10 +265,12 @@ class _FusedTransposeSpec(object):
         self.algo_kn, self.w = 4 * s0.algo_kn, panel
 
 
-def conv_transpose2d(x, specs, y, act=ACT_NONE):
+def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None):
     """y (B,2H,2W,N) <- ConvTranspose2d(4, 2, 1) of x (B,H,W,Cin) given its four parity specs (packing.pack_conv_transpose).
     bf16 activations with Cin <= 128: ONE launch (lwg_conv_transpose4_nhwc_bf16: the input block is staged once for the four
-    parities); otherwise the four parity launches of ``conv2d``."""
+    parities); otherwise the four parity launches of ``conv2d``.  ``splitk`` / ``out_hw`` are handed to those four launches (the
+    training callers' plan: the one-grid form and the four-launch fall-back then differ only in launch count); ``out_hw`` is a
+    callable spec -> (OH, OW) or None."""
     s0 = specs[0]
     if (BF16_UP4 and BF16_HR and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and len(specs) == 4 and s0.Cin in (64, 128)
             and s0.N % 64 == 0 and all(s.ntaps == 4 and s.omul == 2 and (s.ooy, s.oox) == (i >> 1, i & 1) for i, s in enumerate(specs))):
@@ -306,7 +308,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE):
                 CONV_HOOK(False, a.M, whole, EPI_NONE)
             return y
     for s in specs:
-        conv2d(x, s, y, act=act)
+        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s))
     return y
 
 

@@ -131,7 +131,8 @@ class SMPLRenderer(nn.Module):
     @torch.no_grad()
     def get_vis_f2pts(self, f2pts, fims):
         """nmr.py:639-681: keep visible faces and their k nearest same-part faces, others -> -2.  Off the hot path
-        (only consumed when ``only_vis`` is set, flowcomposition.py:559-562); done with index ops, host-sync free."""
+        (only consumed when ``only_vis`` is set, flowcomposition.py:559-562); index ops on the device, no host sync
+        (fixed shapes: boolean marks over the nf + 1 ids instead of ``unique()``)."""
         single = f2pts.dim() == 3
         if single:
             f2pts, fims = f2pts.unsqueeze(0), fims.unsqueeze(0)
@@ -141,12 +142,13 @@ class SMPLRenderer(nn.Module):
             # the reference drops the smallest unique value assuming it is the background id -1 (nmr.py:660)
             seen = torch.zeros(nf + 1, dtype=torch.bool, device=f2pts.device)
             seen[(fims[i].reshape(-1).long() + 1)] = True
-            first = int(torch.nonzero(seen)[0])
-            seen[first] = False
+            first = torch.argmax(seen.to(torch.uint8)).view(1)          # index of the smallest id present, as a device tensor
+            seen.index_fill_(0, first, False)
             vis = seen[1:]
-            keep = torch.zeros(nf, dtype=torch.bool, device=f2pts.device)
-            keep[self.face_k_nearest[vis].reshape(-1)] = True
-            out[i][keep] = f2pts[i][keep]
+            # every visible face marks its k nearest same-part faces (face_k_nearest (nf,k)); invisible rows mark nothing
+            marks = torch.zeros(nf, dtype=torch.int32, device=f2pts.device)
+            marks.index_add_(0, self.face_k_nearest.reshape(-1), vis.to(torch.int32).repeat_interleave(self.face_k_nearest.shape[1]))
+            out[i] = torch.where((marks > 0).view(nf, 1, 1), f2pts[i], out[i])
         return out[0] if single else out
 
     def get_selected_f2pts(self, f2pts, selected_fids):

@@ -438,7 +438,8 @@ def imitate_frame(model, tables, sd, src_info, tgt_smpl, first_cam, image_size, 
     f2pts, fim, wim = render_fim_wim(ref["cam"], ref["verts"], tables["smpl_faces"], image_size)
     cond = encode_fim(tables["map_fn"], fim)
     tsf_inputs, Tuv2t = make_tsf_inputs(src_info["uv_img"], tables["f_uvs2img"], cond, fim, wim)
-    Tst = make_trans_flow(src_info["f2pts"], fim, wim)
+    # flowcomposition.py:556-562: opt.only_vis swaps in the visible-faces-only source projection (nmr.py:639-681)
+    Tst = make_trans_flow(src_info["only_vis_f2pts"] if src_info.get("only_vis") else src_info["f2pts"], fim, wim)
     enc, res = src_info["feats"]
     img, mask = gen_forward_tsf(sd, tsf_inputs, enc, res, Tst, n_down=len(enc), n_res=len(res))
     pred = compose(img, mask, src_info["bg"])

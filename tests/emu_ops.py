@@ -394,12 +394,25 @@ def frames_to_u8(pred, bgr=False):
     return torch.from_numpy(np.ascontiguousarray(u8[..., ::-1] if bgr else u8))
 
 
+def texture_sample(fim, wim, faces_v, textures, eps=1e-3, background_color=(0.0, 0.0, 0.0)):
+    """lwg_texture_sample_f32's contract (include/lwg_hip.h): textures (B | 1, nf, T, T, T, 3) -> rgb (B,S,S,3)."""
+    from oracle import lwg_oracle as orc
+    B = fim.shape[0]
+    tex = textures if textures.shape[0] == B else textures.expand(B, *textures.shape[1:])
+    return orc.texture_sample(fim, wim, faces_v.float(), tex.float(), eps, tuple(float(c) for c in background_color))
+
+
+def grid_sample(x, grid):
+    """lwg_grid_sample_nchw_f32's contract: F.grid_sample(bilinear, zeros, align_corners=False)."""
+    return torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

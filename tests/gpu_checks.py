@@ -606,6 +606,35 @@ def check_num_source_1_and_8():
     return out
 
 
+def check_num_source_8_at_512():
+    """MAX_NUM_SOURCE = 8 (deploy.toml:8) at the headline resolution: one 2-frame batch at 512 x 512, full width, eight sources - the
+    K / V cache of 8 rows per site, 8 source flows per pixel and the 8-way softmax at the 256 / 128 / 64-pixel feature sizes."""
+    return _pipeline(512, *FULL, n_frames=2, frame_batch=2, ns=8, variants=False)
+
+
+def check_only_vis_256():
+    """``opt.only_vis = True`` (flowcomposition.py:556-562): the source flows are built from ``get_vis_f2pts`` (nmr.py:639-681: visible
+    source faces + their 3 nearest same-part faces, every other face at -2) - through Imitator's batched per-frame path against the
+    oracle, stage by stage; and ``SMPLRenderer.get_vis_f2pts`` itself (device index ops, no host sync) equal to the oracle's."""
+    from oracle import lwg_oracle as orc
+    case = pu.build_case(image_size=256, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=2, ns=2)
+    plain = _run_cached("only_vis_plain_256", case, 2)
+    case_v = pu.build_case(image_size=256, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=2, ns=2)
+    case_v.opt["only_vis"] = True
+    r = _run_cached("only_vis_256", case_v, 2)
+    m = dict(r["m"])
+    _parity_asserts(m)
+    im = r["im"]
+    assert im.flow_comp.only_vis
+    vis = im.src_info["only_vis_f2pts"].get()
+    want = orc.get_vis_f2pts(im.src_info["f2pts"].cpu(), im.src_info["fim"].cpu(), im.flow_comp.render.face_k_nearest.cpu().numpy())
+    assert torch.equal(vis.cpu(), want), "get_vis_f2pts differs from the oracle's"
+    m["faces_kept"] = [int(v) for v in (vis[:, :, 0, 0] != -2).sum(dim=1).tolist()]
+    m["only_vis_vs_plain_max"] = (r["got"] - plain["got"]).abs().max().item()
+    assert m["only_vis_vs_plain_max"] > 1e-3, "only_vis left the frames unchanged"
+    return m
+
+
 def _psnr(a, b):
     mse = ((a.double() - b.double()) ** 2).mean().item()
     return 10 * np.log10(4.0 / max(mse, 1e-20))        # frames are in [-1, 1]: peak-to-peak 2
@@ -1334,36 +1363,52 @@ def check_conv_backward():
     return out
 
 
-def check_generator_training_grads():
-    """One training forward + backward of the whole generator (bg + src with decoder + tsf) through ConvFn on the GPU vs
-    torch autograd through the oracle's functional generator on the CPU: outputs and EVERY parameter gradient."""
+def _training_inputs(S, ns, nf, nres, bgf, real_flows):
+    """Seeded network inputs of one personalization sample.  ``real_flows``: Tst comes from the product renderer on a synthetic posed
+    body at S (silhouette-shaped -2 regions, as the trainer's FlowCompositionForTrainer produces them) instead of the 64x64 golden."""
+    if real_flows:
+        case = pu.build_case(image_size=S, num_filters=nf, n_res=nres, bg_filters=bgf, n_frames=1, ns=ns)
+        im = pu.make_imitator(case, frame_batch=1)
+        tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+        _, Tst, _ = im.make_inputs_for_tsf(im.src_info, tgt[0:1], "smooth", t=0)
+        Tst = Tst.view(1, 1, ns, S, S, 2).cpu().clone()
+        del im
+        torch.cuda.empty_cache()
+    else:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+        Tst = torch.tensor(g["render/Tst"]).view(1, 1, ns, S, S, 2)
+    bg_in = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"))
+    src_in = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
+    tsf_in = torch.tensor(synthetic.uniform_image((1, 1, 6, S, S), 9, "tsf_inputs"))
+    return bg_in, src_in, tsf_in, Tst
+
+
+def _generator_training_grads(S, nf, nres, bgf, real_flows=False):
     from oracle import lwg_oracle as orc
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
     from ipercore_amd.networks.training import TrainableGenerator
-    S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
+    ns = 2
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
     sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
     G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
     G.to(DEV).train()
-    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
-    bg_in = torch.tensor(synthetic.uniform_image((1, 1, 4, S, S), 10, "bg_inputs"))
-    src_in = torch.tensor(synthetic.uniform_image((1, ns, 6, S, S), 8, "src_inputs"))
-    tsf_in = torch.tensor(synthetic.uniform_image((1, 1, 6, S, S), 9, "tsf_inputs"))
-    Tst = torch.tensor(g["render/Tst"]).view(1, 1, ns, S, S, 2)
+    bg_in, src_in, tsf_in, Tst = _training_inputs(S, ns, nf, nres, bgf, real_flows)
     tgt = [torch.tensor(synthetic.uniform_image(s, 500 + i, "tgt")) for i, s in enumerate(((1, 1, 3, S, S), (1, ns, 3, S, S), (1, ns, 1, S, S), (1, 1, 3, S, S), (1, 1, 1, S, S)))]
 
     def loss_of(outs, dev):
         return sum((o - t.to(dev)).abs().mean() for o, t in zip(outs, tgt))
 
+    t0 = time.time()
     sd = {k: torch.tensor(v, requires_grad=True) for k, v in sdn.items()}
     outs_ref = orc.gen_forward_train(sd, bg_in, src_in, tsf_in, Tst, n_down=len(nf), n_res=nres, n_bg=len(bgf))
     loss_ref = loss_of(outs_ref, "cpu")
     loss_ref.backward()
+    t_oracle = time.time() - t0
     outs = TrainableGenerator(G).forward(bg_in.to(DEV), src_in.to(DEV), tsf_in.to(DEV), Tst.to(DEV))
     loss = loss_of(outs, DEV)
     loss.backward()
     torch.cuda.synchronize()
-    m = {"loss": abs(loss.item() - loss_ref.item())}
+    m = {"S": S, "num_filters": list(nf), "n_res": nres, "oracle_autograd_s": t_oracle, "loss": abs(loss.item() - loss_ref.item())}
     assert m["loss"] <= 1e-4 * max(1.0, abs(loss_ref.item())), m
     names = ("bg", "src_img", "src_mask", "tsf_img", "tsf_mask")
     for n_, a_, b_ in zip(names, outs, outs_ref):
@@ -1381,6 +1426,20 @@ def check_generator_training_grads():
     m["worst_rel_grad_err"], m["worst_param"], m["n_params"] = worst, worst_name, len(sd)
     assert worst <= 2e-3, m
     return m
+
+
+def check_generator_training_grads():
+    """One training forward + backward of the whole generator (bg + src with decoder + tsf) through ConvFn on the GPU vs
+    torch autograd through the oracle's functional generator on the CPU: outputs and EVERY parameter gradient."""
+    return _generator_training_grads(64, [64, 64, 128], 2, [64, 64, 128])
+
+
+def check_generator_training_grads_512_full():
+    """The same comparison AT THE SHAPES bench.py's ``personalize_step`` RUNS (BASELINE configs[4]; lwg_trainer.py:326-352, 732-832):
+    512 x 512, num_filters [64, 128, 256], 6 residual blocks, ns = 2, nt = 1.  At this size the wiring picks split-K launches, the
+    one-grid transposed convolutions, the stacked gamma | beta and K | V launches and the 4- / 8-lane slab reductions by shape -
+    none of which the 64 x 64 reduced-width case reaches together.  Flows: a rendered body at 512 x 512 (real -2 background)."""
+    return _generator_training_grads(512, *FULL, real_flows=True)
 
 
 def _ref_patch_discriminator(D):
@@ -1488,22 +1547,21 @@ def check_discriminator_and_trainer_step():
     return m
 
 
-def check_graph_vs_eager_steps():
+def _graph_vs_eager_steps(S, nf, nres, bgf, N, real_flows=False):
     """The captured (hipGraph) personalization step against eager launches: N calls of optimize_parameters() must be N Adam updates in
     both modes (the reference does exactly n_iters updates, services/personalization.py:95-151; the capture's warm-up steps are rolled
     back), losses and weights agree within the noise of the fp32 atomics of the attention backward, the host step counts follow the
     replays, the returned loss tensors are not aliases of one buffer, and the inference panels are rebuilt after replayed updates."""
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
     from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
-    S, ns, nf, nres, bgf = 64, 2, [64, 64, 128], 2, [64, 64, 128]
+    ns = 2
     sdn = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
-    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
     u = lambda shape, seed, name: torch.tensor(synthetic.uniform_image(shape, seed, name), device=DEV)      # noqa: E731
-    inp = {"input_G_bg": u((1, 1, 4, S, S), 10, "bg_inputs"), "input_G_src": u((1, ns, 6, S, S), 8, "src_inputs"),
-           "input_G_tsf": u((1, 1, 6, S, S), 9, "tsf_inputs"), "Tst": torch.tensor(g["render/Tst"], device=DEV).view(1, 1, ns, S, S, 2),
+    bg_in, src_in, tsf_in, Tst = _training_inputs(S, ns, nf, nres, bgf, real_flows)
+    inp = {"input_G_bg": bg_in.to(DEV), "input_G_src": src_in.to(DEV), "input_G_tsf": tsf_in.to(DEV), "Tst": Tst.to(DEV),
            "real_src": u((1, ns, 3, S, S), 700, "real_src"), "real_tsf": u((1, 1, 3, S, S), 701, "real_tsf"),
            "real_bg": u((1, 3, S, S), 702, "real_bg"), "body_mask": (u((1, ns + 1, 1, S, S), 703, "mask") > 0).float()}
-    N, runs = 4, {}
+    runs = {}
     for mode in ("eager", "graph"):
         G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False)
         G.load_state_dict({k: torch.tensor(v) for k, v in sdn.items()}, strict=True)
@@ -1527,7 +1585,7 @@ def check_graph_vs_eager_steps():
     assert e["tG"] == gr["tG"] == N and e["tD"] == gr["tD"] == N, (e["tG"], gr["tG"], e["tD"], gr["tD"])
     assert gr["tG_host"] == N, gr["tG_host"]
     lr = 1e-4
-    m = {"steps": N, "losses_eager": e["losses"], "losses_graph": gr["losses"]}
+    m = {"S": S, "steps": N, "losses_eager": e["losses"], "losses_graph": gr["losses"]}
     for (a0, b0), (a1, b1) in zip(e["losses"], gr["losses"]):
         assert abs(a0 - a1) <= 2e-3 * max(1.0, abs(a0)) and abs(b0 - b1) <= 2e-3 * max(1.0, abs(b0)), (e["losses"], gr["losses"])
     for k in ("flatG", "flatD"):
@@ -1536,6 +1594,16 @@ def check_graph_vs_eager_steps():
         # Adam moves a weight by <= lr per step whatever the gradient's size: 2 extra (or missing) updates would show as ~2 lr everywhere
         assert d.max().item() <= 2 * N * lr and d.mean().item() <= 0.1 * lr, (k, m)
     return m
+
+
+def check_graph_vs_eager_steps():
+    return _graph_vs_eager_steps(64, [64, 64, 128], 2, [64, 64, 128], N=4)
+
+
+def check_graph_vs_eager_steps_512_full():
+    """3 captured-graph steps vs 3 eager steps of ``LWGTrainer.optimize_parameters`` at the benched size (512 x 512, full width, ns = 2):
+    the 3-graph replay with D's own step on a side stream must make the same 3 Adam updates as eager launches."""
+    return _graph_vs_eager_steps(512, *FULL, N=3, real_flows=True)
 
 
 def check_rccl_world1():
@@ -2019,5 +2087,6 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16,
        check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
-       check_generator_training_grads, check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants,
-       check_graph_vs_eager_steps, check_rccl_world1]
+       check_generator_training_grads, check_generator_training_grads_512_full, check_num_source_8_at_512, check_only_vis_256,
+       check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants,
+       check_graph_vs_eager_steps, check_graph_vs_eager_steps_512_full, check_rccl_world1]

@@ -25,6 +25,14 @@ def oracle_tables(topo=None):
             "f_uvs2img": mesh.get_f2vts(uv, z=1)[:, :, 0:2].astype(np.float32)}
 
 
+def face_k_nearest_table(topo=None, k=3):
+    """renders/nmr.py:186-190 with FlowComposition's top_k = 3 (flowcomposition.py:66): (nf, k) nearest same-part faces in UV space."""
+    topo = topo or mesh.load_topology()
+    f_img2uvs = mesh.get_f2vts(mesh.obj_from_topology(topo, "fim"), z=1).astype(np.float32)
+    parts = {str(n): topo["part_" + str(n)] for n in topo["part_names"]}
+    return mesh.find_part_k_nearest_faces(f_img2uvs, mesh.get_part_ids(f_img2uvs.shape[0], parts), k=k)
+
+
 def oracle_source(case, tables=None, src_override=None):
     """The oracle's version of the cached source state (what source_setup leaves in src_info).
 
@@ -46,6 +54,8 @@ def oracle_source(case, tables=None, src_override=None):
         feats = orc.gen_forward_src(sd, src_inputs, n_down=len(case.num_filters), n_res=case.n_res)
     info = {"cam": src["cam"], "shape": src["shape"], "offsets": 0, "links_ids": None, "uv_img": torch.tensor(case.uv_img),
             "bg": torch.tensor(case.bg_img), "f2pts": f2pts, "feats": feats, "own_verts": own_verts, "fim": fim}
+    if case.opt.get("only_vis", False):       # flowcomposition.py:559-562: Tst from the visible source faces (+ k nearest) only
+        info["only_vis"], info["only_vis_f2pts"] = True, orc.get_vis_f2pts(f2pts, fim, face_k_nearest_table())
     return model, tables, sd, info
 
 

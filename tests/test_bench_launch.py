@@ -46,7 +46,8 @@ def _run(tmp_path, extra, env_extra=None, launcher=None):
 
 
 def test_bench_self_launches_two_ranks_gloo(tmp_path):
-    """Plain ``python <bench> --gpus 2`` (WORLD_SIZE unset): two ranks, a 7-frame clip in shards of 4 + 3, uint8 exchange by default."""
+    """Plain ``python <bench> --gpus 2`` (WORLD_SIZE unset): two ranks, a 7-frame clip in shards of 4 + 3; the headline exchanges the
+    fp32 (n,3,S,S) video (the result tensor of N = 1 and of the reference), the uint8 exchange is measured beside it."""
     line = _run(tmp_path, ["--gpus", "2"])
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["scaling"] == "strong"
     assert line["value"] > 0 and line["unit"] == "frames/s" and line["config"]["frames_per_step"] == 7
@@ -54,21 +55,24 @@ def test_bench_self_launches_two_ranks_gloo(tmp_path):
     assert [p["rank"] for p in per_rank] == [0, 1] and [p["frames"] for p in per_rank] == [4, 3]
     assert per_rank[0]["shard"] == [0, 4] and per_rank[1]["shard"] == [4, 7]
     assert per_rank[0]["chunk_lengths"] == [2, 2]                     # frame batch 2 over the longest shard (4)
-    # (S,S,3) uint8 blocks of 2 frames from 2 ranks, two chunks
-    assert per_rank[0]["bytes_received_per_step"] == 2 * 2 * 2 * 64 * 64 * 3
-    assert "(u8)" in line["config"]["parallelism"]
+    # (3,S,S) fp32 blocks of 2 frames from 2 ranks, two chunks
+    assert per_rank[0]["bytes_received_per_step"] == 2 * 2 * 2 * 3 * 64 * 64 * 4
+    assert "(f32)" in line["config"]["parallelism"] and "f32 video, all-gathered as f32" in line["result_tensor"]
     assert line["self_check"] is not None and "NOT a measurement" in line["data"]
+    u8 = line["exchange_u8"]
+    assert u8["value"] > 0 and u8["equals_u8_of_the_f32_video"] is True
 
 
-def test_bench_under_torchrun_and_f32_gather(tmp_path):
-    """The documented multi-GPU launch (``python -m torch.distributed.run ... bench.py --gpus 2``) keeps working; fp32 exchange on request."""
+def test_bench_under_torchrun_and_u8_gather(tmp_path):
+    """The documented multi-GPU launch (``python -m torch.distributed.run ... bench.py --gpus 2``) keeps working; uint8 exchange on request."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
-    line = _run(tmp_path, ["--gpus", "2", "--gather-dtype", "f32"], launcher=launcher)
-    assert line["n_gpus"] == 2 and "(f32)" in line["config"]["parallelism"]
-    assert line["config"]["per_rank"][1]["bytes_received_per_step"] == 2 * 2 * 2 * 3 * 64 * 64 * 4
+    line = _run(tmp_path, ["--gpus", "2", "--gather-dtype", "u8"], launcher=launcher)
+    assert line["n_gpus"] == 2 and "(u8)" in line["config"]["parallelism"] and "exchange_u8" not in line
+    assert "uint8 video, all-gathered as u8" in line["result_tensor"]
+    assert line["config"]["per_rank"][1]["bytes_received_per_step"] == 2 * 2 * 2 * 64 * 64 * 3
 
 
 def test_bench_single_process_line(tmp_path):

@@ -139,3 +139,47 @@ def test_frame_batch_clamp_follows_the_activation_dtype(monkeypatch):
     im.image_size = 512
     im.frame_batch = 32
     assert im.frame_batch == 32 and im.max_frame_batch() == 47
+
+
+def test_get_vis_f2pts_matches_reference_golden(monkeypatch):
+    """renders/nmr.py:639-681 ``get_vis_f2pts`` of the drop-in renderer (device-side index ops, no ``unique()``) and of the oracle
+    against the sha of the reference's OWN output (tests/golden/make_golden.py section 4: ``render/vis_f2pts_sha``, S = 64,
+    top_k = 3 as FlowComposition builds it)."""
+    import hashlib
+    emu_ops.install(monkeypatch)
+    from ipercore_amd import synthetic
+    from ipercore_amd.renders import SMPLRenderer
+    from oracle import lwg_oracle as orc
+    from tests.test_oracle_golden import _details72, S
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()          # noqa: E731
+    render = SMPLRenderer(image_size=S, has_front=True, top_k=3)          # make_golden.py:84-92
+    d = _details72()
+    f2pts, fim, wim = render.render_fim_wim(d["cam"][0:1], d["verts"][0:1], smpl_faces=True)
+    assert sha(f2pts.numpy()) == str(golden["render/f2pts_sha"]) and np.array_equal(fim.numpy(), golden["render/fim"])
+    vis = render.get_vis_f2pts(f2pts, fim)
+    assert sha(vis.numpy()) == str(golden["render/vis_f2pts_sha"])
+    want = orc.get_vis_f2pts(f2pts, fim, render.face_k_nearest.numpy())
+    assert torch.equal(vis, want)
+    n_kept = int((vis[0, :, 0, 0] != -2).sum())
+    assert 0 < n_kept < f2pts.shape[1]                 # the fixture really drops invisible faces
+    # single (nf,3,2) form and a map with NO background pixel (the reference drops the smallest id whatever it is, nmr.py:660)
+    assert torch.equal(render.get_vis_f2pts(f2pts[0], fim[0]), vis[0])
+    full = fim.clone()
+    full[full < 0] = 7
+    assert torch.equal(render.get_vis_f2pts(f2pts, full), orc.get_vis_f2pts(f2pts, full, render.face_k_nearest.numpy()))
+    assert synthetic is not None
+
+
+def test_only_vis_frames_on_emulated_abi(monkeypatch):
+    """opt.only_vis = True through Imitator's batched per-frame path (flowcomposition.py:559-562) against the oracle."""
+    emu_ops.install(monkeypatch)
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=3, ns=2)
+    plain = pu.run_hip(case, imitator=pu.make_imitator(case, frame_batch=2, device="cpu"))
+    case.opt["only_vis"] = True
+    im = pu.make_imitator(case, frame_batch=2, device="cpu")
+    assert im.flow_comp.only_vis
+    got = pu.run_hip(case, imitator=im)
+    want = pu.run_oracle(case)
+    assert (got - want).abs().max().item() <= 2e-4
+    assert (got - plain).abs().max().item() > 1e-3       # the option changes the flows (hidden source faces no longer feed the warp)
