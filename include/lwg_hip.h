@@ -27,7 +27,7 @@ extern "C" {
 typedef void* lwg_stream_t; /* hipStream_t */
 
 /* 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 3
+#define LWG_ABI_VERSION 4
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -222,6 +222,21 @@ int lwg_lwb_attention_f32(const float* q, const float* Ks, const float* Vs, cons
 /* The same block on bf16 q / Ks / Vs / out (BASELINE configs[3]: bf16 activation storage); bk / bv / T stay fp32; C in {64,128,256}. */
 int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void* Vs, const float* bk, const float* bv, const float* T, void* out,
                            int B, int ns, int h, int w, int C, int S, int src_batched, lwg_stream_t stream);
+/* The same block with the QUERY PROJECTION FOLDED INTO THE SOURCE SIDE (the form the per-frame engine runs; csrc/lwb_attn_x.hip).
+ * With q = Wq x + bq (fq, attlwb_spade_resunet.py:121-131) and the linear zero-padded warp,
+ *   K_s . q = warp_s(Wq^T Wk f_s) . x + warp_s(bq . Wk f_s) + bk . q,  the last term the same for every source: it cancels in softmax_s.
+ * Kq (nsrc,h,w,C) = (Wq^T Wk) f_src, kappa (nsrc,h,w) = (Wk^T bq) . f_src and Vs (nsrc,h,w,C) = Wv f_src are computed ONCE per source;
+ * per frame:  logit_s = (warp_s(Kq) . x + warp_s(kappa)) / sqrt(C),  out = sum_s softmax_s(logit) warp_s(Vs) + bv.
+ * Replaces, per site and frame, the fq convolution + LWB.transform + SelfAttentionBlock (:106-139, :175-191, :226-227).
+ * x, out (B,h,w,C); T (B,ns,h,w,2): flows ALREADY RESIZED to (h,w) (lwg_flow_resize_f32); K / V tensors < 3 GiB each.
+ * stats: NULL, or B * ceil(h/8) * ceil(w/8) * C * 3 floats: the kernel reads every element of x once and leaves per 8 x 8 tile the
+ * InstanceNorm partial record (count, mean, M2) of x (SPADE's parameter-free norm, :62,:83) - finish with lwg_instnorm_finalize_f32. */
+int lwg_lwb_attention_x_f32(const float* x, const float* Kq, const float* kappa, const float* Vs, const float* bv, const float* T,
+                            float* out, float* stats, int B, int ns, int h, int w, int C, int src_batched, lwg_stream_t stream);
+int lwg_lwb_attention_x_bf16(const void* x, const void* Kq, const float* kappa, const void* Vs, const float* bv, const float* T,
+                             void* out, float* stats, int B, int ns, int h, int w, int C, int src_batched, lwg_stream_t stream);
+/* ws (B,nrec,C,3) records (count, mean, M2) -> mean, rstd (B,C); rstd = 1 / sqrt(M2 / n + eps) (nn.InstanceNorm2d: biased variance). */
+int lwg_instnorm_finalize_f32(const float* ws, int B, int C, int nrec, float eps, float* mean, float* rstd, lwg_stream_t stream);
 /* Backward of the above for the personalization step (lwg_trainer.py:649-697 runs the same block under autograd; the
  * flows are constants there).  dq is written; dKs / dVs are accumulated with fp32 atomics and must be zero on entry;
  * ns <= 8.  The bias gradients need no kernel: dbv = column sum of dout, dbk = 0. */

@@ -81,6 +81,9 @@ _SIGS = {
     "lwg_head_compose_bf16": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "lwg_flow_resize_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_lwb_fuse_f32": (c_i, [c_f] * 5 + [c_i] * 7 + [ctypes.c_float, ctypes.c_float, c_f]),
+    "lwg_lwb_attention_x_f32": (c_i, [c_f] * 8 + [c_i] * 6 + [c_f]),
+    "lwg_lwb_attention_x_bf16": (c_i, [c_f] * 8 + [c_i] * 6 + [c_f]),
+    "lwg_instnorm_finalize_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f]),
     "lwg_lwb_attention_bwd_f32": (c_i, [c_f] * 10 + [c_i] * 7 + [c_f]),
     "lwg_lwb_attention_kv_f32": (c_i, [c_f] * 6 + [c_i] * 7 + [c_f]),
     "lwg_lwb_attention_kv_bwd_f32": (c_i, [c_f] * 8 + [c_i] * 7 + [c_f]),
@@ -136,7 +139,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 3:
+        if handle.lwg_abi_version() != 4:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -43,9 +43,8 @@ class TemporalFIFO(object):
         self.ns = src_feats.ns
         self.f2pts = torch.cat([src_f2pts, src_f2pts.new_zeros((time_step,) + tuple(src_f2pts.shape[1:]))], dim=0)
         self.kv = []
-        for k, v in src_feats.kv:
-            pad = k.new_zeros((time_step,) + tuple(k.shape[1:]))
-            self.kv.append((torch.cat([k, pad], dim=0), torch.cat([v, pad.clone()], dim=0)))
+        for site in src_feats.kv:                   # (Kq, V, kappa) per attention site: one ring tensor each
+            self.kv.append(tuple(torch.cat([t, t.new_zeros((time_step,) + tuple(t.shape[1:]))], dim=0) for t in site))
         self.src_feats = src_feats
 
     @property
@@ -56,16 +55,16 @@ class TemporalFIFO(object):
         """f2pts (1,nf,3,2) of the frame just synthesized; feats: SourceFeatures of forward_src([pred, cond])."""
         i = self.ns + self.index % self.time_step
         self.f2pts[i:i + 1].copy_(f2pts)
-        for (K, V), (k, v) in zip(self.kv, feats.kv):
-            K[i:i + 1].copy_(k)
-            V[i:i + 1].copy_(v)
+        for ring, new in zip(self.kv, feats.kv):
+            for R, t in zip(ring, new):
+                R[i:i + 1].copy_(t)
         self.index += 1
 
     def view(self):
         """(f2pts (ns+nt,nf,3,2), SourceFeatures over ns+nt entries) - slots in ring order, as the reference concatenates."""
         n = self.ns + self.nt
         from .networks.generator import SourceFeatures
-        return self.f2pts[:n], SourceFeatures(self.src_feats.enc, self.src_feats.res, [(K[:n], V[:n]) for K, V in self.kv], n, False)
+        return self.f2pts[:n], SourceFeatures(self.src_feats.enc, self.src_feats.res, [tuple(R[:n] for R in ring) for ring in self.kv], n, False)
 
 
 class Imitator(object):

@@ -86,11 +86,17 @@ class _Packed:
             return [P.spec_to(s, dev) for s in P.pack_conv_transpose(sd[name + ".weight"], sd.get(name + ".bias"), n_pad)]
 
         def site(p):
+            # the query projection folded into the source side (csrc/lwb_attn_x.hip): Kq = (Wq^T Wk) f, kappa = (Wk^T bq) . f per source
+            # texel - the per-frame fq convolution, the q tensor and bk (constant over the sources: it cancels in the softmax) disappear
+            Wq = sd[p + ".fq.weight"].detach()[:, :, 0, 0].double()
+            Wk = sd[p + ".fk.weight"].detach()[:, :, 0, 0].double()
+            bq = sd[p + ".fq.bias"].detach().double()
+            Wkq = (Wq.t() @ Wk).float()[:, :, None, None].contiguous()
+            wkap = (Wk.t() @ bq).float()[None, :, None, None].contiguous()
             d = {
-                "fq": conv(p + ".fq", pad=0),
-                "fk": P.spec_to(P.pack_conv(sd[p + ".fk.weight"], None, 1, 0), dev),     # bias added after the warp
-                "fv": P.spec_to(P.pack_conv(sd[p + ".fv.weight"], None, 1, 0), dev),
-                "bk": sd[p + ".fk.bias"].detach().float().contiguous(),
+                "fkq": P.spec_to(P.pack_conv(Wkq, None, 1, 0), dev),
+                "fkap": P.spec_to(P.pack_conv(wkap, None, 1, 0, None, 64), dev),          # one output column, zero-extended to the kernel's 64
+                "fv": P.spec_to(P.pack_conv(sd[p + ".fv.weight"], None, 1, 0), dev),     # bias added after the warp
                 "bv": sd[p + ".fv.bias"].detach().float().contiguous(),
                 "shared": conv(p + ".spade.mlp_shared.0"),
                 "gb": P.spec_to(P.pack_spade_gamma_beta(sd[p + ".spade.mlp_gamma.weight"], sd[p + ".spade.mlp_gamma.bias"],
@@ -224,9 +230,12 @@ class AttentionLWBGenerator(nn.Module):
         for feats, sites in ((enc, pk.enc_sites), (res, pk.res_sites)):
             for f, st in zip(feats, sites):
                 if self.lwb_kind == "att":
-                    kv.append((ops.conv2d(f, st["fk"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f))))
+                    n, h, w, _ = f.shape
+                    with ops.conv_precision("fp32" if self.conv_precision == "bf16" else self.conv_precision):     # the logit offset stays fp32
+                        kap = ops.conv2d(f.float(), st["fkap"], f.new_empty(n, h, w, 64, dtype=torch.float32))[..., 0].contiguous()
+                    kv.append((ops.conv2d(f, st["fkq"], torch.empty_like(f)), ops.conv2d(f, st["fv"], torch.empty_like(f)), kap))
                 else:
-                    kv.append((f, None))
+                    kv.append((f, None, None))
         return kv
 
     def _attlwb(self, st, tsf_x, kv, Tst, batched, scratch):
@@ -242,13 +251,15 @@ class AttentionLWBGenerator(nn.Module):
             g = ops.conv2d(g, st["g2"], torch.empty_like(tsf_x), act=ops.ACT_SIGMOID)
             return ops.lwb_fuse(tsf_x, kv[0], Tst, torch.empty_like(tsf_x), gate=g,
                                 scale_w=1.0 if self.lwb_kind == "sg_add" else 1.0 / ns, src_batched=batched)
-        q = ops.conv2d(tsf_x, st["fq"], torch.empty_like(tsf_x))
-        att = ops.lwb_attention(q, kv[0], kv[1], st["bk"], st["bv"], scratch.flow(Tst, h, w), torch.empty_like(tsf_x), src_batched=batched)
+        # ONE pass over tsf_x: the attention (query projection folded into kv[0] = Kq / kv[2] = kappa) and the per-tile partial statistics
+        # of SPADE's InstanceNorm of tsf_x
         mean = tsf_x.new_empty(B, C, dtype=torch.float32)
         rstd = tsf_x.new_empty(B, C, dtype=torch.float32)
-        nsplit = max(1, min(64, (h * w) // 64))
-        ws = scratch.get(B * C * nsplit * 3, tsf_x.device)
-        ops.instnorm_stats(tsf_x, mean, rstd, ws, eps=1e-5, nsplit=nsplit)
+        nrec = ops.attn_tiles(h, w)
+        ws = scratch.get(B * nrec * C * 3, tsf_x.device)
+        att = ops.lwb_attention_x(tsf_x, kv[0], kv[2], kv[1], st["bv"], scratch.flow(Tst, h, w), torch.empty_like(tsf_x), stats=ws,
+                                  src_batched=batched)
+        ops.instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5)
         actv = ops.conv2d(att, st["shared"], tsf_x.new_empty(B, h, w, st["shared"].N), act=ops.ACT_RELU)
         return ops.conv2d(actv, st["gb"], torch.empty_like(tsf_x), epi=ops.EPI_SPADE, xn=tsf_x, mean=mean, rstd=rstd)
 
@@ -407,8 +418,8 @@ class AttentionLWBGenerator(nn.Module):
             if bs != 1:
                 raise NotImplementedError("temporal attention runs one clip per process (bs = 1), as Imitator.inference does")
             tfe = self._features_from_api(temp_enc_outs, temp_res_outs, bs)
-            feats = SourceFeatures(feats.enc, feats.res, [(torch.cat([k, tk], dim=0), torch.cat([v, tv], dim=0))
-                                                          for (k, v), (tk, tv) in zip(feats.kv, tfe.kv)],
+            feats = SourceFeatures(feats.enc, feats.res, [tuple(torch.cat([a, ta], dim=0) for a, ta in zip(site, tsite))
+                                                          for site, tsite in zip(feats.kv, tfe.kv)],
                                    feats.ns + Ttt.shape[1], batched=False)
             T = torch.cat([T, Ttt.contiguous().float()], dim=1).contiguous()
         tsf8 = ops.nchw_to_nhwc(tsf_inputs.contiguous().float(), c_pad=8)
@@ -491,8 +502,6 @@ class _Scratch:
         """The (B,ns,S,S,2) flows resized to (h,w) - LWB.resize_trans - once per frame batch and resolution (seven of the nine attention
         sites share one): the block kernels then read one coalesced value per pixel and source instead of resizing per pixel."""
         if Tst.shape[2] == h and Tst.shape[3] == w:
-            return Tst
-        if h != w:                                        # the kernels take a square field: fall back to their in-kernel resize
             return Tst
         key = (h, w, Tst.data_ptr())
         if key not in self.flows:

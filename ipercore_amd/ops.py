@@ -357,6 +357,39 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     return out
 
 
+def attn_tiles(h, w):
+    """Records per image the statistics form of ``lwb_attention_x`` leaves: one per 8 x 8-pixel tile."""
+    return ((h + 7) // 8) * ((w + 7) // 8)
+
+
+def lwb_attention_x(x, Kq, kappa, Vs, bv, T, out, stats=None, src_batched=False):
+    """The attention-form Liquid Warping Block with the query projection folded into the source side (csrc/lwb_attn_x.hip):
+    logit_s = (warp_s(Kq) . x + warp_s(kappa)) / sqrt(C), out = sum_s softmax_s(logit) warp_s(Vs) + bv.
+    x (B,h,w,C) fp32 | bf16; Kq, Vs (nsrc,h,w,C) in x's dtype; kappa (nsrc,h,w) fp32; T (B,ns,h,w,2) flows ALREADY at (h,w).
+    stats: None or a fp32 buffer of >= B * attn_tiles(h,w) * C * 3 floats receiving the per-tile InstanceNorm records of x."""
+    B, h, w, C = x.shape
+    ns = T.shape[1]
+    nsrc = B * ns if src_batched else ns
+    assert tuple(T.shape) == (B, ns, h, w, 2), (tuple(T.shape), (B, ns, h, w, 2))
+    assert tuple(Kq.shape) == (nsrc, h, w, C) and tuple(Vs.shape) == (nsrc, h, w, C) and tuple(kappa.shape) == (nsrc, h, w)
+    assert Kq.dtype == x.dtype and Vs.dtype == x.dtype and out.dtype == x.dtype and kappa.dtype == torch.float32
+    assert stats is None or stats.numel() >= B * attn_tiles(h, w) * C * 3
+    if x.dtype == torch.bfloat16:
+        bf = torch.bfloat16
+        _lib.check(_lib.lib().lwg_lwb_attention_x_bf16(_ptr(x, bf), _ptr(Kq, bf), _ptr(kappa), _ptr(Vs, bf), _ptr(bv), _ptr(T), _ptr(out, bf),
+                                                        _ptr(stats), B, ns, h, w, C, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_x_bf16")
+        return out
+    _lib.check(_lib.lib().lwg_lwb_attention_x_f32(_ptr(x), _ptr(Kq), _ptr(kappa), _ptr(Vs), _ptr(bv), _ptr(T), _ptr(out), _ptr(stats), B, ns, h, w,
+                                                   C, 1 if src_batched else 0, _stream()), "lwg_lwb_attention_x_f32")
+    return out
+
+
+def instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5):
+    """(B, nrec, C, 3) records (count, mean, M2) -> mean, rstd (B, C) of nn.InstanceNorm2d (biased variance)."""
+    assert ws.numel() >= B * nrec * C * 3
+    _lib.check(_lib.lib().lwg_instnorm_finalize_f32(_ptr(ws), B, C, nrec, float(eps), _ptr(mean), _ptr(rstd), _stream()), "lwg_instnorm_finalize_f32")
+
+
 def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batched=False):
     """out = (tsf_x + gate * scale_w * sum_s warp_s(src_x)) * scale_o - AddLWB / AvgLWB / SoftGateLWB fusion."""
     B, h, w, C = tsf_x.shape

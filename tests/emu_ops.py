@@ -73,10 +73,10 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
     return y
 
 
-def conv_transpose2d(x, specs, y, act=0):
+def conv_transpose2d(x, specs, y, act=0, splitk=False, out_hw=None):
     """ops.conv_transpose2d's contract: ConvTranspose2d(4, 2, 1) given its four parity specs = the four parity launches."""
     for s in specs:
-        conv2d(x, s, y, act=act)
+        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s))
     return y
 
 
@@ -147,9 +147,9 @@ def flow_resize(T, h, w):
 
 def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False, _differentiable=False):
     B, h, w, C = q.shape
-    ns, S = T.shape[1], T.shape[2]
-    Tf = T.reshape(B * ns, S, S, 2)
-    if S != h:
+    ns = T.shape[1]
+    Tf = T.reshape(B * ns, T.shape[2], T.shape[3], 2)
+    if (T.shape[2], T.shape[3]) != (h, w):
         Tf = F.interpolate(Tf.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     if src_batched:
         Kn, Vn = Ks, Vs
@@ -166,6 +166,52 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False, _differentiable=
         return res
     out.copy_(res)
     return out
+
+
+def lwb_attention_x(x, Kq, kappa, Vs, bv, T, out, stats=None, src_batched=False):
+    """lwg_lwb_attention_x_*'s contract (include/lwg_hip.h): logit_s = (warp_s(Kq) . x + warp_s(kappa)) / sqrt(C),
+    out = sum_s softmax_s(logit) warp_s(Vs) + bv; stats: per 8 x 8 tile the (count, mean, M2) record of x."""
+    B, h, w, C = x.shape
+    ns = T.shape[1]
+    assert tuple(T.shape) == (B, ns, h, w, 2)
+    Tf = T.reshape(B * ns, h, w, 2).to(x.dtype if x.dtype == torch.float64 else torch.float32)
+    rep = (lambda t: t) if src_batched else (lambda t: t.repeat(B, *([1] * (t.dim() - 1))))
+    cdt = Tf.dtype
+    Kw = F.grid_sample(rep(Kq).to(cdt).permute(0, 3, 1, 2), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    Vw = F.grid_sample(rep(Vs).to(cdt).permute(0, 3, 1, 2), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    aw = F.grid_sample(rep(kappa).to(cdt).unsqueeze(1), Tf, mode="bilinear", padding_mode="zeros", align_corners=False)
+    Kw, Vw, aw = Kw.view(B, ns, C, h, w), Vw.view(B, ns, C, h, w), aw.view(B, ns, 1, h, w)
+    logits = ((Kw * x.to(cdt).permute(0, 3, 1, 2).unsqueeze(1)).sum(dim=2, keepdim=True) + aw) / math.sqrt(C)
+    a = torch.softmax(logits, dim=1)
+    res = (a * Vw).sum(dim=1).permute(0, 2, 3, 1) + bv.to(cdt).view(1, 1, 1, C)
+    out.copy_(res.to(out.dtype))
+    if stats is not None:
+        ty, tx = (h + 7) // 8, (w + 7) // 8
+        rec = stats[:B * ty * tx * C * 3].view(B, ty * tx, C, 3)
+        xf = x.float()
+        for i in range(ty):
+            for j in range(tx):
+                blk = xf[:, i * 8:(i + 1) * 8, j * 8:(j + 1) * 8, :].reshape(B, -1, C)
+                mu = blk.mean(dim=1)
+                rec[:, i * tx + j, :, 0] = blk.shape[1]
+                rec[:, i * tx + j, :, 1] = mu
+                rec[:, i * tx + j, :, 2] = ((blk - mu[:, None, :]) ** 2).sum(dim=1)
+    return out
+
+
+def instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5):
+    """lwg_instnorm_finalize_f32's contract: merge the (count, mean, M2) records of an image (exactly, in fp64)."""
+    rec = ws[:B * nrec * C * 3].view(B, nrec, C, 3).double()
+    n, mu, m2 = rec[..., 0], rec[..., 1], rec[..., 2]
+    tot = n.sum(dim=1)
+    gm = (n * mu).sum(dim=1) / tot
+    var = (m2 + n * (mu - gm[:, None, :]) ** 2).sum(dim=1) / tot
+    mean.copy_(gm.float())
+    rstd.copy_((1.0 / torch.sqrt(var + eps)).float())
+
+
+def attn_tiles(h, w):
+    return ((h + 7) // 8) * ((w + 7) // 8)
 
 
 def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batched=False):
@@ -412,7 +458,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -218,6 +218,65 @@ def check_lwb_attention():
     return out
 
 
+def check_lwb_attention_x():
+    """The engine's attention block (csrc/lwb_attn_x.hip: query projection folded into the source side, background waves skip their
+    gathers, per-tile InstanceNorm records of x) against the ORIGINAL formulation evaluated in fp64 - q = Wq x + bq, K_s = warp_s(Wk f) + bk,
+    V_s = warp_s(Wv f) + bv, softmax over the sources (attlwb_spade_resunet.py:106-139, 226-227) - from the same raw weights; the
+    statistics against torch; a frame bitwise independent of its batch; sizes that are not a multiple of the 8-pixel tile."""
+    out = {}
+    for (B, ns, h, w, C, batched, dt) in ((2, 2, 16, 16, 64, False, "f32"), (1, 3, 8, 8, 256, False, "f32"), (3, 2, 24, 24, 128, False, "f32"),
+                                          (2, 2, 8, 8, 64, True, "f32"), (2, 2, 12, 20, 64, False, "f32"), (2, 8, 16, 16, 32, False, "f32"),
+                                          (2, 2, 16, 16, 64, False, "bf16"), (2, 2, 16, 16, 256, False, "bf16"), (3, 3, 24, 24, 128, False, "bf16")):
+        key = f"{dt}_C{C}_{h}x{w}_ns{ns}_b{int(batched)}"
+        n_src = B * ns if batched else ns
+        x, f = _rand((B, h, w, C), 140), _rand((n_src, h, w, C), 143)
+        Wq, Wk, Wv = (_rand((C, C), 160 + i, 1.0 / np.sqrt(C)) for i in range(3))
+        bq, bk, bv = _rand((C,), 141, 0.3), _rand((C,), 142, 0.3), _rand((C,), 144, 0.3)
+        T = _flows(B, ns, max(h, w), 145 + C)[:, :, :h, :w].contiguous()
+        T[0, :, : h // 2] = -2.0                                  # whole background tiles / waves: the no-gather path
+        adt = torch.bfloat16 if dt == "bf16" else torch.float32
+        xs, fs = x.to(adt), f.to(adt)
+        # once per source (what generator._project_sources does): Kq, kappa, V in the storage type
+        Kq = (fs.double() @ (Wq.double().t() @ Wk.double()).t()).to(adt)
+        Vs = (fs.double() @ Wv.double().t()).to(adt)
+        kap = (fs.double() @ (Wk.double().t() @ bq.double())).float()
+        # the reference order in fp64 on the same (storage-rounded) x / f
+        q64 = xs.double() @ Wq.double().t() + bq.double()
+        want = emu_ops.lwb_attention(q64, fs.double() @ Wk.double().t(), fs.double() @ Wv.double().t(), bk.double(), bv.double(), T.double(),
+                                     torch.zeros(B, h, w, C).double(), src_batched=batched)
+        nrec = ops.attn_tiles(h, w)
+        ws = torch.full((B * nrec * C * 3,), float("nan"), device=DEV)
+        got = ops.lwb_attention_x(xs.to(DEV), Kq.to(DEV), kap.to(DEV), Vs.to(DEV), bv.to(DEV), T.to(DEV),
+                                  torch.full((B, h, w, C), float("nan"), device=DEV, dtype=adt), stats=ws, src_batched=batched)
+        mean, rstd = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+        ops.instnorm_finalize(ws, B, C, nrec, mean, rstd)
+        torch.cuda.synchronize()
+        err = (got.float().cpu().double() - want).abs()
+        m = {"max_abs": err.max().item(), "mean_abs": err.mean().item(), "ref_max": want.abs().max().item()}
+        # fp32: the fold re-associates the logit (Kq = (Wq^T Wk) f rounded once); bf16: Kq / V / out are stored with 8 mantissa bits
+        tol_max, tol_mean = (1e-4, 5e-6) if dt == "f32" else (3e-2, 2e-3)
+        assert m["max_abs"] <= tol_max * max(1.0, m["ref_max"]) and m["mean_abs"] <= tol_mean, (key, m)
+        v = xs.float().reshape(B, h * w, C)
+        m["mean_err"] = (mean.cpu() - v.mean(dim=1)).abs().max().item()
+        m["rstd_rel_err"] = ((rstd.cpu() * torch.sqrt(v.var(dim=1, unbiased=False) + 1e-5)) - 1).abs().max().item()
+        assert m["mean_err"] <= 2e-6 and m["rstd_rel_err"] <= 2e-6, (key, m)
+        # statistics off: same output; one frame alone: bitwise the batched frame (and its statistics)
+        got2 = ops.lwb_attention_x(xs.to(DEV), Kq.to(DEV), kap.to(DEV), Vs.to(DEV), bv.to(DEV), T.to(DEV),
+                                   torch.empty(B, h, w, C, device=DEV, dtype=adt), stats=None, src_batched=batched)
+        assert torch.equal(got, got2), key + ": the statistics form changes the output"
+        b1 = B - 1
+        sl = slice(b1 * ns, (b1 + 1) * ns) if batched else slice(None)
+        ws1 = torch.empty(nrec * C * 3, device=DEV)
+        one = ops.lwb_attention_x(xs[b1:b1 + 1].to(DEV), Kq[sl].to(DEV), kap[sl].to(DEV), Vs[sl].to(DEV), bv.to(DEV), T[b1:b1 + 1].to(DEV),
+                                  torch.empty(1, h, w, C, device=DEV, dtype=adt), stats=ws1, src_batched=batched)
+        m1, r1 = torch.empty(1, C, device=DEV), torch.empty(1, C, device=DEV)
+        ops.instnorm_finalize(ws1, 1, C, nrec, m1, r1)
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], got[b1]) and torch.equal(m1[0], mean[b1]) and torch.equal(r1[0], rstd[b1]), key + ": a frame depends on its batch"
+        out[key] = m
+    return out
+
+
 def check_head_and_layout():
     out = {}
     B, S, C = 2, 40, 64                                    # S not a multiple of the 32-pixel tile
@@ -2081,7 +2140,7 @@ def check_attention_backward():
     return out
 
 
-ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention,
+ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16,
