@@ -620,7 +620,7 @@ def main(argv=None):
     if args.precision != "fp32":
         im.generator.conv_precision = args.precision
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
-    FB_requested, FB = FB, im.frame_batch        # what RUNS: the imitator clamps the request to the 3 GiB-per-tensor limit of the conv kernels
+    FB_requested, FB = FB, im.frame_batch        # (no clamp any more: batches beyond the kernels' 3 GiB buffer range are sliced inside the C entry points)
     if rank == 0:                                                # what tools/pmc_summary.py stamps the PMC traffic file with
         try:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -38,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
-            panel_cache=None, branch=None, overlap_d=None, _keep=None):
+            panel_cache=None, branch=None, overlap_d=None, _keep=None, dp_schedule=None):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -46,6 +46,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     from ipercore_amd.trainers import LWGTrainer, PatchGlobalDiscriminator, TrainOpts
 
     S, ns = size, 2
+    on_gpu = torch.device(dev).type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)        # --device cpu: the CPU test-suite's plumbing run (emulated C ABI)
     nf, nres, bgf = [64, 128, 256], 6, [64, 128, 128, 256]
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=syn.gen_cfg(nf, nres, bgf), temporal=False)
     sd = syn.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
@@ -80,6 +82,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         topts.branch_streams = bool(branch)
     if overlap_d is not None:
         topts.overlap_d_step = bool(overlap_d)
+    if dp_schedule is not None:
+        topts.dp_schedule = dp_schedule
     tr = LWGTrainer(G, D, opts=topts)
     tr.set_input(inp)
     if _keep is not None:
@@ -115,26 +119,26 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     per_step = flops[0] + wg[0]
     for _ in range(warmup):
         tr.optimize_parameters()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         lg, ld = tr.optimize_parameters()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     # host share: one step from an idle queue - time until the last launch is enqueued vs until the GPU is done
     host_ms, total_ms = [], []
     for _ in range(3):
-        torch.cuda.synchronize()
+        sync()
         h0 = time.perf_counter()
         tr.optimize_parameters()
         h1 = time.perf_counter()
-        torch.cuda.synchronize()
+        sync()
         host_ms.append((h1 - h0) * 1e3)
         total_ms.append((time.perf_counter() - h0) * 1e3)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -148,7 +152,8 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     return {
         "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(steps * world / dt, 4),
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "dtype": "f32" if precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "dtype": "f32" if precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)",
+        "data": "synthetic" + ("" if on_gpu else " (CPU plumbing run over the emulated C ABI: NOT a measurement)"),
         "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if use_vgg else "L1") + " tsf" + (" + Sphere20a face" if use_face else "") + " + BCE mask + TV",
                    "global_batch": world,
                    "parallelism": f"dp{world}: the flat gradient buffers of G and D all-reduced over RCCL ({nG} + {nD} fp32 gradients = "
@@ -220,7 +225,7 @@ def breakdown(dev, size=512, steps=3):
         json.dump(out, fp, indent=1)
 
 
-def main():
+def main(argv=None):
     import faulthandler
     faulthandler.enable()
     ap = argparse.ArgumentParser()
@@ -246,17 +251,27 @@ def main():
     ap.add_argument("--no-kv-pair", dest="kv_pair", action="store_false", help="lab: the fk / fv projections as two 1x1 convolutions")
     ap.add_argument("--no-spade-pair", dest="spade_pair", action="store_false", help="lab: SPADE's gamma / beta convolutions as two launches per pass")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
-    args = ap.parse_args()
-    self_launch_if_needed()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend; nccl = RCCL (the product)")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
+                    help="cpu: plumbing dry run for the CPU test-suite ONLY (tests/test_bench_launch.py installs the emulated C ABI around "
+                         "main(); without it every op raises on CPU tensors - there is no CPU product path)")
+    args = ap.parse_args(argv)
+    self_launch_if_needed(sys.argv[1:] if argv is None else argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.device == "cuda":
+        assert torch.cuda.is_available(), "needs the MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group("gloo", init_method="env://")
     assert args.gpus == world
     if not args.fused_convt:
         from ipercore_amd.networks import training as _tr
@@ -283,7 +298,8 @@ def main():
         return breakdown(dev, args.size)
     res = measure(dev, args.steps, args.warmup, args.size, args.use_vgg, args.use_face, args.precision, rank, world,
                   graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
-                  branch=None if args.branch_streams else False, overlap_d=None if args.overlap_d else False)
+                  branch=None if args.branch_streams else False, overlap_d=None if args.overlap_d else False,
+                  dp_schedule="segmented" if (args.device == "cpu" and world > 1) else None)     # no graphs on the CPU: the same segment schedule, eager
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

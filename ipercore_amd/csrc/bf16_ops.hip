@@ -334,14 +334,27 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : (NCB == 3 ? 3 : 4)) void lwg_he
     }
 }
 
-// x (B,S,S,64) bf16 NHWC (< 3 GiB); wb: the bf16 operand panel of ipercore_amd.networks.packing.pack_head_bf16 ([5][2][2][64][8]);
+// x (B,S,S,64) bf16 NHWC (any batch: beyond 3 GiB the launch runs in slices of frames); wb: the bf16 operand panel of ipercore_amd.networks.packing.pack_head_bf16 ([5][2][2][64][8]);
 // bg / pred / mask / img as in lwg_head_compose_f32 (fp32 NCHW).
 extern "C" int lwg_head_compose_bf16(const void* x, const void* wb, const float* bg, size_t bg_bstride, int B, int S, int C, float* pred,
                                      float* mask, float* img, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !wb || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C != 64 || B > 65535) return (int)hipErrorInvalidValue;
-    const unsigned long long xbytes = (unsigned long long)B * S * S * 128ull;
-    if (xbytes >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    const unsigned long long per = (unsigned long long)S * S * 128ull;
+    if (per >= 0xC0000000ull) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)B * per >= 0xC0000000ull) {     // the halo goes through 32-bit buffer offsets: larger batches run in slices of frames
+        const int nbs = (int)((0xC0000000ull - 1ull) / per);
+        const size_t plane = (size_t)S * S;
+        for (int b0 = 0; b0 < B; b0 += nbs) {
+            const int nb = B - b0 < nbs ? B - b0 : nbs;
+            const int e = lwg_head_compose_bf16(static_cast<const char*>(x) + (size_t)b0 * per, wb, bg ? bg + (size_t)b0 * bg_bstride : bg, bg_bstride, nb, S,
+                                                C, pred ? pred + (size_t)b0 * 3 * plane : pred, mask ? mask + (size_t)b0 * plane : mask,
+                                                img ? img + (size_t)b0 * 3 * plane : img, stream_);
+            if (e != 0) return e;
+        }
+        return 0;
+    }
+    const unsigned long long xbytes = (unsigned long long)B * per;
     constexpr int ncb = LWG_HEAD16_NCB;             // 16-pixel column blocks per tile row (compile-time, lwg_common.h)
     static_assert(ncb == 2 || ncb == 3 || ncb == 4, "LWG_HEAD16_NCB");
     const int tw = ncb == 3 ? 32 : 16 * ncb - 4;

@@ -33,6 +33,7 @@
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
+#include "lwg_conv_slices.h"
 #include "lwg_conv_epilogue.h"
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
@@ -530,6 +531,10 @@ extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stre
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return ws ? 1 : lwg_conv2d_nhwc_f32_ws(&s, nullptr, stream_); }, &sliced_err)) return sliced_err;
+    }
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
     if (a.N % 64 != 0 || (Cin & 3) != 0 || (a.YC & 3) != 0 || (a.ycoff & 3) != 0) return (int)hipErrorInvalidValue;
@@ -579,6 +584,10 @@ extern "C" int lwg_conv_transpose4_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t 
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv_transpose4_nhwc_f32(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.stride != 1 || a.omul != 2 || a.ooy != 0 || a.oox != 0 || a.C1 != 0 ||
         a.epi != LWG_EPI_NONE || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.C0 % 32 != 0 || a.N % 64 != 0 || (a.YC & 3) != 0 ||
         (a.ycoff & 3) != 0 || a.OH != a.H || a.OW != a.W || a.YH != 2 * a.H || a.YW != 2 * a.W)

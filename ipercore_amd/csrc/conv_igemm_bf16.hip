@@ -23,6 +23,7 @@
 // Epilogues: bias, ReLU / tanh / sigmoid, residual add, SPADE's IN(x) * (1 + gamma) + beta - all read / written as bf16.
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
+#include "lwg_conv_slices.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -699,6 +700,10 @@ extern "C" int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv_transpose4_nhwc_bf16(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.C1 != 0 || (a.C0 != 64 && a.C0 != 128)) return (int)hipErrorInvalidValue;
     if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16 || a.stride != 1 || a.H != a.OH || a.W != a.OW || a.omul != 2) return (int)hipErrorInvalidValue;
     if (a.YH != 2 * a.OH || a.YW != 2 * a.OW || a.N % 64 != 0 || (a.YC & 7) != 0 || (a.ycoff & 7) != 0 || a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
@@ -904,6 +909,10 @@ extern "C" int lwg_conv2d_nhwc_c8_bf16(const LwgConvArgs* pa, lwg_stream_t strea
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv2d_nhwc_c8_bf16(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps < 1 || a.ntaps > 10) return (int)hipErrorInvalidValue;
     if (a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_BF16 || a.C0 != 8 || a.C1 != 0 || a.N != 64 || a.epi != LWG_EPI_NONE) return (int)hipErrorInvalidValue;
     if ((a.YC & 7) != 0 || (a.ycoff & 7) != 0 || a.stride < 1) return (int)hipErrorInvalidValue;
@@ -926,6 +935,10 @@ extern "C" int lwg_conv2d_nhwc_bf16_hr(const LwgConvArgs* pa, lwg_stream_t strea
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv2d_nhwc_bf16_hr(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 4 && a.ntaps != 1)) return (int)hipErrorInvalidValue;
     if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16 || a.stride != 1 || a.H != a.OH || a.W != a.OW) return (int)hipErrorInvalidValue;
@@ -996,6 +1009,10 @@ extern "C" int lwg_conv2d_nhwc_bf16(const LwgConvArgs* pa, lwg_stream_t stream_)
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv2d_nhwc_bf16(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
     if (a.xdt != LWG_DT_BF16 || a.ydt != LWG_DT_BF16) return (int)hipErrorInvalidValue;

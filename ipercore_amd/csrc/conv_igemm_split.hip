@@ -26,6 +26,7 @@
 
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
+#include "lwg_conv_slices.h"
 #include "lwg_conv_epilogue.h"
 
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
@@ -650,6 +651,10 @@ extern "C" int lwg_conv2d_nhwc_f32_split(const LwgConvArgs* pa, lwg_stream_t str
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
+    {   // inputs beyond the 32-bit buffer-offset range: the same launch in batch slices (lwg_conv_slices.h)
+        int sliced_err = 0;
+        if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv2d_nhwc_f32_split(&s, stream_); }, &sliced_err)) return sliced_err;
+    }
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
     if (a.N % 64 != 0 || Cin % 32 != 0 || (a.YC & 3) != 0 || (a.ycoff & 3) != 0) return (int)hipErrorInvalidValue;

@@ -27,7 +27,10 @@ template <> struct AttnXTraits<float> {
     static constexpr int CPL = 4;
     __device__ static __forceinline__ void unpack(const uintx4 v, float (&f)[4]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f[k] = __builtin_bit_cast(float, v[k]);
+        for (int k = 0; k < 4; ++k) {
+            const unsigned u = v[k];           // (a bit_cast applied to the vector-element lvalue itself reads element 0 for every k)
+            f[k] = __builtin_bit_cast(float, u);
+        }
     }
     __device__ static __forceinline__ uintx4 pack(const float (&f)[4]) {
         uintx4 v;
@@ -281,42 +284,49 @@ extern "C" int lwg_lwb_attention_x_bf16(const void* x, const void* Kq, const flo
 }
 
 // Merge of the per-tile records the STATS form leaves: ws (B, nrec, C, 3) = (count, mean, M2) -> mean / rstd (B, C).  One workgroup per
-// (frame, 64 channels): lane = channel (a wave reads 768 contiguous bytes per record), wave k folds records k, k + 16, ... with Chan's
-// update, the 16 partials are folded in wave order.  The order depends on nrec only: a frame's statistics do not depend on its batch.
+// (frame, 64 channels): lane = channel (a wave reads 768 contiguous bytes per record), wave k takes records k, k + 16, ...  Two passes of
+// plain sums instead of a chain of pairwise (Chan) updates with a division each: mu = sum n_i mean_i / sum n_i, then
+// M2 = sum [M2_i + n_i (mean_i - mu)^2]; the 16 per-wave partials are added in wave order.  The order depends on nrec only: a frame's
+// statistics do not depend on its batch.
 __global__ __launch_bounds__(1024) void lwg_in_stats_merge_tiles(const float* __restrict__ ws, int C, int nrec, float eps,
                                                                 float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
     const bool cok = c < C;
-    float n = 0.f, mu = 0.f, m2 = 0.f;
+    const float* base = ws + ((size_t)b * nrec * C + (cok ? c : 0)) * 3;
+    __shared__ float sh[16][2][64];
+    float sn = 0.f, sm = 0.f;
     if (cok) {
         for (int r = wid; r < nrec; r += 16) {
-            const float* o = ws + (((size_t)b * nrec + r) * C + c) * 3;
-            const float nb = o[0];
-            if (nb <= 0.f) continue;
-            const float tot = n + nb, delta = o[1] - mu, f = nb / tot;
-            mu = __builtin_fmaf(delta, f, mu);
-            m2 += o[2] + delta * delta * (n * f);
-            n = tot;
+            const float* o = base + (size_t)r * C * 3;
+            sn += o[0];
+            sm = __builtin_fmaf(o[0], o[1], sm);
         }
     }
-    __shared__ float sh[16][3][64];
-    sh[wid][0][lane] = n;
-    sh[wid][1][lane] = mu;
-    sh[wid][2][lane] = m2;
+    sh[wid][0][lane] = sn;
+    sh[wid][1][lane] = sm;
+    __syncthreads();
+    float tn = 0.f, tm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tn += sh[k][0][lane]; tm += sh[k][1][lane]; }
+    const float mu = tm / tn;
+    __syncthreads();
+    float sq = 0.f;
+    if (cok) {
+        for (int r = wid; r < nrec; r += 16) {
+            const float* o = base + (size_t)r * C * 3;
+            const float d = o[1] - mu;
+            sq += __builtin_fmaf(o[0] * d, d, o[2]);
+        }
+    }
+    sh[wid][0][lane] = sq;
     __syncthreads();
     if (wid == 0 && cok) {
-        n = sh[0][0][lane]; mu = sh[0][1][lane]; m2 = sh[0][2][lane];
-        for (int k = 1; k < 16; ++k) {
-            const float nb = sh[k][0][lane];
-            if (nb <= 0.f) continue;
-            const float tot = n + nb, delta = sh[k][1][lane] - mu, f = nb / tot;
-            mu = __builtin_fmaf(delta, f, mu);
-            m2 += sh[k][2][lane] + delta * delta * (n * f);
-            n = tot;
-        }
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m2 += sh[k][0][lane];
         mean[(size_t)b * C + c] = mu;
-        rstd[(size_t)b * C + c] = 1.0f / sqrtf(m2 / n + eps);
+        rstd[(size_t)b * C + c] = 1.0f / sqrtf(m2 / tn + eps);
     }
 }
 

@@ -78,7 +78,6 @@ class Imitator(object):
         self._name = "Imitator"
         self.device = torch.device(device)
         self._frame_batch_req = int(frame_batch)   # what the caller asked for; ``frame_batch`` (property) is what runs
-        self._fb_warned = None
         self.streams = max(1, int(streams))       # independent frame batches in flight on separate HIP streams
         self._side_streams = None
         self.src_info = None
@@ -93,23 +92,16 @@ class Imitator(object):
 
     # ------------------------------------------------------------------ frame batch actually launched
     def max_frame_batch(self):
-        """The conv kernels address activations with 32-bit buffer offsets (< 3 GiB per tensor, include/lwg_hip.h).  The largest NHWC
-        tensor of a frame batch is the last decoder output (B, S, S, 64) in the ACTIVATION dtype of the current precision mode: fp32
-        (4 bytes) or, with ``generator.conv_precision == "bf16"``, bf16 (2 bytes: twice the frames fit)."""
-        gen = getattr(self, "generator", None)
-        act_bytes = 2 if (gen is not None and getattr(gen, "conv_precision", "fp32") == "bf16") else 4
-        return max(1, int((3 << 30) // (self.image_size * self.image_size * 64 * act_bytes)) - 1)
+        """No per-tensor cap reaches the caller any more: a launch whose gathered input would exceed the conv kernels' 32-bit buffer
+        offsets (3 GiB) is cut into batch slices INSIDE the C entry points (csrc/lwg_conv_slices.h; a frame is independent of its
+        batch, so the values do not change).  What bounds a frame batch now is device memory (~0.2 GB of fp32 activations per
+        512 x 512 frame): returns None."""
+        return None
 
     @property
     def frame_batch(self):
-        """Frames per launch batch as they RUN: the requested value clamped by ``max_frame_batch()`` for the current precision mode."""
-        fb, cap = self._frame_batch_req, self.max_frame_batch()
-        if fb > cap:
-            if self._fb_warned != (fb, cap):
-                self._fb_warned = (fb, cap)
-                print(f"[ipercore_amd] frame_batch {fb} -> {cap} at {self.image_size}x{self.image_size} (3 GiB per-tensor limit of the conv kernels)")
-            return cap
-        return fb
+        """Frames per launch batch: what the caller asked for."""
+        return self._frame_batch_req
 
     @frame_batch.setter
     def frame_batch(self, value):

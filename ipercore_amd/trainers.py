@@ -22,6 +22,8 @@ collectives for point-to-point xGMI instead of DDP's 25 MB buckets - and updated
 import math
 import os
 
+import time
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -851,6 +853,8 @@ class LWGTrainer(object):
                 e = torch.cuda.Event(enable_timing=True)
                 e.record(stream if stream is not None else torch.cuda.current_stream())
                 ev[name] = e
+            else:                                           # CPU tensors (gloo tests): the host clock - segments run synchronously, the exchange does not
+                ev[name] = time.perf_counter()
         seg["A"]()
         rec("A_done")
         force = bool(getattr(self, "force_dp", False))
@@ -976,8 +980,11 @@ class LWGTrainer(object):
         dp = getattr(self, "_dp_events", None)
         if not dp:
             return None
-        torch.cuda.synchronize()
-        t = lambda a, b: dp[a].elapsed_time(dp[b])                                       # noqa: E731  (ms from a to b)
+        if isinstance(dp["A_done"], float):
+            t = lambda a, b: (dp[b] - dp[a]) * 1e3                                       # noqa: E731  (host clock: CPU / gloo runs)
+        else:
+            torch.cuda.synchronize()
+            t = lambda a, b: dp[a].elapsed_time(dp[b])                                   # noqa: E731  (ms from a to b)
         g_exposed = t("A_done", "G_reduced") if "D_done" not in dp else min(t("A_done", "G_reduced"), t("D_done", "G_reduced"))
         d_exposed = t("adamG_done", "D_reduced") if "D_reduced" in dp else 0.0
         return max(0.0, g_exposed) + max(0.0, d_exposed)

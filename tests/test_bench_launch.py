@@ -80,3 +80,35 @@ def test_bench_single_process_line(tmp_path):
     line = _run(tmp_path, ["--gpus", "1"])
     assert line["n_gpus"] == 1 and line["config"]["world_size"] == 1 and "per_rank" not in line["config"]
     assert line["config"]["frame_batch"] == 2 and line["config"]["frame_batch_requested"] == 2
+
+
+# the training graph's CUDA-only guards (ConvFn.forward etc.) are answered "yes" for CPU tensors, as tests/test_abi_and_sharding.py's
+# data-parallel worker does: the emulated ABI stands behind every op
+_WRAPPER_PERS = _WRAPPER.replace("import bench\nbench.self_launch_if_needed()", "import bench_personalize as bench\nbench.self_launch_if_needed()") \
+    .replace("bench.main()", "import torch\nimport unittest.mock as um\n"
+             "with um.patch.object(torch.Tensor, 'is_cuda', new_callable=um.PropertyMock, return_value=True), \\\n"
+             "        um.patch.object(torch.cuda, 'is_available', return_value=False):\n    bench.main()")
+
+
+def test_bench_personalize_eight_ranks_gloo(tmp_path):
+    """BASELINE configs[4] as the driver would start it at N = 8 (``python bench_personalize.py --gpus 8``, ranks self-launched), on
+    CPU tensors with the gloo backend and the emulated C ABI: the FULL-width generator and discriminator (so the exchanged gradient
+    buffers are the real 36,276,992 + 6,962,625 fp32 values = 173.0 MB per step per rank) at 64 x 64, the data-parallel SEGMENT schedule
+    (G's all-reduce behind D's forward / backward, D's behind Adam(G): LWGTrainer._run_dp_schedule) with its exposed time reported.
+    Reference: DistributedDataParallel, iPERCore/services/train.py:45-51,89-95.  Not a measurement - the line says so."""
+    script = tmp_path / "pers_wrapper.py"
+    script.write_text(_WRAPPER_PERS.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1")
+    cmd = [sys.executable, str(script), "--gpus", "8", "--device", "cpu", "--backend", "gloo", "--size", "64", "--steps", "1", "--warmup", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 and line["scaling"] == "weak"
+    assert line["bytes_allreduced_per_step"] == (36276992 + 6962625) * 4 and round(line["bytes_allreduced_per_step"] / 1e6, 1) == 173.0
+    assert line["exposed_allreduce_ms_per_step"] is not None and line["exposed_allreduce_ms_per_step"] >= 0.0
+    assert "segmented" in line["config"]["step"] and "behind D's forward / backward" in line["allreduce_overlap"]
+    assert "NOT a measurement" in line["data"] and line["value"] > 0
+    assert abs(line["loss_G"]) < 1e4 and abs(line["loss_D"]) < 1e4
