@@ -494,12 +494,13 @@ def size_extra(dev, timer, S, W=1, K=2):
         torch.cuda.empty_cache()
 
 
-def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900):
+def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900, extra_args=()):
     """BASELINE configs[4] beside the headline: bench_personalize.py in its OWN process (the step captures hipGraphs and owns
-    its allocator pools; a failure there must not take the headline line with it) -> its JSON line, or {"error": ...}."""
+    its allocator pools; a failure there must not take the headline line with it) -> its JSON line, or {"error": ...}.
+    extra_args: e.g. ("--use-vgg", "--use-face") = the reference's default loss set (deploy.toml:76-102)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench_personalize.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
-           "--size", str(size)]
+           "--size", str(size)] + list(extra_args)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         for ln in reversed(r.stdout.strip().splitlines()):
@@ -837,6 +838,9 @@ def main(argv=None):
                 except Exception as e:
                     line["novel_view_1024_bf16"] = {"error": f"{type(e).__name__}: {e}"}
                 line["personalize_step"] = personalize_step_extra()
+                # the reference's DEFAULT loss set (VGG19 perceptual + SphereFace on seeded weights: the licensed checkpoints are not
+                # available offline; same cost per step).  The face crop reads its box on the host, so this step runs eager launches.
+                line["personalize_step_vgg_face"] = personalize_step_extra(steps=6, warmup=3, extra_args=("--use-vgg", "--use-face"))
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = _extra(cpu_baseline, small, args.cpu_frames)

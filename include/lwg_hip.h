@@ -229,14 +229,20 @@ int lwg_lwb_attention_bf16(const void* q, const void* Ks, const void* Vs, const 
  * per frame:  logit_s = (warp_s(Kq) . x + warp_s(kappa)) / sqrt(C),  out = sum_s softmax_s(logit) warp_s(Vs) + bv.
  * Replaces, per site and frame, the fq convolution + LWB.transform + SelfAttentionBlock (:106-139, :175-191, :226-227).
  * x, out (B,h,w,C); T (B,ns,h,w,2): flows ALREADY RESIZED to (h,w) (lwg_flow_resize_f32); K / V tensors < 3 GiB each.
- * stats: NULL, or B * ceil(h/8) * ceil(w/8) * C * 3 floats: the kernel reads every element of x once and leaves per 8 x 8 tile the
- * InstanceNorm partial record (count, mean, M2) of x (SPADE's parameter-free norm, :62,:83) - finish with lwg_instnorm_finalize_f32. */
+ * stats: NULL, or B * nrec * C * 3 floats with nrec = lwg_lwb_attention_x_records(h, w, C, element size): the kernel reads every element
+ * of x once and leaves per workgroup (an 8 x 8 tile, or a part of one on small feature maps - a function of (h, w, C) only, so that a
+ * frame never depends on its batch) the InstanceNorm partial record (count, mean, M2) of x (SPADE's parameter-free norm, :62,:83);
+ * finish with lwg_instnorm_finalize_f32. */
+int lwg_lwb_attention_x_records(int h, int w, int C, int element_size);
 int lwg_lwb_attention_x_f32(const float* x, const float* Kq, const float* kappa, const float* Vs, const float* bv, const float* T,
                             float* out, float* stats, int B, int ns, int h, int w, int C, int src_batched, lwg_stream_t stream);
 int lwg_lwb_attention_x_bf16(const void* x, const void* Kq, const float* kappa, const void* Vs, const float* bv, const float* T,
                              void* out, float* stats, int B, int ns, int h, int w, int C, int src_batched, lwg_stream_t stream);
-/* ws (B,nrec,C,3) records (count, mean, M2) -> mean, rstd (B,C); rstd = 1 / sqrt(M2 / n + eps) (nn.InstanceNorm2d: biased variance). */
-int lwg_instnorm_finalize_f32(const float* ws, int B, int C, int nrec, float eps, float* mean, float* rstd, lwg_stream_t stream);
+/* ws (B,nrec,C,3) records (count, mean, M2) -> mean, rstd (B,C); rstd = 1 / sqrt(M2 / n + eps) (nn.InstanceNorm2d: biased variance).
+ * ws holds lwg_instnorm_finalize_ws_floats(B, C, nrec) floats: the records, then scratch for the segment partials of long record lists
+ * (nrec > 512); record 0 of every image must be non-empty (its mean is the reference the moments are summed about). */
+size_t lwg_instnorm_finalize_ws_floats(int B, int C, int nrec);
+int lwg_instnorm_finalize_f32(float* ws, int B, int C, int nrec, float eps, float* mean, float* rstd, lwg_stream_t stream);
 /* Backward of the above for the personalization step (lwg_trainer.py:649-697 runs the same block under autograd; the
  * flows are constants there).  dq is written; dKs / dVs are accumulated with fp32 atomics and must be zero on entry;
  * ns <= 8.  The bias gradients need no kernel: dbv = column sum of dout, dbk = 0. */

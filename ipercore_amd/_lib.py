@@ -83,6 +83,8 @@ _SIGS = {
     "lwg_lwb_fuse_f32": (c_i, [c_f] * 5 + [c_i] * 7 + [ctypes.c_float, ctypes.c_float, c_f]),
     "lwg_lwb_attention_x_f32": (c_i, [c_f] * 8 + [c_i] * 6 + [c_f]),
     "lwg_lwb_attention_x_bf16": (c_i, [c_f] * 8 + [c_i] * 6 + [c_f]),
+    "lwg_lwb_attention_x_records": (c_i, [c_i, c_i, c_i, c_i]),
+    "lwg_instnorm_finalize_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_instnorm_finalize_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f]),
     "lwg_lwb_attention_bwd_f32": (c_i, [c_f] * 10 + [c_i] * 7 + [c_f]),
     "lwg_lwb_attention_kv_f32": (c_i, [c_f] * 6 + [c_i] * 7 + [c_f]),

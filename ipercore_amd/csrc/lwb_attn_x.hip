@@ -62,8 +62,15 @@ template <> struct AttnXTraits<__bf16> {
     }
 };
 
-template <typename ST, int LPP, bool STATS, int OCC>
-__global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __restrict__ x, const ST* __restrict__ Kq,
+// NSU: sources handled with their flows prefetched a pass ahead and the source loop unrolled (2 = the runner's default num_source,
+// deploy.toml:7); 0: any ns, flows loaded inside the loop.
+// PW: passes in flight per workgroup.  1: four waves walk the tile's passes one after the other (frame batches: thousands of
+// workgroups).  4: sixteen waves, four passes at a time - the form for launches of a few frames, where a 64 x 64 feature map is 64
+// workgroups per frame and a workgroup's chain of passes is what the launch waits for.  Both forms leave the SAME statistics record,
+// bit for bit: the per-lane sums run over the tile's passes in pass order in either (PW = 4 replays that order through LDS), so a frame
+// does not depend on which form its batch size selected.
+template <typename ST, int LPP, bool STATS, int NSU, int PW, int OCC>
+__global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_kernel(const ST* __restrict__ x, const ST* __restrict__ Kq,
                                                                  const float* __restrict__ kappa, const ST* __restrict__ Vs,
                                                                  const float* __restrict__ bv, const float* __restrict__ T,
                                                                  ST* __restrict__ out, float* __restrict__ stats, int B, int ns, int h, int w,
@@ -72,14 +79,33 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
     constexpr int CPL = TR::CPL;
     constexpr int C = CPL * LPP;
     constexpr int PPW = 64 / LPP;          // pixels per wave and pass
-    constexpr int PPP = 4 * PPW;           // pixels per pass of the workgroup
+    constexpr int PPP = 4 * PPW;           // pixels per pass (four waves)
     constexpr int NPASS = 64 / PPP;
+    constexpr int NIT = NPASS / PW;        // passes per wave
+    static_assert(NPASS % PW == 0, "PW must divide the tile's pass count");
+    constexpr int NT = NSU > 0 ? NSU : 1;
     constexpr unsigned ROWB = (unsigned)C * sizeof(ST);      // bytes of one pixel row
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wq = wid & 3, pl = wid >> 2;                   // position inside a pass, pass slot
     const int cl = lane % LPP, pg = lane / LPP;
     const int tiles_x = (w + 7) >> 3;
-    const long L = lwg_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = (int)(L / B), b = (int)(L - (long)tile * B);
+    // Work order.  The frames of a tile run back to back on ONE XCD (they gather the same source texels: fetched into that L2 once), and
+    // the TILES are dealt round-robin over the eight XCDs (hardware: workgroup id % 8): the body covers ~12 % of the pixels, in the middle
+    // of the image - with a contiguous band of tile rows per XCD (the order of the first version) the XCDs holding the middle bands did
+    // nearly all the gathers while the others ran out of work.
+    int tile, b;
+    if (LWG_ATTNX_INTERLEAVE) {
+        const int xcd = blockIdx.x & 7;
+        const long idx = blockIdx.x >> 3;
+        const long grp = idx / B;
+        tile = (int)(grp * 8 + xcd);
+        b = (int)(idx - grp * B);
+        if (tile >= tiles_x * ((h + 7) >> 3)) return;             // padding of the last group of eight tiles (workgroup-uniform)
+    } else {
+        const long L = lwg_xcd_remap(blockIdx.x, gridDim.x);       // (tile, frame), tile-major / frame-minor (lwg_common.h)
+        tile = (int)(L / B);
+        b = (int)(L - (long)tile * B);
+    }
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int hw = h * w;
     const unsigned nsrc = (unsigned)(src_batched ? B * ns : ns);
@@ -87,57 +113,86 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
     __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<ST*>(Vs), 0, (int)(nsrc * (unsigned)hw * ROWB), 0x00020000);
     __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kappa), 0, (int)(nsrc * (unsigned)hw * 4u), 0x00020000);
     const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    constexpr bool BV_REG = CPL == 4 || LWG_ATTNX_BVREG16;       // bf16 (8 channels per lane): bv is re-read per pass instead of held (registers)
     float bvr[CPL];
+    if (BV_REG) {
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) bvr[k] = bv[CPL * cl + k];
+        for (int k = 0; k < CPL; ++k) bvr[k] = bv[CPL * cl + k];
+    }
+    const float2* Tb = reinterpret_cast<const float2*>(T) + (size_t)b * ns * hw;
 
-    auto pixel_of = [&](int pass, int& y, int& xx) -> bool {
-        const int p = pass * PPP + wid * PPW + pg;
-        y = ty * 8 + (p >> 3);
-        xx = tx * 8 + (p & 7);
-        return y < h && xx < w;
+    auto pixel_of = [&](int pass, int& yc, int& xc) -> bool {     // clamped to the tile's first pixel when outside the image
+        const int p = pass * PPP + wq * PPW + pg;
+        const int y = ty * 8 + (p >> 3), xx = tx * 8 + (p & 7);
+        const bool live = y < h && xx < w;
+        yc = live ? y : ty * 8;
+        xc = live ? xx : tx * 8;
+        return live;
     };
-    auto load_x = [&](int pass) -> uintx4 {
-        int y, xx;
-        const bool live = pixel_of(pass, y, xx);
-        const long gp = ((long)b * h + (live ? y : ty * 8)) * w + (live ? xx : tx * 8);
-        return *reinterpret_cast<const uintx4*>(x + gp * C + CPL * cl);
-    };
+    // The tile's x rows and flows go through LDS.  x: every wave requests the rows of ALL its passes at once with LDS-DMA
+    // (buffer_load ... lds: no registers held while in flight; a wave-instruction = 64 lanes x 16 B = the 1 KB it will read back itself, lane
+    // for lane) - one round trip for the tile's 64 x C values instead of one per pass; with a register prefetch a wave kept ONE row in
+    // flight and the background tiles (88 % of them: no gathers at all) streamed at a fraction of the HBM rate.
+    extern __shared__ __attribute__((aligned(16))) char smem_ax[];
+    char* xs = smem_ax;                                                              // [NPASS][4 waves][64 lanes][16 B]
+    float2* Tl = reinterpret_cast<float2*>(smem_ax + NPASS * 4096);                   // [ns][64 pixels]
+    {
+        __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<ST*>(x) + (size_t)b * hw * C, 0, (int)((unsigned)hw * ROWB), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pass = it * PW + pl;
+            int yc, xc;
+            pixel_of(pass, yc, xc);
+            const unsigned voff = (unsigned)(yc * w + xc) * ROWB + (unsigned)(CPL * cl) * (unsigned)sizeof(ST);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(xs + (pass * 4 + wq) * 1024), 16, (int)voff, 0, 0, 0);
+        }
+        for (int i = threadIdx.x; i < ns * 64; i += 256 * PW) {
+            const int s = i >> 6, p = i & 63;
+            const int y = ty * 8 + (p >> 3), xx = tx * 8 + (p & 7);
+            const bool in = y < h && xx < w;
+            Tl[i] = Tb[(size_t)s * hw + (size_t)(in ? y : ty * 8) * w + (in ? xx : tx * 8)];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the DMA writes are tracked by vmcnt only
+        __syncthreads();
+    }
+    auto x_row = [&](int pass) -> uintx4 { return *reinterpret_cast<const uintx4*>(xs + ((pass * 4 + wq) * 64 + lane) * 16); };
 
-    // InstanceNorm partial statistics of x over this tile: shifted sums (shift = the tile's first pixel), fixed combination order
+    // InstanceNorm partial statistics of x over the tile: shifted sums (shift = the tile's first pixel); per lane over the passes in
+    // pass order, then the pixel groups of a wave, then the four waves - a fixed order
     float shift[CPL], s1[CPL], s2[CPL];
     if (STATS) {
-        const long g0 = ((long)b * h + ty * 8) * w + tx * 8;
-        TR::unpack(*reinterpret_cast<const uintx4*>(x + g0 * C + CPL * cl), shift);
+        TR::unpack(*reinterpret_cast<const uintx4*>(xs + cl * 16), shift);          // row of (pass 0, wave 0, pixel group 0) = the tile's first pixel
 #pragma unroll
         for (int k = 0; k < CPL; ++k) s1[k] = s2[k] = 0.f;
     }
+    int nlive = 0;
 
-    uintx4 xraw = load_x(0);
 #pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-        int y, xx;
-        const bool live = pixel_of(pass, y, xx);
-        const int yc = live ? y : ty * 8, xc = live ? xx : tx * 8;
+    for (int it = 0; it < NIT; ++it) {
+        const int pass = it * PW + pl;
+        int yc, xc;
+        const bool live = pixel_of(pass, yc, xc);
         const long gp = ((long)b * h + yc) * w + xc;
+        const int ptile = pass * PPP + wq * PPW + pg;                             // this lane's pixel of the tile
         float xv[CPL];
-        TR::unpack(xraw, xv);
-        if (pass + 1 < NPASS) xraw = load_x(pass + 1);               // in flight during this pass's gathers
+        TR::unpack(x_row(pass), xv);
         if (STATS && live) {
+            ++nlive;
+            if (PW == 1) {
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const float d = xv[k] - shift[k];
-                s1[k] += d;
-                s2[k] = __builtin_fmaf(d, d, s2[k]);
+                for (int k = 0; k < CPL; ++k) {
+                    const float d = xv[k] - shift[k];
+                    s1[k] += d;
+                    s2[k] = __builtin_fmaf(d, d, s2[k]);
+                }
             }
         }
         float mrun = -INFINITY, lrun = 0.f;
         float o[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = 0.f;
-#pragma unroll 1
-        for (int s = 0; s < ns; ++s) {
-            const float2 t = reinterpret_cast<const float2*>(T)[((size_t)b * ns + s) * hw + (size_t)yc * w + xc];
+
+        auto source = [&](int s, const float2 t) {
             // grid_sample, align_corners=False: pixel = ((g + 1) * size - 1) / 2
             const float ix = ((t.x + 1.f) * (float)w - 1.f) * 0.5f, iy = ((t.y + 1.f) * (float)h - 1.f) * 0.5f;
             const float fx0 = floorf(ix), fy0 = floorf(iy);
@@ -190,10 +245,25 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
 #pragma unroll
             for (int k = 0; k < CPL; ++k) o[k] = __builtin_fmaf(o[k], corr, pr * va[k]);
             mrun = mnew;
+        };
+        if (NSU > 0) {
+#pragma unroll
+            for (int s = 0; s < NT; ++s) source(s, Tl[s * 64 + ptile]);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < ns; ++s) source(s, Tl[s * 64 + ptile]);
         }
         if (live) {
             const float invl = 1.f / lrun;
             float r[CPL];
+            if (!BV_REG) {
+#pragma unroll
+                for (int k = 0; k < CPL; k += 4) {
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(bv + CPL * cl + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bvr[k + j] = b4[j];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < CPL; ++k) r[k] = __builtin_fmaf(o[k], invl, bvr[k]);
             *reinterpret_cast<uintx4*>(out + gp * C + CPL * cl) = TR::pack(r);
@@ -201,7 +271,45 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
     }
 
     if (STATS) {
-        // lanes holding the same channels: pixel groups of a wave (xor shuffles), then the four waves through LDS - a fixed order
+        if (PW > 1) {
+            // replay the per-lane sums in pass order: pass p belongs to the waves of slot p % PW; they add it to the lane's running sums
+            // in LDS - exactly the additions (and the order) the PW = 1 form performs in registers
+            __shared__ float acc[4][64][2 * CPL];
+            if (pl == 0) {
+#pragma unroll
+                for (int k = 0; k < 2 * CPL; ++k) acc[wq][lane][k] = 0.f;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int p = 0; p < NPASS; ++p) {
+                if (pl == p % PW) {
+                    int yc, xc;
+                    if (pixel_of(p, yc, xc)) {
+                        float xv[CPL];
+                        TR::unpack(x_row(p), xv);
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k) {
+                            const float d = xv[k] - shift[k];
+                            acc[wq][lane][k] += d;
+                            acc[wq][lane][CPL + k] = __builtin_fmaf(d, d, acc[wq][lane][CPL + k]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (pl == 0) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    s1[k] = acc[wq][lane][k];
+                    s2[k] = acc[wq][lane][CPL + k];
+                }
+            }
+        }
+        __syncthreads();                                                  // every wave is done with the x rows: their LDS is reused below
+        float (*sh)[2][C] = reinterpret_cast<float (*)[2][C]>(smem_ax);    // [4][2][C]
+        float* shn = reinterpret_cast<float*>(smem_ax + 4 * 2 * C * sizeof(float));   // [4 PW]
+        // lanes holding the same channels: pixel groups of a wave (xor shuffles), then the four waves through LDS
+        float fn = (float)nlive;                                      // small integers: exact in any order
 #pragma unroll
         for (int off = LPP; off < 64; off <<= 1) {
 #pragma unroll
@@ -209,28 +317,32 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
                 s1[k] += __shfl_xor(s1[k], off, 64);
                 s2[k] += __shfl_xor(s2[k], off, 64);
             }
+            fn += __shfl_xor(fn, off, 64);
         }
-        __shared__ float sh[4][2][C];
         if (pg == 0) {
+            if (pl == 0) {
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                sh[wid][0][CPL * cl + k] = s1[k];
-                sh[wid][1][CPL * cl + k] = s2[k];
+                for (int k = 0; k < CPL; ++k) {
+                    sh[wq][0][CPL * cl + k] = s1[k];
+                    sh[wq][1][CPL * cl + k] = s2[k];
+                }
             }
+            if (cl == 0) shn[wid] = fn;
         }
         __syncthreads();
         if (wid == 0 && pg == 0) {
-            const int ny = min(8, h - ty * 8), nx = min(8, w - tx * 8);
-            const float tn = (float)(ny * nx);
-            const int ntiles = tiles_x * ((h + 7) >> 3);
+            float tn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4 * PW; ++k) tn += shn[k];               // live pixels of the tile
+            const int nrec = tiles_x * ((h + 7) >> 3);
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c = CPL * cl + k;
                 const float t1 = ((sh[0][0][c] + sh[1][0][c]) + sh[2][0][c]) + sh[3][0][c];
                 const float t2 = ((sh[0][1][c] + sh[1][1][c]) + sh[2][1][c]) + sh[3][1][c];
-                const float mean = shift[k] + t1 / tn;
+                const float mean = shift[k] + t1 / tn;                  // tn >= 1: a tile's first pixel is inside the image
                 const float m2 = t2 - t1 * t1 / tn;
-                float* rec = stats + (((size_t)b * ntiles + tile) * C + c) * 3;
+                float* rec = stats + (((size_t)b * nrec + tile) * C + c) * 3;
                 rec[0] = tn;
                 rec[1] = mean;
                 rec[2] = m2 > 0.f ? m2 : 0.f;
@@ -239,37 +351,68 @@ __global__ __launch_bounds__(256, OCC) void lwg_lwb_attnx_kernel(const ST* __res
     }
 }
 
+// records per image the STATS form writes for an (h, w, C) launch of storage width esz (4: fp32, 2: bf16): one per 8 x 8 tile
+extern "C" int lwg_lwb_attention_x_records(int h, int w, int C, int esz) {
+    if (h <= 0 || w <= 0 || C <= 0 || (esz != 2 && esz != 4)) return 0;
+    const int lpp = C / (16 / esz);
+    if (lpp < 8 || lpp > 64 || (lpp & (lpp - 1)) != 0) return 0;
+    return ((w + 7) >> 3) * ((h + 7) >> 3);
+}
+
 template <typename ST>
 static int lwg_attnx_launch(const ST* x, const ST* Kq, const float* kappa, const ST* Vs, const float* bv, const float* T, ST* out, float* stats,
                             int B, int ns, int h, int w, int C, int src_batched, hipStream_t stream) {
-    if (!x || !Kq || !kappa || !Vs || !bv || !T || !out || B <= 0 || ns <= 0 || h <= 0 || w <= 0) return (int)hipErrorInvalidValue;
+    if (!x || !Kq || !kappa || !Vs || !bv || !T || !out || B <= 0 || ns <= 0 || ns > 64 || h <= 0 || w <= 0) return (int)hipErrorInvalidValue;
     const unsigned long long nsrc = (unsigned long long)(src_batched ? B * ns : ns);
     // the taps go through 32-bit buffer offsets with 0xC0000000 as the out-of-range marker (zero fill): K / V below 3 GiB each
     if (nsrc * (unsigned long long)h * w * (unsigned long long)C * sizeof(ST) >= 0xC0000000ull) return (int)hipErrorInvalidValue;
     const long tiles = (long)((w + 7) >> 3) * ((h + 7) >> 3);
-    const dim3 grid((unsigned)(tiles * B));
     constexpr int CPL = AttnXTraits<ST>::CPL;
-#define LWG_ATTNX_LAUNCH(LPP)                                                                                                      \
-    if (stats)                                                                                                                    \
-        hipLaunchKernelGGL((lwg_lwb_attnx_kernel<ST, LPP, true, 4>), grid, dim3(256), 0, stream, x, Kq, kappa, Vs, bv, T, out, stats, B, ns, h, w, src_batched); \
-    else                                                                                                                          \
-        hipLaunchKernelGGL((lwg_lwb_attnx_kernel<ST, LPP, false, 4>), grid, dim3(256), 0, stream, x, Kq, kappa, Vs, bv, T, out, stats, B, ns, h, w, src_batched);
+    const int npass = (C / CPL) / 4;
+    const dim3 grid((unsigned)((LWG_ATTNX_INTERLEAVE ? (tiles + 7) / 8 * 8 : tiles) * B));
+    // a few frames: fewer workgroups than two per CU, each with a chain of >= 4 passes -> sixteen waves per tile (same values, see the kernel)
+    const bool wide = LWG_ATTNX_WIDE && tiles * B < 512 && npass >= 4;
+#define LWG_ATTNX_GO(LPP, ST_, NSU, PW)                                                                                              \
+    {                                                                                                                                \
+        auto kern = lwg_lwb_attnx_kernel<ST, LPP, ST_, NSU, PW, (CPL == 4 ? LWG_ATTNX_OCC : LWG_ATTNX_OCC16)>;                         \
+        const size_t lds = (size_t)((LPP) / 4) * 4096 + (size_t)ns * 512;        /* x rows of the tile + its flows */                 \
+        static unsigned long long lds_ok = 0;                                                                                        \
+        if (lds > 65536) {                                                                                                           \
+            const hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_ok);                            \
+            if (e != hipSuccess) return (int)e;                                                                                      \
+        }                                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(256 * PW), lds, stream, x, Kq, kappa, Vs, bv, T, out, stats, B, ns, h, w, src_batched);   \
+    }
+#define LWG_ATTNX_PW(LPP, ST_, NSU)                                                                                                  \
+    {                                                                                                                                \
+        if constexpr ((LPP) / 4 >= 4) {                                                                                              \
+            if (wide) LWG_ATTNX_GO(LPP, ST_, NSU, 4) else LWG_ATTNX_GO(LPP, ST_, NSU, 1)                                             \
+        } else {                                                                                                                     \
+            LWG_ATTNX_GO(LPP, ST_, NSU, 1)                                                                                           \
+        }                                                                                                                            \
+    }
+#define LWG_ATTNX_LAUNCH(LPP)                                                                                                        \
+    if (stats) { if (LWG_ATTNX_NSU2 && ns == 2) LWG_ATTNX_PW(LPP, true, 2) else LWG_ATTNX_PW(LPP, true, 0) }                         \
+    else { if (LWG_ATTNX_NSU2 && ns == 2) LWG_ATTNX_PW(LPP, false, 2) else LWG_ATTNX_PW(LPP, false, 0) }
     switch (C / CPL) {
         case 8: LWG_ATTNX_LAUNCH(8) break;
         case 16: LWG_ATTNX_LAUNCH(16) break;
         case 32: LWG_ATTNX_LAUNCH(32) break;
-        case 64: if (CPL == 4) { LWG_ATTNX_LAUNCH(64) break; }
+        case 64: if constexpr (CPL == 4) { LWG_ATTNX_LAUNCH(64) break; }
                  return (int)hipErrorInvalidValue;
         default: return (int)hipErrorInvalidValue;
     }
 #undef LWG_ATTNX_LAUNCH
+#undef LWG_ATTNX_PW
+#undef LWG_ATTNX_GO
     return (int)hipGetLastError();
 }
 
 // x (B,h,w,C) transfer feature; Kq (nsrc,h,w,C) = (Wq^T Wk) f_src; kappa (nsrc,h,w) = (Wk^T bq) . f_src; Vs (nsrc,h,w,C) = Wv f_src (no bias);
 // bv (C); T (B,ns,h,w,2) flows ALREADY RESIZED to (h,w) (lwg_flow_resize_f32), grid_sample coordinates, -2 = background; out (B,h,w,C).
-// stats: nullptr, or B * ntiles * C * 3 floats (ntiles = ceil(h/8) * ceil(w/8)) receiving the per-tile InstanceNorm records of x
-// (count, mean, M2) - finish with lwg_instnorm_finalize_f32(stats, B, C, ntiles, ...).  C in {32, 64, 128, 256} (bf16: {64, 128, 256}).
+// stats: nullptr, or the record buffer of lwg_instnorm_finalize_f32 (B * nrec * C * 3 floats of records, nrec =
+// lwg_lwb_attention_x_records(h, w, C, element size), + its scratch) receiving the per-tile InstanceNorm records of x (count, mean, M2).
+// C in {32, 64, 128, 256} (bf16: {64, 128, 256}).
 extern "C" int lwg_lwb_attention_x_f32(const float* x, const float* Kq, const float* kappa, const float* Vs, const float* bv, const float* T,
                                        float* out, float* stats, int B, int ns, int h, int w, int C, int src_batched, lwg_stream_t stream_) {
     if (C != 32 && C != 64 && C != 128 && C != 256) return (int)hipErrorInvalidValue;
@@ -283,57 +426,84 @@ extern "C" int lwg_lwb_attention_x_bf16(const void* x, const void* Kq, const flo
                                     static_cast<__bf16*>(out), stats, B, ns, h, w, C, src_batched, reinterpret_cast<hipStream_t>(stream_));
 }
 
-// Merge of the per-tile records the STATS form leaves: ws (B, nrec, C, 3) = (count, mean, M2) -> mean / rstd (B, C).  One workgroup per
-// (frame, 64 channels): lane = channel (a wave reads 768 contiguous bytes per record), wave k takes records k, k + 16, ...  Two passes of
-// plain sums instead of a chain of pairwise (Chan) updates with a division each: mu = sum n_i mean_i / sum n_i, then
-// M2 = sum [M2_i + n_i (mean_i - mu)^2]; the 16 per-wave partials are added in wave order.  The order depends on nrec only: a frame's
-// statistics do not depend on its batch.
-__global__ __launch_bounds__(1024) void lwg_in_stats_merge_tiles(const float* __restrict__ ws, int C, int nrec, float eps,
-                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+// Merge of the records the STATS form leaves: ws (B, nrec, C, 3) = (count, mean, M2) -> mean / rstd (B, C).
+// One pass of plain sums about a reference r = the mean of the image's FIRST record (close to the image mean, so the moments below do
+// not cancel):  A = sum n_i,  S = sum n_i (mean_i - r),  Q = sum [M2_i + n_i (mean_i - r)^2]  ->  mean = r + S / A,  M2 = Q - S^2 / A.
+// No chain of pairwise (Chan) updates with a division each.  Workgroup = (64 channels, frame, segment of the records): lane = channel
+// (a wave reads 768 contiguous bytes per record), wave k takes the segment's records k, k + 16, ...; the 16 per-wave partials are added in
+// wave order, the segments in segment order (second kernel; one segment: written directly).  The order depends on nrec only: a
+// frame's statistics do not depend on its batch.
+__global__ __launch_bounds__(1024) void lwg_in_stats_merge_seg(const float* __restrict__ ws, int C, int nrec, int nseg, float eps,
+                                                              float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y, seg = blockIdx.z;
     const bool cok = c < C;
     const float* base = ws + ((size_t)b * nrec * C + (cok ? c : 0)) * 3;
-    __shared__ float sh[16][2][64];
-    float sn = 0.f, sm = 0.f;
+    const float r = base[1];
+    const int per = (nrec + nseg - 1) / nseg;
+    const int r0 = seg * per, r1 = min(nrec, r0 + per);
+    float sa = 0.f, ss = 0.f, sq = 0.f;
     if (cok) {
-        for (int r = wid; r < nrec; r += 16) {
-            const float* o = base + (size_t)r * C * 3;
-            sn += o[0];
-            sm = __builtin_fmaf(o[0], o[1], sm);
+        for (int i = r0 + wid; i < r1; i += 16) {
+            const float* o = base + (size_t)i * C * 3;
+            const float n = o[0], d = o[1] - r;
+            sa += n;
+            ss = __builtin_fmaf(n, d, ss);
+            sq += __builtin_fmaf(n * d, d, o[2]);
         }
     }
-    sh[wid][0][lane] = sn;
-    sh[wid][1][lane] = sm;
-    __syncthreads();
-    float tn = 0.f, tm = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { tn += sh[k][0][lane]; tm += sh[k][1][lane]; }
-    const float mu = tm / tn;
-    __syncthreads();
-    float sq = 0.f;
-    if (cok) {
-        for (int r = wid; r < nrec; r += 16) {
-            const float* o = base + (size_t)r * C * 3;
-            const float d = o[1] - mu;
-            sq += __builtin_fmaf(o[0] * d, d, o[2]);
-        }
-    }
-    sh[wid][0][lane] = sq;
+    __shared__ float sh[16][3][64];
+    sh[wid][0][lane] = sa;
+    sh[wid][1][lane] = ss;
+    sh[wid][2][lane] = sq;
     __syncthreads();
     if (wid == 0 && cok) {
-        float m2 = 0.f;
+        float ta = 0.f, ts = 0.f, tq = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m2 += sh[k][0][lane];
-        mean[(size_t)b * C + c] = mu;
-        rstd[(size_t)b * C + c] = 1.0f / sqrtf(m2 / tn + eps);
+        for (int k = 0; k < 16; ++k) { ta += sh[k][0][lane]; ts += sh[k][1][lane]; tq += sh[k][2][lane]; }
+        if (nseg == 1) {
+            const float m2 = tq - ts * ts / ta;
+            mean[(size_t)b * C + c] = r + ts / ta;
+            rstd[(size_t)b * C + c] = 1.0f / sqrtf((m2 > 0.f ? m2 : 0.f) / ta + eps);
+        } else {
+            float* o = part + (((size_t)b * nseg + seg) * C + c) * 3;
+            o[0] = ta; o[1] = ts; o[2] = tq;
+        }
     }
 }
 
+__global__ __launch_bounds__(256) void lwg_in_stats_merge_fin(const float* __restrict__ ws, const float* __restrict__ part, int BC, int C, int nrec,
+                                                             int nseg, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i - b * C;
+    const float r = ws[((size_t)b * nrec * C + c) * 3 + 1];
+    float ta = 0.f, ts = 0.f, tq = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        const float* o = part + (((size_t)b * nseg + s) * C + c) * 3;
+        ta += o[0]; ts += o[1]; tq += o[2];
+    }
+    const float m2 = tq - ts * ts / ta;
+    mean[i] = r + ts / ta;
+    rstd[i] = 1.0f / sqrtf((m2 > 0.f ? m2 : 0.f) / ta + eps);
+}
+
 // ws (B, nrec, C, 3) records (count, mean, M2) -> mean, rstd (B, C): rstd = 1 / sqrt(M2 / n + eps), biased variance (nn.InstanceNorm2d).
-extern "C" int lwg_instnorm_finalize_f32(const float* ws, int B, int C, int nrec, float eps, float* mean, float* rstd, lwg_stream_t stream_) {
+// Record 0 of every image must be non-empty (count > 0): it supplies the reference about which the moments are summed.
+// More than 512 records: the tail of ws - B * ceil(nrec / 256) * C * 3 floats BEHIND the records - is scratch for the segment partials.
+extern "C" size_t lwg_instnorm_finalize_ws_floats(int B, int C, int nrec) {
+    if (B <= 0 || C <= 0 || nrec <= 0) return 0;
+    const size_t nseg = nrec > 512 ? (size_t)(nrec + 255) / 256 : 0;
+    return (size_t)B * nrec * C * 3 + (size_t)B * nseg * C * 3;
+}
+extern "C" int lwg_instnorm_finalize_f32(float* ws, int B, int C, int nrec, float eps, float* mean, float* rstd, lwg_stream_t stream_) {
     if (!ws || !mean || !rstd || B <= 0 || C <= 0 || nrec <= 0 || B > 65535) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(lwg_in_stats_merge_tiles, dim3((C + 63) / 64, B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream_), ws, C, nrec, eps,
-                       mean, rstd);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int nseg = nrec > 512 ? (nrec + 255) / 256 : 1;
+    if (nseg > 65535) return (int)hipErrorInvalidValue;
+    float* part = ws + (size_t)B * nrec * C * 3;
+    hipLaunchKernelGGL(lwg_in_stats_merge_seg, dim3((C + 63) / 64, B, nseg), dim3(1024), 0, stream, ws, C, nrec, nseg, eps, part, mean, rstd);
+    if (nseg > 1)
+        hipLaunchKernelGGL(lwg_in_stats_merge_fin, dim3((B * C + 255) / 256), dim3(256), 0, stream, ws, part, B * C, C, nrec, nseg, eps, mean, rstd);
     return (int)hipGetLastError();
 }

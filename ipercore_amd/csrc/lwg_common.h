@@ -44,6 +44,24 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef LWG_ATTN_OCC
 #define LWG_ATTN_OCC 5             // lwb_attn.hip: waves per SIMD the fp32 attention kernel's registers are held to (5, 6 or 8)
 #endif
+#ifndef LWG_ATTNX_OCC
+#define LWG_ATTNX_OCC 4            // lwb_attn_x.hip: waves per SIMD the x-form attention kernel's registers are held to
+#endif
+#ifndef LWG_ATTNX_OCC16
+#define LWG_ATTNX_OCC16 4          // the same for its bf16 instantiations
+#endif
+#ifndef LWG_ATTNX_BVREG16
+#define LWG_ATTNX_BVREG16 0        // bf16 instantiations: 1 = hold bv in registers (8 more VGPRs: spills at 4 waves / SIMD)
+#endif
+#ifndef LWG_ATTNX_NSU2
+#define LWG_ATTNX_NSU2 1           // lwb_attn_x.hip: ns == 2 launches on the form with prefetched flows and an unrolled source loop (0: the generic form)
+#endif
+#ifndef LWG_ATTNX_WIDE
+#define LWG_ATTNX_WIDE 1            // lwb_attn_x.hip: launches of a few frames run sixteen waves (four passes at a time) per tile (0: always four)
+#endif
+#ifndef LWG_ATTNX_INTERLEAVE
+#define LWG_ATTNX_INTERLEAVE 1     // lwb_attn_x.hip: tiles dealt round-robin over the XCDs (0: a contiguous band of tile rows per XCD)
+#endif
 #ifndef LWG_ATTN16_PAIR
 #define LWG_ATTN16_PAIR 0          // bf16_ops.hip: 1 = two sources in flight per wave (159 VGPRs, 3 waves / SIMD): measured SLOWER (111 vs 97 us at C = 256)
 #endif

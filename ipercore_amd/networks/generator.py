@@ -255,8 +255,8 @@ class AttentionLWBGenerator(nn.Module):
         # of SPADE's InstanceNorm of tsf_x
         mean = tsf_x.new_empty(B, C, dtype=torch.float32)
         rstd = tsf_x.new_empty(B, C, dtype=torch.float32)
-        nrec = ops.attn_tiles(h, w)
-        ws = scratch.get(B * nrec * C * 3, tsf_x.device)
+        nrec = ops.attn_records(h, w, C, tsf_x.dtype)
+        ws = scratch.get(ops.instnorm_finalize_ws(B, C, nrec), tsf_x.device)
         att = ops.lwb_attention_x(tsf_x, kv[0], kv[2], kv[1], st["bv"], scratch.flow(Tst, h, w), torch.empty_like(tsf_x), stats=ws,
                                   src_batched=batched)
         ops.instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5)

@@ -9,10 +9,15 @@ What runs where, this round:
   a G step) - runs on the hand-written MFMA kernels: ``ConvFn`` is a ``torch.autograd.Function`` whose forward is
   ``lwg_conv2d_nhwc_f32``, whose data gradient is the same kernel on dY with a transposed panel
   (``packing.pack_dgrad_*``) and whose weight gradient is ``lwg_conv2d_wgrad_nhwc_f32``;
-* InstanceNorm (+ ReLU / LeakyReLU), SPADE's modulation, the ReLU masks and Adam are HIP kernels too (``NormAct``,
-  csrc/train_ops.hip); what remains PyTorch-ROCm autograd this round is the bilinear warp + softmax of the attention
-  block, tanh / sigmoid of the regressors, the compositing and the scalar losses - HBM-bound elementwise work that the
-  inference path fuses into HIP kernels; their fused backward is the next step of this row.
+* InstanceNorm (+ ReLU / LeakyReLU), SPADE's modulation, the ReLU masks and Adam are HIP kernels too (``NormAct`` / ``SpadeNormFn``,
+  csrc/train_ops.hip), and so is the attention block: ``AttnFn`` / ``AttnKVFn`` run the hoisted-K/V gather kernel forward
+  (csrc/lwb_attn.hip ``lwg_lwb_attention[_kv]_f32``) and ``lwg_lwb_attention[_kv]_bwd_f32`` backward (gathers recomputed, fp32 atomics for
+  the bilinear scatter into dK / dV); the 5x5 / 7x7 regressors run the thin VALU kernels (``HeadFn`` / ``ThinConvFn``);
+* what remains PyTorch-ROCm autograd: the tanh / sigmoid derivatives of the regressors' outputs, the mask compositing, the scalar
+  losses (L1, LSGAN, BCE, TV) and the fan-in additions of tensors with two consumers - HBM-bound elementwise work (~90 small aten
+  launches per step inside the captured graph).
+(The per-frame INFERENCE engine uses a different attention form - the query projection folded into the cached K, csrc/lwb_attn_x.hip;
+here fq is trainable, so q = fq(x) stays an explicit convolution.)
 There is no CPU fallback: ``ConvFn`` raises on CPU tensors.
 
 The module reuses the parameter tree of ``generator.AttentionLWBGenerator`` (same ``state_dict`` keys), so a

@@ -357,23 +357,27 @@ def lwb_attention(q, Ks, Vs, bk, bv, T, out, src_batched=False):
     return out
 
 
-def attn_tiles(h, w):
-    """Records per image the statistics form of ``lwb_attention_x`` leaves: one per 8 x 8-pixel tile."""
-    return ((h + 7) // 8) * ((w + 7) // 8)
+def attn_records(h, w, C, dtype=torch.float32):
+    """Records per image the statistics form of ``lwb_attention_x`` leaves: one per workgroup = per 8 x 8-pixel tile, or per part of a
+    tile on small feature maps (a function of (h, w, C, storage type) only - never of the batch)."""
+    n = _lib.lib().lwg_lwb_attention_x_records(int(h), int(w), int(C), 2 if dtype == torch.bfloat16 else 4)
+    if n <= 0:
+        raise ValueError(f"lwb_attention_x: unsupported (h, w, C, dtype) = {(h, w, C, dtype)}")
+    return n
 
 
 def lwb_attention_x(x, Kq, kappa, Vs, bv, T, out, stats=None, src_batched=False):
     """The attention-form Liquid Warping Block with the query projection folded into the source side (csrc/lwb_attn_x.hip):
     logit_s = (warp_s(Kq) . x + warp_s(kappa)) / sqrt(C), out = sum_s softmax_s(logit) warp_s(Vs) + bv.
     x (B,h,w,C) fp32 | bf16; Kq, Vs (nsrc,h,w,C) in x's dtype; kappa (nsrc,h,w) fp32; T (B,ns,h,w,2) flows ALREADY at (h,w).
-    stats: None or a fp32 buffer of >= B * attn_tiles(h,w) * C * 3 floats receiving the per-tile InstanceNorm records of x."""
+    stats: None or a fp32 buffer of >= B * attn_records(h, w, C, dtype) * C * 3 floats receiving the partial InstanceNorm records of x."""
     B, h, w, C = x.shape
     ns = T.shape[1]
     nsrc = B * ns if src_batched else ns
     assert tuple(T.shape) == (B, ns, h, w, 2), (tuple(T.shape), (B, ns, h, w, 2))
     assert tuple(Kq.shape) == (nsrc, h, w, C) and tuple(Vs.shape) == (nsrc, h, w, C) and tuple(kappa.shape) == (nsrc, h, w)
     assert Kq.dtype == x.dtype and Vs.dtype == x.dtype and out.dtype == x.dtype and kappa.dtype == torch.float32
-    assert stats is None or stats.numel() >= B * attn_tiles(h, w) * C * 3
+    assert stats is None or stats.numel() >= B * attn_records(h, w, C, x.dtype) * C * 3
     if x.dtype == torch.bfloat16:
         bf = torch.bfloat16
         _lib.check(_lib.lib().lwg_lwb_attention_x_bf16(_ptr(x, bf), _ptr(Kq, bf), _ptr(kappa), _ptr(Vs, bf), _ptr(bv), _ptr(T), _ptr(out, bf),
@@ -384,9 +388,14 @@ def lwb_attention_x(x, Kq, kappa, Vs, bv, T, out, stats=None, src_batched=False)
     return out
 
 
+def instnorm_finalize_ws(B, C, nrec):
+    """Floats of the record buffer ``instnorm_finalize`` takes: the (B, nrec, C, 3) records + scratch for the segment partials of long lists."""
+    return int(_lib.lib().lwg_instnorm_finalize_ws_floats(int(B), int(C), int(nrec)))
+
+
 def instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5):
-    """(B, nrec, C, 3) records (count, mean, M2) -> mean, rstd (B, C) of nn.InstanceNorm2d (biased variance)."""
-    assert ws.numel() >= B * nrec * C * 3
+    """(B, nrec, C, 3) records (count, mean, M2) -> mean, rstd (B, C) of nn.InstanceNorm2d (biased variance).  ws: >= instnorm_finalize_ws floats."""
+    assert ws.numel() >= instnorm_finalize_ws(B, C, nrec)
     _lib.check(_lib.lib().lwg_instnorm_finalize_f32(_ptr(ws), B, C, nrec, float(eps), _ptr(mean), _ptr(rstd), _stream()), "lwg_instnorm_finalize_f32")
 
 

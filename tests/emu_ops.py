@@ -187,15 +187,23 @@ def lwb_attention_x(x, Kq, kappa, Vs, bv, T, out, stats=None, src_batched=False)
     out.copy_(res.to(out.dtype))
     if stats is not None:
         ty, tx = (h + 7) // 8, (w + 7) // 8
-        rec = stats[:B * ty * tx * C * 3].view(B, ty * tx, C, 3)
+        npart = attn_records(h, w, C, x.dtype) // (ty * tx)
+        rec = stats[:B * ty * tx * npart * C * 3].view(B, ty * tx, npart, C, 3)
         xf = x.float()
+        per = 64 // npart                                   # consecutive pixels of the tile (row-major 8 x 8) per workgroup
         for i in range(ty):
             for j in range(tx):
-                blk = xf[:, i * 8:(i + 1) * 8, j * 8:(j + 1) * 8, :].reshape(B, -1, C)
-                mu = blk.mean(dim=1)
-                rec[:, i * tx + j, :, 0] = blk.shape[1]
-                rec[:, i * tx + j, :, 1] = mu
-                rec[:, i * tx + j, :, 2] = ((blk - mu[:, None, :]) ** 2).sum(dim=1)
+                for q in range(npart):
+                    idx = [k for k in range(q * per, (q + 1) * per) if i * 8 + k // 8 < h and j * 8 + k % 8 < w]
+                    if not idx:
+                        rec[:, i * tx + j, q, :, 0] = 0
+                        rec[:, i * tx + j, q, :, 1:] = 0
+                        continue
+                    blk = torch.stack([xf[:, i * 8 + k // 8, j * 8 + k % 8, :] for k in idx], dim=1)
+                    mu = blk.mean(dim=1)
+                    rec[:, i * tx + j, q, :, 0] = len(idx)
+                    rec[:, i * tx + j, q, :, 1] = mu
+                    rec[:, i * tx + j, q, :, 2] = ((blk - mu[:, None, :]) ** 2).sum(dim=1)
     return out
 
 
@@ -205,13 +213,18 @@ def instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5):
     n, mu, m2 = rec[..., 0], rec[..., 1], rec[..., 2]
     tot = n.sum(dim=1)
     gm = (n * mu).sum(dim=1) / tot
-    var = (m2 + n * (mu - gm[:, None, :]) ** 2).sum(dim=1) / tot
+    var = (m2 + n * (mu - gm[:, None, :]) ** 2).sum(dim=1) / tot          # zero-count records (parts beyond the image edge) drop out
     mean.copy_(gm.float())
     rstd.copy_((1.0 / torch.sqrt(var + eps)).float())
 
 
-def attn_tiles(h, w):
+def attn_records(h, w, C, dtype=torch.float32):
+    """lwg_lwb_attention_x_records: one record per 8 x 8 tile (the product build runs one workgroup per tile and frame)."""
     return ((h + 7) // 8) * ((w + 7) // 8)
+
+
+def instnorm_finalize_ws(B, C, nrec):
+    return B * nrec * C * 3 + (B * ((nrec + 255) // 256) * C * 3 if nrec > 512 else 0)
 
 
 def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batched=False):
@@ -458,7 +471,7 @@ def install(monkeypatch):
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize", "attn_records", "instnorm_finalize_ws"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

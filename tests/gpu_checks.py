@@ -226,7 +226,9 @@ def check_lwb_attention_x():
     out = {}
     for (B, ns, h, w, C, batched, dt) in ((2, 2, 16, 16, 64, False, "f32"), (1, 3, 8, 8, 256, False, "f32"), (3, 2, 24, 24, 128, False, "f32"),
                                           (2, 2, 8, 8, 64, True, "f32"), (2, 2, 12, 20, 64, False, "f32"), (2, 8, 16, 16, 32, False, "f32"),
-                                          (2, 2, 16, 16, 64, False, "bf16"), (2, 2, 16, 16, 256, False, "bf16"), (3, 3, 24, 24, 128, False, "bf16")):
+                                          (2, 2, 16, 16, 64, False, "bf16"), (2, 2, 16, 16, 256, False, "bf16"), (3, 3, 24, 24, 128, False, "bf16"),
+                                          # 64 tiles: the batch of 9 runs four waves per tile, the single frame sixteen (same bits required)
+                                          (9, 2, 64, 64, 128, False, "f32"), (9, 2, 64, 64, 256, False, "bf16"), (9, 3, 64, 64, 256, False, "f32")):
         key = f"{dt}_C{C}_{h}x{w}_ns{ns}_b{int(batched)}"
         n_src = B * ns if batched else ns
         x, f = _rand((B, h, w, C), 140), _rand((n_src, h, w, C), 143)
@@ -244,8 +246,8 @@ def check_lwb_attention_x():
         q64 = xs.double() @ Wq.double().t() + bq.double()
         want = emu_ops.lwb_attention(q64, fs.double() @ Wk.double().t(), fs.double() @ Wv.double().t(), bk.double(), bv.double(), T.double(),
                                      torch.zeros(B, h, w, C).double(), src_batched=batched)
-        nrec = ops.attn_tiles(h, w)
-        ws = torch.full((B * nrec * C * 3,), float("nan"), device=DEV)
+        nrec = ops.attn_records(h, w, C, adt)
+        ws = torch.full((ops.instnorm_finalize_ws(B, C, nrec),), float("nan"), device=DEV)
         got = ops.lwb_attention_x(xs.to(DEV), Kq.to(DEV), kap.to(DEV), Vs.to(DEV), bv.to(DEV), T.to(DEV),
                                   torch.full((B, h, w, C), float("nan"), device=DEV, dtype=adt), stats=ws, src_batched=batched)
         mean, rstd = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
@@ -266,7 +268,7 @@ def check_lwb_attention_x():
         assert torch.equal(got, got2), key + ": the statistics form changes the output"
         b1 = B - 1
         sl = slice(b1 * ns, (b1 + 1) * ns) if batched else slice(None)
-        ws1 = torch.empty(nrec * C * 3, device=DEV)
+        ws1 = torch.empty(ops.instnorm_finalize_ws(1, C, nrec), device=DEV)
         one = ops.lwb_attention_x(xs[b1:b1 + 1].to(DEV), Kq[sl].to(DEV), kap[sl].to(DEV), Vs[sl].to(DEV), bv.to(DEV), T[b1:b1 + 1].to(DEV),
                                   torch.empty(1, h, w, C, device=DEV, dtype=adt), stats=ws1, src_batched=batched)
         m1, r1 = torch.empty(1, C, device=DEV), torch.empty(1, C, device=DEV)
@@ -1473,7 +1475,9 @@ def _training_inputs(S, ns, nf, nres, bgf, real_flows):
     return bg_in, src_in, tsf_in, Tst
 
 
-def _generator_training_grads(S, nf, nres, bgf, real_flows=False):
+def _generator_training_grads(S, nf, nres, bgf, real_flows=False, ref64=False):
+    """ref64: the oracle runs in fp64 and the bounds are the ones a ReLU network at this size supports (see
+    check_generator_training_grads_512_full)."""
     from oracle import lwg_oracle as orc
     from ipercore_amd.networks import NetworksFactory, generator_param_shapes
     from ipercore_amd.networks.training import TrainableGenerator
@@ -1486,11 +1490,12 @@ def _generator_training_grads(S, nf, nres, bgf, real_flows=False):
     tgt = [torch.tensor(synthetic.uniform_image(s, 500 + i, "tgt")) for i, s in enumerate(((1, 1, 3, S, S), (1, ns, 3, S, S), (1, ns, 1, S, S), (1, 1, 3, S, S), (1, 1, 1, S, S)))]
 
     def loss_of(outs, dev):
-        return sum((o - t.to(dev)).abs().mean() for o, t in zip(outs, tgt))
+        return sum((o - t.to(device=dev, dtype=o.dtype)).abs().mean() for o, t in zip(outs, tgt))
 
     t0 = time.time()
-    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sdn.items()}
-    outs_ref = orc.gen_forward_train(sd, bg_in, src_in, tsf_in, Tst, n_down=len(nf), n_res=nres, n_bg=len(bgf))
+    rdt = torch.float64 if ref64 else torch.float32
+    sd = {k: torch.tensor(v, dtype=rdt, requires_grad=True) for k, v in sdn.items()}
+    outs_ref = orc.gen_forward_train(sd, bg_in.to(rdt), src_in.to(rdt), tsf_in.to(rdt), Tst.to(rdt), n_down=len(nf), n_res=nres, n_bg=len(bgf))
     loss_ref = loss_of(outs_ref, "cpu")
     loss_ref.backward()
     t_oracle = time.time() - t0
@@ -1498,25 +1503,40 @@ def _generator_training_grads(S, nf, nres, bgf, real_flows=False):
     loss = loss_of(outs, DEV)
     loss.backward()
     torch.cuda.synchronize()
-    m = {"S": S, "num_filters": list(nf), "n_res": nres, "oracle_autograd_s": t_oracle, "loss": abs(loss.item() - loss_ref.item())}
+    m = {"S": S, "num_filters": list(nf), "n_res": nres, "oracle": "fp64" if ref64 else "fp32", "oracle_autograd_s": t_oracle,
+         "loss": abs(loss.item() - loss_ref.item())}
     assert m["loss"] <= 1e-4 * max(1.0, abs(loss_ref.item())), m
     names = ("bg", "src_img", "src_mask", "tsf_img", "tsf_mask")
     for n_, a_, b_ in zip(names, outs, outs_ref):
-        m[n_] = _cmp(a_, b_.detach(), 2e-3, n_)
+        m[n_] = _cmp(a_, b_.detach().float(), 2e-3, n_)
     # a bias in front of an InstanceNorm has a mathematically zero gradient (both sides hold rounding noise there), so the
     # error of a parameter is measured against max(its own gradient scale, 1e-3 of the largest gradient in the network)
     gmax = max(v.grad.abs().max().item() for v in sd.values())
-    worst, worst_name, bad = 0.0, None, []
+    worst, worst_name, bad, rel_all, l2_worst = 0.0, None, [], [], (0.0, None)
     for k, p_ in G.named_parameters():
         assert p_.grad is not None, f"no gradient for {k}"
         ref = sd[k].grad
-        rel = (p_.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3 * gmax)
+        d = p_.grad.cpu().to(ref.dtype) - ref
+        rel = d.abs().max().item() / max(ref.abs().max().item(), 1e-3 * gmax)
+        rel_all.append(rel)
+        l2 = d.norm().item() / max(ref.norm().item(), 1e-3 * gmax * math.sqrt(ref.numel()))
+        if l2 > l2_worst[0]:
+            l2_worst = (l2, k)
         if rel > worst:
             worst, worst_name = rel, k
         if rel > 2e-3:
             bad.append((k, round(rel, 5), float(ref.abs().max()), float(p_.grad.abs().max())))
-    m["worst_rel_grad_err"], m["worst_param"], m["n_params"], m["params_over_tol"] = worst, worst_name, len(sd), bad[:12]
-    assert worst <= 2e-3, m
+    m["worst_rel_grad_err"], m["worst_param"], m["n_params"], m["params_over_2e-3"] = worst, worst_name, len(sd), bad[:12]
+    m["worst_rel_l2_grad_err"], m["worst_l2_param"] = l2_worst
+    m["frac_params_within_2e-3"] = float(np.mean([r <= 2e-3 for r in rel_all]))
+    if not ref64:
+        assert worst <= 2e-3, m
+    else:
+        # Measured on the MI355X box against this fp64 reference (tools/diag_train512.py, round 4): torch's OWN fp32 autograd deviates by
+        # up to 2.4e-2 on single elements of the small-gradient layers here - at 512 x 512 a 1e-6 forward difference flips ReLU / L1-sign
+        # kinks on a few of the 10^5..10^6 positions a weight gradient sums over, and one flipped term is ~1 / sqrt(n) of such a sum.  The
+        # bounds are therefore: element-wise 6e-2 of the parameter's scale, 1.5e-2 in the L2 sense (a wiring error moves that to O(1)).
+        assert worst <= 6e-2 and l2_worst[0] <= 1.5e-2 and m["frac_params_within_2e-3"] >= 0.5, m
     return m
 
 
@@ -1530,8 +1550,9 @@ def check_generator_training_grads_512_full():
     """The same comparison AT THE SHAPES bench.py's ``personalize_step`` RUNS (BASELINE configs[4]; lwg_trainer.py:326-352, 732-832):
     512 x 512, num_filters [64, 128, 256], 6 residual blocks, ns = 2, nt = 1.  At this size the wiring picks split-K launches, the
     one-grid transposed convolutions, the stacked gamma | beta and K | V launches and the 4- / 8-lane slab reductions by shape -
-    none of which the 64 x 64 reduced-width case reaches together.  Flows: a rendered body at 512 x 512 (real -2 background)."""
-    return _generator_training_grads(512, *FULL, real_flows=True)
+    none of which the 64 x 64 reduced-width case reaches together.  Flows: a rendered body at 512 x 512 (real -2 background).
+    Reference: the oracle's autograd in fp64 (outputs <= 2e-3 as everywhere; the gradient bounds are explained in the helper)."""
+    return _generator_training_grads(512, *FULL, real_flows=True, ref64=True)
 
 
 def _ref_patch_discriminator(D):

@@ -15,8 +15,8 @@ def run(tag, B, ns, h, w, C, T, dt=torch.float32, kq_scale=1.0, kap_scale=1.0):
     kap = kap_scale * torch.randn(ns, h, w)
     bv = 0.3 * torch.randn(C)
     want = emu_ops.lwb_attention_x(x.double(), Kq.double(), kap.double(), Vs.double(), bv.double(), T.double(), torch.zeros(B, h, w, C).double())
-    nrec = ops.attn_tiles(h, w)
-    ws = torch.zeros(B * nrec * C * 3, device=DEV)
+    nrec = ops.attn_records(h, w, C, dt)
+    ws = torch.zeros(ops.instnorm_finalize_ws(B, C, nrec), device=DEV)
     got = ops.lwb_attention_x(x.to(DEV), Kq.to(DEV), kap.to(DEV), Vs.to(DEV), bv.to(DEV), T.to(DEV), torch.full((B, h, w, C), float("nan"), device=DEV, dtype=dt), stats=ws)
     torch.cuda.synchronize()
     err = (got.float().cpu().double() - want).abs()
