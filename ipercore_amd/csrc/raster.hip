@@ -344,7 +344,7 @@ extern "C" int lwg_rasterize_fim_wim_f32(const float* faces_v, int B, int nf, in
     const size_t bins = (size_t)B * nbx * nbx;
     int* bin_count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + lwg_raster_rec_bytes(B, nf));
     int* bin_list = bin_count + bins;
-    // a kernel, not hipMemsetAsync: the per-frame path is replayed as a hipGraph (Imitator.graph_single_frame) and stays a pure chain
+    // a kernel, not hipMemsetAsync: the per-frame path stays a pure chain of kernel launches (capturable as a hipGraph by a caller)
     // of kernel nodes (no memset / memcpy nodes whose blit arguments the runtime owns)
     hipLaunchKernelGGL(lwg_zero_i32_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, stream, bin_count, bins);
     hipLaunchKernelGGL(lwg_raster_setup_kernel, dim3((nf + 255) / 256, B), dim3(256), (size_t)2 * nbx * nbx * sizeof(int), stream,

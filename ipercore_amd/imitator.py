@@ -68,13 +68,11 @@ class TemporalFIFO(object):
 
 
 class Imitator(object):
-    def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8, streams=1, graph_single_frame=True):
+    def __init__(self, opt, device=torch.device("cuda:0"), frame_batch=8, streams=1):
         self._opt = opt
-        # frame_batch == 1 (the reference's calling convention: one frame per Imitator.forward, imitator.py:341): the ~100 launches of
-        # a frame are replayed as ONE hipGraph (static shapes) - the launches themselves are the same kernels in the same order, so
-        # the frames are bitwise those of eager launches
-        self.graph_single_frame = bool(graph_single_frame)
-        self._frame_graph = None
+        # frame_batch == 1 is the reference's calling convention (one frame per Imitator.forward, imitator.py:341): ~85 eager launches per
+        # frame.  (Rounds 2-3 replayed them as one hipGraph: measured equal to eager launches - 2.99 vs 2.97 ms per frame, the GPU is the
+        # bound at B = 1 - so that path and its capture / fallback logic were removed in round 4.)
         self._name = "Imitator"
         self.device = torch.device(device)
         self._frame_batch_req = int(frame_batch)   # what the caller asked for; ``frame_batch`` (property) is what runs
@@ -229,75 +227,6 @@ class Imitator(object):
                                                want_pred=True, want_mask=True)
         return pred, mask
 
-    # ------------------------------------------------------------------ frame_batch = 1: one hipGraph replay per frame
-    def _frame_graph_key(self, row, cam_strategy, sel):
-        gen = self.generator
-        return (cam_strategy, sel["primary_ids"], sel["use_selected_f2pts"], gen.conv_precision, tuple(row.shape), self.image_size)
-
-    def _frame_graph_current(self, fg, key):
-        """The captured graph reads THESE source tensors and THESE weight panels: besides the value key, the identities must match - the
-        graph dict holds both objects (a freed panel set's address can be handed to its successor, so ``id()`` alone proves nothing)."""
-        return fg is not None and fg.get("key") == key and fg.get("src_info") is self.src_info and fg.get("packed") is self.generator.packed()
-
-    def reset_frame_graph(self):
-        """Drop the captured single-frame graph.  It is keyed on the IDENTITY of ``src_info`` and of the packed weight panels: call this
-        after mutating ``src_info``'s tensors in place (``set_source`` / ``source_setup`` / ``swap_source_setup`` build a new dict and need
-        nothing)."""
-        self._frame_graph = None
-
-    def _graphed_frame(self, row, cam_strategy, sel):
-        """row (1, 85 | 156) on the device -> pred (1,3,S,S): the per-frame path captured once (per source state / weight version /
-        precision mode) and replayed.  Returns None when the frame must run eager (first_cam not fixed yet, capture unavailable)."""
-        if cam_strategy == "smooth" and self.first_cam is None:
-            return None                                   # frame 0 of an un-prepared sequence fixes first_cam on the host path
-        key = self._frame_graph_key(row, cam_strategy, sel)
-        fg = self._frame_graph
-        if not self._frame_graph_current(fg, key):
-            if (fg is not None and fg.get("failed") == key and fg.get("failed_src") is self.src_info
-                    and fg.get("failed_packed") is self.generator.packed()):
-                return None
-            try:
-                fg = self._capture_frame(row, cam_strategy, sel, key)
-            except Exception as e:                        # loud fall-back to eager launches (same kernels, same frames)
-                import warnings
-                warnings.warn(f"Imitator: capturing the single-frame path as a hipGraph failed ({type(e).__name__}: {e}); eager launches")
-                torch.cuda.synchronize()
-                self._frame_graph = {"key": None, "failed": key, "failed_src": self.src_info, "failed_packed": self.generator.packed()}
-                return None
-            self._frame_graph = fg
-        fc = self.first_cam
-        if fc is not None and (fg["fc_id"] is not fc or fg["fc_ver"] != fc._version):
-            fg["first_cam"].copy_(fc)
-            fg["fc_id"], fg["fc_ver"] = fc, fc._version
-        fg["row"].copy_(row)
-        fg["graph"].replay()
-        return fg["out"].clone()                          # the static output is overwritten by the next replay
-
-    def _capture_frame(self, row, cam_strategy, sel, key):
-        dev = row.device
-        static_row = row.clone()
-        static_fc = (self.first_cam if self.first_cam is not None else row[0:1, 0:3]).clone()
-        prev_fc, self.first_cam = self.first_cam, static_fc      # the captured kernels read first_cam from this fixed buffer
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                 # warm-up: every kernel variant launched once (dynamic-LDS opt-ins happen here)
-                for _ in range(2):
-                    tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, static_row, cam_strategy, t=1, **sel)
-                    self.forward(tsf8, Tst)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            # thread_local: HIP calls of OTHER threads (the FrameWriter's event waits / D2H copies, the RCCL watchdog) while this thread
-            # captures are legal and must not fail the capture - or surface as an error in that other thread
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, static_row, cam_strategy, t=1, **sel)
-                out = self.forward(tsf8, Tst)[0]
-        finally:
-            self.first_cam = prev_fc
-        return {"key": key, "graph": g, "row": static_row, "first_cam": static_fc, "out": out, "fc_id": None, "fc_ver": None,
-                "src_info": self.src_info, "packed": self.generator.packed()}      # keeps the captured source state and weight panels alive
-
     @torch.no_grad()
     def synthesize(self, tgt_smpls, cam_strategy="smooth", t0=0, use_selected_f2pts=False):
         """Frames [t0, t0+n) of an (already stabilised) device tensor (n,85) -> pred (n,3,S,S) on the device."""
@@ -305,16 +234,6 @@ class Imitator(object):
         sel = dict(primary_ids=self.primary_ids, use_selected_f2pts=use_selected_f2pts)
         if tgt_smpls.shape[0] == 0:               # an empty shard (clip shorter than the number of ranks): an empty video block
             return torch.empty((0, 3, self.image_size, self.image_size), device=tgt_smpls.device, dtype=torch.float32)
-        if (self.frame_batch == 1 and self.graph_single_frame and self.streams == 1 and tgt_smpls.is_cuda and ops.CONV_HOOK is None
-                and not torch.cuda.is_current_stream_capturing()):
-            for s in range(tgt_smpls.shape[0]):
-                row = tgt_smpls[s:s + 1]
-                pred = self._graphed_frame(row, cam_strategy, sel)
-                if pred is None:
-                    tsf8, Tst, _ = self.make_inputs_for_tsf(self.src_info, row, cam_strategy, t=t0 + s, **sel)
-                    pred = self.forward(tsf8, Tst)[0]
-                outs.append(pred)
-            return torch.cat(outs, dim=0)
         if self.streams > 1 and tgt_smpls.is_cuda:
             # frames are independent: batches alternate over HIP streams so one batch's kernel tails, launch gaps and
             # HBM-bound kernels overlap another batch's MFMA work (+6 % frames/s at 3 streams on MI355X)

@@ -124,23 +124,60 @@ class _Packed:
         self.head = P.pack_head(sd["tsf_img_reg.0.weight"], sd["tsf_att_reg.0.weight"]).to(dev)
         # bf16 mode: the same regressors as an MFMA operand panel (csrc/bf16_ops.hip); needs the 64-channel decoder output
         self.head16 = P.pack_head_bf16(sd["tsf_img_reg.0.weight"], sd["tsf_att_reg.0.weight"]).to(dev) if nf[0] == 64 else None
-        self.bg = None
-        if gen.has_bg:
-            bgf = gen.bg_filters
-            i = 0
-            layers = [("conv", conv(f"bg_net.main.{i}", stride=1, pad=3, cin_pad=4))]
-            i += 3
-            for d in range(1, len(bgf)):
-                layers.append(("conv", conv(f"bg_net.main.{i}", stride=2)))
-                i += 3
-            for _ in range(n_res):
-                layers.append(("res", (conv(f"bg_net.main.{i}.main.0"), conv(f"bg_net.main.{i}.main.3"))))
-                i += 1
-            for d in range(len(bgf) - 1, 0, -1):
-                layers.append(("convT", convT(f"bg_net.main.{i}")))
-                i += 3
-            layers.append(("out", conv(f"bg_net.main.{i}", stride=1, pad=3, n_pad=64)))
-            self.bg = layers
+        self.bg = pack_bg_layers(sd, gen.bg_filters, n_res, dev) if gen.has_bg else None
+
+
+def pack_bg_layers(sd, bgf, n_res, dev):
+    """The background network (ResNetInpaintor, bg_inpaintor.py:24-60) as a list of (kind, packed spec) in execution order."""
+    P = packing
+
+    def conv(name, stride=1, pad=None, cin_pad=None, n_pad=None):
+        return P.spec_to(P.pack_conv(sd[name + ".weight"], sd.get(name + ".bias"), stride, pad, cin_pad, n_pad), dev)
+
+    def convT(name, n_pad=None):
+        return [P.spec_to(s, dev) for s in P.pack_conv_transpose(sd[name + ".weight"], sd.get(name + ".bias"), n_pad)]
+    i = 0
+    layers = [("conv", conv(f"bg_net.main.{i}", stride=1, pad=3, cin_pad=4))]
+    i += 3
+    for d in range(1, len(bgf)):
+        layers.append(("conv", conv(f"bg_net.main.{i}", stride=2)))
+        i += 3
+    for _ in range(n_res):
+        layers.append(("res", (conv(f"bg_net.main.{i}.main.0"), conv(f"bg_net.main.{i}.main.3"))))
+        i += 1
+    for d in range(len(bgf) - 1, 0, -1):
+        layers.append(("convT", convT(f"bg_net.main.{i}")))
+        i += 3
+    layers.append(("out", conv(f"bg_net.main.{i}", stride=1, pad=3, n_pad=64)))
+    return layers
+
+
+def run_bg_layers(layers, bg4):
+    """bg4 (n,S,S,4) NHWC through the packed background network -> (n,3,S,S) NCHW (InstanceNorm after every conv, tanh at the end)."""
+    scratch = _Scratch()
+    x = bg4
+
+    def norm(t, act, res=None):
+        B, h, w, C = t.shape
+        mean, rstd = t.new_empty(B, C), t.new_empty(B, C)
+        nsplit = max(1, min(64, (h * w) // 64))
+        ops.instnorm_stats(t, mean, rstd, scratch.get(B * C * nsplit * 3, t.device), eps=1e-5, nsplit=nsplit)
+        return ops.instnorm_apply(t, mean, rstd, torch.empty_like(t), act=act, res=res)
+
+    for kind, spec in layers:
+        B, H, W, _ = x.shape
+        if kind == "conv":
+            y = ops.conv2d(x, spec, x.new_empty(B, H // spec.stride, W // spec.stride, spec.N))
+            x = norm(y, ops.ACT_RELU)
+        elif kind == "res":
+            h = norm(ops.conv2d(x, spec[0], torch.empty_like(x)), ops.ACT_RELU)
+            x = norm(ops.conv2d(h, spec[1], torch.empty_like(x)), ops.ACT_NONE, res=x)
+        elif kind == "convT":
+            y = x.new_empty(B, 2 * H, 2 * W, spec[0].N)
+            x = norm(ops.conv_transpose2d(x, spec, y, act=ops.ACT_NONE), ops.ACT_RELU)
+        else:
+            y = ops.conv2d(x, spec, x.new_empty(B, H, W, spec.N), act=ops.ACT_TANH)
+            return ops.nhwc_to_nchw(y, channels=3)
 
 
 def _param_version(gen):
@@ -257,7 +294,11 @@ class AttentionLWBGenerator(nn.Module):
         rstd = tsf_x.new_empty(B, C, dtype=torch.float32)
         nrec = ops.attn_records(h, w, C, tsf_x.dtype)
         ws = scratch.get(ops.instnorm_finalize_ws(B, C, nrec), tsf_x.device)
-        att = ops.lwb_attention_x(tsf_x, kv[0], kv[2], kv[1], st["bv"], scratch.flow(Tst, h, w), torch.empty_like(tsf_x), stats=ws,
+        flow = scratch.flow(Tst, h, w)
+        if tuple(flow.shape[2:4]) != (h, w):
+            raise NotImplementedError("the attention block takes flows resized to its feature size: non-square feature maps are not built "
+                                      "(image_size is one number throughout the reference)")
+        att = ops.lwb_attention_x(tsf_x, kv[0], kv[2], kv[1], st["bv"], flow, torch.empty_like(tsf_x), stats=ws,
                                   src_batched=batched)
         ops.instnorm_finalize(ws, B, C, nrec, mean, rstd, eps=1e-5)
         actv = ops.conv2d(att, st["shared"], tsf_x.new_empty(B, h, w, st["shared"].N), act=ops.ACT_RELU)
@@ -316,30 +357,7 @@ class AttentionLWBGenerator(nn.Module):
     @torch.no_grad()
     def _run_bg_impl(self, bg4):
         """bg4 (n,S,S,4) NHWC -> (n,3,S,S) NCHW."""
-        pk = self.packed()
-        scratch = _Scratch()
-        x = bg4
-
-        def norm(t, act, res=None):
-            B, h, w, C = t.shape
-            mean, rstd = t.new_empty(B, C), t.new_empty(B, C)
-            nsplit = max(1, min(64, (h * w) // 64))
-            ops.instnorm_stats(t, mean, rstd, scratch.get(B * C * nsplit * 3, t.device), eps=1e-5, nsplit=nsplit)
-            return ops.instnorm_apply(t, mean, rstd, torch.empty_like(t), act=act, res=res)
-
-        for kind, spec in pk.bg:
-            B, H, W, _ = x.shape
-            if kind == "conv":
-                y = ops.conv2d(x, spec, x.new_empty(B, H // spec.stride, W // spec.stride, spec.N))
-                x = norm(y, ops.ACT_RELU)
-            elif kind == "res":
-                h = norm(ops.conv2d(x, spec[0], torch.empty_like(x)), ops.ACT_RELU)
-                x = norm(ops.conv2d(h, spec[1], torch.empty_like(x)), ops.ACT_NONE, res=x)
-            elif kind == "convT":
-                x = norm(self._upconv(x, spec, ops.ACT_NONE), ops.ACT_RELU)
-            else:
-                y = ops.conv2d(x, spec, x.new_empty(B, H, W, spec.N), act=ops.ACT_TANH)
-                return ops.nhwc_to_nchw(y, channels=3)
+        return run_bg_layers(self.packed().bg, bg4)
 
     @torch.no_grad()
     def _run_src_decode_impl(self, x):
@@ -503,6 +521,8 @@ class _Scratch:
         sites share one): the block kernels then read one coalesced value per pixel and source instead of resizing per pixel."""
         if Tst.shape[2] == h and Tst.shape[3] == w:
             return Tst
+        if h != w:                                        # the Add / Avg / SoftGate kernels take a square field: their in-kernel resize
+            return Tst
         key = (h, w, Tst.data_ptr())
         if key not in self.flows:
             self.flows[key] = ops.flow_resize(Tst, h, w)
@@ -523,3 +543,149 @@ def _get(cfg, key, default=None):
     if default is not None:
         return default
     raise KeyError(key)
+
+
+class _ConcatPacked:
+    """Packed panels of ``bg_net`` + ``tsf_net`` (ResAutoEncoder) for the input-concatenation baselines."""
+
+    def __init__(self, gen):
+        sd = {k: v for k, v in gen.named_parameters()}
+        dev = next(gen.parameters()).device
+        self.version = _param_version(gen)
+        P = packing
+        nf, n_down = gen.num_filters, len(gen.num_filters)
+
+        def conv(name, stride=1, pad=None, cin_pad=None):
+            return P.spec_to(P.pack_conv(sd[name + ".weight"], sd.get(name + ".bias"), stride, pad, cin_pad, None), dev)
+        self.enc = [conv(f"tsf_net.encoders.layers.{i}.0", stride=2, cin_pad=gen.cin_pad if i == 0 else None) for i in range(n_down)]
+        self.res = [(conv(f"tsf_net.res_blocks.{i}.main.0"), conv(f"tsf_net.res_blocks.{i}.main.2")) for i in range(gen.n_res_block)]
+        self.dec = [[P.spec_to(sp, dev) for sp in P.pack_conv_transpose(sd[f"tsf_net.decoders.layers.{i}.0.weight"],
+                                                                       sd[f"tsf_net.decoders.layers.{i}.0.bias"], None)] for i in range(n_down)]
+        self.head = P.pack_head(sd["tsf_net.img_reg.0.weight"], sd["tsf_net.att_reg.0.weight"]).to(dev)
+        self.bg = pack_bg_layers(sd, gen.bg_filters, gen.bg_n_res_block, dev)
+
+
+class InputConcatGenerator(nn.Module):
+    """generators/input_concat_resunet.py:182-307 (factory name ``InputConcat``, networks/__init__.py:38-40): NO warp - the sources
+    (padded by repetition / truncated to ``cfg.TSFNet.num_source``, :215-249) are concatenated with the target's condition channels and go
+    through ONE ``ResAutoEncoder`` (:126-179; ``cond_nc`` = 6 num_source + 3 = 27), plus the background network.  A baseline of the
+    paper behind the same four methods as every generator; the convolutions run on the MFMA kernels (the 27-channel input is
+    zero-extended to 32), the regressors + tanh / sigmoid on the head kernel."""
+    has_bg = True
+
+    def __init__(self, cfg, temporal=False):
+        super().__init__()
+        self._name = _get(cfg, "name", "InputConcat")
+        tsf, bgc = _get(cfg, "TSFNet"), _get(cfg, "BGNet")
+        self.num_filters = [int(c) for c in _get(tsf, "num_filters")]
+        self.n_res_block = int(_get(tsf, "n_res_block"))
+        self.cond_nc = int(_get(tsf, "cond_nc"))
+        self.num_source = int(_get(tsf, "num_source", 4)) if self._uses_sources() else None
+        self.bg_filters = [int(c) for c in _get(bgc, "num_filters")]
+        self.bg_n_res_block = int(_get(bgc, "n_res_block"))
+        self.temporal = temporal
+        if self.num_filters[0] != 64 or any(c not in (64, 128, 256) for c in self.num_filters):
+            raise ValueError(f"num_filters must start with 64 and stay in {{64,128,256}} for the HIP kernels, got {self.num_filters}")
+        # the conv kernels take Cin in {4, 8, 16} or a multiple of 32: the network input is zero-extended
+        self.cin_pad = 8 if self.cond_nc <= 8 else (16 if self.cond_nc <= 16 else (self.cond_nc + 31) // 32 * 32)
+        from .params import concat_generator_param_shapes
+        tree = ParamTree(concat_generator_param_shapes(self.num_filters, self.n_res_block, self.bg_filters, self.cond_nc,
+                                                        int(_get(bgc, "cond_nc", 4)), self.bg_n_res_block))
+        for name, child in tree.named_children():
+            self.add_module(name, child)
+        self._packed = None
+
+    def _uses_sources(self):
+        return True
+
+    def packed(self):
+        if self._packed is None or self._packed.version != _param_version(self):
+            self._packed = _ConcatPacked(self)
+        return self._packed
+
+    @staticmethod
+    def _check(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("ipercore_amd generator runs on the MI355X only: got a CPU tensor (no fallback)")
+
+    @torch.no_grad()
+    def forward_bg(self, bg_inputs):
+        """(bs, ns, 4, h, w) -> (bs, ns, 3, h, w)."""
+        self._check(bg_inputs)
+        bs, ns, c, h, w = bg_inputs.shape
+        x = ops.nchw_to_nhwc(bg_inputs.reshape(bs * ns, c, h, w).contiguous().float(), c_pad=4)
+        return run_bg_layers(self.packed().bg, x).view(bs, ns, 3, h, w)
+
+    def forward_src(self, src_inputs, only_enc=True):
+        """:215-249: no network - the sources, repeated / cut to ``num_source``, as one (bs, ns * 6, h, w) tensor (returned twice)."""
+        bs, ns, _, h, w = src_inputs.shape
+        need = self.num_source
+        if ns > need:
+            src_inputs = src_inputs[:, 0:need]
+        elif ns < need:
+            src_inputs = torch.cat([src_inputs, torch.stack([src_inputs[:, s % ns] for s in range(need - ns)], dim=1)], dim=1)
+        enc = src_inputs.reshape(bs, -1, h, w)
+        return (enc, enc) if only_enc else (enc, enc, None, None)
+
+    @torch.no_grad()
+    def _autoencode(self, inputs):
+        """(n, cond_nc, h, w) NCHW -> (img (n,3,h,w), mask (n,1,h,w)): ResAutoEncoder.forward (:160-169)."""
+        self._check(inputs)
+        pk = self.packed()
+        x = ops.nchw_to_nhwc(inputs.contiguous().float(), c_pad=self.cin_pad)
+        for spec in pk.enc:
+            n, H, W, _ = x.shape
+            x = ops.conv2d(x, spec, x.new_empty(n, H // 2, W // 2, spec.N), act=ops.ACT_RELU)
+        for c0, c1 in pk.res:
+            t = ops.conv2d(x, c0, torch.empty_like(x), act=ops.ACT_RELU)
+            x = ops.conv2d(t, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
+        for specs in pk.dec:
+            n, H, W, _ = x.shape
+            x = ops.conv_transpose2d(x, specs, x.new_empty(n, 2 * H, 2 * W, specs[0].N), act=ops.ACT_RELU)
+        _, mask, img = ops.head_compose(x, pk.head, None, want_pred=False, want_mask=True, want_img=True)
+        return img, mask
+
+    @torch.no_grad()
+    def forward_tsf(self, tsf_inputs, src_enc_outs, src_res_outs=None, Tst=None, temp_enc_outs=None, temp_res_outs=None, Ttt=None):
+        """:251-277: cat[sources, the target's last three (condition) channels] -> ResAutoEncoder."""
+        return self._autoencode(torch.cat([src_enc_outs, tsf_inputs[:, -3:]], dim=1))
+
+    @torch.no_grad()
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst=None, Ttt=None, only_tsf=True):
+        """:279-307 -> (bg_img (bs,ns,3,h,w), tsf_imgs (bs,nt,3,h,w), tsf_masks (bs,nt,1,h,w))."""
+        bg_img = self.forward_bg(bg_inputs)
+        enc, _ = self.forward_src(src_inputs, only_enc=True)
+        outs = [self.forward_tsf(tsf_inputs[:, t], enc) for t in range(tsf_inputs.shape[1])]
+        return bg_img, torch.stack([o[0] for o in outs], dim=1), torch.stack([o[1] for o in outs], dim=1)
+
+
+class TextureWarpingGenerator(InputConcatGenerator):
+    """generators/texture_warping_resunet.py:8-112 (factory name ``TextureWarping``): the transfer network sees ONLY ``tsf_inputs`` -
+    the UV-warped synthetic image already inside them (flowcomposition.py:206-248) plus the condition; ``cond_nc`` = 6."""
+
+    def __init__(self, cfg, temporal=False):
+        super().__init__(cfg, temporal)
+        self._name = _get(cfg, "name", "TextureWarping")
+
+    def _uses_sources(self):
+        return False
+
+    def forward_src(self, src_inputs, only_enc=True):
+        """:40-60: the sources as one (bs, ns * 6, h, w) view; nothing consumes it."""
+        bs, ns, _, h, w = src_inputs.shape
+        enc = src_inputs.reshape(bs, -1, h, w)
+        return (enc, enc) if only_enc else (enc, enc, None, None)
+
+    @torch.no_grad()
+    def forward_tsf(self, tsf_inputs, src_enc_outs=None, src_res_outs=None, Tst=None, temp_enc_outs=None, temp_res_outs=None, Ttt=None):
+        """:62-84."""
+        return self._autoencode(tsf_inputs)
+
+    @torch.no_grad()
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, Tst=None, Ttt=None, only_tsf=True):
+        """:86-112: every target frame in one batch."""
+        bg_img = self.forward_bg(bg_inputs)
+        bs, nt, c, h, w = tsf_inputs.shape
+        img, mask = self._autoencode(tsf_inputs.reshape(bs * nt, c, h, w))
+        return bg_img, img.view(bs, nt, 3, h, w), mask.view(bs, nt, 1, h, w)

@@ -107,3 +107,30 @@ def generator_param_shapes(num_filters=(64, 128, 256), n_res_block=6, bg_filters
     _conv(spec, "tsf_img_reg.0", 3, nf[0], 5, bias=False)
     _conv(spec, "tsf_att_reg.0", 1, nf[0], 5, bias=False)
     return spec
+
+
+def resautoencoder_param_shapes(spec, prefix, in_channel, num_filters, n_res_block):
+    """ResAutoEncoder (input_concat_resunet.py:126-179 / attlwb_spade_resunet.py:360-412): Encoder with bias, residual blocks, the plain
+    Decoder (reversed filters, no skips), the 5x5 image / mask regressors - under ``prefix`` ("src_net", "tsf_net")."""
+    nf = list(num_filters)
+    n_down = len(nf)
+    for i in range(n_down):
+        _conv(spec, f"{prefix}.encoders.layers.{i}.0", nf[i], in_channel if i == 0 else nf[i - 1], 3)
+    for i in range(n_res_block):
+        _conv(spec, f"{prefix}.res_blocks.{i}.main.0", nf[-1], nf[-1], 3)
+        _conv(spec, f"{prefix}.res_blocks.{i}.main.2", nf[-1], nf[-1], 3)
+    rev = list(reversed(nf))
+    for i in range(n_down):
+        _convT(spec, f"{prefix}.decoders.layers.{i}.0", nf[-1] if i == 0 else rev[i - 1], rev[i])
+    _conv(spec, f"{prefix}.img_reg.0", 3, nf[0], 5, bias=False)
+    _conv(spec, f"{prefix}.att_reg.0", 1, nf[0], 5, bias=False)
+
+
+def concat_generator_param_shapes(num_filters=(64, 128, 256), n_res_block=6, bg_filters=(64, 128, 128, 256), cond_nc=27, bg_cond_nc=4,
+                                  bg_n_res_block=None):
+    """InputConcatGenerator (input_concat_resunet.py:182-307; cond_nc = 27) / TextureWarpingGenerator (texture_warping_resunet.py:8-112;
+    cond_nc = 6): ``bg_net`` (ResNetInpaintor) + ``tsf_net`` (ResAutoEncoder)."""
+    spec = OrderedDict()
+    bg_net_param_shapes(spec, bg_cond_nc, list(bg_filters), n_res_block if bg_n_res_block is None else bg_n_res_block)
+    resautoencoder_param_shapes(spec, "tsf_net", cond_nc, num_filters, n_res_block)
+    return spec

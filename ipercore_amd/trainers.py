@@ -171,12 +171,41 @@ class PatchGlobalDiscriminator(GlobalDiscriminator):
         super().__init__(None, False, cond_nc=cond_nc, ndf=ndf, n_layers=n_layers, max_nf_mult=max_nf_mult)
 
 
+class MultiScaleDiscriminator(nn.Module):
+    """multi_scale_dis.py:287-332 (factory name ``multi_scale``): an optional global PatchDiscriminator on ``global_x`` plus two
+    PatchDiscriminators on ``local_x`` and on its half-size bilinear (align_corners=True) resize; ``forward`` returns the list
+    [global?, scale 0, scale 1].  The reference's positional signature; ``norm_type`` must be "instance" (its default, "batch", is not
+    built: no runner or config of the reference constructs this class).  The reference's ``get_avg=True`` path calls an undefined
+    ``self.reduce_tensor`` and raises; here it returns the mean logit as its other discriminators do (``reduce_tensor`` :9-18)."""
+
+    def __init__(self, global_nc, input_nc, ndf=32, n_layers=3, max_nf_mult=8, norm_type="batch", use_sigmoid=False):
+        super().__init__()
+        self.n_scales = 2
+        self.scale_models = nn.ModuleList([PatchDiscriminator(input_nc, ndf, n_layers, max_nf_mult, norm_type, use_sigmoid)
+                                           for _ in range(self.n_scales)])
+        self.global_model = PatchDiscriminator(global_nc, ndf, n_layers, max_nf_mult, norm_type, use_sigmoid) if global_nc is not None else None
+
+    def forward(self, global_x, local_x, body_rects=None, head_rects=None, get_avg=True):
+        outs = []
+        if self.global_model is not None:
+            outs.append(self.global_model(global_x))
+        _, _, H, W = local_x.shape
+        x = local_x
+        for i in range(self.n_scales):
+            outs.append(self.scale_models[i](x))
+            if i < self.n_scales - 1:
+                fact = 2 ** (i + 1)
+                x = F.interpolate(local_x, size=(H // fact, W // fact), mode="bilinear", align_corners=True)
+        return (outs, _reduce_outs(outs)) if get_avg else outs
+
+
 def create_discriminator(name, cfg=None, use_aug_bg=False):
     """The discriminator entries of the reference's NetworksFactory (networks/__init__.py:50-60)."""
     table = {"patch_global": GlobalDiscriminator, "patch_global_local": GlobalLocalDiscriminator,
              "patch_global_body_head": GlobalBodyHeadDiscriminator}
     if name not in table:
-        raise ValueError(f"Network {name} not recognized (built: {sorted(table)}; multi_scale is not)")
+        raise ValueError(f"Network {name} not recognized (built: {sorted(table)}; multi_scale has its own constructor signature: "
+                         "NetworksFactory.get_by_name('multi_scale', global_nc, input_nc, ...))")
     return table[name](cfg, use_aug_bg=use_aug_bg)
 
 

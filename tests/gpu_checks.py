@@ -506,6 +506,56 @@ def check_lwb_variant_generators():
     return out
 
 
+def check_concat_baselines_and_multi_scale():
+    """The remaining names of the reference's NetworksFactory (networks/__init__.py:38-48) on the GPU: ``InputConcat`` /
+    ``TextureWarping`` (one ResAutoEncoder over concatenated inputs, no warp) and the ``multi_scale`` discriminator, against outputs of
+    the reference's OWN classes (tests/golden/golden_concat_v1.npz, make_golden_concat.py); multi_scale additionally backward against
+    the reference architecture rebuilt on the CPU."""
+    from tests.golden.make_golden_concat import concat_cfg, inputs
+    from ipercore_amd.networks import NetworksFactory
+    gc = np.load(os.path.join(ROOT, "tests", "golden", "golden_concat_v1.npz"))
+    bg_in, src_in, tsf_in = (t.to(DEV) for t in inputs())
+    out = {}
+    for name in ("InputConcat", "TextureWarping"):
+        cfg = concat_cfg(name, 27, 4) if name == "InputConcat" else concat_cfg(name, 6)
+        G = NetworksFactory.get_by_name(name, cfg=cfg, temporal=False).eval()
+        shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        assert hashlib.sha256("\n".join(f"{k}:{shapes[k]}" for k in sorted(shapes)).encode()).hexdigest() == str(gc[f"{name}/keys_sha"])
+        G.load_state_dict({k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=13).items()}, strict=True)
+        G.to(DEV)
+        enc, _ = G.forward_src(src_in, only_enc=True)
+        img, mask = G.forward_tsf(tsf_in[:, 0], enc)
+        bg, imgs, masks = G(bg_in, src_in, tsf_in)
+        torch.cuda.synchronize()
+        out[name] = {"img": _cmp(img, torch.tensor(gc[f"{name}/img"]), 2e-4, name + " img"),
+                     "mask": _cmp(mask, torch.tensor(gc[f"{name}/mask"]), 2e-4, name + " mask"),
+                     "bg": _cmp(bg, torch.tensor(gc[f"{name}/bg"]), 5e-4, name + " bg"),
+                     "imgs": _cmp(imgs, torch.tensor(gc[f"{name}/imgs"]), 2e-4, name + " imgs"),
+                     "masks": _cmp(masks, torch.tensor(gc[f"{name}/masks"]), 2e-4, name + " masks")}
+    D = NetworksFactory.get_by_name("multi_scale", 6, 6, ndf=32, n_layers=3, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    assert hashlib.sha256("\n".join(f"{k}:{shapes[k]}" for k in sorted(shapes)).encode()).hexdigest() == str(gc["multi_scale/keys_sha"])
+    D.load_state_dict({k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=17).items()}, strict=True)
+    D.to(DEV)
+    S = 64
+    gx = torch.tensor(synthetic.uniform_image((2, 6, S, S), 30, "global_x"))
+    lx = torch.tensor(synthetic.uniform_image((2, 6, S, S), 31, "local_x"))
+    lxd = lx.to(DEV).requires_grad_(True)
+    outs = D(gx.to(DEV), lxd, None, None, get_avg=False)
+    sum((o ** 2).mean() for o in outs).backward()
+    torch.cuda.synchronize()
+    out["multi_scale"] = {f"out{i}": _cmp(o, torch.tensor(gc[f"multi_scale/out{i}"]), 2e-4, f"multi_scale out{i}") for i, o in enumerate(outs)}
+    # backward: the two scale models see local_x and its half-size resize - the input gradient against the reference architecture on the CPU
+    refs = [_ref_patch_discriminator(m) for m in D.scale_models]
+    lxr = lx.clone().requires_grad_(True)
+    ro = [refs[0](lxr), refs[1](F.interpolate(lxr, size=(S // 2, S // 2), mode="bilinear", align_corners=True))]
+    sum((o ** 2).mean() for o in ro).backward()
+    rel = float((lxd.grad.cpu() - lxr.grad).abs().max() / lxr.grad.abs().max())
+    out["multi_scale"]["input_rel_grad_err"] = rel
+    assert rel <= 2e-3, out["multi_scale"]
+    return out
+
+
 _RUNS = {}          # oracle runs are the expensive part of this file: one per (configuration), shared by the checks that need its frames
 
 
@@ -2201,5 +2251,5 @@ ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_in
        check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
        check_generator_training_grads, check_generator_training_grads_512_full, check_num_source_8_at_512, check_only_vis_256,
-       check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants,
+       check_discriminator_and_trainer_step, check_bf16_generator, check_edge_cases, check_temporal_mode, check_train_ops, check_attention_backward, check_split_products, check_lwb_variant_generators, check_swapper, check_concat_baselines_and_multi_scale, check_personalize_loop, check_reference_shape_tests, check_vgg_loss, check_face_loss, check_smpl24, check_textured_render, check_discriminator_variants,
        check_graph_vs_eager_steps, check_graph_vs_eager_steps_512_full, check_rccl_world1]

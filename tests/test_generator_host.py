@@ -108,7 +108,63 @@ def test_cpu_tensors_fail_loudly():
 
 def test_unknown_network_name():
     with pytest.raises(ValueError):
-        NetworksFactory.get_by_name("InputConcat", cfg=None)
+        NetworksFactory.get_by_name("AttLWB-AdaIN", cfg=None)
+
+
+def _concat_case(name):
+    from tests.golden.make_golden_concat import concat_cfg, inputs
+    gc = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_concat_v1.npz"))
+    cfg = concat_cfg(name, 27, 4) if name == "InputConcat" else concat_cfg(name, 6)
+    G = NetworksFactory.get_by_name(name, cfg=cfg, temporal=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    import hashlib
+    assert hashlib.sha256("\n".join(f"{k}:{shapes[k]}" for k in sorted(shapes)).encode()).hexdigest() == str(gc[f"{name}/keys_sha"])
+    G.load_state_dict({k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=13).items()}, strict=True)
+    return G, gc, inputs()
+
+
+@pytest.mark.parametrize("name", ["InputConcat", "TextureWarping"])
+def test_concat_baseline_generators_through_emulated_abi(monkeypatch, name):
+    """The input-concatenation baselines of the reference's factory (networks/__init__.py:38-44; input_concat_resunet.py:182-307,
+    texture_warping_resunet.py:8-112): state_dict keys and the outputs of all four methods against the reference's OWN classes."""
+    emu_ops.install(monkeypatch)
+    G, gc, (bg_in, src_in, tsf_in) = _concat_case(name)
+    enc, enc2 = G.forward_src(src_in, only_enc=True)
+    assert tuple(enc.shape) == tuple(gc[f"{name}/src_enc_shape"]) and enc2 is enc
+    assert G.forward_src(src_in, only_enc=False)[2:] == (None, None)
+    img, mask = G.forward_tsf(tsf_in[:, 0], enc)
+    assert np.abs(img.numpy() - gc[f"{name}/img"]).max() <= 2e-4 and np.abs(mask.numpy() - gc[f"{name}/mask"]).max() <= 2e-4
+    bg, imgs, masks = G(bg_in, src_in, tsf_in)
+    assert np.abs(bg.numpy() - gc[f"{name}/bg"]).max() <= 5e-4
+    assert np.abs(imgs.numpy() - gc[f"{name}/imgs"]).max() <= 2e-4 and np.abs(masks.numpy() - gc[f"{name}/masks"]).max() <= 2e-4
+    if name == "InputConcat":          # more sources than num_source are cut, fewer are repeated (:215-249)
+        six = torch.cat([src_in, src_in, src_in], dim=1)
+        assert torch.equal(G.forward_src(six)[0], six[:, :4].reshape(1, 24, S, S))
+        assert torch.equal(G.forward_src(src_in[:, :1])[0], src_in[:, :1].repeat(1, 4, 1, 1, 1).reshape(1, 24, S, S))
+
+
+def test_multi_scale_discriminator_host_logic(monkeypatch):
+    """``multi_scale`` (discriminators/multi_scale_dis.py:287-332) through the factory: keys and logits against the reference's OWN class."""
+    import hashlib
+    import unittest.mock as um
+    from ipercore_amd.networks import training as tr
+    emu_ops.install(monkeypatch)
+    monkeypatch.setattr(tr.ConvFn, "forward", staticmethod(_cpu_ok(tr.ConvFn.forward)))
+    gc = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_concat_v1.npz"))
+    D = NetworksFactory.get_by_name("multi_scale", 6, 6, ndf=32, n_layers=3, max_nf_mult=8, norm_type="instance", use_sigmoid=False)
+    shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    assert hashlib.sha256("\n".join(f"{k}:{shapes[k]}" for k in sorted(shapes)).encode()).hexdigest() == str(gc["multi_scale/keys_sha"])
+    D.load_state_dict({k: torch.tensor(v) for k, v in synthetic.fill_state_dict(shapes, seed=17).items()}, strict=True)
+    gx = torch.tensor(synthetic.uniform_image((2, 6, S, S), 30, "global_x"))
+    lx = torch.tensor(synthetic.uniform_image((2, 6, S, S), 31, "local_x"))
+    with torch.no_grad(), um.patch.object(torch.Tensor, "is_cuda", new_callable=um.PropertyMock, return_value=True):
+        outs, avg = D(gx, lx, None, None, get_avg=True)
+    assert len(outs) == 3
+    for i, o in enumerate(outs):
+        assert np.abs(o.numpy() - gc[f"multi_scale/out{i}"]).max() <= 2e-4, i
+    assert abs(float(avg) - float(np.mean([gc[f"multi_scale/out{i}"].mean() for i in range(3)]))) <= 1e-4
+    with pytest.raises(NotImplementedError):
+        NetworksFactory.get_by_name("multi_scale", 6, 6)               # the reference default norm_type="batch" is not built
 
 
 def test_training_conv_packing_cpu(monkeypatch):
@@ -218,7 +274,7 @@ def test_discriminator_variants_host_logic(monkeypatch):
     assert [o.shape[1] for o in outs] == [1, 1] and torch.equal(outs[0], x.mean(dim=1, keepdim=True))     # [global, bg]
     outs = G1(x)                                                                                           # the trainer's tensor form
     assert len(outs) == 1
-    with pytest.raises(ValueError):
+    with pytest.raises(TypeError):                  # multi_scale has the reference's own positional signature (global_nc, input_nc, ...), not (cfg)
         NetworksFactory.get_by_name("multi_scale", cfg)
 
 
