@@ -30,5 +30,7 @@ done
 # per-launch HBM-side traffic of the dominant kernel -> profiles/pmc_traffic.json (read by bench.py) + per-kernel tables
 if [ -d gpurun_out/pmc_fetch$TAG ] && [ -d gpurun_out/pmc_write$TAG ]; then
   python tools/pmc_summary.py --traffic gpurun_out/pmc_fetch$TAG gpurun_out/pmc_write$TAG gpurun_out/pmc_traffic$TAG.json "$KERNEL"
+  python tools/pmc_summary.py gpurun_out/pmc_fetch$TAG gpurun_out/pmc_fetch$TAG.md > /dev/null 2>&1      # per-kernel tables (all kernels) before the raw CSVs are pruned
+  python tools/pmc_summary.py gpurun_out/pmc_write$TAG gpurun_out/pmc_write$TAG.md > /dev/null 2>&1
   find gpurun_out/pmc_fetch$TAG gpurun_out/pmc_write$TAG -type f -size +3M -delete
 fi
