@@ -290,6 +290,18 @@ def check_head_and_layout():
     gp, gm, gi = ops.head_compose(x.to(DEV), wpk.to(DEV), bg.to(DEV), want_pred=True, want_mask=True, want_img=True)
     torch.cuda.synchronize()
     out["pred"], out["mask"], out["img"] = _cmp(gp, wp, 2e-5, "head pred"), _cmp(gm, wm, 2e-5, "head mask"), _cmp(gi, wim_, 2e-5, "head img")
+    # the 64 x 32-tile form of frame batches (>= 512 tiles; S not a multiple of either tile edge) against the emulation on two frames,
+    # and bitwise against the 32 x 16-tile form a single frame takes
+    B2, S2 = 20, 200
+    x2, bg2 = _rand((B2, S2, S2, C), 157).to(DEV), _rand((B2, 3, S2, S2), 158).to(DEV)
+    gp2, gm2, gi2 = ops.head_compose(x2, wpk.to(DEV), bg2, want_pred=True, want_mask=True, want_img=True)
+    for b in (0, B2 - 1):
+        wp2, wm2, wi2 = emu_ops.head_compose(x2[b:b + 1].cpu(), wpk, bg2[b:b + 1].cpu(), want_pred=True, want_mask=True, want_img=True)
+        out[f"batch_form_pred_{b}"] = _cmp(gp2[b:b + 1], wp2, 2e-5, "head pred (batch form)")
+        _cmp(gm2[b:b + 1], wm2, 2e-5, "head mask (batch form)"), _cmp(gi2[b:b + 1], wi2, 2e-5, "head img (batch form)")
+        sp, sm, si = ops.head_compose(x2[b:b + 1].contiguous(), wpk.to(DEV), bg2[b:b + 1].contiguous(), want_pred=True, want_mask=True, want_img=True)
+        torch.cuda.synchronize()
+        assert torch.equal(sp, gp2[b:b + 1]) and torch.equal(sm, gm2[b:b + 1]) and torch.equal(si, gi2[b:b + 1]), "head: a frame depends on its batch"
     # the thin regressor forward (7x7 image head of the background network, bg_inpaintor.py:53) vs torch conv2d, and its autograd
     # form (forward on the vector-ALU kernel, backward on the thin MFMA forms) vs torch autograd
     from ipercore_amd.networks.training import ThinConvFn
