@@ -26,8 +26,9 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 4
+/* 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+ * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
+#define LWG_ABI_VERSION 5
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -43,7 +44,10 @@ enum { LWG_ACTIVATION_NONE = 0, LWG_ACTIVATION_RELU = 1, LWG_ACTIVATION_TANH = 2
  * relu(...) (res = that input): the ReLU backward of the producing layer rides in the epilogue that writes its output gradient
  * (torch autograd runs it as a separate threshold_backward pass, lwg_trainer.py:326-352 loss.backward()). */
 #define LWG_ACTIVATION_RELU_MASK 5
-enum { LWG_DT_F32 = 0, LWG_DT_BF16 = 1 };   /* activation storage type (BASELINE configs[3]: bf16 activations end to end) */
+enum { LWG_DT_F32 = 0, LWG_DT_BF16 = 1,     /* activation storage type (BASELINE configs[3]: bf16 activations end to end) */
+       /* ydt only, fp32 launches with LWG_EPI_NONE and no split-K workspace: y is written as channel-quad PLANES (B, YC/4, YH, YW, 4) instead of
+        * NHWC - the layout lwg_head_compose_q4_f32 stages whole 128-byte lines from (the last decoder layer -> the output head) */
+       LWG_DT_F32_Q4 = 2 };
 
 typedef struct LwgConvArgs {
     const float* x0;   /* input, NHWC (B,H,W,C0); each input tensor must be < 3 GiB (32-bit buffer offsets) */
@@ -328,6 +332,12 @@ int lwg_smpl_lbs_f32(const float* pose, int pose_stride, const float* beta, int 
  * ------------------------------------------------------------------------------------------------ */
 int lwg_head_compose_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
                          float* pred, float* mask, float* img, lwg_stream_t stream);
+/* The same head on an input stored as channel-quad planes, x (B, C/4, S, S, 4) = what a convolution with ydt = LWG_DT_F32_Q4 writes: a
+ * stage of the halo tile then reads whole 128-byte lines whatever its channel count (NHWC: 32 B of every pixel's 256-B row per stage,
+ * every line re-fetched four times), which lets a thread keep 8 pixels in registers (64 x 32-pixel tiles).  Same outputs; the sums
+ * are formed in a different order than lwg_head_compose_f32's (fp32 rounding differs), identically for every batch size. */
+int lwg_head_compose_q4_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
+                            float* pred, float* mask, float* img, lwg_stream_t stream);
 /* Thin regressor forward: a stride-1 ks x ks convolution (ks = 5 or 7, pad ks/2, no bias, no activation) with <= 4 output channels at
  * full resolution on the vector ALUs - the 7x7 image head of the background network, bg_inpaintor.py:53 (Conv2d(64, 3, 7, 1, 3,
  * bias=False), the Tanh that follows is the caller's).  x (B,S,S,C) NHWC, C % 8 == 0; wpk [ks*ks][C][4] (tap = ky*ks + kx, unused

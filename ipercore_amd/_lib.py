@@ -16,7 +16,7 @@ LWG_MAX_TAPS = 52
 EPI_NONE, EPI_RESIDUAL, EPI_SPADE = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_LRELU = 0, 1, 2, 3, 4
 ACT_RELU_MASK = 5       # conv launches with EPI_RESIDUAL only: y = res > 0 ? acc + bias : 0 (include/lwg_hip.h)
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F32_Q4 = 0, 1, 2      # DT_F32_Q4: fp32 output written as channel-quad planes (B, C/4, H, W, 4)
 
 c_f = ctypes.c_void_p  # device pointers travel as void*
 c_i = ctypes.c_int
@@ -100,6 +100,7 @@ _SIGS = {
     "lwg_smpl_lbs_f32": (c_i, [c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i,
                                c_i, c_f, c_f, c_f, c_f, c_f]),
     "lwg_head_compose_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "lwg_head_compose_q4_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "lwg_thin_conv_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_nchw_to_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_nhwc_to_nchw_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
@@ -141,7 +142,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 4:
+        if handle.lwg_abi_version() != 5:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

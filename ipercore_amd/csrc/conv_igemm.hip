@@ -538,7 +538,8 @@ extern "C" int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stre
     const int Cin = a.C0 + a.C1;
     if (!a.x0 || !a.w || !a.y || a.ntaps < 1 || a.ntaps > LWG_MAX_TAPS || a.M <= 0) return (int)hipErrorInvalidValue;
     if (a.N % 64 != 0 || (Cin & 3) != 0 || (a.YC & 3) != 0 || (a.ycoff & 3) != 0) return (int)hipErrorInvalidValue;
-    if (a.xdt != LWG_DT_F32 || (a.ydt != LWG_DT_F32 && (a.ydt != LWG_DT_BF16 || a.epi != LWG_EPI_NONE || ws))) return (int)hipErrorInvalidValue;
+    if (a.xdt != LWG_DT_F32 || (a.ydt != LWG_DT_F32 && ((a.ydt != LWG_DT_BF16 && a.ydt != LWG_DT_F32_Q4) || a.epi != LWG_EPI_NONE || ws))) return (int)hipErrorInvalidValue;
+    if (a.ydt == LWG_DT_F32_Q4 && a.act == LWG_ACT_RELU_MASK) return (int)hipErrorInvalidValue;
     // buffer-load addressing: every tensor the kernel gathers from must be smaller than LWG_OOB_OFFSET bytes
     const unsigned long long pix = (unsigned long long)a.B * a.H * a.W;
     if (pix * (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1) * 4ull >= 0xC0000000ull) return (int)hipErrorInvalidValue;
@@ -589,7 +590,7 @@ extern "C" int lwg_conv_transpose4_nhwc_f32(const LwgConvArgs* pa, lwg_stream_t 
         if (lwg_conv_run_sliced(a, [&](const LwgConvArgs& s) { return lwg_conv_transpose4_nhwc_f32(&s, stream_); }, &sliced_err)) return sliced_err;
     }
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.stride != 1 || a.omul != 2 || a.ooy != 0 || a.oox != 0 || a.C1 != 0 ||
-        a.epi != LWG_EPI_NONE || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.C0 % 32 != 0 || a.N % 64 != 0 || (a.YC & 3) != 0 ||
+        a.epi != LWG_EPI_NONE || a.xdt != LWG_DT_F32 || (a.ydt != LWG_DT_F32 && a.ydt != LWG_DT_F32_Q4) || a.C0 % 32 != 0 || a.N % 64 != 0 || (a.YC & 3) != 0 ||
         (a.ycoff & 3) != 0 || a.OH != a.H || a.OW != a.W || a.YH != 2 * a.H || a.YW != 2 * a.W)
         return (int)hipErrorInvalidValue;
     for (int t = 0; t < 4; ++t)

@@ -103,6 +103,144 @@ __global__ __launch_bounds__(256) void lwg_head_compose_kernel(const float* __re
     }
 }
 
+// The head on an input stored as channel-quad planes, x (B, C/4, S, S, 4) (LWG_DT_F32_Q4: what the last decoder layer's epilogue
+// writes for it).  Why a second form: lwg_head_compose_kernel sits on two bounds at once - the LDS array (four broadcast weight quads
+// + four activation quads per 32 packed FMAs: twice the FMA time) and the re-fetch of its NHWC input (a stage takes 32 B of every
+// pixel's 256-B row, the co-resident tiles' lines do not fit L2, so each 128-B line comes from the memory side four times: 16 GB
+// per 48-frame launch at the ~7.5 TB/s that pattern sustains).  Fewer LDS reads need more pixels per thread, i.e. a larger tile,
+// i.e. fewer channels per stage - which on NHWC multiplies the re-fetch (measured: 4.2 ms against 2.15).  On quad planes a stage
+// of ONE channel quad reads whole lines (consecutive pixels are consecutive 16-byte quads), so:
+//   a thread owns RY CONSECUTIVE rows of NX columns 32 apart (lanes stay on consecutive columns: every ds_read_b128 conflict-free);
+//   for a tap column kx it reads the RY + 4 rows it needs once and feeds the five vertical taps from registers, and a tap's four weight
+//   quads serve NX * RY pixels: (NX (RY + 4) + 20) LDS reads per 80 NX RY FMAs - 36 per 640 for NX = 2, RY = 4 (64 x 32-pixel tiles,
+//   frame batches) against 80; the input is read 1.2 times (the halo) instead of 5.
+// NX = 1, RY = 2 (32 x 16 tiles) serves launches that would leave CUs without a workgroup (one 512 x 512 frame is 128 tiles of 64 x 32).
+// Both forms add an output's terms in the same order (channel quad, kx, ky, channel), products as explicit fmaf: a frame is bitwise
+// the same in either.
+template <int NX, int RY>
+#ifndef LWG_HEADQ4_OCC
+#define LWG_HEADQ4_OCC 2
+#endif
+__global__ __launch_bounds__(256, LWG_HEADQ4_OCC) void lwg_head_q4_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                         const float* __restrict__ bg, size_t bg_bstride, int S, int C,
+                                                         float* __restrict__ pred, float* __restrict__ mask_out,
+                                                         float* __restrict__ img_out) {
+    constexpr int TW = 32 * NX, TH = 8 * RY, HX = TW + 4, HY = TH + 4, NR = RY + 4;
+    __shared__ __attribute__((aligned(16))) float sx[HY][HX][4];
+    __shared__ __attribute__((aligned(16))) float sw[25][4][4];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    // 1-D grid, XCD-aware: every XCD walks a contiguous band of tile rows, so the halo rows two vertically adjacent tiles share are
+    // fetched into ONE L2
+    const int tilesx = (S + TW - 1) / TW, tilesy = (S + TH - 1) / TH;
+    const int lid = lwg_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (tilesx * tilesy), trem = lid - b * tilesx * tilesy;
+    const int x0 = (trem % tilesx) * TW, y0 = (trem / tilesx) * TH;
+    const size_t plane = (size_t)S * S;
+    const float* xb = x + (size_t)b * (C >> 2) * plane * 4;
+    float acc[NX][RY][4];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[i][r][o] = 0.f;
+
+    // The halo tile of a channel quad is NLD 16-byte loads per thread (rows of consecutive quads: whole 128-byte lines).  Quad cq + 1's
+    // loads are issued before quad cq's FMAs and sit in registers meanwhile (a stage is ~6400 FMA cycles per wave, a load round trip
+    // under load is of that order: issued one at a time in front of the LDS store they cost more than the FMAs).
+    constexpr int NLD = (HY * HX + 255) / 256;
+    int goff[NLD];                                              // element offset of this thread's halo quads inside a plane; -1: padding
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        const int py = i / HX, px = i - py * HX;
+        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        goff[k] = (i < HY * HX && gy >= 0 && gy < S && gx >= 0 && gx < S) ? (gy * S + gx) * 4 : -1;
+    }
+    floatx4 pre[NLD], wpre = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int cq) {
+        const float* xq = xb + (size_t)cq * plane * 4;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            pre[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (goff[k] >= 0) pre[k] = *reinterpret_cast<const floatx4*>(xq + goff[k]);
+        }
+        if (tid < 100) wpre = *reinterpret_cast<const floatx4*>(wpk + ((size_t)(tid >> 2) * C + 4 * cq + (tid & 3)) * 4);   // wpk is [25][C][4]
+    };
+    fetch(0);
+    for (int cq = 0; cq < (C >> 2); ++cq) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < HY * HX) *reinterpret_cast<floatx4*>(&sx[0][0][0] + (size_t)i * 4) = pre[k];
+        }
+        if (tid < 100) *reinterpret_cast<floatx4*>(&sw[tid >> 2][tid & 3][0]) = wpre;
+        __syncthreads();
+        if (cq + 1 < (C >> 2)) fetch(cq + 1);
+#pragma unroll 1
+        for (int kx = 0; kx < 5; ++kx) {
+            floatx4 av[NX][NR];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) av[i][rr] = *reinterpret_cast<const floatx4*>(&sx[ty * RY + rr][tx + 32 * i + kx][0]);
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                floatx4 w4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w4[c] = *reinterpret_cast<const floatx4*>(&sw[ky * 5 + kx][c][0]);
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int r = 0; r < RY; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[i][r][o] = __builtin_fmaf(av[i][r + ky][c], w4[c][o], acc[i][r][o]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int gx = x0 + tx + 32 * i;
+        if (gx >= S) continue;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int gy = y0 + ty * RY + r;
+            if (gy >= S) continue;
+            const size_t pix = (size_t)gy * S + gx;
+            const float m = 1.f / (1.f + expf(-acc[i][r][3]));
+            if (mask_out) mask_out[(size_t)b * plane + pix] = m;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float im = tanhf(acc[i][r][c]);
+                if (img_out) img_out[((size_t)b * 3 + c) * plane + pix] = im;
+                if (pred) {
+                    const float bgv = bg[(size_t)b * bg_bstride + c * plane + pix];
+                    pred[((size_t)b * 3 + c) * plane + pix] = m * bgv + (1.f - m) * im;
+                }
+            }
+        }
+    }
+}
+
+// x (B, C/4, S, S, 4) channel-quad planes (LWG_DT_F32_Q4), C % 4 == 0; everything else as lwg_head_compose_f32.
+extern "C" int lwg_head_compose_q4_f32(const float* x, const float* wpk, const float* bg, size_t bg_bstride, int B, int S, int C,
+                                       float* pred, float* mask, float* img, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !wpk || (pred && !bg) || (!pred && !mask && !img) || B <= 0 || S <= 0 || C <= 0 || (C & 3) != 0 || B > 65535)
+        return (int)hipErrorInvalidValue;
+    const long big = (long)((S + 63) / 64) * ((S + 31) / 32) * B;       // 64 x 32-pixel tiles
+    if (big < 512) {                                                     // fewer than two per CU: 32 x 16 tiles
+        const long small = (long)((S + 31) / 32) * ((S + 15) / 16) * B;
+        hipLaunchKernelGGL((lwg_head_q4_kernel<1, 2>), dim3((unsigned)small), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred, mask, img);
+    } else {
+        hipLaunchKernelGGL((lwg_head_q4_kernel<2, 4>), dim3((unsigned)big), dim3(256), 0, stream, x, wpk, bg, bg_bstride, S, C, pred, mask, img);
+    }
+    return (int)hipGetLastError();
+}
+
 // Thin regressor forward: a stride-1 KS x KS convolution (pad KS / 2, no bias) with <= 4 output channels at full resolution - the
 // 7x7 image head of the background network (bg_inpaintor.py:53: Conv2d(64, 3, 7, 1, 3, bias=False) before the Tanh).  As an MFMA
 // launch its 3 outputs are zero-extended to 64 GEMM columns: 21x the useful flops (0.78 ms per personalization step at 512x512).

@@ -59,6 +59,24 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                 }
                 *reinterpret_cast<floatx4*>(yr + 8 * g) = o;
             }
+        } else if (EPI == LWG_EPI_NONE && a.ydt == LWG_DT_F32_Q4) {
+            // channel-quad planes (B, YC/4, YH, YW, 4): this lane's quads of its pixel; 32 consecutive lanes = 32 output pixels of a row
+            // (every second one in a transposed convolution's parity launch) -> 16-byte stores side by side instead of 256 bytes apart
+            const int b = m / HW;
+            const int rem = m - b * HW;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            const size_t plane = (size_t)a.YH * a.YW;
+            const size_t pix = (size_t)(oy * a.omul + a.ooy + ooy_add) * a.YW + (ox * a.omul + a.oox + oox_add);
+            float* yq = a.y + (((size_t)b * (a.YC >> 2) + ((a.ycoff + ncol0) >> 2)) * plane + pix) * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c], a.act);
+                    *reinterpret_cast<floatx4*>(yq + (size_t)(8 * j + 2 * g) * plane * 4) = o;
+                }
         } else {
             float* yr = a.y + opix * a.YC + a.ycoff + ncol0;
             const float* rr = EPI == LWG_EPI_RESIDUAL ? a.res + opix * a.YC + a.ycoff + ncol0 : nullptr;

@@ -305,8 +305,11 @@ class AttentionLWBGenerator(nn.Module):
         return ops.conv2d(actv, st["gb"], torch.empty_like(tsf_x), epi=ops.EPI_SPADE, xn=tsf_x, mean=mean, rstd=rstd)
 
     @staticmethod
-    def _upconv(x, specs, act):
+    def _upconv(x, specs, act, q4=False):
+        """q4: the output as channel-quad planes (B, N/4, 2H, 2W, 4) - the layer that feeds the fp32 output head (csrc/head.hip)."""
         B, H, W, _ = x.shape
+        if q4:
+            return ops.conv_transpose2d(x, specs, x.new_empty(B, specs[0].N // 4, 2 * H, 2 * W, 4), act=act, q4=True)
         y = x.new_empty(B, 2 * H, 2 * W, specs[0].N)
         return ops.conv_transpose2d(x, specs, y, act=act)
 
@@ -336,8 +339,10 @@ class AttentionLWBGenerator(nn.Module):
             x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
             x = self._attlwb(pk.res_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
             site += 1
+        # fp32 MFMA path: the last up-sampling layer writes channel-quad planes, the layout the fp32 head stages whole lines from
+        q4 = adt == torch.float32 and ops.CONV_PRECISION == "fp32"
         for i in range(n_down):
-            x = self._upconv(x, pk.upconvs[i], ops.ACT_RELU)
+            x = self._upconv(x, pk.upconvs[i], ops.ACT_RELU, q4=q4 and i == n_down - 1)
             if i != n_down - 1:
                 skip = enc[n_down - 2 - i]
                 sp = pk.skippers[i]
@@ -348,7 +353,7 @@ class AttentionLWBGenerator(nn.Module):
                 head = pk.head16
             else:
                 x = x.float()
-        return ops.head_compose(x, head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img)
+        return ops.head_compose(x, head, bg, want_pred=want_pred and bg is not None, want_mask=want_mask, want_img=want_img, q4=q4)
 
     def _act_dtype(self):
         """Storage type of the engine's activation tensors: bf16 in the "bf16" precision mode (BASELINE configs[3]), else fp32."""

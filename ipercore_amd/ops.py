@@ -179,12 +179,18 @@ def _w16x3(spec):
 
 
 def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
-              out_hw=None, ycoff=0):
-    """Fill the C-ABI argument block of one conv launch (see ``conv2d``)."""
+              out_hw=None, ycoff=0, q4=False):
+    """Fill the C-ABI argument block of one conv launch (see ``conv2d``).  q4: y is (B, YC/4, YH, YW, 4) - channel-quad planes
+    (LWG_DT_F32_Q4), fp32 launches without a fused residual / SPADE epilogue only."""
     B, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     assert C0 + C1 == spec.Cin, (C0, C1, spec.Cin)
-    YB, YH, YW, YC = y.shape
+    if q4:
+        YB, YCq, YH, YW, four = y.shape
+        assert four == 4 and y.dtype == torch.float32 and x0.dtype == torch.float32 and epi == EPI_NONE and y.is_contiguous()
+        YC = 4 * YCq
+    else:
+        YB, YH, YW, YC = y.shape
     if out_hw is None:
         OH, OW = (YH, YW) if spec.omul == 1 else (YH // spec.omul, YW // spec.omul)
     else:
@@ -192,7 +198,7 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
     a = _lib.LwgConvArgs()
     xdt, ydt = x0.dtype, y.dtype
     a.xdt = _lib.DT_BF16 if xdt == torch.bfloat16 else _lib.DT_F32
-    a.ydt = _lib.DT_BF16 if ydt == torch.bfloat16 else _lib.DT_F32
+    a.ydt = _lib.DT_F32_Q4 if q4 else (_lib.DT_BF16 if ydt == torch.bfloat16 else _lib.DT_F32)
     a.x0, a.x1 = _ptr(x0, xdt), _ptr(x1, xdt)
     a.C0, a.C1 = C0, C1
     a.B, a.H, a.W = B, H, W
@@ -210,11 +216,14 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
 
 
 def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
-           out_hw=None, ycoff=0, splitk=False):
+           out_hw=None, ycoff=0, splitk=False, q4=False):
     """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place).
     splitk: let the library split small-M / large-K launches over K (the training step's one-sample launches).  Off on the
-    synthesis path: a frame's result must not depend on how many frames share its launch (batch invariance is a parity check)."""
-    a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff)
+    synthesis path: a frame's result must not depend on how many frames share its launch (batch invariance is a parity check).
+    q4: y is (B, YC/4, YH, YW, 4), channel-quad planes (the fp32 MFMA path only: what ``head_compose(..., q4=True)`` reads)."""
+    a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff, q4)
+    if q4 and (splitk or CONV_PRECISION != "fp32" or x0.dtype != torch.float32):
+        raise ValueError("channel-quad-plane outputs: fp32 activations on the fp32 MFMA path, no split-K")
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec, epi)
     if x0.dtype == torch.bfloat16:
@@ -265,12 +274,12 @@ class _FusedTransposeSpec(object):
         self.algo_kn, self.w = 4 * s0.algo_kn, panel
 
 
-def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None):
+def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=False):
     """y (B,2H,2W,N) <- ConvTranspose2d(4, 2, 1) of x (B,H,W,Cin) given its four parity specs (packing.pack_conv_transpose).
     bf16 activations with Cin <= 128: ONE launch (lwg_conv_transpose4_nhwc_bf16: the input block is staged once for the four
     parities); otherwise the four parity launches of ``conv2d``.  ``splitk`` / ``out_hw`` are handed to those four launches (the
     training callers' plan: the one-grid form and the four-launch fall-back then differ only in launch count); ``out_hw`` is a
-    callable spec -> (OH, OW) or None."""
+    callable spec -> (OH, OW) or None.  q4 (fp32 only): y is (B, N/4, 2H, 2W, 4), channel-quad planes (see ``conv2d``)."""
     s0 = specs[0]
     if (BF16_UP4 and BF16_HR and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and len(specs) == 4 and s0.Cin in (64, 128)
             and s0.N % 64 == 0 and all(s.ntaps == 4 and s.omul == 2 and (s.ooy, s.oox) == (i >> 1, i & 1) for i, s in enumerate(specs))):
@@ -293,7 +302,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None):
         # fp32, small launch (one frame: a parity is a workgroup per CU or less): ONE grid of four times the workgroups
         # (lwg_conv_transpose4_nhwc_f32); large launches stay four conv2d calls (the library would issue the same four launches). The
         # values are those of the four conv2d calls bit for bit (same tiles, same K order).
-        a = conv_args(x, s0, y, act=act)
+        a = conv_args(x, s0, y, act=act, q4=q4)
         if _lib.lib().lwg_conv_transpose4_is_one_grid(a):
             panel = getattr(s0, "_w32up", None)
             if panel is None or panel.device != s0.w.device:
@@ -308,7 +317,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None):
                 CONV_HOOK(False, a.M, whole, EPI_NONE)
             return y
     for s in specs:
-        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s))
+        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s), q4=q4)
     return y
 
 
@@ -515,8 +524,14 @@ def encode_fim(fim, map_fn):
     return out
 
 
-def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
-    B, S, _, C = x.shape
+def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False, q4=False):
+    """q4: x is (B, C/4, S, S, 4) fp32, channel-quad planes (a convolution launched with q4=True wrote it)."""
+    if q4:
+        B, Cq, S, _, four = x.shape
+        C = 4 * Cq
+        assert four == 4 and x.dtype == torch.float32 and x.is_contiguous()
+    else:
+        B, S, _, C = x.shape
     dev = x.device
     pred = torch.empty(B, 3, S, S, device=dev, dtype=torch.float32) if want_pred else None
     mask = torch.empty(B, 1, S, S, device=dev, dtype=torch.float32) if want_mask else None
@@ -528,6 +543,10 @@ def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
     if x.dtype == torch.bfloat16:                    # wpk: packing.pack_head_bf16
         _lib.check(_lib.lib().lwg_head_compose_bf16(_ptr(x, torch.bfloat16), _ptr(wpk, torch.bfloat16), _ptr(bg), bstride, B, S, C, _ptr(pred),
                                                      _ptr(mask), _ptr(img), _stream()), "lwg_head_compose_bf16")
+        return pred, mask, img
+    if q4:
+        _lib.check(_lib.lib().lwg_head_compose_q4_f32(_ptr(x), _ptr(wpk), _ptr(bg), bstride, B, S, C, _ptr(pred), _ptr(mask), _ptr(img),
+                                                       _stream()), "lwg_head_compose_q4_f32")
         return pred, mask, img
     _lib.check(_lib.lib().lwg_head_compose_f32(_ptr(x), _ptr(wpk), _ptr(bg), bstride, B, S, C, _ptr(pred), _ptr(mask), _ptr(img),
                                                 _stream()), "lwg_head_compose_f32")

@@ -26,7 +26,14 @@ def _unpanel(w, ntaps, cin):
     return wk
 
 
-def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0, splitk=False):
+def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rstd=None, out_hw=None, ycoff=0, splitk=False, q4=False):
+    if q4:      # LWG_DT_F32_Q4: y (B, YC/4, YH, YW, 4) channel-quad planes: run the launch on the NHWC image of y and write it back
+        assert epi == 0 and not splitk and y.dim() == 5 and y.shape[4] == 4
+        B_, Cq, YH_, YW_, _ = y.shape
+        t = y.permute(0, 2, 3, 1, 4).reshape(B_, YH_, YW_, 4 * Cq).clone()
+        conv2d(x0, spec, t, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff, False)
+        y.copy_(t.view(B_, YH_, YW_, Cq, 4).permute(0, 3, 1, 2, 4))
+        return y
     x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
     B, H, W, Cin = x.shape
     assert Cin == spec.Cin
@@ -73,10 +80,10 @@ def conv2d(x0, spec, y, x1=None, epi=0, act=0, res=None, xn=None, mean=None, rst
     return y
 
 
-def conv_transpose2d(x, specs, y, act=0, splitk=False, out_hw=None):
+def conv_transpose2d(x, specs, y, act=0, splitk=False, out_hw=None, q4=False):
     """ops.conv_transpose2d's contract: ConvTranspose2d(4, 2, 1) given its four parity specs = the four parity launches."""
     for s in specs:
-        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s))
+        conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s), q4=q4)
     return y
 
 
@@ -240,7 +247,9 @@ def lwb_fuse(tsf_x, src_x, T, out, gate=None, scale_w=1.0, scale_o=1.0, src_batc
     return out
 
 
-def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False):
+def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False, q4=False):
+    if q4:      # x (B, C/4, S, S, 4) channel-quad planes
+        x = x.permute(0, 2, 3, 1, 4).reshape(x.shape[0], x.shape[2], x.shape[3], -1)
     B, S, _, C = x.shape
     w = wpk.view(5, 5, C, 4).permute(3, 2, 0, 1)
     o = F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=2)

@@ -136,7 +136,25 @@ def check_conv_transpose():
         a = ops.conv_args(x.to(DEV), specs[0], y1, act=ops.ACT_RELU)
         out[tag]["one_grid"] = int(_lib.lib().lwg_conv_transpose4_is_one_grid(a))
         assert torch.equal(y1, y), f"one-call transposed convolution differs from the four parity launches ({tag})"
+        # the same launch writing channel-quad planes (LWG_DT_F32_Q4, the layout of the fp32 output head's input): the NHWC values, moved
+        yq = torch.full((B, N // 4, 2 * H, 2 * W, 4), float("nan"), device=DEV)
+        ops.conv_transpose2d(x.to(DEV), specs, yq, act=ops.ACT_RELU, q4=True)
+        torch.cuda.synchronize()
+        assert torch.equal(yq.permute(0, 2, 3, 1, 4).reshape(B, 2 * H, 2 * W, N), y), f"channel-quad-plane output differs from NHWC ({tag})"
     assert out["small"]["one_grid"] == 1 and out["large"]["one_grid"] == 0, out
+    # a plain (stride 1, 3x3) launch into quad planes at a channel offset, and the launches the layout is refused for
+    B, H, W, Cin, N = 2, 24, 40, 64, 64
+    wc, bc, xc = _rand((N, Cin, 3, 3), 103, 0.05), _rand((N,), 104, 0.1), _rand((B, H, W, Cin), 105).to(DEV)
+    spec = _spec_dev(packing.pack_conv(wc, bc, stride=1, pad=1))
+    ref = torch.zeros(B, H, W, 2 * N, device=DEV)
+    ops.conv2d(xc, spec, ref, act=ops.ACT_RELU, ycoff=N)
+    yq = torch.zeros(B, 2 * N // 4, H, W, 4, device=DEV)
+    ops.conv2d(xc, spec, yq, act=ops.ACT_RELU, ycoff=N, q4=True)
+    torch.cuda.synchronize()
+    assert torch.equal(yq.permute(0, 2, 3, 1, 4).reshape(B, H, W, 2 * N), ref), "channel-quad-plane output at a channel offset"
+    a = ops.conv_args(xc, spec, yq, ycoff=N, q4=True)
+    a.epi, a.res = ops.EPI_RESIDUAL, a.y
+    assert _lib.lib().lwg_conv2d_nhwc_f32(a, None) != 0, "quad planes with a residual epilogue must be refused"
     return out
 
 
@@ -290,6 +308,22 @@ def check_head_and_layout():
     gp, gm, gi = ops.head_compose(x.to(DEV), wpk.to(DEV), bg.to(DEV), want_pred=True, want_mask=True, want_img=True)
     torch.cuda.synchronize()
     out["pred"], out["mask"], out["img"] = _cmp(gp, wp, 2e-5, "head pred"), _cmp(gm, wm, 2e-5, "head mask"), _cmp(gi, wim_, 2e-5, "head img")
+    # the head on channel-quad planes (lwg_head_compose_q4_f32): both tile forms vs the emulation, a frame bitwise independent of its batch
+    B3, S3 = 20, 200                                            # 4 x 7 tiles of 64 x 32 per frame: 560 >= 512 -> the frame-batch form
+    xq, bg3 = _rand((B3, C // 4, S3, S3, 4), 159).to(DEV), _rand((B3, 3, S3, S3), 160).to(DEV)
+    qp, qm, qi = ops.head_compose(xq, wpk.to(DEV), bg3, want_pred=True, want_mask=True, want_img=True, q4=True)
+    for b in (0, 7, B3 - 1):
+        ep, em, ei = emu_ops.head_compose(xq[b:b + 1].cpu(), wpk, bg3[b:b + 1].cpu(), want_pred=True, want_mask=True, want_img=True, q4=True)
+        out[f"q4_batch_form_pred_{b}"] = _cmp(qp[b:b + 1], ep, 2e-5, "q4 head pred (batch form)")
+        _cmp(qm[b:b + 1], em, 2e-5, "q4 head mask (batch form)"), _cmp(qi[b:b + 1], ei, 2e-5, "q4 head img (batch form)")
+        sp, sm, si = ops.head_compose(xq[b:b + 1].contiguous(), wpk.to(DEV), bg3[b:b + 1].contiguous(), want_pred=True, want_mask=True, want_img=True, q4=True)
+        torch.cuda.synchronize()
+        assert torch.equal(sp, qp[b:b + 1]) and torch.equal(sm, qm[b:b + 1]) and torch.equal(si, qi[b:b + 1]), "q4 head: a frame depends on its batch"
+    xs_, bgs = _rand((2, C // 4, 40, 40, 4), 161), _rand((1, 3, 40, 40), 162)            # small form, one shared background, ragged edges
+    ep, em, ei = emu_ops.head_compose(xs_, wpk, bgs, want_pred=True, want_mask=True, want_img=True, q4=True)
+    qp, qm, qi = ops.head_compose(xs_.to(DEV), wpk.to(DEV), bgs.to(DEV), want_pred=True, want_mask=True, want_img=True, q4=True)
+    torch.cuda.synchronize()
+    out["q4_small_form"] = [_cmp(qp, ep, 2e-5, "q4 head pred"), _cmp(qm, em, 2e-5, "q4 head mask"), _cmp(qi, ei, 2e-5, "q4 head img")]
     # the 64 x 32-tile form of frame batches (>= 512 tiles; S not a multiple of either tile edge) against the emulation on two frames,
     # and bitwise against the 32 x 16-tile form a single frame takes
     B2, S2 = 20, 200
