@@ -136,12 +136,16 @@ def check_conv_transpose():
         a = ops.conv_args(x.to(DEV), specs[0], y1, act=ops.ACT_RELU)
         out[tag]["one_grid"] = int(_lib.lib().lwg_conv_transpose4_is_one_grid(a))
         assert torch.equal(y1, y), f"one-call transposed convolution differs from the four parity launches ({tag})"
+        if ops.CONV_PRECISION != "fp32":            # check_split_products re-runs this check on the bf16x6 kernel: NHWC outputs only
+            continue
         # the same launch writing channel-quad planes (LWG_DT_F32_Q4, the layout of the fp32 output head's input): the NHWC values, moved
         yq = torch.full((B, N // 4, 2 * H, 2 * W, 4), float("nan"), device=DEV)
         ops.conv_transpose2d(x.to(DEV), specs, yq, act=ops.ACT_RELU, q4=True)
         torch.cuda.synchronize()
         assert torch.equal(yq.permute(0, 2, 3, 1, 4).reshape(B, 2 * H, 2 * W, N), y), f"channel-quad-plane output differs from NHWC ({tag})"
     assert out["small"]["one_grid"] == 1 and out["large"]["one_grid"] == 0, out
+    if ops.CONV_PRECISION != "fp32":
+        return out
     # a plain (stride 1, 3x3) launch into quad planes at a channel offset, and the launches the layout is refused for
     B, H, W, Cin, N = 2, 24, 40, 64, 64
     wc, bc, xc = _rand((N, Cin, 3, 3), 103, 0.05), _rand((N,), 104, 0.1), _rand((B, H, W, Cin), 105).to(DEV)
