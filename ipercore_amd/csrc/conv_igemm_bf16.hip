@@ -579,6 +579,14 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_up4_k
     extern __shared__ __attribute__((aligned(16))) char smem_u[];
     char* Ah = smem_u;                                       // [NCH][LWG_HALO_BYTES]
 
+#ifdef LAB_TS       // tools/up4ts.py: wave 0 stamps s_memtime at the phase boundaries of its tile and leaves the stamps in args->res (12 per tile)
+    unsigned long long ts[12];
+    int nts = 0;
+#define LAB_STAMP() do { ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+    LAB_STAMP();
+#else
+#define LAB_STAMP() do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -633,6 +641,7 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_up4_k
     for (int q = 0; q < R; ++q) load_w(0, q, q);
     const int hx0 = (lane & 15) + 1;
     __syncthreads();
+    LAB_STAMP();             // halo in LDS
 
 #pragma unroll 1
     for (int parity = 0; parity < 4; ++parity) {
@@ -675,11 +684,21 @@ __global__ __launch_bounds__(256, WAVES_M == 1 ? 2 : 3) void lwg_conv_bf16_up4_k
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        LAB_STAMP();         // this parity's K loop issued
         LwgConvArgs ap = a;
         ap.ooy = py;
         ap.oox = px;
         lwg_bf16_epilogue<TM, 1, LWG_EPI_NONE, 2>(ap, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
+        LAB_STAMP();         // its stores issued
     }
+#ifdef LAB_TS
+    __builtin_amdgcn_s_waitcnt(0);
+    LAB_STAMP();             // everything of this wave acknowledged
+    if (a.res && lane == 0 && wid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res)) + (size_t)lid * 12;
+        for (int q = 0; q < 12; ++q) o[q] = q < nts ? ts[q] : 0ull;
+    }
+#endif
 }
 
 template <int NCH, int WAVES_M>
