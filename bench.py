@@ -47,18 +47,28 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (same guide)
 PEAK_HBM_TBS = 8.0
-FB_512 = {"fp32": 32, "split": 32, "bf16": 80}      # default frame batch at 512x512 per precision mode (scaled by (512 / size)^2, clamped to [2, 64])
+# Default frame batch at 512x512 per precision mode, scaled by (512 / size)^2.  N = 1: the whole clip is ONE launch batch when it fits the budget
+# below (300 frames at 512x512 fp32 hold 29 GB of the 288 GB; measured on one box: 498.6 / 500.6 / 501.8 / 507.2 / 510.8 frames/s at 32 / 48 / 64 /
+# 100 / 300 frames per batch - fewer launch prologues and tails per clip; bf16 1024x1024: 850 / 857 / 860 / 870 at 20 / 45 / 90 / 180).  N > 1: a
+# rank's shard goes in batches of FB_512_SHARDED so that the exchange of one batch overlaps the synthesis of the next (sharding.py).
+FB_512 = {"fp32": 384, "split": 384, "bf16": 768}
+FB_512_SHARDED = {"fp32": 32, "split": 32, "bf16": 80}
+
+
+def default_frame_batch(precision, S, world=1):
+    base = (FB_512 if world == 1 else FB_512_SHARDED)[precision]
+    return max(2, min(1024 if world == 1 else 64, int(round(base * (512.0 / S) ** 2))))
 
 
 class ConvTimer:
     """Brackets every conv launch with events on torch's current stream (the stream the kernels are launched on)."""
 
     def __init__(self):
-        self.pairs, self.flops, self.bytes, self.enabled, self.meta = [], 0.0, 0.0, False, []
+        self.pairs, self.flops, self.bytes, self.enabled, self.meta, self.kernels = [], 0.0, 0.0, False, [], 0
         self._start = None
 
     def reset(self):
-        self.pairs, self.flops, self.bytes, self.meta = [], 0.0, 0.0, []
+        self.pairs, self.flops, self.bytes, self.meta, self.kernels = [], 0.0, 0.0, [], 0
 
     def __call__(self, begin, M, spec, epi=0, act_bytes=4):
         if not self.enabled:
@@ -70,6 +80,8 @@ class ConvTimer:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record()
             self.pairs.append((self._start, stop))
+            from ipercore_amd import ops as _ops
+            self.kernels += _ops.LAST_CONV_KERNELS           # a call whose input exceeds the 32-bit buffer range runs as batch slices
             self.flops += 2.0 * M * spec.algo_kn
             # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
             out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
@@ -79,9 +91,11 @@ class ConvTimer:
             self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn, nbytes))
 
     def result(self):
-        """(busy ms, flops, launches, mean launch ms).  busy = length of the UNION of the launches' [start, stop] intervals
+        """(busy ms, flops, kernel launches, mean kernel-launch ms).  busy = length of the UNION of the bracketed [start, stop] intervals
         on the device clock: with one stream that is the sum of the durations; with several streams, launches of
-        different streams overlap in time and share the machine, and flops / busy is the aggregate rate."""
+        different streams overlap in time and share the machine, and flops / busy is the aggregate rate.  A bracket is one
+        entry-point call = one kernel launch, or several when the library slices the batch (ops.LAST_CONV_KERNELS): the mean is
+        per KERNEL launch, the quantity a rocprofv3 kernel trace averages."""
         if not self.pairs:
             return 0.0, 0.0, 0, 0.0
         base = self.pairs[0][0]
@@ -94,8 +108,9 @@ class ConvTimer:
             else:
                 cur_e = max(cur_e, e0)
         busy += cur_e - cur_s
-        mean = sum(e0 - s0 for s0, e0 in iv) / len(iv)
-        return busy, self.flops, len(self.pairs), mean
+        nk = max(self.kernels, len(self.pairs))
+        mean = sum(e0 - s0 for s0, e0 in iv) / nk
+        return busy, self.flops, nk, mean
 
     def governing(self, peak_tflops, peak_tbs=PEAK_HBM_TBS):
         """Fraction of the GOVERNING roof, launch by launch: a launch's roof time is max(flops / matrix peak, algorithmic bytes / HBM
@@ -309,18 +324,20 @@ def pipelined(im, render, n, W, K, n_streams, tgt=None):
     per-kernel roofline accounting needs launches that own the machine)."""
     from ipercore_amd import ops
     hook, ops.CONV_HOOK = ops.CONV_HOOK, None
-    prev = im.streams
+    prev, prev_fb = im.streams, im.frame_batch
     im.streams = n_streams
+    im.frame_batch = min(im.frame_batch, -(-n // n_streams))         # one batch per stream (the headline runs the clip as one batch)
     try:
         dt, video = _timed_clips(render, W, K)
         assert torch.isfinite(video).all()
-        out = {"value": round(K * n / dt, 3), "unit": "frames/s", "streams": n_streams, "ms_per_clip": round(dt / K * 1e3, 3), "clips": K}
+        out = {"value": round(K * n / dt, 3), "unit": "frames/s", "streams": n_streams, "frame_batch": im.frame_batch,
+               "ms_per_clip": round(dt / K * 1e3, 3), "clips": K}
         if tgt is not None:
             chk = rerender_check(im, tgt, video)
             out["self_check"], out["self_check_detail"] = chk["result"], chk
         return out
     finally:
-        im.streams = prev
+        im.streams, im.frame_batch = prev, prev_fb
         ops.CONV_HOOK = hook
 
 
@@ -390,7 +407,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
     from ipercore_amd import ops, synthetic as syn
     S, n = 1024, 180
     case = syn.build_case(image_size=S, n_frames=1, ns=2)
-    FB = 20                      # 180 poses = 9 batches; one box, one process per value: 746 / 754 / 757 frames/s at 12 / 16 / 20 (round 3)
+    FB = default_frame_batch("bf16", S)      # the 180 poses as one launch batch (see FB_512)
     im = syn.make_imitator(case, frame_batch=FB, device=dev)
     im.generator.conv_precision = "bf16"
     im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
@@ -417,6 +434,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
         nbytes_launch = timer.bytes / max(n_launch, 1)
         timer.enabled, ops.CONV_HOOK = False, None
         prev_streams, im.streams = im.streams, 3             # the same clip with three frame batches in flight on HIP streams
+        prev_fb, im.frame_batch = im.frame_batch, min(im.frame_batch, n // 3)
         try:
             im.synthesize(tgt, "smooth")
             torch.cuda.synchronize()
@@ -426,8 +444,8 @@ def novel_view_1024_bf16(dev, timer, W, K):
             torch.cuda.synchronize()
             piped = K * n / (time.perf_counter() - t1)
         finally:
-            im.streams = prev_streams
-        return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": im.frame_batch,
+            im.streams, im.frame_batch = prev_streams, prev_fb
+        return {"value": round(K * n / dt, 2), "unit": "frames/s", "frames_per_clip": n, "clips": K, "frame_batch": min(im.frame_batch, n),
                 "frame_batch_requested": FB, "image_size": S, "self_check": chk["result"], "self_check_detail": chk,
                 "pipelined_3_streams_frames_per_s": round(piped, 2),
                 "dtype": "bf16 MFMA operands + bf16 activation storage, f32 accumulation / renderer",
@@ -448,7 +466,7 @@ def size_extra(dev, timer, S, W=1, K=2):
     (W warm-up + K timed clips), with the conv kernel's roofline fraction from HIP events.  Reported beside the headline, never as it."""
     from ipercore_amd import ops, synthetic as syn
     n = {256: 300, 1024: 96}.get(S, 96)
-    FB = max(2, min(64, int(round(FB_512["fp32"] * (512.0 / S) ** 2))))
+    FB = default_frame_batch("fp32", S)
     case = syn.build_case(image_size=S, n_frames=n, ns=2)
     im = syn.make_imitator(case, frame_batch=FB, device=dev)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
@@ -471,7 +489,7 @@ def size_extra(dev, timer, S, W=1, K=2):
         chk = rerender_check(im, tgt, video)
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         return {"value": round(K * n / dt, 2), "unit": "frames/s", "image_size": S, "dtype": "f32", "frames_per_clip": n, "clips": K,
-                "frame_batch": im.frame_batch, "self_check": chk["result"], "self_check_detail": chk,
+                "frame_batch": min(im.frame_batch, n), "self_check": chk["result"], "self_check_detail": chk,
                 "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
                              "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 2), "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
@@ -593,10 +611,9 @@ def main(argv=None):
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
 
     S = args.size
-    # frames per launch batch: fp32 - 32 at 512x512 (the 64x64-feature layers have 64 output tiles per frame: every multiple of 8 frames
-    # is a whole number of rounds of the 256 CUs at two workgroups each; more frames per launch = fewer prologues / tails per clip);
-    # bf16 - 20 at 1024x1024 (64 at 512x512)
-    FB = args.frame_batch or max(2, min(64, int(round((FB_512[args.precision]) * (512.0 / S) ** 2))))
+    # frames per launch batch (FB_512 above): N = 1 - the whole clip as one batch; N > 1 - 32 at 512x512 fp32 (the 64x64-feature layers have
+    # 64 output tiles per frame: every multiple of 8 frames is a whole number of rounds of the 256 CUs at two workgroups each)
+    FB = args.frame_batch or default_frame_batch(args.precision, S, world)
     K, W = args.steps, args.warmup
     clip = args.mode == "clip"
     n_clip = args.frames or (180 if args.workload == "novel_view" else 300)
@@ -754,7 +771,7 @@ def main(argv=None):
                                     f"run_imitator {S}x{S} single src/ref pair, one {FB}-frame batch per GPU per step (weak scaling)")
                        if args.precision == "fp32" else
                        f"per-frame path {S}x{S}, AttLWB-SPADE generator, precision mode {args.precision}",
-                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": FB, "frame_batch_requested": FB_requested,
+                       "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": (min(FB, -(-n_clip // world)) if clip else FB), "frame_batch_requested": FB_requested,
                        "frames_per_step": frames_per_step,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "parallelism": f"frame-shard x{world}" + (f" + RCCL all-gather of the output video ({args.gather_dtype}), " +

@@ -215,6 +215,26 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
     return a
 
 
+LAST_CONV_KERNELS = 1   # kernel launches behind the call a CONV_HOOK pair brackets (batch slices, csrc/lwg_conv_slices.h): launch accounting only
+
+
+def _conv_kernel_launches(a):
+    """How many kernel launches one conv entry-point call makes: 1, or the number of batch slices when a gathered input exceeds the
+    kernels' 32-bit buffer range (the rule of csrc/lwg_conv_slices.h)."""
+    esz = 2 if a.xdt == _lib.DT_BF16 else 4
+    per = a.H * a.W * max(a.C0, a.C1) * esz
+    if per == 0 or a.B * per < 0xC0000000:
+        return 1
+    nbs = max(1, (0xC0000000 - 1) // per)
+    return -(-a.B // nbs)
+
+
+def _hook_begin(a, spec, epi):
+    global LAST_CONV_KERNELS
+    LAST_CONV_KERNELS = _conv_kernel_launches(a)
+    CONV_HOOK(True, a.M, spec, epi)
+
+
 def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
            out_hw=None, ycoff=0, splitk=False, q4=False):
     """y <- conv(cat[x0, x1]) per ``spec``; x*: (B,H,W,C) NHWC; y: (B,YH,YW,YC) NHWC (written in place).
@@ -225,7 +245,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     if q4 and (splitk or CONV_PRECISION != "fp32" or x0.dtype != torch.float32):
         raise ValueError("channel-quad-plane outputs: fp32 activations on the fp32 MFMA path, no split-K")
     if CONV_HOOK is not None:
-        CONV_HOOK(True, a.M, spec, epi)
+        _hook_begin(a, spec, epi)
     if x0.dtype == torch.bfloat16:
         # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
         if y.dtype != torch.bfloat16 or spec.Cin % 64 != 0:
@@ -291,7 +311,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
         a.w = _ptr(panel, torch.bfloat16)
         if CONV_HOOK is not None:                # one launch = the whole transposed convolution: 16 taps, 4 N output values per input pixel
             whole = _FusedTransposeSpec(s0, panel)
-            CONV_HOOK(True, a.M, whole, EPI_NONE)
+            _hook_begin(a, whole, EPI_NONE)
         _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_bf16(a, _stream()), "lwg_conv_transpose4_nhwc_bf16")
         if CONV_HOOK is not None:
             CONV_HOOK(False, a.M, whole, EPI_NONE)
@@ -311,7 +331,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
             a.w = _ptr(panel)
             if CONV_HOOK is not None:
                 whole = _FusedTransposeSpec(s0, panel)
-                CONV_HOOK(True, a.M, whole, EPI_NONE)
+                _hook_begin(a, whole, EPI_NONE)
             _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_f32(a, _stream()), "lwg_conv_transpose4_nhwc_f32")
             if CONV_HOOK is not None:
                 CONV_HOOK(False, a.M, whole, EPI_NONE)

@@ -747,6 +747,46 @@ def check_benched_shapes_1024_bf16():
     return m
 
 
+def check_whole_clip_batches():
+    """What bench.py runs at N = 1 since round 4: the WHOLE clip as one launch batch (bench.default_frame_batch: 300 frames at 512 x 512
+    fp32 - the full-resolution layers then run as 4-7 batch slices inside the C entry points -, the 180 novel-view poses at 1024 x 1024
+    bf16).  Every frame of the one-batch rendering bitwise equal to its small-batch rendering (512: frame_batch = 1; 1024 bf16: batches of 2),
+    three frames of the fp32 clip stage by stage against the oracle, bf16 >= 40 dB PSNR against the fp32 result."""
+    import bench
+    m = {}
+    fb = bench.default_frame_batch("fp32", 512)
+    assert fb >= 300, fb
+    case = pu.build_case(image_size=512, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=300, ns=2)
+    r = _run_cached("bench512_whole_clip", case, fb, frames=[0, 149, 299])
+    m.update({k: v for k, v in r["m"].items() if not isinstance(v, (list, dict))})
+    _parity_asserts(dict(r["m"]))
+    im = r["im"]
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    im.frame_batch = 1
+    single = im.synthesize(tgt, "smooth").cpu()
+    m["fp32_300_vs_single_max"] = (single - r["got"]).abs().max().item()
+    assert m["fp32_300_vs_single_max"] == 0.0, "one 300-frame batch and per-frame results differ at 512"
+    del single, im, tgt
+    _RUNS.pop("bench512_whole_clip", None)
+    torch.cuda.empty_cache()
+    fb16 = bench.default_frame_batch("bf16", 1024)
+    assert fb16 >= 180, fb16
+    case = _novel_view_clip(1024, 180)
+    im = pu.make_imitator(case, frame_batch=2)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    ref32 = im.synthesize(tgt[:4], "smooth").cpu()
+    im.generator.conv_precision = "bf16"
+    im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    small = im.synthesize(tgt, "smooth").cpu()
+    im.frame_batch = fb16
+    big = im.synthesize(tgt, "smooth").cpu()
+    m["bf16_180_vs_batches_of_2_max"] = (big - small).abs().max().item()
+    m["bf16_psnr_vs_fp32_db_min"] = min(_psnr(big[t], ref32[t]) for t in range(4))
+    assert torch.isfinite(big).all() and m["bf16_180_vs_batches_of_2_max"] == 0.0, m
+    assert m["bf16_psnr_vs_fp32_db_min"] >= 40.0, m
+    return m
+
+
 def check_batch_slicing_1024():
     """Frame batches whose gathered tensors exceed the conv kernels' 32-bit buffer offsets (3 GiB): the C entry points cut the launch
     into batch slices (csrc/lwg_conv_slices.h), the caller sees no limit.  1024 x 1024 novel-view poses: fp32 at frame batch 26 (the
@@ -2297,7 +2337,7 @@ def check_attention_backward():
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
-       check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024,
+       check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches,
        check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
        check_generator_training_grads, check_generator_training_grads_512_full, check_num_source_8_at_512, check_only_vis_256,
