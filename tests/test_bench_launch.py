@@ -112,3 +112,27 @@ def test_bench_personalize_eight_ranks_gloo(tmp_path):
     assert "segmented" in line["config"]["step"] and "behind D's forward / backward" in line["allreduce_overlap"]
     assert "NOT a measurement" in line["data"] and line["value"] > 0
     assert abs(line["loss_G"]) < 1e4 and abs(line["loss_D"]) < 1e4
+
+
+def test_default_frame_batch_and_kernel_launch_count():
+    """N = 1: the clip of every benched configuration is ONE launch batch; N > 1: batches of 32 (fp32 at 512) so that the exchange of one batch
+    overlaps the next.  The launch accounting counts the kernel launches behind a call the library slices over the batch: the Python rule
+    (ops._conv_kernel_launches) is the C rule of csrc/lwg_conv_slices.h (lwg_conv_slice_frames)."""
+    import bench
+    from ipercore_amd import _lib, ops
+    assert bench.default_frame_batch("fp32", 512) >= 300 and bench.default_frame_batch("fp32", 1024) >= 96
+    assert bench.default_frame_batch("fp32", 256) >= 300 and bench.default_frame_batch("bf16", 1024) >= 180
+    assert bench.default_frame_batch("fp32", 512, world=8) == 32 and bench.default_frame_batch("bf16", 1024, world=8) == 20
+
+    def launches(B, H, W, C0, C1=0, bf16=False):
+        a = _lib.LwgConvArgs()
+        a.B, a.H, a.W, a.C0, a.C1 = B, H, W, C0, C1
+        a.xdt = _lib.DT_BF16 if bf16 else _lib.DT_F32
+        return ops._conv_kernel_launches(a)
+
+    assert launches(32, 512, 512, 64) == 1                        # 2.1 GiB
+    assert launches(300, 64, 64, 256) == 1                        # the residual blocks of a 300-frame batch: 1.2 GiB
+    assert launches(300, 512, 512, 64) == 7                       # 67 MB per frame: 47 frames per slice
+    assert launches(300, 256, 256, 128, 128) == 4                 # the larger of the two concatenated inputs governs
+    assert launches(47, 512, 512, 64) == 1 and launches(48, 512, 512, 64) == 2
+    assert launches(180, 512, 512, 128, bf16=True) == 4           # bf16: half the bytes per element
