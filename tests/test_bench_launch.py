@@ -136,3 +136,13 @@ def test_default_frame_batch_and_kernel_launch_count():
     assert launches(300, 256, 256, 128, 128) == 4                 # the larger of the two concatenated inputs governs
     assert launches(47, 512, 512, 64) == 1 and launches(48, 512, 512, 64) == 2
     assert launches(180, 512, 512, 128, bf16=True) == 4           # bf16: half the bytes per element
+
+
+def test_bench_default_frame_batches(tmp_path):
+    """No --frame-batch: N = 1 renders the clip as ONE launch batch (reported: the clip length, the request beside it); N = 2 keeps the
+    shard in batches of the sharded default (here larger than the 4-frame shard)."""
+    line = _run(tmp_path, ["--gpus", "1", "--frame-batch", "0"])
+    assert line["config"]["frame_batch"] == 7 and line["config"]["frame_batch_requested"] == 1024
+    line = _run(tmp_path, ["--gpus", "2", "--frame-batch", "0", "--no-exchange-u8"])
+    assert line["config"]["frame_batch"] == 4 and line["config"]["frame_batch_requested"] == 64
+    assert [p["frames"] for p in line["config"]["per_rank"]] == [4, 3]
