@@ -17,7 +17,7 @@ Prints ONE JSON line on rank 0.  ``roofline`` is for the dominant kernel (the MF
 all its launches in the timed region / their HIP-event time, against the matrix peak of the dtype.  ``cpu_baseline`` times the CPU
 oracle ("port") on this host for a few frames of the same workload and, where the reference checkout is importable
 (LWG_REFERENCE, default /root/reference - the authoring container, not the GPU box), the reference's own modules ("reference").
-Extra objects, each measured in its own loop and never the headline: ``pipelined``, ``split_products``, ``with_output``,
+Extra objects, each measured in its own loop and never the headline: ``pipelined``, ``split_products``, ``winograd_products``, ``with_output``,
 ``b1_latency`` (frame_batch = 1), ``novel_view_1024_bf16`` (BASELINE configs[3]), ``personalize_step`` (configs[4]).
 """
 import argparse
@@ -313,6 +313,27 @@ def split_products(im, render, n, W, K, ref_video):
                 "self_check": "allclose (max |d| <= 2e-3 vs the fp32 path's frames of the same clip)" if diff <= 2e-3 else f"MISMATCH: max |d| = {diff:.3e}",
                 "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
                 "what": "bf16x6: exact 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per product, fp32 accumulation"}
+    finally:
+        im.generator.conv_precision = prev
+        ops.CONV_HOOK = hook
+
+
+def winograd_products(im, render, n, W, K, ref_video):
+    """Reported separately: the same clip with the 3x3 / stride 1 convolutions (plain and residual epilogues) as fused F(2x2, 3x3) Winograd
+    convolutions on the fp32 matrix pipe (csrc/conv_winograd.hip; 16 multiplies per 2x2 outputs instead of 36, fp32 throughout).  Not the
+    headline value: its sums are fp32-grade but not the direct kernel's bits."""
+    from ipercore_amd import ops
+    hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    prev = im.generator.conv_precision
+    im.generator.conv_precision = "winograd"
+    try:
+        dt, video = _timed_clips(render, W, K)
+        diff = (video - ref_video).abs().max().item()
+        return {"value": round(K * n / dt, 3), "unit": "frames/s", "ms_per_clip": round(dt / K * 1e3, 3), "clips": K,
+                "self_check": "allclose (max |d| <= 1e-4 vs the fp32 path's frames of the same clip)" if diff <= 1e-4 else f"MISMATCH: max |d| = {diff:.3e}",
+                "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
+                "what": "F(2x2,3x3) Winograd on v_mfma_f32_32x32x2_f32 for the res-block / SPADE-shared 3x3 convolutions; SPADE-epilogue, skip-concat, "
+                        "strided, transposed and 1x1 launches stay on the direct kernel"}
     finally:
         im.generator.conv_precision = prev
         ops.CONV_HOOK = hook
@@ -831,6 +852,7 @@ def main(argv=None):
                 line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams, tgt if args.self_check else None)
             if args.split_extra and args.precision == "fp32":
                 line["split_products"] = _extra(split_products, im, render, n_clip, 1, Ke, last)
+                line["winograd_products"] = _extra(winograd_products, im, render, n_clip, 1, Ke, last)
             if args.output_frames > 0:
                 # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
                 # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)

@@ -53,6 +53,7 @@ _SIGS = {
     "lwg_conv2d_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_winograd_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
@@ -142,7 +143,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 5:
+        if handle.lwg_abi_version() != 6:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -1,0 +1,294 @@
+// Fused F(2x2, 3x3) Winograd form of the 3x3 / stride 1 / pad 1 fp32 convolution on v_mfma_f32_32x32x2_f32 (opt-in: ops.conv_precision("winograd"),
+// round 4; developed as tools/probes/winograd_f23.hip, numerics in tools/winograd_study.py and DESIGN.md 7).
+//   y = act(bias + sum x * w [+ res]) computed as U = G w G^T (host: the fragment panel Upk[16][Cin/8][2][N][4]), V = B^T d B per 4x4 input patch d
+//   (patches overlap by two pixels), M_{xi,nu} = V_{xi,nu} U_{xi,nu} - sixteen GEMMs over Cin -, Y = A^T M A: 16 multiplies per 2x2 outputs instead of 36.
+// Workgroup: 512 threads = 8 waves; block = 8 x 8 patches (16 x 16 output pixels) x 64 output channels; wave w owns the two products (xi,nu) = 2w, 2w+1
+// for all 64 patches x 64 channels (2 x 2 x 2 accumulator tiles of 32 x 32 = 128 VGPRs).  A K stage is 8 input channels:
+//   * U fragments: a 32x32x2 fp32 MFMA operand is ONE register, so a lane loads its four k-pairs of a (product, channel tile) as one 16-byte load
+//     from the panel, one stage ahead, into the other of two register sets - the weights never touch LDS;
+//   * the raw 18 x 18 x 8 halo patch goes global -> registers one stage ahead -> raw[s % 2] (channel-major planes);
+//   * iteration s: eight groups of four MFMAs of stage s (fragments of Vs[s % 2], all read up front) with the next stage's input transform
+//     (one (patch, channel) 4x4 -> V[16] per thread: raw[(s + 1) % 2] -> Vs[(s + 1) % 2]) cut into pieces behind them; ONE barrier.
+// Epilogue: the 16 products of a (patch, channel) live in 8 different waves -> through LDS one 32-channel half at a time (rows padded to 65 floats),
+// inverse transform + bias (+ residual) + activation per thread, NHWC stores with lanes on consecutive channels.
+// Measured as a probe on 32 x 64x64 x 256 -> 256: 0.756 ms against 1.128 ms for lwg_conv_igemm_kernel (205 algorithmic TFLOP/s; the fp32 MFMA roof is 157).
+// Rounding: relative L2 error against fp64 1.6x that of the direct fp32 convolution over the generator's layers (tools/winograd_study.py); NOT bitwise
+// the direct kernel's result - which is why it is a precision mode of its own and not the default.
+#include <hip/hip_runtime.h>
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define WG_THREADS 512
+#define TPB 8            // patches per block edge: 8 x 8 patches = 16 x 16 output pixels
+#define NPATCH 64
+#define NB 64            // output channels per block
+#define KS 8             // input channels per stage
+#define HALO 18
+#define RAW_FLOATS (KS * HALO * HALO)        // [c][py][px]
+#define VS_FLOATS (16 * KS * NPATCH)         // [xinu][k][patch]
+#define MS_STRIDE 65
+#define MS_FLOATS (16 * 32 * MS_STRIDE)      // [xinu][n (32)][patch (64) + 1]
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+template <int EPI>
+__global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
+    const float* __restrict__ x = a.x0;
+    const float* __restrict__ U = a.w;
+    const float* __restrict__ bias = a.bias;
+    float* __restrict__ y = a.y;
+    const int H = a.H, W = a.W, Cin = a.C0, N = a.N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const raw0 = smem;                                // [2][RAW]
+    float* const Vs0 = smem + 2 * RAW_FLOATS;                // [2][VS]
+    float* Ms = smem;                                        // the epilogue's exchange buffer (after the K loop)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = (W + 2 * TPB - 1) / (2 * TPB), by = (H + 2 * TPB - 1) / (2 * TPB);
+    int blk = blockIdx.x;
+    const int b = blk / (bx * by);
+    blk -= b * bx * by;
+    const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
+    const int n0 = blockIdx.y * NB;
+    const float* xb = x + (size_t)b * H * W * Cin;
+    const int nst = Cin / KS;
+
+    floatx16 acc[2][2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][nb][tb][r] = 0.f;
+
+    int roff[2];                                             // element offset of this thread's raw float4s inside the image (without c0); -1: padding / none
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + WG_THREADS * q;
+        const int pix = i >> 1, py = pix / HALO, px = pix - py * HALO;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        roff[q] = (i < HALO * HALO * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * Cin + 4 * (i & 1) : -1;
+    }
+    floatx4 rreg[2];
+    auto rload = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rreg[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (roff[q] >= 0) rreg[q] = *reinterpret_cast<const floatx4*>(xb + roff[q] + st * KS);
+        }
+    };
+    auto rstore = [&](int buf) {
+        float* raw = raw0 + buf * RAW_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + WG_THREADS * q;
+            if (i < HALO * HALO * 2) {
+                const int pix = i >> 1, half = i & 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) raw[(4 * half + k) * (HALO * HALO) + pix] = rreg[q][k];
+            }
+        }
+    };
+    floatx4 ufr[2][2][2];                                    // [register set][product e][channel tile nb]: the four k-pairs of this lane's row
+    const float* ubase = U + ((size_t)(lane >> 5) * N + n0 + (lane & 31)) * 4;
+    auto uload = [&](int st, auto SET) {
+        constexpr int set = decltype(SET)::value;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                ufr[set][e][nb] = *reinterpret_cast<const floatx4*>(ubase + (((size_t)(2 * wid + e) * nst + st) * 2 * N + nb * 32) * 4);
+    };
+    const int patch = tid & 63, tc = tid >> 6;
+    const int pty = patch >> 3, ptx = patch & 7;
+    auto transform = [&](int buf) {
+        const float* d = raw0 + buf * RAW_FLOATS + tc * (HALO * HALO) + (2 * pty) * HALO + 2 * ptx;
+        float* Vs = Vs0 + buf * VS_FLOATS;
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d0 = d[j], d1 = d[HALO + j], d2 = d[2 * HALO + j], d3 = d[3 * HALO + j];
+            t[0][j] = d0 - d2;
+            t[1][j] = d1 + d2;
+            t[2][j] = d2 - d1;
+            t[3][j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* v = Vs + ((i * 4) * KS + tc) * NPATCH + patch;
+            v[0 * KS * NPATCH] = t[i][0] - t[i][2];
+            v[1 * KS * NPATCH] = t[i][1] + t[i][2];
+            v[2 * KS * NPATCH] = t[i][2] - t[i][1];
+            v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+        }
+    };
+    // one iteration = eight groups of four MFMAs (k-pair kk = g / 2, product e = g % 2) with the rest of the stage's work cut into pieces that
+    // ride behind them (sched_barrier keeps the order): fragments of the whole stage read up front, then halo store / next loads / the next
+    // stage's input transform in four pieces
+    auto iteration = [&](int s, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        const float* Vs = Vs0 + set * VS_FLOATS;
+        float fb[4][2][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[((2 * wid + e) * KS + 2 * kk + (lane >> 5)) * NPATCH + tb * 32 + (lane & 31)];
+        const bool nxt = s + 1 < nst;
+        const float* d = raw0 + (set ^ 1) * RAW_FLOATS + tc * (HALO * HALO) + (2 * pty) * HALO + 2 * ptx;
+        float* Vn = Vs0 + (set ^ 1) * VS_FLOATS + tc * NPATCH + patch;
+        float dd[4][4], t[4][4];
+        auto group = [&](int g) {
+            const int kk = g >> 1, e = g & 1;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[e][nb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[set][e][nb][kk], fb[kk][e][tb], acc[e][nb][tb], 0, 0, 0);
+        };
+        group(0);
+        if (s + 2 < nst) rstore(set);                        // stage s + 2's halo (loaded during iteration s - 1) -> raw[s % 2]
+        __builtin_amdgcn_sched_barrier(0);
+        group(1);
+        if (s + 3 < nst) rload(s + 3);
+        if (nxt) uload(s + 1, IntC<set ^ 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        group(2);
+        if (nxt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = d[i * HALO + j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        group(3);
+        __builtin_amdgcn_sched_barrier(0);
+        group(4);
+        if (nxt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = dd[0][j] - dd[2][j];
+                t[1][j] = dd[1][j] + dd[2][j];
+                t[2][j] = dd[2][j] - dd[1][j];
+                t[3][j] = dd[1][j] - dd[3][j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        group(5);
+        if (nxt) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float* v = Vn + (size_t)(i * 4) * KS * NPATCH;
+                v[0 * KS * NPATCH] = t[i][0] - t[i][2];
+                v[1 * KS * NPATCH] = t[i][1] + t[i][2];
+                v[2 * KS * NPATCH] = t[i][2] - t[i][1];
+                v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        group(6);
+        if (nxt) {
+#pragma unroll
+            for (int i = 2; i < 4; ++i) {
+                float* v = Vn + (size_t)(i * 4) * KS * NPATCH;
+                v[0 * KS * NPATCH] = t[i][0] - t[i][2];
+                v[1 * KS * NPATCH] = t[i][1] + t[i][2];
+                v[2 * KS * NPATCH] = t[i][2] - t[i][1];
+                v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        group(7);
+        __syncthreads();
+    };
+
+    // prologue: stage 0 transformed, stage 1 in raw[1], stage 2's halo in registers, U(0) in set 0
+    rload(0);
+    uload(0, IntC<0>());
+    rstore(0);
+    if (nst > 1) rload(1);
+    __syncthreads();
+    transform(0);
+    if (nst > 1) rstore(1);
+    if (nst > 2) rload(2);
+    __syncthreads();
+    for (int s = 0; s < nst; s += 2) {
+        iteration(s, IntC<0>());
+        if (s + 1 < nst) iteration(s + 1, IntC<1>());
+    }
+    // epilogue, one 32-channel half at a time: products -> LDS [xinu][n][patch], inverse transform, bias, activation, NHWC stores
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int p = 2 * wid + e;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);           // D layout: row of this accumulator register
+                    Ms[(p * 32 + n) * MS_STRIDE + tb * 32 + (lane & 31)] = acc[e][nb][tb][r];
+                }
+        }
+        __syncthreads();
+        for (int q = tid; q < NPATCH * 32; q += WG_THREADS) {
+            const int n = q & 31, patch = q >> 5;
+            const int ty = patch >> 3, tx = patch & 7;
+            float m[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[i][j] = Ms[((i * 4 + j) * 32 + n) * MS_STRIDE + patch];
+            float s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = m[0][j] + m[1][j] + m[2][j];
+                s[1][j] = m[1][j] - m[2][j] - m[3][j];
+            }
+            const int ch = n0 + nb * 32 + n;
+            const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oy = y0 + 2 * ty + i;
+                const float o0 = s[i][0] + s[i][1] + s[i][2], o1 = s[i][1] - s[i][2] - s[i][3];
+                const int ox = x0 + 2 * tx;
+                const size_t o = (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + ch;
+                if (oy < H && ox < W) y[o] = lwg_act(o0 + bv + (EPI == LWG_EPI_RESIDUAL ? a.res[o] : 0.f), a.act);
+                if (oy < H && ox + 1 < W) y[o + a.YC] = lwg_act(o1 + bv + (EPI == LWG_EPI_RESIDUAL ? a.res[o + a.YC] : 0.f), a.act);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// args: the launch description of the 3 x 3 / stride 1 / pad 1 convolution as lwg_conv2d_nhwc_f32 takes it (nine taps, omul = 1, OH = H, OW = W,
+// one input, C0 % 8 == 0, N % 64 == 0, LWG_EPI_NONE or LWG_EPI_RESIDUAL, any activation of lwg_act) EXCEPT args->w = the Winograd fragment panel
+// Upk[16][C0/8][2][N][4]: element (p, s, kh, n, kk) = (G w G^T)[xi = p / 4][nu = p % 4] of input channel 8 s + 2 kk + kh and output channel n.
+extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C1 != 0 || a.C0 <= 0 || (a.C0 % KS) != 0 ||
+        a.N <= 0 || (a.N % NB) != 0 || a.OH != a.H || a.OW != a.W || a.YH != a.H || a.YW != a.W || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 ||
+        a.M != a.B * a.H * a.W || a.ycoff < 0 || a.ycoff + a.N > a.YC || a.act == LWG_ACT_RELU_MASK)
+        return (int)hipErrorInvalidValue;
+    if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.H * a.W * (unsigned long long)a.C0 >= 0x7fffffffull) return (int)hipErrorInvalidValue;      // per-image element offsets are ints
+    const size_t loop = (size_t)(RAW_FLOATS + VS_FLOATS) * 8, epi = (size_t)MS_FLOATS * 4;
+    const size_t lds = loop > epi ? loop : epi;
+    const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
+    const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / NB));
+    static unsigned long long done0 = 0, done1 = 0;
+    if (a.epi == LWG_EPI_RESIDUAL) {
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<LWG_EPI_RESIDUAL>), lds, done1); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(lwg_conv_winograd_kernel<LWG_EPI_RESIDUAL>, grid, dim3(WG_THREADS), lds, stream, a);
+    } else {
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<LWG_EPI_NONE>), lds, done0); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(lwg_conv_winograd_kernel<LWG_EPI_NONE>, grid, dim3(WG_THREADS), lds, stream, a);
+    }
+    return (int)hipGetLastError();
+}

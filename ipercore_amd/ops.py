@@ -28,7 +28,9 @@ def _ptr(t, dtype=torch.float32):
 
 # "fp32": native fp32 MFMA.  "bf16": the engine keeps every activation tensor in bf16 and the convs with Cin % 64 == 0 run on the bf16
 # MFMA kernel (dispatch is by tensor dtype: ops.conv2d on bf16 tensors; this flag tells the generator what to allocate).  "split": the same convs run on the bf16x6 kernel - both operands split EXACTLY into three bf16 parts,
-# six bf16 MFMAs per fp32 product, fp32 accumulation: fp32-level accuracy at 0.375 of the native matrix-pipe time.
+# six bf16 MFMAs per fp32 product, fp32 accumulation: fp32-level accuracy at 0.375 of the native matrix-pipe time.  "winograd": the 3x3 / stride 1
+# convolutions with Cin % 32 == 0 and a plain or residual epilogue run as fused F(2x2, 3x3) Winograd convolutions on the fp32 matrix pipe
+# (csrc/conv_winograd.hip: 16 multiplies per 2x2 outputs instead of 36; fp32-grade, not bitwise the direct result); everything else as "fp32".
 CONV_PRECISION = "fp32"
 
 
@@ -36,7 +38,7 @@ class conv_precision(object):
     """Context manager: ``with ops.conv_precision("bf16"): ...``."""
 
     def __init__(self, mode):
-        assert mode in ("fp32", "bf16", "split")
+        assert mode in ("fp32", "bf16", "split", "winograd")
         self.mode = mode
 
     def __enter__(self):
@@ -57,7 +59,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up", "_wwino")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -73,6 +75,7 @@ class ConvSpec:
         self._w16c8 = None
         self._w16up = None
         self._w32up = None
+        self._wwino = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -178,6 +181,39 @@ def _w16x3(spec):
     return spec._w16x3
 
 
+_WINO_TAPS = sorted((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+
+
+def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4):
+    """Launches lwg_conv2d_winograd_f32 takes: 3x3 / stride 1 / pad 1, one fp32 input, Cin % 32 == 0, plain or residual epilogue, dense output."""
+    if x1 is not None or q4 or x0.dtype != torch.float32 or y.dtype != torch.float32 or epi not in (EPI_NONE, EPI_RESIDUAL) or act == ACT_RELU_MASK:
+        return False
+    if spec.ntaps != 9 or spec.stride != 1 or spec.omul != 1 or spec.Cin % 32 != 0 or spec.N % 64 != 0:
+        return False
+    if sorted(zip(spec.dy, spec.dx)) != _WINO_TAPS:
+        return False
+    hw = (y.shape[1], y.shape[2]) if out_hw is None else tuple(out_hw)
+    return hw == (x0.shape[1], x0.shape[2]) == (y.shape[1], y.shape[2])
+
+
+def _wwino(spec):
+    """The transformed-weight fragment panel of lwg_conv2d_winograd_f32, built once per spec from the fp32 panel: U = G w G^T per (input, output)
+    channel pair (in fp64, rounded once), stored [16][Cin/8][2][N][4] - element (p, s, kh, n, kk) = U[p // 4][p % 4] of input channel 8 s + 2 kk + kh."""
+    if spec._wwino is None or spec._wwino.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        cin, nt = spec.Cin, spec.ntaps
+        assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin, (cin, nt, K4)
+        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)                                    # k' = ((c // 32) * ntaps + tap) * 32 + c % 32
+        w = wk.view(cin // 32, nt, 32, N).permute(1, 0, 2, 3).reshape(nt, cin, N).double()     # [tap][c][n]
+        g = w.new_zeros(3, 3, cin, N)
+        for t in range(nt):
+            g[spec.dy[t] + 1, spec.dx[t] + 1] = w[t]
+        G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=g.device)
+        U = torch.einsum("ij,jkcn,lk->ilcn", G, g, G).reshape(16, cin, N)
+        spec._wwino = U.view(16, cin // 8, 4, 2, N).permute(0, 1, 3, 4, 2).contiguous().float()
+    return spec._wwino
+
+
 def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
               out_hw=None, ycoff=0, q4=False):
     """Fill the C-ABI argument block of one conv launch (see ``conv2d``).  q4: y is (B, YC/4, YH, YW, 4) - channel-quad planes
@@ -266,6 +302,9 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_c8_bf16(a, _stream()), "lwg_conv2d_nhwc_c8_bf16")
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
+    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4):
+        a.w = _ptr(_wwino(spec))
+        _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")

@@ -787,6 +787,49 @@ def check_whole_clip_batches():
     return m
 
 
+def check_winograd_mode():
+    """ops.conv_precision("winograd") (csrc/conv_winograd.hip, opt-in): the fused F(2x2, 3x3) Winograd form of the 3x3 / stride 1 convolutions.
+    1. kernel level against an fp64 convolution at the conv checks' tolerance: ragged sizes, ReLU, a residual epilogue into a channel slice of a
+       wider tensor - and NOT the direct kernel's bits (the mode really ran);
+    2. the whole per-frame path at 512 x 512 full width: frames within 1e-4 of the fp32 mode's (measured ~1e-6; SURVEY 8c allows 2e-3), a frame
+       bitwise independent of its batch inside the mode."""
+    out = {}
+    for tag, (B, H, W, Cin, N, YC, ycoff, epi) in (("relu", (2, 24, 40, 64, 64, 64, 0, ops.EPI_NONE)),
+                                                   ("residual_slice_ragged", (1, 17, 31, 32, 128, 192, 64, ops.EPI_RESIDUAL))):
+        w, b = _rand((N, Cin, 3, 3), 170, (Cin * 9) ** -0.5), _rand((N,), 171, 0.1)
+        x, res = _rand((B, H, W, Cin), 172), _rand((B, H, W, YC), 173)
+        spec = _spec_dev(packing.pack_conv(w, b, stride=1, pad=1))
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if epi == ops.EPI_RESIDUAL:
+            want = want + res[..., ycoff:ycoff + N].double()
+        want = want.relu().float()
+        kw = dict(epi=epi, act=ops.ACT_RELU, ycoff=ycoff, res=res.to(DEV) if epi == ops.EPI_RESIDUAL else None)
+        yd = torch.zeros(B, H, W, YC, device=DEV)
+        ops.conv2d(x.to(DEV), spec, yd, **kw)
+        yw = torch.zeros(B, H, W, YC, device=DEV)
+        with ops.conv_precision("winograd"):
+            ops.conv2d(x.to(DEV), spec, yw, **kw)
+        torch.cuda.synchronize()
+        out[tag] = _cmp(yw[..., ycoff:ycoff + N], want, 2e-5, "winograd conv " + tag)
+        assert not torch.equal(yw, yd), "winograd mode returned the direct kernel's bits: it did not run"
+        if YC > N:
+            assert float(yw[..., :ycoff].abs().max()) == 0.0 and float(yw[..., ycoff + N:].abs().max()) == 0.0, "wrote outside its channel slice"
+    case = pu.build_case(image_size=512, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=4, ns=2)
+    im = pu.make_imitator(case, frame_batch=4)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    ref = im.synthesize(tgt, "smooth").clone()
+    im.generator.conv_precision = "winograd"
+    im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+    got = im.synthesize(tgt, "smooth").clone()
+    im.frame_batch = 1
+    single = im.synthesize(tgt, "smooth")
+    torch.cuda.synchronize()
+    out["frames_vs_fp32_mode_max"] = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all() and 0.0 < out["frames_vs_fp32_mode_max"] <= 1e-4, out
+    assert torch.equal(got, single), "winograd mode: a frame depends on its batch"
+    return out
+
+
 def check_batch_slicing_1024():
     """Frame batches whose gathered tensors exceed the conv kernels' 32-bit buffer offsets (3 GiB): the C entry points cut the launch
     into batch slices (csrc/lwg_conv_slices.h), the caller sees no limit.  1024 x 1024 novel-view poses: fp32 at frame batch 26 (the
@@ -2337,7 +2380,7 @@ def check_attention_backward():
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
-       check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches,
+       check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,
        check_split_vs_oracle, check_source_setup_128,
        check_source_setup_512, check_output_stage, check_conv_backward,
        check_generator_training_grads, check_generator_training_grads_512_full, check_num_source_8_at_512, check_only_vis_256,
