@@ -795,7 +795,7 @@ def check_winograd_mode():
        bitwise independent of its batch inside the mode."""
     out = {}
     for tag, (B, H, W, Cin, N, YC, ycoff, epi) in (("relu", (2, 24, 40, 64, 64, 64, 0, ops.EPI_NONE)),
-                                                   ("residual_slice_ragged", (1, 17, 31, 32, 128, 192, 64, ops.EPI_RESIDUAL))):
+                                                   ("residual_slice_ragged", (1, 17, 31, 32, 128, 256, 64, ops.EPI_RESIDUAL))):
         w, b = _rand((N, Cin, 3, 3), 170, (Cin * 9) ** -0.5), _rand((N,), 171, 0.1)
         x, res = _rand((B, H, W, Cin), 172), _rand((B, H, W, YC), 173)
         spec = _spec_dev(packing.pack_conv(w, b, stride=1, pad=1))
