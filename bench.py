@@ -51,8 +51,8 @@ PEAK_HBM_TBS = 8.0
 # below (300 frames at 512x512 fp32 hold 29 GB of the 288 GB; measured on one box: 498.6 / 500.6 / 501.8 / 507.2 / 510.8 frames/s at 32 / 48 / 64 /
 # 100 / 300 frames per batch - fewer launch prologues and tails per clip; bf16 1024x1024: 850 / 857 / 860 / 870 at 20 / 45 / 90 / 180).  N > 1: a
 # rank's shard goes in batches of FB_512_SHARDED so that the exchange of one batch overlaps the synthesis of the next (sharding.py).
-FB_512 = {"fp32": 384, "split": 384, "bf16": 768}
-FB_512_SHARDED = {"fp32": 32, "split": 32, "bf16": 80}
+FB_512 = {"fp32": 384, "split": 384, "winograd": 384, "bf16": 768}
+FB_512_SHARDED = {"fp32": 32, "split": 32, "winograd": 32, "bf16": 80}
 
 
 def default_frame_batch(precision, S, world=1):
@@ -580,7 +580,7 @@ def main(argv=None):
                          "around main(); without it every op raises on CPU tensors - there is no CPU product path)")
     ap.add_argument("--no-overlap-gather", dest="overlap", action="store_false", help="one all-gather after the frame loop")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "bf16", "split"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "bf16", "split", "winograd"), default="fp32",
                     help="bf16: BASELINE configs[3] mode - bf16 MFMA operands and bf16 activation storage in the convs (fp32 accumulation); "
                          "the headline metric (configs[1]) is fp32")
     ap.add_argument("--workload", choices=("imitate", "novel_view"), default="imitate",
@@ -819,7 +819,7 @@ def main(argv=None):
                 if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload:   # same launches
                     traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision in ("fp32", "winograd") else PEAK_BF16_MFMA_TFLOPS
             if args.precision == "split":
                 achieved *= 6.0          # executed bf16 MFMA flops: six partial products per algorithmic fp32 product
             line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -829,7 +829,9 @@ def main(argv=None):
                                 "kernel": {"fp32": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
                                            "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
-                                                    "MFMA work actually executed) + fp32 first layers"}[args.precision],
+                                                    "MFMA work actually executed) + fp32 first layers",
+                                           "winograd": "lwg_conv_winograd_kernel (F(2x2,3x3) on the fp32 MFMA pipe: achieved counts the ALGORITHMIC flops of a "
+                                                       "direct convolution, 2.25 x the executed ones on those launches) + lwg_conv_igemm_kernel for the rest"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops * world / frames / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}

@@ -10,7 +10,8 @@
 //   * iteration s: eight groups of four MFMAs of stage s (fragments of Vs[s % 2], all read up front) with the next stage's input transform
 //     (one (patch, channel) 4x4 -> V[16] per thread: raw[(s + 1) % 2] -> Vs[(s + 1) % 2]) cut into pieces behind them; ONE barrier.
 // Epilogue: the 16 products of a (patch, channel) live in 8 different waves -> through LDS one 32-channel half at a time (rows padded to 65 floats),
-// inverse transform + bias (+ residual) + activation per thread, NHWC stores with lanes on consecutive channels.
+// inverse transform + bias (+ residual, or the SPADE modulation of a gamma | beta launch) + activation per thread, NHWC stores with lanes on
+// consecutive channels.  A second input (skip concatenation) is read stage by stage: a stage's 8 channels lie in one of the two tensors.
 // Measured as a probe on 32 x 64x64 x 256 -> 256: 0.756 ms against 1.128 ms for lwg_conv_igemm_kernel (205 algorithmic TFLOP/s; the fp32 MFMA roof is 157).
 // Rounding: relative L2 error against fp64 1.6x that of the direct fp32 convolution over the generator's layers (tools/winograd_study.py); NOT bitwise
 // the direct kernel's result - which is why it is a precision mode of its own and not the default.
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     const float* __restrict__ U = a.w;
     const float* __restrict__ bias = a.bias;
     float* __restrict__ y = a.y;
-    const int H = a.H, W = a.W, Cin = a.C0, N = a.N;
+    const int H = a.H, W = a.W, Cin = a.C0 + a.C1, N = a.N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const raw0 = smem;                                // [2][RAW]
     float* const Vs0 = smem + 2 * RAW_FLOATS;                // [2][VS]
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     blk -= b * bx * by;
     const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
     const int n0 = blockIdx.y * NB;
-    const float* xb = x + (size_t)b * H * W * Cin;
+    const float* xb = x + (size_t)b * H * W * a.C0;
+    const float* xb1 = a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : nullptr;      // second input, concatenated along C (skip connection)
     const int nst = Cin / KS;
 
     floatx16 acc[2][2][2];
@@ -63,20 +65,23 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[e][nb][tb][r] = 0.f;
 
-    int roff[2];                                             // element offset of this thread's raw float4s inside the image (without c0); -1: padding / none
+    int roff[2];                                             // pixel index of this thread's raw float4s inside the image; -1: padding / none
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + WG_THREADS * q;
         const int pix = i >> 1, py = pix / HALO, px = pix - py * HALO;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        roff[q] = (i < HALO * HALO * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * Cin + 4 * (i & 1) : -1;
+        roff[q] = (i < HALO * HALO * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
     }
     floatx4 rreg[2];
     auto rload = [&](int st) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             rreg[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (roff[q] >= 0) rreg[q] = *reinterpret_cast<const floatx4*>(xb + roff[q] + st * KS);
+            const int c = st * KS + 4 * ((tid + WG_THREADS * q) & 1);          // a stage lies in ONE input (C0 % 8 == 0)
+            if (roff[q] >= 0)
+                rreg[q] = c < a.C0 ? *reinterpret_cast<const floatx4*>(xb + (size_t)roff[q] * a.C0 + c)
+                                   : *reinterpret_cast<const floatx4*>(xb1 + (size_t)roff[q] * a.C1 + (c - a.C0));
         }
     };
     auto rstore = [&](int buf) {
@@ -219,7 +224,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         iteration(s, IntC<0>());
         if (s + 1 < nst) iteration(s + 1, IntC<1>());
     }
-    // epilogue, one 32-channel half at a time: products -> LDS [xinu][n][patch], inverse transform, bias, activation, NHWC stores
+    // epilogue, one 32-channel half at a time: products -> LDS [xinu][n][patch], inverse transform, bias, (residual | SPADE modulation), activation,
+    // NHWC stores.  LWG_EPI_SPADE: the block's 64 columns are gamma | beta of the SAME 32 channels (the host interleaves the stacked panel in blocks
+    // of 32, as for lwg_conv_igemm_kernel): the first half leaves gamma in registers, the second forms (xn - mean) rstd (1 + gamma) + beta.
+    float gam[4][2][2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -234,7 +242,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 }
         }
         __syncthreads();
-        for (int q = tid; q < NPATCH * 32; q += WG_THREADS) {
+#pragma unroll
+        for (int it = 0; it < NPATCH * 32 / WG_THREADS; ++it) {
+            const int q = tid + WG_THREADS * it;
             const int n = q & 31, patch = q >> 5;
             const int ty = patch >> 3, tx = patch & 7;
             float m[4][4];
@@ -248,16 +258,28 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 s[0][j] = m[0][j] + m[1][j] + m[2][j];
                 s[1][j] = m[1][j] - m[2][j] - m[3][j];
             }
-            const int ch = n0 + nb * 32 + n;
-            const float bv = bias ? bias[ch] : 0.f;
+            const float bv = bias ? bias[n0 + nb * 32 + n] : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int oy = y0 + 2 * ty + i;
-                const float o0 = s[i][0] + s[i][1] + s[i][2], o1 = s[i][1] - s[i][2] - s[i][3];
+                const float o0 = s[i][0] + s[i][1] + s[i][2] + bv, o1 = s[i][1] - s[i][2] - s[i][3] + bv;
                 const int ox = x0 + 2 * tx;
-                const size_t o = (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + ch;
-                if (oy < H && ox < W) y[o] = lwg_act(o0 + bv + (EPI == LWG_EPI_RESIDUAL ? a.res[o] : 0.f), a.act);
-                if (oy < H && ox + 1 < W) y[o + a.YC] = lwg_act(o1 + bv + (EPI == LWG_EPI_RESIDUAL ? a.res[o + a.YC] : 0.f), a.act);
+                if (EPI == LWG_EPI_SPADE) {
+                    if (nb == 0) {
+                        gam[it][i][0] = o0;
+                        gam[it][i][1] = o1;
+                    } else {
+                        const int ch = (n0 >> 1) + n;                                  // the modulated channel
+                        const size_t o = (((size_t)b * H + oy) * W + ox) * a.YC + ch;
+                        const float mu = a.mean[(size_t)b * a.YC + ch], rs = a.rstd[(size_t)b * a.YC + ch];
+                        if (oy < H && ox < W) y[o] = lwg_act((a.xn[o] - mu) * rs * (1.f + gam[it][i][0]) + o0, a.act);
+                        if (oy < H && ox + 1 < W) y[o + a.YC] = lwg_act((a.xn[o + a.YC] - mu) * rs * (1.f + gam[it][i][1]) + o1, a.act);
+                    }
+                } else {
+                    const size_t o = (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + n0 + nb * 32 + n;
+                    if (oy < H && ox < W) y[o] = lwg_act(o0 + (EPI == LWG_EPI_RESIDUAL ? a.res[o] : 0.f), a.act);
+                    if (oy < H && ox + 1 < W) y[o + a.YC] = lwg_act(o1 + (EPI == LWG_EPI_RESIDUAL ? a.res[o + a.YC] : 0.f), a.act);
+                }
             }
         }
         __syncthreads();
@@ -266,29 +288,38 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 
 
 // args: the launch description of the 3 x 3 / stride 1 / pad 1 convolution as lwg_conv2d_nhwc_f32 takes it (nine taps, omul = 1, OH = H, OW = W,
-// one input, C0 % 8 == 0, N % 64 == 0, LWG_EPI_NONE or LWG_EPI_RESIDUAL, any activation of lwg_act) EXCEPT args->w = the Winograd fragment panel
-// Upk[16][C0/8][2][N][4]: element (p, s, kh, n, kk) = (G w G^T)[xi = p / 4][nu = p % 4] of input channel 8 s + 2 kk + kh and output channel n.
+// one or two inputs with C0 % 8 == 0 and C1 % 8 == 0, N % 64 == 0; LWG_EPI_NONE, LWG_EPI_RESIDUAL or LWG_EPI_SPADE (N = 2 YC, columns gamma | beta
+// interleaved in blocks of 32, ycoff = 0); any activation of lwg_act) EXCEPT args->w = the Winograd fragment panel Upk[16][Cin/8][2][N][4]:
+// element (p, s, kh, n, kk) = (G w G^T)[xi = p / 4][nu = p % 4] of input channel 8 s + 2 kk + kh (concatenated order) and output column n.
 extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
-    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C1 != 0 || a.C0 <= 0 || (a.C0 % KS) != 0 ||
-        a.N <= 0 || (a.N % NB) != 0 || a.OH != a.H || a.OW != a.W || a.YH != a.H || a.YW != a.W || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 ||
-        a.M != a.B * a.H * a.W || a.ycoff < 0 || a.ycoff + a.N > a.YC || a.act == LWG_ACT_RELU_MASK)
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C0 <= 0 || (a.C0 % KS) != 0 || a.C1 < 0 ||
+        (a.C1 % KS) != 0 || (a.C1 > 0 && !a.x1) || a.N <= 0 || (a.N % NB) != 0 || a.OH != a.H || a.OW != a.W || a.YH != a.H || a.YW != a.W ||
+        a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.M != a.B * a.H * a.W || a.ycoff < 0 || a.act == LWG_ACT_RELU_MASK)
         return (int)hipErrorInvalidValue;
-    if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return (int)hipErrorInvalidValue;
-    if ((unsigned long long)a.H * a.W * (unsigned long long)a.C0 >= 0x7fffffffull) return (int)hipErrorInvalidValue;      // per-image element offsets are ints
+    if (a.epi == LWG_EPI_SPADE) {
+        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return (int)hipErrorInvalidValue;
+    } else {
+        if (a.ycoff + a.N > a.YC) return (int)hipErrorInvalidValue;
+        if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return (int)hipErrorInvalidValue;
+    }
+    if ((unsigned long long)a.H * a.W >= 0x7fffffffull) return (int)hipErrorInvalidValue;
     const size_t loop = (size_t)(RAW_FLOATS + VS_FLOATS) * 8, epi = (size_t)MS_FLOATS * 4;
     const size_t lds = loop > epi ? loop : epi;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
     const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / NB));
-    static unsigned long long done0 = 0, done1 = 0;
-    if (a.epi == LWG_EPI_RESIDUAL) {
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<LWG_EPI_RESIDUAL>), lds, done1); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(lwg_conv_winograd_kernel<LWG_EPI_RESIDUAL>, grid, dim3(WG_THREADS), lds, stream, a);
-    } else {
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<LWG_EPI_NONE>), lds, done0); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(lwg_conv_winograd_kernel<LWG_EPI_NONE>, grid, dim3(WG_THREADS), lds, stream, a);
+    static unsigned long long done[3] = {0, 0, 0};
+#define LWG_WINO_GO(E, SLOT)                                                                                                          \
+    {                                                                                                                                 \
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E>), lds, done[SLOT]); e != hipSuccess) \
+            return (int)e;                                                                                                            \
+        hipLaunchKernelGGL(lwg_conv_winograd_kernel<E>, grid, dim3(WG_THREADS), lds, stream, a);                                      \
     }
+    if (a.epi == LWG_EPI_RESIDUAL) LWG_WINO_GO(LWG_EPI_RESIDUAL, 1)
+    else if (a.epi == LWG_EPI_SPADE) LWG_WINO_GO(LWG_EPI_SPADE, 2)
+    else LWG_WINO_GO(LWG_EPI_NONE, 0)
+#undef LWG_WINO_GO
     return (int)hipGetLastError();
 }

@@ -184,11 +184,16 @@ def _w16x3(spec):
 _WINO_TAPS = sorted((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
 
 
-def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4):
-    """Launches lwg_conv2d_winograd_f32 takes: 3x3 / stride 1 / pad 1, one fp32 input, Cin % 32 == 0, plain or residual epilogue, dense output."""
-    if x1 is not None or q4 or x0.dtype != torch.float32 or y.dtype != torch.float32 or epi not in (EPI_NONE, EPI_RESIDUAL) or act == ACT_RELU_MASK:
+def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff=0):
+    """Launches lwg_conv2d_winograd_f32 takes: 3x3 / stride 1 / pad 1, fp32, Cin % 32 == 0 (one input or a skip concatenation with both channel
+    counts % 8 == 0), plain / residual / SPADE (gamma | beta stacked, N = 2 C) epilogue, dense output."""
+    if q4 or x0.dtype != torch.float32 or y.dtype != torch.float32 or epi not in (EPI_NONE, EPI_RESIDUAL, EPI_SPADE) or act == ACT_RELU_MASK:
+        return False
+    if x1 is not None and (x1.dtype != torch.float32 or x0.shape[3] % 8 != 0 or x1.shape[3] % 8 != 0):
         return False
     if spec.ntaps != 9 or spec.stride != 1 or spec.omul != 1 or spec.Cin % 32 != 0 or spec.N % 64 != 0:
+        return False
+    if epi == EPI_SPADE and (y.shape[3] * 2 != spec.N or ycoff != 0):
         return False
     if sorted(zip(spec.dy, spec.dx)) != _WINO_TAPS:
         return False
@@ -302,7 +307,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_c8_bf16(a, _stream()), "lwg_conv2d_nhwc_c8_bf16")
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
-    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4):
+    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff):
         a.w = _ptr(_wwino(spec))
         _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:

@@ -814,6 +814,28 @@ def check_winograd_mode():
         assert not torch.equal(yw, yd), "winograd mode returned the direct kernel's bits: it did not run"
         if YC > N:
             assert float(yw[..., :ycoff].abs().max()) == 0.0 and float(yw[..., ycoff + N:].abs().max()) == 0.0, "wrote outside its channel slice"
+    # a skip concatenation (two inputs) and the SPADE epilogue (gamma | beta stacked) against the direct kernel's results of the same launches
+    B, H, W = 2, 20, 36
+    x0_, x1_ = _rand((B, H, W, 64), 174).to(DEV), _rand((B, H, W, 32), 175).to(DEV)
+    spec = _spec_dev(packing.pack_conv(_rand((64, 96, 3, 3), 176, (96 * 9) ** -0.5), _rand((64,), 177, 0.1), stride=1, pad=1))
+    yd, yw = torch.empty(B, H, W, 64, device=DEV), torch.empty(B, H, W, 64, device=DEV)
+    ops.conv2d(x0_, spec, yd, x1=x1_, act=ops.ACT_RELU)
+    with ops.conv_precision("winograd"):
+        ops.conv2d(x0_, spec, yw, x1=x1_, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    out["two_inputs"] = _cmp(yw, yd.cpu(), 2e-5, "winograd conv, two inputs")
+    assert not torch.equal(yw, yd)
+    C = 64
+    sp = _spec_dev(packing.pack_spade_gamma_beta(_rand((C, 128, 3, 3), 178, 0.03), _rand((C,), 179, 0.1), _rand((C, 128, 3, 3), 180, 0.03), _rand((C,), 181, 0.1)))
+    actv, xn = _rand((B, H, W, 128), 182).to(DEV), (_rand((B, H, W, C), 183, 2.0) + 0.5).to(DEV)
+    mean, rstd = xn.reshape(B, -1, C).mean(1).contiguous(), (1 / torch.sqrt(xn.reshape(B, -1, C).var(1, unbiased=False) + 1e-5)).contiguous()
+    yd, yw = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    ops.conv2d(actv, sp, yd, epi=ops.EPI_SPADE, act=ops.ACT_RELU, xn=xn, mean=mean, rstd=rstd)
+    with ops.conv_precision("winograd"):
+        ops.conv2d(actv, sp, yw, epi=ops.EPI_SPADE, act=ops.ACT_RELU, xn=xn, mean=mean, rstd=rstd)
+    torch.cuda.synchronize()
+    out["spade"] = _cmp(yw, yd.cpu(), 2e-5, "winograd conv, SPADE epilogue")
+    assert not torch.equal(yw, yd)
     case = pu.build_case(image_size=512, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=4, ns=2)
     im = pu.make_imitator(case, frame_batch=4)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
