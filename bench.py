@@ -777,13 +777,14 @@ def main(argv=None):
     if rank == 0:
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
         frames = K * frames_per_step
-        prec_tag = {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]"}[args.precision]
+        prec_tag = {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]", "winograd": " [F(2x2,3x3) Winograd 3x3 convolutions]"}[args.precision]
         line = {
             "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}") + prec_tag,
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if clip else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
-                      "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split"}[args.precision],
+                      "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split",
+                      "winograd": "f32 (3x3 / stride 1 convolutions as F(2x2,3x3) Winograd on the fp32 MFMA pipe)"}[args.precision],
             "data": "synthetic" + (" (tiny architecture, CPU plumbing run: NOT a measurement)" if (args.tiny_arch or not on_gpu) else ""),
             "result_tensor": ("(n,3,S,S) f32 video" if (world == 1 or args.gather_dtype == "f32") else "(n,S,S,3) uint8 video") +
                              (f", all-gathered as {args.gather_dtype}" if world > 1 else ""),
