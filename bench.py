@@ -332,8 +332,8 @@ def winograd_products(im, render, n, W, K, ref_video):
         return {"value": round(K * n / dt, 3), "unit": "frames/s", "ms_per_clip": round(dt / K * 1e3, 3), "clips": K,
                 "self_check": "allclose (max |d| <= 1e-4 vs the fp32 path's frames of the same clip)" if diff <= 1e-4 else f"MISMATCH: max |d| = {diff:.3e}",
                 "max_abs_diff_vs_fp32_path": diff, "frames_range": "[-1, 1]",
-                "what": "F(2x2,3x3) Winograd on v_mfma_f32_32x32x2_f32 for the res-block / SPADE-shared 3x3 convolutions; SPADE-epilogue, skip-concat, "
-                        "strided, transposed and 1x1 launches stay on the direct kernel"}
+                "what": "F(2x2,3x3) Winograd on v_mfma_f32_32x32x2_f32 for every 3x3 / stride 1 convolution with Cin % 32 == 0 (plain, residual, SPADE "
+                        "epilogues, skip concatenations); strided, transposed, 1x1 and first-layer launches stay on the direct kernel"}
     finally:
         im.generator.conv_precision = prev
         ops.CONV_HOOK = hook
