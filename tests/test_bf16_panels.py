@@ -187,3 +187,42 @@ def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
     c = sc.flow(T, 32, 32)
     assert a is b and a.shape == (2, 2, 16, 16, 2) and c.shape == (2, 2, 32, 32, 2) and resized == [(16, 16), (32, 32)]
     assert sc.flow(T, 64, 64) is T and sc.flow(T, 16, 32) is T                # same size / non-square: passed through
+
+
+def test_winograd_panel_and_eligibility():
+    """ops._wwino: the fragment panel of lwg_conv2d_winograd_f32 holds U = G w G^T of every (input, output) channel pair at
+    [xi * 4 + nu][c // 8][c % 2][n][(c % 8) // 2]; F(2x2, 3x3) evaluated with it in torch equals the convolution.  ops._wino_eligible: which
+    launches the mode takes."""
+    import torch.nn.functional as F
+    from ipercore_amd import ops
+    from ipercore_amd.networks import packing
+    g = torch.Generator().manual_seed(3)
+    N, Cin = 64, 32
+    w, b = torch.randn(N, Cin, 3, 3, generator=g) * 0.1, torch.randn(N, generator=g)
+    spec = packing.pack_conv(w, b, stride=1, pad=1)
+    Upk = ops._wwino(spec)
+    assert tuple(Upk.shape) == (16, Cin // 8, 2, N, 4) and Upk.dtype == torch.float32 and ops._wwino(spec) is Upk
+    U = Upk.permute(0, 1, 4, 2, 3).reshape(16, Cin, N)                       # [p][c = 8 s + 2 kk + kh][n]
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    assert torch.allclose(U, torch.einsum("ij,ncjk,lk->ilcn", G, w, G).reshape(16, Cin, N), atol=1e-7)
+    # the whole algorithm with this U on one image: V = B^T d B, M = sum_c U V, Y = A^T M A
+    BT = torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+    AT = torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]])
+    x = torch.randn(1, 10, 14, Cin, generator=g)
+    t = F.pad(x.permute(0, 3, 1, 2), [1, 1, 1, 1]).unfold(2, 4, 2).unfold(3, 4, 2)            # (1,C,th,tw,4,4)
+    V = torch.einsum("ij,ncthjk,lk->ncthil", BT, t, BT)
+    M = torch.einsum("ilco,ncthil->nothil", U.view(4, 4, Cin, N), V)
+    Y = torch.einsum("pi,nothil,ql->nothpq", AT, M, AT)
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(1, N, 10, 14) + b.view(1, -1, 1, 1)
+    want = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)
+    assert torch.allclose(y, want, atol=2e-5), float((y - want).abs().max())
+    # eligibility
+    x0, yy = torch.zeros(1, 8, 8, Cin), torch.zeros(1, 8, 8, N)
+    ok = lambda **k: ops._wino_eligible(k.get("spec", spec), k.get("x0", x0), k.get("y", yy), k.get("x1"), k.get("epi", ops.EPI_NONE),
+                                        k.get("act", ops.ACT_RELU), k.get("out_hw"), k.get("q4", False), k.get("ycoff", 0))
+    assert ok() and ok(epi=ops.EPI_RESIDUAL) and not ok(q4=True) and not ok(act=ops.ACT_RELU_MASK)
+    assert not ok(spec=packing.pack_conv(w, b, stride=2, pad=1)) and not ok(spec=packing.pack_conv(w[:, :, 1:2, 1:2].contiguous(), b, stride=1, pad=0))
+    assert not ok(y=torch.zeros(1, 8, 8, N, dtype=torch.bfloat16))
+    sp2 = packing.pack_conv(torch.randn(N, 96, 3, 3, generator=g), b, stride=1, pad=1)
+    assert ok(spec=sp2, x0=torch.zeros(1, 8, 8, 64), x1=torch.zeros(1, 8, 8, 32))
+    assert ok(spec=spec, y=torch.zeros(1, 8, 8, N // 2), epi=ops.EPI_SPADE) and not ok(spec=spec, epi=ops.EPI_SPADE)
