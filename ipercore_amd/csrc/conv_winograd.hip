@@ -26,7 +26,15 @@
 #define KS 8             // input channels per stage
 #define HALO 18
 #define RAW_FLOATS (KS * HALO * HALO)        // [c][py][px]
-#define VS_FLOATS (16 * KS * NPATCH)         // [xinu][k][patch]
+// lab knobs (defaults = the measured kernel; variant libraries: tools/labvariant.sh NAME conv_winograd.hip -D...; tools/winolab.py times them)
+#ifndef LWG_WINO_VSTRIDE
+#define LWG_WINO_VSTRIDE 64      // floats between two k rows of Vs: 64 = dense (the two half-waves of a fragment read meet in the same banks), 96 = staggered
+#endif
+#ifndef LWG_WINO_PRIO
+#define LWG_WINO_PRIO 0          // 1: s_setprio 1 around every MFMA group
+#endif
+#define VSTR LWG_WINO_VSTRIDE
+#define VS_FLOATS (16 * KS * VSTR)           // [xinu][k][patch (+ pad)]
 #define MS_STRIDE 65
 #define MS_FLOATS (16 * 32 * MS_STRIDE)      // [xinu][n (32)][patch (64) + 1]
 
@@ -122,11 +130,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float* v = Vs + ((i * 4) * KS + tc) * NPATCH + patch;
-            v[0 * KS * NPATCH] = t[i][0] - t[i][2];
-            v[1 * KS * NPATCH] = t[i][1] + t[i][2];
-            v[2 * KS * NPATCH] = t[i][2] - t[i][1];
-            v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+            float* v = Vs + ((i * 4) * KS + tc) * VSTR + patch;
+            v[0 * KS * VSTR] = t[i][0] - t[i][2];
+            v[1 * KS * VSTR] = t[i][1] + t[i][2];
+            v[2 * KS * VSTR] = t[i][2] - t[i][1];
+            v[3 * KS * VSTR] = t[i][1] - t[i][3];
         }
     };
     // one iteration = eight groups of four MFMAs (k-pair kk = g / 2, product e = g % 2) with the rest of the stage's work cut into pieces that
@@ -141,18 +149,20 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[((2 * wid + e) * KS + 2 * kk + (lane >> 5)) * NPATCH + tb * 32 + (lane & 31)];
+                for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[((2 * wid + e) * KS + 2 * kk + (lane >> 5)) * VSTR + tb * 32 + (lane & 31)];
         const bool nxt = s + 1 < nst;
         const float* d = raw0 + (set ^ 1) * RAW_FLOATS + tc * (HALO * HALO) + (2 * pty) * HALO + 2 * ptx;
-        float* Vn = Vs0 + (set ^ 1) * VS_FLOATS + tc * NPATCH + patch;
+        float* Vn = Vs0 + (set ^ 1) * VS_FLOATS + tc * VSTR + patch;
         float dd[4][4], t[4][4];
         auto group = [&](int g) {
             const int kk = g >> 1, e = g & 1;
+            if (LWG_WINO_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
                     acc[e][nb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[set][e][nb][kk], fb[kk][e][tb], acc[e][nb][tb], 0, 0, 0);
+            if (LWG_WINO_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         group(0);
         if (s + 2 < nst) rstore(set);                        // stage s + 2's halo (loaded during iteration s - 1) -> raw[s % 2]
@@ -186,11 +196,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         if (nxt) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float* v = Vn + (size_t)(i * 4) * KS * NPATCH;
-                v[0 * KS * NPATCH] = t[i][0] - t[i][2];
-                v[1 * KS * NPATCH] = t[i][1] + t[i][2];
-                v[2 * KS * NPATCH] = t[i][2] - t[i][1];
-                v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+                float* v = Vn + (size_t)(i * 4) * KS * VSTR;
+                v[0 * KS * VSTR] = t[i][0] - t[i][2];
+                v[1 * KS * VSTR] = t[i][1] + t[i][2];
+                v[2 * KS * VSTR] = t[i][2] - t[i][1];
+                v[3 * KS * VSTR] = t[i][1] - t[i][3];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -198,11 +208,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         if (nxt) {
 #pragma unroll
             for (int i = 2; i < 4; ++i) {
-                float* v = Vn + (size_t)(i * 4) * KS * NPATCH;
-                v[0 * KS * NPATCH] = t[i][0] - t[i][2];
-                v[1 * KS * NPATCH] = t[i][1] + t[i][2];
-                v[2 * KS * NPATCH] = t[i][2] - t[i][1];
-                v[3 * KS * NPATCH] = t[i][1] - t[i][3];
+                float* v = Vn + (size_t)(i * 4) * KS * VSTR;
+                v[0 * KS * VSTR] = t[i][0] - t[i][2];
+                v[1 * KS * VSTR] = t[i][1] + t[i][2];
+                v[2 * KS * VSTR] = t[i][2] - t[i][1];
+                v[3 * KS * VSTR] = t[i][1] - t[i][3];
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -1,5 +1,7 @@
-"""Lab: the fused F(2x2, 3x3) Winograd probe (tools/probes/winograd_f23.hip -> tools/lab/libwino.so) against torch (fp64 on the CPU) and
-against the product's direct fp32 MFMA convolution: errors and launch times.  Run on the GPU box: python tools/winolab.py"""
+"""Lab: the fused F(2x2, 3x3) Winograd convolution against torch (fp64 on the CPU) and against the direct fp32 MFMA convolution: errors and
+launch times.  usage: winolab.py            the probe (tools/probes/winograd_f23.hip -> tools/lab/libwino.so, build command in its header)
+       winolab.py LIB.so [...]  the library kernel (ops.conv_precision("winograd")) of each variant library (tools/labvariant.sh NAME
+                                conv_winograd.hip -DLWG_WINO_VSTRIDE=96 ...), one process per library"""
 import ctypes
 import os
 import sys
@@ -11,9 +13,20 @@ from ipercore_amd import ops
 from ipercore_amd.networks import packing
 
 dev = "cuda:0"
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "lab", "libwino.so"))
-lib.wino_conv3x3_f32.restype = ctypes.c_int
-lib.wino_conv3x3_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+if len(sys.argv) > 2 or (len(sys.argv) == 2 and sys.argv[1] != "--lib"):
+    import subprocess
+    for L in sys.argv[1:]:
+        print("==", L, flush=True)
+        subprocess.run([sys.executable, __file__, "--lib"], env=dict(os.environ, LWG_WINOLAB_LIB=os.path.abspath(L)))
+    sys.exit(0)
+USE_LIB = len(sys.argv) == 2
+if USE_LIB:
+    from ipercore_amd import _lib as _l
+    _l.LIB_PATH = os.environ["LWG_WINOLAB_LIB"]
+else:
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "lab", "libwino.so"))
+    lib.wino_conv3x3_f32.restype = ctypes.c_int
+    lib.wino_conv3x3_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
 
 
@@ -47,8 +60,12 @@ for (B, H, W, Cin, N, check) in ((2, 24, 40, 64, 64, True), (1, 17, 31, 32, 128,
     # the probe's fragment panel [16][Cin/8][kh 2][N][kk 4]: channel 8 s + 2 kk + kh
     U = U.view(16, Cin // 8, 4, 2, N).permute(0, 1, 3, 4, 2).contiguous().to(dev)
     xd, bd = x.to(dev), b.to(dev)
-    yw = wino(xd, U, bd, 1)
     spec = packing.spec_to(packing.pack_conv(w, b, stride=1, pad=1), dev)
+    if USE_LIB:
+        def wino(xd_, U_, bd_, act_):
+            with ops.conv_precision("winograd"):
+                return ops.conv2d(xd_, spec, torch.empty(B, H, W, N, device=dev), act=ops.ACT_RELU)
+    yw = wino(xd, U, bd, 1)
     yd = ops.conv2d(xd, spec, torch.empty(B, H, W, N, device=dev), act=ops.ACT_RELU)
     torch.cuda.synchronize()
     line = f"B={B} {H}x{W} {Cin}->{N}: max |wino - direct| {float((yw - yd).abs().max()):.2e}"
