@@ -65,7 +65,7 @@ class ConvTimer:
 
     def __init__(self):
         self.pairs, self.flops, self.bytes, self.enabled, self.meta, self.kernels = [], 0.0, 0.0, False, [], 0
-        self._start = None
+        self._start, self._ops = None, None
 
     def reset(self):
         self.pairs, self.flops, self.bytes, self.meta, self.kernels = [], 0.0, 0.0, [], 0
@@ -80,8 +80,10 @@ class ConvTimer:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record()
             self.pairs.append((self._start, stop))
-            from ipercore_amd import ops as _ops
-            self.kernels += _ops.LAST_CONV_KERNELS           # a call whose input exceeds the 32-bit buffer range runs as batch slices
+            if self._ops is None:
+                from ipercore_amd import ops as _ops
+                self._ops = _ops
+            self.kernels += self._ops.LAST_CONV_KERNELS      # a call whose input exceeds the 32-bit buffer range runs as batch slices
             self.flops += 2.0 * M * spec.algo_kn
             # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
             out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
