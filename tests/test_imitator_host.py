@@ -3,6 +3,7 @@ pre-pass) on CPU with the C-ABI ops emulated (tests/emu_ops.py), against the ora
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from tests import emu_ops
@@ -178,3 +179,25 @@ def test_only_vis_frames_on_emulated_abi(monkeypatch):
     want = pu.run_oracle(case)
     assert (got - want).abs().max().item() <= 2e-4
     assert (got - plain).abs().max().item() > 1e-3       # the option changes the flows (hidden source faces no longer feed the warp)
+
+
+def test_precision_modes_plumbing(monkeypatch):
+    """generator.conv_precision = "winograd" / "split" route through the same engine wiring (the emulated ABI computes every mode exactly, so the
+    frames must equal the default mode's): the quad-plane head input is used by the fp32 mode only, the other modes take the NHWC head."""
+    emu_ops.install(monkeypatch)
+    from ipercore_amd import ops
+    case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=3, ns=2)
+    im = pu.make_imitator(case, frame_batch=2, device="cpu")
+    calls = []
+    real_head = ops.head_compose
+    monkeypatch.setattr(ops, "head_compose", lambda *a, **k: (calls.append(bool(k.get("q4"))), real_head(*a, **k))[1])
+    ref = pu.run_hip(case, imitator=im)
+    assert calls and all(calls), "the fp32 mode feeds the head channel-quad planes"
+    for mode in ("winograd", "split"):
+        del calls[:]
+        im.generator.conv_precision = mode
+        got = pu.run_hip(case, imitator=im)
+        assert calls and not any(calls), mode
+        assert torch.equal(got, ref), mode
+    with pytest.raises(AssertionError):
+        ops.conv_precision("fp16")
