@@ -33,6 +33,10 @@
 #ifndef LWG_WINO_PRIO
 #define LWG_WINO_PRIO 0          // 1: s_setprio 1 around every MFMA group
 #endif
+#ifndef LWG_WINO_FRAG128
+#define LWG_WINO_FRAG128 0       // 1: Vs as [xinu][kh][patch][4 k-pairs] - a lane's four fragments of a (product, patch tile) are ONE ds_read_b128 (VSTRIDE ignored)
+#endif
+#define VIDX128(p, k, patch) (((((p) * 2 + ((k) & 1)) * NPATCH + (patch)) << 2) + ((k) >> 1))
 #define VSTR LWG_WINO_VSTRIDE
 #define VS_FLOATS (16 * KS * VSTR)           // [xinu][k][patch (+ pad)]
 #define MS_STRIDE 65
@@ -130,11 +134,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if LWG_WINO_FRAG128
+            Vs[VIDX128(i * 4 + 0, tc, patch)] = t[i][0] - t[i][2];
+            Vs[VIDX128(i * 4 + 1, tc, patch)] = t[i][1] + t[i][2];
+            Vs[VIDX128(i * 4 + 2, tc, patch)] = t[i][2] - t[i][1];
+            Vs[VIDX128(i * 4 + 3, tc, patch)] = t[i][1] - t[i][3];
+#else
             float* v = Vs + ((i * 4) * KS + tc) * VSTR + patch;
             v[0 * KS * VSTR] = t[i][0] - t[i][2];
             v[1 * KS * VSTR] = t[i][1] + t[i][2];
             v[2 * KS * VSTR] = t[i][2] - t[i][1];
             v[3 * KS * VSTR] = t[i][1] - t[i][3];
+#endif
         }
     };
     // one iteration = eight groups of four MFMAs (k-pair kk = g / 2, product e = g % 2) with the rest of the stage's work cut into pieces that
@@ -149,7 +160,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
+#if LWG_WINO_FRAG128
+                for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[VIDX128(2 * wid + e, 2 * kk + (lane >> 5), tb * 32 + (lane & 31))];
+#else
                 for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[((2 * wid + e) * KS + 2 * kk + (lane >> 5)) * VSTR + tb * 32 + (lane & 31)];
+#endif
         const bool nxt = s + 1 < nst;
         const float* d = raw0 + (set ^ 1) * RAW_FLOATS + tc * (HALO * HALO) + (2 * pty) * HALO + 2 * ptx;
         float* Vn = Vs0 + (set ^ 1) * VS_FLOATS + tc * VSTR + patch;
@@ -196,11 +211,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         if (nxt) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+#if LWG_WINO_FRAG128
+                float* vb = Vs0 + (set ^ 1) * VS_FLOATS;
+                vb[VIDX128(i * 4 + 0, tc, patch)] = t[i][0] - t[i][2];
+                vb[VIDX128(i * 4 + 1, tc, patch)] = t[i][1] + t[i][2];
+                vb[VIDX128(i * 4 + 2, tc, patch)] = t[i][2] - t[i][1];
+                vb[VIDX128(i * 4 + 3, tc, patch)] = t[i][1] - t[i][3];
+#else
                 float* v = Vn + (size_t)(i * 4) * KS * VSTR;
                 v[0 * KS * VSTR] = t[i][0] - t[i][2];
                 v[1 * KS * VSTR] = t[i][1] + t[i][2];
                 v[2 * KS * VSTR] = t[i][2] - t[i][1];
                 v[3 * KS * VSTR] = t[i][1] - t[i][3];
+#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -208,11 +231,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         if (nxt) {
 #pragma unroll
             for (int i = 2; i < 4; ++i) {
+#if LWG_WINO_FRAG128
+                float* vb = Vs0 + (set ^ 1) * VS_FLOATS;
+                vb[VIDX128(i * 4 + 0, tc, patch)] = t[i][0] - t[i][2];
+                vb[VIDX128(i * 4 + 1, tc, patch)] = t[i][1] + t[i][2];
+                vb[VIDX128(i * 4 + 2, tc, patch)] = t[i][2] - t[i][1];
+                vb[VIDX128(i * 4 + 3, tc, patch)] = t[i][1] - t[i][3];
+#else
                 float* v = Vn + (size_t)(i * 4) * KS * VSTR;
                 v[0 * KS * VSTR] = t[i][0] - t[i][2];
                 v[1 * KS * VSTR] = t[i][1] + t[i][2];
                 v[2 * KS * VSTR] = t[i][2] - t[i][1];
                 v[3 * KS * VSTR] = t[i][1] - t[i][3];
+#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
