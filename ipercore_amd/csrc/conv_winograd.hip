@@ -36,11 +36,23 @@
 #ifndef LWG_WINO_FRAG128
 #define LWG_WINO_FRAG128 0       // 1: Vs as [xinu][kh][patch][4 k-pairs] - a lane's four fragments of a (product, patch tile) are ONE ds_read_b128 (VSTRIDE ignored)
 #endif
+#ifndef LWG_WINO_FINE
+#define LWG_WINO_FINE 0          // 1: ONE MFMA per scheduling slot, the stage's other work cut into ~24 pieces of a few instructions behind them; barrier eight MFMAs early
+#endif
+#ifndef LWG_WINO_EPI4
+#define LWG_WINO_EPI4 0          // 1: epilogue threads own (patch, four channels): 16-byte NHWC stores / residual loads
+#endif
 #define VIDX128(p, k, patch) (((((p) * 2 + ((k) & 1)) * NPATCH + (patch)) << 2) + ((k) >> 1))
 #define VSTR LWG_WINO_VSTRIDE
 #define VS_FLOATS (16 * KS * VSTR)           // [xinu][k][patch (+ pad)]
 #define MS_STRIDE 65
 #define MS_FLOATS (16 * 32 * MS_STRIDE)      // [xinu][n (32)][patch (64) + 1]
+
+#ifdef LWG_WINO_TS           // lab: wave 0 of every workgroup stamps s_memtime into args->res (64 stamps per workgroup; LWG_EPI_NONE launches only; tools/winots.py)
+#define WTS(i) do { if (tid == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WTS(i) do { } while (0)
+#endif
 
 template <int V> struct IntC { static constexpr int value = V; };
 
@@ -66,6 +78,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     const float* xb = x + (size_t)b * H * W * a.C0;
     const float* xb1 = a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : nullptr;      // second input, concatenated along C (skip connection)
     const int nst = Cin / KS;
+    WTS(0);
 
     floatx16 acc[2][2][2];
 #pragma unroll
@@ -148,6 +161,109 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #endif
         }
     };
+#if LWG_WINO_FINE
+    // FINE: one iteration = 32 slots of ONE MFMA (m = kk * 8 + e * 4 + nb * 2 + tb) each followed by at most a handful of the stage's other
+    // instructions (sched_barrier keeps the order), so that neither wave of a SIMD ever leaves the matrix pipe waiting for a block of
+    // vector / LDS / memory instructions: halo store (slots 0-1), next halo + weight loads (2-7), the next stage's input transform (reads 8-11,
+    // first pass 16-17, second pass + V stores 18-21).  The stage's barrier sits after slot 23: the next stage's fragments for k-pairs 0..2 are
+    // read right behind it into the registers slots 0-23 have finished with, the k-pair 3 fragments at the top of the next iteration.
+    float fb[4][2][2];
+    auto fragread = [&](int set, int kk) {
+        const float* Vs = Vs0 + set * VS_FLOATS;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) fb[kk][e][tb] = Vs[((2 * wid + e) * KS + 2 * kk + (lane >> 5)) * VSTR + tb * 32 + (lane & 31)];
+    };
+    auto iteration = [&](int s, auto SET, auto NXT) {
+        constexpr int set = decltype(SET)::value;
+        constexpr bool nxt = decltype(NXT)::value != 0;      // the last stage has no next one to prepare (peeled: no branches in the loop)
+        const float* d = raw0 + (set ^ 1) * RAW_FLOATS + tc * (HALO * HALO) + (2 * pty) * HALO + 2 * ptx;
+        float* Vn = Vs0 + (set ^ 1) * VS_FLOATS + tc * VSTR + patch;
+        float* rawst = raw0 + set * RAW_FLOATS;
+        const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
+        float dd[4][4];
+        auto mf = [&](int m) {
+            const int kk = m >> 3, e = (m >> 2) & 1, nb = (m >> 1) & 1, tb = m & 1;
+            acc[e][nb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[set][e][nb][kk], fb[kk][e][tb], acc[e][nb][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rst = [&](int q) {                              // stage s + 2's halo (loaded during iteration s - 1) -> raw[s % 2]
+            const int i = tid + WG_THREADS * q;
+            if (nxt && i < HALO * HALO * 2) {
+                const int pix = i >> 1, half = i & 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rawst[(4 * half + k) * (HALO * HALO) + pix] = rreg[q][k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rld = [&](int q) {
+            if (nxt) {
+                const int c = s3 * KS + 4 * ((tid + WG_THREADS * q) & 1);
+                const float* src = c < a.C0 ? xb + (size_t)roff[q] * a.C0 + c : xb1 + (size_t)roff[q] * a.C1 + (c - a.C0);
+                floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (roff[q] >= 0) v = *reinterpret_cast<const floatx4*>(src);
+                rreg[q] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto uld = [&](int e, int nb) {
+            if (nxt) ufr[set ^ 1][e][nb] = *reinterpret_cast<const floatx4*>(ubase + (((size_t)(2 * wid + e) * nst + s + 1) * 2 * N + nb * 32) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto ddr = [&](int i) {
+            if (nxt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = d[i * HALO + j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto t2 = [&](int i) {                               // row i of B^T d B: first pass over the four columns, second pass, V stores
+            if (nxt) {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[j] = i == 0 ? dd[0][j] - dd[2][j] : i == 1 ? dd[1][j] + dd[2][j] : i == 2 ? dd[2][j] - dd[1][j] : dd[1][j] - dd[3][j];
+                float* v = Vn + (size_t)(i * 4) * KS * VSTR;
+                v[0 * KS * VSTR] = t[0] - t[2];
+                v[1 * KS * VSTR] = t[1] + t[2];
+                v[2 * KS * VSTR] = t[2] - t[1];
+                v[3 * KS * VSTR] = t[1] - t[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fragread(set, 3);                                    // k-pair 3 of THIS stage (its registers were busy until the previous slot 31)
+        __builtin_amdgcn_sched_barrier(0);
+        mf(0); rst(0);
+        mf(1); rst(1);
+        mf(2); rld(0);
+        mf(3); rld(1);
+        mf(4); uld(0, 0);
+        mf(5); uld(0, 1);
+        mf(6); uld(1, 0);
+        mf(7); uld(1, 1);
+        mf(8); ddr(0);
+        mf(9); ddr(1);
+        mf(10); ddr(2);
+        mf(11); ddr(3);
+        mf(12); mf(13); mf(14); mf(15);
+        mf(16); t2(0);
+        mf(17); t2(1);
+        mf(18); t2(2);
+        mf(19); t2(3);
+        mf(20); mf(21); mf(22); mf(23);
+        __syncthreads();
+        if (nxt) {
+            fragread(set ^ 1, 0);
+            fragread(set ^ 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mf(24);
+        if (nxt) fragread(set ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mf(25); mf(26); mf(27); mf(28); mf(29); mf(30); mf(31);
+    };
+#else
     // one iteration = eight groups of four MFMAs (k-pair kk = g / 2, product e = g % 2) with the rest of the stage's work cut into pieces that
     // ride behind them (sched_barrier keeps the order): fragments of the whole stage read up front, then halo store / next loads / the next
     // stage's input transform in four pieces
@@ -250,6 +366,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         group(7);
         __syncthreads();
     };
+#endif
 
     // prologue: stage 0 transformed, stage 1 in raw[1], stage 2's halo in registers, U(0) in set 0
     rload(0);
@@ -261,14 +378,39 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     if (nst > 1) rstore(1);
     if (nst > 2) rload(2);
     __syncthreads();
+#if LWG_WINO_FINE
+    fragread(0, 0);
+    fragread(0, 1);
+    fragread(0, 2);
+#endif
+    WTS(1);
+#if LWG_WINO_FINE
+    {
+        int s = 0;
+        for (; s + 2 < nst; s += 2) {
+            iteration(s, IntC<0>(), IntC<1>());
+            iteration(s + 1, IntC<1>(), IntC<1>());
+            WTS(2 + (s >> 1));
+        }
+        iteration(s, IntC<0>(), IntC<1>());                  // nst is even (host: Cin % 16 == 0)
+        iteration(s + 1, IntC<1>(), IntC<0>());
+    }
+#else
     for (int s = 0; s < nst; s += 2) {
         iteration(s, IntC<0>());
         if (s + 1 < nst) iteration(s + 1, IntC<1>());
+        WTS(2 + (s >> 1));
     }
+#endif
+    WTS(40);
     // epilogue, one 32-channel half at a time: products -> LDS [xinu][n][patch], inverse transform, bias, (residual | SPADE modulation), activation,
     // NHWC stores.  LWG_EPI_SPADE: the block's 64 columns are gamma | beta of the SAME 32 channels (the host interleaves the stacked panel in blocks
     // of 32, as for lwg_conv_igemm_kernel): the first half leaves gamma in registers, the second forms (xn - mean) rstd (1 + gamma) + beta.
+#if LWG_WINO_EPI4
+    floatx4 gam4[2][2];
+#else
     float gam[4][2][2];
+#endif
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -283,6 +425,62 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 }
         }
         __syncthreads();
+#if LWG_WINO_EPI4
+        {   // a thread owns one patch x four consecutive channels: 64 conflict-free LDS reads, 16-byte NHWC stores / residual / xn loads
+            const int n4 = (tid & 7) * 4, ep = tid >> 3;
+            const int ty = ep >> 3, tx = ep & 7;
+            floatx4 o[2][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float m[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[i][j] = Ms[((i * 4 + j) * 32 + n4 + c) * MS_STRIDE + ep];
+                float sr[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sr[0][j] = m[0][j] + m[1][j] + m[2][j];
+                    sr[1][j] = m[1][j] - m[2][j] - m[3][j];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    o[i][0][c] = sr[i][0] + sr[i][1] + sr[i][2];
+                    o[i][1][c] = sr[i][1] - sr[i][2] - sr[i][3];
+                }
+            }
+            const floatx4 bv = bias ? *reinterpret_cast<const floatx4*>(bias + n0 + nb * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int oy = y0 + 2 * ty + i, ox = x0 + 2 * tx + px;
+                    floatx4 v = o[i][px] + bv;
+                    if (EPI == LWG_EPI_SPADE) {
+                        if (nb == 0) {
+                            gam4[i][px] = v;
+                        } else if (oy < H && ox < W) {
+                            const int ch = (n0 >> 1) + n4;                             // the modulated channels
+                            const size_t off = (((size_t)b * H + oy) * W + ox) * a.YC + ch;
+                            const floatx4 mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)b * a.YC + ch);
+                            const floatx4 rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)b * a.YC + ch);
+                            const floatx4 xv = *reinterpret_cast<const floatx4*>(a.xn + off);
+                            floatx4 r;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) r[c] = lwg_act((xv[c] - mu[c]) * rs[c] * (1.f + gam4[i][px][c]) + v[c], a.act);
+                            *reinterpret_cast<floatx4*>(y + off) = r;
+                        }
+                    } else if (oy < H && ox < W) {
+                        const size_t off = (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + n0 + nb * 32 + n4;
+                        if (EPI == LWG_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(a.res + off);
+                        floatx4 r;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = lwg_act(v[c], a.act);
+                        *reinterpret_cast<floatx4*>(y + off) = r;
+                    }
+                }
+        }
+#else
 #pragma unroll
         for (int it = 0; it < NPATCH * 32 / WG_THREADS; ++it) {
             const int q = tid + WG_THREADS * it;
@@ -323,7 +521,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 }
             }
         }
+#endif
         __syncthreads();
+        WTS(41 + nb);
     }
 }
 

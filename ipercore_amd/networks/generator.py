@@ -339,8 +339,9 @@ class AttentionLWBGenerator(nn.Module):
             x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
             x = self._attlwb(pk.res_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
             site += 1
-        # fp32 MFMA path: the last up-sampling layer writes channel-quad planes, the layout the fp32 head stages whole lines from
-        q4 = adt == torch.float32 and ops.CONV_PRECISION == "fp32"
+        # fp32 MFMA path (direct or Winograd 3x3 layers - the transposed convolutions are the direct kernel's in both): the last up-sampling
+        # layer writes channel-quad planes, the layout the fp32 head stages whole lines from
+        q4 = adt == torch.float32 and self.conv_precision in ("fp32", "winograd")
         for i in range(n_down):
             x = self._upconv(x, pk.upconvs[i], ops.ACT_RELU, q4=q4 and i == n_down - 1)
             if i != n_down - 1:

@@ -283,7 +283,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     synthesis path: a frame's result must not depend on how many frames share its launch (batch invariance is a parity check).
     q4: y is (B, YC/4, YH, YW, 4), channel-quad planes (the fp32 MFMA path only: what ``head_compose(..., q4=True)`` reads)."""
     a = conv_args(x0, spec, y, x1, epi, act, res, xn, mean, rstd, out_hw, ycoff, q4)
-    if q4 and (splitk or CONV_PRECISION != "fp32" or x0.dtype != torch.float32):
+    if q4 and (splitk or CONV_PRECISION not in ("fp32", "winograd") or x0.dtype != torch.float32):
         raise ValueError("channel-quad-plane outputs: fp32 activations on the fp32 MFMA path, no split-K")
     if CONV_HOOK is not None:
         _hook_begin(a, spec, epi)
@@ -360,7 +360,7 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
         if CONV_HOOK is not None:
             CONV_HOOK(False, a.M, whole, EPI_NONE)
         return y
-    if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION == "fp32" and len(specs) == 4 and s0.Cin % 32 == 0
+    if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION in ("fp32", "winograd") and len(specs) == 4 and s0.Cin % 32 == 0
             and all(s.ntaps == 4 and s.omul == 2 and s.stride == 1 and (s.ooy, s.oox) == (i >> 1, i & 1) and s.N == s0.N and s.Cin == s0.Cin
                     and [(dy - (i >> 1), dx - (i & 1)) for dy, dx in zip(s.dy, s.dx)] == list(zip(s0.dy, s0.dx)) for i, s in enumerate(specs))):
         # fp32, small launch (one frame: a parity is a workgroup per CU or less): ONE grid of four times the workgroups
