@@ -65,12 +65,14 @@ class ConvTimer:
 
     def __init__(self):
         self.pairs, self.flops, self.bytes, self.enabled, self.meta, self.kernels = [], 0.0, 0.0, False, [], 0
-        self._start, self._ops = None, None
+        self.exec_flops, self.kinds = 0.0, {}
+        self._start = None
 
     def reset(self):
         self.pairs, self.flops, self.bytes, self.meta, self.kernels = [], 0.0, 0.0, [], 0
+        self.exec_flops, self.kinds = 0.0, {}
 
-    def __call__(self, begin, M, spec, epi=0, act_bytes=4):
+    def __call__(self, begin, M, spec, epi=0, info=None, act_bytes=4):
         if not self.enabled:
             return
         if begin:
@@ -80,11 +82,17 @@ class ConvTimer:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record()
             self.pairs.append((self._start, stop))
-            if self._ops is None:
-                from ipercore_amd import ops as _ops
-                self._ops = _ops
-            self.kernels += self._ops.LAST_CONV_KERNELS      # a call whose input exceeds the 32-bit buffer range runs as batch slices
+            info = info or {"kernels": 1, "kind": "direct"}
+            self.kernels += info["kernels"]                  # a call whose input exceeds the 32-bit buffer range runs as batch slices
             self.flops += 2.0 * M * spec.algo_kn
+            # EXECUTED matrix-pipe flops: the F(2x2, 3x3) Winograd kernel forms 16 products per 2 x 2 outputs where the direct form has 36
+            ex = 2.0 * M * spec.algo_kn * (4.0 / 9.0 if info["kind"] == "winograd" else 1.0)
+            self.exec_flops += ex
+            k = self.kinds.setdefault(info["kind"], [0, 0.0, 0.0, []])     # calls, algorithmic flops, executed flops, event pairs
+            k[0] += 1
+            k[1] += 2.0 * M * spec.algo_kn
+            k[2] += ex
+            k[3].append((self._start, stop))
             # algorithmic bytes of the launch: input read once + weight panel + output written (+ the epilogue's operands)
             out = M * spec.N if epi != 2 else M * spec.N       # SPADE: reads xn (M*N/2) and writes y (M*N/2)
             nbytes = float(act_bytes) * (M * spec.stride ** 2 * spec.Cin + out + (M * spec.N if epi == 1 else 0)) + \
@@ -113,6 +121,15 @@ class ConvTimer:
         nk = max(self.kernels, len(self.pairs))
         mean = sum(e0 - s0 for s0, e0 in iv) / nk
         return busy, self.flops, nk, mean
+
+    def by_kind(self):
+        """Per kernel family: calls, measured ms (sum of the bracketed durations), algorithmic and executed TFLOP/s."""
+        out = {}
+        for kind, (calls, alg, ex, pairs) in self.kinds.items():
+            ms = sum(a.elapsed_time(b) for a, b in pairs)
+            out[kind] = {"calls": calls, "ms": round(ms, 3), "algorithmic_tflops": round(alg / ms / 1e9, 2) if ms > 0 else None,
+                         "executed_tflops": round(ex / ms / 1e9, 2) if ms > 0 else None}
+        return out
 
     def governing(self, peak_tflops, peak_tbs=PEAK_HBM_TBS):
         """Fraction of the GOVERNING roof, launch by launch: a launch's roof time is max(flops / matrix peak, algorithmic bytes / HBM
@@ -441,7 +458,7 @@ def novel_view_1024_bf16(dev, timer, W, K):
         for _ in range(W):
             im.synthesize(tgt, "smooth")
         timer.reset()
-        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0: timer(b, M, spec, epi, 2))     # bf16 tensors: 2 bytes per element
+        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0, info=None: timer(b, M, spec, epi, info, 2))     # bf16 tensors: 2 bytes per element
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
@@ -499,7 +516,7 @@ def size_extra(dev, timer, S, W=1, K=2):
         for _ in range(W):
             im.synthesize(tgt, "smooth")
         timer.reset()
-        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0: timer(b, M, spec, epi, 4))
+        timer.enabled, ops.CONV_HOOK = True, (lambda b, M, spec, epi=0, info=None: timer(b, M, spec, epi, info, 4))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
@@ -663,7 +680,7 @@ def main(argv=None):
     act_bytes = 2 if args.precision == "bf16" else 4
 
     timer = ConvTimer()
-    hook = None if args.no_conv_events else (lambda b, M, spec, epi=0: timer(b, M, spec, epi, act_bytes))
+    hook = None if args.no_conv_events else (lambda b, M, spec, epi=0, info=None: timer(b, M, spec, epi, info, act_bytes))
     ops.CONV_HOOK = hook
 
     def to_u8(x):
@@ -778,6 +795,7 @@ def main(argv=None):
 
     if rank == 0:
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
+        conv_exec_flops, conv_by_kind = timer.exec_flops, timer.by_kind()
         frames = K * frames_per_step
         prec_tag = {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]", "winograd": " [F(2x2,3x3) Winograd 3x3 convolutions]"}[args.precision]
         line = {
@@ -821,7 +839,9 @@ def main(argv=None):
                 cfg = tj.get("bench_config") or {}
                 if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload:   # same launches
                     traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-            achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+            # matrix-pipe flops EXECUTED per second over all conv launches: the direct kernels execute their algorithmic flops, the F(2x2,3x3)
+            # Winograd kernel 4/9 of them (16 products per 2 x 2 outputs instead of 36) - a roofline fraction is executed work over the pipe's peak
+            achieved = (conv_exec_flops if args.precision == "winograd" else conv_flops) / (conv_ms * 1e-3) / 1e12
             peak = PEAK_FP32_MFMA_TFLOPS if args.precision in ("fp32", "winograd") else PEAK_BF16_MFMA_TFLOPS
             if args.precision == "split":
                 achieved *= 6.0          # executed bf16 MFMA flops: six partial products per algorithmic fp32 product
@@ -833,11 +853,18 @@ def main(argv=None):
                                            "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
                                                     "MFMA work actually executed) + fp32 first layers",
-                                           "winograd": "lwg_conv_winograd_kernel (F(2x2,3x3) on the fp32 MFMA pipe: achieved counts the ALGORITHMIC flops of a "
-                                                       "direct convolution, 2.25 x the executed ones on those launches) + lwg_conv_igemm_kernel for the rest"}[args.precision],
+                                           "winograd": "lwg_conv_winograd_kernel (F(2x2,3x3) on the fp32 MFMA pipe: achieved counts the EXECUTED flops, "
+                                                       "2 M 4 Cin N on those launches) + lwg_conv_igemm_kernel for the strided / transposed / first layers"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops * world / frames / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
+            if args.precision == "winograd":
+                wk = conv_by_kind.get("winograd") or {}
+                line["roofline"]["algorithmic_equivalent_tflops"] = round(conv_flops / (conv_ms * 1e-3) / 1e12, 2)    # what a direct convolution would have to sustain
+                line["roofline"]["executed_gflop_per_frame"] = round(conv_exec_flops * world / frames / 1e9, 2)
+                line["roofline"]["by_kernel"] = conv_by_kind
+                if wk.get("executed_tflops"):
+                    line["roofline"]["winograd_kernel_frac"] = round(wk["executed_tflops"] / peak, 4)
             if args.precision == "bf16":
                 line["roofline"]["hbm_time_at_peak_us_per_launch"] = round(timer.bytes / n_launch / (PEAK_HBM_TBS * 1e12) * 1e6, 2)
                 gov, hbm_share = timer.governing(PEAK_BF16_MFMA_TFLOPS)

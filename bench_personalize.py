@@ -91,7 +91,7 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
 
     flops = [0.0]
 
-    def hook(begin, M, spec, epi=0):
+    def hook(begin, M, spec, epi=0, info=None):
         if begin:
             flops[0] += 2.0 * M * spec.algo_kn
     wg = [0.0]
@@ -188,7 +188,7 @@ def breakdown(dev, size=512, steps=3):
         hold["r"] = measure(dev, steps=1, warmup=0, size=size, graph=False, _keep=hold)
     build()
     tr = hold["trainer"]
-    ops.CONV_HOOK = lambda b, M, spec, epi=0: timer(b, M, spec, epi, 4)
+    ops.CONV_HOOK = lambda b, M, spec, epi=0, info=None: timer(b, M, spec, epi, info, 4)
     orig_u, orig_w = ops.conv2d_wgrad_unpacked, ops.conv2d_wgrad
 
     def wrap(fn):

@@ -26,9 +26,9 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 7: lwg_conv_slice_count, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 6
+#define LWG_ABI_VERSION 7
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -85,6 +85,9 @@ int lwg_conv2d_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
  * lwg_conv2d_ws_floats returns 0 when the launch would not be split; ws = NULL runs it whole. */
 size_t lwg_conv2d_ws_floats(const LwgConvArgs* args);
 int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stream);
+/* Kernel launches behind one call of the convolution entry points above / below for this description: 1, or the number of batch slices when a
+ * gathered input exceeds the 32-bit buffer range (the entry points cut such a launch along the batch dimension); 0: one frame does not fit. */
+int lwg_conv_slice_count(const LwgConvArgs* args);
 
 /* BASELINE configs[3] ("MFMA bf16 conv tiles"): bf16 activations in HBM end to end, bf16 MFMA operands, fp32 accumulation.
  * Same launch description as lwg_conv2d_nhwc_f32 with xdt = ydt = LWG_DT_BF16: x0 / x1 / y / res / xn are bf16 NHWC tensors
@@ -94,13 +97,17 @@ int lwg_conv2d_nhwc_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stre
  * ds_read_b128 on 128-byte rows).  The first layer of a network (fp32 image-like input, Cin < 32) runs lwg_conv2d_nhwc_f32 with
  * ydt = LWG_DT_BF16 (LWG_EPI_NONE only): fp32 in, bf16 out. */
 int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
-/* The 3 x 3 / stride 1 / pad 1 fp32 convolution (nine taps, omul = 1, OH = H, OW = W, YH = H, YW = W, one input, C0 % 8 == 0, N % 64 == 0,
- * LWG_EPI_NONE or LWG_EPI_RESIDUAL, activation none / ReLU / tanh / sigmoid) as a fused F(2x2, 3x3) Winograd convolution on the fp32 matrix
- * pipe: 16 multiplies per 2 x 2 outputs instead of 36 (csrc/conv_winograd.hip).  args->w = the transformed-weight fragment panel
- * Upk[16][C0/8][2][N][4]: element (p, s, kh, n, kk) = (G w G^T)[p / 4][p % 4] for input channel 8 s + 2 kk + kh and output channel n, with
- * G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] and w the 3 x 3 kernel of that channel pair (ipercore_amd.ops builds it from the fp32 panel).
+/* The 3 x 3 / stride 1 / pad 1 fp32 convolution (attlwb_spade_resunet.py:18-22 ResidualBlock, :73-78,:87-92 SPADE, :337-340,:353-355 skip
+ * convolutions) as a fused F(2x2, 3x3) Winograd convolution on the fp32 matrix pipe: 16 multiplies per 2 x 2 outputs instead of 36
+ * (csrc/conv_winograd.hip).  Launch description as for lwg_conv2d_nhwc_f32 with: nine taps, stride = omul = 1, OH = YH = H, OW = YW = W,
+ * xdt = ydt = LWG_DT_F32; one or two inputs (skip concatenation) with C0 % 8 == 0, C1 % 8 == 0 and (C0 + C1) % 16 == 0, every image of an input
+ * < 3 GiB (any batch size: no slicing); N % 64 == 0, YC % 4 == 0; LWG_EPI_NONE or LWG_EPI_RESIDUAL (any channel slice ycoff % 4 == 0 of a wider
+ * output) or LWG_EPI_SPADE (N = 2 YC, columns and bias gamma | beta interleaved in blocks of 32, ycoff = 0); activation none / ReLU / tanh /
+ * sigmoid.  args->w = the transformed-weight fragment panel Upk[16][Cin/8][2][N][4]: element (p, s, kh, n, kk) = (G w G^T)[p / 4][p % 4] for
+ * input channel 8 s + 2 kk + kh (concatenated order) and output column n, with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] and w the 3 x 3
+ * kernel of that channel pair (ipercore_amd.ops builds it from the fp32 panel in fp64, rounded once).
  * fp32-grade results (relative error against fp64 1.6x the direct kernel's), not bitwise those of lwg_conv2d_nhwc_f32: a precision mode
- * of its own (ops.conv_precision("winograd")), opt-in. */
+ * of its own (ops.conv_precision("winograd")); a frame's result does not depend on the batch it is launched in. */
 int lwg_conv2d_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
 /* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches, as the
  * halo-tile kernel with register-streamed weights: args->w = the bf16 panel [ntaps*Cin/64][4][N][16] - element

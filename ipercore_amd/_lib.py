@@ -59,6 +59,7 @@ _SIGS = {
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_is_one_grid": (c_i, [ctypes.POINTER(LwgConvArgs)]),
+    "lwg_conv_slice_count": (c_i, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_wgrad_ws_floats": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "lwg_conv2d_wgrad_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, c_f, c_f]),
@@ -143,7 +144,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 6:
+        if handle.lwg_abi_version() != 7:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

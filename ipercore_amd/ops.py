@@ -29,8 +29,9 @@ def _ptr(t, dtype=torch.float32):
 # "fp32": native fp32 MFMA.  "bf16": the engine keeps every activation tensor in bf16 and the convs with Cin % 64 == 0 run on the bf16
 # MFMA kernel (dispatch is by tensor dtype: ops.conv2d on bf16 tensors; this flag tells the generator what to allocate).  "split": the same convs run on the bf16x6 kernel - both operands split EXACTLY into three bf16 parts,
 # six bf16 MFMAs per fp32 product, fp32 accumulation: fp32-level accuracy at 0.375 of the native matrix-pipe time.  "winograd": the 3x3 / stride 1
-# convolutions with Cin % 32 == 0 and a plain or residual epilogue run as fused F(2x2, 3x3) Winograd convolutions on the fp32 matrix pipe
-# (csrc/conv_winograd.hip: 16 multiplies per 2x2 outputs instead of 36; fp32-grade, not bitwise the direct result); everything else as "fp32".
+# convolutions with Cin % 32 == 0 - one input or a skip concatenation (both channel counts % 8 == 0), plain / residual / SPADE (gamma | beta stacked)
+# epilogue, fp32 NHWC output - run as fused F(2x2, 3x3) Winograd convolutions on the fp32 matrix pipe (csrc/conv_winograd.hip: 16 multiplies per
+# 2x2 outputs instead of 36; fp32-grade, not bitwise the direct result); everything else exactly as "fp32" (same kernels, same head).
 CONV_PRECISION = "fp32"
 
 
@@ -50,7 +51,10 @@ class conv_precision(object):
         CONV_PRECISION = self.prev
 
 
-CONV_HOOK = None     # bench.py installs a callable(begin, M, spec, epi) to bracket conv launches with HIP events
+# bench.py installs a callable(begin, M, spec, epi, info) to bracket conv entry-point calls with HIP events; info (the closing call only, else
+# None) = {"kernels": launches behind the call (lwg_conv_slice_count: batch slices), "kind": which kernel family ran ("direct", "winograd",
+# "split", "bf16", "up4")} - launch / executed-flop accounting only
+CONV_HOOK = None
 
 
 def _stream():
@@ -256,24 +260,10 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
     return a
 
 
-LAST_CONV_KERNELS = 1   # kernel launches behind the call a CONV_HOOK pair brackets (batch slices, csrc/lwg_conv_slices.h): launch accounting only
-
-
-def _conv_kernel_launches(a):
-    """How many kernel launches one conv entry-point call makes: 1, or the number of batch slices when a gathered input exceeds the
-    kernels' 32-bit buffer range (the rule of csrc/lwg_conv_slices.h)."""
-    esz = 2 if a.xdt == _lib.DT_BF16 else 4
-    per = a.H * a.W * max(a.C0, a.C1) * esz
-    if per == 0 or a.B * per < 0xC0000000:
-        return 1
-    nbs = max(1, (0xC0000000 - 1) // per)
-    return -(-a.B // nbs)
-
-
-def _hook_begin(a, spec, epi):
-    global LAST_CONV_KERNELS
-    LAST_CONV_KERNELS = _conv_kernel_launches(a)
-    CONV_HOOK(True, a.M, spec, epi)
+def _hook_end(a, spec, epi, kind, slices=True):
+    """Closing hook call: how many kernel launches the entry point made (the C rule: lwg_conv_slice_count) and which kernel family ran."""
+    n = max(1, int(_lib.lib().lwg_conv_slice_count(a))) if slices else 1
+    CONV_HOOK(False, a.M, spec, epi, {"kernels": n, "kind": kind})
 
 
 def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
@@ -286,8 +276,10 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     if q4 and (splitk or CONV_PRECISION not in ("fp32", "winograd") or x0.dtype != torch.float32):
         raise ValueError("channel-quad-plane outputs: fp32 activations on the fp32 MFMA path, no split-K")
     if CONV_HOOK is not None:
-        _hook_begin(a, spec, epi)
+        CONV_HOOK(True, a.M, spec, epi, None)
+    kind, sliced = "direct", True
     if x0.dtype == torch.bfloat16:
+        kind = "bf16"
         # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
         if y.dtype != torch.bfloat16 or spec.Cin % 64 != 0:
             raise ValueError("bf16 convolutions need bf16 outputs and Cin % 64 == 0")
@@ -309,9 +301,11 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff):
         a.w = _ptr(_wwino(spec))
+        kind, sliced = "winograd", False            # per-image buffer descriptors: one launch at any batch size
         _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
+        kind = "split"
         _lib.check(_lib.lib().lwg_conv2d_nhwc_f32_split(a, _stream()), "lwg_conv2d_nhwc_f32_split")
     else:
         nws = _lib.lib().lwg_conv2d_ws_floats(a) if splitk else 0    # > 0: a small-M / large-K launch the library runs split-K
@@ -321,7 +315,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
-        CONV_HOOK(False, a.M, spec, epi)
+        _hook_end(a, spec, epi, kind, sliced)
     return y
 
 
@@ -355,10 +349,10 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
         a.w = _ptr(panel, torch.bfloat16)
         if CONV_HOOK is not None:                # one launch = the whole transposed convolution: 16 taps, 4 N output values per input pixel
             whole = _FusedTransposeSpec(s0, panel)
-            _hook_begin(a, whole, EPI_NONE)
+            CONV_HOOK(True, a.M, whole, EPI_NONE, None)
         _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_bf16(a, _stream()), "lwg_conv_transpose4_nhwc_bf16")
         if CONV_HOOK is not None:
-            CONV_HOOK(False, a.M, whole, EPI_NONE)
+            _hook_end(a, whole, EPI_NONE, "up4")
         return y
     if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION in ("fp32", "winograd") and len(specs) == 4 and s0.Cin % 32 == 0
             and all(s.ntaps == 4 and s.omul == 2 and s.stride == 1 and (s.ooy, s.oox) == (i >> 1, i & 1) and s.N == s0.N and s.Cin == s0.Cin
@@ -375,10 +369,10 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
             a.w = _ptr(panel)
             if CONV_HOOK is not None:
                 whole = _FusedTransposeSpec(s0, panel)
-                _hook_begin(a, whole, EPI_NONE)
+                CONV_HOOK(True, a.M, whole, EPI_NONE, None)
             _lib.check(_lib.lib().lwg_conv_transpose4_nhwc_f32(a, _stream()), "lwg_conv_transpose4_nhwc_f32")
             if CONV_HOOK is not None:
-                CONV_HOOK(False, a.M, whole, EPI_NONE)
+                _hook_end(a, whole, EPI_NONE, "up4")
             return y
     for s in specs:
         conv2d(x, s, y, act=act, splitk=splitk, out_hw=None if out_hw is None else out_hw(s), q4=q4)

@@ -27,7 +27,7 @@ def main():
         im = pu.make_imitator(case, frame_batch=16, device=dev)
         tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
         timer = bench.ConvTimer()
-        ops.CONV_HOOK = lambda b, M, spec, epi=0: timer(b, M, spec, epi, 4)
+        ops.CONV_HOOK = lambda b, M, spec, epi=0, info=None: timer(b, M, spec, epi, info, 4)
         render = lambda: im.synthesize(tgt, "smooth")          # noqa: E731
         last = render()
         for st in stages:

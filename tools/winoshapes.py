@@ -17,6 +17,7 @@ ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--nodirect", action="store_true")
 ap.add_argument("--ts", action="store_true")
+ap.add_argument("--ts2", action="store_true", help="-DLWG_WINO_TS2 build: per-wave slot timeline of iterations 8 and 9 (shape --only, plain epilogue, Cin >= 96)")
 args = ap.parse_args()
 import torch
 from ipercore_amd import _lib
@@ -77,6 +78,25 @@ for idx, (tag, mul, S, C0, C1, Co, epi) in enumerate(SHAPES):
         if epi == "res":
             kw.update(epi=ops.EPI_RESIDUAL, res=rnd((B, S, S, Co), 8).to(dev))
     yw, yd = torch.empty(B, S, S, Co, device=dev), torch.empty(B, S, S, Co, device=dev)
+    if args.ts2:
+        nblk = ((S + 15) // 16) ** 2 * B * (N // 64)
+        stamps = torch.zeros(nblk * 8 * 16 * 2, device=dev)
+        with ops.conv_precision("winograd"):
+            for _ in range(2):
+                ops.conv2d(x0, spec, yw, x1=x1, act=ops.ACT_RELU, res=stamps)
+        torch.cuda.synchronize()
+        t = stamps.view(torch.int64).view(nblk, 8, 16).cpu()
+        names = ["top", "slot4", "slot8", "slot16", "pre-barrier", "post-barrier", "slot29", "end"]
+        for blk in (0, nblk // 2, nblk - 1):
+            base = int(t[blk, :, 0].min())
+            print(f"[ts2] {tag}: workgroup {blk}: cycles since the first wave's top of iteration 8 (rows = waves 0..7; columns = " + ", ".join(names) + " of iteration 8, then 9)")
+            for w in range(8):
+                print("   wave %d: " % w + " ".join("%6d" % (int(t[blk, w, i]) - base) for i in range(16)))
+        d = (t[:, :, 8] - t[:, :, 0]).double()
+        print(f"     iteration 8 top -> iteration 9 top, per wave: mean over workgroups " + " ".join("%.0f" % d[:, w].mean() for w in range(8)))
+        bar = (t[:, :, 5] - t[:, :, 4]).double()
+        print(f"     cycles parked at the barrier of iteration 8, per wave: " + " ".join("%.0f" % bar[:, w].mean() for w in range(8)))
+        continue
     if args.ts:
         nblk = ((S + 15) // 16) ** 2 * B * (N // 64)
         stamps = torch.zeros(nblk * 128, device=dev)              # 64 x u64 per workgroup
