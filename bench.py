@@ -337,6 +337,25 @@ def split_products(im, render, n, W, K, ref_video):
         ops.CONV_HOOK = hook
 
 
+def direct_products(im, render, n, W, K, ref_video):
+    """Reported separately: the same clip with EVERY convolution on the direct implicit-GEMM kernel (generator.conv_precision = "fp32", the
+    rounds 1-4 default): what the F(2x2,3x3) Winograd engine of the 3x3 / stride 1 layers buys, and how far the frames of the two engines are apart."""
+    from ipercore_amd import ops
+    hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    prev = im.generator.conv_precision
+    im.generator.conv_precision = "fp32"
+    try:
+        dt, video = _timed_clips(render, W, K)
+        diff = (video - ref_video).abs().max().item()
+        return {"value": round(K * n / dt, 3), "unit": "frames/s", "ms_per_clip": round(dt / K * 1e3, 3), "clips": K,
+                "self_check": "allclose (max |d| <= 1e-4 vs the default engine's frames of the same clip)" if diff <= 1e-4 else f"MISMATCH: max |d| = {diff:.3e}",
+                "max_abs_diff_vs_default_engine": diff, "frames_range": "[-1, 1]",
+                "what": "every convolution as a direct fp32 MFMA implicit GEMM (lwg_conv_igemm_kernel)"}
+    finally:
+        im.generator.conv_precision = prev
+        ops.CONV_HOOK = hook
+
+
 def winograd_products(im, render, n, W, K, ref_video):
     """Reported separately: the same clip with the 3x3 / stride 1 convolutions (plain and residual epilogues) as fused F(2x2, 3x3) Winograd
     convolutions on the fp32 matrix pipe (csrc/conv_winograd.hip; 16 multiplies per 2x2 outputs instead of 36, fp32 throughout).  Not the
@@ -419,9 +438,10 @@ def b1_latency(im, tgt, timer, n_frames=64):
         dt = time.perf_counter() - t0
         timer.enabled = False
         conv_ms, conv_flops, n_launch, mean_ms = timer.result()
-        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        ach = timer.exec_flops / (conv_ms * 1e-3) / 1e12          # executed matrix-pipe flops (the Winograd launches execute 4/9 of the algorithmic)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_equivalent_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                           "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
                            "conv_ms_per_frame": round(conv_ms / n, 3), "measured_in": "a pass with events around every conv launch",
                            "share_of_time": round(conv_ms * 1e-3 / dt, 4)}
         return out
@@ -527,11 +547,12 @@ def size_extra(dev, timer, S, W=1, K=2):
         assert video.shape[0] == n and torch.isfinite(video).all()
         conv_ms, conv_flops, n_launch, mean_ms = timer.result()
         chk = rerender_check(im, tgt, video)
-        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        ach = timer.exec_flops / (conv_ms * 1e-3) / 1e12          # executed flops (Winograd launches: 4/9 of the algorithmic)
         return {"value": round(K * n / dt, 2), "unit": "frames/s", "image_size": S, "dtype": "f32", "frames_per_clip": n, "clips": K,
                 "frame_batch": min(im.frame_batch, n), "self_check": chk["result"], "self_check_detail": chk,
                 "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
+                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_equivalent_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                             "launches": n_launch, "avg_launch_us": round(mean_ms * 1e3, 2),
                              "algorithmic_gflop_per_frame": round(conv_flops / (K * n) / 1e9, 2), "share_of_time": round(conv_ms * 1e-3 / dt, 4)}}
     except Exception as e:                       # an extra must never take the headline line with it
         return {"error": f"{type(e).__name__}: {e}"}
@@ -599,7 +620,7 @@ def main(argv=None):
                          "around main(); without it every op raises on CPU tensors - there is no CPU product path)")
     ap.add_argument("--no-overlap-gather", dest="overlap", action="store_false", help="one all-gather after the frame loop")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "bf16", "split", "winograd"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "bf16", "split", "winograd"), default="winograd",
                     help="bf16: BASELINE configs[3] mode - bf16 MFMA operands and bf16 activation storage in the convs (fp32 accumulation); "
                          "the headline metric (configs[1]) is fp32")
     ap.add_argument("--workload", choices=("imitate", "novel_view"), default="imitate",
@@ -665,8 +686,10 @@ def main(argv=None):
     if args.workload == "novel_view":
         nv = novel_view_smpls(case, im.body_rec.np_hands_mean, 180)
         case.tgt_smpls = np.concatenate([nv] * (n_seq // 180 + 1), axis=0)[:n_seq]
-    if args.precision != "fp32":
-        im.generator.conv_precision = args.precision
+    im.generator.conv_precision = args.precision
+    is_f32 = args.precision in ("fp32", "winograd")           # fp32 tensors and fp32 MFMA arithmetic (BASELINE configs[1] / [2])
+    headline = args.precision == "winograd"                   # the product's default engine
+    if args.precision != "winograd":                          # the sources were encoded in the default mode: again in this one
         im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
     FB_requested, FB = FB, im.frame_batch        # (no clamp any more: batches beyond the kernels' 3 GiB buffer range are sliced inside the C entry points)
     if rank == 0:                                                # what tools/pmc_summary.py stamps the PMC traffic file with
@@ -797,21 +820,25 @@ def main(argv=None):
         conv_ms, conv_flops, n_launch, mean_launch_ms = timer.result()
         conv_exec_flops, conv_by_kind = timer.exec_flops, timer.by_kind()
         frames = K * frames_per_step
-        prec_tag = {"fp32": "", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]", "winograd": " [F(2x2,3x3) Winograd 3x3 convolutions]"}[args.precision]
+        prec_tag = {"winograd": "", "fp32": " [every layer on the direct kernel]", "bf16": " [bf16 MFMA conv tiles]", "split": " [bf16x6 exact-split products]"}[args.precision]
         line = {
             "metric": ("synthesized frames/sec at 512x512 (run_imitator)" if S == 512 else f"synthesized frames/sec at {S}x{S}") + prec_tag,
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if clip else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split",
-                      "winograd": "f32 (3x3 / stride 1 convolutions as F(2x2,3x3) Winograd on the fp32 MFMA pipe)"}[args.precision],
+                      "winograd": "f32"}[args.precision],
+            "conv_engine": {"winograd": "fp32 MFMA: 3x3 / stride 1 layers as fused F(2x2,3x3) Winograd convolutions (lwg_conv_winograd_kernel), the strided / "
+                                        "transposed / first layers as direct implicit GEMMs (lwg_conv_igemm_kernel)",
+                            "fp32": "fp32 MFMA: every layer as a direct implicit GEMM (lwg_conv_igemm_kernel)",
+                            "bf16": "bf16 MFMA implicit GEMMs", "split": "bf16x6 implicit GEMMs"}[args.precision],
             "data": "synthetic" + (" (tiny architecture, CPU plumbing run: NOT a measurement)" if (args.tiny_arch or not on_gpu) else ""),
             "result_tensor": ("(n,3,S,S) f32 video" if (world == 1 or args.gather_dtype == "f32") else "(n,S,S,3) uint8 video") +
                              (f", all-gathered as {args.gather_dtype}" if world > 1 else ""),
             "config": {"workload": (f"run_imitator {S}x{S} single src/ref pair, {n_clip}-frame reference clip frame-sharded over {world} GPU(s), "
                                     "AttLWB-SPADE generator fp32 (BASELINE configs[1] at N = 1, configs[2] at N = 8)" if clip else
                                     f"run_imitator {S}x{S} single src/ref pair, one {FB}-frame batch per GPU per step (weak scaling)")
-                       if args.precision == "fp32" else
+                       if is_f32 else
                        f"per-frame path {S}x{S}, AttLWB-SPADE generator, precision mode {args.precision}",
                        "poses": args.workload, "image_size": S, "num_source": 2, "frame_batch": (min(FB, -(-n_clip // world)) if clip else FB), "frame_batch_requested": FB_requested,
                        "frames_per_step": frames_per_step,
@@ -831,13 +858,14 @@ def main(argv=None):
             line["self_check_detail"] = self_check
         if n_launch:
             traffic, traffic_src = None, None
-            tname = {"fp32": "pmc_traffic.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
+            tname = {"winograd": "pmc_traffic.json", "fp32": "pmc_traffic_direct.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
             tpath = os.path.join(ROOT, "profiles", tname) if tname else None       # written by tools/pmc_round.sh (separate --pmc passes)
-            if tpath and S == (512 if args.precision == "fp32" else 1024) and args.streams == 1 and os.path.exists(tpath):
+            if tpath and S == (512 if is_f32 else 1024) and args.streams == 1 and os.path.exists(tpath):
                 with open(tpath) as fp:
                     tj = json.load(fp)
                 cfg = tj.get("bench_config") or {}
-                if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload:   # same launches
+                if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload and \
+                        cfg.get("precision", "fp32") == args.precision:   # same launches
                     traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             # matrix-pipe flops EXECUTED per second over all conv launches: the direct kernels execute their algorithmic flops, the F(2x2,3x3)
             # Winograd kernel 4/9 of them (16 products per 2 x 2 outputs instead of 36) - a roofline fraction is executed work over the pipe's peak
@@ -882,16 +910,19 @@ def main(argv=None):
                 return im.synthesize(tgt, "smooth")
             if args.pipelined_streams > 1:
                 line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams, tgt if args.self_check else None)
-            if args.split_extra and args.precision == "fp32":
+            if args.split_extra and is_f32:
                 line["split_products"] = _extra(split_products, im, render, n_clip, 1, Ke, last)
-                line["winograd_products"] = _extra(winograd_products, im, render, n_clip, 1, Ke, last)
+                if headline:
+                    line["direct_products"] = _extra(direct_products, im, render, n_clip, 1, Ke, last)
+                else:
+                    line["winograd_products"] = _extra(winograd_products, im, render, n_clip, 1, Ke, last)
             if args.output_frames > 0:
                 # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
                 # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)
                 line["with_output"] = _extra(with_output, im, tgt, min(FB, 16), args.output_frames, 0)
-            if args.precision == "fp32" and S == 512 and args.sizes_extra:
+            if headline and S == 512 and args.sizes_extra:
                 line["sizes"] = {str(S2): size_extra(dev, timer, S2) for S2 in (256, 1024)}
-            if args.precision == "fp32" and S == 512:
+            if headline and S == 512:
                 line["b1_latency"] = _extra(b1_latency, im, tgt, timer)
                 ops.CONV_HOOK = hook
                 try:

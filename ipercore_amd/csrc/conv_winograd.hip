@@ -11,15 +11,12 @@
 //   * the raw 18 x 18 x 8 halo patch goes global -> registers (three stages ahead) -> raw[s % 2] (channel-major planes, two stages ahead); padding
 //     pixels and threads without a halo element carry an out-of-range buffer offset (the hardware returns zeros: no branches, no exec masks);
 //   * the next stage's input transform (one (patch, channel) 4x4 -> V[16] per thread: raw[(s + 1) % 2] -> Vs[(s + 1) % 2]) runs beside the MFMAs.
-// Schedule (round 5, measured with tools/winoshapes.py --ts / --ts2 and rocprofv3 PMC, profiles/r05_*): an iteration is 32 slots of ONE MFMA
-// (m = kk * 8 + nu * 2 + tb) each followed by at most ~5 instructions with immediate offsets and scalar (SGPR) stage offsets; the barrier sits after
-// slot 23 and the next stage's fragments for k-pairs 0..2 are read right behind it into the registers slots 0-23 have finished with (k-pair 3 at
-// the next top).  A load costs the issuing wave 125-190 cycles before its next MFMA issues, and the two waves of a SIMD do not share the matrix
-// pipe evenly: the older one (waves 0-3) is served first after every barrier, runs ahead and parks at the next barrier while the younger one
-// (waves 4-7) finishes its stage alone, every stall exposed.  So the two halves run DIFFERENT slot plans of the same work (two instantiations of
-// the whole kernel body, chosen per wave): the leaders put their loads last (the stalls fall into time they would spend parked, beside the trailers'
-// transform), the trailers put theirs first (beside the leaders' dense MFMA stretch right after the barrier, where they wait for the pipe anyway)
-// and end the stage on bare MFMAs.
+// Schedule (round 5, measured with tools/winoshapes.py --ts / --ts2 on knock-out and calibration builds, profiles/r05_b_*): an iteration is 32 slots
+// of ONE MFMA (m = kk * 8 + nu * 2 + tb) with the stage's other work behind the first dozen of them; the barrier sits after slot 23 and the next
+// stage's fragments for k-pairs 0..2 are read right behind it into the registers slots 0-23 have finished with (k-pair 3 at the next top).  What
+// the filler instructions cost in matrix-pipe time (the fp32 MFMA runs at the vector rate and shares the SIMD's issue with the vector ALU): a
+// vector ALU instruction 2 cycles + 6 per slot that has any, an LDS instruction 1-2.5, a buffer load nothing to issue - so every LDS address is a
+// base register + immediate, stage offsets are scalar, the transform's 32 adds sit in two slots, and the loads go first (only their latency matters).
 // Epilogue: every wave folds its four products over nu in registers (M A: two values per (patch, channel)), the four rows xi of a (patch, channel)
 // live in four different waves -> ONE exchange through LDS ([xi][column][n][patch], rows padded to 65 floats: conflict-free both ways); a thread then
 // owns one patch x two channel quads (n4.., 32 + n4..): A^T (.) over xi + bias (+ residual, or the SPADE modulation of a gamma | beta launch) +
@@ -67,9 +64,10 @@ __device__ __forceinline__ floatx4 wino_buf_load(__amdgpu_buffer_rsrc_t r, unsig
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-// ROLE 0: waves 0-3 (lead their SIMD partners), ROLE 1: waves 4-7 (trail them) - the same work on different slot plans (see iteration)
-template <int EPI, int ROLE>
-__device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, const int wid) {
+template <int EPI>
+__global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ bias = a.bias;
     float* __restrict__ y = a.y;
     const int H = a.H, W = a.W, Cin = a.C0 + a.C1, N = a.N;
@@ -125,8 +123,26 @@ __device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, con
     const int patch = tid & 63, tc = tid >> 6;
     const int pty = patch >> 3, ptx = patch & 7;
     const float* const dbase = raw0 + tc * PLANE + (2 * pty) * HALO + 2 * ptx;      // this thread's 4 x 4 input patch inside raw[0]
-    float* const vbase = Vs0 + tc * VSTR + patch;                                  // its 16 transformed values inside Vs[0]
-    const float* const fbase = Vs0 + (4 * xi * KS + (lane >> 5)) * VSTR + (lane & 31);    // this lane's fragments inside Vs[0]
+    // Vs rows hold patch p at position (p % 32) * 2 + p / 32: a lane's fragments of the two patch tiles are ONE 8-byte read
+    float* const vbase = Vs0 + tc * VSTR + (patch & 31) * 2 + (patch >> 5);        // its 16 transformed values inside Vs[0]
+    // base registers with immediate offsets behind them (a vector add between two MFMAs costs matrix-pipe time: the fp32 MFMA shares the SIMD's
+    // issue with the vector ALU - measured 2 cycles per instruction + 6 per slot that has any, profiles/r05_b_winograd_calibration.txt);
+    // the empty asm keeps the compiler from re-deriving one base from another inside the loop
+    // (float indices into smem, not pointers: the LDS address space has to survive the asm)
+    unsigned dbs[2];
+    unsigned fbs[2][4];                                      // [buffer][product nu]: this lane's fragments
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        dbs[u] = (unsigned)(u * RAW_FLOATS + tc * PLANE + (2 * pty) * HALO + 2 * ptx) >> 1;     // (even: the asm hides the value, the shift
+        asm volatile("" : "+v"(dbs[u]));                                                          //  keeps the 8-byte alignment visible)
+        dbs[u] <<= 1;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            fbs[u][nu] = (unsigned)(2 * RAW_FLOATS + u * VS_FLOATS + ((4 * xi + nu) * KS + (lane >> 5)) * VSTR + (lane & 31) * 2) >> 1;
+            asm volatile("" : "+v"(fbs[u][nu]));
+            fbs[u][nu] <<= 1;
+        }
+    }
     auto transform = [&](int buf) {                          // prologue only
         const float* d = dbase + buf * RAW_FLOATS;
         float* v = vbase + buf * VS_FLOATS;
@@ -152,12 +168,11 @@ __device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, con
 #pragma unroll
     for (int i = 0; i < 16; ++i) ts2[i] = 0;
 #endif
-    float fb[4][4][2];                                       // [k-pair][product nu][patch tile tb]
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    floatx2 fb[4][4];                                        // [k-pair][product nu]: patch tiles 0 | 1
     auto fragread = [&](int set, int kk) {
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) fb[kk][nu][tb] = fbase[set * VS_FLOATS + (nu * KS + 2 * kk) * VSTR + tb * 32];
+        for (int nu = 0; nu < 4; ++nu) fb[kk][nu] = *reinterpret_cast<const floatx2*>(smem + fbs[set][nu] + 2 * kk * VSTR);
     };
     auto iteration = [&](int s, auto SET, auto NXT) {
         constexpr int set = decltype(SET)::value;
@@ -184,7 +199,7 @@ __device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, con
         auto ddr = [&](int i) {
             if (nxt) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dd[i][j] = dbase[(set ^ 1) * RAW_FLOATS + i * HALO + j];
+                for (int j = 0; j < 4; ++j) dd[i][j] = smem[dbs[set ^ 1] + i * HALO + j];
             }
             WSB();
         };
@@ -209,57 +224,25 @@ __device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, con
         WTS2(0);
         fragread(set, 3);                                    // k-pair 3 of THIS stage (its registers were busy until the previous slot 31)
         WSB();
-        if (ROLE == 0) {                                     // leaders: transform first, halo store, loads last
-            mf(0); ddr(0);
-            mf(1); ddr(1);
-            mf(2); ddr(2);
-            mf(3); ddr(3);
-            WTS2(1);
-            mf(4);
-            mf(5); t2a(0);
-            mf(6); t2b(0);
-            mf(7); t2a(1);
-            WTS2(2);
-            mf(8); t2b(1);
-            mf(9); t2a(2);
-            mf(10); t2b(2);
-            mf(11); t2a(3);
-            mf(12); t2b(3);
-            mf(13); rst(0);
-            mf(14); rst(1);
-            mf(15); rld(0);
-            WTS2(3);
-            mf(16); rld(1);
-            mf(17); uld(0);
-            mf(18); uld(1);
-            mf(19); uld(2);
-            mf(20); uld(3);
-        } else {                                             // trailers: loads first, halo store, transform, then bare MFMAs
-            mf(0); uld(0);
-            mf(1); uld(1);
-            mf(2); uld(2);
-            mf(3); uld(3);
-            WTS2(1);
-            mf(4); rst(0);
-            mf(5); rst(1);
-            mf(6); rld(0);
-            mf(7); rld(1);
-            WTS2(2);
-            mf(8); ddr(0);
-            mf(9); ddr(1);
-            mf(10); ddr(2);
-            mf(11); ddr(3);
-            mf(12);
-            mf(13); t2a(0);
-            mf(14); t2b(0);
-            mf(15); t2a(1);
-            WTS2(3);
-            mf(16); t2b(1);
-            mf(17); t2a(2);
-            mf(18); t2b(2);
-            mf(19); t2a(3);
-            mf(20); t2b(3);
-        }
+        // slot plan: loads first (their issue is free, their latency is what has to be covered), then the halo store, the transform reads, and the
+        // transform's 32 vector adds in TWO slots (a slot that has any vector instruction costs ~6 cycles of matrix pipe on top of 2 per instruction)
+        mf(0); uld(0);
+        mf(1); uld(1);
+        mf(2); uld(2);
+        mf(3); uld(3);
+        WTS2(1);
+        mf(4); rst(0); rld(0);
+        mf(5); rst(1); rld(1);
+        mf(6); ddr(0); ddr(1); ddr(2); ddr(3);
+        mf(7);
+        WTS2(2);
+        mf(8);
+        mf(9); t2a(0); t2b(0); t2a(1); t2b(1);
+        mf(10);
+        mf(11); t2a(2); t2b(2); t2a(3); t2b(3);
+        mf(12); mf(13); mf(14); mf(15);
+        WTS2(3);
+        mf(16); mf(17); mf(18); mf(19); mf(20);
         mf(21); mf(22); mf(23);
         WTS2(4);
         __syncthreads();
@@ -407,16 +390,6 @@ __device__ __forceinline__ void wino_body(const LwgConvArgs& a, float* smem, con
     }
     WTS(41);
     WTS(42);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // two instantiations of the whole body, nothing shared before the branch: no register state has to meet at a join (both execute the same
-    // sequence of barriers)
-    if (wid < 4) wino_body<EPI, 0>(a, smem, wid);
-    else wino_body<EPI, 1>(a, smem, wid);
 }
 
 

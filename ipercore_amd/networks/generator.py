@@ -223,9 +223,15 @@ class AttentionLWBGenerator(nn.Module):
         for name, child in tree.named_children():     # graft the tree's top-level nodes onto this module
             self.add_module(name, child)
         self._packed = None
+        # How the engine's convolutions run (ops.conv_precision):
+        # "winograd" (default since round 5; BASELINE configs[1] / [2]: "AttLWB generator fp32"): fp32 tensors and fp32 MFMA arithmetic throughout;
+        #   the 3x3 / stride 1 layers (SPADE, residual blocks, skip convolutions: 81 % of the flops) as fused F(2x2,3x3) Winograd convolutions
+        #   (csrc/conv_winograd.hip: 16 products per 2 x 2 outputs instead of 36), everything else on the direct implicit-GEMM kernel;
+        # "fp32": every layer on the direct kernel (the rounds 1-4 default; frames differ from "winograd" by ~3e-6);
         # "bf16": BASELINE configs[3] - every activation tensor of the engine is stored as bf16, the convs run on the bf16 MFMA kernel
-        # (fp32 accumulation), InstanceNorm statistics / attention / head read bf16; the first conv of a stream takes the fp32 input
-        self.conv_precision = "fp32"
+        #   (fp32 accumulation), InstanceNorm statistics / attention / head read bf16; the first conv of a stream takes the fp32 input;
+        # "split": fp32 tensors, every product formed from six bf16 MFMAs (exact three-way operand split).
+        self.conv_precision = "winograd"
 
     # ------------------------------------------------------------------ plumbing
     def packed(self):

@@ -116,8 +116,8 @@ def test_bench_personalize_eight_ranks_gloo(tmp_path):
 
 def test_default_frame_batch_and_kernel_launch_count():
     """N = 1: the clip of every benched configuration is ONE launch batch; N > 1: batches of 32 (fp32 at 512) so that the exchange of one batch
-    overlaps the next.  The launch accounting counts the kernel launches behind a call the library slices over the batch: the Python rule
-    (ops._conv_kernel_launches) is the C rule of csrc/lwg_conv_slices.h (lwg_conv_slice_frames)."""
+    overlaps the next.  The launch accounting counts the kernel launches behind a call the library slices over the batch: the library itself says
+    how many (lwg_conv_slice_count = the rule of csrc/lwg_conv_slices.h; no Python copy of it)."""
     import bench
     from ipercore_amd import _lib, ops
     assert bench.default_frame_batch("fp32", 512) >= 300 and bench.default_frame_batch("fp32", 1024) >= 96
@@ -128,7 +128,7 @@ def test_default_frame_batch_and_kernel_launch_count():
         a = _lib.LwgConvArgs()
         a.B, a.H, a.W, a.C0, a.C1 = B, H, W, C0, C1
         a.xdt = _lib.DT_BF16 if bf16 else _lib.DT_F32
-        return ops._conv_kernel_launches(a)
+        return _lib.lib().lwg_conv_slice_count(a)
 
     assert launches(32, 512, 512, 64) == 1                        # 2.1 GiB
     assert launches(300, 64, 64, 256) == 1                        # the residual blocks of a 300-frame batch: 1.2 GiB
@@ -136,6 +136,7 @@ def test_default_frame_batch_and_kernel_launch_count():
     assert launches(300, 256, 256, 128, 128) == 4                 # the larger of the two concatenated inputs governs
     assert launches(47, 512, 512, 64) == 1 and launches(48, 512, 512, 64) == 2
     assert launches(180, 512, 512, 128, bf16=True) == 4           # bf16: half the bytes per element
+    assert launches(2, 4096, 4096, 64) == 0 and launches(0, 8, 8, 64) == 0      # one frame does not fit / empty batch: rejected by the entry points
 
 
 def test_bench_default_frame_batches(tmp_path):

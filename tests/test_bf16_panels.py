@@ -155,12 +155,16 @@ def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
         def lwg_conv_transpose4_nhwc_bf16(self, a, stream):
             calls.append(("fused", a.contents.ntaps if hasattr(a, "contents") else a.ntaps))
             return 0
+
+        def lwg_conv_slice_count(self, a):
+            return 1
     monkeypatch.setattr(_lib, "lib", lambda: _Stub())
     monkeypatch.setattr(ops, "_stream", lambda: None)
     monkeypatch.setattr(ops, "_ptr", lambda t, dt=None: 0 if t is None else t.data_ptr())
     monkeypatch.setattr(ops, "conv2d", lambda x, s, y, act=0, **kw: calls.append(("parity", s.ooy, s.oox)))
     hooked = []
-    monkeypatch.setattr(ops, "CONV_HOOK", lambda begin, M, spec, epi=0: hooked.append((begin, M, spec.N, spec.ntaps, spec.algo_kn)))
+    infos = []
+    monkeypatch.setattr(ops, "CONV_HOOK", lambda begin, M, spec, epi=0, info=None: (hooked.append((begin, M, spec.N, spec.ntaps, spec.algo_kn)), infos.append(info)))
 
     specs128 = packing.pack_conv_transpose(_w((128, 64, 4, 4), 20), torch.zeros(64))
     x = torch.zeros(1, 8, 16, 128, dtype=torch.bfloat16)
@@ -168,6 +172,7 @@ def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
     ops.conv_transpose2d(x, specs128, y, act=ops.ACT_RELU)
     assert calls == [("fused", 4)]
     assert hooked == [(True, 128, 256, 16, 4 * specs128[0].algo_kn), (False, 128, 256, 16, 4 * specs128[0].algo_kn)]
+    assert infos == [None, {"kernels": 1, "kind": "up4"}]          # the closing call says what ran: launches behind the call, kernel family
     assert specs128[0]._w16up.shape == (4, 2 * 4, 4, 64, 16)                   # [parity][Cin/64 * taps][ks][N][16]
 
     calls.clear()

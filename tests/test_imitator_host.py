@@ -182,9 +182,9 @@ def test_only_vis_frames_on_emulated_abi(monkeypatch):
 
 
 def test_precision_modes_plumbing(monkeypatch):
-    """generator.conv_precision = "winograd" / "split" route through the same engine wiring (the emulated ABI computes every mode exactly, so the
-    frames must equal the default mode's): the quad-plane head input is used by the fp32 MFMA modes ("fp32" and "winograd", whose last
-    up-sampling layer is the same direct transposed convolution), "split" takes the NHWC head."""
+    """generator.conv_precision = "winograd" (the default) / "fp32" / "split" route through the same engine wiring (the emulated ABI computes every
+    mode exactly, so the frames must equal the default mode's): the quad-plane head input is used by the fp32 MFMA modes ("winograd" and "fp32",
+    whose last up-sampling layer is the same direct transposed convolution), "split" takes the NHWC head."""
     emu_ops.install(monkeypatch)
     from ipercore_amd import ops
     case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=3, ns=2)
@@ -192,13 +192,14 @@ def test_precision_modes_plumbing(monkeypatch):
     calls = []
     real_head = ops.head_compose
     monkeypatch.setattr(ops, "head_compose", lambda *a, **k: (calls.append(bool(k.get("q4"))), real_head(*a, **k))[1])
+    assert im.generator.conv_precision == "winograd"
     ref = pu.run_hip(case, imitator=im)
-    assert calls and all(calls), "the fp32 mode feeds the head channel-quad planes"
-    for mode in ("winograd", "split"):
+    assert calls and all(calls), "the default mode feeds the head channel-quad planes"
+    for mode in ("fp32", "split"):
         del calls[:]
         im.generator.conv_precision = mode
         got = pu.run_hip(case, imitator=im)
-        assert calls and (all(calls) if mode == "winograd" else not any(calls)), mode
+        assert calls and (all(calls) if mode == "fp32" else not any(calls)), mode
         assert torch.equal(got, ref), mode
     with pytest.raises(AssertionError):
         ops.conv_precision("fp16")
