@@ -580,6 +580,75 @@ def personalize_step_extra(steps=10, warmup=4, size=512, timeout_s=900, extra_ar
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def shard_of_8(im, tgt, n_clip, reps=6):
+    """Reported separately, and NOT a hardware measurement of 8 GPUs: what ONE rank of BASELINE configs[2] does (300 frames over 8 ranks = shards of
+    38 / 37 frames, models/imitator.py:298-299,327-382), timed on this one GPU - the sharded frame loop of ipercore_amd.sharding exactly as a rank
+    runs it (chunk plan, post-processing, async all-gather per chunk through RCCL in a ONE-rank group: the collective is issued and waited
+    for, the volume is 1/8 of the real one).  compute_ceiling_8gpu_fps = 300 / t_shard is the bound the driver's 8-GPU line cannot exceed."""
+    import torch.distributed as dist
+    from ipercore_amd import ops, sharding
+    hook, ops.CONV_HOOK = ops.CONV_HOOK, None
+    prev_fb = im.frame_batch
+    out = {"what": "one rank's share of the 300-frame clip at N = 8, run on one GPU (no 8-GPU hardware curve was measured)",
+           "shard_frames": max(sharding.shard_counts(n_clip, 8))}
+    own_group = False
+    try:
+        n = out["shard_frames"]
+        shard = tgt[:n]
+        try:
+            if not dist.is_initialized():
+                port = 29500 + (os.getpid() % 2000)
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=tgt.device)
+                own_group = True
+            rccl = True
+        except Exception as e:       # noqa: BLE001
+            rccl = False
+            out["rccl_error"] = f"{type(e).__name__}: {e}"[:200]
+
+        def timed(fn):
+            fn()
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return min(ts), sorted(ts)[len(ts) // 2]
+
+        variants = {}
+        for fb in (32, n):
+            im.frame_batch = fb
+            plan = [m for _, m in sharding.chunk_plan(n_clip, 8, fb, sharding.round_frames_of(im))]
+            tag = "+".join(str(m) for m in plan)
+
+            def compute_only():
+                off = 0
+                for m in plan:
+                    im.synthesize(shard[off:off + m], "smooth", t0=off)
+                    off += m
+            variants[f"chunks_{tag}_compute_only_ms"] = [round(v, 3) for v in timed(compute_only)]
+            if rccl:
+                for post_name, post in (("f32", None), ("u8", ops.frames_to_u8)):
+                    def full(post=post):
+                        sharding.sharded_synthesize(im, shard, "smooth", prepared=True, post=post, force_collective=True)
+                    variants[f"chunks_{tag}_{post_name}_exchange_ms"] = [round(v, 3) for v in timed(full)]
+        out["ms_min_median"] = variants
+        best = min(v[0] for k, v in variants.items() if "exchange" in k or not rccl)
+        out["t_shard_ms"] = round(best, 3)
+        out["frames_per_s_per_rank"] = round(n / best * 1e3, 1)
+        out["compute_ceiling_8gpu_fps"] = round(n_clip / best * 1e3, 1)
+        return out
+    finally:
+        im.frame_batch = prev_fb
+        ops.CONV_HOOK = hook
+        if own_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:        # noqa: BLE001
+                pass
+
+
 def _extra(fn, *a, **kw):
     """A separately reported measurement must never take the headline line with it: an exception becomes {"error": ...}."""
     try:
@@ -922,6 +991,8 @@ def main(argv=None):
                 line["with_output"] = _extra(with_output, im, tgt, min(FB, 16), args.output_frames, 0)
             if headline and S == 512 and args.sizes_extra:
                 line["sizes"] = {str(S2): size_extra(dev, timer, S2) for S2 in (256, 1024)}
+            if headline and S == 512 and clip:
+                line["shard_of_8"] = _extra(shard_of_8, im, tgt, n_clip)
             if headline and S == 512:
                 line["b1_latency"] = _extra(b1_latency, im, tgt, timer)
                 ops.CONV_HOOK = hook

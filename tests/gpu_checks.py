@@ -519,6 +519,36 @@ def check_generator_golden(conv_precision=None):
     return out
 
 
+def check_generator_golden_256():
+    """forward_src + forward_tsf at S = 256, full width, against outputs of the REFERENCE's own module (tests/golden/golden_tsf256_v1.npz from
+    make_golden_tsf256.py; the other reference goldens are S = 64 / 128): flows resized down to 32 x 32, out-of-range and -2 flow values, in
+    the default engine and with every layer on the direct kernel."""
+    from ipercore_amd.networks import NetworksFactory, generator_param_shapes
+    from tests.golden.make_golden_tsf256 import synthetic_flow
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_tsf256_v1.npz"))
+    nf, nres, bgf = [64, 128, 256], 6, [64, 128, 128, 256]
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).eval()
+    sd = synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7)
+    G.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    G.to(DEV)
+    src_inputs = torch.tensor(synthetic.uniform_image((1, 2, 6, 256, 256), 8, "src_inputs_256"), device=DEV)
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, 256, 256), 9, "tsf_inputs_256"), device=DEV)
+    Tst = torch.tensor(synthetic_flow(), device=DEV)
+    out = {}
+    for mode in ("winograd", "fp32"):
+        G.conv_precision = mode
+        enc, res = G.forward_src(src_inputs, only_enc=True)
+        img, mask = G.forward_tsf(tsf_inputs, enc, res, Tst)
+        torch.cuda.synchronize()
+        out[mode] = {"enc": _cmp(enc[-1][:, ::16, ::2, ::2], torch.tensor(g["enc2_sub"]), 1e-4, "enc"),
+                     "res": _cmp(res[-1][:, ::16, ::2, ::2], torch.tensor(g["res_last_sub"]), 2e-4, "res"),
+                     "img": _cmp(img[:, :, ::2, ::2], torch.tensor(g["img_sub"]), 2e-3, "tsf_img"),           # SURVEY 8c tolerance
+                     "mask": _cmp(mask[:, :, ::2, ::2], torch.tensor(g["mask_sub"]), 2e-3, "tsf_mask")}
+        assert out[mode]["img"]["mean_abs"] <= 1e-4 and out[mode]["mask"]["mean_abs"] <= 1e-4, out
+        assert abs(img.double().mean().item() - float(g["img_mean"])) <= 1e-5, out
+    return out
+
+
 def check_lwb_variant_generators():
     """AddLWB / AvgLWB / SoftGateAddLWB / SoftGateAvgLWB (reference networks/__init__.py:22-36) on the GPU - lwg_lwb_fuse_f32 +
     the gate convs with the sigmoid epilogue - against outputs of the REFERENCE's own generators
@@ -802,7 +832,7 @@ def check_winograd_mode():
     out = {}
     cases = (("relu", (2, 24, 40, 64, 0, 64, 64, 0, ops.EPI_NONE)),
              ("residual_slice_ragged", (1, 17, 31, 32, 0, 128, 256, 64, ops.EPI_RESIDUAL)),
-             ("odd_1px_rows", (3, 1, 33, 48, 0, 64, 64, 0, ops.EPI_NONE)),
+             ("odd_1px_rows", (3, 1, 33, 96, 0, 64, 64, 0, ops.EPI_NONE)),
              ("two_inputs_ragged", (2, 21, 35, 64, 32, 64, 64, 0, ops.EPI_NONE)),
              ("skip_1024_shape", (1, 96, 80, 128, 64, 128, 128, 0, ops.EPI_NONE)),
              ("res_block_wide", (2, 40, 24, 256, 0, 256, 256, 0, ops.EPI_RESIDUAL)))
@@ -1749,12 +1779,37 @@ def _generator_training_grads(S, nf, nres, bgf, real_flows=False, ref64=False):
     m["frac_params_within_2e-3"] = float(np.mean([r <= 2e-3 for r in rel_all]))
     if not ref64:
         assert worst <= 2e-3, m
-    else:
-        # Measured on the MI355X box against this fp64 reference (tools/diag_train512.py, round 4): torch's OWN fp32 autograd deviates by
-        # up to 2.4e-2 on single elements of the small-gradient layers here - at 512 x 512 a 1e-6 forward difference flips ReLU / L1-sign
-        # kinks on a few of the 10^5..10^6 positions a weight gradient sums over, and one flipped term is ~1 / sqrt(n) of such a sum.  The
-        # bounds are therefore: element-wise 6e-2 of the parameter's scale, 1.5e-2 in the L2 sense (a wiring error moves that to O(1)).
-        assert worst <= 6e-2 and l2_worst[0] <= 1.5e-2 and m["frac_params_within_2e-3"] >= 0.5, m
+        return m
+    # At 512 x 512 a 1e-6 forward difference flips ReLU / L1-sign kinks on a few of the 10^5..10^6 positions a weight gradient sums over, and
+    # one flipped term is ~1 / sqrt(n) of such a sum: ANY fp32 evaluation deviates from the fp64 gradient by more than 2e-3 on some small-gradient
+    # layers (torch's own fp32 autograd: up to 2.4e-2, tools/diag_train512.py).  So the yardstick is measured, not assumed: the SAME oracle
+    # graph is differentiated again in fp32 by torch on this box, and every parameter's HIP error (against fp64) must stay within 3x the
+    # error torch-fp32 makes on that parameter (floor: 2e-3 of the parameter's scale - the bound the small case meets outright), element-wise
+    # and in the L2 sense; plus the global L2 bound (a wiring error moves that to O(1)).
+    t0 = time.time()
+    sd32 = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in sdn.items()}
+    outs32 = orc.gen_forward_train(sd32, bg_in, src_in, tsf_in, Tst, n_down=len(nf), n_res=nres, n_bg=len(bgf))
+    loss_of(outs32, "cpu").backward()
+    m["torch_fp32_autograd_s"] = time.time() - t0
+    over, ratio_worst, t32_worst = [], (0.0, None), 0.0
+    for k, p_ in G.named_parameters():
+        ref = sd[k].grad
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        l2s = max(ref.norm().item(), 1e-3 * gmax * math.sqrt(ref.numel()))
+        e_hip = (p_.grad.cpu().double() - ref).abs().max().item() / scale
+        e_t32 = (sd32[k].grad.double() - ref).abs().max().item() / scale
+        l_hip = (p_.grad.cpu().double() - ref).norm().item() / l2s
+        l_t32 = (sd32[k].grad.double() - ref).norm().item() / l2s
+        t32_worst = max(t32_worst, e_t32)
+        r = max(e_hip / max(e_t32, 2e-3 / 3), l_hip / max(l_t32, 2e-3 / 3))
+        if r > ratio_worst[0]:
+            ratio_worst = (r, k)
+        if e_hip > 3 * max(e_t32, 2e-3 / 3) or l_hip > 3 * max(l_t32, 2e-3 / 3):
+            over.append((k, round(e_hip, 5), round(e_t32, 5), round(l_hip, 5), round(l_t32, 5)))
+    m["torch_fp32_worst_rel_grad_err"], m["worst_hip_over_torch_fp32_ratio"], m["worst_ratio_param"] = t32_worst, ratio_worst[0], ratio_worst[1]
+    m["params_over_3x_torch_fp32"] = over[:12]
+    assert not over, m
+    assert l2_worst[0] <= 1.5e-2, m
     return m
 
 
@@ -2413,7 +2468,7 @@ def check_attention_backward():
 
 
 ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
-       check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden,
+       check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden, check_generator_golden_256,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,
        check_split_vs_oracle, check_source_setup_128,

@@ -120,6 +120,25 @@ def test_generator_full(golden):
     _gen_case(golden, "full", [64, 128, 256], 6, [64, 128, 128, 256])
 
 
+def test_generator_full_at_256():
+    """The oracle against the reference's own generator at S = 256, full width (tests/golden/make_golden_tsf256.py): the other generator goldens
+    are S = 64 / 128 - this one pins the size-dependent parts (flow resizing down to 32 x 32, out-of-range and -2 flows, four times the area)."""
+    from ipercore_amd.networks import generator_param_shapes
+    from tests.golden.make_golden_tsf256 import synthetic_flow
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_tsf256_v1.npz"))
+    nf, nres, bgf = [64, 128, 256], 6, [64, 128, 128, 256]
+    sd = {k: torch.tensor(v) for k, v in synthetic.fill_state_dict(generator_param_shapes(nf, nres, bgf), seed=7).items()}
+    src_inputs = torch.tensor(synthetic.uniform_image((1, 2, 6, 256, 256), 8, "src_inputs_256"))
+    tsf_inputs = torch.tensor(synthetic.uniform_image((1, 6, 256, 256), 9, "tsf_inputs_256"))
+    with torch.no_grad():
+        enc, res = orc.gen_forward_src(sd, src_inputs, n_down=3, n_res=nres)
+        img, mask = orc.gen_forward_tsf(sd, tsf_inputs, enc, res, torch.tensor(synthetic_flow()), n_down=3, n_res=nres)
+    assert np.abs(enc[-1].numpy()[:, ::16, ::2, ::2] - g["enc2_sub"]).max() <= 1e-5
+    assert np.abs(res[-1].numpy()[:, ::16, ::2, ::2] - g["res_last_sub"]).max() <= 1e-4
+    assert np.abs(img.numpy()[:, :, ::2, ::2] - g["img_sub"]).max() <= 1e-4 and np.abs(mask.numpy()[:, :, ::2, ::2] - g["mask_sub"]).max() <= 1e-4
+    assert abs(img.double().mean().item() - float(g["img_mean"])) <= 1e-6 and abs(mask.double().mean().item() - float(g["mask_mean"])) <= 1e-6
+
+
 LWB_VARIANTS = (("AddLWB", "add", "plain"), ("AvgLWB", "avg", "plain"), ("SoftGateAddLWB", "sg_add", "softgate"),
                 ("SoftGateAvgLWB", "sg_avg", "softgate"))
 

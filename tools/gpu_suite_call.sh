@@ -1,6 +1,6 @@
 #!/bin/bash
+# usage: gpu_suite_call.sh [-k EXPR]   the -m gpu suite (optionally a subset), logs under gpurun_out/suite
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/suite; mkdir -p $O
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=8 2>&1 | tail -40 > $O/pytest_gpu.log; echo "pytest exit=${PIPESTATUS[0]}"; tail -15 $O/pytest_gpu.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench exit=$?"; head -c 2500 $O/bench.json; echo; tail -3 $O/bench.err
+timeout 2400 python -m pytest tests -q -m gpu --durations=8 "$@" 2>&1 | tail -60 > $O/pytest_gpu.log; echo "pytest exit=${PIPESTATUS[0]}"; tail -25 $O/pytest_gpu.log
