@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 7: lwg_conv_slice_count, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 7: lwg_conv_slice_count, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
 #define LWG_ABI_VERSION 7
 int lwg_abi_version(void);
@@ -208,6 +208,14 @@ int lwg_pack_panels_f32(const LwgPackDesc* descs_dev, int ndesc, int total_block
  * (B,H,W,C), each gradient going to the first maximum of its window in scan order.  H, W even; C % 4 == 0. */
 int lwg_maxpool2_fwd_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, lwg_stream_t stream);
 int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, lwg_stream_t stream);
+/* FaceLoss head crops (criterions/faceloss.py:316-341,384-406: imgs[i, :, y0:y1, x0:x1] resized to (OH, OW) = (112, 96) with F.interpolate(bilinear,
+ * align_corners = True)) with the boxes read ON THE DEVICE: x (N,C,H,W) NCHW fp32; box (N,4) int64 = (min_x, max_x, min_y, max_y) as
+ * tools/trainers/base.py:205-246 computes them; y (N,C,OH,OW).  The reference reads the boxes on the host and drops samples whose box is empty; here
+ * every sample gets a crop - zeros, and valid[i] = 0 (valid: (N) fp32 or NULL), for an empty or out-of-image box - so the personalization step keeps
+ * static shapes and is captured as a hipGraph.  _bwd: dx (N,C,H,W), ZERO-FILLED by the caller, += the transposed interpolation of dy (atomic adds). */
+int lwg_crop_resize_bilinear_f32(const float* x, const long long* box, float* y, float* valid, int N, int C, int H, int W, int OH, int OW,
+                                 lwg_stream_t stream);
+int lwg_crop_resize_bilinear_bwd_f32(const float* dy, const long long* box, float* dx, int N, int C, int H, int W, int OH, int OW, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.

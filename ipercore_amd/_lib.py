@@ -75,6 +75,8 @@ _SIGS = {
     "lwg_unpack_wgrad_f32": (c_i, [c_f] + [c_i] * 5 + [ctypes.POINTER(ctypes.c_int)] + [c_i] * 5 + [c_f, c_f]),
     "lwg_maxpool2_fwd_nhwc_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_maxpool2_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_crop_resize_bilinear_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_crop_resize_bilinear_bwd_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "lwg_instnorm_stats_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
     "lwg_instnorm_apply_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_lwb_attention_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),

@@ -492,3 +492,81 @@ extern "C" int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float*
                        stream, x, dy, dx, B, H / 2, W / 2, C / 4);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Head crop + bilinear resize with the box read ON THE DEVICE (FaceLoss, criterions/faceloss.py:316-341,384-406: imgs[i, :, y0:y1, x0:x1] ->
+// F.interpolate(size = (112, 96), bilinear, align_corners = True); the reference reads the box on the host and drops samples whose box is
+// empty).  Here the box (min_x, max_x, min_y, max_y as int64, what cal_head_bbox_by_kps leaves on the device) never leaves the GPU: every
+// sample gets a crop - zeros and valid[i] = 0 for an empty box - so the step has static shapes and can be captured in a hipGraph.
+// Interpolation exactly as torch's upsample_bilinear2d (align_corners): scale = (in - 1) / (out - 1), src = scale * dst, i0 = (int)src,
+// i1 = i0 + (i0 < in - 1), l1 = src - i0, value = l0y (l0x v00 + l1x v01) + l1y (l0x v10 + l1x v11).
+struct LwgCropGeom { int x0, y0, cw, ch; float sx, sy; };
+
+__device__ __forceinline__ bool lwg_crop_geom(const long long* __restrict__ box, int i, int H, int W, int OH, int OW, LwgCropGeom& g) {
+    const long long bx0 = box[4 * i], bx1 = box[4 * i + 1], by0 = box[4 * i + 2], by1 = box[4 * i + 3];
+    if (bx0 == bx1 || by0 == by1 || bx0 < 0 || by0 < 0 || bx1 > W || by1 > H || bx1 < bx0 || by1 < by0) return false;
+    g.x0 = (int)bx0; g.y0 = (int)by0; g.cw = (int)(bx1 - bx0); g.ch = (int)(by1 - by0);
+    g.sx = OW > 1 ? (float)(g.cw - 1) / (float)(OW - 1) : 0.f;
+    g.sy = OH > 1 ? (float)(g.ch - 1) / (float)(OH - 1) : 0.f;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void lwg_crop_resize_kernel(const float* __restrict__ x, const long long* __restrict__ box, float* __restrict__ y,
+                                                              float* __restrict__ valid, int N, int C, int H, int W, int OH, int OW) {
+    const int i = blockIdx.y, c = blockIdx.z;
+    LwgCropGeom g;
+    const bool ok = lwg_crop_geom(box, i, H, W, OH, OW, g);
+    if (valid && c == 0 && blockIdx.x == 0 && threadIdx.x == 0) valid[i] = ok ? 1.f : 0.f;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= OH * OW) return;
+    float v = 0.f;
+    if (ok) {
+        const int oy = p / OW, ox = p - oy * OW;
+        const float fy = g.sy * (float)oy, fx = g.sx * (float)ox;
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const int iy1 = iy0 + (iy0 < g.ch - 1), ix1 = ix0 + (ix0 < g.cw - 1);
+        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* s = x + ((size_t)i * C + c) * H * W;
+        const float v00 = s[(size_t)(g.y0 + iy0) * W + g.x0 + ix0], v01 = s[(size_t)(g.y0 + iy0) * W + g.x0 + ix1];
+        const float v10 = s[(size_t)(g.y0 + iy1) * W + g.x0 + ix0], v11 = s[(size_t)(g.y0 + iy1) * W + g.x0 + ix1];
+        v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    }
+    y[((size_t)i * C + c) * OH * OW + p] = v;
+}
+
+// dx (N,C,H,W), zero-filled by the caller, += the transposed interpolation of dy (N,C,OH,OW) (atomic adds: up to four output pixels share a source)
+__global__ __launch_bounds__(256) void lwg_crop_resize_bwd_kernel(const float* __restrict__ dy, const long long* __restrict__ box, float* __restrict__ dx,
+                                                                  int N, int C, int H, int W, int OH, int OW) {
+    const int i = blockIdx.y, c = blockIdx.z;
+    LwgCropGeom g;
+    if (!lwg_crop_geom(box, i, H, W, OH, OW, g)) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= OH * OW) return;
+    const int oy = p / OW, ox = p - oy * OW;
+    const float fy = g.sy * (float)oy, fx = g.sx * (float)ox;
+    const int iy0 = (int)fy, ix0 = (int)fx;
+    const int iy1 = iy0 + (iy0 < g.ch - 1), ix1 = ix0 + (ix0 < g.cw - 1);
+    const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float d = dy[((size_t)i * C + c) * OH * OW + p];
+    float* s = dx + ((size_t)i * C + c) * H * W;
+    atomicAdd(s + (size_t)(g.y0 + iy0) * W + g.x0 + ix0, ly0 * lx0 * d);
+    atomicAdd(s + (size_t)(g.y0 + iy0) * W + g.x0 + ix1, ly0 * lx1 * d);
+    atomicAdd(s + (size_t)(g.y0 + iy1) * W + g.x0 + ix0, ly1 * lx0 * d);
+    atomicAdd(s + (size_t)(g.y0 + iy1) * W + g.x0 + ix1, ly1 * lx1 * d);
+}
+
+extern "C" int lwg_crop_resize_bilinear_f32(const float* x, const long long* box, float* y, float* valid, int N, int C, int H, int W, int OH, int OW,
+                                            lwg_stream_t stream_) {
+    if (!x || !box || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || C > 65535 || N > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_crop_resize_kernel, dim3((unsigned)((OH * OW + 255) / 256), (unsigned)N, (unsigned)C), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), x, box, y, valid, N, C, H, W, OH, OW);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_crop_resize_bilinear_bwd_f32(const float* dy, const long long* box, float* dx, int N, int C, int H, int W, int OH, int OW,
+                                                lwg_stream_t stream_) {
+    if (!dy || !box || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || C > 65535 || N > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_crop_resize_bwd_kernel, dim3((unsigned)((OH * OW + 255) / 256), (unsigned)N, (unsigned)C), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), dy, box, dx, N, C, H, W, OH, OW);
+    return (int)hipGetLastError();
+}

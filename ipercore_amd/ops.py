@@ -914,6 +914,30 @@ def act_bwd(dy, y, act):
     return out
 
 
+def crop_resize(x, box, out_hw, want_valid=True):
+    """(N,C,H,W) fp32 NCHW, box (N,4) int64 device tensor (min_x, max_x, min_y, max_y) -> (crops (N,C,OH,OW), valid (N) fp32): the head crops of
+    FaceLoss (faceloss.py:384-406) resized with bilinear / align_corners = True, the boxes never read by the host (lwg_crop_resize_bilinear_f32)."""
+    N, C, H, W = x.shape
+    OH, OW = out_hw
+    x = x.contiguous()
+    box = box.contiguous()
+    y = x.new_empty(N, C, OH, OW)
+    valid = x.new_empty(N) if want_valid else None
+    _lib.check(_lib.lib().lwg_crop_resize_bilinear_f32(_ptr(x), _ptr(box, torch.int64), _ptr(y), _ptr(valid), N, C, H, W, OH, OW, _stream()),
+               "lwg_crop_resize_bilinear_f32")
+    return y, valid
+
+
+def crop_resize_bwd(dy, box, in_hw):
+    """Gradient of ``crop_resize`` with respect to the images: (N,C,OH,OW) -> (N,C,H,W)."""
+    N, C, OH, OW = dy.shape
+    H, W = in_hw
+    dx = dy.new_zeros(N, C, H, W)
+    _lib.check(_lib.lib().lwg_crop_resize_bilinear_bwd_f32(_ptr(dy.contiguous()), _ptr(box.contiguous(), torch.int64), _ptr(dx), N, C, H, W, OH, OW,
+                                                           _stream()), "lwg_crop_resize_bilinear_bwd_f32")
+    return dx
+
+
 def _nsplit(hw):
     return max(1, min(64, hw // 64))
 

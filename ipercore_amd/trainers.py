@@ -536,9 +536,29 @@ class Sphere20aFeatures(nn.Module):
         return outs
 
 
+class _CropResizeFn(torch.autograd.Function):
+    """Head crops with the boxes read on the device (ops.crop_resize / lwg_crop_resize_bilinear_f32): (crops, valid)."""
+
+    @staticmethod
+    def forward(ctx, imgs, box, oh, ow):
+        y, valid = ops.crop_resize(imgs, box, (oh, ow))
+        ctx.save_for_backward(box)
+        ctx.hw = (imgs.shape[2], imgs.shape[3])
+        ctx.mark_non_differentiable(valid)
+        return y, valid
+
+    @staticmethod
+    def backward(ctx, dy, _dvalid):
+        (box,) = ctx.saved_tensors
+        return ops.crop_resize_bwd(dy.contiguous(), box, ctx.hw), None, None, None
+
+
 class FaceLoss(nn.Module):
     """criterions/faceloss.py:288-406 (Sphere20a branch): heads cropped by bounding box, resized to 112x96 (bilinear,
-    align_corners=True), weighted L1 between the five Sphere20a features; the second argument is the target (detached)."""
+    align_corners=True), weighted L1 between the five Sphere20a features; the second argument is the target (detached).
+    The reference reads the boxes on the host (``bboxs[i]`` indexing, :384-400) and drops samples whose box is empty; here the boxes stay on
+    the device (``crop_head_bbox`` -> crops + a validity flag per sample, zeros for an empty box) and the L1 means run over the valid samples
+    only - the same value, with static shapes: the step with the reference's default loss set is captured as a hipGraph like the others."""
     WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
     HEIGHT, WIDTH = 112, 96
 
@@ -547,22 +567,27 @@ class FaceLoss(nn.Module):
         self.net = Sphere20aFeatures(pretrained_path, allow_seeded=allow_seeded)
 
     def crop_head_bbox(self, imgs, bboxs):
-        """:384-406; bboxs (N,4) = [min_x, max_x, min_y, max_y] (a host read of N*4 integers per step, as in the reference)."""
-        heads = []
-        for i, (x0, x1, y0, y1) in enumerate(bboxs.tolist()):
-            if x0 != x1 and y0 != y1:
-                heads.append(F.interpolate(imgs[i:i + 1, :, y0:y1, x0:x1], size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True))
-        return torch.cat(heads, dim=0) if heads else None
+        """:384-406; bboxs (N,4) = [min_x, max_x, min_y, max_y] int64 on the device -> (crops (N,3,112,96), valid (N))."""
+        return _CropResizeFn.apply(imgs.contiguous().float(), bboxs.to(device=imgs.device, dtype=torch.int64), self.HEIGHT, self.WIDTH)
 
     def forward(self, imgs1, imgs2, bbox1=None, bbox2=None):
-        h1 = self.crop_head_bbox(imgs1, bbox1) if bbox1 is not None else F.interpolate(imgs1, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
-        h2 = self.crop_head_bbox(imgs2, bbox2) if bbox2 is not None else F.interpolate(imgs2, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
-        if h1 is None or h2 is None:
-            return imgs1.new_zeros(())
+        valid = None
+        if bbox1 is not None:
+            h1, valid = self.crop_head_bbox(imgs1, bbox1)
+        else:
+            h1 = F.interpolate(imgs1, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
+        if bbox2 is not None:
+            h2, v2 = self.crop_head_bbox(imgs2, bbox2)
+            valid = v2 if valid is None else valid * v2
+        else:
+            h2 = F.interpolate(imgs2, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
         with torch.no_grad():
             f2 = self.net(h2)
         f1 = self.net(h1)
-        return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, f1, f2))
+        if valid is None:
+            return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, f1, f2))
+        nv = valid.sum().clamp_min(1.0)                      # no valid head at all: every term is zero (the reference returns 0)
+        return sum(w * (((a - b).abs().flatten(1).mean(dim=1) * valid).sum() / nv) for w, a, b in zip(self.WEIGHTS, f1, f2))
 
 
 class TrainOpts(object):
@@ -952,11 +977,11 @@ class LWGTrainer(object):
 
     # ---- hipGraph replay of the step -----------------------------------------------------------------------------------------
     def _graphable(self):
-        """The step is captured when its shapes are static and nothing in it reads the device from the host: no FaceLoss / crop
-        discriminators (their boxes are host-read integers, as in the reference), CUDA tensors, use_graph on."""
+        """The step is captured when its shapes are static and nothing in it reads the device from the host: no crop discriminators (their
+        boxes are host-read integers, as in the reference; FaceLoss crops on the device since round 5), CUDA tensors, use_graph on."""
         if not getattr(self.opts, "use_graph", False) or getattr(self, "_graph_failed", False):
             return False
-        if not torch.cuda.is_available() or not next(self.G.parameters()).is_cuda or self.crt_face is not None:
+        if not torch.cuda.is_available() or not next(self.G.parameters()).is_cuda:
             return False
         if self.D is not None and getattr(self.D, "CROPS", ()):
             return False
@@ -989,7 +1014,7 @@ class LWGTrainer(object):
             # [A: G fwd / bwd] -> {G's all-reduce on RCCL's stream || [D: D fwd / bwd on the second stream]} -> {Adam(G) || D's all-reduce}
             # -> Adam(D): _run_dp_schedule
             self._run_dp_schedule({"A": gr["A"].replay, "D": None if gr["D"] is None else gr["D"].replay, "adamG": gr["B"].replay,
-                                   "adamD": gr["C"].replay})
+                                   "adamD": None if gr["C"] is None else gr["C"].replay})
         else:
             gr["A"].replay()
             gr["B"].replay()
@@ -1041,7 +1066,8 @@ class LWGTrainer(object):
         self.optimizer_G._armed = False                     # no hook-driven collectives inside a capture
         if self.optimizer_D is not None:
             self.optimizer_D._armed = False
-        gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gC = torch.cuda.CUDAGraph() if self.D is not None else None      # no discriminator: no third segment (an empty capture is not a graph)
         gD = None
         multi = self._multi()
         # The discriminator's own step needs this iteration's fake images (detached) and D's weights - not G's update.  Same values as
@@ -1080,8 +1106,8 @@ class LWGTrainer(object):
                 loss_D = self._seg_D(fake_tsf_imgs)
                 loss_D.backward()
                 self.optimizer_D._gather()
-        with torch.cuda.graph(gC, pool=pool):
-            if self.D is not None:
+        if gC is not None:
+            with torch.cuda.graph(gC, pool=pool):
                 self.optimizer_D.step()
         for o, sn in zip(opts_, snaps):                     # capturing step() advanced the host mirrors only; nothing ran on the device
             o.t = sn[4]

@@ -475,12 +475,38 @@ def grid_sample(x, grid):
     return torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
+def _crop_ref(x, box, out_hw):
+    """lwg_crop_resize_bilinear_f32's contract in the reference's own formulation (faceloss.py:384-406): per-sample slice + F.interpolate."""
+    N = x.shape[0]
+    ys, valid = [], []
+    for i, (x0, x1, y0, y1) in enumerate(box.tolist()):
+        ok = x0 != x1 and y0 != y1 and 0 <= x0 < x1 <= x.shape[3] and 0 <= y0 < y1 <= x.shape[2]
+        valid.append(1.0 if ok else 0.0)
+        ys.append(F.interpolate(x[i:i + 1, :, y0:y1, x0:x1], size=tuple(out_hw), mode="bilinear", align_corners=True) if ok
+                  else x.new_zeros(1, x.shape[1], *out_hw))
+    return torch.cat(ys, dim=0), x.new_tensor(valid)
+
+
+def crop_resize(x, box, out_hw, want_valid=True):
+    with torch.no_grad():
+        y, valid = _crop_ref(x.detach(), box, out_hw)
+    return y, (valid if want_valid else None)
+
+
+def crop_resize_bwd(dy, box, in_hw):
+    x = torch.zeros(dy.shape[0], dy.shape[1], *in_hw, requires_grad=True)
+    with torch.enable_grad():
+        y, _ = _crop_ref(x, box, dy.shape[2:])
+        (y * dy).sum().backward()
+    return x.grad.detach()
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize", "attn_records", "instnorm_finalize_ws"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize", "attn_records", "instnorm_finalize_ws", "crop_resize", "crop_resize_bwd"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -1515,12 +1515,33 @@ def check_face_loss():
     gerr = (xd.grad.cpu() - xr.grad).abs() / xr.grad.abs().max().item()
     out["grad_rel_err_median"], out["grad_outlier_frac"] = gerr.median().item(), (gerr > 5e-4).float().mean().item()
     assert out["grad_outlier_frac"] <= 2e-3, out
-    # head crop + a degenerate box (skipped, as the reference does)
-    imgs = _rand((2, 3, 128, 128), 995, 0.5).to(DEV)
-    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10]])
-    heads = crt.crop_head_bbox(imgs, box)
-    want = F.interpolate(imgs[0:1, :, 10:90, 20:84], size=(112, 96), mode="bilinear", align_corners=True)
-    assert heads.shape == (1, 3, 112, 96) and torch.equal(heads, want)
+    # head crops with the boxes read on the device (lwg_crop_resize_bilinear_f32) against the reference's formulation (faceloss.py:384-406:
+    # per-sample slice + F.interpolate(bilinear, align_corners = True)): values, validity of a degenerate box (the reference drops that
+    # sample), the image gradient, and the loss of a batch with a dropped sample = the reference's loss over the kept ones
+    imgs = _rand((3, 3, 128, 128), 995, 0.5).to(DEV)
+    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10], [0, 128, 3, 128]], device=DEV)
+    xi = imgs.clone().requires_grad_(True)
+    heads, valid = crt.crop_head_bbox(xi, box)
+    want, wv = emu_ops._crop_ref(imgs, box.cpu(), (112, 96))
+    assert heads.shape == (3, 3, 112, 96) and valid.tolist() == [1.0, 0.0, 1.0] == wv.tolist()
+    out["crop_max_abs"] = (heads.detach() - want).abs().max().item()
+    assert out["crop_max_abs"] <= 2e-6 and float(heads[1].abs().max()) == 0.0, out
+    dyc = _rand((3, 3, 112, 96), 996).to(DEV)
+    (heads * dyc).sum().backward()
+    xr2 = imgs.clone().requires_grad_(True)
+    (emu_ops._crop_ref(xr2, box.cpu(), (112, 96))[0] * dyc).sum().backward()
+    torch.cuda.synchronize()
+    out["crop_grad_max_abs"] = (xi.grad - xr2.grad).abs().max().item()
+    assert out["crop_grad_max_abs"] <= 2e-5 * max(1.0, xr2.grad.abs().max().item()), out
+    a3, b3 = _rand((3, 3, 128, 128), 997, 0.5).to(DEV), _rand((3, 3, 128, 128), 998, 0.5).to(DEV)
+    with torch.no_grad():
+        l_dev = crt(a3, b3, bbox1=box, bbox2=box)
+        keep = [0, 2]
+        ha = torch.cat([F.interpolate(a3[i:i + 1, :, box[i, 2]:box[i, 3], box[i, 0]:box[i, 1]], size=(112, 96), mode="bilinear", align_corners=True) for i in keep])
+        hb = torch.cat([F.interpolate(b3[i:i + 1, :, box[i, 2]:box[i, 3], box[i, 0]:box[i, 1]], size=(112, 96), mode="bilinear", align_corners=True) for i in keep])
+        l_ref = crt(ha, hb)
+    out["loss_with_dropped_sample"] = [l_dev.item(), l_ref.item()]
+    assert abs(l_dev.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item()), out
     # trainer step with both perceptual losses
     S, nf, nres, bgf, ns = 64, [64, 64, 128], 2, [64, 64, 128], 2
     G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=pu.gen_cfg(nf, nres, bgf), temporal=False).to(DEV).train()
@@ -1537,6 +1558,9 @@ def check_face_loss():
     torch.cuda.synchronize()
     assert np.isfinite(float(lg)) and float(tr.losses["g_face"].detach()) > 0
     out["trainer_g_face"] = float(tr.losses["g_face"].detach())
+    # the reference's DEFAULT loss set is a captured step now (the boxes never reach the host)
+    out["step_mode_with_vgg_and_face"] = tr.step_mode
+    assert "graph" in tr.step_mode and "failed" not in tr.step_mode, tr.step_mode
     return out
 
 

@@ -436,6 +436,24 @@ def test_loss_networks_host_logic_cpu(monkeypatch):
         got = f.permute(0, 3, 1, 2)[:, ::8] if f.dim() == 4 else f
         assert (got - torch.tensor(gf[f"fx{i}"])).abs().max().item() <= 2e-4, i
     assert abs(loss.item() - float(gf["loss"])) <= 2e-4 * abs(float(gf["loss"]))
+    # head boxes stay device tensors (faceloss.py:384-406 reads them on the host and drops empty ones): crops for every sample + a validity flag,
+    # the L1 means over the valid samples only = the reference's value on the kept samples; the gradient reaches the images through the crop
+    imgs_a = torch.tensor(synthetic.uniform_image((3, 3, 128, 128), 72, "face_a")).requires_grad_(True)
+    imgs_b = torch.tensor(synthetic.uniform_image((3, 3, 128, 128), 73, "face_b"))
+    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10], [0, 128, 3, 128]])
+
+    def run_boxes():
+        l_ = crt(imgs_a, imgs_b, bbox1=box, bbox2=box)
+        l_.backward()
+        with torch.no_grad():
+            keep = [0, 2]
+            cut = lambda t: torch.cat([F.interpolate(t[i:i + 1, :, box[i, 2]:box[i, 3], box[i, 0]:box[i, 1]], size=(112, 96), mode="bilinear",   # noqa: E731
+                                                     align_corners=True) for i in keep])
+            return l_.detach(), crt(cut(imgs_a.detach()), cut(imgs_b))
+    l_dev, l_ref = _as_device(run_boxes)
+    assert abs(l_dev.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item())
+    assert imgs_a.grad is not None and float(imgs_a.grad[1].abs().max()) == 0.0 and float(imgs_a.grad[0].abs().max()) > 0      # dropped sample: no gradient
+    assert float(imgs_a.grad[0, :, :10].abs().max()) == 0.0                                                                     # outside the box: none either
     # VGG19 perceptual loss at a small size
     vcrt = VGGLoss(ckpt_path=None, allow_seeded=True)
     sd = {k: v.detach() for k, v in vcrt.vgg.state_dict().items()}
