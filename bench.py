@@ -664,6 +664,11 @@ def _extra(fn, *a, **kw):
 def main(argv=None):
     import faulthandler
     faulthandler.enable()                    # a crash inside a native library leaves a Python traceback on stderr
+    # ONE JSON line on stdout, whatever the libraries print (RCCL writes its version banner to stdout when a communicator is created): file
+    # descriptor 1 points at stderr for the whole run, the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -1007,7 +1012,8 @@ def main(argv=None):
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = _extra(cpu_baseline, small, args.cpu_frames)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
