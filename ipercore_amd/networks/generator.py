@@ -247,6 +247,14 @@ class AttentionLWBGenerator(nn.Module):
             if t is not None and not t.is_cuda:
                 raise RuntimeError("ipercore_amd generator runs on the MI355X only: got a CPU tensor (no fallback)")
 
+    @staticmethod
+    def _check_square(t):
+        """The attention blocks take flows resized to their (square) feature size; image_size is one number throughout the reference
+        (deploy.toml image_size, options_base.py): a non-square input is refused HERE, before any network has run."""
+        if t.shape[-1] != t.shape[-2]:
+            raise ValueError(f"square images only (got {t.shape[-2]} x {t.shape[-1]}): the reference's image_size is one number and the "
+                             "attention blocks' flow fields are resized to square feature maps")
+
     # ------------------------------------------------------------------ NHWC engine
     @torch.no_grad()
     def _encode_sources_impl(self, src8, batched=False, ns=None):
@@ -413,6 +421,7 @@ class AttentionLWBGenerator(nn.Module):
         """(bs, ns, 6, h, w) -> (enc_outs, res_outs[, img, mask]) as NCHW lists (:450-478).  The returned lists carry
         the NHWC/KV cache so a following ``forward_tsf`` does not recompute it."""
         self._check(src_inputs)
+        self._check_square(src_inputs)
         bs, ns, c, h, w = src_inputs.shape
         src8 = ops.nchw_to_nhwc(src_inputs.reshape(bs * ns, c, h, w).contiguous().float(), c_pad=8)
         feats = self.encode_sources(src8, batched=bs > 1, ns=ns)
@@ -441,6 +450,7 @@ class AttentionLWBGenerator(nn.Module):
         temp_enc_outs / temp_res_outs ((bs*nt,c,h,w) lists) + Ttt (bs,nt,h,w,2): the temporal attention inputs (:232-243) -
         their K / V join the sources' along the attention axis."""
         self._check(tsf_inputs, Tst)
+        self._check_square(tsf_inputs)
         bs = tsf_inputs.shape[0]
         feats = self._features_from_api(src_enc_outs, src_res_outs, bs)
         T = Tst.contiguous().float()

@@ -180,6 +180,9 @@ class MultiScaleDiscriminator(nn.Module):
 
     def __init__(self, global_nc, input_nc, ndf=32, n_layers=3, max_nf_mult=8, norm_type="batch", use_sigmoid=False):
         super().__init__()
+        if norm_type != "instance":
+            raise NotImplementedError(f"MultiScaleDiscriminator(norm_type={norm_type!r}): only norm_type='instance' is built (the reference's default, "
+                                      "'batch', is reached by none of its runners or configs): pass norm_type='instance'")
         self.n_scales = 2
         self.scale_models = nn.ModuleList([PatchDiscriminator(input_nc, ndf, n_layers, max_nf_mult, norm_type, use_sigmoid)
                                            for _ in range(self.n_scales)])

@@ -100,6 +100,21 @@ def test_lwb_variant_generators_through_emulated_abi(monkeypatch, golden, name):
     assert torch.allclose(img, img2, atol=1e-6)
 
 
+def test_non_square_inputs_are_refused_before_any_network_runs(monkeypatch):
+    """image_size is one number in the reference; the attention blocks take flows resized to square feature maps: a non-square input raises at
+    the API entry (forward_src / forward_tsf), not at the first attention site after the encoder has run."""
+    emu_ops.install(monkeypatch)
+    from ipercore_amd.networks import NetworksFactory
+    G = NetworksFactory.get_by_name("AttLWB-SPADE", cfg=synthetic.gen_cfg([64, 64, 128], 2, [64, 64, 128]), temporal=False).eval()
+    calls = []
+    monkeypatch.setattr(emu_ops.real_ops, "conv2d", lambda *a, **k: calls.append(1))
+    with pytest.raises(ValueError, match="square images only"):
+        G.forward_src(torch.zeros(1, 2, 6, 64, 96))
+    with pytest.raises(ValueError, match="square images only"):
+        G.forward_tsf(torch.zeros(1, 6, 64, 96), None, None, torch.zeros(1, 2, 64, 96, 2))
+    assert not calls
+
+
 def test_cpu_tensors_fail_loudly():
     G, _ = build([64, 64, 128], 2, [64, 64, 128])
     with pytest.raises(RuntimeError):
@@ -162,6 +177,8 @@ def test_multi_scale_discriminator_host_logic(monkeypatch):
     assert len(outs) == 3
     for i, o in enumerate(outs):
         assert np.abs(o.numpy() - gc[f"multi_scale/out{i}"]).max() <= 2e-4, i
+    with pytest.raises(NotImplementedError, match="norm_type='instance'"):       # the reference's default argument: a targeted error, not a nested one
+        NetworksFactory.get_by_name("multi_scale", 6, 6)
     assert abs(float(avg) - float(np.mean([gc[f"multi_scale/out{i}"].mean() for i in range(3)]))) <= 1e-4
     with pytest.raises(NotImplementedError):
         NetworksFactory.get_by_name("multi_scale", 6, 6)               # the reference default norm_type="batch" is not built
