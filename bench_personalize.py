@@ -38,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
-            panel_cache=None, branch=None, overlap_d=None, _keep=None, dp_schedule=None):
+            panel_cache=None, branch=None, overlap_d=None, _keep=None, dp_schedule=None, _host_probe=True):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
     from ipercore_amd import ops, synthetic as syn
@@ -133,7 +133,7 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     dt = time.perf_counter() - t0
     # host share: one step from an idle queue - time until the last launch is enqueued vs until the GPU is done
     host_ms, total_ms = [], []
-    for _ in range(3):
+    for _ in range(3 if _host_probe else 0):
         sync()
         h0 = time.perf_counter()
         tr.optimize_parameters()
@@ -171,8 +171,36 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
                               ("no collective at N = 1; at N > 1 the captured step runs G's gradient all-reduce (4 ranges, RCCL's stream) "
                                "behind D's forward / backward graph and D's behind Adam(G)" if world == 1 else
                                f"hook-driven: {getattr(tr.optimizer_G, 'overlapped_ranges', None)} ranges of G issued during backward")),
-        "single_step_host_enqueue_ms": round(min(host_ms), 2), "single_step_total_ms": round(min(total_ms), 2),
+        "single_step_host_enqueue_ms": round(min(host_ms), 2) if host_ms else None, "single_step_total_ms": round(min(total_ms), 2) if total_ms else None,
         "loss_G": round(lg.item(), 4), "loss_D": round(ld.item(), 4)}
+
+
+def graph_vs_eager_check(dev, size, use_vgg, use_face, precision, steps=3):
+    """Self-check of the benched configuration: the same seeded trainer run ``steps`` optimisation steps as captured hipGraph replays and as eager
+    launches (fresh networks, the same inputs, the same number of updates): every parameter of G and D afterwards within 5e-5 of its
+    magnitude scale of each other (the two forms issue the same kernels; atomics in the weight-gradient slabs and the head-crop backward
+    are the only order-dependent sums), losses within 1e-4 relative."""
+    hold_g, hold_e = {}, {}
+    rg = measure(dev, steps=steps, warmup=0, size=size, use_vgg=use_vgg, use_face=use_face, precision=precision, graph=True, _keep=hold_g, _host_probe=False)
+    re_ = measure(dev, steps=steps, warmup=0, size=size, use_vgg=use_vgg, use_face=use_face, precision=precision, graph=False, _keep=hold_e, _host_probe=False)
+    tg, te = hold_g["trainer"], hold_e["trainer"]
+    lr = tg.optimizer_G.lr
+    n_upd = steps + 1                                      # + the flop-counting step of measure()
+    dmax, dsum, n = 0.0, 0.0, 0
+    for net_g, net_e in ((tg.G, te.G), (tg.D, te.D)):
+        for (k, a), (_, b) in zip(net_g.named_parameters(), net_e.named_parameters()):
+            d = (a.detach() - b.detach()).abs()
+            dmax = max(dmax, d.max().item())
+            dsum += d.sum().item()
+            n += d.numel()
+    dl = max(abs(rg["loss_G"] - re_["loss_G"]) / max(abs(re_["loss_G"]), 1e-6), abs(rg["loss_D"] - re_["loss_D"]) / max(abs(re_["loss_D"]), 1e-6))
+    captured = "hipGraph" in rg["config"]["step"] and "failed" not in rg["config"]["step"]
+    # Adam moves a weight by <= lr per update whatever the gradient's size (a noise-level gradient can flip the direction of a single weight):
+    # a missing or extra update would show as ~lr EVERYWHERE - the bound of tests/gpu_checks.py::check_graph_vs_eager_steps_512_full
+    ok = captured and dmax <= 2 * n_upd * lr and dsum / n <= 0.1 * lr and dl <= 2e-3
+    return {"result": ("captured == eager (same updates: mean |d theta| <= 0.1 lr, max <= 2 n lr)" if ok else "MISMATCH" if captured else "NOT CAPTURED: " + rg["config"]["step"]),
+            "updates_each": n_upd, "max_param_diff_over_lr": dmax / lr, "mean_param_diff_over_lr": dsum / n / lr, "max_rel_loss_diff": dl,
+            "captured_step": rg["config"]["step"], "eager_step": re_["config"]["step"]}
 
 
 def breakdown(dev, size=512, steps=3):
@@ -250,6 +278,7 @@ def main(argv=None):
     ap.add_argument("--no-relu-mask", dest="relu_mask", action="store_false", help="lab: every ReLU convolution runs its own act_bwd pass")
     ap.add_argument("--no-kv-pair", dest="kv_pair", action="store_false", help="lab: the fk / fv projections as two 1x1 convolutions")
     ap.add_argument("--no-spade-pair", dest="spade_pair", action="store_false", help="lab: SPADE's gamma / beta convolutions as two launches per pass")
+    ap.add_argument("--no-self-check", dest="self_check", action="store_false", help="skip the captured-vs-eager self-check (N = 1, GPU)")
     ap.add_argument("--breakdown", action="store_true", help="lab: per-shape conv times of one eager step (events around every launch)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend; nccl = RCCL (the product)")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
@@ -300,6 +329,12 @@ def main(argv=None):
                   graph=None if args.graph else False, panel_cache=None if args.panel_cache else False,
                   branch=None if args.branch_streams else False, overlap_d=None if args.overlap_d else False,
                   dp_schedule="segmented" if (args.device == "cpu" and world > 1) else None)     # no graphs on the CPU: the same segment schedule, eager
+    if rank == 0 and world == 1 and args.self_check and args.graph and args.device == "cuda":
+        try:
+            res["self_check_detail"] = graph_vs_eager_check(dev, args.size, args.use_vgg, args.use_face, args.precision)
+            res["self_check"] = res["self_check_detail"]["result"]
+        except Exception as e:       # noqa: BLE001
+            res["self_check"] = f"error: {type(e).__name__}: {e}"[:300]
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

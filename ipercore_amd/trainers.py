@@ -571,7 +571,9 @@ class FaceLoss(nn.Module):
 
     def crop_head_bbox(self, imgs, bboxs):
         """:384-406; bboxs (N,4) = [min_x, max_x, min_y, max_y] int64 on the device -> (crops (N,3,112,96), valid (N))."""
-        return _CropResizeFn.apply(imgs.contiguous().float(), bboxs.to(device=imgs.device, dtype=torch.int64), self.HEIGHT, self.WIDTH)
+        if bboxs.device != imgs.device or bboxs.dtype != torch.int64:      # (the trainer binds device int64 boxes: nothing to do in a captured step)
+            bboxs = bboxs.to(device=imgs.device, dtype=torch.int64)
+        return _CropResizeFn.apply(imgs.contiguous().float(), bboxs, self.HEIGHT, self.WIDTH)
 
     def forward(self, imgs1, imgs2, bbox1=None, bbox2=None):
         valid = None
@@ -768,6 +770,14 @@ class LWGTrainer(object):
     def _bind_inputs(self, inp):
         """The captured step reads its inputs from fixed buffers: once graphs exist, a new sample is COPIED into them (same shapes:
         the personalization loop cycles over samples of one video); a sample of another shape drops the graphs (re-captured)."""
+        # the boxes are read by device kernels (FaceLoss crops): int64 tensors next to the images, moved there ONCE per sample - a pageable
+        # host-to-device copy inside a stream capture is not permitted
+        dev_ = next((v.device for v in inp.values() if torch.is_tensor(v) and v.is_cuda), None)
+        if dev_ is not None:
+            inp = dict(inp)
+            for k in ("head_bbox", "body_bbox"):
+                if torch.is_tensor(inp.get(k)) and (inp[k].device != dev_ or inp[k].dtype != torch.int64):
+                    inp[k] = inp[k].to(device=dev_, dtype=torch.int64)
         st = getattr(self, "_static_inp", None)
         if getattr(self, "_graphs", None) is None or st is None:
             self.inp = inp

@@ -1560,7 +1560,7 @@ def check_face_loss():
     out["trainer_g_face"] = float(tr.losses["g_face"].detach())
     # the reference's DEFAULT loss set is a captured step now (the boxes never reach the host)
     out["step_mode_with_vgg_and_face"] = tr.step_mode
-    assert "graph" in tr.step_mode and "failed" not in tr.step_mode, tr.step_mode
+    assert "hipGraph" in tr.step_mode and "failed" not in tr.step_mode, tr.step_mode
     return out
 
 
