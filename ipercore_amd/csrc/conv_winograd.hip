@@ -18,9 +18,9 @@
 // vector ALU instruction 2 cycles + 6 per slot that has any, an LDS instruction 1-2.5, a buffer load nothing to issue - so every LDS address is a
 // base register + immediate, stage offsets are scalar, the transform's 32 adds sit in two slots, and the loads go first (only their latency matters).
 // Epilogue: every wave folds its four products over nu in registers (M A: two values per (patch, channel)), the four rows xi of a (patch, channel)
-// live in four different waves -> ONE exchange through LDS ([xi][column][n][patch], rows padded to 65 floats: conflict-free both ways); a thread then
-// owns one patch x two channel quads (n4.., 32 + n4..): A^T (.) over xi + bias (+ residual, or the SPADE modulation of a gamma | beta launch) +
-// activation, 16-byte NHWC stores.  A second input (skip concatenation) is read stage by stage: a stage's 8 channels lie in one of the two tensors.
+// live in four different waves -> ONE exchange through LDS ([xi][column][patch][n], rows padded to 68 floats: 16-byte stores and loads, conflict-free
+// both ways); a thread then owns one patch x two channel quads (n4.., 32 + n4..): A^T (.) over xi + bias (+ residual, or the SPADE modulation of a
+// gamma | beta launch) + activation, 16-byte NHWC stores.  A second input (skip concatenation) is read stage by stage: a stage's 8 channels lie in one of the two tensors.
 // Rounding: relative L2 error against fp64 1.6x that of the direct fp32 convolution over the generator's layers (tools/winograd_study.py); NOT bitwise
 // the direct kernel's result - which is why it is a precision mode of its own.
 #include <hip/hip_runtime.h>
@@ -40,8 +40,9 @@
 #define DUMP_OFF (2 * RAW_FLOATS + 2 * VS_FLOATS)                 // where the threads without a halo element store their zeros (dead LDS)
 #define DUMP_FLOATS (WG_THREADS + 3 * PLANE + RAW_FLOATS)
 #define LOOP_FLOATS (DUMP_OFF + DUMP_FLOATS)
-#define MS_STRIDE 65
-#define MS_FLOATS (8 * NB * MS_STRIDE)       // [xi (4)][output column (2)][n (64)][patch (64) + 1]
+#define MS_STRIDE 68                         // floats per (plane, patch) row of the epilogue's exchange buffer: 64 channels + 4 (16-byte accesses
+                                             // of eight consecutive patches then cover all banks once: 68 j mod 32 = 4 j)
+#define MS_FLOATS (8 * NPATCH * MS_STRIDE)   // [xi (4)][output column (2)][patch (64)][n (64) + 4]
 #define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
@@ -308,12 +309,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int i = 0; i < 16; ++i)
             reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 16 + i] = ts2[i];
 #endif
-    // epilogue: M A in registers (two values per product row, patch, channel), ONE exchange through LDS [xi][column][n][patch], then a thread owns
-    // one patch x the channel quads n4.. and 32 + n4..: 64 conflict-free LDS reads, A^T (.) over xi, bias, (residual | SPADE modulation),
+    // epilogue: M A in registers (two values per product row, patch, channel), ONE exchange through LDS [xi][column][patch][n], then a thread owns
+    // one patch x the channel quads n4.. and 32 + n4..: 16 conflict-free 16-byte LDS reads, A^T (.) over xi, bias, (residual | SPADE modulation),
     // activation, 16-byte NHWC stores (the residual / xn values are fetched before the exchange).  LWG_EPI_SPADE: the block's 64 columns are
     // gamma | beta of the SAME 32 channels (the host interleaves the stacked panel in blocks of 32, as for lwg_conv_igemm_kernel): quad n4.. is
     // gamma, quad 32 + n4.. beta of channels (n0 / 2) + n4..: y = (xn - mean) rstd (1 + gamma) + beta.
-    const int n4 = (tid & 7) * 4, ep = tid >> 3;
+    // reader threads: channel quad n4 = 4 (lane % 8), patch = (lane / 8) * 8 + wave: the sixteen lanes one ds_read_b128 serves together hold
+    // quads and patches whose 16-byte rows fall into different banks (68 p + n4 over p, p + 8, p + 16, p + 24)
+    const int n4 = (tid & 7) * 4, ep = (lane & 56) + wid;
     const int ety = ep >> 3, etx = ep & 7;
     floatx4 ext[2][2][2];                                    // [channel group h][row][column]: residual (LWG_EPI_RESIDUAL) / xn (LWG_EPI_SPADE: h = 0 only)
     floatx4 bv[2], mu, rs;
@@ -341,28 +344,30 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = nbw * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);        // D layout: row (channel) of this accumulator register
-            float* dst = Ms + ((xi * 2) * NB + n) * MS_STRIDE + tb * 32 + (lane & 31);
-            dst[0] = acc[0][tb][r] + acc[1][tb][r] + acc[2][tb][r];
-            dst[NB * MS_STRIDE] = acc[1][tb][r] - acc[2][tb][r] - acc[3][tb][r];
+        for (int g = 0; g < 4; ++g) {                        // D layout: registers 4 g .. 4 g + 3 are four consecutive rows (channels): one 16-byte store
+            floatx4 c0, c1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * g + k;
+                c0[k] = acc[0][tb][r] + acc[1][tb][r] + acc[2][tb][r];
+                c1[k] = acc[1][tb][r] - acc[2][tb][r] - acc[3][tb][r];
+            }
+            float* dst = Ms + ((xi * 2) * NPATCH + tb * 32 + (lane & 31)) * MS_STRIDE + nbw * 32 + 8 * g + 4 * (lane >> 5);
+            *reinterpret_cast<floatx4*>(dst) = c0;
+            *reinterpret_cast<floatx4*>(dst + NPATCH * MS_STRIDE) = c1;
         }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        floatx4 o[2][2];
+        floatx4 o[2][2], sx[4][2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float sx[4][2];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int px = 0; px < 2; ++px) sx[i][px] = *reinterpret_cast<const floatx4*>(Ms + ((i * 2 + px) * NPATCH + ep) * MS_STRIDE + h * 32 + n4);
 #pragma unroll
-                for (int px = 0; px < 2; ++px) sx[i][px] = Ms[((i * 2 + px) * NB + h * 32 + n4 + c) * MS_STRIDE + ep];
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                o[0][px][c] = sx[0][px] + sx[1][px] + sx[2][px];
-                o[1][px][c] = sx[1][px] - sx[2][px] - sx[3][px];
-            }
+        for (int px = 0; px < 2; ++px) {
+            o[0][px] = sx[0][px] + sx[1][px] + sx[2][px];
+            o[1][px] = sx[1][px] - sx[2][px] - sx[3][px];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
