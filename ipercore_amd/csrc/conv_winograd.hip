@@ -40,9 +40,8 @@
 #define DUMP_OFF (2 * RAW_FLOATS + 2 * VS_FLOATS)                 // where the threads without a halo element store their zeros (dead LDS)
 #define DUMP_FLOATS (WG_THREADS + 3 * PLANE + RAW_FLOATS)
 #define LOOP_FLOATS (DUMP_OFF + DUMP_FLOATS)
-#define MS_STRIDE 68                         // floats per (plane, patch) row of the epilogue's exchange buffer: 64 channels + 4 (16-byte accesses
-                                             // of eight consecutive patches then cover all banks once: 68 j mod 32 = 4 j)
-#define MS_FLOATS (8 * NPATCH * MS_STRIDE)   // [xi (4)][output column (2)][patch (64)][n (64) + 4]
+#define MS_FLOATS (8 * NPATCH * (NB + 4))    // the epilogue's exchange buffer [xi (4)][output column (2)][patch (64)][n (NBV) + 4]: rows of NBV + 4
+                                             // floats - 16-byte accesses of eight consecutive patches then cover all banks once (68 j, 36 j = 4 j mod 32)
 #define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
@@ -65,9 +64,15 @@ __device__ __forceinline__ floatx4 wino_buf_load(__amdgpu_buffer_rsrc_t r, unsig
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-template <int EPI>
+// NBV = output channels per workgroup.  64: the form described above.  32 (small launches - a frame or two -, plain / residual epilogues): the
+// same 64 patches x 32 channels, wave w = (xi = w % 4, patch tile w / 4) with ONE accumulator tile per product: twice the workgroups of half the
+// matrix work each, so that a launch that would leave most of the chip idle fills it.  Every output element is accumulated over the stages and
+// k-pairs in the same order and finished by the same expressions in both forms: bitwise the same result (a frame does not depend on its batch).
+template <int EPI, int NBV>
 __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NBV / 32;                             // accumulator (patch) tiles per product and wave
+    constexpr int MSR = NBV + 4;                             // floats per (plane, patch) row of the epilogue's exchange buffer
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ bias = a.bias;
     float* __restrict__ y = a.y;
@@ -81,15 +86,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     const int b = blk / (bx * by);
     blk -= b * bx * by;
     const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
-    const int n0 = blockIdx.y * NB;
+    const int n0 = blockIdx.y * NBV;
     const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
     WTS(0);
     // buffer resources: this image of each input, the weight panel
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : a.x0), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(64u * (unsigned)Cin * (unsigned)N), 0x00020000);
-    const int xi = wid & 3, nbw = wid >> 2;                   // this wave's row of the transformed patch, its 32-channel tile
-    floatx16 acc[4][2];                                      // [product nu][patch tile tb] (cleared in the prologue, behind the first loads)
+    const int xi = wid & 3;                                   // this wave's row of the transformed patch
+    const int nbw = NT == 2 ? wid >> 2 : 0;                   // ... its 32-channel tile (NBV = 64)
+    const int ptw = NT == 2 ? 0 : wid >> 2;                   // ... or its 32-patch tile (NBV = 32)
+    floatx16 acc[4][NT];                                     // [product nu][patch tile] (cleared in the prologue, behind the first loads)
 
     // this thread's two halo elements (pixel, channel quad): byte offsets of the pixel inside either input (out of range: padding / none), LDS slot
     unsigned voff0[2], voff1[2];
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
             fbs[u][nu] = (unsigned)(2 * RAW_FLOATS + u * VS_FLOATS + ((4 * xi + nu) * KS + (lane >> 5)) * VSTR + (lane & 31) * 2) >> 1;
             asm volatile("" : "+v"(fbs[u][nu]));
             fbs[u][nu] <<= 1;
+            if (NT == 1) fbs[u][nu] += ptw;                  // one patch tile: the 4-byte half of the pair
         }
     }
     auto transform = [&](int buf) {                          // prologue only
@@ -169,19 +177,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
     for (int i = 0; i < 16; ++i) ts2[i] = 0;
 #endif
-    typedef float floatx2 __attribute__((ext_vector_type(2)));
-    floatx2 fb[4][4];                                        // [k-pair][product nu]: patch tiles 0 | 1
+    typedef float fragx __attribute__((ext_vector_type(NT)));
+    fragx fb[4][4];                                          // [k-pair][product nu]: patch tiles 0 | 1 (NBV = 64) or this wave's one
     auto fragread = [&](int set, int kk) {
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) fb[kk][nu] = *reinterpret_cast<const floatx2*>(smem + fbs[set][nu] + 2 * kk * VSTR);
+        for (int nu = 0; nu < 4; ++nu) fb[kk][nu] = *reinterpret_cast<const fragx*>(smem + fbs[set][nu] + 2 * kk * VSTR);
     };
     auto iteration = [&](int s, auto SET, auto NXT) {
         constexpr int set = decltype(SET)::value;
         constexpr bool nxt = decltype(NXT)::value != 0;      // the last stage has no next one to prepare (peeled: no branches in the loop)
         const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
         float dd[4][4], t[4];
-        auto mf = [&](int m) {
-            const int kk = m >> 3, nu = (m >> 1) & 3, tb = m & 1;
+        auto mf = [&](int m) {                               // slot m of 16 NT: k-pair m / (4 NT), product (m / NT) % 4, patch tile m % NT
+            const int kk = m / (4 * NT), nu = (m / NT) & 3, tb = m % NT;
             acc[nu][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[set][nu][kk], fb[kk][nu][tb], acc[nu][tb], 0, 0, 0);
             WSB();
         };
@@ -227,24 +235,37 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         WSB();
         // slot plan: loads first (their issue is free, their latency is what has to be covered), then the halo store, the transform reads, and the
         // transform's 32 vector adds in TWO slots (a slot that has any vector instruction costs ~6 cycles of matrix pipe on top of 2 per instruction)
-        mf(0); uld(0);
-        mf(1); uld(1);
-        mf(2); uld(2);
-        mf(3); uld(3);
-        WTS2(1);
-        mf(4); rst(0); rld(0);
-        mf(5); rst(1); rld(1);
-        mf(6); ddr(0); ddr(1); ddr(2); ddr(3);
-        mf(7);
-        WTS2(2);
-        mf(8);
-        mf(9); t2a(0); t2b(0); t2a(1); t2b(1);
-        mf(10);
-        mf(11); t2a(2); t2b(2); t2a(3); t2b(3);
-        mf(12); mf(13); mf(14); mf(15);
-        WTS2(3);
-        mf(16); mf(17); mf(18); mf(19); mf(20);
-        mf(21); mf(22); mf(23);
+        if (NT == 2) {
+            mf(0); uld(0);
+            mf(1); uld(1);
+            mf(2); uld(2);
+            mf(3); uld(3);
+            WTS2(1);
+            mf(4); rst(0); rld(0);
+            mf(5); rst(1); rld(1);
+            mf(6); ddr(0); ddr(1); ddr(2); ddr(3);
+            mf(7);
+            WTS2(2);
+            mf(8);
+            mf(9); t2a(0); t2b(0); t2a(1); t2b(1);
+            mf(10);
+            mf(11); t2a(2); t2b(2); t2a(3); t2b(3);
+            mf(12); mf(13); mf(14); mf(15);
+            WTS2(3);
+            mf(16); mf(17); mf(18); mf(19); mf(20);
+            mf(21); mf(22); mf(23);
+        } else {
+            mf(0); uld(0); uld(1);
+            mf(1); uld(2); uld(3);
+            mf(2); rst(0); rld(0);
+            mf(3); rst(1); rld(1);
+            mf(4); ddr(0); ddr(1); ddr(2); ddr(3);
+            mf(5);
+            mf(6); t2a(0); t2b(0); t2a(1); t2b(1);
+            mf(7);
+            mf(8); t2a(2); t2b(2); t2a(3); t2b(3);
+            mf(9); mf(10); mf(11);
+        }
         WTS2(4);
         __syncthreads();
         WTS2(5);
@@ -253,12 +274,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
             fragread(set ^ 1, 1);
         }
         WSB();
-        mf(24);
+        mf(12 * NT);
         if (nxt) fragread(set ^ 1, 2);
         WSB();
-        mf(25); mf(26); mf(27); mf(28);
-        WTS2(6);
-        mf(29); mf(30); mf(31);
+        if (NT == 2) {
+            mf(25); mf(26); mf(27); mf(28);
+            WTS2(6);
+            mf(29); mf(30); mf(31);
+        } else {
+            mf(13); mf(14); mf(15);
+        }
         WTS2(7);
     };
 
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)                       // (the accumulators are cleared while the first loads are in flight)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
+            for (int tb = 0; tb < NT; ++tb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nu][tb][r] = 0.f;
 #pragma unroll
@@ -318,17 +343,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     // quads and patches whose 16-byte rows fall into different banks (68 p + n4 over p, p + 8, p + 16, p + 24)
     const int n4 = (tid & 7) * 4, ep = (lane & 56) + wid;
     const int ety = ep >> 3, etx = ep & 7;
+    constexpr int NH = NT;                                   // channel quads per reader thread: n4.. and (NBV = 64) 32 + n4..
     floatx4 ext[2][2][2];                                    // [channel group h][row][column]: residual (LWG_EPI_RESIDUAL) / xn (LWG_EPI_SPADE: h = 0 only)
     floatx4 bv[2], mu, rs;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + n0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < NH; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + n0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
     if (EPI == LWG_EPI_SPADE) {
         mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)b * a.YC + (n0 >> 1) + n4);
         rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)b * a.YC + (n0 >> 1) + n4);
     }
     if (EPI != LWG_EPI_NONE) {
 #pragma unroll
-        for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : 2); ++h) {
+        for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : NH); ++h) {
             const int ch = EPI == LWG_EPI_SPADE ? (n0 >> 1) + n4 : a.ycoff + n0 + h * 32 + n4;
             const float* src = EPI == LWG_EPI_SPADE ? a.xn : a.res;
 #pragma unroll
@@ -342,7 +368,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         }
     }
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int tb = 0; tb < NT; ++tb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                        // D layout: registers 4 g .. 4 g + 3 are four consecutive rows (channels): one 16-byte store
             floatx4 c0, c1;
@@ -352,18 +378,18 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 c0[k] = acc[0][tb][r] + acc[1][tb][r] + acc[2][tb][r];
                 c1[k] = acc[1][tb][r] - acc[2][tb][r] - acc[3][tb][r];
             }
-            float* dst = Ms + ((xi * 2) * NPATCH + tb * 32 + (lane & 31)) * MS_STRIDE + nbw * 32 + 8 * g + 4 * (lane >> 5);
+            float* dst = Ms + ((xi * 2) * NPATCH + (NT == 2 ? tb : ptw) * 32 + (lane & 31)) * MSR + nbw * 32 + 8 * g + 4 * (lane >> 5);
             *reinterpret_cast<floatx4*>(dst) = c0;
-            *reinterpret_cast<floatx4*>(dst + NPATCH * MS_STRIDE) = c1;
+            *reinterpret_cast<floatx4*>(dst + NPATCH * MSR) = c1;
         }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         floatx4 o[2][2], sx[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int px = 0; px < 2; ++px) sx[i][px] = *reinterpret_cast<const floatx4*>(Ms + ((i * 2 + px) * NPATCH + ep) * MS_STRIDE + h * 32 + n4);
+            for (int px = 0; px < 2; ++px) sx[i][px] = *reinterpret_cast<const floatx4*>(Ms + ((i * 2 + px) * NPATCH + ep) * MSR + h * 32 + n4);
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
             o[0][px] = sx[0][px] + sx[1][px] + sx[2][px];
@@ -424,17 +450,34 @@ extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t strea
     const size_t loop = (size_t)LOOP_FLOATS * 4, epi = (size_t)MS_FLOATS * 4;
     const size_t lds = loop > epi ? loop : epi;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
-    const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / NB));
-    static unsigned long long done[3] = {0, 0, 0};
-#define LWG_WINO_GO(E, SLOT)                                                                                                          \
-    {                                                                                                                                 \
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E>), lds, done[SLOT]); e != hipSuccess) \
-            return (int)e;                                                                                                            \
-        hipLaunchKernelGGL(lwg_conv_winograd_kernel<E>, grid, dim3(WG_THREADS), lds, stream, a);                                      \
+    // small launches (a frame or two): workgroups of 64 patches x 32 channels when that shortens the launch - the chip holds one workgroup per CU
+    // (LDS), a launch is ceil(workgroups / CUs) rounds, and a half-size workgroup costs ~0.55 of a full one (same per-stage overheads on half the
+    // MFMAs).  Same bits either way.
+    const long blocks64 = (long)bx * by * a.B * (a.N / NB);
+    static int cus = 0;                                      // compute units of the device (one node = one device type)
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
     }
-    if (a.epi == LWG_EPI_RESIDUAL) LWG_WINO_GO(LWG_EPI_RESIDUAL, 1)
-    else if (a.epi == LWG_EPI_SPADE) LWG_WINO_GO(LWG_EPI_SPADE, 2)
-    else LWG_WINO_GO(LWG_EPI_NONE, 0)
+    const long rounds64 = (blocks64 + cus - 1) / cus, rounds32 = (2 * blocks64 + cus - 1) / cus;
+    const bool small = a.epi != LWG_EPI_SPADE && (double)rounds32 * 0.55 < (double)rounds64;
+    const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / (small ? 32 : NB)));
+    static unsigned long long done[5] = {0, 0, 0, 0, 0};
+#define LWG_WINO_GO(E, V, SLOT)                                                                                                       \
+    {                                                                                                                                 \
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E, V>), lds, done[SLOT]); e != hipSuccess) \
+            return (int)e;                                                                                                            \
+        hipLaunchKernelGGL((lwg_conv_winograd_kernel<E, V>), grid, dim3(WG_THREADS), lds, stream, a);                                 \
+    }
+    if (a.epi == LWG_EPI_SPADE) LWG_WINO_GO(LWG_EPI_SPADE, 64, 2)
+    else if (a.epi == LWG_EPI_RESIDUAL) {
+        if (small) LWG_WINO_GO(LWG_EPI_RESIDUAL, 32, 3)
+        else LWG_WINO_GO(LWG_EPI_RESIDUAL, 64, 1)
+    } else {
+        if (small) LWG_WINO_GO(LWG_EPI_NONE, 32, 4)
+        else LWG_WINO_GO(LWG_EPI_NONE, 64, 0)
+    }
 #undef LWG_WINO_GO
     return (int)hipGetLastError();
 }

@@ -826,7 +826,8 @@ def check_winograd_mode():
     ns = 1 / 8, the reference goldens) already runs it.  Here:
     1. kernel level against an fp64 convolution at the conv checks' tolerance: ragged / odd sizes, ReLU, a residual epilogue into a channel slice
        of a wider tensor, a skip concatenation, the SPADE epilogue, the 1024 x 1024 generator's layer shapes - and NOT the direct kernel's bits
-       (the kernel really ran); a launch's frames bitwise independent of the batch they are launched in;
+       (the kernel really ran); a launch's frames bitwise independent of the batch they are launched in - including across the kernel's two forms
+       (64- and 32-channel workgroups, chosen by launch size);
     2. the all-direct mode ("fp32", the rounds 1-4 default) still meets the oracle tolerances on the 512 x 512 pipeline, differs from the
        default mode's frames (both engines ran) by no more than 1e-4, and is itself batch-invariant."""
     out = {}
@@ -835,7 +836,11 @@ def check_winograd_mode():
              ("odd_1px_rows", (3, 1, 33, 96, 0, 64, 64, 0, ops.EPI_NONE)),
              ("two_inputs_ragged", (2, 21, 35, 64, 32, 64, 64, 0, ops.EPI_NONE)),
              ("skip_1024_shape", (1, 96, 80, 128, 64, 128, 128, 0, ops.EPI_NONE)),
-             ("res_block_wide", (2, 40, 24, 256, 0, 256, 256, 0, ops.EPI_RESIDUAL)))
+             ("res_block_wide", (2, 40, 24, 256, 0, 256, 256, 0, ops.EPI_RESIDUAL)),
+             # 16 frames x 4 tiles x 4 column blocks = 256 workgroups of 64 channels (one full round: the large form); the last frame alone is 16
+             # workgroups -> the 32-channel small-launch form: the batch-invariance assertion below then compares the two forms bit for bit
+             ("forms_residual", (16, 32, 32, 64, 0, 256, 256, 0, ops.EPI_RESIDUAL)),
+             ("forms_plain_two_inputs", (16, 32, 32, 32, 32, 256, 256, 0, ops.EPI_NONE)))
     for tag, (B, H, W, C0, C1, N, YC, ycoff, epi) in cases:
         Cin = C0 + C1
         w, b = _rand((N, Cin, 3, 3), 170, (Cin * 9) ** -0.5), _rand((N,), 171, 0.1)
