@@ -37,7 +37,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="fp32", rank=0, world=1, graph=None,
+def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, precision="winograd", rank=0, world=1, graph=None,
             panel_cache=None, branch=None, overlap_d=None, _keep=None, dp_schedule=None, _host_probe=True):
     """One process' share of the measurement -> the result dict (rank 0) / None.  ``graph``: None = the trainer's default (the
     static-shape step replayed as a hipGraph when that is supported), False = eager launches."""
@@ -89,11 +89,13 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
     if _keep is not None:
         _keep["trainer"] = tr
 
-    flops = [0.0]
+    flops, wino_algo = [0.0], [0.0]
 
     def hook(begin, M, spec, epi=0, info=None):
         if begin:
             flops[0] += 2.0 * M * spec.algo_kn
+        elif info is not None and info.get("kind") == "winograd":
+            wino_algo[0] += 2.0 * M * spec.algo_kn          # executes 4/9 of these: sixteen products per 2 x 2 outputs instead of 36
     wg = [0.0]
     orig = ops.conv2d_wgrad
 
@@ -149,10 +151,14 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
         return None
     nG, nD = sum(p.numel() for p in G.parameters()), sum(p.numel() for p in D.parameters())
     tf = per_step / (dt / steps) / 1e12
+    executed = per_step - wino_algo[0] * 5.0 / 9.0
+    tf_exec = executed / (dt / steps) / 1e12
     return {
         "metric": f"personalization steps (samples)/sec at {S}x{S}, G+D fwd/bwd/Adam, 1 sample per GPU", "value": round(steps * world / dt, 4),
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "dtype": "f32" if precision == "fp32" else "f32 (forward / dgrad products as bf16x6 exact split)",
+        "higher_is_better": True, "scaling": "weak", "dtype": "f32" if precision in ("fp32", "winograd") else "f32 (forward / dgrad products as bf16x6 exact split)",
+        "conv_engine": {"fp32": "direct fp32 MFMA implicit GEMMs", "winograd": "3x3 / stride 1 forward + data-gradient convolutions as F(2x2,3x3) Winograd (fp32 MFMA), "
+                        "the rest and every weight gradient direct", "split": "bf16x6"}[precision],
         "data": "synthetic" + ("" if on_gpu else " (CPU plumbing run over the emulated C ABI: NOT a measurement)"),
         "config": {"workload": f"personalize step {S}x{S} ns=2 nt=1 (BASELINE configs[4]); losses: LSGAN + L1 rec + " + ("VGG19 perceptual" if use_vgg else "L1") + " tsf" + (" + Sphere20a face" if use_face else "") + " + BCE mask + TV",
                    "global_batch": world,
@@ -160,9 +166,11 @@ def measure(dev, steps=5, warmup=2, size=512, use_vgg=False, use_face=False, pre
                                   f"{(nG + nD) * 4 / 1e6:.1f} MB per step per rank), G's in 4 ranges behind D's forward / backward segment",
                    "step": getattr(tr, "step_mode", "eager launches"),
                    "panel_cache": bool(getattr(tr.opts, "use_panel_cache", False)), "branch_streams": bool(getattr(tr.opts, "branch_streams", False))},
-        "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
-        "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                     "what": "algorithmic conv flops of the step (forward + dgrad + wgrad of G, D) / whole-step wall time"},
+        "conv_gflop_per_step": round(per_step / 1e9, 1), "conv_gflop_executed_per_step": round(executed / 1e9, 1), "conv_tflops_whole_step": round(tf, 2),
+        "roofline": {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf_exec / 157.3, 4),
+                     "algorithmic_equivalent_tflops": round(tf, 2),
+                     "what": "EXECUTED conv flops of the step (forward + dgrad + wgrad of G, D and the loss networks; a Winograd launch counts 4/9 of its "
+                             "2 M K N) / whole-step wall time; algorithmic_equivalent_tflops prices the same step at 2 M K N throughout"},
         "bytes_allreduced_per_step": (nG + nD) * 4 if world > 1 else 0,
         # N > 1: time the compute stream waited for RCCL in the last step (G's exchange runs behind D's forward / backward segment, D's
         # behind Adam(G): trainers.LWGTrainer._run_dp_schedule); N = 1: nothing is exchanged
@@ -264,8 +272,9 @@ def main(argv=None):
     ap.add_argument("--use-vgg", action="store_true", help="VGG19 perceptual transfer loss (deploy.toml:83; seeded weights: "
                                                           "vgg19-dcbb9e9d.pth is not available offline) instead of L1")
     ap.add_argument("--use-face", action="store_true", help="SphereFace (Sphere20a) loss on the head crop (deploy.toml:77-79)")
-    ap.add_argument("--precision", choices=("fp32", "split"), default="fp32",
-                    help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA")
+    ap.add_argument("--precision", choices=("fp32", "split", "winograd"), default="winograd",
+                    help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA; winograd: the 3x3 / "
+                         "stride 1 forward and data-gradient convs as F(2x2,3x3) Winograd convolutions (fp32 MFMA), weight gradients direct")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
     ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
     ap.add_argument("--no-branch-streams", dest="branch_streams", action="store_false",

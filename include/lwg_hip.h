@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 7: lwg_conv_slice_count, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
 #define LWG_ABI_VERSION 7
 int lwg_abi_version(void);
@@ -109,6 +109,20 @@ int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
  * fp32-grade results (relative error against fp64 1.6x the direct kernel's), not bitwise those of lwg_conv2d_nhwc_f32: a precision mode
  * of its own (ops.conv_precision("winograd")); a frame's result does not depend on the batch it is launched in. */
 int lwg_conv2d_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
+/* The fragment panel Upk[16][Cin/8][2][N][4] of the call above from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w, nine taps,
+ * Cin % 32 == 0): U = G w G^T per (input channel, output column) in fp64, rounded once.  tap9[3 r + s] = index of the tap (dy, dx) = (r - 1, s - 1)
+ * in the GEMM panel's tap order.  With LWG_EPI_RESIDUAL the Winograd call also takes LWG_ACTIVATION_RELU_MASK (the data gradient behind a ReLU). */
+int lwg_winograd_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream);
+/* The same for every registered panel of a training step in ONE launch (the weights change every step): descs_dev = ndesc records in DEVICE memory,
+ * each the argument list of one lwg_winograd_panel_f32 call plus first_block = the sum of ceil(N / 64) * ceil(Cin / 4) over the records before it;
+ * total_blocks = that sum over all records.  Same values as ndesc single launches. */
+typedef struct LwgWinoDesc {
+    const float* wpanel;
+    float* upk;
+    int Cin, N, first_block;
+    int tap9[9];
+} LwgWinoDesc;
+int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, int total_blocks, lwg_stream_t stream);
 /* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches, as the
  * halo-tile kernel with register-streamed weights: args->w = the bf16 panel [ntaps*Cin/64][4][N][16] - element
  * [step][ks][n][e] = weight of GEMM column n at k = step*64 + ks*16 + e (k order as above) - and, for LWG_EPI_SPADE, columns
@@ -216,6 +230,11 @@ int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B,
 int lwg_crop_resize_bilinear_f32(const float* x, const long long* box, float* y, float* valid, int N, int C, int H, int W, int OH, int OW,
                                  lwg_stream_t stream);
 int lwg_crop_resize_bilinear_bwd_f32(const float* dy, const long long* box, float* dx, int N, int C, int H, int W, int OH, int OW, lwg_stream_t stream);
+/* nn.PReLU(C) of the frozen Sphere20a (criterions/faceloss.py:209-283, relu{b}_{i}) on NHWC rows, with the block's residual add (:262-281, x + relu(conv(..)))
+ * folded in: y = (res ? res : 0) + (x >= 0 ? x : slope[c] x); x, res, y (rows, C), slope (C), C % 4 == 0.  _bwd: dx = dy * (x >= 0 ? 1 : slope[c]) - the slopes
+ * are frozen (no gradient for them) and the residual's gradient is dy itself. */
+int lwg_prelu_f32(const float* x, const float* slope, const float* res, size_t rows, int C, float* y, lwg_stream_t stream);
+int lwg_prelu_bwd_f32(const float* x, const float* slope, const float* dy, size_t rows, int C, float* dx, lwg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False) statistics (biased variance), NHWC.

@@ -40,6 +40,11 @@ class LwgConvArgs(ctypes.Structure):
     ]
 
 
+class LwgWinoDesc(ctypes.Structure):
+    """Mirror of include/lwg_hip.h LwgWinoDesc (one record of lwg_winograd_panels_f32's device table)."""
+    _fields_ = [("wpanel", ctypes.c_void_p), ("upk", ctypes.c_void_p), ("Cin", c_i), ("N", c_i), ("first_block", c_i), ("tap9", c_i * 9)]
+
+
 class LwgPackDesc(ctypes.Structure):
     """Mirror of ``struct LwgPackDesc`` (include/lwg_hip.h): one panel of lwg_pack_panels_f32."""
     _fields_ = [("w", c_f), ("out", c_f)] + [(n, c_i) for n in ("D1", "KHW", "transposed", "ntaps", "cin", "cin_pad", "nout", "n_pad", "Kp",
@@ -54,6 +59,8 @@ _SIGS = {
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_winograd_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_winograd_panel_f32": (c_i, [c_f, c_f, c_i, c_i, ctypes.POINTER(c_i), c_f]),
+    "lwg_winograd_panels_f32": (c_i, [c_f, c_i, c_i, c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
@@ -77,6 +84,8 @@ _SIGS = {
     "lwg_maxpool2_bwd_nhwc_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_crop_resize_bilinear_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "lwg_crop_resize_bilinear_bwd_f32": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "lwg_prelu_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_f, c_f]),
+    "lwg_prelu_bwd_f32": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_f, c_f]),
     "lwg_instnorm_stats_nhwc_f32": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
     "lwg_instnorm_apply_nhwc_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "lwg_lwb_attention_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),

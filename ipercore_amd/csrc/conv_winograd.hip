@@ -411,16 +411,92 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                         *reinterpret_cast<floatx4*>(y + (((size_t)b * H + oy) * W + ox) * a.YC + (n0 >> 1) + n4) = r;
                     }
                 } else if (oy < H && ox < W) {
-                    if (EPI == LWG_EPI_RESIDUAL) v += ext[h][i][px];
                     floatx4 r;
+                    if (EPI == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK) {       // data gradient behind a ReLU: res = the forward input, the mask source
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) r[c] = lwg_act(v[c], a.act);
+                        for (int c = 0; c < 4; ++c) r[c] = ext[h][i][px][c] > 0.f ? v[c] : 0.f;
+                    } else {
+                        if (EPI == LWG_EPI_RESIDUAL) v += ext[h][i][px];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = lwg_act(v[c], a.act);
+                    }
                     *reinterpret_cast<floatx4*>(y + (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + n0 + h * 32 + n4) = r;
                 }
             }
     }
     WTS(41);
     WTS(42);
+}
+
+
+// The fragment panel from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w: [9 Cin / 4][N][4], k = ((c / 32) 9 + tap) 32 + c % 32):
+// U = G w G^T per (input channel, output column) in fp64, rounded once, written as Upk[16][Cin/8][2][N][4] - one thread per (c, n).  tap9[3 r + s] =
+// the tap index of kernel position (dy, dx) = (r - 1, s - 1) in that panel.  Inference builds it once per weight version; the personalization step
+// once per convolution call (the weights change every step).
+struct LwgWinoTaps { int t[9]; };
+
+__device__ __forceinline__ void lwg_winograd_panel_elem(const float* __restrict__ wp, float* __restrict__ U, int Cin, int N, const int* t9, int c, int n) {
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = ((c >> 5) * 9 + t9[3 * r + q]) * 32 + (c & 31);
+            g[r][q] = (double)wp[((size_t)(k >> 2) * N + n) * 4 + (k & 3)];
+        }
+    double t[4][3];                                          // G g: rows (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        t[0][q] = g[0][q];
+        t[1][q] = 0.5 * (g[0][q] + g[1][q] + g[2][q]);
+        t[2][q] = 0.5 * (g[0][q] - g[1][q] + g[2][q]);
+        t[3][q] = g[2][q];
+    }
+    const int s8 = c >> 3, kk = (c & 7) >> 1, kh = c & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[((((size_t)(i * 4 + j) * (Cin >> 3) + s8) * 2 + kh) * N + n) * 4 + kk] = (float)u[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void lwg_winograd_panel_kernel(const float* __restrict__ wp, float* __restrict__ U, int Cin, int N, LwgWinoTaps taps) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n < N && c < Cin) lwg_winograd_panel_elem(wp, U, Cin, N, taps.t, c, n);
+}
+
+// every registered panel of a training step in one launch (the weights change every step): workgroup b serves descriptor d = the last one with
+// first_block <= b (binary search), as lwg_pack_panels_f32 does for the GEMM panels
+__global__ __launch_bounds__(256) void lwg_winograd_panels_kernel(const LwgWinoDesc* __restrict__ descs, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const LwgWinoDesc* d = descs + lo;
+    const int N = d->N, Cin = d->Cin, nbx = (N + 63) >> 6;
+    const int lb = (int)blockIdx.x - d->first_block;
+    const int n = (lb % nbx) * 64 + (threadIdx.x & 63), c = (lb / nbx) * 4 + (threadIdx.x >> 6);
+    if (n < N && c < Cin) lwg_winograd_panel_elem(d->wpanel, d->upk, Cin, N, d->tap9, c, n);
+}
+
+extern "C" int lwg_winograd_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream_) {
+    if (!wpanel || !upk || !tap9 || Cin <= 0 || (Cin % 32) != 0 || N <= 0) return (int)hipErrorInvalidValue;
+    LwgWinoTaps taps;
+    for (int i = 0; i < 9; ++i) {
+        if (tap9[i] < 0 || tap9[i] > 8) return (int)hipErrorInvalidValue;
+        taps.t[i] = tap9[i];
+    }
+    hipLaunchKernelGGL(lwg_winograd_panel_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((Cin + 3) / 4)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), wpanel, upk, Cin, N, taps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, int total_blocks, lwg_stream_t stream_) {
+    if (!descs_dev || ndesc < 1 || total_blocks < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lwg_winograd_panels_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), descs_dev, ndesc);
+    return (int)hipGetLastError();
 }
 
 
@@ -436,7 +512,7 @@ extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t strea
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C0 <= 0 || (a.C0 % KS) != 0 || a.C1 < 0 ||
         (a.C1 % KS) != 0 || ((a.C0 + a.C1) % (2 * KS)) != 0 || (a.C1 > 0 && !a.x1) || a.N <= 0 || (a.N % NB) != 0 || a.OH != a.H || a.OW != a.W ||
         a.YH != a.H || a.YW != a.W || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.M != a.B * a.H * a.W || a.ycoff < 0 || (a.ycoff % 4) != 0 ||
-        (a.YC % 4) != 0 || a.act == LWG_ACT_RELU_MASK)
+        (a.YC % 4) != 0 || (a.act == LWG_ACT_RELU_MASK && a.epi != LWG_EPI_RESIDUAL))
         return (int)hipErrorInvalidValue;
     if (a.epi == LWG_EPI_SPADE) {
         if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return (int)hipErrorInvalidValue;

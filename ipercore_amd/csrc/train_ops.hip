@@ -44,6 +44,51 @@ extern "C" int lwg_act_bwd_f32(const float* dy, const float* y, size_t n, int ac
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- per-channel PReLU (+ residual)
+// The frozen Sphere20a of the face loss (criterions/faceloss.py:203-285): y = res + (x >= 0 ? x : slope[c] x) on NHWC rows, res optional;
+// backward dx = dy * (x >= 0 ? 1 : slope[c]) (the slopes are frozen: no gradient for them; the residual's gradient is dy itself).
+template <bool BWD>
+__global__ void lwg_prelu_kernel(const floatx4* __restrict__ x, const floatx4* __restrict__ slope, const floatx4* __restrict__ other,
+                                 int C4, size_t n4, floatx4* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const floatx4 v = x[i], a = slope[i % C4];
+        floatx4 o;
+        if (BWD) {
+            const floatx4 g = other[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = v[k] >= 0.f ? g[k] : g[k] * a[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = v[k] >= 0.f ? v[k] : v[k] * a[k];
+            if (other) {
+                const floatx4 r = other[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += r[k];
+            }
+        }
+        out[i] = o;
+    }
+}
+
+template <bool BWD>
+static int lwg_prelu_launch(const float* x, const float* slope, const float* other, size_t rows, int C, float* out, lwg_stream_t stream_) {
+    if (!x || !slope || !out || (BWD && !other) || rows == 0 || C <= 0 || (C & 3)) return (int)hipErrorInvalidValue;
+    const size_t n4 = rows * (size_t)(C / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL((lwg_prelu_kernel<BWD>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       reinterpret_cast<const floatx4*>(x), reinterpret_cast<const floatx4*>(slope), reinterpret_cast<const floatx4*>(other), C / 4, n4,
+                       reinterpret_cast<floatx4*>(out));
+    return (int)hipGetLastError();
+}
+
+extern "C" int lwg_prelu_f32(const float* x, const float* slope, const float* res, size_t rows, int C, float* y, lwg_stream_t stream) {
+    return lwg_prelu_launch<false>(x, slope, res, rows, C, y, stream);
+}
+
+extern "C" int lwg_prelu_bwd_f32(const float* x, const float* slope, const float* dy, size_t rows, int C, float* dx, lwg_stream_t stream) {
+    return lwg_prelu_launch<true>(x, slope, dy, rows, C, dx, stream);
+}
+
 // ---------------------------------------------------------------------------------------------- normalise (+ modulate) forward
 // y = act( (x - mean) * rstd * (1 + gamma) + beta )   gamma / beta optional (NULL: plain InstanceNorm + activation)
 // gs4: float4s per pixel row of gamma / beta (C4 for dense tensors; 2 * C4 when both are halves of ONE (B,HW,2C) convolution output)

@@ -191,7 +191,8 @@ _WINO_TAPS = sorted((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
 def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff=0):
     """Launches lwg_conv2d_winograd_f32 takes: 3x3 / stride 1 / pad 1, fp32, Cin % 32 == 0 (one input or a skip concatenation with both channel
     counts % 8 == 0), plain / residual / SPADE (gamma | beta stacked, N = 2 C) epilogue, dense output."""
-    if q4 or x0.dtype != torch.float32 or y.dtype != torch.float32 or epi not in (EPI_NONE, EPI_RESIDUAL, EPI_SPADE) or act == ACT_RELU_MASK:
+    if q4 or x0.dtype != torch.float32 or y.dtype != torch.float32 or epi not in (EPI_NONE, EPI_RESIDUAL, EPI_SPADE) or \
+            (act == ACT_RELU_MASK and epi != EPI_RESIDUAL):
         return False
     if x1 is not None and (x1.dtype != torch.float32 or x0.shape[3] % 8 != 0 or x1.shape[3] % 8 != 0):
         return False
@@ -205,21 +206,38 @@ def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff=0):
     return hw == (x0.shape[1], x0.shape[2]) == (y.shape[1], y.shape[2])
 
 
+WINO_MIN_GRID = 128     # workgroups (64 patches x 32 channels) below which a splitk=True caller gets the direct split-K form instead
+
+
+def _wino_underfills(spec, y):
+    """A training launch (splitk=True) whose Winograd grid would leave most of the 256 CUs idle - a 28 x 28 x 512 VGG19 layer is 64
+    workgroups of 64 K stages each: 79 us against the direct kernel's split-K 51 us; 56 x 56 x 256 (128 workgroups) is the break-even
+    (profiles/r05_g_winograd_small_launches.txt).  The synthesis path never asks (splitk=False: batch invariance)."""
+    tiles = y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 15) // 16)
+    return tiles * (spec.N // 32) < WINO_MIN_GRID
+
+
 def _wwino(spec):
-    """The transformed-weight fragment panel of lwg_conv2d_winograd_f32, built once per spec from the fp32 panel: U = G w G^T per (input, output)
-    channel pair (in fp64, rounded once), stored [16][Cin/8][2][N][4] - element (p, s, kh, n, kk) = U[p // 4][p % 4] of input channel 8 s + 2 kk + kh."""
+    """The transformed-weight fragment panel of lwg_conv2d_winograd_f32, built once per spec from the fp32 GEMM panel by ONE launch
+    (lwg_winograd_panel_f32): U = G w G^T per (input, output) channel pair in fp64, rounded once, stored [16][Cin/8][2][N][4] - element
+    (p, s, kh, n, kk) = U[p // 4][p % 4] of input channel 8 s + 2 kk + kh."""
     if spec._wwino is None or spec._wwino.device != spec.w.device:
         K4, N, _ = spec.w.shape
         cin, nt = spec.Cin, spec.ntaps
         assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin, (cin, nt, K4)
-        wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)                                    # k' = ((c // 32) * ntaps + tap) * 32 + c % 32
-        w = wk.view(cin // 32, nt, 32, N).permute(1, 0, 2, 3).reshape(nt, cin, N).double()     # [tap][c][n]
-        g = w.new_zeros(3, 3, cin, N)
+        if not spec.w.is_cuda:
+            raise RuntimeError("ipercore_amd ops need CUDA (HIP) tensors: the MI355X path has no CPU fallback")
+        tap9 = (ctypes.c_int * 9)()
         for t in range(nt):
-            g[spec.dy[t] + 1, spec.dx[t] + 1] = w[t]
-        G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=g.device)
-        U = torch.einsum("ij,jkcn,lk->ilcn", G, g, G).reshape(16, cin, N)
-        spec._wwino = U.view(16, cin // 8, 4, 2, N).permute(0, 1, 3, 4, 2).contiguous().float()
+            tap9[3 * (spec.dy[t] + 1) + spec.dx[t] + 1] = t
+        if PANEL_CACHE is not None:                          # a training step: panels of registered weights are refreshed once per step
+            U = PANEL_CACHE.winograd(spec, list(tap9))
+            if U is not None:
+                spec._wwino = U
+                return U
+        U = torch.empty(16, cin // 8, 2, N, 4, device=spec.w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().lwg_winograd_panel_f32(_ptr(spec.w), _ptr(U), cin, N, tap9, _stream()), "lwg_winograd_panel_f32")
+        spec._wwino = U
     return spec._wwino
 
 
@@ -299,7 +317,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_c8_bf16(a, _stream()), "lwg_conv2d_nhwc_c8_bf16")
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
-    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff):
+    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff) and not (splitk and _wino_underfills(spec, y)):
         a.w = _ptr(_wwino(spec))
         kind, sliced = "winograd", False            # per-image buffer descriptors: one launch at any batch size
         _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
@@ -803,7 +821,12 @@ class PanelCache:
         call (e.g. the concatenated image + mask regressors of the fused head's backward) lives in a temporary: its address
         changes every step, so it is packed by a single launch each time and never registered."""
         self.out, self.rows, self.keep, self.table, self.blocks = {}, [], [], None, 0
+        params = list(params)
         self.storages = {p.untyped_storage().data_ptr() for p in params}
+        self.training_storages = {p.untyped_storage().data_ptr() for p in params if p.requires_grad}    # (pack_panel sees detached views)
+        # Winograd fragment panels derived from registered GEMM panels (ops._wwino): key (panel address, tap order) -> U; the ones whose
+        # weights train are re-derived by ONE launch per step behind the GEMM panels' refresh (lwg_winograd_panels_f32)
+        self.src_of, self.wino, self.wino_rows, self.wino_table, self.wino_blocks = {}, {}, [], None, 0
 
     def cacheable(self, w):
         return w.untyped_storage().data_ptr() in self.storages
@@ -820,6 +843,7 @@ class PanelCache:
         Kp = (len(kidx) * cin_pad + 31) // 32 * 32
         out = torch.empty(Kp // 4, n_pad, 4, device=w.device, dtype=torch.float32)
         self.out[key] = out
+        self.src_of[out.data_ptr()] = w
         self.keep.append(w)
         self.rows.append((w.data_ptr(), out.data_ptr(), D1, KH * KW, 1 if transposed else 0, len(kidx), cin, cin_pad, nout, n_pad, Kp, kidx))
         self.table = None
@@ -842,6 +866,42 @@ class PanelCache:
             self.table = raw.to(self.keep[0].device)
             self.blocks = first
         _lib.check(_lib.lib().lwg_pack_panels_f32(self.table.data_ptr(), len(self.rows), self.blocks, _stream()), "lwg_pack_panels_f32")
+        if self.wino_rows:
+            if self.wino_table is None:
+                descs = (_lib.LwgWinoDesc * len(self.wino_rows))()
+                first = 0
+                for d, (wp, up, cin, N, tap9) in zip(descs, self.wino_rows):
+                    d.wpanel, d.upk, d.Cin, d.N, d.first_block = wp, up, cin, N, first
+                    for i in range(9):
+                        d.tap9[i] = tap9[i]
+                    first += ((N + 63) // 64) * ((cin + 3) // 4)
+                raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+                self.wino_table = raw.to(self.keep[0].device)
+                self.wino_blocks = first
+            _lib.check(_lib.lib().lwg_winograd_panels_f32(self.wino_table.data_ptr(), len(self.wino_rows), self.wino_blocks, _stream()),
+                       "lwg_winograd_panels_f32")
+
+    def winograd(self, spec, tap9):
+        """The fragment panel of a spec whose GEMM panel is registered here, or None (a per-call temporary: single launch each time).  First
+        request: allocated, built by a single launch and - when the source weight trains - registered for the per-step refresh."""
+        w = self.src_of.get(spec.w.data_ptr())
+        if w is None:
+            return None
+        key = (spec.w.data_ptr(), tuple(tap9))
+        U = self.wino.get(key)
+        if U is None:
+            trains = w.untyped_storage().data_ptr() in self.training_storages
+            if self.wino_table is not None and trains and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PanelCache: a Winograd panel was requested for the first time inside a hipGraph capture: run one eager step first")
+            K4, N, _ = spec.w.shape
+            U = torch.empty(16, spec.Cin // 8, 2, N, 4, device=spec.w.device, dtype=torch.float32)
+            arr = (ctypes.c_int * 9)(*tap9)
+            _lib.check(_lib.lib().lwg_winograd_panel_f32(_ptr(spec.w), _ptr(U), spec.Cin, N, arr, _stream()), "lwg_winograd_panel_f32")
+            self.wino[key] = U
+            if trains:                                       # frozen weights (the loss networks): built once
+                self.wino_rows.append((spec.w.data_ptr(), U.data_ptr(), spec.Cin, N, tuple(tap9)))
+                self.wino_table = None
+        return U
 
 
 PANEL_CACHE = None      # a PanelCache while a trainer step runs (trainers.LWGTrainer), else None: every pack_panel call launches
@@ -935,6 +995,25 @@ def crop_resize_bwd(dy, box, in_hw):
     dx = dy.new_zeros(N, C, H, W)
     _lib.check(_lib.lib().lwg_crop_resize_bilinear_bwd_f32(_ptr(dy.contiguous()), _ptr(box.contiguous(), torch.int64), _ptr(dx), N, C, H, W, OH, OW,
                                                            _stream()), "lwg_crop_resize_bilinear_bwd_f32")
+    return dx
+
+
+def prelu(x, slope, res=None):
+    """(.., C) NHWC fp32, slope (C): res + PReLU(x) in one launch (lwg_prelu_f32; the frozen Sphere20a's activations and residual adds)."""
+    x = x.contiguous()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().lwg_prelu_f32(_ptr(x), _ptr(slope.contiguous()), None if res is None else _ptr(res.contiguous()), x.numel() // C, C, _ptr(y),
+                                        _stream()), "lwg_prelu_f32")
+    return y
+
+
+def prelu_bwd(x, slope, dy):
+    """dx of ``prelu`` (the slopes are frozen; the residual's gradient is dy)."""
+    x, dy = x.contiguous(), dy.contiguous()
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().lwg_prelu_bwd_f32(_ptr(x), _ptr(slope.contiguous()), _ptr(dy), x.numel() // C, C, _ptr(dx), _stream()), "lwg_prelu_bwd_f32")
     return dx
 
 

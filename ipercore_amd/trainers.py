@@ -496,11 +496,30 @@ class VGGLoss(nn.Module):
         return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, fx, fy))
 
 
+class _PReLUFn(torch.autograd.Function):
+    """res + PReLU(x) with frozen per-channel slopes: one launch forward, one backward (ops.prelu / lwg_prelu_f32) - the ten launches of the
+    torch.where form per activation were 1.6 ms of the step with the reference's default loss set."""
+
+    @staticmethod
+    def forward(ctx, x, slope, res):
+        if slope.requires_grad:
+            raise RuntimeError("_PReLUFn: the slopes are frozen (the Sphere20a of the face loss); a trainable nn.PReLU is not part of this path")
+        ctx.save_for_backward(x, slope)
+        ctx.has_res = res is not None
+        return ops.prelu(x, slope, res)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.prelu_bwd(x, slope, dy) if ctx.needs_input_grad[0] else None), None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None)
+
+
 class Sphere20aFeatures(nn.Module):
     """criterions/faceloss.py:203-285 (Sphere20a): 20 frozen 3x3 convolutions (four of them stride 2) with per-channel PReLU and
     residual adds, then fc5; parameter names as in ``sphere20a_20171020.pth`` (conv{b}_{i}, relu{b}_{i}, fc5) so the checkpoint
     loads when present (strict=False: its fc6 classifier head is not part of the loss).  The convolutions run on the MFMA kernels
-    (data gradient only: the network is frozen); PReLU / residual adds / fc5 are PyTorch-ROCm autograd + one library GEMM."""
+    (data gradient only: the network is frozen), PReLU + residual add on one HIP launch each way; fc5 is one library GEMM."""
     BLOCKS = ((1, 3, 64, 3), (2, 64, 128, 5), (3, 128, 256, 9), (4, 256, 512, 3))          # (block, cin, cout, number of convs)
 
     def __init__(self, ckpt_path=None, seed=0, allow_seeded=False):
@@ -521,10 +540,10 @@ class Sphere20aFeatures(nn.Module):
         self.fc5.bias = nn.Parameter(torch.zeros(512), requires_grad=False)
         _load_frozen(self, ckpt_path, allow_seeded, "SphereFace loss (use_face)")
 
-    def _cp(self, b, i, x, stride=1, first=False):
+    def _cp(self, b, i, x, stride=1, first=False, res=None):
         c, a = getattr(self, f"conv{b}_{i}"), getattr(self, f"relu{b}_{i}")
         y = conv(x, c.weight, c.bias, stride=stride, cin_pad=64 if first else None)
-        return torch.where(y >= 0, y, y * a.weight)                                      # nn.PReLU(C) on NHWC
+        return _PReLUFn.apply(y, a.weight, res)                                          # nn.PReLU(C) on NHWC (+ the block's residual add)
 
     def forward(self, x_nchw):
         """(N,3,112,96) -> [block1 (N,56,48,64), block2 (N,28,24,128), block3 (N,14,12,256), block4 (N,7,6,512), fc5 (N,512)]."""
@@ -533,7 +552,7 @@ class Sphere20aFeatures(nn.Module):
         for b, cin, cout, n in self.BLOCKS:
             x = self._cp(b, 1, x, stride=2, first=b == 1)
             for i in range(2, n + 1, 2):
-                x = x + self._cp(b, i + 1, self._cp(b, i, x))
+                x = self._cp(b, i + 1, self._cp(b, i, x), res=x)
             outs.append(x)
         outs.append(F.linear(x.permute(0, 3, 1, 2).reshape(x.shape[0], -1), self.fc5.weight, self.fc5.bias))
         return outs
@@ -602,9 +621,11 @@ class TrainOpts(object):
     lambda_rec, lambda_tsf, lambda_mask, lambda_mask_smooth, lambda_D_prob = 10.0, 10.0, 5.0, 1.0, 1.0
     lr_G, lr_D = 1e-4, 1e-4
     G_adam_b1, G_adam_b2, D_adam_b1, D_adam_b2 = 0.9, 0.999, 0.9, 0.999
-    # "split": forward and data-gradient convs with Cin % 32 == 0 run on the bf16x6 kernel (fp32-level accuracy);
-    # weight gradients stay on the fp32 MFMA kernel
-    conv_precision = "fp32"
+    # "winograd" (default since round 5): the 3 x 3 / stride 1 forward and data-gradient convolutions run as F(2x2,3x3) Winograd
+    # convolutions on the fp32 matrix pipe (csrc/conv_winograd.hip; launches too small to fill the chip keep the direct split-K form:
+    # ops.WINO_MIN_GRID), everything else - and every weight gradient - on the direct fp32 MFMA kernels; "fp32": all direct;
+    # "split": forward and data-gradient convs with Cin % 32 == 0 on the bf16x6 kernel (fp32-level accuracy)
+    conv_precision = "winograd"
     # "VGG19": the transfer loss is the VGG19 perceptual loss (deploy.toml:83, the reference's default) instead of L1;
     # vgg_loss_path: torchvision vgg19 state_dict (used when the file exists, seeded weights otherwise)
     use_vgg = "VGG19"

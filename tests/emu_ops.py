@@ -475,6 +475,21 @@ def grid_sample(x, grid):
     return torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
+def winograd_panel(spec):
+    """lwg_winograd_panel_f32's contract in torch (fp64, rounded once): Upk[16][Cin/8][2][N][4] from the fp32 GEMM panel of a 3x3 ConvSpec."""
+    K4, N, _ = spec.w.shape
+    cin, nt = spec.Cin, spec.ntaps
+    assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin
+    wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)                                    # k' = ((c // 32) * ntaps + tap) * 32 + c % 32
+    w = wk.view(cin // 32, nt, 32, N).permute(1, 0, 2, 3).reshape(nt, cin, N).double()     # [tap][c][n]
+    g = w.new_zeros(3, 3, cin, N)
+    for t in range(nt):
+        g[spec.dy[t] + 1, spec.dx[t] + 1] = w[t]
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    U = torch.einsum("ij,jkcn,lk->ilcn", G, g, G).reshape(16, cin, N)
+    return U.view(16, cin // 8, 4, 2, N).permute(0, 1, 3, 4, 2).contiguous().float()
+
+
 def _crop_ref(x, box, out_hw):
     """lwg_crop_resize_bilinear_f32's contract in the reference's own formulation (faceloss.py:384-406): per-sample slice + F.interpolate."""
     N = x.shape[0]
@@ -501,12 +516,21 @@ def crop_resize_bwd(dy, box, in_hw):
     return x.grad.detach()
 
 
+def prelu(x, slope, res=None):
+    y = torch.where(x >= 0, x, x * slope)
+    return y if res is None else res + y
+
+
+def prelu_bwd(x, slope, dy):
+    return torch.where(x >= 0, dy, dy * slope)
+
+
 def install(monkeypatch):
     """Route ipercore_amd.ops.* to the emulation and relax the CUDA-only guards (tests only)."""
     for name in ("conv2d", "instnorm_stats", "instnorm_apply", "lwb_attention", "head_compose", "nchw_to_nhwc",
                  "nhwc_to_nchw", "project_faces", "rasterize_fim_wim", "bc_transform", "encode_fim", "flow_compose",
                  "smpl_lbs", "conv2d_wgrad", "colsum", "act_bwd", "lwb_fuse", "pack_panel", "unpack_wgrad", "norm_fwd", "norm_bwd",
-                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize", "attn_records", "instnorm_finalize_ws", "crop_resize", "crop_resize_bwd"):
+                 "lwb_attention_bwd", "lwb_attention_kv", "lwb_attention_kv_bwd", "adam_step", "adam_step_dev", "conv2d_wgrad_unpacked", "maxpool2_fwd", "maxpool2_bwd", "flow_resize", "frames_to_u8", "thin_conv", "conv_transpose2d", "texture_sample", "grid_sample", "lwb_attention_x", "instnorm_finalize", "attn_records", "instnorm_finalize_ws", "crop_resize", "crop_resize_bwd", "prelu", "prelu_bwd"):
         monkeypatch.setattr(real_ops, name, globals()[name])
     from ipercore_amd.networks import generator
     monkeypatch.setattr(generator.AttentionLWBGenerator, "_check", lambda self, *a: None)

@@ -34,8 +34,9 @@ def test_conv_args_struct_layout_matches_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "lwg_hip.h"
-    int main(void) { printf("%zu %zu %zu %zu %zu %zu\n", sizeof(LwgConvArgs), offsetof(LwgConvArgs, w),
-        offsetof(LwgConvArgs, y), offsetof(LwgConvArgs, res), offsetof(LwgConvArgs, dy), offsetof(LwgConvArgs, dx)); return 0; }
+    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(LwgConvArgs), offsetof(LwgConvArgs, w),
+        offsetof(LwgConvArgs, y), offsetof(LwgConvArgs, res), offsetof(LwgConvArgs, dy), offsetof(LwgConvArgs, dx),
+        sizeof(LwgWinoDesc), offsetof(LwgWinoDesc, upk), offsetof(LwgWinoDesc, first_block), offsetof(LwgWinoDesc, tap9)); return 0; }
     '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -45,7 +46,9 @@ def test_conv_args_struct_layout_matches_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     A = _lib.LwgConvArgs
-    assert got == [ctypes.sizeof(A), A.w.offset, A.y.offset, A.res.offset, A.dy.offset, A.dx.offset]
+    Wd = _lib.LwgWinoDesc
+    assert got == [ctypes.sizeof(A), A.w.offset, A.y.offset, A.res.offset, A.dy.offset, A.dx.offset,
+                   ctypes.sizeof(Wd), Wd.upk.offset, Wd.first_block.offset, Wd.tap9.offset]
 
 
 def test_invalid_arguments_are_rejected_on_the_host():
@@ -55,6 +58,11 @@ def test_invalid_arguments_are_rejected_on_the_host():
     L = _lib.lib()
     bad = 0xdead0000                     # a non-NULL pointer that is never dereferenced: the shape checks fail first
     a = _lib.LwgConvArgs()
+    assert L.lwg_winograd_panel_f32(None, None, 64, 64, None, None) == 1 and L.lwg_winograd_panels_f32(None, 0, 0, None) == 1
+    assert L.lwg_crop_resize_bilinear_f32(None, None, None, None, 1, 3, 8, 8, 4, 4, None) == 1
+    assert L.lwg_prelu_f32(None, None, None, 4, 64, None, None) == 1 and L.lwg_prelu_f32(bad, bad, None, 4, 6, bad, None) == 1      # C % 4
+    assert L.lwg_prelu_bwd_f32(bad, bad, None, 4, 64, bad, None) == 1                                                               # no dy
+    assert L.lwg_conv_slice_count(None) == 0
     assert L.lwg_conv2d_nhwc_f32(None, None) == 1
     assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # NULL tensors
     a.x0, a.w, a.y = bad, bad, bad

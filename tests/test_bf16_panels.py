@@ -4,6 +4,7 @@ The kernels' own arithmetic is checked on the GPU (tests/gpu_checks.py check_bf1
 import itertools
 
 import numpy as np
+import pytest
 import torch
 
 from ipercore_amd import ops
@@ -205,8 +206,11 @@ def test_winograd_panel_and_eligibility():
     N, Cin = 64, 32
     w, b = torch.randn(N, Cin, 3, 3, generator=g) * 0.1, torch.randn(N, generator=g)
     spec = packing.pack_conv(w, b, stride=1, pad=1)
-    Upk = ops._wwino(spec)
-    assert tuple(Upk.shape) == (16, Cin // 8, 2, N, 4) and Upk.dtype == torch.float32 and ops._wwino(spec) is Upk
+    from tests import emu_ops
+    Upk = emu_ops.winograd_panel(spec)               # the contract of lwg_winograd_panel_f32 (the GPU suite holds the kernel against it)
+    assert tuple(Upk.shape) == (16, Cin // 8, 2, N, 4) and Upk.dtype == torch.float32
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._wwino(spec)
     U = Upk.permute(0, 1, 4, 2, 3).reshape(16, Cin, N)                       # [p][c = 8 s + 2 kk + kh][n]
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
     assert torch.allclose(U, torch.einsum("ij,ncjk,lk->ilcn", G, w, G).reshape(16, Cin, N), atol=1e-7)

@@ -1,7 +1,7 @@
 """Lab: the fused Winograd convolution (csrc/conv_winograd.hip) on the launch shapes of the 512 x 512 generator, per shape: launch time, executed
 TFLOP/s (2 M 4 Cin N - sixteen products per 2 x 2 outputs) against the fp32 matrix pipe (157.3), algorithmic TFLOP/s (2 M 9 Cin N), the direct kernel's
 time for the same launch and max |wino - direct|.
-usage: winoshapes.py [--lib LIB.so] [--frames F] [--only i] [--reps n] [--nodirect] [--ts]
+usage: winoshapes.py [--lib LIB.so] [--frames F] [--only i] [--reps n] [--nodirect] [--splitk] [--vgg] [--ts]
   --lib     a variant library (tools/labvariant.sh NAME conv_winograd.hip -D...) instead of the tree's
   --only i  shape i only (PMC passes: rocprofv3 --pmc ... -- python tools/winoshapes.py --only 0 --nodirect)
   --ts      the library is a -DLWG_WINO_TS build: print the per-workgroup phase timeline (s_memtime) of shape --only (plain epilogue)"""
@@ -17,6 +17,8 @@ ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--nodirect", action="store_true")
 ap.add_argument("--ts", action="store_true")
+ap.add_argument("--splitk", action="store_true", help="the direct side with splitk=True (how the training convolutions call it)")
+ap.add_argument("--vgg", action="store_true", help="the VGG19 perceptual loss's launch shapes (224 x 224 input) instead of the generator's")
 ap.add_argument("--ts2", action="store_true", help="-DLWG_WINO_TS2 build: per-wave slot timeline of iterations 8 and 9 (shape --only, plain epilogue, Cin >= 96)")
 args = ap.parse_args()
 import torch
@@ -38,6 +40,9 @@ SHAPES = [("res 64^2 256->256 residual", 1, 64, 256, 0, 256, "res"),
           ("spade gamma|beta 256^2 128->2x64", 1, 256, 128, 0, 64, "spade"),
           ("skip0 128^2 256+128->256", 1, 128, 256, 128, 256, "none"),
           ("skip1 256^2 128+64->128", 1, 256, 128, 64, 128, "none")]
+if args.vgg:
+    SHAPES = [(f"vgg {S}^2 {ci}->{co}", 1, S, ci, 0, co, "none") for S, ci, co in
+              ((224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256), (28, 256, 512), (28, 512, 512), (14, 512, 512))]
 
 
 def rnd(shape, seed, scale=1.0):
@@ -126,7 +131,7 @@ for idx, (tag, mul, S, C0, C1, Co, epi) in enumerate(SHAPES):
             ops.conv2d(x0, spec, yw, x1=x1, **kw)
 
     def run_d():
-        ops.conv2d(x0, spec, yd, x1=x1, **kw)
+        ops.conv2d(x0, spec, yd, x1=x1, splitk=args.splitk, **kw)
 
     run_w()
     tw = timeit(run_w, args.reps)
