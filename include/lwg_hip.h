@@ -109,6 +109,13 @@ int lwg_conv2d_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
  * fp32-grade results (relative error against fp64 1.6x the direct kernel's), not bitwise those of lwg_conv2d_nhwc_f32: a precision mode
  * of its own (ops.conv_precision("winograd")); a frame's result does not depend on the batch it is launched in. */
 int lwg_conv2d_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
+/* The same launch with an optional workspace (the training step's one-sample launches): when the launch's 64-patch x 32-channel workgroups would
+ * cover half the CUs or less (plain epilogue, or LWG_EPI_RESIDUAL with LWG_ACTIVATION_RELU_MASK) the K loop runs in lwg_conv2d_winograd_ws_floats(args)
+ * / (M N) slices of >= 64 input channels whose dense (M, N) slabs the finishing kernel of lwg_conv2d_nhwc_f32_ws adds in slice order (deterministic).
+ * lwg_conv2d_winograd_ws_floats returns 0 when the launch would not be split (or does not meet the contract above); ws = NULL runs it whole.
+ * The synthesis path never passes one: a frame must not depend on its batch. */
+size_t lwg_conv2d_winograd_ws_floats(const LwgConvArgs* args);
+int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stream);
 /* The fragment panel Upk[16][Cin/8][2][N][4] of the call above from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w, nine taps,
  * Cin % 32 == 0): U = G w G^T per (input channel, output column) in fp64, rounded once.  tap9[3 r + s] = index of the tap (dy, dx) = (r - 1, s - 1)
  * in the GEMM panel's tap order.  With LWG_EPI_RESIDUAL the Winograd call also takes LWG_ACTIVATION_RELU_MASK (the data gradient behind a ReLU). */

@@ -59,6 +59,8 @@ _SIGS = {
     "lwg_conv2d_nhwc_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_conv2d_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_winograd_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv2d_winograd_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
+    "lwg_conv2d_winograd_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
     "lwg_winograd_panel_f32": (c_i, [c_f, c_f, c_i, c_i, ctypes.POINTER(c_i), c_f]),
     "lwg_winograd_panels_f32": (c_i, [c_f, c_i, c_i, c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),

@@ -440,6 +440,14 @@ __global__ __launch_bounds__(256) void lwg_splitk_finish_kernel(const LwgConvArg
     }
 }
 
+// (also the finish of the Winograd kernel's split launches: conv_winograd.hip)
+hipError_t lwg_splitk_finish_launch(const LwgConvArgs& a, const float* ws, int slices, hipStream_t stream) {
+    const size_t total4 = (size_t)a.M * (a.N / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(lwg_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, slices);
+    return hipGetLastError();
+}
+
 // Split-K plan of a launch (0 slices = run it whole).  Only the 64x64-tile regime (one training sample, the discriminator's
 // deep layers: M of a few thousand rows against K of a few thousand) is split: the tile grid alone leaves most CUs with one
 // workgroup or none, while 3-4 fit (33 KB LDS, ~80 VGPRs).  Slices are whole 32-channel chunks (all taps of a chunk stay
@@ -482,10 +490,7 @@ static hipError_t launch_cfg(const LwgConvArgs& a, hipStream_t stream, float* ws
         const int slices = ws ? lwg_conv_split_plan(a, &cps) : 0;
         if (slices > 1) {
             hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, slices), dim3(256), lds, stream, a, cps, ws, 0u);
-            const size_t total4 = (size_t)a.M * (a.N / 4);
-            const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-            hipLaunchKernelGGL(lwg_splitk_finish_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, slices);
-            return hipGetLastError();
+            return lwg_splitk_finish_launch(a, ws, slices, stream);
         }
     }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, 0, (float*)nullptr, 0u);

@@ -68,15 +68,18 @@ __device__ __forceinline__ floatx4 wino_buf_load(__amdgpu_buffer_rsrc_t r, unsig
 // same 64 patches x 32 channels, wave w = (xi = w % 4, patch tile w / 4) with ONE accumulator tile per product: twice the workgroups of half the
 // matrix work each, so that a launch that would leave most of the chip idle fills it.  Every output element is accumulated over the stages and
 // k-pairs in the same order and finished by the same expressions in both forms: bitwise the same result (a frame does not depend on its batch).
-template <int EPI, int NBV>
+// SPLIT (training launches that leave half the chip or more idle; NBV = 32, plain epilogue): blockIdx.z owns the stages [z a.cshift, (z + 1) a.cshift)
+// of the K loop (a.cshift - unused by convolutions with Cin >= 32 - carries the stages per slice here) and leaves raw sums in its dense (M, N) slab
+// a.y + z M N (the host passes YC = N, ycoff = 0, no bias, no activation); lwg_splitk_finish_kernel adds the slabs in slice order and finishes.
+template <int EPI, int NBV, bool SPLIT = false>
 __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NBV / 32;                             // accumulator (patch) tiles per product and wave
     constexpr int MSR = NBV + 4;                             // floats per (plane, patch) row of the epilogue's exchange buffer
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ bias = a.bias;
-    float* __restrict__ y = a.y;
     const int H = a.H, W = a.W, Cin = a.C0 + a.C1, N = a.N;
+    float* __restrict__ y = SPLIT ? a.y + (size_t)blockIdx.z * (size_t)a.M * (size_t)N : a.y;
     float* const raw0 = smem;                                // [2][RAW]
     float* const Vs0 = smem + 2 * RAW_FLOATS;                // [2][VS]
     float* Ms = smem;                                        // the epilogue's exchange buffer (after the K loop)
@@ -87,7 +90,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     blk -= b * bx * by;
     const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
     const int n0 = blockIdx.y * NBV;
-    const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
+    const int nst_all = Cin / KS;                            // even (host: Cin % 16 == 0)
+    const int sbeg = SPLIT ? (int)blockIdx.z * a.cshift : 0; // this workgroup's first stage and its number of stages (even as well)
+    const int nst = SPLIT ? (a.cshift < nst_all - sbeg ? a.cshift : nst_all - sbeg) : nst_all;
     WTS(0);
     // buffer resources: this image of each input, the weight panel
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     }
     floatx4 rreg[2];
     auto rld1 = [&](int st, int q) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
-        const int c = st * KS;
+        const int c = (st + sbeg) * KS;
         return c < a.C0 ? wino_buf_load(rx0, voff0[q], (unsigned)c * 4u) : wino_buf_load(rx1, voff1[q], (unsigned)(c - a.C0) * 4u);
     };
     auto rst1 = [&](int buf, int q, floatx4 v) {
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     const unsigned ustage = (unsigned)N * 32u;               // bytes between two stages of a product: [2][N][4] floats
     unsigned usoff[4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) usoff[nu] = (unsigned)(4 * xi + nu) * (unsigned)nst * ustage;
+    for (int nu = 0; nu < 4; ++nu) usoff[nu] = ((unsigned)(4 * xi + nu) * (unsigned)nst_all + (unsigned)sbeg) * ustage;
     auto uld1 = [&](int st, int nu) -> floatx4 { return wino_buf_load(ru, uvoff, usoff[nu] + (unsigned)st * ustage); };
     const int patch = tid & 63, tc = tid >> 6;
     const int pty = patch >> 3, ptx = patch & 7;
@@ -505,24 +510,61 @@ extern "C" int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, 
 // or LWG_EPI_SPADE (N = 2 YC, columns gamma | beta interleaved in blocks of 32, ycoff = 0); any activation of lwg_act; every image of an input
 // < 3 GiB) EXCEPT args->w = the Winograd fragment panel Upk[16][Cin/8][2][N][4]: element (p, s, kh, n, kk) = (G w G^T)[xi = p / 4][nu = p % 4] of
 // input channel 8 s + 2 kk + kh (concatenated order) and output column n.
-extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!pa) return (int)hipErrorInvalidValue;
-    const LwgConvArgs& a = *pa;
+static bool lwg_wino_contract(const LwgConvArgs& a);
+
+// Split plan of a training launch (0 = run it whole): a launch whose 64-patch x 32-channel workgroups cover half the CUs or less runs its K loop
+// in 2 .. 8 slices of >= 8 stages (64 input channels; each slice pays the prologue and the epilogue again) - twice to eight times the workgroups.
+// Plain epilogues and the ReLU-mask data gradient only (what lwg_splitk_finish_kernel finishes).
+static int lwg_wino_split_plan(const LwgConvArgs& a, int* stages_per_slice) {
+    const bool mask = a.epi == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK;
+    if (!LWG_WINO_SPLITK || (a.epi != LWG_EPI_NONE && !mask)) return 0;
+    const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
+    const long blocks32 = (long)bx * by * a.B * (a.N / 32);
+    if (blocks32 > 128) return 0;
+    const int nst = (a.C0 + a.C1) / KS;
+    int want = (int)(256 / blocks32);
+    if (want > 8) want = 8;
+    int sps = (nst + want - 1) / want;
+    if (sps < 8) sps = 8;
+    sps += sps & 1;
+    const int slices = (nst + sps - 1) / sps;
+    if (slices < 2) return 0;
+    *stages_per_slice = sps;
+    return slices;
+}
+
+extern "C" size_t lwg_conv2d_winograd_ws_floats(const LwgConvArgs* pa) {
+    if (!pa || !lwg_wino_contract(*pa)) return 0;
+    int sps = 0;
+    return (size_t)lwg_wino_split_plan(*pa, &sps) * (size_t)pa->M * (size_t)pa->N;
+}
+
+extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stream_t stream_);
+extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) { return lwg_conv2d_winograd_f32_ws(pa, nullptr, stream_); }
+
+static bool lwg_wino_contract(const LwgConvArgs& a) {
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C0 <= 0 || (a.C0 % KS) != 0 || a.C1 < 0 ||
         (a.C1 % KS) != 0 || ((a.C0 + a.C1) % (2 * KS)) != 0 || (a.C1 > 0 && !a.x1) || a.N <= 0 || (a.N % NB) != 0 || a.OH != a.H || a.OW != a.W ||
         a.YH != a.H || a.YW != a.W || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.M != a.B * a.H * a.W || a.ycoff < 0 || (a.ycoff % 4) != 0 ||
         (a.YC % 4) != 0 || (a.act == LWG_ACT_RELU_MASK && a.epi != LWG_EPI_RESIDUAL))
-        return (int)hipErrorInvalidValue;
+        return false;
     if (a.epi == LWG_EPI_SPADE) {
-        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return (int)hipErrorInvalidValue;
+        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return false;
     } else {
-        if (a.ycoff + a.N > a.YC) return (int)hipErrorInvalidValue;
-        if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return (int)hipErrorInvalidValue;
+        if (a.ycoff + a.N > a.YC) return false;
+        if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return false;
     }
     const unsigned long long cmax = (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1);
     if ((unsigned long long)a.H * a.W * cmax * 4ull >= (unsigned long long)WINO_OOB || 64ull * (a.C0 + a.C1) * a.N >= 0xffffffffull)
-        return (int)hipErrorInvalidValue;
+        return false;
+    return true;
+}
+
+// ws: NULL, or lwg_conv2d_winograd_ws_floats(args) floats - a launch that would leave half the chip idle then runs split over K through it.
+extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa || !lwg_wino_contract(*pa)) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
     const size_t loop = (size_t)LOOP_FLOATS * 4, epi = (size_t)MS_FLOATS * 4;
     const size_t lds = loop > epi ? loop : epi;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
@@ -538,8 +580,25 @@ extern "C" int lwg_conv2d_winograd_f32(const LwgConvArgs* pa, lwg_stream_t strea
     }
     const long rounds64 = (blocks64 + cus - 1) / cus, rounds32 = (2 * blocks64 + cus - 1) / cus;
     const bool small = a.epi != LWG_EPI_SPADE && (double)rounds32 * 0.55 < (double)rounds64;
+    static unsigned long long done[6] = {0, 0, 0, 0, 0, 0};
+    int sps = 0;
+    const int slices = ws ? lwg_wino_split_plan(a, &sps) : 0;
+    if (slices > 1) {
+        auto kern = lwg_conv_winograd_kernel<LWG_EPI_NONE, 32, true>;
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[5]); e != hipSuccess) return (int)e;
+        LwgConvArgs part = a;                                // raw sums into the slabs: dense (M, N) rows, no bias / residual / activation
+        part.y = ws;
+        part.YC = a.N;
+        part.ycoff = 0;
+        part.bias = nullptr;
+        part.epi = LWG_EPI_NONE;
+        part.act = LWG_ACT_NONE;
+        part.res = nullptr;
+        part.cshift = sps;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(bx * by * a.B), (unsigned)(a.N / 32), (unsigned)slices), dim3(WG_THREADS), lds, stream, part);
+        return (int)lwg_splitk_finish_launch(a, ws, slices, stream);
+    }
     const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / (small ? 32 : NB)));
-    static unsigned long long done[5] = {0, 0, 0, 0, 0};
 #define LWG_WINO_GO(E, V, SLOT)                                                                                                       \
     {                                                                                                                                 \
         if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E, V>), lds, done[SLOT]); e != hipSuccess) \

@@ -17,6 +17,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef LWG_CONV_SPLITK
 #define LWG_CONV_SPLITK 1          // conv_igemm.hip: split-K of the small-M fp32 launches that hand in a workspace (0 = never)
 #endif
+#ifndef LWG_WINO_SPLITK
+#define LWG_WINO_SPLITK 1          // conv_winograd.hip: split-K of the training launches that cover half the CUs or less and hand in a workspace (0 = never)
+#endif
 #ifndef LWG_CONV_SMALL_TILES
 #define LWG_CONV_SMALL_TILES 300   // conv_igemm.hip: launches with fewer 128 x 128 tiles than this use 64 x 64 tiles
 #endif
@@ -119,6 +122,10 @@ __device__ __forceinline__ bool lwg_tile_frame_pixel(long L, int B, int h, int w
     return ty < tiles_y && y < h && x < w;
 }
 static inline long lwg_tile_frame_positions(int B, int h, int w) { return (long)((w + 7) >> 3) * ((h + 7) >> 3) * B * 64; }
+
+// conv_igemm.hip: y = act(sum of the (M, N) slabs in slice order + bias) (| ReLU mask) - the finish of a split-K launch of either conv engine
+struct LwgConvArgs;
+hipError_t lwg_splitk_finish_launch(const LwgConvArgs& a, const float* ws, int slices, hipStream_t stream);
 
 static inline hipError_t lwg_allow_dynamic_lds(const void* kern, size_t bytes, unsigned long long& done) {
     int dev = 0;

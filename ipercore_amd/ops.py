@@ -206,15 +206,23 @@ def _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff=0):
     return hw == (x0.shape[1], x0.shape[2]) == (y.shape[1], y.shape[2])
 
 
-WINO_MIN_GRID = 128     # workgroups (64 patches x 32 channels) below which a splitk=True caller gets the direct split-K form instead
+WINO_MIN_GRID = 128     # workgroups (64 patches x 32 channels, times the K slices) below which a splitk=True caller gets the direct split-K form instead
+WINO_SPLITK = True      # lab switch: False = training launches never split the Winograd kernel's K loop
 
 
-def _wino_underfills(spec, y):
-    """A training launch (splitk=True) whose Winograd grid would leave most of the 256 CUs idle - a 28 x 28 x 512 VGG19 layer is 64
-    workgroups of 64 K stages each: 79 us against the direct kernel's split-K 51 us; 56 x 56 x 256 (128 workgroups) is the break-even
+def _wino_plan(a, spec, y, splitk):
+    """How an eligible launch runs in the "winograd" mode: 0 = the Winograd kernel whole, n > 0 = split over K through a workspace of n floats
+    (lwg_conv2d_winograd_f32_ws), None = not on the Winograd kernel.  Only a training launch (splitk=True) asks: one whose Winograd grid would leave
+    most of the 256 CUs idle - a 28 x 28 x 512 VGG19 layer is 64 workgroups of 64 K stages each, 79 us whole against the direct kernel's split-K
+    51 us - runs its K loop in slices when that fills the chip, and stays on the direct split-K kernel when even the slices do not
     (profiles/r05_g_winograd_small_launches.txt).  The synthesis path never asks (splitk=False: batch invariance)."""
-    tiles = y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 15) // 16)
-    return tiles * (spec.N // 32) < WINO_MIN_GRID
+    if not splitk:
+        return 0
+    blocks = y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 15) // 16) * (spec.N // 32)
+    nws = int(_lib.lib().lwg_conv2d_winograd_ws_floats(a)) if WINO_SPLITK else 0
+    if nws:
+        blocks *= nws // (a.M * spec.N)
+    return nws if blocks >= WINO_MIN_GRID else None
 
 
 def _wwino(spec):
@@ -278,9 +286,10 @@ def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=Non
     return a
 
 
-def _hook_end(a, spec, epi, kind, slices=True):
-    """Closing hook call: how many kernel launches the entry point made (the C rule: lwg_conv_slice_count) and which kernel family ran."""
-    n = max(1, int(_lib.lib().lwg_conv_slice_count(a))) if slices else 1
+def _hook_end(a, spec, epi, kind, slices=True, extra=0):
+    """Closing hook call: how many kernel launches the entry point made (the C rule: lwg_conv_slice_count; extra: a split launch's finishing
+    kernel) and which kernel family ran."""
+    n = (max(1, int(_lib.lib().lwg_conv_slice_count(a))) if slices else 1) + extra
     CONV_HOOK(False, a.M, spec, epi, {"kernels": n, "kind": kind})
 
 
@@ -295,7 +304,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         raise ValueError("channel-quad-plane outputs: fp32 activations on the fp32 MFMA path, no split-K")
     if CONV_HOOK is not None:
         CONV_HOOK(True, a.M, spec, epi, None)
-    kind, sliced = "direct", True
+    kind, sliced, extra = "direct", True, 0
     if x0.dtype == torch.bfloat16:
         kind = "bf16"
         # bf16 activation storage (BASELINE configs[3]): bf16 in, bf16 out, bf16 MFMA operands, fp32 accumulation
@@ -317,10 +326,15 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_c8_bf16(a, _stream()), "lwg_conv2d_nhwc_c8_bf16")
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
-    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff) and not (splitk and _wino_underfills(spec, y)):
+    elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff) and \
+            (nws := _wino_plan(a, spec, y, splitk)) is not None:
         a.w = _ptr(_wwino(spec))
         kind, sliced = "winograd", False            # per-image buffer descriptors: one launch at any batch size
-        _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
+        if nws:
+            ws, extra = torch.empty(nws, device=x0.device, dtype=torch.float32), 1
+            _lib.check(_lib.lib().lwg_conv2d_winograd_f32_ws(a, _ptr(ws), _stream()), "lwg_conv2d_winograd_f32_ws")
+        else:
+            _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
         kind = "split"
@@ -333,7 +347,7 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
         else:
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     if CONV_HOOK is not None:
-        _hook_end(a, spec, epi, kind, sliced)
+        _hook_end(a, spec, epi, kind, sliced, extra)
     return y
 
 
@@ -836,7 +850,7 @@ class PanelCache:
         hit = self.out.get(key)
         if hit is not None:
             return hit, False
-        if self.table is not None and torch.cuda.is_current_stream_capturing():
+        if self.table is not None and torch.cuda.is_current_stream_capturing() and w.untyped_storage().data_ptr() in self.training_storages:
             raise RuntimeError("PanelCache: a panel was requested for the first time inside a hipGraph capture (the table upload is "
                                "not capturable): run one eager step before capturing")
         D0, D1, KH, KW = w.shape
@@ -845,12 +859,14 @@ class PanelCache:
         self.out[key] = out
         self.src_of[out.data_ptr()] = w
         self.keep.append(w)
-        self.rows.append((w.data_ptr(), out.data_ptr(), D1, KH * KW, 1 if transposed else 0, len(kidx), cin, cin_pad, nout, n_pad, Kp, kidx))
-        self.table = None
+        if w.untyped_storage().data_ptr() in self.training_storages:     # a frozen weight (the loss networks) is packed once, by the caller's launch
+            self.rows.append((w.data_ptr(), out.data_ptr(), D1, KH * KW, 1 if transposed else 0, len(kidx), cin, cin_pad, nout, n_pad, Kp, kidx))
+            self.table = None
         return out, True
 
     def refresh(self):
-        """Re-pack every registered panel from the current weights (one launch on the current stream)."""
+        """Re-pack every registered panel of a weight that trains (requires_grad when the cache was built) from the current weights: one launch
+        on the current stream, one more for the Winograd panels derived from them.  Panels of frozen weights are built once."""
         if not self.rows:
             return
         if self.table is None:

@@ -490,10 +490,11 @@ class VGGLoss(nn.Module):
         if self.resize:
             x = F.interpolate(x, size=(224, 224), mode="bilinear", align_corners=True)
             y = F.interpolate(y, size=(224, 224), mode="bilinear", align_corners=True)
-        with torch.no_grad():
-            fy = self.vgg(y)
-        fx = self.vgg(x)
-        return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, fx, fy))
+        # one pass over [x | y] (the network is frozen and has no batch statistics: the same features as two passes, half the launches - a
+        # one-sample launch leaves most of the chip idle); the target half is cut out of the graph
+        n = x.shape[0]
+        f = self.vgg(torch.cat([x, y.detach()], dim=0))
+        return sum(w * F.l1_loss(a[:n], a[n:].detach()) for w, a in zip(self.WEIGHTS, f))
 
 
 class _PReLUFn(torch.autograd.Function):
@@ -605,9 +606,9 @@ class FaceLoss(nn.Module):
             valid = v2 if valid is None else valid * v2
         else:
             h2 = F.interpolate(imgs2, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
-        with torch.no_grad():
-            f2 = self.net(h2)
-        f1 = self.net(h1)
+        n = h1.shape[0]
+        f = self.net(torch.cat([h1, h2.detach()], dim=0))          # one pass over [fake | target] heads (see VGGLoss.forward)
+        f1, f2 = [a[:n] for a in f], [a[n:].detach() for a in f]
         if valid is None:
             return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, f1, f2))
         nv = valid.sum().clamp_min(1.0)                      # no valid head at all: every term is zero (the reference returns 0)

@@ -887,6 +887,28 @@ def check_winograd_mode():
     torch.cuda.synchronize()
     out["relu_mask"] = _cmp(yw, yd.cpu(), 2e-5, "winograd conv, ReLU-mask epilogue")
     assert not torch.equal(yw, yd) and torch.equal(yw == 0, yd == 0)
+    # training launches that leave half the chip idle run their K loop in slices (lwg_conv2d_winograd_f32_ws: slabs + the finishing kernel of the
+    # direct engine's split launches): plain + ReLU and the ReLU-mask data gradient, a two-input launch whose slices cut inside the second input,
+    # against the whole launch (another summation order: not its bits) and a workspace really requested
+    for tag, (B, H, W, C0, C1, N, e_) in (("split_plain", (1, 28, 28, 512, 0, 128, ops.EPI_NONE)), ("split_mask", (1, 30, 23, 256, 0, 64, ops.EPI_RESIDUAL)),
+                                          ("split_two_inputs", (2, 16, 16, 32, 224, 64, ops.EPI_NONE))):
+        ss = _spec_dev(packing.pack_conv(_rand((N, C0 + C1, 3, 3), 192, (9 * (C0 + C1)) ** -0.5), _rand((N,), 193, 0.1), stride=1, pad=1))
+        xs0 = _rand((B, H, W, C0), 194).to(DEV)
+        xs1 = _rand((B, H, W, C1), 195).to(DEV) if C1 else None
+        kw = dict(epi=e_, act=ops.ACT_RELU_MASK, res=_rand((B, H, W, N), 196).to(DEV)) if e_ == ops.EPI_RESIDUAL else dict(act=ops.ACT_RELU)
+        y_whole, y_split = torch.empty(B, H, W, N, device=DEV), torch.empty(B, H, W, N, device=DEV)
+        prev_grid, ops.WINO_MIN_GRID = ops.WINO_MIN_GRID, 0              # (these small cases would otherwise be handed to the direct kernel)
+        try:
+            with ops.conv_precision("winograd"):
+                ops.conv2d(xs0, ss, y_whole, x1=xs1, **kw)
+                a_ = ops.conv_args(xs0, ss, y_split, xs1, kw.get("epi", ops.EPI_NONE), kw["act"], kw.get("res"))
+                assert ops._wino_plan(a_, ss, y_split, True), (tag, "expected a split plan")
+                ops.conv2d(xs0, ss, y_split, x1=xs1, splitk=True, **kw)
+        finally:
+            ops.WINO_MIN_GRID = prev_grid
+        torch.cuda.synchronize()
+        out[tag] = _cmp(y_split, y_whole.cpu(), 2e-5, "winograd conv, K loop in slices (" + tag + ")")
+        assert torch.equal(y_split == 0, y_whole == 0) or e_ != ops.EPI_RESIDUAL
     # the SPADE epilogue (gamma | beta stacked) against the direct kernel's result of the same launch (ragged size)
     B, H, W, C = 2, 19, 37, 64
     sp = _spec_dev(packing.pack_spade_gamma_beta(_rand((C, 128, 3, 3), 178, 0.03), _rand((C,), 179, 0.1), _rand((C, 128, 3, 3), 180, 0.03), _rand((C,), 181, 0.1)))

@@ -17,7 +17,7 @@ ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--nodirect", action="store_true")
 ap.add_argument("--ts", action="store_true")
-ap.add_argument("--splitk", action="store_true", help="the direct side with splitk=True (how the training convolutions call it)")
+ap.add_argument("--splitk", action="store_true", help="the direct side with splitk=True (how the training convolutions call it) + a third column: the Winograd kernel with splitk=True")
 ap.add_argument("--vgg", action="store_true", help="the VGG19 perceptual loss's launch shapes (224 x 224 input) instead of the generator's")
 ap.add_argument("--ts2", action="store_true", help="-DLWG_WINO_TS2 build: per-wave slot timeline of iterations 8 and 9 (shape --only, plain epilogue, Cin >= 96)")
 args = ap.parse_args()
@@ -133,6 +133,10 @@ for idx, (tag, mul, S, C0, C1, Co, epi) in enumerate(SHAPES):
     def run_d():
         ops.conv2d(x0, spec, yd, x1=x1, splitk=args.splitk, **kw)
 
+    def run_ws():                                    # the training form: the K loop in slices when the launch leaves the chip half empty
+        with ops.conv_precision("winograd"):
+            ops.conv2d(x0, spec, ys, x1=x1, splitk=True, **kw)
+
     run_w()
     tw = timeit(run_w, args.reps)
     ex, al = 2.0 * B * S * S * 4 * Cin * N, 2.0 * B * S * S * 9 * Cin * N
@@ -145,6 +149,12 @@ for idx, (tag, mul, S, C0, C1, Co, epi) in enumerate(SHAPES):
         tot_d += td
         torch.cuda.synchronize()
         line += f"  | direct {td * 1e3:8.1f} us ({al / td / 1e9 / 157.3:.3f})  x{td / tw:.2f}  max|d| {float((yw - yd).abs().max()):.1e}"
+    if args.splitk:
+        ys = torch.empty_like(yw)
+        ops.WINO_MIN_GRID = 0
+        run_ws()
+        ts = timeit(run_ws, args.reps)
+        line += f"  | wino split-K {ts * 1e3:8.1f} us (max|d| vs whole {float((ys - yw).abs().max()):.1e})"
     print(line, flush=True)
 if tot_w and args.only < 0:
     print(f"sum: wino {tot_w * 1e3:.1f} us, executed {tot_fl / tot_w / 1e9 / 157.3:.3f} of the pipe" + (f"; direct {tot_d * 1e3:.1f} us (x{tot_d / tot_w:.2f})" if tot_d else ""))
