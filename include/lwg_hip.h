@@ -121,7 +121,7 @@ int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t 
  * in the GEMM panel's tap order.  With LWG_EPI_RESIDUAL the Winograd call also takes LWG_ACTIVATION_RELU_MASK (the data gradient behind a ReLU). */
 int lwg_winograd_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream);
 /* The same for every registered panel of a training step in ONE launch (the weights change every step): descs_dev = ndesc records in DEVICE memory,
- * each the argument list of one lwg_winograd_panel_f32 call plus first_block = the sum of ceil(N / 64) * ceil(Cin / 4) over the records before it;
+ * each the argument list of one lwg_winograd_panel_f32 call plus first_block = the sum of ceil(N / 64) * ceil(Cin / 16) over the records before it;
  * total_blocks = that sum over all records.  Same values as ndesc single launches. */
 typedef struct LwgWinoDesc {
     const float* wpanel;

@@ -417,6 +417,28 @@ __global__ void lwg_pack_panels_kernel(const LwgPackDesc* __restrict__ descs, in
     const int i = ((int)blockIdx.x - d->first_block) * 256 + (int)threadIdx.x;
     if (i >= total) return;
     const float* __restrict__ w = d->w;
+    if ((cin_pad & 31) == 0) {
+        // chunked K order (Kp = ntaps cin_pad): a thread owns one output column x FOUR input channels and walks the taps - per channel it reads
+        // (a subset of) KHW consecutive floats, a whole cache sector's worth, instead of 4 bytes of a sector per tap (the launch was bound by
+        // the L2 -> L1 traffic of 32-byte sectors used once: 0.32 ms for 350 MB, r05_g); the descriptor's other workgroups have nothing to do
+        if (i >= (cin_pad >> 2) * n_pad) return;
+        const int cq = i / n_pad, n = i - cq * n_pad, c0 = cq * 4;
+        const size_t ob = ((size_t)(c0 >> 5) * ntaps * 8 + ((c0 & 31) >> 2)) * n_pad + n;      // float4 index of tap 0
+        size_t src[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) src[kk] = ((size_t)(tr ? c0 + kk : n) * D1 + (tr ? n : c0 + kk)) * KHW;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < nout) {
+                const int kp = d->kidx[tap];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (c0 + kk < cin) v[kk] = w[src[kk] + kp];
+            }
+            *reinterpret_cast<floatx4*>(d->out + (ob + (size_t)tap * 8 * n_pad) * 4) = v;
+        }
+        return;
+    }
     const int k4 = i / n_pad, n = i - k4 * n_pad;
     floatx4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

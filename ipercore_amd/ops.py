@@ -890,7 +890,7 @@ class PanelCache:
                     d.wpanel, d.upk, d.Cin, d.N, d.first_block = wp, up, cin, N, first
                     for i in range(9):
                         d.tap9[i] = tap9[i]
-                    first += ((N + 63) // 64) * ((cin + 3) // 4)
+                    first += ((N + 63) // 64) * ((cin + 15) // 16)
                 raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
                 self.wino_table = raw.to(self.keep[0].device)
                 self.wino_blocks = first

@@ -3,6 +3,7 @@ whole per-frame path against the oracle and the reference-generated golden fixtu
 dict of metrics and raises AssertionError on failure; ``tests/test_gpu_parity.py`` runs them under pytest
 (-m gpu) and ``tools/gpu_diag.py`` runs them all and dumps a JSON report (nothing here reads /root/reference).
 """
+import ctypes
 import hashlib
 import math
 import os
@@ -2563,7 +2564,71 @@ def check_attention_backward():
     return out
 
 
-ALL = [check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
+def check_panel_cache_refresh():
+    """ops.PanelCache (the personalization step's one-launch re-pack of every weight panel, lwg_pack_panels_f32, and of the Winograd panels derived
+    from them, lwg_winograd_panels_f32): after the weights change in place, refresh() leaves in EVERY registered panel - forward, data-gradient
+    (transposed, flipped taps), the four parity sub-kernels of a transposed convolution, a first layer with 6 of 8 channels, padded output columns -
+    the bits a fresh single-launch pack of the new weights gives, the Winograd panels the bits lwg_winograd_panel_f32 gives on the refreshed
+    panels; panels of frozen weights (requires_grad False when the cache was built) are built once and not touched."""
+    g = torch.Generator().manual_seed(77)
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(DEV)     # noqa: E731
+    flat = mk(64 * 6 * 49 + 128 * 64 * 9 + 64 * 128 * 9 + 128 * 64 * 16 + 40 * 64 * 9).requires_grad_(True)      # one flat buffer, as FlatAdam lays parameters out
+    views, off = [], 0
+    for sh in ((64, 6, 7, 7), (128, 64, 3, 3), (64, 128, 3, 3), (128, 64, 4, 4), (40, 64, 3, 3)):
+        nel = int(np.prod(sh))
+        views.append(flat.detach()[off:off + nel].view(*sh))
+        off += nel
+    frozen = mk(64, 64, 3, 3)
+    cache = ops.PanelCache([flat, frozen])
+    # (weight, transposed, kidx, cin, cin_pad, nout, n_pad): what packing.pack_conv / pack_dgrad_conv / pack_conv_transpose request
+    reqs = [(views[0], False, tuple(range(49)), 6, 8, 64, 64),
+            (views[1], False, tuple(range(9)), 64, 64, 128, 128),
+            (views[1], True, tuple(reversed(range(9))), 128, 128, 64, 64),
+            (views[2], False, tuple(range(9)), 128, 128, 64, 64),
+            (views[3], True, (5, 7, 13, 15), 128, 128, 64, 64), (views[3], True, (0, 2, 8, 10), 128, 128, 64, 64),
+            (views[4], False, tuple(range(9)), 64, 64, 40, 64),
+            (frozen, False, tuple(range(9)), 64, 64, 64, 64)]
+    prev, ops.PANEL_CACHE = ops.PANEL_CACHE, cache
+    try:
+        panels = [ops.pack_panel(*r) for r in reqs]                       # first request: single launches, registered
+        tap9 = list(range(9))
+        class _S:                                                           # the fields PanelCache.winograd reads of a conv spec
+            pass
+        wspecs = []
+        for i in (1, 3, 7):
+            sp = _S()
+            sp.w, sp.Cin = panels[i], reqs[i][4]
+            wspecs.append(sp)
+        U0 = [cache.winograd(sp, tap9).clone() for sp in wspecs]
+        assert len(cache.rows) == 7 and len(cache.wino_rows) == 2, (len(cache.rows), len(cache.wino_rows))     # the frozen weight's are not refreshed
+        old = [p_.clone() for p_ in panels]
+        with torch.no_grad():
+            flat.mul_(-0.5).add_(0.25)
+            frozen.add_(1.0)                                                # (a frozen weight that changes anyway stays stale: documented)
+        cache.refresh()
+        cache.refresh()                                                     # idempotent
+        U1 = [cache.winograd(sp, tap9) for sp in wspecs]
+    finally:
+        ops.PANEL_CACHE = prev
+    torch.cuda.synchronize()
+    out = {"panels": len(panels), "winograd_panels": len(U1)}
+    for i, (r, p_) in enumerate(zip(reqs, panels)):
+        fresh = ops.pack_panel(*r)                                          # no cache installed: a plain single launch
+        if i < 7:
+            assert torch.equal(p_, fresh) and not torch.equal(p_, old[i]), f"panel {i}: refresh() differs from a fresh pack"
+        else:
+            assert torch.equal(p_, old[i]) and not torch.equal(p_, fresh), "a frozen weight's panel was re-packed"
+    for j, (sp, u) in enumerate(zip(wspecs, U1)):
+        want = torch.empty_like(u)
+        arr = (ctypes.c_int * 9)(*tap9)
+        _lib.check(_lib.lib().lwg_winograd_panel_f32(ops._ptr(sp.w), ops._ptr(want), sp.Cin, sp.w.shape[1], arr, ops._stream()), "lwg_winograd_panel_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(u, want), f"winograd panel {j}: refresh() differs from a single launch on the refreshed panel"
+        assert (j < 2) != torch.equal(u, U0[j]), f"winograd panel {j}: " + ("not refreshed" if j < 2 else "a frozen weight's panel was rebuilt")
+    return out
+
+
+ALL = [check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden, check_generator_golden_256,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,
