@@ -114,10 +114,14 @@ def test_panel_cache_bookkeeping(monkeypatch):
     import ctypes
 
     from ipercore_amd import _lib
-    flat = torch.zeros(64 * 32 * 9 + 32 * 64 * 16)                     # a flat parameter buffer with two weight views
-    w1 = flat[:64 * 32 * 9].view(64, 32, 3, 3)
-    w2 = flat[64 * 32 * 9:].view(32, 64, 4, 4)
-    cache = ops.PanelCache([flat])
+    flat = torch.zeros(64 * 32 * 9 + 32 * 64 * 16, requires_grad=True)   # a flat parameter buffer (it trains) with two weight views
+    w1 = flat.detach()[:64 * 32 * 9].view(64, 32, 3, 3)
+    w2 = flat.detach()[64 * 32 * 9:].view(32, 64, 4, 4)
+    frozen = torch.zeros(64, 32, 3, 3)                                   # a loss network's weight: cached, packed once by its caller, never re-packed
+    cache = ops.PanelCache([flat, frozen])
+    f, fresh_f = cache.get(frozen, False, tuple(range(9)), 32, 32, 64, 64)
+    f2, fresh_f2 = cache.get(frozen, False, tuple(range(9)), 32, 32, 64, 64)
+    assert fresh_f and not fresh_f2 and f2 is f and cache.cacheable(frozen) and not cache.rows
     assert cache.cacheable(w1) and cache.cacheable(w2) and not cache.cacheable(torch.cat([w1, w1]))
     a, fresh_a = cache.get(w1, False, tuple(range(9)), 32, 32, 64, 64)
     b, fresh_b = cache.get(w1, False, tuple(range(9)), 32, 32, 64, 64)

@@ -11,10 +11,13 @@ pmc() { # name shape counters...
   python tools/pmc_summary.py $O/pmc_wino_$name $O/pmc_wino_$name.md > /dev/null 2>&1
   find $O/pmc_wino_$name -type f -size +1M -delete
 }
-for sh in 0 5 7; do
+for sh in ${WINO_PMC_SHAPES-0 5 7}; do          # WINO_PMC_SHAPES="" skips the per-shape PMC passes (the kernel's whole-launch form did not change)
   pmc s${sh}_mfma $sh SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU
   pmc s${sh}_lds $sh SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 done
 cat $O/pmc_wino_*.md | grep -i "wino\|kernel |" | cut -c1-330
 timeout 300 python tools/winoshapes.py --frames 64 > $O/winoshapes_64.log 2>&1; grep -v amdgpu $O/winoshapes_64.log | tail -11
 bash tools/prof_pers.sh > $O/prof_pers_final.txt 2>&1; head -8 $O/prof_pers_final.txt
+bash tools/prof_pers.sh --use-vgg --use-face > $O/prof_pers_vgg_face_final.txt 2>&1; head -6 $O/prof_pers_vgg_face_final.txt
+timeout 300 python tools/winoshapes.py --frames 1 --splitk --vgg 2>&1 | grep -v amdgpu > $O/winoshapes_split_vgg.log
+timeout 300 python tools/winoshapes.py --frames 1 --splitk 2>&1 | grep -v amdgpu > $O/winoshapes_split_f1.log; tail -3 $O/winoshapes_split_f1.log | cut -c1-200
