@@ -1,6 +1,6 @@
 // Fused F(2x2, 3x3) Winograd form of the 3x3 / stride 1 / pad 1 fp32 convolution on v_mfma_f32_32x32x2_f32 (ops.conv_precision("winograd");
 // round 4, re-designed in round 5; first developed as tools/probes/winograd_f23.hip, numerics in tools/winograd_study.py).
-//   y = act(bias + sum x * w [+ res]) computed as U = G w G^T (host: the fragment panel Upk[16][Cin/8][2][N][4]), V = B^T d B per 4x4 input patch d
+//   y = act(bias + sum x * w [+ res]) computed as U = G w G^T (the fragment panel Upk[16][Cin/8][2][N][4], built by the panel kernels below), V = B^T d B per 4x4 input patch d
 //   (patches overlap by two pixels), M_{xi,nu} = V_{xi,nu} U_{xi,nu} - sixteen GEMMs over Cin -, Y = A^T M A: 16 multiplies per 2x2 outputs instead of 36.
 // Workgroup: 512 threads = 8 waves; block = 8 x 8 patches (16 x 16 output pixels) x 64 output channels; wave w owns the FOUR products of one row of
 // the transformed patch, (xi, nu = 0..3) with xi = w % 4, for all 64 patches x the 32 channels of tile w / 4 (4 x 2 accumulator tiles of 32 x 32 =
@@ -21,6 +21,10 @@
 // live in four different waves -> ONE exchange through LDS ([xi][column][patch][n], rows padded to 68 floats: 16-byte stores and loads, conflict-free
 // both ways); a thread then owns one patch x two channel quads (n4.., 32 + n4..): A^T (.) over xi + bias (+ residual, or the SPADE modulation of a
 // gamma | beta launch) + activation, 16-byte NHWC stores.  A second input (skip concatenation) is read stage by stage: a stage's 8 channels lie in one of the two tensors.
+// Training step (trainers.TrainOpts.conv_precision = "winograd"): the same kernel runs the data gradients (dY with the flipped, transposed kernel; the
+// LWG_ACTIVATION_RELU_MASK epilogue = the producing layer's ReLU backward); the fragment panels of weights that change every step are built on the
+// device from the GEMM panels (lwg_winograd_panel_f32 / lwg_winograd_panels_f32 below); one-sample launches that would leave half the chip idle run
+// their K loop in slices (template flag SPLIT, lwg_conv2d_winograd_f32_ws: slabs + the direct engine's finishing kernel).
 // Rounding: relative L2 error against fp64 1.6x that of the direct fp32 convolution over the generator's layers (tools/winograd_study.py); NOT bitwise
 // the direct kernel's result - which is why it is a precision mode of its own.
 #include <hip/hip_runtime.h>
