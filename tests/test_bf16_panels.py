@@ -148,6 +148,85 @@ def test_panel_cache_bookkeeping(monkeypatch):
     assert ctypes.sizeof(_lib.LwgPackDesc) == 264
 
 
+def test_winograd_panel_cache_and_launch_plan(monkeypatch):
+    """Host logic around the Winograd engine in the training step (no GPU): PanelCache.winograd builds a fragment panel once per (GEMM panel, tap
+    order), registers it for the per-step refresh only when the source weight trains, and refresh() hands the library one LwgWinoDesc per registered
+    panel with consecutive block ranges; ops._wino_plan: the synthesis path (splitk=False) always runs the kernel whole, a training launch takes the
+    split form when the library plans one and its slices fill >= WINO_MIN_GRID workgroups, stays whole when the grid is large enough, and is handed
+    to the direct kernel (None) otherwise."""
+    from ipercore_amd import _lib
+    flat = torch.zeros(64 * 64 * 9, requires_grad=True)
+    w = flat.detach().view(64, 64, 3, 3)
+    frozen = torch.zeros(128, 64, 3, 3)
+    cache = ops.PanelCache([flat, frozen])
+    calls = []
+
+    class _Stub:
+        ws_floats = 0
+
+        def lwg_winograd_panel_f32(self, wp, up, cin, n, taps, stream):
+            calls.append(("one", cin, n, list(taps)))
+            return 0
+
+        def lwg_pack_panels_f32(self, table, n, blocks, stream):
+            calls.append(("pack", n, blocks))
+            return 0
+
+        def lwg_winograd_panels_f32(self, table, n, blocks, stream):
+            calls.append(("all", n, blocks))
+            return 0
+
+        def lwg_conv2d_winograd_ws_floats(self, a):
+            return self.ws_floats
+    stub = _Stub()
+    monkeypatch.setattr(_lib, "lib", lambda: stub)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    monkeypatch.setattr(ops, "_ptr", lambda t, dt=None: 0 if t is None else t.data_ptr())
+    pa, _ = cache.get(w, False, tuple(range(9)), 64, 64, 64, 64)
+    pt, _ = cache.get(w, True, tuple(reversed(range(9))), 64, 64, 64, 64)
+    pf, _ = cache.get(frozen, False, tuple(range(9)), 64, 64, 128, 128)
+
+    class _Spec:
+        def __init__(self, panel, cin):
+            self.w, self.Cin = panel, cin
+    taps, rtaps = list(range(9)), list(reversed(range(9)))
+    ua = cache.winograd(_Spec(pa, 64), taps)
+    assert cache.winograd(_Spec(pa, 64), taps) is ua and ua.shape == (16, 8, 2, 64, 4)          # once per (panel, tap order)
+    ut = cache.winograd(_Spec(pt, 64), rtaps)
+    uf = cache.winograd(_Spec(pf, 64), taps)
+    assert uf.shape == (16, 8, 2, 128, 4) and cache.winograd(_Spec(torch.zeros(144, 64, 4), 64), taps) is None      # a per-call temporary: not cached
+    assert [c[0] for c in calls] == ["one", "one", "one"] and calls[1][3] == rtaps
+    assert len(cache.rows) == 2 and len(cache.wino_rows) == 2                                     # the frozen weight's panels are not re-derived
+    calls.clear()
+    cache.refresh()
+    cache.refresh()
+    assert [c[0] for c in calls] == ["pack", "all", "pack", "all"] and calls[1] == calls[3] and calls[1][1] == 2
+    descs = (_lib.LwgWinoDesc * 2).from_buffer_copy(bytes(cache.wino_table.numpy().tobytes()))
+    per = ((64 + 63) // 64) * ((64 + 15) // 16)
+    assert [d_.first_block for d_ in descs] == [0, per] and calls[1][2] == 2 * per
+    assert descs[0].wpanel == pa.data_ptr() and descs[0].upk == ua.data_ptr() and descs[1].upk == ut.data_ptr() and list(descs[1].tap9) == rtaps
+    # the launch plan
+    a = _lib.LwgConvArgs()
+
+    class _S2:
+        N = 256
+    y_small, y_mid, y_big = torch.zeros(1, 28, 28, 256), torch.zeros(1, 64, 64, 256), torch.zeros(2, 128, 128, 256)
+    a.M = 28 * 28
+    assert ops._wino_plan(a, _S2, y_small, False) == 0 and ops._wino_plan(a, _S2, y_big, False) == 0     # synthesis path: whole, always
+    stub.ws_floats = 0
+    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 4 tiles x 8 = 32 workgroups, no plan: direct split-K
+    a.M = 64 * 64
+    assert ops._wino_plan(a, _S2, y_mid, True) == 0                                                        # 16 x 8 = 128: whole
+    a.M = 28 * 28
+    stub.ws_floats = 4 * a.M * 256
+    assert ops._wino_plan(a, _S2, y_small, True) == stub.ws_floats                                         # 32 x 4 slices = 128: the split form
+    stub.ws_floats = 2 * a.M * 256
+    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 64 workgroups even when split
+    monkeypatch.setattr(ops, "WINO_SPLITK", False)
+    stub.ws_floats = 4 * a.M * 256
+    assert ops._wino_plan(a, _S2, y_small, True) is None
+
+
 def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
     """Host logic around two round-2 kernels (no GPU): ops.conv_transpose2d picks the one-launch form only for bf16 tensors with
     Cin <= 128 and the four parity specs in order, and hands the accounting hook ONE pseudo-spec for the whole transposed
