@@ -86,7 +86,8 @@ class ConvTimer:
             self.kernels += info["kernels"]                  # a call whose input exceeds the 32-bit buffer range runs as batch slices
             self.flops += 2.0 * M * spec.algo_kn
             # EXECUTED matrix-pipe flops: the F(2x2, 3x3) Winograd kernel forms 16 products per 2 x 2 outputs where the direct form has 36
-            ex = 2.0 * M * spec.algo_kn * (4.0 / 9.0 if info["kind"] == "winograd" else 1.0)
+            # ... and the F(2x2, 2x2) form of a transposed convolution 36 per 4 x 4 input patch where the direct form has 64
+            ex = 2.0 * M * spec.algo_kn * {"winograd": 4.0 / 9.0, "winograd_up4": 9.0 / 16.0}.get(info["kind"], 1.0)
             self.exec_flops += ex
             k = self.kinds.setdefault(info["kind"], [0, 0.0, 0.0, []])     # calls, algorithmic flops, executed flops, event pairs
             k[0] += 1

@@ -158,6 +158,15 @@ int lwg_conv_transpose4_nhwc_bf16(const LwgConvArgs* args, lwg_stream_t stream);
 int lwg_conv_transpose4_nhwc_f32(const LwgConvArgs* args, lwg_stream_t stream);
 /* 1 if the call above runs this description as one grid, 0 if as four launches (for callers that bracket launches with events). */
 int lwg_conv_transpose4_is_one_grid(const LwgConvArgs* args);
+/* The same layer as a fused F(2x2, 2x2) Winograd convolution on the fp32 matrix pipe (csrc/convt_winograd.hip): an output parity of
+ * ConvTranspose2d(4, 2, 1) is a 2 x 2-tap convolution - 9 multiplies per 2 x 2 outputs of a parity instead of 16.  args = the parity-(0,0) launch
+ * description as above (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2H, YW = 2W, LWG_EPI_NONE, one input) with Cin % 16 == 0, N % 32 == 0,
+ * the image < 3 GiB, ydt = LWG_DT_F32 or LWG_DT_F32_Q4, any activation of the forward path; args->w = the transformed-weight panel
+ * Upk[4][Cin/8][4][2][N][12]: element (parity 2 py + px, s, kk, kh, n, 3 xi + nu) = sgn (G g G^T)[xi][nu] for input channel 8 s + 2 kk + kh and output
+ * column n, g[r][q] = w[c][n][3 - py - 2 r][3 - px - 2 q] (the parity's 2 x 2 sub-kernel), G = [[1,0],[1,1],[0,1]], sgn = (py == 1 && xi == 0 ? -1 : 1)
+ * (px == 1 && nu == 0 ? -1 : 1); elements 9 .. 11 are padding.  fp32-grade results, not the bits of the call above: part of the "winograd" precision
+ * mode of ipercore_amd.ops; a frame's result does not depend on the batch it is launched in. */
+int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
 
 /* fp32 convolution on the bf16 matrix pipe ("bf16x6"): both operands are split exactly into three bf16 parts
  * (activations in the kernel, weights on the host: args->w = [3][ntaps*Cin/8][N][8] bf16 planes hi / mid / lo), six bf16 MFMAs

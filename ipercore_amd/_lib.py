@@ -67,6 +67,7 @@ _SIGS = {
     "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_conv_transpose4_winograd_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_is_one_grid": (c_i, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv_slice_count": (c_i, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_nhwc_f32_split": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),

@@ -1,0 +1,287 @@
+// nn.ConvTranspose2d(kernel 4, stride 2, padding 1) in fp32 as a fused F(2x2, 2x2) Winograd convolution on v_mfma_f32_32x32x2_f32 - the sibling of
+// conv_winograd.hip for the decoders' up-sampling layers (attlwb_spade_resunet.py:331-340).
+//   Output parity (py, px) of the layer is a 2 x 2-tap convolution of the input: y[2i + py][2j + px] = sum_{r,q in {0,1}} x[i + py - 1 + r][j + px - 1 + q]
+//   g_p[r][q] with g_p[r][q] = w[3 - py - 2 r][3 - px - 2 q].  Two adjacent outputs of one parity per dimension from three inputs with three
+//   multiplies instead of four: m0 = (d0 - d1) g0, m1 = d1 (g0 + g1), m2 = (d2 - d1) g1, y0 = m0 + m1, y1 = m1 + m2 - in two dimensions 9 products
+//   per 2 x 2 outputs of a parity instead of 16, 36 per 4 x 4 input patch instead of 64.  The patch of parity (py, px) is rows py .. py + 2, columns
+//   px .. px + 2 of the SAME 4 x 4 input patch (rows i - 1 .. i + 2) the 3 x 3 kernel stages, so the halo staging is that kernel's.  Row forms of the
+//   patch: R0 = r0 - r1, R1 = r1, R2 = r2 - r1, R3 = r2, R4 = r3 - r2 (parity 0 uses R0 R1 R2, parity 1 uses -R2 R3 R4: the sign lives in the
+//   weight panel), the same over columns: 25 transformed values per (patch, input channel) serve all 36 products.
+// Workgroup: 512 threads = 8 waves; block = 8 x 8 patches (16 x 16 input pixels -> 32 x 32 output pixels) x 32 output channels; wave w owns ALL NINE
+// products of parity w % 4 for the 32 patches of tile w / 4 (9 accumulator tiles of 32 x 32 = 144 VGPRs, rows = output channels): the output
+// transform A^T M A is register-local - no exchange between waves, every wave writes its parity's pixels itself.
+// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the
+// panel Upk[4][Cin/8][4][2][N][12] (one k-pair ahead, two register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
+// halo goes global -> registers (three stages ahead) -> raw[s % 2]; every thread transforms ONE (patch, channel) 4 x 4 -> 25 values (27 subtractions)
+// from raw[(s + 1) % 2] into Vs[(s + 1) % 2] beside the MFMAs of k-pairs 0 .. 2; one barrier per stage, behind k-pair 2.
+// Rounding: the transforms only add / subtract (no 1/2 factors as in F(2x2, 3x3)); panel entries are sums of up to four weights formed in fp64
+// and rounded once.  fp32-grade, NOT the direct kernel's bits: part of the "winograd" precision mode.
+#include <hip/hip_runtime.h>
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define WG_THREADS 512
+#define TPB 8            // patches per block edge: 8 x 8 patches = 16 x 16 input pixels
+#define NPATCH 64
+#define NBT 32           // output channels per block
+#define KS 8             // input channels per stage
+#define HALO 18
+#define PLANE (HALO * HALO)
+#define RAW_FLOATS (KS * PLANE)              // [c][py][px]
+#define VSTR 64
+#define NFORM 25
+#define VS_FLOATS (NFORM * KS * VSTR)        // [form][k][patch]
+#define DUMP_OFF (2 * RAW_FLOATS + 2 * VS_FLOATS)                 // where the threads without a halo element store their zeros (dead LDS)
+#define DUMP_FLOATS (WG_THREADS + 3 * PLANE + RAW_FLOATS)
+#define LOOP_FLOATS (DUMP_OFF + DUMP_FLOATS)
+#define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+
+
+template <int V> struct IntT { static constexpr int value = V; };
+
+__device__ __forceinline__ floatx4 ctw_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+__global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const LwgConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W, Cin = a.C0, N = a.N;
+    float* const raw0 = smem;                                // [2][RAW], then [2][VS] (25 planes of [k][patch])
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bx = (W + 2 * TPB - 1) / (2 * TPB), by = (H + 2 * TPB - 1) / (2 * TPB);
+    int blk = blockIdx.x;
+    const int b = blk / (bx * by);
+    blk -= b * bx * by;
+    const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
+    const int n0 = blockIdx.y * NBT;
+    const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * Cin), 0, (int)((unsigned)(H * W) * (unsigned)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
+    const int par = wid & 3, py = par >> 1, px = par & 1;    // this wave's output parity
+    const int pt = wid >> 2;                                  // ... and its 32-patch tile
+    floatx16 acc[9];                                         // [product 3 xi + nu]
+
+    // this thread's two halo elements (pixel, channel quad): byte offset of the pixel inside the image (out of range: padding / none), LDS slot
+    unsigned voff0[2];
+    int wst[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + WG_THREADS * q;
+        const int pix = i >> 1, half = i & 1, hy = pix / HALO, hx = pix - hy * HALO;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool have = i < PLANE * 2, in = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff0[q] = in ? (unsigned)((gy * W + gx) * Cin + 4 * half) * 4u : WINO_OOB;
+        wst[q] = have ? 4 * half * PLANE + pix : DUMP_OFF + tid;
+    }
+    floatx4 rreg[2];
+    auto rld1 = [&](int st, int q) -> floatx4 { return ctw_buf_load(rx0, voff0[q], (unsigned)(st * KS) * 4u); };
+    auto rst1 = [&](int buf, int q, floatx4 v) {
+        float* dst = raw0 + buf * RAW_FLOATS + wst[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k * PLANE] = v[k];
+    };
+    // weights: lane = (k-half lane / 32, channel lane % 32); element (parity, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
+    floatx4 ufr[2][3];                                       // [register set = k-pair % 2][products 0-3 | 4-7 | 8 + padding]
+    const unsigned uvoff = (unsigned)((((lane >> 5) * N + n0 + (lane & 31)) * 12) * 4);
+    const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
+    const unsigned upar = (unsigned)par * (unsigned)nst * 4u * ukk;
+    auto uld1 = [&](int st, int kk, int j) -> floatx4 { return ctw_buf_load(ru, uvoff + 16u * j, upar + (unsigned)(st * 4 + kk) * ukk); };
+    const int patch = tid & 63, tc = tid >> 6;
+    const int pty = patch >> 3, ptx = patch & 7;
+    unsigned dbs[2];                                         // this thread's 4 x 4 input patch inside raw[u] (float index into smem)
+    unsigned vbs[2];                                         // ... its 25 transformed values inside Vs[u]
+    unsigned fbs[2];                                         // this lane's fragments inside Vs[u]: form (2 py + xi, 2 px + nu), k-half, patch
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        dbs[u] = (unsigned)(u * RAW_FLOATS + tc * PLANE + (2 * pty) * HALO + 2 * ptx) >> 1;
+        asm volatile("" : "+v"(dbs[u]));
+        dbs[u] <<= 1;
+        vbs[u] = (unsigned)(2 * RAW_FLOATS + u * VS_FLOATS + tc * VSTR + patch);
+        asm volatile("" : "+v"(vbs[u]));
+        fbs[u] = (unsigned)(2 * RAW_FLOATS + u * VS_FLOATS + (10 * py + 2 * px) * KS * VSTR + (lane >> 5) * VSTR + pt * 32 + (lane & 31));
+        asm volatile("" : "+v"(fbs[u]));
+    }
+    float fb[2][9];                                          // [register set = k-pair % 2][product]
+    auto fragread = [&](int buf, int kk) {                    // the nine fragments of k-pair kk of the stage in Vs[buf] -> set kk % 2
+#pragma unroll
+        for (int xi = 0; xi < 3; ++xi)
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) fb[kk & 1][3 * xi + nu] = smem[fbs[buf] + ((5 * xi + nu) * KS + 2 * kk) * VSTR];
+    };
+    auto transform_store = [&](int buf, const float (&dd)[4][4]) {
+        float t[5][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = dd[0][j] - dd[1][j];
+            t[1][j] = dd[1][j];
+            t[2][j] = dd[2][j] - dd[1][j];
+            t[3][j] = dd[2][j];
+            t[4][j] = dd[3][j] - dd[2][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            float* v = smem + vbs[buf] + (5 * i) * KS * VSTR;
+            v[0 * KS * VSTR] = t[i][0] - t[i][1];
+            v[1 * KS * VSTR] = t[i][1];
+            v[2 * KS * VSTR] = t[i][2] - t[i][1];
+            v[3 * KS * VSTR] = t[i][2];
+            v[4 * KS * VSTR] = t[i][3] - t[i][2];
+        }
+    };
+    auto iteration = [&](int s, auto SET, auto NXT) {
+        constexpr int set = decltype(SET)::value;            // s % 2
+        constexpr bool nxt = decltype(NXT)::value != 0;      // the last stage has no next one to prepare (peeled: no branches in the loop)
+        const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
+        float dd[4][4];
+        auto mf = [&](int kk, int q) {
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk & 1][q >> 2][q & 3], fb[kk & 1][q], acc[q], 0, 0, 0);
+            WSB();
+        };
+        auto uldn = [&](int kk) {                            // the weights of the NEXT k-pair (kk + 1 of this stage, or 0 of the next) -> the other set
+            if (kk < 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ufr[(kk + 1) & 1][j] = uld1(s, kk + 1, j);
+            } else if (nxt) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ufr[0][j] = uld1(s + 1, 0, j);
+            }
+            WSB();
+        };
+        // k-pair 0: next weights, next fragments; the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3
+        uldn(0);
+        fragread(set, 1);
+        WSB();
+        mf(0, 0);
+        if (nxt) { rst1(set, 0, rreg[0]); rreg[0] = rld1(s3, 0); }
+        WSB();
+        mf(0, 1);
+        if (nxt) { rst1(set, 1, rreg[1]); rreg[1] = rld1(s3, 1); }
+        WSB();
+        mf(0, 2);
+        if (nxt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = smem[dbs[set ^ 1] + i * HALO + j];
+        }
+        WSB();
+        mf(0, 3); mf(0, 4); mf(0, 5); mf(0, 6); mf(0, 7); mf(0, 8);
+        // k-pair 1: the transform of stage s + 1 (its 25 values into Vs[(s + 1) % 2])
+        uldn(1);
+        fragread(set, 2);
+        WSB();
+        mf(1, 0);
+        if (nxt) transform_store(set ^ 1, dd);
+        WSB();
+        mf(1, 1); mf(1, 2); mf(1, 3); mf(1, 4); mf(1, 5); mf(1, 6); mf(1, 7); mf(1, 8);
+        // k-pair 2
+        uldn(2);
+        fragread(set, 3);
+        WSB();
+        mf(2, 0); mf(2, 1); mf(2, 2); mf(2, 3); mf(2, 4); mf(2, 5); mf(2, 6); mf(2, 7); mf(2, 8);
+        __syncthreads();
+        // k-pair 3: the next stage's first fragments
+        uldn(3);
+        if (nxt) fragread(set ^ 1, 0);
+        WSB();
+        mf(3, 0); mf(3, 1); mf(3, 2); mf(3, 3); mf(3, 4); mf(3, 5); mf(3, 6); mf(3, 7); mf(3, 8);
+    };
+
+    // prologue: stages 0 and 1 -> raw[0], raw[1]; stage 0 transformed; stage 2's halo in registers; the first weights and fragments
+    {
+        floatx4 r0[2], r1[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            r0[q] = rld1(0, q);
+            r1[q] = rld1(1, q);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ufr[0][j] = uld1(0, 0, j);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rst1(0, q, r0[q]);
+            rst1(1, q, r1[q]);
+        }
+    }
+    __syncthreads();
+    {
+        float dd[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dd[i][j] = smem[dbs[0] + i * HALO + j];
+        transform_store(0, dd);
+    }
+    __syncthreads();
+    fragread(0, 0);
+    {
+        int s = 0;
+        for (; s + 2 < nst; s += 2) {
+            iteration(s, IntT<0>(), IntT<1>());
+            iteration(s + 1, IntT<1>(), IntT<1>());
+        }
+        iteration(s, IntT<0>(), IntT<1>());
+        iteration(s + 1, IntT<1>(), IntT<0>());
+    }
+    // epilogue (register-local): Y[a][b] = sum over xi in {a, a + 1}, nu in {b, b + 1} of M[xi][nu]; + bias, activation; this lane holds patch
+    // pt * 32 + lane % 32 and, per register group g, the four channels n0 + 8 g + 4 (lane / 32) ..: one 16-byte store per (output pixel, g)
+    const int p = pt * 32 + (lane & 31);
+    const int ety = p >> 3, etx = p & 7;
+    const int chl = 4 * (lane >> 5);
+    const bool q4 = a.ydt == LWG_DT_F32_Q4;
+    const size_t plane = (size_t)a.YH * a.YW;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = a.ycoff + n0 + 8 * g + chl;
+        const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + n0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int iy = y0 + 2 * ety + ia, ix = x0 + 2 * etx + ib;
+                if (iy < H && ix < W) {
+                    floatx4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * g + k;
+                        const float v = (acc[3 * ia + ib][r] + acc[3 * ia + ib + 1][r]) + (acc[3 * ia + 3 + ib][r] + acc[3 * ia + 4 + ib][r]);
+                        o[k] = lwg_act(v + bv[k], a.act);
+                    }
+                    const size_t opix = (size_t)(2 * iy + py) * a.YW + (2 * ix + px);
+                    float* dst = q4 ? a.y + (((size_t)b * (a.YC >> 2) + (ch >> 2)) * plane + opix) * 4 : a.y + ((size_t)b * plane + opix) * a.YC + ch;
+                    *reinterpret_cast<floatx4*>(dst) = o;
+                }
+            }
+    }
+}
+
+// args: the parity-(0, 0) launch description of lwg_conv_transpose4_nhwc_f32 (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2 H, YW = 2 W,
+// LWG_EPI_NONE, one input) with Cin % 16 == 0, N % 32 == 0, ydt LWG_DT_F32 or LWG_DT_F32_Q4, EXCEPT args->w = the Winograd panel
+// Upk[4][Cin/8][4][2][N][12]: element (parity 2 py + px, stage s, k-pair kk, k-half kh, column n, product 3 xi + nu) =
+// sgn * (G g G^T)[xi][nu] with g[r][q] = w[c][n][3 - py - 2 r][3 - px - 2 q] the parity's 2 x 2 sub-kernel of input channel c = 8 s + 2 kk + kh,
+// G = [[1,0],[1,1],[0,1]] and sgn = (py == 1 && xi == 0 ? -1 : 1) * (px == 1 && nu == 0 ? -1 : 1); products 9 .. 11 are padding (zero).
+extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 4 || a.stride != 1 || a.omul != 2 || a.C0 <= 0 || (a.C0 % (2 * KS)) != 0 || a.C1 != 0 ||
+        a.N <= 0 || (a.N % NBT) != 0 || a.OH != a.H || a.OW != a.W || a.YH != 2 * a.H || a.YW != 2 * a.W || a.xdt != LWG_DT_F32 ||
+        (a.ydt != LWG_DT_F32 && a.ydt != LWG_DT_F32_Q4) || a.M != a.B * a.H * a.W || a.epi != LWG_EPI_NONE || a.act == LWG_ACT_RELU_MASK ||
+        a.ycoff < 0 || (a.ycoff % 4) != 0 || (a.YC % 4) != 0 || a.ycoff + a.N > a.YC)
+        return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.H * a.W * a.C0 * 4ull >= (unsigned long long)WINO_OOB || 192ull * a.C0 * a.N >= 0xffffffffull) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)LOOP_FLOATS * 4;
+    static unsigned long long done = 0;
+    if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_convt_winograd_kernel), lds, done); e != hipSuccess) return (int)e;
+    const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
+    hipLaunchKernelGGL(lwg_convt_winograd_kernel, dim3((unsigned)(bx * by * a.B), (unsigned)(a.N / NBT)), dim3(WG_THREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}

@@ -63,7 +63,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up", "_wwino")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up", "_wwino", "_wwino_t")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -80,6 +80,7 @@ class ConvSpec:
         self._w16up = None
         self._w32up = None
         self._wwino = None
+        self._wwino_t = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -351,8 +352,49 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
     return y
 
 
+WINO_UP4 = True         # lab switch: in the "winograd" mode the fp32 transposed convolutions of the synthesis path run lwg_conv_transpose4_winograd_f32
 F32_UP4 = True          # lab switch: fp32 transposed convolutions through lwg_conv_transpose4_nhwc_f32 (False: four conv2d calls)
 BF16_UP4 = True         # lab switch: the four parity launches of a bf16 transposed convolution fused into one (Cin <= 128)
+
+
+def _parity_specs_ok(specs):
+    """The four parity specs of ONE ConvTranspose2d(4, 2, 1) in order (packing.pack_conv_transpose): parity p's taps are parity 0's shifted by p."""
+    s0 = specs[0]
+    return (len(specs) == 4 and all(s.ntaps == 4 and s.omul == 2 and s.stride == 1 and (s.ooy, s.oox) == (i >> 1, i & 1) and s.N == s0.N and s.Cin == s0.Cin
+                                    and [(dy - (i >> 1), dx - (i & 1)) for dy, dx in zip(s.dy, s.dx)] == list(zip(s0.dy, s0.dx)) for i, s in enumerate(specs)))
+
+
+def _wwino_t(specs):
+    """The transformed-weight panel of lwg_conv_transpose4_winograd_f32 from the four parity GEMM panels, built once per layer (a weight transform at
+    load time, like the packing itself): Upk[4][Cin/8][4][2][N][12], element (2 py + px, s, kk, kh, n, 3 xi + nu) = sgn (G g G^T)[xi][nu] for input
+    channel 8 s + 2 kk + kh - g the parity's 2 x 2 sub-kernel in input-offset order, G = [[1,0],[1,1],[0,1]], formed in fp64 and rounded once; the
+    sign (-1 where a parity-1 row / column takes the form the parity-0 one already holds negated) is documented in include/lwg_hip.h."""
+    s0 = specs[0]
+    U = s0._wwino_t
+    if U is not None and U.device == s0.w.device:
+        return U
+    Cin, N = s0.Cin, s0.N
+    G = torch.tensor([[1.0, 0.0], [1.0, 1.0], [0.0, 1.0]], dtype=torch.float64, device=s0.w.device)
+    parts = []
+    for par, sp in enumerate(specs):
+        py, px = par >> 1, par & 1
+        W = sp.w.double().permute(0, 2, 1).reshape(4 * Cin, N)                  # rows k = ((c / 32) 4 + tap) 32 + c % 32
+        W = W.view(Cin // 32, 4, 32, N).permute(1, 0, 2, 3).reshape(4, Cin, N)  # [tap][c][n]
+        g = torch.zeros(2, 2, Cin, N, dtype=torch.float64, device=W.device)
+        for t, (dy, dx) in enumerate(zip(sp.dy, sp.dx)):
+            g[dy - (py - 1), dx - (px - 1)] = W[t]                               # g[r][q] multiplies x[i + py - 1 + r][j + px - 1 + q]
+        u = torch.einsum("ar,rqcn,bq->abcn", G, g, G)                          # (3, 3, Cin, N)
+        if py:
+            u[0] = -u[0]
+        if px:
+            u[:, 0] = -u[:, 0]
+        parts.append(u.reshape(9, Cin, N))
+    U9 = torch.stack(parts)                                                      # (4, 9, Cin, N)
+    U = torch.zeros(4, Cin, N, 12, dtype=torch.float32, device=s0.w.device)
+    U[..., :9] = U9.permute(0, 2, 3, 1).float()
+    U = U.view(4, Cin // 8, 4, 2, N, 12).contiguous()                            # c = 8 s + 2 kk + kh
+    s0._wwino_t = U
+    return U
 
 
 class _FusedTransposeSpec(object):
@@ -386,9 +428,22 @@ def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=Fa
         if CONV_HOOK is not None:
             _hook_end(a, whole, EPI_NONE, "up4")
         return y
-    if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION in ("fp32", "winograd") and len(specs) == 4 and s0.Cin % 32 == 0
-            and all(s.ntaps == 4 and s.omul == 2 and s.stride == 1 and (s.ooy, s.oox) == (i >> 1, i & 1) and s.N == s0.N and s.Cin == s0.Cin
-                    and [(dy - (i >> 1), dx - (i & 1)) for dy, dx in zip(s.dy, s.dx)] == list(zip(s0.dy, s0.dx)) for i, s in enumerate(specs))):
+    if (WINO_UP4 and CONV_PRECISION == "winograd" and not splitk and out_hw is None and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32
+            and s0.Cin % 32 == 0 and s0.N % 32 == 0 and _parity_specs_ok(specs)):
+        # the synthesis path in the "winograd" mode: the layer as ONE fused F(2x2, 2x2) Winograd launch (36 products per 4 x 4 input patch instead
+        # of 64; per-image work in a fixed order: a frame does not depend on its batch).  Training callers (splitk=True) keep the direct forms.
+        a = conv_args(x, s0, y, act=act, q4=q4)
+        panel = _wwino_t(specs)
+        a.w = _ptr(panel)
+        if CONV_HOOK is not None:
+            whole = _FusedTransposeSpec(s0, panel)
+            CONV_HOOK(True, a.M, whole, EPI_NONE, None)
+        _lib.check(_lib.lib().lwg_conv_transpose4_winograd_f32(a, _stream()), "lwg_conv_transpose4_winograd_f32")
+        if CONV_HOOK is not None:
+            _hook_end(a, whole, EPI_NONE, "winograd_up4", False)
+        return y
+    if (F32_UP4 and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and CONV_PRECISION in ("fp32", "winograd") and s0.Cin % 32 == 0
+            and _parity_specs_ok(specs)):
         # fp32, small launch (one frame: a parity is a workgroup per CU or less): ONE grid of four times the workgroups
         # (lwg_conv_transpose4_nhwc_f32); large launches stay four conv2d calls (the library would issue the same four launches). The
         # values are those of the four conv2d calls bit for bit (same tiles, same K order).

@@ -2564,6 +2564,73 @@ def check_attention_backward():
     return out
 
 
+def check_winograd_up4():
+    """ConvTranspose2d(4, 2, 1) as ONE fused F(2x2, 2x2) Winograd launch (csrc/convt_winograd.hip, lwg_conv_transpose4_winograd_f32; the
+    "winograd" mode's form of the decoders' up-sampling layers on the synthesis path) against an fp64 transposed convolution at the conv checks'
+    tolerance: ragged / odd sizes (tiles cut by the image edge), ReLU / tanh / no activation, 32 .. 256 output channels, the channel-quad-plane
+    output (= the NHWC values, moved), an output channel slice of a wider tensor; NOT the direct kernel's bits (the kernel really ran); a
+    frame's result bitwise independent of the batch it is launched in; training callers (splitk=True) keep the direct form; the contract."""
+    out = {}
+    cases = (("ragged_relu", (2, 24, 40, 64, 64, ops.ACT_RELU)), ("odd_none", (1, 17, 31, 128, 64, ops.ACT_NONE)), ("deep", (3, 16, 16, 256, 256, ops.ACT_RELU)),
+             ("last_layer", (2, 48, 64, 128, 64, ops.ACT_TANH)), ("tiny", (1, 3, 5, 32, 64, ops.ACT_RELU)))
+    for tag, (B, H, W, Cin, N, act) in cases:
+        w = _rand((Cin, N, 4, 4), 300, 1.0 / np.sqrt(Cin * 4))
+        bsv = _rand((N,), 301, 0.1)
+        x = _rand((B, H, W, Cin), 302)
+        want = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2), w.double(), bsv.double(), stride=2, padding=1)
+        want = {ops.ACT_RELU: torch.relu, ops.ACT_TANH: torch.tanh, ops.ACT_NONE: lambda t: t}[act](want).permute(0, 2, 3, 1).float()
+        specs = [_spec_dev(s_) for s_ in packing.pack_conv_transpose(w, bsv)]
+        xd = x.to(DEV)
+        yd = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        ops.conv_transpose2d(xd, specs, yd, act=act)                            # the direct engine
+        yw = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        y1 = torch.full((1, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        yq = torch.full((B, N // 4, 2 * H, 2 * W, 4), float("nan"), device=DEV)
+        ys = torch.zeros(B, 2 * H, 2 * W, N + 32, device=DEV)
+        yt = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+        seen = []
+        prev_hook, ops.CONV_HOOK = ops.CONV_HOOK, (lambda begin, M, spec, epi=0, info=None: seen.append(info["kind"]) if not begin else None)
+        try:
+            with ops.conv_precision("winograd"):
+                ops.conv_transpose2d(xd, specs, yw, act=act)
+                ops.conv_transpose2d(xd[-1:].contiguous(), specs, y1, act=act)
+                ops.conv_transpose2d(xd, specs, yq, act=act, q4=True)
+                ops.conv_transpose2d(xd, specs, yt, act=act, splitk=True)       # a training caller: the direct form
+                a = ops.conv_args(xd, specs[0], ys, act=act)
+                a.ycoff, a.w = 16, ops._ptr(ops._wwino_t(specs))
+                _lib.check(_lib.lib().lwg_conv_transpose4_winograd_f32(a, ops._stream()), "lwg_conv_transpose4_winograd_f32")
+        finally:
+            ops.CONV_HOOK = prev_hook
+        torch.cuda.synchronize()
+        assert seen[:3] == ["winograd_up4"] * 3 and "winograd_up4" not in seen[3:], seen
+        out[tag] = _cmp(yw, want, 2e-5, "winograd convT " + tag)
+        out[tag]["vs_direct"] = (yw - yd).abs().max().item()
+        assert not torch.equal(yw, yd), tag + ": the Winograd form returned the direct kernel's bits (did it run?)"
+        assert torch.equal(yt, yd), tag + ": a splitk=True caller must get the direct form"
+        assert torch.equal(yw[-1:], y1), tag + ": a frame's result depends on its launch batch"
+        assert torch.equal(yq.permute(0, 2, 3, 1, 4).reshape(B, 2 * H, 2 * W, N), yw), tag + ": channel-quad-plane output differs from NHWC"
+        assert torch.equal(ys[..., 16:16 + N], yw) and float(ys[..., :16].abs().max()) == 0.0 and float(ys[..., 16 + N:].abs().max()) == 0.0, tag + ": channel slice"
+    # 96 output channels (N % 32 == 0 is all the kernel asks; the direct kernel needs N % 64 == 0 and cannot run this one)
+    B, H, W, Cin, N = 1, 20, 12, 64, 96
+    w96, b96, x96 = _rand((Cin, N, 4, 4), 303, 0.06), _rand((N,), 304, 0.1), _rand((B, H, W, Cin), 305)
+    want = torch.nn.functional.conv_transpose2d(x96.double().permute(0, 3, 1, 2), w96.double(), b96.double(), stride=2, padding=1).permute(0, 2, 3, 1).float()
+    sp96 = [_spec_dev(s_) for s_ in packing.pack_conv_transpose(w96, b96)]
+    y96 = torch.full((B, 2 * H, 2 * W, N), float("nan"), device=DEV)
+    with ops.conv_precision("winograd"):
+        ops.conv_transpose2d(x96.to(DEV), sp96, y96)
+    torch.cuda.synchronize()
+    out["n96"] = _cmp(y96, want, 2e-5, "winograd convT, 96 output channels")
+    # contract: what the kernel does not take is refused before any launch
+    a = ops.conv_args(xd, specs[0], yw, act=ops.ACT_RELU)
+    a.w = ops._ptr(ops._wwino_t(specs))
+    for field, val in (("C0", 40), ("N", 48), ("ycoff", 2), ("epi", ops.EPI_RESIDUAL), ("ntaps", 9)):
+        keep = getattr(a, field)
+        setattr(a, field, val)
+        assert _lib.lib().lwg_conv_transpose4_winograd_f32(a, None) == 1, field
+        setattr(a, field, keep)
+    return out
+
+
 def check_panel_cache_refresh():
     """ops.PanelCache (the personalization step's one-launch re-pack of every weight panel, lwg_pack_panels_f32, and of the Winograd panels derived
     from them, lwg_winograd_panels_f32): after the weights change in place, refresh() leaves in EVERY registered panel - forward, data-gradient
@@ -2628,7 +2695,7 @@ def check_panel_cache_refresh():
     return out
 
 
-ALL = [check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
+ALL = [check_winograd_up4, check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden, check_generator_golden_256,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,

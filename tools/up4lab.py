@@ -1,52 +1,70 @@
-"""Lab: the fused bf16 transposed convolution (lwg_conv_transpose4_nhwc_bf16) at the last up-sampling layer's shape.
-usage: up4lab.py [LIB.so ...]  (each in its own process; prints us / launch, PFLOP/s and a checksum of the output: variants must agree)"""
-import sys, os, subprocess, json, hashlib
+"""Lab: the decoders' three ConvTranspose2d(4, 2, 1) layers of the 512 x 512 generator as the fused F(2x2, 2x2) Winograd launch
+(csrc/convt_winograd.hip) against the direct forms (four parity launches / one grid), per layer: launch time, executed TFLOP/s (2 M 36/4 Cin N per
+input pixel: 36 products per 4 x 4 patch) against the fp32 matrix pipe (157.3), the direct time and max |wino - direct|.
+usage: up4lab.py [--lib LIB.so] [--frames F] [--reps n] [--only i]"""
+import argparse
+import os
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--only", type=int, default=-1)
+args = ap.parse_args()
+import torch
+from ipercore_amd import _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+from ipercore_amd import ops
+from ipercore_amd.networks import packing
+
+dev = "cuda:0"
+SHAPES = [("up0 64^2 256->256", 64, 256, 256, False), ("up1 128^2 256->128", 128, 256, 128, False), ("up2 256^2 128->64 (quad planes)", 256, 128, 64, True)]
 
 
-def worker(lib):
-    import torch
-    from ipercore_amd import _lib
-    if lib != "product":
-        _lib.LIB_PATH = os.path.abspath(lib)
-    from ipercore_amd import ops
-    from ipercore_amd.networks import packing
-    dev, BF = "cuda:0", torch.bfloat16
-    res = {}
-    for (B, H, Cin, N) in ((20, 512, 128, 64), (20, 256, 128, 64), (8, 512, 64, 64)):
-        g = torch.Generator().manual_seed(5)
-        w = (torch.randn(Cin, N, 4, 4, generator=g) * (Cin * 4) ** -0.5).to(BF).float()
-        specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(w, 0.1 * torch.randn(N, generator=g))]
-        x = torch.randn(B, H, H, Cin, generator=g).to(BF).to(dev)
-        y = torch.empty(B, 2 * H, 2 * H, N, device=dev, dtype=BF)
-        for _ in range(3):
-            ops.conv_transpose2d(x, specs, y, act=ops.ACT_RELU)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 10
-        e0.record()
-        for _ in range(n):
-            ops.conv_transpose2d(x, specs, y, act=ops.ACT_RELU)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / n * 1e3
-        flops = 2.0 * B * H * H * Cin * 16 * N
-        sha = hashlib.sha256(y[:2].cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:12]
-        res[f"{B}x{H}x{H}x{Cin}->{N}"] = {"us": round(us, 1), "PFLOP/s": round(flops / us / 1e9, 3), "sha": sha}
-    print("RESULT " + json.dumps(res))
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
 
 
-if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--worker":
-        worker(sys.argv[2])
-    else:
-        for lib in (sys.argv[1:] or ["product"]):
-            r = subprocess.run([sys.executable, __file__, "--worker", lib], capture_output=True, text=True)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
-            print("==", lib)
-            if not line:
-                print(r.stdout[-1500:], r.stderr[-3000:])
-                continue
-            for k, v in json.loads(line[0][7:]).items():
-                print(f"  {k:28s} {v}")
+def timeit(fn, n):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+tw_all = td_all = fl_all = 0.0
+for idx, (tag, S, Cin, N, q4) in enumerate(SHAPES):
+    if args.only >= 0 and idx != args.only:
+        continue
+    B = args.frames
+    specs = [packing.spec_to(s, dev) for s in packing.pack_conv_transpose(rnd((Cin, N, 4, 4), 3 + idx, (Cin * 4) ** -0.5), rnd((N,), 4 + idx, 0.1))]
+    x = rnd((B, S, S, Cin), 5 + idx).to(dev)
+    shape = (B, N // 4, 2 * S, 2 * S, 4) if q4 else (B, 2 * S, 2 * S, N)
+    yw, yd = torch.empty(*shape, device=dev), torch.empty(*shape, device=dev)
+
+    def run_w():
+        with ops.conv_precision("winograd"):
+            ops.conv_transpose2d(x, specs, yw, act=ops.ACT_RELU, q4=q4)
+
+    def run_d():
+        with ops.conv_precision("fp32"):
+            ops.conv_transpose2d(x, specs, yd, act=ops.ACT_RELU, q4=q4)
+
+    tw, td = timeit(run_w, args.reps), timeit(run_d, args.reps)
+    torch.cuda.synchronize()
+    M = B * S * S
+    ex, al = 2.0 * M * 9 * Cin * N, 2.0 * M * 16 * Cin * N
+    tw_all, td_all, fl_all = tw_all + tw, td_all + td, fl_all + ex
+    print(f"{idx} {tag:34s} B={B:3d}: wino {tw * 1e3:8.1f} us  executed {ex / tw / 1e9:6.1f} TF/s = {ex / tw / 1e9 / 157.3:.3f} of the pipe  algorithmic {al / tw / 1e9:6.1f} TF/s"
+          f"  | direct {td * 1e3:8.1f} us ({al / td / 1e9 / 157.3:.3f})  x{td / tw:.2f}  max|d| {float((yw - yd).abs().max()):.1e}", flush=True)
+if tw_all and args.only < 0:
+    print(f"sum: wino {tw_all * 1e3:.1f} us, executed {fl_all / tw_all / 1e9 / 157.3:.3f} of the pipe; direct {td_all * 1e3:.1f} us (x{td_all / tw_all:.2f})")
