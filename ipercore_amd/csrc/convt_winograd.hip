@@ -9,9 +9,10 @@
 //   weight panel), the same over columns: 25 transformed values per (patch, input channel) serve all 36 products.
 // Workgroup: 512 threads = 8 waves; block = 8 x 8 patches (16 x 16 input pixels -> 32 x 32 output pixels) x 32 output channels; wave w owns ALL NINE
 // products of parity w % 4 for the 32 patches of tile w / 4 (9 accumulator tiles of 32 x 32 = 144 VGPRs, rows = output channels): the output
-// transform A^T M A is register-local - no exchange between waves, every wave writes its parity's pixels itself.
+// transform A^T M A is register-local; the block's outputs then cross LDS once so that the global stores are whole 128-byte (NHWC) / 512-byte
+// (channel-quad planes) runs.
 // A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the
-// panel Upk[4][Cin/8][4][2][N][12] (one k-pair ahead, two register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
+// panel Upk[4][Cin/8][4][2][N][12] (two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
 // halo goes global -> registers (three stages ahead) -> raw[s % 2]; every thread transforms ONE (patch, channel) 4 x 4 -> 25 values (27 subtractions)
 // from raw[(s + 1) % 2] into Vs[(s + 1) % 2] beside the MFMAs of k-pairs 0 .. 2; one barrier per stage, behind k-pair 2.
 // Rounding: the transforms only add / subtract (no 1/2 factors as in F(2x2, 3x3)); panel entries are sums of up to four weights formed in fp64
@@ -34,11 +35,25 @@
 #define DUMP_OFF (2 * RAW_FLOATS + 2 * VS_FLOATS)                 // where the threads without a halo element store their zeros (dead LDS)
 #define DUMP_FLOATS (WG_THREADS + 3 * PLANE + RAW_FLOATS)
 #define LOOP_FLOATS (DUMP_OFF + DUMP_FLOATS)
+#define OROW 36                              // floats per pixel row of the epilogue's exchange buffer [32 x 32 output pixels][32 channels + 4]
+#define OUT_FLOATS (32 * 32 * OROW)
 #define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
+#ifdef CTW_NOWSB                             // lab: leave the order of the loop's instructions to the compiler
+#define WSB() do { } while (0)
+#else
 #define WSB() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 
 template <int V> struct IntT { static constexpr int value = V; };
+
+// lab instrumentation (compiled out of the product): tools/up4lab.py --ts on a -DLWG_CTW_TS variant library - every wave stamps kernel entry, K-loop
+// entry, K-loop exit and its end into args->res (four 64-bit stamps per wave)
+#ifdef LWG_CTW_TS
+#define CTS(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CTS(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ floatx4 ctw_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
@@ -57,6 +72,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
     const int n0 = blockIdx.y * NBT;
     const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
+    CTS(0);
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * Cin), 0, (int)((unsigned)(H * W) * (unsigned)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
     const int par = wid & 3, py = par >> 1, px = par & 1;    // this wave's output parity
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         for (int k = 0; k < 4; ++k) dst[k * PLANE] = v[k];
     };
     // weights: lane = (k-half lane / 32, channel lane % 32); element (parity, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
-    floatx4 ufr[2][3];                                       // [register set = k-pair % 2][products 0-3 | 4-7 | 8 + padding]
+    floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 + padding]: loaded TWO k-pairs ahead
     const unsigned uvoff = (unsigned)((((lane >> 5) * N + n0 + (lane & 31)) * 12) * 4);
     const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
     const unsigned upar = (unsigned)par * (unsigned)nst * 4u * ukk;
@@ -136,16 +152,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
         float dd[4][4];
         auto mf = [&](int kk, int q) {
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk & 1][q >> 2][q & 3], fb[kk & 1][q], acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk][q >> 2][q & 3], fb[kk & 1][q], acc[q], 0, 0, 0);
             WSB();
         };
-        auto uldn = [&](int kk) {                            // the weights of the NEXT k-pair (kk + 1 of this stage, or 0 of the next) -> the other set
-            if (kk < 3) {
+        auto uldn = [&](int kk) {                            // the weights of the k-pair after the next (kk + 2 of this stage, or kk - 2 of the next)
+            if (kk < 2) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) ufr[(kk + 1) & 1][j] = uld1(s, kk + 1, j);
+                for (int j = 0; j < 3; ++j) ufr[kk + 2][j] = uld1(s, kk + 2, j);
             } else if (nxt) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) ufr[0][j] = uld1(s + 1, 0, j);
+                for (int j = 0; j < 3; ++j) ufr[kk - 2][j] = uld1(s + 1, kk - 2, j);
             }
             WSB();
         };
@@ -159,6 +175,54 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         mf(0, 1);
         if (nxt) { rst1(set, 1, rreg[1]); rreg[1] = rld1(s3, 1); }
         WSB();
+#ifdef CTW_SPREAD                            // lab: the patch reads and the transform a few instructions per MFMA slot
+        float t[5][4];
+        auto ddr = [&](int i) {
+            if (nxt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] = smem[dbs[set ^ 1] + i * HALO + j];
+            }
+            WSB();
+        };
+        auto tcol = [&](int i) {
+            if (nxt) {
+                float* v = smem + vbs[set ^ 1] + (5 * i) * KS * VSTR;
+                v[0 * KS * VSTR] = t[i][0] - t[i][1];
+                v[1 * KS * VSTR] = t[i][1];
+                v[2 * KS * VSTR] = t[i][2] - t[i][1];
+                v[3 * KS * VSTR] = t[i][2];
+                v[4 * KS * VSTR] = t[i][3] - t[i][2];
+            }
+            WSB();
+        };
+        mf(0, 2); ddr(0);
+        mf(0, 3); ddr(1);
+        mf(0, 4); ddr(2);
+        mf(0, 5); ddr(3);
+        mf(0, 6);
+        mf(0, 7);
+        if (nxt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = dd[0][j] - dd[1][j];
+                t[1][j] = dd[1][j];
+                t[2][j] = dd[2][j] - dd[1][j];
+                t[3][j] = dd[2][j];
+                t[4][j] = dd[3][j] - dd[2][j];
+            }
+        }
+        WSB();
+        mf(0, 8);
+        uldn(1);
+        fragread(set, 2);
+        WSB();
+        mf(1, 0); tcol(0);
+        mf(1, 1); tcol(1);
+        mf(1, 2); tcol(2);
+        mf(1, 3); tcol(3);
+        mf(1, 4); tcol(4);
+        mf(1, 5); mf(1, 6); mf(1, 7); mf(1, 8);
+#else
         mf(0, 2);
         if (nxt) {
 #pragma unroll
@@ -176,6 +240,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         if (nxt) transform_store(set ^ 1, dd);
         WSB();
         mf(1, 1); mf(1, 2); mf(1, 3); mf(1, 4); mf(1, 5); mf(1, 6); mf(1, 7); mf(1, 8);
+#endif
         // k-pair 2
         uldn(2);
         fragread(set, 3);
@@ -198,7 +263,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
             r1[q] = rld1(1, q);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ufr[0][j] = uld1(0, 0, j);
+        for (int j = 0; j < 3; ++j) {
+            ufr[0][j] = uld1(0, 0, j);
+            ufr[1][j] = uld1(0, 1, j);
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
 #pragma unroll
@@ -222,6 +290,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     }
     __syncthreads();
     fragread(0, 0);
+    CTS(1);
     {
         int s = 0;
         for (; s + 2 < nst; s += 2) {
@@ -231,36 +300,60 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         iteration(s, IntT<0>(), IntT<1>());
         iteration(s + 1, IntT<1>(), IntT<0>());
     }
-    // epilogue (register-local): Y[a][b] = sum over xi in {a, a + 1}, nu in {b, b + 1} of M[xi][nu]; + bias, activation; this lane holds patch
-    // pt * 32 + lane % 32 and, per register group g, the four channels n0 + 8 g + 4 (lane / 32) ..: one 16-byte store per (output pixel, g)
+    CTS(2);
+    // epilogue: Y[a][b] = sum over xi in {a, a + 1}, nu in {b, b + 1} of M[xi][nu] is register-local (this lane holds patch pt * 32 + lane % 32 and,
+    // per register group g, the four channels 8 g + 4 (lane / 32) ..); + bias, activation; then ONE exchange through LDS - the block's 32 x 32 output
+    // pixels x 32 channels, rows of 36 floats - so that the global stores are whole lines: written straight from the accumulator layout a lane's
+    // 16-byte pieces lie a pixel (YC floats) apart and the stores of a 256-channel layer took 55 k cycles per block (9 K stages' worth; r05_h)
     const int p = pt * 32 + (lane & 31);
     const int ety = p >> 3, etx = p & 7;
     const int chl = 4 * (lane >> 5);
-    const bool q4 = a.ydt == LWG_DT_F32_Q4;
-    const size_t plane = (size_t)a.YH * a.YW;
+    __syncthreads();                                         // every wave has read its last fragments: the loop's LDS is free
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int ch = a.ycoff + n0 + 8 * g + chl;
         const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + n0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {
-                const int iy = y0 + 2 * ety + ia, ix = x0 + 2 * etx + ib;
-                if (iy < H && ix < W) {
-                    floatx4 o;
+                floatx4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = 4 * g + k;
-                        const float v = (acc[3 * ia + ib][r] + acc[3 * ia + ib + 1][r]) + (acc[3 * ia + 3 + ib][r] + acc[3 * ia + 4 + ib][r]);
-                        o[k] = lwg_act(v + bv[k], a.act);
-                    }
-                    const size_t opix = (size_t)(2 * iy + py) * a.YW + (2 * ix + px);
-                    float* dst = q4 ? a.y + (((size_t)b * (a.YC >> 2) + (ch >> 2)) * plane + opix) * 4 : a.y + ((size_t)b * plane + opix) * a.YC + ch;
-                    *reinterpret_cast<floatx4*>(dst) = o;
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * g + k;
+                    const float v = (acc[3 * ia + ib][r] + acc[3 * ia + ib + 1][r]) + (acc[3 * ia + 3 + ib][r] + acc[3 * ia + 4 + ib][r]);
+                    o[k] = lwg_act(v + bv[k], a.act);
                 }
+                const int ly = 2 * (2 * ety + ia) + py, lx = 2 * (2 * etx + ib) + px;      // the pixel inside the block's 32 x 32 outputs
+                *reinterpret_cast<floatx4*>(smem + (ly * 32 + lx) * OROW + 8 * g + chl) = o;
             }
     }
+    __syncthreads();
+    const int oy0 = 2 * y0, ox0 = 2 * x0;
+    const size_t plane = (size_t)a.YH * a.YW;
+    if (a.ydt == LWG_DT_F32_Q4) {
+        // channel-quad planes (B, YC/4, YH, YW, 4): 32 lanes = one output row of the block in one plane, 512 contiguous bytes
+        const int lx = tid & 31;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int idx = pass * 16 + (tid >> 5), cq = idx & 7, ly = idx >> 3;
+            if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(smem + (ly * 32 + lx) * OROW + 4 * cq);
+                *reinterpret_cast<floatx4*>(a.y + (((size_t)b * (a.YC >> 2) + ((a.ycoff + n0) >> 2) + cq) * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * 4) = v;
+            }
+        }
+    } else {
+        // NHWC: 8 lanes = the block's 32 channels of one pixel, 128 contiguous bytes
+        const int cq = tid & 7;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int pi = pass * 64 + (tid >> 3), ly = pi >> 5, lx = pi & 31;
+            if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(smem + pi * OROW + 4 * cq);
+                *reinterpret_cast<floatx4*>(a.y + ((size_t)b * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * a.YC + a.ycoff + n0 + 4 * cq) = v;
+            }
+        }
+    }
+    CTS(3);
 }
 
 // args: the parity-(0, 0) launch description of lwg_conv_transpose4_nhwc_f32 (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2 H, YW = 2 W,
@@ -278,7 +371,7 @@ extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_strea
         a.ycoff < 0 || (a.ycoff % 4) != 0 || (a.YC % 4) != 0 || a.ycoff + a.N > a.YC)
         return (int)hipErrorInvalidValue;
     if ((unsigned long long)a.H * a.W * a.C0 * 4ull >= (unsigned long long)WINO_OOB || 192ull * a.C0 * a.N >= 0xffffffffull) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)LOOP_FLOATS * 4;
+    const size_t lds = (size_t)(LOOP_FLOATS > OUT_FLOATS ? LOOP_FLOATS : OUT_FLOATS) * 4;
     static unsigned long long done = 0;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_convt_winograd_kernel), lds, done); e != hipSuccess) return (int)e;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
