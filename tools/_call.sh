@@ -1,3 +1,2 @@
-timeout 200 python -m pytest tests -q -m gpu -k "check_winograd_up4" 2>&1 | tail -3
-for v in "" "--lib tools/lab/ctw_spread.so" "--lib tools/lab/ctw_nowsb.so"; do echo "== $v"; timeout 200 python tools/up4lab.py --frames 64 --reps 5 $v 2>&1 | grep -v amdgpu | tail -4; done
-timeout 200 python tools/up4lab.py --frames 16 --ts --lib tools/lab/ctw_ts.so 2>&1 | grep -v amdgpu | grep "\[ts\]"
+timeout 900 python -m pytest tests -q -m gpu -k "winograd or check_pipeline_full_512 or whole_clip or generator_golden or benched_shapes_512 or pipeline_tiny or check_conv_transpose or num_source_1_and_8" 2>&1 | tail -4
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_h.json 2> gpurun_out/bench_h.err; echo "bench exit=$?"; head -c 400 gpurun_out/bench_h.json; echo
