@@ -903,8 +903,9 @@ def main(argv=None):
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split",
                       "winograd": "f32"}[args.precision],
-            "conv_engine": {"winograd": "fp32 MFMA: 3x3 / stride 1 layers as fused F(2x2,3x3) Winograd convolutions (lwg_conv_winograd_kernel), the strided / "
-                                        "transposed / first layers as direct implicit GEMMs (lwg_conv_igemm_kernel)",
+            "conv_engine": {"winograd": "fp32 MFMA: 3x3 / stride 1 layers as fused F(2x2,3x3) Winograd convolutions (lwg_conv_winograd_kernel), the transposed "
+                                        "convolutions as fused F(2x2,2x2) Winograd convolutions (lwg_convt_winograd_kernel), the strided / first layers as direct "
+                                        "implicit GEMMs (lwg_conv_igemm_kernel)",
                             "fp32": "fp32 MFMA: every layer as a direct implicit GEMM (lwg_conv_igemm_kernel)",
                             "bf16": "bf16 MFMA implicit GEMMs", "split": "bf16x6 implicit GEMMs"}[args.precision],
             "data": "synthetic" + (" (tiny architecture, CPU plumbing run: NOT a measurement)" if (args.tiny_arch or not on_gpu) else ""),
@@ -957,7 +958,8 @@ def main(argv=None):
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
                                                     "MFMA work actually executed) + fp32 first layers",
                                            "winograd": "lwg_conv_winograd_kernel (F(2x2,3x3) on the fp32 MFMA pipe: achieved counts the EXECUTED flops, "
-                                                       "2 M 4 Cin N on those launches) + lwg_conv_igemm_kernel for the strided / transposed / first layers"}[args.precision],
+                                                       "2 M 4 Cin N on those launches) + lwg_convt_winograd_kernel (F(2x2,2x2) form of the transposed convolutions: "
+                                                       "2 M 9 Cin N per input pixel instead of 16) + lwg_conv_igemm_kernel for the strided / first layers"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops * world / frames / 1e9, 2),
                                 "share_of_step_time": round(conv_ms * 1e-3 / dt, 4)}
@@ -968,6 +970,8 @@ def main(argv=None):
                 line["roofline"]["by_kernel"] = conv_by_kind
                 if wk.get("executed_tflops"):
                     line["roofline"]["winograd_kernel_frac"] = round(wk["executed_tflops"] / peak, 4)
+                if (conv_by_kind.get("winograd_up4") or {}).get("executed_tflops"):
+                    line["roofline"]["winograd_up4_kernel_frac"] = round(conv_by_kind["winograd_up4"]["executed_tflops"] / peak, 4)
             if args.precision == "bf16":
                 line["roofline"]["hbm_time_at_peak_us_per_launch"] = round(timer.bytes / n_launch / (PEAK_HBM_TBS * 1e12) * 1e6, 2)
                 gov, hbm_share = timer.governing(PEAK_BF16_MFMA_TFLOPS)
