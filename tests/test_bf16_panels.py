@@ -227,6 +227,39 @@ def test_winograd_panel_cache_and_launch_plan(monkeypatch):
     assert ops._wino_plan(a, _S2, y_small, True) is None
 
 
+def test_winograd_transpose_panel_and_algorithm_cpu():
+    """The F(2x2, 2x2) Winograd form of ConvTranspose2d(4, 2, 1) (csrc/convt_winograd.hip) restated on the CPU around the REAL panel builder
+    (ops._wwino_t, from the four parity GEMM panels): 25 transformed values per 4 x 4 input patch and channel (row / column forms r0-r1, r1, r2-r1, r2,
+    r3-r2), product (xi, nu) of parity (py, px) = form (2 py + xi, 2 px + nu) x panel element 3 xi + nu (the sign of a shared form lives in the panel),
+    Y[a][b] = the sum of the four products around (a, b) - equal to torch's transposed convolution on a ragged size; panel layout
+    [4][Cin/8][4][2][N][12] with the padding entries zero."""
+    torch.manual_seed(0)
+    B, H, W, Cin, N = 1, 6, 5, 32, 64
+    w, b, x = torch.randn(Cin, N, 4, 4) * 0.1, torch.randn(N) * 0.1, torch.randn(B, H, W, Cin)
+    want = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    specs = packing.pack_conv_transpose(w, b)
+    assert ops._parity_specs_ok(specs) and not ops._parity_specs_ok(specs[::-1])
+    U = ops._wwino_t(specs)
+    assert U.shape == (4, Cin // 8, 4, 2, N, 12) and U.dtype == torch.float32 and float(U[..., 9:].abs().max()) == 0.0 and ops._wwino_t(specs) is U
+    Uc = U.double().permute(0, 1, 2, 3, 5, 4).reshape(4, Cin, 12, N)                       # [parity][c = 8 s + 2 kk + kh][product][n]
+    xp = torch.zeros(H + 4, W + 4, Cin, dtype=torch.float64)
+    xp[1:H + 1, 1:W + 1] = x[0].double()                                                    # xp[r] = x[r - 1]: the patch of input rows i - 1 .. i + 2 is xp[i : i + 4]
+    y = torch.zeros(2 * H, 2 * W, N, dtype=torch.float64)
+    for i in range(0, H + 1, 2):
+        for j in range(0, W + 1, 2):
+            d = xp[i:i + 4, j:j + 4]
+            t = torch.stack([d[0] - d[1], d[1], d[2] - d[1], d[2], d[3] - d[2]])
+            V = torch.stack([t[:, 0] - t[:, 1], t[:, 1], t[:, 2] - t[:, 1], t[:, 2], t[:, 3] - t[:, 2]], dim=1)      # (5, 5, Cin)
+            for par in range(4):
+                py, px = par >> 1, par & 1
+                M = torch.stack([torch.stack([V[2 * py + xi, 2 * px + nu] @ Uc[par, :, 3 * xi + nu] for nu in range(3)]) for xi in range(3)])
+                for a_ in range(2):
+                    for b_ in range(2):
+                        if i + a_ < H and j + b_ < W:
+                            y[2 * (i + a_) + py, 2 * (j + b_) + px] = M[a_, b_] + M[a_, b_ + 1] + M[a_ + 1, b_] + M[a_ + 1, b_ + 1] + b.double()
+    assert (y - want[0]).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+
+
 def test_fused_transpose_dispatch_and_flow_cache(monkeypatch):
     """Host logic around two round-2 kernels (no GPU): ops.conv_transpose2d picks the one-launch form only for bf16 tensors with
     Cin <= 128 and the four parity specs in order, and hands the accounting hook ONE pseudo-spec for the whole transposed
