@@ -409,7 +409,9 @@ class _FusedTransposeSpec(object):
 def conv_transpose2d(x, specs, y, act=ACT_NONE, splitk=False, out_hw=None, q4=False):
     """y (B,2H,2W,N) <- ConvTranspose2d(4, 2, 1) of x (B,H,W,Cin) given its four parity specs (packing.pack_conv_transpose).
     bf16 activations with Cin <= 128: ONE launch (lwg_conv_transpose4_nhwc_bf16: the input block is staged once for the four
-    parities); otherwise the four parity launches of ``conv2d``.  ``splitk`` / ``out_hw`` are handed to those four launches (the
+    parities); fp32 in the "winograd" mode on the synthesis path (splitk=False): ONE fused F(2x2, 2x2) Winograd launch
+    (lwg_conv_transpose4_winograd_f32: 36 products per 4 x 4 input patch instead of 64; fp32-grade, not the direct forms' bits);
+    otherwise the one-grid form for small fp32 launches or the four parity launches of ``conv2d``.  ``splitk`` / ``out_hw`` are handed to those four launches (the
     training callers' plan: the one-grid form and the four-launch fall-back then differ only in launch count); ``out_hw`` is a
     callable spec -> (OH, OW) or None.  q4 (fp32 only): y is (B, N/4, 2H, 2W, 4), channel-quad planes (see ``conv2d``)."""
     s0 = specs[0]
