@@ -14,7 +14,7 @@
 // A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the
 // panel Upk[4][Cin/8][4][2][N][12] (two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
 // halo goes global -> registers (three stages ahead) -> raw[s % 2]; every thread transforms ONE (patch, channel) 4 x 4 -> 25 values (27 subtractions)
-// from raw[(s + 1) % 2] into Vs[(s + 1) % 2] beside the MFMAs of k-pairs 0 .. 2; one barrier per stage, behind k-pair 2.
+// from raw[(s + 1) % 2] into Vs[(s + 1) % 2] beside the MFMAs of k-pairs 0 and 1; one barrier per stage, in the middle of k-pair 3.
 // Rounding: the transforms only add / subtract (no 1/2 factors as in F(2x2, 3x3)); panel entries are sums of up to four weights formed in fp64
 // and rounded once.  fp32-grade, NOT the direct kernel's bits: part of the "winograd" precision mode.
 #include <hip/hip_runtime.h>
@@ -38,6 +38,13 @@
 #define OROW 36                              // floats per pixel row of the epilogue's exchange buffer [32 x 32 output pixels][32 channels + 4]
 #define OUT_FLOATS (32 * 32 * OROW)
 #define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
+// slot plan of the K loop (profiles/r05_h_convt_winograd_lab.txt, 64 frames, all three layers): first plan (patch reads and transform in one slot each,
+// barrier behind k-pair 2) 0.622 of the pipe; barrier in front of k-pair 2 0.644; barrier in the middle of k-pair 3 0.646; that + the patch reads and the
+// transform a few instructions per slot 0.650 = the product's plan.  -DCTW_LAB_BASE builds the first plan.
+#ifndef CTW_LAB_BASE
+#define CTW_BAR_LATE
+#define CTW_SPREAD
+#endif
 #ifdef CTW_NOWSB                             // lab: leave the order of the loop's instructions to the compiler
 #define WSB() do { } while (0)
 #else
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         mf(0, 1);
         if (nxt) { rst1(set, 1, rreg[1]); rreg[1] = rld1(s3, 1); }
         WSB();
-#ifdef CTW_SPREAD                            // lab: the patch reads and the transform a few instructions per MFMA slot
+#ifdef CTW_SPREAD                            // the patch reads and the transform a few instructions per MFMA slot
         float t[5][4];
         auto ddr = [&](int i) {
             if (nxt) {
@@ -245,13 +252,27 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         uldn(2);
         fragread(set, 3);
         WSB();
-        mf(2, 0); mf(2, 1); mf(2, 2); mf(2, 3); mf(2, 4); mf(2, 5); mf(2, 6); mf(2, 7); mf(2, 8);
+#if defined(CTW_BAR_EARLY)                   // lab: the stage's barrier in front of k-pair 2 instead of behind it
         __syncthreads();
+        WSB();
+#endif
+        mf(2, 0); mf(2, 1); mf(2, 2); mf(2, 3); mf(2, 4); mf(2, 5); mf(2, 6); mf(2, 7); mf(2, 8);
+#if !defined(CTW_BAR_EARLY) && !defined(CTW_BAR_LATE)
+        __syncthreads();
+#endif
         // k-pair 3: the next stage's first fragments
         uldn(3);
+#if defined(CTW_BAR_LATE)                    // ... or in the middle of k-pair 3 (the product's plan)
+        mf(3, 0); mf(3, 1); mf(3, 2); mf(3, 3);
+        __syncthreads();
+        if (nxt) fragread(set ^ 1, 0);
+        WSB();
+        mf(3, 4); mf(3, 5); mf(3, 6); mf(3, 7); mf(3, 8);
+#else
         if (nxt) fragread(set ^ 1, 0);
         WSB();
         mf(3, 0); mf(3, 1); mf(3, 2); mf(3, 3); mf(3, 4); mf(3, 5); mf(3, 6); mf(3, 7); mf(3, 8);
+#endif
     };
 
     // prologue: stages 0 and 1 -> raw[0], raw[1]; stage 0 transformed; stage 2's halo in registers; the first weights and fragments
