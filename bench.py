@@ -89,7 +89,7 @@ class ConvTimer:
             # ... and the F(2x2, 2x2) form of a transposed convolution 36 per 4 x 4 input patch where the direct form has 64
             ex = 2.0 * M * spec.algo_kn * {"winograd": 4.0 / 9.0, "winograd_up4": 9.0 / 16.0}.get(info["kind"], 1.0)
             self.exec_flops += ex
-            k = self.kinds.setdefault(info["kind"], [0, 0.0, 0.0, []])     # calls, algorithmic flops, executed flops, event pairs
+            k = self.kinds.setdefault(info["kind"], [0, 0.0, 0.0, [], 0.0, 0])     # calls, algorithmic flops, executed flops, event pairs, bytes, kernels
             k[0] += 1
             k[1] += 2.0 * M * spec.algo_kn
             k[2] += ex
@@ -99,6 +99,8 @@ class ConvTimer:
             nbytes = float(act_bytes) * (M * spec.stride ** 2 * spec.Cin + out + (M * spec.N if epi == 1 else 0)) + \
                 float(act_bytes) * spec.w.numel()
             self.bytes += nbytes
+            k[4] += nbytes
+            k[5] += info["kernels"]
             self.meta.append((M, spec.N, spec.Cin, spec.ntaps, spec.stride, spec.omul, 2.0 * M * spec.algo_kn, nbytes))
 
     def result(self):
@@ -126,10 +128,11 @@ class ConvTimer:
     def by_kind(self):
         """Per kernel family: calls, measured ms (sum of the bracketed durations), algorithmic and executed TFLOP/s."""
         out = {}
-        for kind, (calls, alg, ex, pairs) in self.kinds.items():
+        for kind, (calls, alg, ex, pairs, nbytes, kernels) in self.kinds.items():
             ms = sum(a.elapsed_time(b) for a, b in pairs)
             out[kind] = {"calls": calls, "ms": round(ms, 3), "algorithmic_tflops": round(alg / ms / 1e9, 2) if ms > 0 else None,
-                         "executed_tflops": round(ex / ms / 1e9, 2) if ms > 0 else None}
+                         "executed_tflops": round(ex / ms / 1e9, 2) if ms > 0 else None, "kernel_launches": kernels,
+                         "algorithmic_bytes_per_launch": round(nbytes / max(kernels, 1), 1)}
         return out
 
     def governing(self, peak_tflops, peak_tbs=PEAK_HBM_TBS):
@@ -694,6 +697,10 @@ def main(argv=None):
                     help="cpu: plumbing dry run for the CPU test-suite ONLY (tests/test_bench_launch.py installs the emulated C ABI "
                          "around main(); without it every op raises on CPU tensors - there is no CPU product path)")
     ap.add_argument("--no-overlap-gather", dest="overlap", action="store_false", help="one all-gather after the frame loop")
+    ap.add_argument("--chunk-plan", choices=("auto", "batches", "one"), default="auto",
+                    help="N > 1: the chunk schedule of a rank's shard.  batches: frame batches of --frame-batch, each exchanged behind the next one's "
+                         "synthesis (38 frames -> 24 + 14); one: the shard as ONE chunk (no launch set cut, the exchange exposed); auto: whichever the "
+                         "ring model of sharding.choose_chunk_plan predicts faster from this run's measured per-frame time")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=("fp32", "bf16", "split", "winograd"), default="winograd",
                     help="bf16: BASELINE configs[3] mode - bf16 MFMA operands and bf16 activation storage in the convs (fp32 accumulation); "
@@ -788,11 +795,14 @@ def main(argv=None):
     fmt = {"post": post}
     stats = {}
 
+    plan_box = {"plan": None, "model": None}       # N > 1: the chunk schedule, chosen after the first warm-up step (below)
     if clip:
         def step(i):
             st = {"sync": sync} if world > 1 else {}
-            v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=fmt["post"], stats=st)
+            v = sharding.sharded_synthesize(im, tgt, "smooth", gather=True, overlap=args.overlap, prepared=True, post=fmt["post"], stats=st,
+                                            plan=plan_box["plan"])
             stats.setdefault("exposed_gather_s", []).append(st.get("exposed_gather_s"))
+            stats.setdefault("compute_s", []).append(st.get("compute_s"))
             stats.update({k: st[k] for k in ("shard", "bytes_received", "chunks", "chunk_lengths") if k in st})
             return v
         frames_per_step = n_clip
@@ -808,6 +818,18 @@ def main(argv=None):
         frames_per_step = FB * world
 
     last = None
+    if world > 1 and clip and args.overlap and args.chunk_plan == "auto":
+        # the chunk schedule of the timed steps (sharding.choose_chunk_plan: one chunk per shard - no launch set cut, the whole exchange exposed - or
+        # frame batches exchanged behind each other's synthesis), from THIS run's own per-frame time: one untimed step on the default plan, the
+        # slowest rank's compute time per frame, the per-link ring model of the exchange; every rank computes the same choice
+        step(0)
+        step(0)
+        t_f = torch.tensor([(stats["compute_s"][-1] or 0.0) / max(1, -(-n_clip // world))], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_f, op=dist.ReduceOp.MAX)
+        bpf = S * S * 3 * (1 if args.gather_dtype == "u8" else 4)
+        plan_box["plan"], plan_box["model"] = sharding.choose_chunk_plan(n_clip, world, FB, sharding.round_frames_of(im), bpf, float(t_f.item()))
+    elif world > 1 and clip and args.overlap and args.chunk_plan == "one":
+        plan_box["plan"] = [(0, max(sharding.shard_counts(n_clip, world)))]
     for i in range(W):                       # untimed: settles the clock and, for N > 1, sets up RCCL's channels at the timed sizes
         last = step(i)
     if last is None and world > 1:
@@ -817,6 +839,7 @@ def main(argv=None):
         dist.barrier()
     sync()
     stats.pop("exposed_gather_s", None)
+    stats.pop("compute_s", None)
     timer.reset()
     timer.enabled = True
     t0 = time.perf_counter()
@@ -862,6 +885,7 @@ def main(argv=None):
     if world > 1 and clip:
         mine_stats = {"rank": rank, "shard": list(stats.get("shard", ())), "frames": stats["shard"][1] - stats["shard"][0],
                       "exposed_gather_ms_per_step": round(1e3 * float(np.mean([x for x in stats.get("exposed_gather_s", []) if x is not None] or [0.0])), 3),
+                      "compute_ms_per_step": round(1e3 * float(np.mean([x for x in stats.get("compute_s", []) if x is not None] or [0.0])), 3),
                       "bytes_received_per_step": stats.get("bytes_received"), "chunk_lengths": stats.get("chunk_lengths")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_stats)
@@ -927,13 +951,23 @@ def main(argv=None):
         }
         if per_rank is not None:
             line["config"]["per_rank"] = per_rank
+            # self-diagnosing top level for the first 8-GPU run (no hardware curve was measured by the builder): where a step's time went on the
+            # slowest rank, what every rank rendered, what RCCL saw, which chunk schedule ran and what the model behind that choice predicted
+            line["t_compute_ms"] = max(r["compute_ms_per_step"] for r in per_rank)
+            line["t_exposed_gather_ms"] = max(r["exposed_gather_ms_per_step"] for r in per_rank)
+            line["frames_per_rank"] = [r["frames"] for r in per_rank]
+            line["rccl_world_size"] = dist.get_world_size()
+            line["backend"] = dist.get_backend()
+            line["chunk_plan"] = per_rank[0].get("chunk_lengths")
+            line["chunk_plan_model"] = plan_box["model"]
+            line["bytes_received_per_rank_per_step"] = per_rank[0].get("bytes_received_per_step")
         if exchange_u8 is not None:
             line["exchange_u8"] = exchange_u8
         line["self_check"] = self_check["result"] if self_check else None
         if self_check:
             line["self_check_detail"] = self_check
         if n_launch:
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_by_kernel = None, None, None
             tname = {"winograd": "pmc_traffic.json", "fp32": "pmc_traffic_direct.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
             tpath = os.path.join(ROOT, "profiles", tname) if tname else None       # written by tools/pmc_round.sh (separate --pmc passes)
             if tpath and S == (512 if is_f32 else 1024) and args.streams == 1 and os.path.exists(tpath):
@@ -943,6 +977,15 @@ def main(argv=None):
                 if cfg.get("frame_batch") == FB and cfg.get("image_size") == S and cfg.get("workload") == args.workload and \
                         cfg.get("precision", "fp32") == args.precision:   # same launches
                     traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                    # like for like (round 6): the counters per KERNEL FAMILY against that family's own algorithmic bytes per kernel launch
+                    fam = {"lwg_conv_winograd_kernel": "winograd", "lwg_convt_winograd_kernel": "winograd_up4", "lwg_conv_igemm_kernel": "direct"}
+                    traffic_by_kernel = {}
+                    for kname, rec in (tj.get("by_kernel") or {}).items():
+                        bk = conv_by_kind.get(fam.get(kname, kname)) or {}
+                        tb, ab = rec.get("traffic_bytes_per_launch"), bk.get("algorithmic_bytes_per_launch")
+                        traffic_by_kernel[kname] = {"traffic": tb, "algorithmic_bytes_per_launch": ab, "launches_pmc_pass": rec.get("launches_fetch_pass"),
+                                                    "launches_per_step": (bk.get("kernel_launches") or 0) // max(K, 1),
+                                                    "traffic_over_algorithmic": round(tb / ab, 3) if tb and ab else None}
             # matrix-pipe flops EXECUTED per second over all conv launches: the direct kernels execute their algorithmic flops, the F(2x2,3x3)
             # Winograd kernel 4/9 of them (16 products per 2 x 2 outputs instead of 36) - a roofline fraction is executed work over the pipe's peak
             achieved = (conv_exec_flops if args.precision == "winograd" else conv_flops) / (conv_ms * 1e-3) / 1e12
@@ -953,6 +996,7 @@ def main(argv=None):
                                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
+                                "traffic_by_kernel": traffic_by_kernel,
                                 "kernel": {"fp32": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
                                            "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "

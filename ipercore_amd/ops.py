@@ -898,6 +898,9 @@ class PanelCache:
         # Winograd fragment panels derived from registered GEMM panels (ops._wwino): key (panel address, tap order) -> U; the ones whose
         # weights train are re-derived by ONE launch per step behind the GEMM panels' refresh (lwg_winograd_panels_f32)
         self.src_of, self.wino, self.wino_rows, self.wino_table, self.wino_blocks = {}, {}, [], None, 0
+        # frozen weights (the loss networks): packed once - but watched: [weight, tensor version at pack time, cache key]; refresh() re-packs a
+        # panel whose weight was written since (load_state_dict / an un-freeze after the first step) instead of training against a stale one
+        self.frozen = []
 
     def cacheable(self, w):
         return w.untyped_storage().data_ptr() in self.storages
@@ -919,11 +922,43 @@ class PanelCache:
         if w.untyped_storage().data_ptr() in self.training_storages:     # a frozen weight (the loss networks) is packed once, by the caller's launch
             self.rows.append((w.data_ptr(), out.data_ptr(), D1, KH * KW, 1 if transposed else 0, len(kidx), cin, cin_pad, nout, n_pad, Kp, kidx))
             self.table = None
+        else:
+            self.frozen.append([w, w._version, key])
         return out, True
+
+    def _repack_stale_frozen(self):
+        """Frozen weights written in place since their panels were packed: single launches, eager only (a captured step cannot see the host check:
+        ``invalidate()`` + a re-capture is the route there, and the trainer re-captures when this raises)."""
+        stale = [f for f in self.frozen if f[0]._version != f[1]]
+        if not stale:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PanelCache: a frozen weight changed (load_state_dict / un-freeze) - its panels cannot be re-packed inside a hipGraph "
+                               "capture: call refresh() eagerly once (or invalidate()) before capturing")
+        for f in stale:
+            w, _, key = f
+            _, _, transposed, kidx, cin, cin_pad, nout, n_pad = key
+            out = self.out[key]
+            D0, D1, KH, KW = w.shape
+            arr = (ctypes.c_int * len(kidx))(*kidx)
+            _lib.check(_lib.lib().lwg_pack_panel_f32(_ptr(w), D0, D1, KH, KW, 1 if transposed else 0, arr, len(kidx), cin, cin_pad, nout, n_pad,
+                                                     _ptr(out), _stream()), "lwg_pack_panel_f32")
+            for (pp, tap9), U in self.wino.items():
+                if pp == out.data_ptr():
+                    arr9 = (ctypes.c_int * 9)(*tap9)
+                    _lib.check(_lib.lib().lwg_winograd_panel_f32(_ptr(out), _ptr(U), cin_pad, out.shape[1], arr9, _stream()), "lwg_winograd_panel_f32")
+            f[1] = w._version
+
+    def invalidate(self):
+        """Forget every panel (weights re-allocated or reloaded wholesale): the next requests pack afresh."""
+        self.out, self.rows, self.keep, self.table, self.blocks, self.frozen = {}, [], [], None, 0, []
+        self.src_of, self.wino, self.wino_rows, self.wino_table, self.wino_blocks = {}, {}, [], None, 0
 
     def refresh(self):
         """Re-pack every registered panel of a weight that trains (requires_grad when the cache was built) from the current weights: one launch
-        on the current stream, one more for the Winograd panels derived from them.  Panels of frozen weights are built once."""
+        on the current stream, one more for the Winograd panels derived from them.  Panels of frozen weights are built once and re-packed only
+        when the weight's tensor version moved since (an in-place load_state_dict)."""
+        self._repack_stale_frozen()
         if not self.rows:
             return
         if self.table is None:

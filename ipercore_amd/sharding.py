@@ -58,6 +58,7 @@ class OverlappedGather(object):
         self.pending = []
         self.bytes_received = 0           # per rank, all chunks (incl. its own block and the padding)
         self.exposed_s = None             # finish(sync=...): wall time between "compute done" and "video assembled"
+        self.compute_done_t = None        # finish(sync=...): perf_counter() when the compute stream had drained
 
     def submit(self, frames, offset, length=None):
         """frames: this rank's frames [offset, offset + k) of its shard, 0 <= k <= length; ``length`` = the chunk length every rank
@@ -78,7 +79,7 @@ class OverlappedGather(object):
         t0 = None
         if sync is not None:
             sync()
-            t0 = time.perf_counter()
+            t0 = self.compute_done_t = time.perf_counter()
         video = None
         for offset, m, out, work, _ in self.pending:
             work.wait()
@@ -121,6 +122,31 @@ def chunk_plan(n_frames, world_size, frame_batch, round_frames=1):
     return plan
 
 
+def choose_chunk_plan(n_frames, world_size, frame_batch, round_frames, bytes_per_frame, t_frame_s, link_bytes_per_s=150e9, split_penalty=0.022):
+    """Pick between the overlapped plan (``chunk_plan`` at ``frame_batch``: every chunk but the last is exchanged behind the next chunk's
+    synthesis) and ONE chunk per shard (no launch set is cut: ``split_penalty`` = the measured cost of cutting a 38-frame shard into 24 + 14,
+    46.3 vs 45.3 ms in bench.py's shard_of_8 - but the whole exchange is exposed) with a per-link-bound ring model of the all-gather: a rank
+    receives (world - 1) blocks of a chunk over its slowest link, ~150 GB/s on xGMI (7 links x ~153 GB/s per GPU, point to point: the guide).
+    Returns (plan, model) - model holds both estimates, for the bench line.  An ESTIMATE until an 8-GPU run replaces it."""
+    cap = max(shard_counts(n_frames, world_size))
+    split = chunk_plan(n_frames, world_size, frame_batch, round_frames)
+    one = [(0, cap)]
+
+    def exposed(m):
+        return (world_size - 1) * m * bytes_per_frame / link_bytes_per_s
+    t_one = cap * t_frame_s + exposed(cap)
+    # two in-order queues: the compute stream renders chunk after chunk, RCCL's stream exchanges chunk i once it is rendered and chunk i - 1's
+    # exchange is done; the clip is assembled when the last exchange ends
+    t_c_end = t_x_end = 0.0
+    for _, m in split:
+        t_c_end += m * t_frame_s * (1.0 + (split_penalty if len(split) > 1 else 0.0))
+        t_x_end = max(t_x_end, t_c_end) + exposed(m)
+    t_split = t_x_end
+    model = {"one_chunk_s": t_one, "chunked_s": t_split, "chunked_plan": [m for _, m in split], "link_GBps_assumed": link_bytes_per_s / 1e9,
+             "bytes_per_frame": bytes_per_frame, "t_frame_s_assumed": t_frame_s}
+    return (one if (len(split) > 1 and t_one < t_split) else split), model
+
+
 def round_frames_of(imitator):
     """Frames per full tile round of the coarsest, (S/8)^2 x 256-channel layers: (S/8)^2 / 128 row tiles x 2 column tiles of 128 x 128
     per frame against 512 workgroup slots (256 CUs x 2) -> 8 at 512x512, 32 at 256x256, 2 at 1024x1024."""
@@ -129,14 +155,17 @@ def round_frames_of(imitator):
 
 
 def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, group=None, overlap=True, prepared=False, post=None,
-                       stats=None, force_collective=False):
+                       stats=None, force_collective=False, plan=None):
     """Every rank: prepare the whole sequence, synthesize its block, all-gather the video tensor
     (``overlap``: chunk by chunk behind the frame loop, see OverlappedGather; False: one collective at the end).
     prepared: ``tgt_smpls`` is already the output of ``imitator.prepare_sequence`` (the sequence-global pre-pass, identical on every
     rank).  post: a per-chunk transform applied before the exchange - ``ops.frames_to_u8`` turns the (n,3,S,S) fp32 video into the
     (n,S,S,3) uint8 one the PNG writer consumes: a quarter of the bytes on the xGMI ring.  stats: a dict that receives this rank's
     shard, the bytes it received and (when ``stats["sync"]`` is a callable) the exposed gather time.  force_collective: issue the
-    collectives even in a one-rank group (the RCCL check on a single GPU)."""
+    collectives even in a one-rank group (the RCCL check on a single GPU).  plan: [(offset, length)] chunk schedule, the same on every
+    rank (``choose_chunk_plan``); default ``chunk_plan`` at the imitator's frame batch."""
+    import time
+    t_entry = time.perf_counter()
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     tgt = tgt_smpls if prepared else imitator.prepare_sequence(tgt_smpls, cam_strategy)
@@ -150,7 +179,8 @@ def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, 
         local = fin(imitator.synthesize(tgt[lo:hi], cam_strategy, t0=lo))
         return all_gather_frames(local, n, group, force=force_collective) if gather else local
     og = OverlappedGather(n, group)
-    plan = chunk_plan(n, world, getattr(imitator, "frame_batch", 8), round_frames_of(imitator))
+    if plan is None:
+        plan = chunk_plan(n, world, getattr(imitator, "frame_batch", 8), round_frames_of(imitator))
     for off, m in plan:
         a = min(lo + off, hi)
         b = min(lo + off + m, hi)
@@ -159,6 +189,7 @@ def sharded_synthesize(imitator, tgt_smpls, cam_strategy="smooth", gather=True, 
         og.submit(fin(imitator.synthesize(tgt[a:b], cam_strategy, t0=a)), off, length=m)
     video = og.finish(sync=None if stats is None else stats.get("sync"))
     if stats is not None:
-        stats.update(bytes_received=og.bytes_received, exposed_gather_s=og.exposed_s, chunks=len(plan), chunk_lengths=[m for _, m in plan])
+        stats.update(bytes_received=og.bytes_received, exposed_gather_s=og.exposed_s, chunks=len(plan), chunk_lengths=[m for _, m in plan],
+                     compute_s=None if og.compute_done_t is None else og.compute_done_t - t_entry)
         stats.pop("sync", None)
     return video

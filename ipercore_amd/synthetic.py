@@ -142,6 +142,30 @@ def fill_state_dict(shapes, seed=0):
     return {k: param_array(k, shapes[k], seed) for k in sorted(shapes)}
 
 
+def adversarial_param_array(name, shape, seed=0):
+    """A seeded tensor with the statistics a TRAINED checkpoint shows and N(0, 1/fan_in) does not (the published generator weights are
+    not distributable): heavy-tailed kernels (Student-t, 3 degrees of freedom), input-channel scales spread over two decades, one dominant
+    input channel per layer, a same-sign (DC) component in every filter, and positive biases - so post-ReLU activations carry DC offsets and
+    a few large-norm channels.  Same overall gain per layer as ``param_array`` (the network neither dies nor saturates).  Used by the
+    Winograd engine's adversarial parity checks (the transforms' cancellation scales with |d| |g| of a patch, not of the result)."""
+    r = _rs(seed, "adv:" + name)
+    shape = tuple(int(s) for s in shape)
+    if len(shape) < 2:
+        return (0.25 + 0.25 * r.standard_normal(shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    w = r.standard_t(3.0, size=shape) / np.sqrt(3.0)
+    if len(shape) == 4 and shape[1] >= 32:
+        sc = 10.0 ** r.uniform(-1.0, 1.0, size=shape[1])
+        sc[r.randint(shape[1])] *= 8.0
+        w = w * (sc / np.sqrt(np.mean(sc ** 2))).reshape(1, -1, 1, 1)
+    w = w / np.sqrt(max(fan_in, 1)) + 1.0 / max(fan_in, 1)
+    return w.astype(np.float32)
+
+
+def adversarial_state_dict(shapes, seed=0):
+    return {k: adversarial_param_array(k, shapes[k], seed) for k in sorted(shapes)}
+
+
 def uniform_image(shape, seed, name):
     return _rs(seed, name).uniform(-1.0, 1.0, size=shape).astype(np.float32)
 

@@ -148,6 +148,35 @@ def test_shard_range_partitions():
     assert sharding.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
 
 
+def test_choose_chunk_plan_ring_model():
+    """sharding.choose_chunk_plan (bench.py --chunk-plan auto): the N = 8 clip with the round-5 shard_of_8 time per frame (45.3 ms / 38):
+    the fp32 exchange (0.83 GB received per rank) keeps the overlapped 24 + 14 schedule, the uint8 exchange (a quarter of it) takes the shard as
+    one chunk; a shard that fits one frame batch has nothing to choose; the plan given to sharded_synthesize is what runs."""
+    t_f = 45.3e-3 / 38
+    plan, model = sharding.choose_chunk_plan(300, 8, 32, 8, 3 * 512 * 512 * 4, t_f)
+    assert plan == [(0, 24), (24, 14)] and model["chunked_plan"] == [24, 14] and model["chunked_s"] < model["one_chunk_s"]
+    # the model's arithmetic: one chunk = compute + the whole exchange exposed at (world - 1) blocks over one ~150 GB/s link
+    assert abs(model["one_chunk_s"] - (38 * t_f + 7 * 38 * 3 * 512 * 512 * 4 / 150e9)) < 1e-9
+    plan8, model8 = sharding.choose_chunk_plan(300, 8, 32, 8, 3 * 512 * 512, t_f)
+    assert plan8 == [(0, 38)] and model8["one_chunk_s"] < model8["chunked_s"]
+    plan1, _ = sharding.choose_chunk_plan(64, 8, 32, 8, 3 * 512 * 512 * 4, t_f)
+    assert plan1 == [(0, 8)]
+
+    class Fake:
+        frame_batch = 2
+
+        def prepare_sequence(self, s, cam):
+            return torch.as_tensor(s)
+
+        def synthesize(self, chunk, cam, t0=0):
+            self.calls.append(int(chunk.shape[0]))
+            return chunk[:, None].expand(-1, 3) * 1.0
+    f = Fake()
+    f.calls = []
+    out = sharding.sharded_synthesize(f, torch.arange(5, dtype=torch.float32), plan=[(0, 5)])     # one rank, no group: the plan is moot, one call
+    assert out.shape == (5, 3) and f.calls == [5]
+
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -172,6 +201,12 @@ class Fake3(Fake):
     frame_batch = 3
 vid = sharding.sharded_synthesize(Fake3(), seq, overlap=True)
 assert torch.equal(vid[:, 0, 0, 0], seq * 2 + 1)
+# an explicit chunk schedule (bench.py --chunk-plan): the shard as ONE chunk, and an uneven two-chunk plan - same video, the plan's chunk count
+cap = max(sharding.shard_counts(n, world))
+for plan in ([(0, cap)], [(0, 1), (1, cap - 1)]):
+    st = {"sync": lambda: None}
+    vid = sharding.sharded_synthesize(Fake3(), seq, overlap=True, plan=plan, stats=st)
+    assert torch.equal(vid[:, 0, 0, 0], seq * 2 + 1) and st["chunks"] == len(plan) and st["compute_s"] >= 0.0, (plan, st)
 og = sharding.OverlappedGather(n)
 lo, hi = sharding.shard_range(n, rank, world)
 for off in range(0, og.cap, 2):

@@ -54,9 +54,18 @@ def test_bench_self_launches_two_ranks_gloo(tmp_path):
     per_rank = line["config"]["per_rank"]
     assert [p["rank"] for p in per_rank] == [0, 1] and [p["frames"] for p in per_rank] == [4, 3]
     assert per_rank[0]["shard"] == [0, 4] and per_rank[1]["shard"] == [4, 7]
-    assert per_rank[0]["chunk_lengths"] == [2, 2]                     # frame batch 2 over the longest shard (4)
-    # (3,S,S) fp32 blocks of 2 frames from 2 ranks, two chunks
+    # --chunk-plan auto (the default): frame batch 2 over the longest shard (4) as [2, 2], or the shard as one chunk - whichever the ring model
+    # predicts faster from this run's own per-frame time (on CPU tensors a frame takes ~1 s: the cut's 2.2 % outweighs any exchange -> one chunk)
+    assert per_rank[0]["chunk_lengths"] in ([2, 2], [4]) and line["chunk_plan"] == per_rank[0]["chunk_lengths"]
+    # (3,S,S) fp32 blocks of 4 frames from 2 ranks, in one or two chunks
     assert per_rank[0]["bytes_received_per_step"] == 2 * 2 * 2 * 3 * 64 * 64 * 4
+    # the self-diagnosing top level of an N > 1 line
+    assert line["rccl_world_size"] == 2 and line["backend"] == "gloo" and line["frames_per_rank"] == [4, 3]
+    assert line["t_compute_ms"] > 0 and line["t_exposed_gather_ms"] >= 0 and line["bytes_received_per_rank_per_step"] == per_rank[0]["bytes_received_per_step"]
+    model = line["chunk_plan_model"]
+    assert model["chunked_plan"] == [2, 2] and model["one_chunk_s"] > 0 and model["chunked_s"] > 0
+    assert (model["one_chunk_s"] < model["chunked_s"]) == (line["chunk_plan"] == [4])
+    assert all(p["compute_ms_per_step"] > 0 for p in per_rank)
     assert "(f32)" in line["config"]["parallelism"] and "f32 video, all-gathered as f32" in line["result_tensor"]
     assert line["self_check"] is not None and "NOT a measurement" in line["data"]
     u8 = line["exchange_u8"]
@@ -69,8 +78,9 @@ def test_bench_under_torchrun_and_u8_gather(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
-    line = _run(tmp_path, ["--gpus", "2", "--gather-dtype", "u8"], launcher=launcher)
+    line = _run(tmp_path, ["--gpus", "2", "--gather-dtype", "u8", "--chunk-plan", "batches"], launcher=launcher)
     assert line["n_gpus"] == 2 and "(u8)" in line["config"]["parallelism"] and "exchange_u8" not in line
+    assert line["chunk_plan"] == [2, 2] and line["chunk_plan_model"] is None
     assert "uint8 video, all-gathered as u8" in line["result_tensor"]
     assert line["config"]["per_rank"][1]["bytes_received_per_step"] == 2 * 2 * 2 * 64 * 64 * 3
 

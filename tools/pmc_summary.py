@@ -52,8 +52,23 @@ def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_k
                     vals.append(float(r["Counter_Value"]))
         return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
+    def mean_kb_of(d, counter, sub):
+        vals = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if sub in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
     fk, nf = mean_kb(fetch_dir, "FETCH_SIZE")
     wk, nw = mean_kb(write_dir, "WRITE_SIZE")
+    by_kernel = {}
+    for sub in ("lwg_conv_winograd_kernel", "lwg_convt_winograd_kernel", "lwg_conv_igemm_kernel", "lwg_conv_bf16_hr2_kernel", "lwg_lwb_attn_x"):
+        f1, n1 = mean_kb_of(fetch_dir, "FETCH_SIZE", sub)
+        w1, n2 = mean_kb_of(write_dir, "WRITE_SIZE", sub)
+        if n1 and n2:
+            by_kernel[sub] = {"launches_fetch_pass": n1, "launches_write_pass": n2, "fetch_size_kib_per_launch_raw": f1, "write_size_kib_per_launch_raw": w1,
+                              "traffic_bytes_per_launch": (2.0 * f1 + w1) * 1024.0}
     cfg = None
     cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_last_config.json")
     if os.path.exists(cfg_path):          # written by the bench run the counters were collected on (the last one)
@@ -62,7 +77,8 @@ def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_k
     out = {"kernel": kernel_substr, "command": os.environ.get("LWG_PMC_CMD", ""), "bench_config": cfg, "launches_fetch_pass": nf, "launches_write_pass": nw,
            "fetch_size_kib_per_launch_raw": fk, "write_size_kib_per_launch_raw": wk,
            "fetch_correction": 2.0,
-           "traffic_bytes_per_launch": None if fk is None or wk is None else (2.0 * fk + wk) * 1024.0}
+           "traffic_bytes_per_launch": None if fk is None or wk is None else (2.0 * fk + wk) * 1024.0,
+           "by_kernel": by_kernel}
     with open(out_path, "w") as fp:
         json.dump(out, fp, indent=1)
     print(json.dumps(out))
