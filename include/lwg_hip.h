@@ -26,9 +26,9 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 8: lwg_conv2d_winograd_plan; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 7
+#define LWG_ABI_VERSION 8
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -116,6 +116,12 @@ int lwg_conv2d_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
  * The synthesis path never passes one: a frame must not depend on its batch. */
 size_t lwg_conv2d_winograd_ws_floats(const LwgConvArgs* args);
 int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* args, float* ws, lwg_stream_t stream);
+/* How the library runs such a launch (so that callers that route launches by their size - ops._wino_plan: a one-sample training launch whose grid would leave
+ * the chip idle stays on the direct split-K kernel - ask the kernel's own tile geometry instead of mirroring it): *blocks = 64-patch blocks of the launch
+ * (times the K slices when with_ws != 0 and the split plan applies), *slices = K slices (0 = run whole), *nbv = output channels per block (64, or 32 for
+ * small launches and slices), *workgroups = workgroups launched (persistent: min(blocks, compute units) for whole launches).  Any pointer may be NULL.
+ * Returns 0, or 1 (hipErrorInvalidValue) when args does not meet lwg_conv2d_winograd_f32's contract. */
+int lwg_conv2d_winograd_plan(const LwgConvArgs* args, int with_ws, long long* blocks, int* slices, int* nbv, int* workgroups);
 /* The fragment panel Upk[16][Cin/8][2][N][4] of the call above from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w, nine taps,
  * Cin % 32 == 0): U = G w G^T per (input channel, output column) in fp64, rounded once.  tap9[3 r + s] = index of the tap (dy, dx) = (r - 1, s - 1)
  * in the GEMM panel's tap order.  With LWG_EPI_RESIDUAL the Winograd call also takes LWG_ACTIVATION_RELU_MASK (the data gradient behind a ReLU). */

@@ -61,6 +61,8 @@ _SIGS = {
     "lwg_conv2d_winograd_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_winograd_ws_floats": (ctypes.c_size_t, [ctypes.POINTER(LwgConvArgs)]),
     "lwg_conv2d_winograd_f32_ws": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f]),
+    "lwg_conv2d_winograd_plan": (c_i, [ctypes.POINTER(LwgConvArgs), c_i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(c_i), ctypes.POINTER(c_i),
+                                       ctypes.POINTER(c_i)]),
     "lwg_winograd_panel_f32": (c_i, [c_f, c_f, c_i, c_i, ctypes.POINTER(c_i), c_f]),
     "lwg_winograd_panels_f32": (c_i, [c_f, c_i, c_i, c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
@@ -158,7 +160,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 7:
+        if handle.lwg_abi_version() != 8:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

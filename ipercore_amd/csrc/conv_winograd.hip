@@ -89,36 +89,58 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     float* Ms = smem;                                        // the epilogue's exchange buffer (after the K loop)
     const int tid = threadIdx.x, lane = tid & 63;
     const int bx = (W + 2 * TPB - 1) / (2 * TPB), by = (H + 2 * TPB - 1) / (2 * TPB);
+    // PERSISTENT WORKGROUPS (round 6): the grid is min(blocks, CUs) workgroups (the chip holds one per CU: LDS) and a workgroup walks the block ids
+    // blockIdx.x, blockIdx.x + gridDim.x, ... (id = column block * tiles + tile: the order the 2-D grid of round 5 was dispatched in).  What that
+    // buys: the first halo stages and weight fragments of block k + 1 are REQUESTED before block k's epilogue exchange and land under it (the
+    // prologue's exposed global round trip, ~1/2 of its 6.3 k cycles, is gone), and the per-workgroup dispatch / descriptor set-up is paid once.
+    // A block's arithmetic does not depend on which workgroup runs it: results are bitwise those of the one-block-per-workgroup form.
+    const int tiles = bx * by * a.B;
+    const int total = tiles * (N / NBV);
     int blk = blockIdx.x;
-    const int b = blk / (bx * by);
-    blk -= b * bx * by;
-    const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
-    const int n0 = blockIdx.y * NBV;
     const int nst_all = Cin / KS;                            // even (host: Cin % 16 == 0)
     const int sbeg = SPLIT ? (int)blockIdx.z * a.cshift : 0; // this workgroup's first stage and its number of stages (even as well)
     const int nst = SPLIT ? (a.cshift < nst_all - sbeg ? a.cshift : nst_all - sbeg) : nst_all;
     WTS(0);
-    // buffer resources: this image of each input, the weight panel
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : a.x0), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(64u * (unsigned)Cin * (unsigned)N), 0x00020000);
+    // ---- per-block state (workgroup-uniform): image b, tile corner (x0, y0), first output column n0; this image of each input as a buffer
+    int b, x0, y0, n0;
+    __amdgpu_buffer_rsrc_t rx0, rx1;
+    unsigned voff0[2], voff1[2];                             // this thread's two halo elements (pixel, channel quad): byte offsets inside either input
+    unsigned uvoff;                                          // this lane's column of the fragment panel
+    const int nbw_ = (NBV / 32) == 2 ? wid >> 2 : 0;
+    auto setup = [&](int id) {
+        const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
+        int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        b = __builtin_amdgcn_readfirstlane(t / (bx * by));
+        t -= b * bx * by;
+        x0 = (t % bx) * 2 * TPB;
+        y0 = (t / bx) * 2 * TPB;
+        n0 = cb * NBV;
+        rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
+        rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : a.x0), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                        // padding pixels / threads without a halo element: an out-of-range offset (zeros)
+            const int i = tid + WG_THREADS * q;
+            const int pix = i >> 1, half = i & 1, py = pix / HALO, px = pix - py * HALO;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool in = i < PLANE * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            voff0[q] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * half) * 4u : WINO_OOB;
+            voff1[q] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * half) * 4u : WINO_OOB;
+        }
+        uvoff = (unsigned)(((lane >> 5) * N + n0 + nbw_ * 32 + (lane & 31)) * 16);
+    };
+    setup(blk);
     const int xi = wid & 3;                                   // this wave's row of the transformed patch
     const int nbw = NT == 2 ? wid >> 2 : 0;                   // ... its 32-channel tile (NBV = 64)
     const int ptw = NT == 2 ? 0 : wid >> 2;                   // ... or its 32-patch tile (NBV = 32)
     floatx16 acc[4][NT];                                     // [product nu][patch tile] (cleared in the prologue, behind the first loads)
 
-    // this thread's two halo elements (pixel, channel quad): byte offsets of the pixel inside either input (out of range: padding / none), LDS slot
-    unsigned voff0[2], voff1[2];
-    int wst[2];
+    int wst[2];                                              // ... and their LDS slot (threads without a halo element store their zeros into dead LDS)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + WG_THREADS * q;
-        const int pix = i >> 1, half = i & 1, py = pix / HALO, px = pix - py * HALO;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool have = i < PLANE * 2, in = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        voff0[q] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * half) * 4u : WINO_OOB;
-        voff1[q] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * half) * 4u : WINO_OOB;
-        wst[q] = have ? 4 * half * PLANE + pix : DUMP_OFF + tid;
+        const int pix = i >> 1, half = i & 1;
+        wst[q] = i < PLANE * 2 ? 4 * half * PLANE + pix : DUMP_OFF + tid;
     }
     floatx4 rreg[2];
     auto rld1 = [&](int st, int q) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
@@ -131,7 +153,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int k = 0; k < 4; ++k) dst[k * PLANE] = v[k];
     };
     floatx4 ufr[2][4];                                       // [register set][product nu]: the four k-pairs of this lane's row (channel)
-    const unsigned uvoff = (unsigned)(((lane >> 5) * N + n0 + nbw * 32 + (lane & 31)) * 16);
     const unsigned ustage = (unsigned)N * 32u;               // bytes between two stages of a product: [2][N][4] floats
     unsigned usoff[4];
 #pragma unroll
@@ -296,9 +317,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         WTS2(7);
     };
 
-    // prologue: stages 0 and 1 loaded together -> raw[0], raw[1]; stage 0 transformed; stage 2's halo in registers; U(0) in set 0; fragments 0..2 read
-    {
-        floatx4 r0[2], r1[2];
+    // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), U(0) in set 0 - requested here for the
+    // workgroup's first block, and for every later one from inside the previous block's epilogue
+    floatx4 r0[2], r1[2];
+    auto issue_loads = [&]() {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             r0[q] = rld1(0, q);
@@ -308,17 +330,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int nu = 0; nu < 4; ++nu) ufr[0][nu] = uld1(0, nu);
 #pragma unroll
         for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
+    };
+    issue_loads();
+    for (;;) {
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu)                       // (the accumulators are cleared while the first loads are in flight)
-#pragma unroll
-            for (int tb = 0; tb < NT; ++tb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nu][tb][r] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            rst1(0, q, r0[q]);
-            rst1(1, q, r1[q]);
-        }
+    for (int q = 0; q < 2; ++q) {
+        rst1(0, q, r0[q]);
+        rst1(1, q, r1[q]);
     }
     __syncthreads();
     transform(0);
@@ -326,6 +344,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     fragread(0, 0);
     fragread(0, 1);
     fragread(0, 2);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)                           // (cleared here, not at the top: the first stages' halo registers are free by now)
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][tb][r] = 0.f;
     WTS(1);
     {
         int s = 0;
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int i = 0; i < 16; ++i)
             reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 16 + i] = ts2[i];
 #endif
+    const int eb = b, ex0 = x0, ey0 = y0, en0 = n0;          // this block's coordinates (the state moves on to the next block below)
     // epilogue: M A in registers (two values per product row, patch, channel), ONE exchange through LDS [xi][column][patch][n], then a thread owns
     // one patch x the channel quads n4.. and 32 + n4..: 16 conflict-free 16-byte LDS reads, A^T (.) over xi, bias, (residual | SPADE modulation),
     // activation, 16-byte NHWC stores (the residual / xn values are fetched before the exchange).  LWG_EPI_SPADE: the block's 64 columns are
@@ -350,29 +375,34 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     // gamma, quad 32 + n4.. beta of channels (n0 / 2) + n4..: y = (xn - mean) rstd (1 + gamma) + beta.
     // reader threads: channel quad n4 = 4 (lane % 8), patch = (lane / 8) * 8 + wave: the sixteen lanes one ds_read_b128 serves together hold
     // quads and patches whose 16-byte rows fall into different banks (68 p + n4 over p, p + 8, p + 16, p + 24)
-    const int n4 = (tid & 7) * 4, ep = (lane & 56) + wid;
+    // (thread ids taken through an empty asm per block: the epilogue's address arithmetic must not be hoisted out of the block loop - it would sit in
+    // registers through the K loop, which has none to spare)
+    int tide = tid;
+    asm volatile("" : "+v"(tide));
+    const int lanee = tide & 63;
+    const int n4 = (tide & 7) * 4, ep = (lanee & 56) + wid;
     const int ety = ep >> 3, etx = ep & 7;
     constexpr int NH = NT;                                   // channel quads per reader thread: n4.. and (NBV = 64) 32 + n4..
     floatx4 ext[2][2][2];                                    // [channel group h][row][column]: residual (LWG_EPI_RESIDUAL) / xn (LWG_EPI_SPADE: h = 0 only)
     floatx4 bv[2], mu, rs;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + n0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < NH; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + en0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
     if (EPI == LWG_EPI_SPADE) {
-        mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)b * a.YC + (n0 >> 1) + n4);
-        rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)b * a.YC + (n0 >> 1) + n4);
+        mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + (en0 >> 1) + n4);
+        rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)eb * a.YC + (en0 >> 1) + n4);
     }
     if (EPI != LWG_EPI_NONE) {
 #pragma unroll
         for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : NH); ++h) {
-            const int ch = EPI == LWG_EPI_SPADE ? (n0 >> 1) + n4 : a.ycoff + n0 + h * 32 + n4;
+            const int ch = EPI == LWG_EPI_SPADE ? (en0 >> 1) + n4 : a.ycoff + en0 + h * 32 + n4;
             const float* src = EPI == LWG_EPI_SPADE ? a.xn : a.res;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int px = 0; px < 2; ++px) {
-                    const int oy = y0 + 2 * ety + i, ox = x0 + 2 * etx + px;
+                    const int oy = ey0 + 2 * ety + i, ox = ex0 + 2 * etx + px;
                     ext[h][i][px] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    if (oy < H && ox < W) ext[h][i][px] = *reinterpret_cast<const floatx4*>(src + (((size_t)b * H + oy) * W + ox) * a.YC + ch);
+                    if (oy < H && ox < W) ext[h][i][px] = *reinterpret_cast<const floatx4*>(src + (((size_t)eb * H + oy) * W + ox) * a.YC + ch);
                 }
         }
     }
@@ -387,10 +417,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                 c0[k] = acc[0][tb][r] + acc[1][tb][r] + acc[2][tb][r];
                 c1[k] = acc[1][tb][r] - acc[2][tb][r] - acc[3][tb][r];
             }
-            float* dst = Ms + ((xi * 2) * NPATCH + (NT == 2 ? tb : ptw) * 32 + (lane & 31)) * MSR + nbw * 32 + 8 * g + 4 * (lane >> 5);
+            float* dst = Ms + ((xi * 2) * NPATCH + (NT == 2 ? tb : ptw) * 32 + (lanee & 31)) * MSR + nbw * 32 + 8 * g + 4 * (lanee >> 5);
             *reinterpret_cast<floatx4*>(dst) = c0;
             *reinterpret_cast<floatx4*>(dst + NPATCH * MSR) = c1;
         }
+    // the next block of this workgroup: its first loads go out HERE - the accumulators are dead (folded into the exchange buffer), the residual / xn
+    // fetches are ahead of them in the queue - and land while the products cross LDS and the outputs are stored
+    // (UNCONDITIONAL for the last block too - it re-requests its own first stages, ten loads per thread nobody waits for: under `if (more)` the
+    // halo registers would be conditionally defined, i.e. merged with their previous values, i.e. live through the whole K loop - 24 registers the
+    // 64-channel form does not have)
+    const int nblk = blk + (int)gridDim.x;
+    const bool more = !SPLIT && nblk < total;
+    if constexpr (!SPLIT) {
+        setup(more ? nblk : blk);
+        issue_loads();
+    }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -408,7 +449,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                const int oy = y0 + 2 * ety + i, ox = x0 + 2 * etx + px;
+                const int oy = ey0 + 2 * ety + i, ox = ex0 + 2 * etx + px;
                 floatx4 v = o[i][px] + bv[h];
                 if (EPI == LWG_EPI_SPADE) {
                     if (h == 0) {
@@ -417,7 +458,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                         floatx4 r;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) r[c] = lwg_act((ext[0][i][px][c] - mu[c]) * rs[c] * (1.f + ext[1][i][px][c]) + v[c], a.act);
-                        *reinterpret_cast<floatx4*>(y + (((size_t)b * H + oy) * W + ox) * a.YC + (n0 >> 1) + n4) = r;
+                        *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4) = r;
                     }
                 } else if (oy < H && ox < W) {
                     floatx4 r;
@@ -429,11 +470,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
                         for (int c = 0; c < 4; ++c) r[c] = lwg_act(v[c], a.act);
                     }
-                    *reinterpret_cast<floatx4*>(y + (((size_t)b * H + oy) * W + ox) * a.YC + a.ycoff + n0 + h * 32 + n4) = r;
+                    *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + a.ycoff + en0 + h * 32 + n4) = r;
                 }
             }
     }
     WTS(41);
+    if (!more) break;
+    blk = nblk;
+    __syncthreads();                                         // every reader is done with the exchange buffer: raw[0] / raw[1] (the same LDS) may be written
+    }
     WTS(42);
 }
 
@@ -573,6 +618,35 @@ static bool lwg_wino_contract(const LwgConvArgs& a) {
     return true;
 }
 
+// small launches (a frame or two): blocks of 64 patches x 32 channels when that shortens the launch - the chip holds one workgroup per CU (LDS), a
+// launch is ceil(blocks / CUs) rounds, and a half-size block costs ~0.55 of a full one (same per-stage overheads on half the MFMAs).  Same bits.
+static bool lwg_wino_small(const LwgConvArgs& a, int cus) {
+    const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
+    const long blocks64 = (long)bx * by * a.B * (a.N / NB);
+    const long rounds64 = (blocks64 + cus - 1) / cus, rounds32 = (2 * blocks64 + cus - 1) / cus;
+    return a.epi != LWG_EPI_SPADE && (double)rounds32 * 0.55 < (double)rounds64;
+}
+
+// How the library runs a launch (the host-side mirror of nothing: ops._wino_plan asks instead of recomputing the tile geometry - ADVICE r05):
+// *blocks = 64-patch blocks of the launch (x K slices when with_ws and the split plan applies), *slices = K slices (0 = whole), *nbv = output
+// channels per block (64 | 32), *workgroups = persistent workgroups launched.  Returns 0, or 1 when the launch does not meet the contract.
+extern "C" int lwg_conv2d_winograd_plan(const LwgConvArgs* pa, int with_ws, long long* blocks, int* slices, int* nbv, int* workgroups) {
+    if (!pa || !lwg_wino_contract(*pa)) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
+    const long tiles = (long)bx * by * a.B;
+    int sps = 0;
+    const int sl = with_ws ? lwg_wino_split_plan(a, &sps) : 0;
+    const int cus = lwg_device_cus();
+    const int v = sl > 1 ? 32 : (lwg_wino_small(a, cus) ? 32 : NB);
+    const long long nb = (long long)tiles * (a.N / v) * (sl > 1 ? sl : 1);
+    if (blocks) *blocks = nb;
+    if (slices) *slices = sl > 1 ? sl : 0;
+    if (nbv) *nbv = v;
+    if (workgroups) *workgroups = (int)(sl > 1 ? nb : (nb < cus ? nb : cus));
+    return 0;
+}
+
 // ws: NULL, or lwg_conv2d_winograd_ws_floats(args) floats - a launch that would leave half the chip idle then runs split over K through it.
 extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -581,18 +655,8 @@ extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_
     const size_t loop = (size_t)LOOP_FLOATS * 4, epi = (size_t)MS_FLOATS * 4;
     const size_t lds = loop > epi ? loop : epi;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
-    // small launches (a frame or two): workgroups of 64 patches x 32 channels when that shortens the launch - the chip holds one workgroup per CU
-    // (LDS), a launch is ceil(workgroups / CUs) rounds, and a half-size workgroup costs ~0.55 of a full one (same per-stage overheads on half the
-    // MFMAs).  Same bits either way.
-    const long blocks64 = (long)bx * by * a.B * (a.N / NB);
-    static int cus = 0;                                      // compute units of the device (one node = one device type)
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    const long rounds64 = (blocks64 + cus - 1) / cus, rounds32 = (2 * blocks64 + cus - 1) / cus;
-    const bool small = a.epi != LWG_EPI_SPADE && (double)rounds32 * 0.55 < (double)rounds64;
+    const int cus = lwg_device_cus();
+    const bool small = lwg_wino_small(a, cus);
     static unsigned long long done[6] = {0, 0, 0, 0, 0, 0};
     int sps = 0;
     const int slices = ws ? lwg_wino_split_plan(a, &sps) : 0;
@@ -608,10 +672,12 @@ extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_
         part.act = LWG_ACT_NONE;
         part.res = nullptr;
         part.cshift = sps;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(bx * by * a.B), (unsigned)(a.N / 32), (unsigned)slices), dim3(WG_THREADS), lds, stream, part);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(bx * by * a.B * (a.N / 32)), 1u, (unsigned)slices), dim3(WG_THREADS), lds, stream, part);
         return (int)lwg_splitk_finish_launch(a, ws, slices, stream);
     }
-    const dim3 grid((unsigned)(bx * by * a.B), (unsigned)(a.N / (small ? 32 : NB)));
+    // persistent workgroups: one per CU (LDS) at most, each walking block ids blockIdx.x + k gridDim.x (LWG_WINO_PERSIST = 0: one block per workgroup)
+    const long total = (long)bx * by * a.B * (a.N / (small ? 32 : NB));
+    const dim3 grid((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total));
 #define LWG_WINO_GO(E, V, SLOT)                                                                                                       \
     {                                                                                                                                 \
         if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E, V>), lds, done[SLOT]); e != hipSuccess) \

@@ -73,30 +73,48 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     float* const raw0 = smem;                                // [2][RAW], then [2][VS] (25 planes of [k][patch])
     const int tid = threadIdx.x, lane = tid & 63;
     const int bx = (W + 2 * TPB - 1) / (2 * TPB), by = (H + 2 * TPB - 1) / (2 * TPB);
+    // persistent workgroups (round 6, as conv_winograd.hip): min(blocks, CUs) workgroups walk the block ids blockIdx.x + k gridDim.x (id = column block *
+    // tiles + tile); the next block's first halo stages and weights are requested inside this block's epilogue.  Bitwise the one-block-per-workgroup results.
+    const int tiles = bx * by * a.B;
+    const int total = tiles * (N / NBT);
     int blk = blockIdx.x;
-    const int b = blk / (bx * by);
-    blk -= b * bx * by;
-    const int x0 = (blk % bx) * 2 * TPB, y0 = (blk / bx) * 2 * TPB;
-    const int n0 = blockIdx.y * NBT;
     const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
     CTS(0);
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * Cin), 0, (int)((unsigned)(H * W) * (unsigned)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
     const int par = wid & 3, py = par >> 1, px = par & 1;    // this wave's output parity
     const int pt = wid >> 2;                                  // ... and its 32-patch tile
     floatx16 acc[9];                                         // [product 3 xi + nu]
-
-    // this thread's two halo elements (pixel, channel quad): byte offset of the pixel inside the image (out of range: padding / none), LDS slot
+    // ---- per-block state (workgroup-uniform): image b, tile corner (x0, y0), first output column n0, this image as a buffer; this thread's two halo
+    // elements (pixel, channel quad): byte offset of the pixel inside the image (out of range: padding / none); this lane's column of the panel
+    int b, x0, y0, n0;
+    __amdgpu_buffer_rsrc_t rx0;
     unsigned voff0[2];
-    int wst[2];
+    unsigned uvoff;
+    auto setup = [&](int id) {
+        const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
+        int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        b = __builtin_amdgcn_readfirstlane(t / (bx * by));
+        t -= b * bx * by;
+        x0 = (t % bx) * 2 * TPB;
+        y0 = (t / bx) * 2 * TPB;
+        n0 = cb * NBT;
+        rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * Cin), 0, (int)((unsigned)(H * W) * (unsigned)Cin * 4u), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + WG_THREADS * q;
+            const int pix = i >> 1, half = i & 1, hy = pix / HALO, hx = pix - hy * HALO;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool in = i < PLANE * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            voff0[q] = in ? (unsigned)((gy * W + gx) * Cin + 4 * half) * 4u : WINO_OOB;
+        }
+        uvoff = (unsigned)((((lane >> 5) * N + n0 + (lane & 31)) * 12) * 4);
+    };
+    setup(blk);
+    int wst[2];                                              // the halo elements' LDS slot (threads without one store their zeros into dead LDS)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + WG_THREADS * q;
-        const int pix = i >> 1, half = i & 1, hy = pix / HALO, hx = pix - hy * HALO;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool have = i < PLANE * 2, in = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        voff0[q] = in ? (unsigned)((gy * W + gx) * Cin + 4 * half) * 4u : WINO_OOB;
-        wst[q] = have ? 4 * half * PLANE + pix : DUMP_OFF + tid;
+        wst[q] = i < PLANE * 2 ? 4 * (i & 1) * PLANE + (i >> 1) : DUMP_OFF + tid;
     }
     floatx4 rreg[2];
     auto rld1 = [&](int st, int q) -> floatx4 { return ctw_buf_load(rx0, voff0[q], (unsigned)(st * KS) * 4u); };
@@ -107,7 +125,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     };
     // weights: lane = (k-half lane / 32, channel lane % 32); element (parity, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
     floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 + padding]: loaded TWO k-pairs ahead
-    const unsigned uvoff = (unsigned)((((lane >> 5) * N + n0 + (lane & 31)) * 12) * 4);
     const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
     const unsigned upar = (unsigned)par * (unsigned)nst * 4u * ukk;
     auto uld1 = [&](int st, int kk, int j) -> floatx4 { return ctw_buf_load(ru, uvoff + 16u * j, upar + (unsigned)(st * 4 + kk) * ukk); };
@@ -275,9 +292,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
 #endif
     };
 
-    // prologue: stages 0 and 1 -> raw[0], raw[1]; stage 0 transformed; stage 2's halo in registers; the first weights and fragments
-    {
-        floatx4 r0[2], r1[2];
+    // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested
+    // here for the workgroup's first block, for every later one from inside the previous block's epilogue
+    floatx4 r0[2], r1[2];
+    auto issue_loads = [&]() {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             r0[q] = rld1(0, q);
@@ -290,15 +308,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
+    };
+    issue_loads();
+    for (;;) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            rst1(0, q, r0[q]);
-            rst1(1, q, r1[q]);
-        }
+    for (int q = 0; q < 2; ++q) {
+        rst1(0, q, r0[q]);
+        rst1(1, q, r1[q]);
     }
     __syncthreads();
     {
@@ -311,6 +327,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     }
     __syncthreads();
     fragread(0, 0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     CTS(1);
     {
         int s = 0;
@@ -322,17 +342,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         iteration(s + 1, IntT<1>(), IntT<0>());
     }
     CTS(2);
+    const int eb = b, ex0 = x0, ey0 = y0, en0 = n0;          // this block's coordinates (the state moves on to the next block below)
     // epilogue: Y[a][b] = sum over xi in {a, a + 1}, nu in {b, b + 1} of M[xi][nu] is register-local (this lane holds patch pt * 32 + lane % 32 and,
     // per register group g, the four channels 8 g + 4 (lane / 32) ..); + bias, activation; then ONE exchange through LDS - the block's 32 x 32 output
     // pixels x 32 channels, rows of 36 floats - so that the global stores are whole lines: written straight from the accumulator layout a lane's
     // 16-byte pieces lie a pixel (YC floats) apart and the stores of a 256-channel layer took 55 k cycles per block (9 K stages' worth; r05_h)
-    const int p = pt * 32 + (lane & 31);
+    int tide = tid;                                          // (through an empty asm per block: the epilogue's address arithmetic must not be hoisted out
+    asm volatile("" : "+v"(tide));                           //  of the block loop - it would sit in registers through the K loop)
+    const int lanee = tide & 63;
+    const int p = pt * 32 + (lanee & 31);
     const int ety = p >> 3, etx = p & 7;
-    const int chl = 4 * (lane >> 5);
+    const int chl = 4 * (lanee >> 5);
     __syncthreads();                                         // every wave has read its last fragments: the loop's LDS is free
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + n0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
+        const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + en0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -348,31 +372,41 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
                 *reinterpret_cast<floatx4*>(smem + (ly * 32 + lx) * OROW + 8 * g + chl) = o;
             }
     }
+    // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the stores below (unconditional:
+    // the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
+    const int nblk = blk + (int)gridDim.x;
+    const bool more = nblk < total;
+    setup(more ? nblk : blk);
+    issue_loads();
     __syncthreads();
-    const int oy0 = 2 * y0, ox0 = 2 * x0;
+    const int oy0 = 2 * ey0, ox0 = 2 * ex0;
     const size_t plane = (size_t)a.YH * a.YW;
     if (a.ydt == LWG_DT_F32_Q4) {
         // channel-quad planes (B, YC/4, YH, YW, 4): 32 lanes = one output row of the block in one plane, 512 contiguous bytes
-        const int lx = tid & 31;
+        const int lx = tide & 31;
 #pragma unroll 4
         for (int pass = 0; pass < 16; ++pass) {
-            const int idx = pass * 16 + (tid >> 5), cq = idx & 7, ly = idx >> 3;
+            const int idx = pass * 16 + (tide >> 5), cq = idx & 7, ly = idx >> 3;
             if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
                 const floatx4 v = *reinterpret_cast<const floatx4*>(smem + (ly * 32 + lx) * OROW + 4 * cq);
-                *reinterpret_cast<floatx4*>(a.y + (((size_t)b * (a.YC >> 2) + ((a.ycoff + n0) >> 2) + cq) * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * 4) = v;
+                *reinterpret_cast<floatx4*>(a.y + (((size_t)eb * (a.YC >> 2) + ((a.ycoff + en0) >> 2) + cq) * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * 4) = v;
             }
         }
     } else {
         // NHWC: 8 lanes = the block's 32 channels of one pixel, 128 contiguous bytes
-        const int cq = tid & 7;
+        const int cq = tide & 7;
 #pragma unroll 4
         for (int pass = 0; pass < 16; ++pass) {
-            const int pi = pass * 64 + (tid >> 3), ly = pi >> 5, lx = pi & 31;
+            const int pi = pass * 64 + (tide >> 3), ly = pi >> 5, lx = pi & 31;
             if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
                 const floatx4 v = *reinterpret_cast<const floatx4*>(smem + pi * OROW + 4 * cq);
-                *reinterpret_cast<floatx4*>(a.y + ((size_t)b * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * a.YC + a.ycoff + n0 + 4 * cq) = v;
+                *reinterpret_cast<floatx4*>(a.y + ((size_t)eb * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * a.YC + a.ycoff + en0 + 4 * cq) = v;
             }
         }
+    }
+    if (!more) break;
+    blk = nblk;
+    __syncthreads();                                         // every thread has read its outputs from the exchange buffer: raw[0] / raw[1] may be written
     }
     CTS(3);
 }
@@ -396,6 +430,8 @@ extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_strea
     static unsigned long long done = 0;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_convt_winograd_kernel), lds, done); e != hipSuccess) return (int)e;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
-    hipLaunchKernelGGL(lwg_convt_winograd_kernel, dim3((unsigned)(bx * by * a.B), (unsigned)(a.N / NBT)), dim3(WG_THREADS), lds, stream, a);
+    const long total = (long)bx * by * a.B * (a.N / NBT);
+    const int cus = lwg_device_cus();                        // persistent workgroups: one per CU (LDS) at most
+    hipLaunchKernelGGL(lwg_convt_winograd_kernel, dim3((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total)), dim3(WG_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }

@@ -23,6 +23,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef LWG_CONV_SMALL_TILES
 #define LWG_CONV_SMALL_TILES 300   // conv_igemm.hip: launches with fewer 128 x 128 tiles than this use 64 x 64 tiles
 #endif
+#ifndef LWG_WINO_PERSIST
+#define LWG_WINO_PERSIST 1         // conv_winograd.hip / convt_winograd.hip: persistent workgroups (one per CU walks the blocks, the next block's first loads under the epilogue); 0 = one block per workgroup
+#endif
 #ifndef LWG_CONV_DEEP
 #define LWG_CONV_DEEP 1            // conv_igemm.hip: the small-tile launches load two K-steps ahead (0 = one, as the large tiles)
 #endif
@@ -126,6 +129,18 @@ static inline long lwg_tile_frame_positions(int B, int h, int w) { return (long)
 // conv_igemm.hip: y = act(sum of the (M, N) slabs in slice order + bias) (| ReLU mask) - the finish of a split-K launch of either conv engine
 struct LwgConvArgs;
 hipError_t lwg_splitk_finish_launch(const LwgConvArgs& a, const float* ws, int slices, hipStream_t stream);
+
+// compute units of the current device, cached per device id (a benign race: every thread stores the same value)
+static inline int lwg_device_cus() {
+    static int cus[64];
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
 
 static inline hipError_t lwg_allow_dynamic_lds(const void* kern, size_t bytes, unsigned long long& done) {
     int dev = 0;

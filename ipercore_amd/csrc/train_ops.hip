@@ -570,8 +570,14 @@ extern "C" int lwg_maxpool2_bwd_nhwc_f32(const float* x, const float* dy, float*
 struct LwgCropGeom { int x0, y0, cw, ch; float sx, sy; };
 
 __device__ __forceinline__ bool lwg_crop_geom(const long long* __restrict__ box, int i, int H, int W, int OH, int OW, LwgCropGeom& g) {
-    const long long bx0 = box[4 * i], bx1 = box[4 * i + 1], by0 = box[4 * i + 2], by1 = box[4 * i + 3];
-    if (bx0 == bx1 || by0 == by1 || bx0 < 0 || by0 < 0 || bx1 > W || by1 > H || bx1 < bx0 || by1 < by0) return false;
+    const long long bx0 = box[4 * i], by0 = box[4 * i + 2];
+    long long bx1 = box[4 * i + 1], by1 = box[4 * i + 3];
+    if (bx0 == bx1 || by0 == by1 || bx0 < 0 || by0 < 0) return false;       // the reference's own test (faceloss.py:398); negative (wrapping) starts: refused
+    // Python slice semantics of imgs[i, :, y0:y1, x0:x1]: a stop beyond the image is clamped to it (the sample is KEPT); a slice that is then
+    // empty would make the reference's F.interpolate raise - here the sample is dropped (valid = 0)
+    bx1 = bx1 > W ? W : bx1;
+    by1 = by1 > H ? H : by1;
+    if (bx1 <= bx0 || by1 <= by0) return false;
     g.x0 = (int)bx0; g.y0 = (int)by0; g.cw = (int)(bx1 - bx0); g.ch = (int)(by1 - by0);
     g.sx = OW > 1 ? (float)(g.cw - 1) / (float)(OW - 1) : 0.f;
     g.sy = OH > 1 ? (float)(g.ch - 1) / (float)(OH - 1) : 0.f;

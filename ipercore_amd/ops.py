@@ -219,11 +219,12 @@ def _wino_plan(a, spec, y, splitk):
     (profiles/r05_g_winograd_small_launches.txt).  The synthesis path never asks (splitk=False: batch invariance)."""
     if not splitk:
         return 0
-    blocks = y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 15) // 16) * (spec.N // 32)
-    nws = int(_lib.lib().lwg_conv2d_winograd_ws_floats(a)) if WINO_SPLITK else 0
-    if nws:
-        blocks *= nws // (a.M * spec.N)
-    return nws if blocks >= WINO_MIN_GRID else None
+    # the kernel's own plan (lwg_conv2d_winograd_plan) - not a host copy of its tile geometry (ADVICE r05)
+    blocks, slices, nbv = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.lib().lwg_conv2d_winograd_plan(a, 1 if WINO_SPLITK else 0, ctypes.byref(blocks), ctypes.byref(slices), ctypes.byref(nbv), None) != 0:
+        return None
+    units32 = blocks.value * (nbv.value // 32)              # 64-patch x 32-channel units of work, times the K slices
+    return slices.value * a.M * spec.N if units32 >= WINO_MIN_GRID else None
 
 
 def _wwino(spec):

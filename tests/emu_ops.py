@@ -495,7 +495,9 @@ def _crop_ref(x, box, out_hw):
     N = x.shape[0]
     ys, valid = [], []
     for i, (x0, x1, y0, y1) in enumerate(box.tolist()):
-        ok = x0 != x1 and y0 != y1 and 0 <= x0 < x1 <= x.shape[3] and 0 <= y0 < y1 <= x.shape[2]
+        # Python slice semantics of the reference's imgs[i, :, y0:y1, x0:x1]: a stop beyond the image is clamped (sample kept); an empty slice
+        # (the reference's F.interpolate would raise) and negative, i.e. wrapping, starts are dropped
+        ok = x0 != x1 and y0 != y1 and 0 <= x0 < min(x1, x.shape[3]) and 0 <= y0 < min(y1, x.shape[2])
         valid.append(1.0 if ok else 0.0)
         ys.append(F.interpolate(x[i:i + 1, :, y0:y1, x0:x1], size=tuple(out_hw), mode="bilinear", align_corners=True) if ok
                   else x.new_zeros(1, x.shape[1], *out_hw))

@@ -1687,25 +1687,25 @@ def check_face_loss():
     # head crops with the boxes read on the device (lwg_crop_resize_bilinear_f32) against the reference's formulation (faceloss.py:384-406:
     # per-sample slice + F.interpolate(bilinear, align_corners = True)): values, validity of a degenerate box (the reference drops that
     # sample), the image gradient, and the loss of a batch with a dropped sample = the reference's loss over the kept ones
-    imgs = _rand((3, 3, 128, 128), 995, 0.5).to(DEV)
-    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10], [0, 128, 3, 128]], device=DEV)
+    imgs = _rand((4, 3, 128, 128), 995, 0.5).to(DEV)
+    box = torch.tensor([[20, 84, 10, 90], [5, 5, 0, 10], [0, 128, 3, 128], [100, 140, 90, 200]], device=DEV)   # the last one runs past the image: clamped, KEPT (a Python slice)
     xi = imgs.clone().requires_grad_(True)
     heads, valid = crt.crop_head_bbox(xi, box)
     want, wv = emu_ops._crop_ref(imgs, box.cpu(), (112, 96))
-    assert heads.shape == (3, 3, 112, 96) and valid.tolist() == [1.0, 0.0, 1.0] == wv.tolist()
+    assert heads.shape == (4, 3, 112, 96) and valid.tolist() == [1.0, 0.0, 1.0, 1.0] == wv.tolist()
     out["crop_max_abs"] = (heads.detach() - want).abs().max().item()
     assert out["crop_max_abs"] <= 2e-6 and float(heads[1].abs().max()) == 0.0, out
-    dyc = _rand((3, 3, 112, 96), 996).to(DEV)
+    dyc = _rand((4, 3, 112, 96), 996).to(DEV)
     (heads * dyc).sum().backward()
     xr2 = imgs.clone().requires_grad_(True)
     (emu_ops._crop_ref(xr2, box.cpu(), (112, 96))[0] * dyc).sum().backward()
     torch.cuda.synchronize()
     out["crop_grad_max_abs"] = (xi.grad - xr2.grad).abs().max().item()
     assert out["crop_grad_max_abs"] <= 2e-5 * max(1.0, xr2.grad.abs().max().item()), out
-    a3, b3 = _rand((3, 3, 128, 128), 997, 0.5).to(DEV), _rand((3, 3, 128, 128), 998, 0.5).to(DEV)
+    a3, b3 = _rand((4, 3, 128, 128), 997, 0.5).to(DEV), _rand((4, 3, 128, 128), 998, 0.5).to(DEV)
     with torch.no_grad():
         l_dev = crt(a3, b3, bbox1=box, bbox2=box)
-        keep = [0, 2]
+        keep = [0, 2, 3]                                     # (the reference's own slicing clamps box 3 to the image)
         ha = torch.cat([F.interpolate(a3[i:i + 1, :, box[i, 2]:box[i, 3], box[i, 0]:box[i, 1]], size=(112, 96), mode="bilinear", align_corners=True) for i in keep])
         hb = torch.cat([F.interpolate(b3[i:i + 1, :, box[i, 2]:box[i, 3], box[i, 0]:box[i, 1]], size=(112, 96), mode="bilinear", align_corners=True) for i in keep])
         l_ref = crt(ha, hb)

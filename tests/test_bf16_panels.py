@@ -162,7 +162,7 @@ def test_winograd_panel_cache_and_launch_plan(monkeypatch):
     calls = []
 
     class _Stub:
-        ws_floats = 0
+        plan, asked = (0, 0, 64), []
 
         def lwg_winograd_panel_f32(self, wp, up, cin, n, taps, stream):
             calls.append(("one", cin, n, list(taps)))
@@ -176,8 +176,12 @@ def test_winograd_panel_cache_and_launch_plan(monkeypatch):
             calls.append(("all", n, blocks))
             return 0
 
-        def lwg_conv2d_winograd_ws_floats(self, a):
-            return self.ws_floats
+        def lwg_conv2d_winograd_plan(self, a, with_ws, blocks, slices, nbv, workgroups):
+            # the library's answer, stubbed: (64-patch blocks x K slices, slices, channels per block); with_ws = 0: never sliced
+            self.asked.append(int(with_ws))
+            b, sl, v = self.plan if with_ws else (self.plan[0] // max(1, self.plan[1]), 0, self.plan[2])
+            blocks._obj.value, slices._obj.value, nbv._obj.value = b, sl, v
+            return 0
     stub = _Stub()
     monkeypatch.setattr(_lib, "lib", lambda: stub)
     monkeypatch.setattr(ops, "_stream", lambda: None)
@@ -212,19 +216,21 @@ def test_winograd_panel_cache_and_launch_plan(monkeypatch):
         N = 256
     y_small, y_mid, y_big = torch.zeros(1, 28, 28, 256), torch.zeros(1, 64, 64, 256), torch.zeros(2, 128, 128, 256)
     a.M = 28 * 28
-    assert ops._wino_plan(a, _S2, y_small, False) == 0 and ops._wino_plan(a, _S2, y_big, False) == 0     # synthesis path: whole, always
-    stub.ws_floats = 0
-    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 4 tiles x 8 = 32 workgroups, no plan: direct split-K
+    assert ops._wino_plan(a, _S2, y_small, False) == 0 and ops._wino_plan(a, _S2, y_big, False) == 0     # synthesis path: whole, always (the library is not asked)
+    assert stub.asked == []
+    stub.plan = (4 * 8, 0, 32)
+    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 4 tiles x 8 blocks of 32 channels = 32 units, no slices: direct split-K
     a.M = 64 * 64
-    assert ops._wino_plan(a, _S2, y_mid, True) == 0                                                        # 16 x 8 = 128: whole
+    stub.plan = (16 * 4, 0, 64)
+    assert ops._wino_plan(a, _S2, y_mid, True) == 0                                                        # 16 tiles x 4 blocks of 64 channels = 128 units: whole
     a.M = 28 * 28
-    stub.ws_floats = 4 * a.M * 256
-    assert ops._wino_plan(a, _S2, y_small, True) == stub.ws_floats                                         # 32 x 4 slices = 128: the split form
-    stub.ws_floats = 2 * a.M * 256
-    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 64 workgroups even when split
+    stub.plan = (4 * 8 * 4, 4, 32)
+    assert ops._wino_plan(a, _S2, y_small, True) == 4 * a.M * 256                                          # 32 x 4 slices = 128 units: the split form, its workspace
+    stub.plan = (4 * 8 * 2, 2, 32)
+    assert ops._wino_plan(a, _S2, y_small, True) is None                                                   # 64 units even when split
     monkeypatch.setattr(ops, "WINO_SPLITK", False)
-    stub.ws_floats = 4 * a.M * 256
-    assert ops._wino_plan(a, _S2, y_small, True) is None
+    stub.plan, stub.asked = (4 * 8 * 4, 4, 32), []
+    assert ops._wino_plan(a, _S2, y_small, True) is None and stub.asked == [0]                             # the lab switch: the library is asked for the whole-launch plan
 
 
 def test_winograd_transpose_panel_and_algorithm_cpu():

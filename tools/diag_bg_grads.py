@@ -92,10 +92,33 @@ def main():
             db.copy_(dy[..., :N].sum(dim=(0, 1, 2)))
         return dw
 
-    def hip_run(no_splitk=False, torch_norm=False, torch_wgrad=False):
+    def torch_wgrad_convT(x0, specs, dy, cin, n, adj_spec=None):
+        # d/dw of conv_transpose2d(x, w, stride 2, padding 1), w (Cin, N, 4, 4): torch autograd on the SAME x / dy, fp32, ROCm kernels
+        w = torch.zeros(cin, n, 4, 4, device=dy.device, requires_grad=True)
+        with torch.enable_grad():
+            y = F.conv_transpose2d(x0[..., :cin].permute(0, 3, 1, 2), w, stride=2, padding=1)
+        return torch.autograd.grad(y, w, dy[..., :n].permute(0, 3, 1, 2))[0]
+
+    CAP = {}
+
+    def hip_run(no_splitk=False, torch_norm=False, torch_wgrad=False, torch_wgrad_t=False, capture=False):
         for p_ in G.parameters():
             p_.grad = None
-        keep = (ops.conv2d, training.instance_norm, packing.wgrad_conv)
+        keep = (ops.conv2d, training.instance_norm, packing.wgrad_conv, packing.wgrad_conv_transpose)
+        if torch_wgrad_t:
+            packing.wgrad_conv_transpose = torch_wgrad_convT
+        if capture:                 # the weight-gradient kernels ALONE: their inputs of this run -> fp64 on the CPU against what they returned
+            def cap_t(x0, specs, dy, cin, n, adj_spec=None):
+                g = keep[3](x0, specs, dy, cin, n, adj_spec=adj_spec)
+                CAP[("convT", cin, n, x0.shape[1])] = (x0.detach().cpu(), dy.detach().cpu(), g.detach().cpu())
+                return g
+
+            def cap_c(x0, spec, dy, x1, kh, kw, cin, n, db=None):
+                g = keep[2](x0, spec, dy, x1, kh, kw, cin, n, db=db)
+                if (kh, spec.stride) in ((3, 1), (4, 2), (3, 2)) and len(CAP) < 12:
+                    CAP[("conv", cin, n, x0.shape[1], kh, spec.stride, -spec.dy[0])] = (x0.detach().cpu(), dy.detach().cpu(), g.detach().cpu())
+                return g
+            packing.wgrad_conv_transpose, packing.wgrad_conv = cap_t, cap_c
         if no_splitk:
             ops.conv2d = lambda *a, **k: keep[0](*a, **{**k, "splitk": False})
         if torch_norm:
@@ -109,16 +132,39 @@ def main():
                 (out.permute(0, 3, 1, 2) - tgt.view(1, 3, S, S).to(DEV)).abs().mean().backward()
             torch.cuda.synchronize()
         finally:
-            ops.conv2d, training.instance_norm, packing.wgrad_conv = keep
+            ops.conv2d, training.instance_norm, packing.wgrad_conv, packing.wgrad_conv_transpose = keep
         return {k: p_.grad.double().cpu() for k, p_ in G.named_parameters() if k.startswith("bg_net")}
 
     gpu = {"hip": hip_run(), "hip no-splitK": hip_run(no_splitk=True), "hip torch-norm": hip_run(torch_norm=True),
            "hip torch-wgrad": hip_run(torch_wgrad=True), "hip t-norm+wg": hip_run(torch_norm=True, torch_wgrad=True),
-           "hip all three": hip_run(True, True, True)}
+           "hip all three": hip_run(True, True, True), "hip t-wgradT": hip_run(torch_wgrad_t=True),
+           "hip nosplit+wgT": hip_run(no_splitk=True, torch_wgrad_t=True)}
     gpu["torch-ROCm f32"] = cpu_run(torch.float32, device=DEV)
     gpu["t32 (CPU)"] = cpu["t32"]
     gpu["max perturbed"] = {k: max((cpu[n][k] for n in cpu if "in*1e-7" in n), key=lambda g_: (g_ - g64[k]).abs().max().item()) for k in g64}
     table("GPU", g64, gpu)
+    # L2 view of the same columns (a flipped ReLU / L1-sign kink lands on a few elements: large element-wise, small in L2; an arithmetic defect is both)
+    gmax = max(v.abs().max().item() for v in g64.values())
+    print("\n== GPU, relative L2 error per parameter: ||g - g64|| / ||g64||")
+    print("param".ljust(30) + " ".join(n[:14].rjust(14) for n in gpu))
+    for k in g64:
+        if k.endswith("weight"):
+            print(k[7:].ljust(30) + " ".join(f"{((gpu[n][k] - g64[k]).norm() / g64[k].norm()).item():14.2e}" for n in gpu))
+    # the weight-gradient kernels alone: captured inputs of one default run, fp64 on the CPU
+    hip_run(capture=True)
+    print("\n== weight-gradient kernels ALONE (inputs captured from the default run; reference: fp64 on the CPU from the same tensors)")
+    for key, (x0, dy, g) in CAP.items():
+        if key[0] == "convT":
+            _, cin, n, _ = key
+            w = torch.zeros(cin, n, 4, 4, dtype=torch.float64, requires_grad=True)
+            y = F.conv_transpose2d(x0[..., :cin].double().permute(0, 3, 1, 2), w, stride=2, padding=1)
+            ref = torch.autograd.grad(y, w, dy[..., :n].double().permute(0, 3, 1, 2))[0]
+        else:
+            _, cin, n, _, kh, st, pad = key
+            ref = torch.nn.grad.conv2d_weight(x0[..., :cin].double().permute(0, 3, 1, 2), (n, cin, kh, kh), dy[..., :n].double().permute(0, 3, 1, 2), stride=st, padding=pad)
+        d = g.double() - ref
+        print(f"  {str(key):40s} max |d| / max |ref| {d.abs().max().item() / ref.abs().max().item():.2e}   rel L2 {(d.norm() / ref.norm()).item():.2e}   "
+              f"dy: {float((dy != 0).float().mean()):.3f} non-zero, max {dy.abs().max().item():.2e}", flush=True)
 
 
 if __name__ == "__main__":
