@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 8: lwg_conv2d_winograd_plan; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 8: lwg_conv2d_winograd_plan, lwg_up4_head_compose_bf16; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
 #define LWG_ABI_VERSION 8
 int lwg_abi_version(void);
@@ -413,6 +413,13 @@ int lwg_thin_conv_f32(const float* x, const float* wpk, int B, int S, int C, int
  * Outputs fp32 NCHW as lwg_head_compose_f32. */
 int lwg_head_compose_bf16(const void* x, const void* wb, const float* bg, size_t bg_bstride, int B, int S, int C, float* pred,
                           float* mask, float* img, lwg_stream_t stream);
+/* BASELINE configs[3], the last stage of forward_tsf as ONE launch (csrc/up4_head_bf16.hip): nn.ConvTranspose2d(128 -> 64, 4, 2, 1) + ReLU
+ * (attlwb_spade_resunet.py:331-340), the two 5x5 regressors with tanh / sigmoid (:605-613) and the compositing (models/imitator.py:393) - the
+ * (B, 2H, 2W, 64) tensor between them is never written.  args: the launch description lwg_conv_transpose4_nhwc_bf16 takes for that layer (C0 = 128, N = 64,
+ * LWG_EPI_NONE + LWG_ACT_RELU, args->w = the four parity panels, args->bias), its y / YH / YW / YC ignored; whead: lwg_head_compose_bf16's panel; bg / pred /
+ * mask / img as there, at (2H, 2W).  Same values as the two calls it replaces (the intermediate is rounded to bf16 as they round it). */
+int lwg_up4_head_compose_bf16(const LwgConvArgs* args, const void* whead, const float* bg, size_t bg_bstride, float* pred, float* mask, float* img,
+                              lwg_stream_t stream);
 /* lwg_frames_to_u8: the output conversion of Imitator.inference (models/imitator.py:368-372 ->
  * cv_utils.save_cv2_img(normalize=True), tools/utils/filesio/cv_utils.py:100-116): pred (B,3,S,S) fp32 ->
  * (B,S,S,3) uint8 = uint8((x+1)/2.0*255) in numpy fp32 arithmetic (truncation); bgr = 1: cv2's channel order. */

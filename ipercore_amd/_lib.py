@@ -97,6 +97,7 @@ _SIGS = {
     "lwg_lwb_attention_bf16": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "lwg_instnorm_stats_nhwc_bf16": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_f, c_i, c_f]),
     "lwg_head_compose_bf16": (c_i, [c_f, c_f, c_f, ctypes.c_size_t, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "lwg_up4_head_compose_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f, c_f, ctypes.c_size_t, c_f, c_f, c_f, c_f]),
     "lwg_flow_resize_f32": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "lwg_lwb_fuse_f32": (c_i, [c_f] * 5 + [c_i] * 7 + [ctypes.c_float, ctypes.c_float, c_f]),
     "lwg_lwb_attention_x_f32": (c_i, [c_f] * 8 + [c_i] * 6 + [c_f]),

@@ -353,10 +353,15 @@ class AttentionLWBGenerator(nn.Module):
             x = ops.conv2d(h, c1, torch.empty_like(x), epi=ops.EPI_RESIDUAL, res=x)
             x = self._attlwb(pk.res_sites[i], x, feats.kv[site], Tst, feats.batched, scratch)
             site += 1
-        # fp32 MFMA path (direct or Winograd 3x3 layers - the transposed convolutions are the direct kernel's in both): the last up-sampling
-        # layer writes channel-quad planes, the layout the fp32 head stages whole lines from
+        # fp32 MFMA path ("fp32": direct transposed convolutions; "winograd": lwg_conv_transpose4_winograd_f32, incl. this last layer): the last
+        # up-sampling layer writes channel-quad planes, the layout the fp32 head stages whole lines from
         q4 = adt == torch.float32 and self.conv_precision in ("fp32", "winograd")
         for i in range(n_down):
+            if i == n_down - 1 and pk.head16 is not None and ops.up4_head_eligible(x, pk.upconvs[i], ops.ACT_RELU):
+                # bf16 engine (BASELINE configs[3]): the last up-sampling layer, the 5x5 regressors and the compositing as ONE launch - the
+                # (B, S, S, 64) tensor between them is never written (csrc/up4_head_bf16.hip)
+                return ops.up4_head_compose_bf16(x, pk.upconvs[i], pk.head16, bg, want_pred=want_pred and bg is not None, want_mask=want_mask,
+                                                 want_img=want_img)
             x = self._upconv(x, pk.upconvs[i], ops.ACT_RELU, q4=q4 and i == n_down - 1)
             if i != n_down - 1:
                 skip = enc[n_down - 2 - i]

@@ -701,6 +701,50 @@ def head_compose(x, wpk, bg, want_pred=True, want_mask=True, want_img=False, q4=
     return pred, mask, img
 
 
+BF16_UP4_HEAD = True    # lab switch: False = the bf16 engine's last up-sampling layer and its output head as two launches (rounds 2-5)
+
+
+def up4_head_eligible(x, specs, act):
+    """The fused last stage of the bf16 engine (lwg_up4_head_compose_bf16): ConvTranspose2d(128 -> 64, 4, 2, 1) + ReLU on a bf16 input."""
+    s0 = specs[0]
+    return (BF16_UP4_HEAD and BF16_UP4 and BF16_HR and x.is_cuda and x.dtype == torch.bfloat16 and len(specs) == 4 and s0.Cin == 128 and s0.N == 64
+            and act == ACT_RELU and s0.bias is not None
+            and all(s.ntaps == 4 and s.omul == 2 and (s.ooy, s.oox) == (i >> 1, i & 1) for i, s in enumerate(specs)))
+
+
+def up4_head_compose_bf16(x, specs, head16, bg, want_pred=True, want_mask=True, want_img=False):
+    """BASELINE configs[3]'s last stage as ONE launch (csrc/up4_head_bf16.hip): x (B,H,W,128) bf16 -> ReLU(ConvTranspose2d(4, 2, 1)) (B,2H,2W,64), never
+    written -> the 5x5 regressors + tanh / sigmoid + compositing -> (pred, mask, img) fp32 NCHW at (2H, 2W), as ``head_compose`` returns them.
+    specs: the layer's four parity specs (packing.pack_conv_transpose); head16: packing.pack_head_bf16's panel."""
+    B, H, W, _ = x.shape
+    s0 = specs[0]
+    dev = x.device
+    S2h, S2w = 2 * H, 2 * W
+    pred = torch.empty(B, 3, S2h, S2w, device=dev, dtype=torch.float32) if want_pred else None
+    mask = torch.empty(B, 1, S2h, S2w, device=dev, dtype=torch.float32) if want_mask else None
+    img = torch.empty(B, 3, S2h, S2w, device=dev, dtype=torch.float32) if want_img else None
+    bstride = 0
+    if bg is not None and bg.shape[0] != 1:
+        assert bg.shape[0] == B
+        bstride = 3 * S2h * S2w
+    # the layer's output does not exist: a zero-batch tensor gives the launch description its geometry
+    a = conv_args(x, s0, torch.empty(0, S2h, S2w, s0.N, device=dev, dtype=torch.bfloat16), act=ACT_RELU, out_hw=(H, W))
+    panel = getattr(s0, "_w16up", None)
+    if panel is None or panel.device != s0.w.device:
+        panel = torch.stack([_w16hr(s, False)[0] for s in specs]).contiguous()
+        s0._w16up = panel
+    a.w = _ptr(panel, torch.bfloat16)
+    if CONV_HOOK is not None:          # accounted as the transposed convolution it contains (16 taps, 4 N outputs per input pixel) + nothing for the head (as before)
+        whole = _FusedTransposeSpec(s0, panel)
+        CONV_HOOK(True, a.M, whole, EPI_NONE, None)
+    _lib.check(_lib.lib().lwg_up4_head_compose_bf16(a, _ptr(head16, torch.bfloat16), _ptr(bg), bstride, _ptr(pred), _ptr(mask), _ptr(img), _stream()),
+               "lwg_up4_head_compose_bf16")
+    if CONV_HOOK is not None:
+        per = H * W * 256
+        CONV_HOOK(False, a.M, whole, EPI_NONE, {"kernels": max(1, -(-B // max(1, (0xC0000000 - 1) // per))), "kind": "up4_head"})
+    return pred, mask, img
+
+
 def thin_conv(x, wpk, ks):
     """Stride-1 ks x ks convolution (pad ks // 2, no bias) with <= 4 outputs: x (B,S,S,C) NHWC, wpk (ks*ks, C, 4) -> (B,S,S,4)
     pre-activation (csrc/head.hip lwg_thin_conv_f32)."""

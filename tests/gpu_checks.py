@@ -1064,6 +1064,58 @@ def check_winograd_adversarial():
     return out
 
 
+def check_bf16_up4_head():
+    """BASELINE configs[3]'s last stage as ONE launch (csrc/up4_head_bf16.hip, lwg_up4_head_compose_bf16): ConvTranspose2d(128 -> 64, 4, 2, 1) + ReLU
+    (attlwb_spade_resunet.py:331-340) -> the two 5x5 regressors + tanh / sigmoid (:605-613) -> compositing (models/imitator.py:393), the 64-channel tensor
+    between them never written.  Against the TWO launches it replaces (lwg_conv_transpose4_nhwc_bf16 + lwg_head_compose_bf16: same MFMA order, same bf16
+    rounding of the intermediate -> the same values) on sizes that cut the 12 x 28 tiles by the image edge, a per-frame and a shared background, every output
+    combination; and against an fp64 evaluation of the same layers on the bf16-rounded operands with the intermediate rounded to bf16 as the engine stores it."""
+    out = {}
+    for tag, (B, H, W, per_frame_bg) in (("sq64", (2, 64, 64, False)), ("ragged", (3, 23, 23, True)), ("ragged37", (2, 37, 37, False)), ("tiny", (1, 5, 5, False)),
+                                         ("tile_exact", (1, 42, 42, True)), ("many_tiles_per_workgroup", (5, 96, 96, True))):
+        w = _rand((128, 64, 4, 4), 700, 1.0 / np.sqrt(128 * 4))
+        bsv = _rand((64,), 701, 0.1)
+        w_img, w_att = _rand((3, 64, 5, 5), 702, 0.05), _rand((1, 64, 5, 5), 703, 0.05)
+        x = _rand((B, H, W, 128), 704).to(torch.bfloat16)
+        bg = _rand((B if per_frame_bg else 1, 3, 2 * H, 2 * W), 705, 0.5).to(DEV)
+        specs = [_spec_dev(s_) for s_ in packing.pack_conv_transpose(w, bsv)]
+        head16 = packing.pack_head_bf16(w_img, w_att).to(DEV)
+        xd = x.to(DEV)
+        assert ops.up4_head_eligible(xd, specs, ops.ACT_RELU)
+        y = torch.empty(B, 2 * H, 2 * W, 64, device=DEV, dtype=torch.bfloat16)
+        ops.conv_transpose2d(xd, specs, y, act=ops.ACT_RELU)
+        p2, m2, i2 = ops.head_compose(y, head16, bg, want_pred=True, want_mask=True, want_img=True)
+        p1, m1, i1 = ops.up4_head_compose_bf16(xd, specs, head16, bg, want_pred=True, want_mask=True, want_img=True)
+        pm, mm, _ = ops.up4_head_compose_bf16(xd, specs, head16, bg, want_pred=True, want_mask=False, want_img=False)
+        _, mo, io = ops.up4_head_compose_bf16(xd, specs, head16, None, want_pred=False, want_mask=True, want_img=True)
+        torch.cuda.synchronize()
+        assert mm is None and torch.equal(pm, p1) and torch.equal(mo, m1) and torch.equal(io, i1), tag + ": output selection changes the values"
+        d = max((p1 - p2).abs().max().item(), (m1 - m2).abs().max().item(), (i1 - i2).abs().max().item())
+        out[tag] = {"vs_two_launches_max": d, "bitwise": bool(torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(i1, i2))}
+        assert torch.isfinite(p1).all() and d <= 1e-6, (tag, out[tag])
+        # fp64 on the bf16-rounded operands, intermediate rounded to bf16
+        wb, w5 = w.to(torch.bfloat16).double(), torch.cat([w_img, w_att]).to(torch.bfloat16).double()
+        t = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), wb, bsv.double(), stride=2, padding=1).relu().to(torch.bfloat16).double()
+        s5 = F.conv2d(t, w5, padding=2)
+        img_r, m_r = torch.tanh(s5[:, :3]), torch.sigmoid(s5[:, 3:4])
+        pred_r = m_r * bg.cpu().double() + (1 - m_r) * img_r
+        out[tag]["pred_vs_fp64_max"] = (p1.cpu().double() - pred_r).abs().max().item()
+        out[tag]["intermediate_bf16_flips_bound"] = 2e-2
+        assert out[tag]["pred_vs_fp64_max"] <= 2e-2, (tag, out[tag])          # (an fp32-vs-fp64 sum that rounds to the other bf16 neighbour moves a pre-activation by 2^-9 of it)
+    # the contract: what the kernel does not take is refused before any launch
+    a = ops.conv_args(xd, specs[0], torch.empty(0, 2 * H, 2 * W, 64, device=DEV, dtype=torch.bfloat16), act=ops.ACT_RELU, out_hw=(H, W))
+    a.w = ops._ptr(specs[0]._w16up, torch.bfloat16)
+    hp = ops._ptr(head16, torch.bfloat16)
+    pp = ops._ptr(p1)
+    for field, val in (("C0", 64), ("N", 128), ("act", ops.ACT_NONE), ("ntaps", 9), ("omul", 1)):
+        keep = getattr(a, field)
+        setattr(a, field, val)
+        assert _lib.lib().lwg_up4_head_compose_bf16(a, hp, ops._ptr(bg), 0, pp, None, None, None) == 1, field
+        setattr(a, field, keep)
+    assert _lib.lib().lwg_up4_head_compose_bf16(a, hp, None, 0, pp, None, None, None) == 1            # pred without a background
+    return out
+
+
 def check_batch_slicing_1024():
     """Frame batches whose gathered tensors exceed the conv kernels' 32-bit buffer offsets (3 GiB): the C entry points cut the launch
     into batch slices (csrc/lwg_conv_slices.h), the caller sees no limit.  1024 x 1024 novel-view poses: fp32 at frame batch 26 (the
@@ -2815,7 +2867,7 @@ def check_panel_cache_refresh():
     return out
 
 
-ALL = [check_winograd_up4, check_winograd_adversarial, check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
+ALL = [check_winograd_up4, check_winograd_adversarial, check_bf16_up4_head, check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden, check_generator_golden_256,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,

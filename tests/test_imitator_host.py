@@ -183,8 +183,8 @@ def test_only_vis_frames_on_emulated_abi(monkeypatch):
 
 def test_precision_modes_plumbing(monkeypatch):
     """generator.conv_precision = "winograd" (the default) / "fp32" / "split" route through the same engine wiring (the emulated ABI computes every
-    mode exactly, so the frames must equal the default mode's): the quad-plane head input is used by the fp32 MFMA modes ("winograd" and "fp32",
-    whose last up-sampling layer is the same direct transposed convolution), "split" takes the NHWC head."""
+    mode exactly, so the frames must equal the default mode's): the quad-plane head input is used by the fp32 MFMA modes ("winograd": the
+    last up-sampling layer is lwg_conv_transpose4_winograd_f32 with a quad-plane output; "fp32": the direct transposed convolution), "split" takes the NHWC head."""
     emu_ops.install(monkeypatch)
     from ipercore_amd import ops
     case = pu.build_case(image_size=64, num_filters=[64, 64, 128], n_res=2, bg_filters=[64, 64, 128], n_frames=3, ns=2)

@@ -101,7 +101,7 @@ def main():
 
     CAP = {}
 
-    def hip_run(no_splitk=False, torch_norm=False, torch_wgrad=False, torch_wgrad_t=False, capture=False):
+    def hip_run(no_splitk=False, torch_norm=False, torch_wgrad=False, torch_wgrad_t=False, capture=False, nosplit_if=None):
         for p_ in G.parameters():
             p_.grad = None
         keep = (ops.conv2d, training.instance_norm, packing.wgrad_conv, packing.wgrad_conv_transpose)
@@ -121,6 +121,8 @@ def main():
             packing.wgrad_conv_transpose, packing.wgrad_conv = cap_t, cap_c
         if no_splitk:
             ops.conv2d = lambda *a, **k: keep[0](*a, **{**k, "splitk": False})
+        if nosplit_if is not None:      # split-K off for ONE class of launches (a[1] = the ConvSpec): where does the extra error enter?
+            ops.conv2d = lambda *a, **k: keep[0](*a, **{**k, "splitk": k.get("splitk", False) and not nosplit_if(a[1], a[0])})
         if torch_norm:
             training.instance_norm = torch_instance_norm
         if torch_wgrad:
@@ -150,6 +152,20 @@ def main():
     for k in g64:
         if k.endswith("weight"):
             print(k[7:].ljust(30) + " ".join(f"{((gpu[n][k] - g64[k]).norm() / g64[k].norm()).item():14.2e}" for n in gpu))
+    # split-K off for one class of launches at a time (L2 error of three parameters: first layer, a residual block, the first transposed convolution)
+    classes = {"none (all split)": lambda sp, x: False, "all": lambda sp, x: True,
+               "3x3 s1 (res blocks fwd + dgrad)": lambda sp, x: sp.ntaps == 9 and sp.stride == 1 and sp.omul == 1,
+               "16-tap s2 (convT dgrad)": lambda sp, x: sp.ntaps == 16,
+               "3x3 s2 fwd": lambda sp, x: sp.ntaps == 9 and sp.stride == 2,
+               "omul 2 (s2 dgrad parities / convT fwd parities)": lambda sp, x: sp.omul == 2,
+               "launches on 64 x 64 maps": lambda sp, x: x.shape[1] == 64,
+               "launches on 128 x 128 maps": lambda sp, x: x.shape[1] == 128,
+               "launches on >= 256 maps": lambda sp, x: x.shape[1] >= 256}
+    print("\n== split-K off for ONE class of launches: relative L2 error of dW (first layer | res block 12.main.0 | convT main.18 | main.9)")
+    for name, pred in classes.items():
+        gr = hip_run(nosplit_if=pred)
+        print(f"  {name:52s} " + "  ".join(f"{((gr[k] - g64[k]).norm() / g64[k].norm()).item():.2e}" for k in
+                                          ("bg_net.main.0.weight", "bg_net.main.12.main.0.weight", "bg_net.main.18.weight", "bg_net.main.9.weight")), flush=True)
     # the weight-gradient kernels alone: captured inputs of one default run, fp64 on the CPU
     hip_run(capture=True)
     print("\n== weight-gradient kernels ALONE (inputs captured from the default run; reference: fp64 on the CPU from the same tensors)")
