@@ -433,6 +433,23 @@ def b1_latency(im, tgt, timer, n_frames=64):
         out = {"frame_batch": 1, "frames": n, "mode": "eager launches", "ms_per_frame_back_to_back": round(dt / n * 1e3, 3),
                "frames_per_s": round(n / dt, 2), "ms_one_frame_from_idle_median": round(float(np.median(idle)), 3),
                "ms_one_frame_from_idle_min": round(min(idle), 3)}
+        # single frames alternating over 2 / 3 HIP streams (Imitator(streams=k)): a one-frame launch of a 64 x 64 layer is 64-128 workgroups on 256
+        # CUs - the frame on the other stream takes the idle half.  Same kernels, same bits; the latency of ONE frame from idle does not change.
+        prev_streams = im.streams
+        try:
+            ref = im.synthesize(tgt[:n], "smooth") if n <= 64 else None
+            for k in (2, 3):
+                im.streams, im._side_streams = k, None
+                im.synthesize(tgt[:8], "smooth")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fr = im.synthesize(tgt[:n], "smooth")
+                torch.cuda.synchronize()
+                out[f"ms_per_frame_back_to_back_{k}_streams"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+                if ref is not None:
+                    out[f"bitwise_{k}_streams_vs_1"] = bool(torch.equal(fr, ref))
+        finally:
+            im.streams, im._side_streams = prev_streams, None
         timer.reset()
         timer.enabled, ops.CONV_HOOK = True, timer
         torch.cuda.synchronize()

@@ -190,29 +190,34 @@ __global__ __launch_bounds__(512, 1) void lwg_up4_head_bf16_kernel(const __bf16*
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int khalf_e = lane_e >> 5;
+        // (the epilogue is vector-ALU work between two barriers - 64 outputs per lane: the bias quads are read once, ReLU is one v_max per value, the
+        // out-of-image test is applied to the PACKED words - 8 selects per row tile instead of 16 compares + 16 selects + 8 merges; r06_d: 8-11 k cycles
+        // of a 27 k-cycle tile were spent here)
+        floatx4 b4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const floatx4*>(sm + UH_BIAS_OFF + (wn * 32 + 8 * g + 4 * khalf_e) * 4);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int cr = i + TM * ((lane_e >> 4) & 1), cc = lane_e & 15;
             const int iy = 2 * cr + py, ix = 2 * cc + px;      // pixel inside the 16 x 32 intermediate tile
             const int gy = oy0 - 2 + iy, gx = ox0 - 2 + ix;    // ... and inside the frame
             const bool inside = gy >= 0 && gy < OH && gx >= 0 && gx < OW;
-            float o[4][4];
+            unsigned pk[4][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 b4 = *reinterpret_cast<const floatx4*>(sm + UH_BIAS_OFF + (wn * 32 + 8 * g + 4 * khalf_e) * 4);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = acc[i][4 * g + c] + b4[c];
-                    o[g][c] = inside ? (v > 0.f ? v : 0.f) : 0.f;
+                for (int d = 0; d < 2; ++d) {
+                    const float v0 = __builtin_fmaxf(acc[i][4 * g + 2 * d] + b4[g][2 * d], 0.f), v1 = __builtin_fmaxf(acc[i][4 * g + 2 * d + 1] + b4[g][2 * d + 1], 0.f);
+                    const unsigned w2 = uh_pack_bf16x2(v0, v1);
+                    pk[g][d] = inside ? w2 : 0u;
                 }
-            }
             // the two half-waves exchange halves (as lwg_bf16_epilogue's store): lanes 0..31 end up with channels [0, 16), lanes 32..63 with [16, 32) of the tile
             uintx4 st[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    auto sres = __builtin_amdgcn_permlane32_swap(uh_pack_bf16x2(o[h][2 * d], o[h][2 * d + 1]), uh_pack_bf16x2(o[2 + h][2 * d], o[2 + h][2 * d + 1]), false, false);
+                    auto sres = __builtin_amdgcn_permlane32_swap(pk[h][d], pk[2 + h][d], false, false);
                     st[h][d] = sres[0];
                     st[h][2 + d] = sres[1];
                 }
