@@ -47,9 +47,11 @@ __device__ __forceinline__ float lwg_bf16_hi(unsigned u) { return __builtin_bit_
 // SPATIAL = 0: GEMM row m_base + r is output position (b, oy, ox) in row-major order.  SPATIAL = 1 (the halo-tile kernels):
 // the workgroup's 128 rows are the 8 x 16 pixel block whose corner (image tb, row ty0, column tx0) the caller passes; row r is
 // pixel (ty0 + r / 16, tx0 + r % 16) and rows outside the image are dead.
-template <int TM, int TN, int EPI, int SPATIAL = 0>
-__device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
-                                                  int lane, int tb = 0, int ty0 = 0, int tx0 = 0) {
+// EA: the activation as a compile-time constant (>= 0) or a.act at run time (-1) - lwg_bf16_epilogue below resolves it once per workgroup
+// (lwg_common.h, LwgActC: a runtime code inside the innermost loops costs a uniform branch ladder per group of outputs).
+template <int TM, int TN, int EPI, int SPATIAL, int EA>
+__device__ __forceinline__ void lwg_bf16_epilogue_a(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
+                                                    int lane, int tb, int ty0, int tx0) {
     const int khalf = lane >> 5;
     const int HW = a.OH * a.OW;
     // ---- epilogue: D^T tiles -> bf16 NHWC.  acc[i][j][4*g + c] = pixel (lane & 31) of row tile i, channel 8*g + 4*khalf + c of
@@ -143,7 +145,7 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
                 for (int c = 0; c < 4; ++c) {
                     const float gm = acc[i][0][4 * g + c] + bg4[c];
                     const float bt = acc[i][0][4 * (g + 2) + c] + bb4[c];
-                    o[c] = lwg_act((xf[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
+                    o[c] = lwg_act_c<EA>((xf[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
                 }
                 if (live) {
                     uintx2 pk;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
                 for (int c = 0; c < 4; ++c) {
                     const float gm = acc[i][0][4 * g + c] + bg4[c];
                     const float bt = acc[i][TN - 1][4 * g + c] + bb4[c];
-                    o[g][c] = lwg_act((xf[g][c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
+                    o[g][c] = lwg_act_c<EA>((xf[g][c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
                 }
             }
             store_dt(yb + opix * a.YC + chb, live, o);
@@ -184,12 +186,20 @@ __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16
                     if (a.bias) b4 = *reinterpret_cast<const floatx4*>(a.bias + ncol + 8 * g + 4 * khalf);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        o[g][c] = lwg_act(acc[i][j][4 * g + c] + b4[c] + (EPI == LWG_EPI_RESIDUAL ? r4[g][c] : 0.f), a.act);
+                        o[g][c] = lwg_act_c<EA>(acc[i][j][4 * g + c] + b4[c] + (EPI == LWG_EPI_RESIDUAL ? r4[g][c] : 0.f), a.act);
                 }
                 store_dt(yb + opix * a.YC + a.ycoff + ncol, live, o);
             }
         }
     }
+}
+
+template <int TM, int TN, int EPI, int SPATIAL = 0>
+__device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
+                                                  int lane, int tb = 0, int ty0 = 0, int tx0 = 0) {
+    if (a.act == LWG_ACT_RELU) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_RELU>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
+    else if (a.act == LWG_ACT_NONE) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_NONE>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
+    else lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, -1>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool DMA_A>

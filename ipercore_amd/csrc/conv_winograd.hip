@@ -53,8 +53,12 @@
 // (tools/labvariant.sh); the stamps go to args->res (LWG_EPI_NONE launches only)
 #ifdef LWG_WINO_TS           // wave 0 of every workgroup: entry, K-loop entry, every second stage, K-loop exit, end (64 stamps per workgroup)
 #define WTS(i) do { if (tid == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define WTSB(k, i) do { if (lab_bi == (k)) WTS(i); } while (0)     // the workgroup's k-th block only (persistent form: block 1 = steady state)
+#define WTS_COUNT() ++lab_bi
 #else
 #define WTS(i) do { } while (0)
+#define WTSB(k, i) do { } while (0)
+#define WTS_COUNT() do { } while (0)
 #endif
 #ifdef LWG_WINO_TS2          // every wave: eight points of iterations 8 and 9
 #define WTS2(k) do { if (s == 8 || s == 9) ts2[(s - 8) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -332,15 +336,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
     };
     issue_loads();
+#ifdef LWG_WINO_TS
+    int lab_bi = 0;
+#endif
     for (;;) {
+    WTSB(2, 50);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         rst1(0, q, r0[q]);
         rst1(1, q, r1[q]);
     }
     __syncthreads();
+    WTSB(2, 51);
     transform(0);
     __syncthreads();
+    WTSB(2, 52);
     fragread(0, 0);
     fragread(0, 1);
     fragread(0, 2);
@@ -351,6 +361,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][tb][r] = 0.f;
     WTS(1);
+    WTSB(1, 44);
+    WTSB(2, 53);
     {
         int s = 0;
         for (; s + 2 < nst; s += 2) {
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         iteration(s + 1, IntC<1>(), IntC<0>());
     }
     WTS(40);
+    WTSB(1, 45);
 #ifdef LWG_WINO_TS2
     if (lane == 0)
         for (int i = 0; i < 16; ++i)
@@ -426,13 +439,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     // (UNCONDITIONAL for the last block too - it re-requests its own first stages, ten loads per thread nobody waits for: under `if (more)` the
     // halo registers would be conditionally defined, i.e. merged with their previous values, i.e. live through the whole K loop - 24 registers the
     // 64-channel form does not have)
+    WTSB(1, 54);
     const int nblk = blk + (int)gridDim.x;
     const bool more = !SPLIT && nblk < total;
     if constexpr (!SPLIT) {
         setup(more ? nblk : blk);
         issue_loads();
     }
+    WTSB(1, 46);
     __syncthreads();
+    WTSB(1, 47);
+    // (the activation resolved once per block: lwg_act_dispatch, lwg_common.h)
+    lwg_act_dispatch(a.act, [&](auto ACTC) {
+    constexpr int EA = decltype(ACTC)::value;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         floatx4 o[2][2], sx[4][2];
@@ -457,27 +476,31 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
                     } else if (oy < H && ox < W) {
                         floatx4 r;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r[c] = lwg_act((ext[0][i][px][c] - mu[c]) * rs[c] * (1.f + ext[1][i][px][c]) + v[c], a.act);
+                        for (int c = 0; c < 4; ++c) r[c] = lwg_act_c<EA>((ext[0][i][px][c] - mu[c]) * rs[c] * (1.f + ext[1][i][px][c]) + v[c], a.act);
                         *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4) = r;
                     }
                 } else if (oy < H && ox < W) {
                     floatx4 r;
-                    if (EPI == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK) {       // data gradient behind a ReLU: res = the forward input, the mask source
+                    if (EPI == LWG_EPI_RESIDUAL && lwg_act_is_mask<EA>(a.act)) {       // data gradient behind a ReLU: res = the forward input, the mask source
 #pragma unroll
                         for (int c = 0; c < 4; ++c) r[c] = ext[h][i][px][c] > 0.f ? v[c] : 0.f;
                     } else {
                         if (EPI == LWG_EPI_RESIDUAL) v += ext[h][i][px];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r[c] = lwg_act(v[c], a.act);
+                        for (int c = 0; c < 4; ++c) r[c] = lwg_act_c<EA>(v[c], a.act);
                     }
                     *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + a.ycoff + en0 + h * 32 + n4) = r;
                 }
             }
     }
+    });
     WTS(41);
+    WTSB(1, 48);
     if (!more) break;
     blk = nblk;
-    __syncthreads();                                         // every reader is done with the exchange buffer: raw[0] / raw[1] (the same LDS) may be written
+    __syncthreads();
+    WTSB(1, 49);
+    WTS_COUNT();                                         // every reader is done with the exchange buffer: raw[0] / raw[1] (the same LDS) may be written
     }
     WTS(42);
 }

@@ -354,6 +354,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     const int ety = p >> 3, etx = p & 7;
     const int chl = 4 * (lanee >> 5);
     __syncthreads();                                         // every wave has read its last fragments: the loop's LDS is free
+    lwg_act_dispatch(a.act, [&](auto ACTC) {                 // (the activation resolved once per block: lwg_common.h)
+    constexpr int EA = decltype(ACTC)::value;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + en0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
@@ -366,12 +368,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * g + k;
                     const float v = (acc[3 * ia + ib][r] + acc[3 * ia + ib + 1][r]) + (acc[3 * ia + 3 + ib][r] + acc[3 * ia + 4 + ib][r]);
-                    o[k] = lwg_act(v + bv[k], a.act);
+                    o[k] = lwg_act_c<EA>(v + bv[k], a.act);
                 }
                 const int ly = 2 * (2 * ety + ia) + py, lx = 2 * (2 * etx + ib) + px;      // the pixel inside the block's 32 x 32 outputs
                 *reinterpret_cast<floatx4*>(smem + (ly * 32 + lx) * OROW + 8 * g + chl) = o;
             }
     }
+    });
     // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the stores below (unconditional:
     // the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
     const int nblk = blk + (int)gridDim.x;

@@ -91,6 +91,21 @@ __device__ __forceinline__ float lwg_act(float v, int act) {
     return v;
 }
 
+// The activation of an epilogue resolved ONCE per workgroup instead of once per value (round 6): with the runtime code inside the innermost loops the
+// compiler emits a uniform branch ladder around every group of outputs (the tanh / sigmoid bodies in between) - measured on the fused Winograd kernel:
+// 4.5 k cycles per block for the output pass against 2.1 k with the activation a constant (profiles/r06_i_*).  An epilogue body is a generic lambda
+// taking LwgActC<A>; A >= 0: compile-time activation, -1: a.act at run time (tanh / sigmoid / the ReLU mask of a data gradient).  Same expressions per
+// value in every copy: same bits.
+template <int A> struct LwgActC { static constexpr int value = A; };
+template <int A> __device__ __forceinline__ float lwg_act_c(float v, int act_runtime) { return lwg_act(v, A >= 0 ? A : act_runtime); }
+template <int A> __device__ __forceinline__ bool lwg_act_is_mask(int act_runtime) { return A == LWG_ACT_RELU_MASK || (A < 0 && act_runtime == LWG_ACT_RELU_MASK); }
+template <typename F> __device__ __forceinline__ void lwg_act_dispatch(int act, F&& body) {
+    if (act == LWG_ACT_RELU) body(LwgActC<LWG_ACT_RELU>());
+    else if (act == LWG_ACT_NONE) body(LwgActC<LWG_ACT_NONE>());
+    else if (act == LWG_ACT_RELU_MASK) body(LwgActC<LWG_ACT_RELU_MASK>());      // (the data gradients of the training step)
+    else body(LwgActC<-1>());
+}
+
 // XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are adjacent share
 // operand panels, so give every XCD one contiguous chunk of the logical id space.  Bijective for any nwg.
 __device__ __forceinline__ int lwg_xcd_remap(int bid, int nwg) {

@@ -4,9 +4,10 @@
 #include "lwg_conv_args.h"
 
 // acc[i][j] are 32x32 D^T tiles: rows = output channels, columns = output pixels (see conv_igemm.hip).
-template <int TM, int TN, int EPI>
-__device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base,
-                                                  int wm, int wn, int lane, int ooy_add = 0, int oox_add = 0) {
+// EA: the activation as a compile-time constant (>= 0) or a.act at run time (-1): lwg_conv_epilogue below resolves it once (lwg_common.h, LwgActC).
+template <int TM, int TN, int EPI, int EA>
+__device__ __forceinline__ void lwg_conv_epilogue_a(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base,
+                                                    int wm, int wn, int lane, int ooy_add, int oox_add) {
     const int khalf = lane >> 5;
     const int HW = a.OH * a.OW;
     // ---- epilogue.  The MFMAs computed D^T (weights as the row operand), so a lane owns ONE output pixel
@@ -55,7 +56,7 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                 for (int c = 0; c < 4; ++c) {
                     const float gm = acc[i][0][4 * g + c] + bias4[0][g][c];
                     const float bt = acc[i][TN - 1][4 * g + c] + bias4[TN - 1][g][c];
-                    o[c] = lwg_act((xv[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
+                    o[c] = lwg_act_c<EA>((xv[c] - mu[c]) * rs[c] * (1.f + gm) + bt, a.act);
                 }
                 *reinterpret_cast<floatx4*>(yr + 8 * g) = o;
             }
@@ -74,7 +75,7 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                 for (int g = 0; g < 4; ++g) {
                     floatx4 o;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = lwg_act(acc[i][j][4 * g + c] + bias4[j][g][c], a.act);
+                    for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>(acc[i][j][4 * g + c] + bias4[j][g][c], a.act);
                     *reinterpret_cast<floatx4*>(yq + (size_t)(8 * j + 2 * g) * plane * 4) = o;
                 }
         } else {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float v = acc[i][j][4 * g + c] + bias4[j][g][c];
-                        o[c] = (EPI == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK) ? (rv[c] > 0.f ? v : 0.f) : lwg_act(v + rv[c], a.act);
+                        o[c] = (EPI == LWG_EPI_RESIDUAL && lwg_act_is_mask<EA>(a.act)) ? (rv[c] > 0.f ? v : 0.f) : lwg_act_c<EA>(v + rv[c], a.act);
                     }
                     if (EPI == LWG_EPI_NONE && a.ydt == LWG_DT_BF16) {      // first layer of the bf16 mode: fp32 in, bf16 NHWC out
                         typedef __bf16 lwg_bf16x4 __attribute__((ext_vector_type(4)));
@@ -104,6 +105,16 @@ __device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16
                 }
         }
     }
+}
+
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void lwg_conv_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base,
+                                                  int wm, int wn, int lane, int ooy_add = 0, int oox_add = 0) {
+    if (a.act == LWG_ACT_RELU) lwg_conv_epilogue_a<TM, TN, EPI, LWG_ACT_RELU>(a, acc, m_base, n_base, wm, wn, lane, ooy_add, oox_add);
+    else if (a.act == LWG_ACT_NONE) lwg_conv_epilogue_a<TM, TN, EPI, LWG_ACT_NONE>(a, acc, m_base, n_base, wm, wn, lane, ooy_add, oox_add);
+    else if (EPI == LWG_EPI_RESIDUAL && a.act == LWG_ACT_RELU_MASK)
+        lwg_conv_epilogue_a<TM, TN, EPI, LWG_ACT_RELU_MASK>(a, acc, m_base, n_base, wm, wn, lane, ooy_add, oox_add);
+    else lwg_conv_epilogue_a<TM, TN, EPI, -1>(a, acc, m_base, n_base, wm, wn, lane, ooy_add, oox_add);
 }
 
 // Split-K launches: the raw partial sums of one K slice as a dense (M, N) slab (no bias / activation / output geometry; the

@@ -55,7 +55,7 @@ else:
     pred, mask, _ = ops.up4_head_compose_bf16(x, specs, head16, bg, want_pred=True, want_mask=True)
     torch.cuda.synchronize()
     ts = mask.view(-1).view(torch.int64)[:256 * 16].view(256, 2, 8).cpu().numpy().astype(np.float64)
-    names = ["top barrier", "phase 1 (K loops + 2 epilogues)", "prefetch issue", "barrier (T complete)", "phase 2 MFMAs + partial stores", "wait next tile's loads", "barrier", "final pass"]
+    names = ["(stamp 0)", "top barrier", "K loops (+ next halo requested)", "epilogue into T", "barrier (T complete)", "phase 2 MFMAs + partial stores", "wait next tile's loads", "barrier + final pass"]
     for wv, tag in ((0, "wave 0"), (1, "wave 7")):
         d = np.diff(ts[:, wv, :], axis=1)
         ok = (ts[:, wv, 0] > 0) & (d > 0).all(axis=1)

@@ -122,6 +122,14 @@ for idx, (tag, mul, S, C0, C1, Co, epi) in enumerate(SHAPES):
               f" (per stage {d_loop.mean() / nst:.0f}; ideal 4096)  epilogue halves {d_e0.mean():.0f} + {d_e1.mean():.0f}  total {tot.mean():.0f}")
         if pairs is not None:
             print(f"     steady-state stage (inside the loop, from stamp pairs): mean {pairs.mean():.0f} median {pairs.median():.0f} min {pairs.min():.0f} max {pairs.max():.0f}")
+        # persistent form (round 6): the workgroup's block 1 (steady state) and the prologue of its block 2 (needs >= 3 blocks per workgroup: --frames 48)
+        ok = (t[:, 53] > 0) & (t[:, 44] > 0)
+        if int(ok.sum()) > 0:
+            u = t[ok].double()
+            seg = [("K loop", 45, 44), ("fold -> Ms", 54, 45), ("next block's set-up + loads issued", 46, 54), ("barrier", 47, 46), ("Ms reads + output transform + stores", 48, 47),
+                   ("barrier", 49, 48), ("raw stages 0 / 1 -> LDS + barrier", 51, 50), ("transform(0) + barrier", 52, 51), ("first fragments + accumulator clear", 53, 52)]
+            print(f"     persistent block timeline ({int(ok.sum())} workgroups; medians): " + "; ".join(f"{n} {float((u[:, i1] - u[:, i0]).median()):.0f}" for n, i1, i0 in seg)
+                  + f"; block 1 K-loop entry -> block 2 K-loop entry {float((u[:, 53] - u[:, 44]).median()):.0f}")
         span = float(t[:, 42].max() - t[:, 0].min())
         print(f"     first entry -> last exit {span:.0f} ticks; sum of workgroup cycles / 256 CUs = {float(tot.sum()) / 256:.0f}")
         continue
