@@ -79,7 +79,10 @@ __device__ __forceinline__ floatx4 wino_buf_load(__amdgpu_buffer_rsrc_t r, unsig
 // SPLIT (training launches that leave half the chip or more idle; NBV = 32, plain epilogue): blockIdx.z owns the stages [z a.cshift, (z + 1) a.cshift)
 // of the K loop (a.cshift - unused by convolutions with Cin >= 32 - carries the stages per slice here) and leaves raw sums in its dense (M, N) slab
 // a.y + z M N (the host passes YC = N, ycoff = 0, no bias, no activation); lwg_splitk_finish_kernel adds the slabs in slice order and finishes.
-template <int EPI, int NBV, bool SPLIT = false>
+// TWO (round 6): the launch has a second input (skip concatenation).  One-input launches - four fifths of the engine's time - carry no per-load choice
+// of the source tensor at all: as a uniform branch pair around every halo load it cost 1.9 % of the K loop and 700 cycles of every block's set-up
+// (profiles/r06_k_*); the two-input form selects the descriptor / offset (scalar selects + one v_cndmask per load) instead of branching.
+template <int EPI, int NBV, bool SPLIT = false, bool TWO = false>
 __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const LwgConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NBV / 32;                             // accumulator (patch) tiles per product and wave
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
         y0 = (t / bx) * 2 * TPB;
         n0 = cb * NBV;
         rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
-        rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.C1 ? a.x1 + (size_t)b * H * W * a.C1 : a.x0), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
+        if constexpr (TWO) rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * H * W * a.C1), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                        // padding pixels / threads without a halo element: an out-of-range offset (zeros)
             const int i = tid + WG_THREADS * q;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             const bool in = i < PLANE * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
             voff0[q] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * half) * 4u : WINO_OOB;
-            voff1[q] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * half) * 4u : WINO_OOB;
+            if constexpr (TWO) voff1[q] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * half) * 4u : WINO_OOB;
         }
         uvoff = (unsigned)(((lane >> 5) * N + n0 + nbw_ * 32 + (lane & 31)) * 16);
     };
@@ -149,7 +152,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_conv_winograd_kernel(const 
     floatx4 rreg[2];
     auto rld1 = [&](int st, int q) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
         const int c = (st + sbeg) * KS;
-        return c < a.C0 ? wino_buf_load(rx0, voff0[q], (unsigned)c * 4u) : wino_buf_load(rx1, voff1[q], (unsigned)(c - a.C0) * 4u);
+        if constexpr (!TWO) {
+            return wino_buf_load(rx0, voff0[q], (unsigned)c * 4u);
+        } else {
+            const bool first = c < a.C0;
+            const __amdgpu_buffer_rsrc_t r = first ? rx0 : rx1;
+            const unsigned v = first ? voff0[q] : voff1[q];
+            return wino_buf_load(r, v, (unsigned)(first ? c : c - a.C0) * 4u);
+        }
     };
     auto rst1 = [&](int buf, int q, floatx4 v) {
         float* dst = raw0 + buf * RAW_FLOATS + wst[q];
@@ -680,12 +690,13 @@ extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);
     const int cus = lwg_device_cus();
     const bool small = lwg_wino_small(a, cus);
-    static unsigned long long done[6] = {0, 0, 0, 0, 0, 0};
+    static unsigned long long done[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool two = a.C1 > 0;
     int sps = 0;
     const int slices = ws ? lwg_wino_split_plan(a, &sps) : 0;
     if (slices > 1) {
-        auto kern = lwg_conv_winograd_kernel<LWG_EPI_NONE, 32, true>;
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[5]); e != hipSuccess) return (int)e;
+        auto kern = two ? lwg_conv_winograd_kernel<LWG_EPI_NONE, 32, true, true> : lwg_conv_winograd_kernel<LWG_EPI_NONE, 32, true, false>;
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[two ? 11 : 5]); e != hipSuccess) return (int)e;
         LwgConvArgs part = a;                                // raw sums into the slabs: dense (M, N) rows, no bias / residual / activation
         part.y = ws;
         part.YC = a.N;
@@ -701,11 +712,15 @@ extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_
     // persistent workgroups: one per CU (LDS) at most, each walking block ids blockIdx.x + k gridDim.x (LWG_WINO_PERSIST = 0: one block per workgroup)
     const long total = (long)bx * by * a.B * (a.N / (small ? 32 : NB));
     const dim3 grid((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total));
+#define LWG_WINO_GO2(E, V, T, SLOT)                                                                                                   \
+    {                                                                                                                                 \
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E, V, false, T>), lds, done[SLOT]); e != hipSuccess) \
+            return (int)e;                                                                                                            \
+        hipLaunchKernelGGL((lwg_conv_winograd_kernel<E, V, false, T>), grid, dim3(WG_THREADS), lds, stream, a);                       \
+    }
 #define LWG_WINO_GO(E, V, SLOT)                                                                                                       \
     {                                                                                                                                 \
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd_kernel<E, V>), lds, done[SLOT]); e != hipSuccess) \
-            return (int)e;                                                                                                            \
-        hipLaunchKernelGGL((lwg_conv_winograd_kernel<E, V>), grid, dim3(WG_THREADS), lds, stream, a);                                 \
+        if (two) LWG_WINO_GO2(E, V, true, SLOT + 6) else LWG_WINO_GO2(E, V, false, SLOT)                                              \
     }
     if (a.epi == LWG_EPI_SPADE) LWG_WINO_GO(LWG_EPI_SPADE, 64, 2)
     else if (a.epi == LWG_EPI_RESIDUAL) {
@@ -716,5 +731,6 @@ extern "C" int lwg_conv2d_winograd_f32_ws(const LwgConvArgs* pa, float* ws, lwg_
         else LWG_WINO_GO(LWG_EPI_NONE, 64, 0)
     }
 #undef LWG_WINO_GO
+#undef LWG_WINO_GO2
     return (int)hipGetLastError();
 }
