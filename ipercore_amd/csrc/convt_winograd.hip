@@ -37,6 +37,7 @@
 #define LOOP_FLOATS (DUMP_OFF + DUMP_FLOATS)
 #define OROW 36                              // floats per pixel row of the epilogue's exchange buffer [32 x 32 output pixels][32 channels + 4]
 #define OUT_FLOATS (32 * 32 * OROW)
+#define BIAS_OFF (LOOP_FLOATS > OUT_FLOATS ? LOOP_FLOATS : OUT_FLOATS)    // the block's 32 bias values, behind both uses of the LDS
 #define WINO_OOB 0xC0000000u                 // >= any image's byte size (host: H * W * C * 4 < 3 GiB): the buffer load returns 0
 // slot plan of the K loop (profiles/r05_h_convt_winograd_lab.txt, 64 frames, all three layers): first plan (patch reads and transform in one slot each,
 // barrier behind k-pair 2) 0.622 of the pipe; barrier in front of k-pair 2 0.644; barrier in the middle of k-pair 3 0.646; that + the patch reads and the
@@ -57,9 +58,13 @@ template <int V> struct IntT { static constexpr int value = V; };
 // lab instrumentation (compiled out of the product): tools/up4lab.py --ts on a -DLWG_CTW_TS variant library - every wave stamps kernel entry, K-loop
 // entry, K-loop exit and its end into args->res (four 64-bit stamps per wave)
 #ifdef LWG_CTW_TS
-#define CTS(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define CTS(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define CTSB(k, i) do { if (lab_bi == (k)) CTS(i); } while (0)     // the workgroup's k-th block only (persistent form: block 1 = steady state)
+#define CTS_COUNT() ++lab_bi
 #else
 #define CTS(i) do { } while (0)
+#define CTSB(k, i) do { } while (0)
+#define CTS_COUNT() do { } while (0)
 #endif
 
 __device__ __forceinline__ floatx4 ctw_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -295,7 +300,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested
     // here for the workgroup's first block, for every later one from inside the previous block's epilogue
     floatx4 r0[2], r1[2];
+    float bq;                                                // the block's bias, one value per lane: requested with the first loads, parked in LDS by the
+                                                             // prologue (read straight from global memory in the epilogue it was an exposed L2 round trip)
     auto issue_loads = [&]() {
+        bq = a.bias ? a.bias[n0 + (tid & 31)] : 0.f;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             r0[q] = rld1(0, q);
@@ -310,13 +318,19 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         for (int q = 0; q < 2; ++q) rreg[q] = rld1(nst > 2 ? 2 : 1, q);
     };
     issue_loads();
+#ifdef LWG_CTW_TS
+    int lab_bi = 0;
+#endif
     for (;;) {
+    CTSB(2, 10);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         rst1(0, q, r0[q]);
         rst1(1, q, r1[q]);
     }
+    if (tid < 32) smem[BIAS_OFF + tid] = bq;
     __syncthreads();
+    CTSB(2, 11);
     {
         float dd[4][4];
 #pragma unroll
@@ -332,6 +346,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     CTS(1);
+    CTSB(1, 4);
+    CTSB(2, 12);
     {
         int s = 0;
         for (; s + 2 < nst; s += 2) {
@@ -342,6 +358,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         iteration(s + 1, IntT<1>(), IntT<0>());
     }
     CTS(2);
+    CTSB(1, 5);
     const int eb = b, ex0 = x0, ey0 = y0, en0 = n0;          // this block's coordinates (the state moves on to the next block below)
     // epilogue: Y[a][b] = sum over xi in {a, a + 1}, nu in {b, b + 1} of M[xi][nu] is register-local (this lane holds patch pt * 32 + lane % 32 and,
     // per register group g, the four channels 8 g + 4 (lane / 32) ..); + bias, activation; then ONE exchange through LDS - the block's 32 x 32 output
@@ -354,11 +371,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     const int ety = p >> 3, etx = p & 7;
     const int chl = 4 * (lanee >> 5);
     __syncthreads();                                         // every wave has read its last fragments: the loop's LDS is free
+    CTSB(1, 6);
     lwg_act_dispatch(a.act, [&](auto ACTC) {                 // (the activation resolved once per block: lwg_common.h)
     constexpr int EA = decltype(ACTC)::value;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const floatx4 bv = a.bias ? *reinterpret_cast<const floatx4*>(a.bias + en0 + 8 * g + chl) : floatx4{0.f, 0.f, 0.f, 0.f};
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(smem + BIAS_OFF + 8 * g + chl);
 #pragma unroll
         for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -377,39 +395,52 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     });
     // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the stores below (unconditional:
     // the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
+    CTSB(1, 7);
     const int nblk = blk + (int)gridDim.x;
     const bool more = nblk < total;
     setup(more ? nblk : blk);
     issue_loads();
+    CTSB(1, 8);
     __syncthreads();
+    CTSB(1, 9);
     const int oy0 = 2 * ey0, ox0 = 2 * ex0;
     const size_t plane = (size_t)a.YH * a.YW;
+    // The block's 32 x 32 x 32 outputs leave as BUFFER stores (round 6): image eb is one buffer, a thread's offset inside it is computed once, the
+    // sixteen passes differ by a SCALAR offset - no per-pass 64-bit address arithmetic, no per-pass bounds branch (profiles/r06_m_*: the store phase was
+    // 4.2-5.4 k cycles of instruction issue per block).  Pixels right of the image: an out-of-range thread offset (the store is dropped); rows below it:
+    // beyond the buffer's end in the NHWC layout (rows are its slowest dimension), an out-of-range scalar offset for the pass in the plane layout.
+    typedef unsigned int ctw_u4 __attribute__((ext_vector_type(4)));
     if (a.ydt == LWG_DT_F32_Q4) {
         // channel-quad planes (B, YC/4, YH, YW, 4): 32 lanes = one output row of the block in one plane, 512 contiguous bytes
-        const int lx = tide & 31;
-#pragma unroll 4
+        const int lx = tide & 31, cq = (tide >> 5) & 7, lyh = tide >> 8;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)eb * (size_t)(a.YC >> 2) * plane * 4, 0,
+                                                                            (int)((unsigned)(a.YC >> 2) * (unsigned)plane * 16u), 0x00020000);
+        const unsigned yv = ox0 + lx < a.YW ? (unsigned)(((((a.ycoff + en0) >> 2) + cq) * (int)plane + (oy0 + lyh) * a.YW + ox0 + lx) * 16) : WINO_OOB;
+        const float* src = smem + (lyh * 32 + lx) * OROW + 4 * cq;
+        const unsigned rowpair = (unsigned)a.YW * 32u;           // bytes between the rows of two passes (two rows of 16-byte pixels)
+#pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
-            const int idx = pass * 16 + (tide >> 5), cq = idx & 7, ly = idx >> 3;
-            if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
-                const floatx4 v = *reinterpret_cast<const floatx4*>(smem + (ly * 32 + lx) * OROW + 4 * cq);
-                *reinterpret_cast<floatx4*>(a.y + (((size_t)eb * (a.YC >> 2) + ((a.ycoff + en0) >> 2) + cq) * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * 4) = v;
-            }
+            const ctw_u4 v = *reinterpret_cast<const ctw_u4*>(src + pass * 64 * OROW);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yv, (int)(oy0 + 2 * pass < a.YH ? (unsigned)pass * rowpair : WINO_OOB), 0);
         }
     } else {
         // NHWC: 8 lanes = the block's 32 channels of one pixel, 128 contiguous bytes
-        const int cq = tide & 7;
-#pragma unroll 4
+        const int cq = tide & 7, lx = (tide >> 3) & 31, lyh = tide >> 8;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)eb * plane * a.YC, 0, (int)((unsigned)plane * (unsigned)a.YC * 4u), 0x00020000);
+        const unsigned yv = ox0 + lx < a.YW ? (unsigned)((((oy0 + lyh) * a.YW + ox0 + lx) * a.YC + a.ycoff + en0 + 4 * cq) * 4) : WINO_OOB;
+        const float* src = smem + (tide >> 3) * OROW + 4 * cq;
+        const unsigned rowpair = (unsigned)a.YW * (unsigned)a.YC * 8u;
+#pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
-            const int pi = pass * 64 + (tide >> 3), ly = pi >> 5, lx = pi & 31;
-            if (oy0 + ly < a.YH && ox0 + lx < a.YW) {
-                const floatx4 v = *reinterpret_cast<const floatx4*>(smem + pi * OROW + 4 * cq);
-                *reinterpret_cast<floatx4*>(a.y + ((size_t)eb * plane + (size_t)(oy0 + ly) * a.YW + (ox0 + lx)) * a.YC + a.ycoff + en0 + 4 * cq) = v;
-            }
+            const ctw_u4 v = *reinterpret_cast<const ctw_u4*>(src + pass * 64 * OROW);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yv, (int)((unsigned)pass * rowpair), 0);
         }
     }
+    CTSB(1, 13);
     if (!more) break;
     blk = nblk;
     __syncthreads();                                         // every thread has read its outputs from the exchange buffer: raw[0] / raw[1] may be written
+    CTS_COUNT();
     }
     CTS(3);
 }
@@ -429,7 +460,9 @@ extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_strea
         a.ycoff < 0 || (a.ycoff % 4) != 0 || (a.YC % 4) != 0 || a.ycoff + a.N > a.YC)
         return (int)hipErrorInvalidValue;
     if ((unsigned long long)a.H * a.W * a.C0 * 4ull >= (unsigned long long)WINO_OOB || 192ull * a.C0 * a.N >= 0xffffffffull) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)(LOOP_FLOATS > OUT_FLOATS ? LOOP_FLOATS : OUT_FLOATS) * 4;
+    // (an output image is one buffer of the store path: byte offsets + the sixteen row-pair offsets of a block stay below the out-of-range marker)
+    if ((unsigned long long)a.YH * a.YW * a.YC * 4ull + 32ull * a.YW * a.YC * 4ull >= (unsigned long long)WINO_OOB) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(BIAS_OFF + 32) * 4;
     static unsigned long long done = 0;
     if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_convt_winograd_kernel), lds, done); e != hipSuccess) return (int)e;
     const int bx = (a.W + 2 * TPB - 1) / (2 * TPB), by = (a.H + 2 * TPB - 1) / (2 * TPB);

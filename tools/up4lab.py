@@ -67,18 +67,26 @@ for idx, (tag, S, Cin, N, q4) in enumerate(SHAPES):
 
     if args.ts:
         nblk = ((S + 15) // 16) ** 2 * B * (N // 32)
-        stamps = torch.zeros(nblk * 8 * 4 * 2, device=dev)
+        stamps = torch.zeros(nblk * 8 * 16 * 2, device=dev)
         a = ops.conv_args(x, specs[0], yw, act=ops.ACT_RELU, q4=q4)
         a.w, a.res = ops._ptr(ops._wwino_t(specs)), ops._ptr(stamps)
         for _ in range(3):
             _lib.check(ENTRY(a, ops._stream()), "lwg_conv_transpose4_winograd_f32")
         torch.cuda.synchronize()
-        t = stamps.view(torch.int64).view(nblk, 8, 4).cpu().double()
+        t = stamps.view(torch.int64).view(nblk, 8, 16).cpu().double()
         nst = Cin // 8
         pro, loop, epi = t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2]
         print(f"[ts] {tag} B={B}: workgroups {nblk}, stages {nst}; cycles mean over waves (median): prologue {pro.mean():.0f} ({pro.median():.0f})  K loop {loop.mean():.0f} "
               f"= {loop.mean() / nst:.0f} per stage (ideal 4608: 36 MFMAs x 64 cycles x 2 waves per SIMD)  epilogue {epi.mean():.0f} ({epi.median():.0f})")
         print("     per wave, K loop per stage: " + " ".join("%.0f" % (loop[:, w].mean() / nst) for w in range(8)) + "   epilogue: " + " ".join("%.0f" % epi[:, w].mean() for w in range(8)))
+        ok = (t[:, 0, 12] > 0) & (t[:, 0, 4] > 0)      # persistent form: the workgroup's block 1 and the prologue of block 2 (needs >= 3 blocks per workgroup)
+        if int(ok.sum()) > 0:
+            seg = [("K loop", 5, 4), ("barrier", 6, 5), ("output transform -> LDS", 7, 6), ("next block's set-up + loads issued", 8, 7), ("barrier", 9, 8), ("stores", 13, 9),
+                   ("barrier + raw stages -> LDS + barrier", 11, 13), ("transform(0) + barrier + first fragments + clear", 12, 11)]
+            for w in (0, 7):
+                u = t[ok][:, w, :]
+                print(f"     persistent block timeline, wave {w} ({int(ok.sum())} workgroups; medians): " + "; ".join(f"{n} {float((u[:, i1] - u[:, i0]).median()):.0f}" for n, i1, i0 in seg)
+                      + f"; block 1 K-loop entry -> block 2 K-loop entry {float((u[:, 12] - u[:, 4]).median()):.0f}")
         wg = (t[:, :, 3].max(dim=1).values - t[:, :, 0].min(dim=1).values)
         print(f"     workgroup entry -> exit {wg.mean():.0f}; sum over workgroups / 256 CUs = {wg.sum() / 256:.0f}; first entry -> last exit {float(t[:, :, 3].max() - t[:, :, 0].min()):.0f}")
         continue
