@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
         const bool more = chunk + 1 < nchunks;
+        const int cnext = more ? chunk + 1 : chunk;
         if (more) load_halo(chunk + 1);                    // lands during this chunk's MFMAs
         bf16x8 E[2][NE];
         auto read_e = [&](int g, int buf) {                // fragments of group g = (tap column, k-step)
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
                 __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                // ... then the MFMAs of this tap row
                 const int nq = ql + R;                                             // refill the slot just consumed
                 if (nq < FPC) load_w(chunk, nq, slot);
-                else if (more) load_w(chunk + 1, nq - FPC, slot);
+                else load_w(cnext, nq - FPC, slot);        // (last chunk: a harmless re-load of its own first fragments - unconditional, so that no
+                                                           //  uniform branch sits between the MFMAs: twelve per chunk in the 3 x 3 form until round 6)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
