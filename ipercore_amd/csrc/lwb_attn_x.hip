@@ -69,7 +69,7 @@ template <> struct AttnXTraits<__bf16> {
 // workgroups per frame and a workgroup's chain of passes is what the launch waits for.  Both forms leave the SAME statistics record,
 // bit for bit: the per-lane sums run over the tile's passes in pass order in either (PW = 4 replays that order through LDS), so a frame
 // does not depend on which form its batch size selected.
-template <typename ST, int LPP, bool STATS, int NSU, int PW, int OCC>
+template <typename ST, int LPP, bool STATS, int NSU, int PW, int OCC, bool PIPE = false>
 __global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_kernel(const ST* __restrict__ x, const ST* __restrict__ Kq,
                                                                  const float* __restrict__ kappa, const ST* __restrict__ Vs,
                                                                  const float* __restrict__ bv, const float* __restrict__ T,
@@ -166,7 +166,161 @@ __global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_ker
         for (int k = 0; k < CPL; ++k) s1[k] = s2[k] = 0.f;
     }
     int nlive = 0;
+    auto stats_add = [&](const float (&xv)[CPL]) {
+        ++nlive;
+        if (PW == 1) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const float d = xv[k] - shift[k];
+                s1[k] += d;
+                s2[k] = __builtin_fmaf(d, d, s2[k]);
+            }
+        }
+    };
+    // grid_sample, align_corners=False: pixel = ((g + 1) * size - 1) / 2; the four bilinear weights and the top-left tap (clamped before the int
+    // conversion so wild flows cannot overflow; out-of-range taps read zeros)
+    auto taps_of = [&](const float2 t, float (&wt)[4], int& tx0, int& ty0) {
+        const float ix = ((t.x + 1.f) * (float)w - 1.f) * 0.5f, iy = ((t.y + 1.f) * (float)h - 1.f) * 0.5f;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+        tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
+        ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+        wt[0] = wy0 * wx0; wt[1] = wy0 * wx1; wt[2] = wy1 * wx0; wt[3] = wy1 * wx1;
+    };
+    // one source's logit / value folded into the running softmax of a pixel (online form, the sources in order)
+    auto fold = [&](const float (&ka)[CPL], const float (&va)[CPL], float kap, const float (&xv)[CPL], float& mrun, float& lrun, float (&o)[CPL]) {
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) dot = __builtin_fmaf(ka[k], xv[k], dot);
+#pragma unroll
+        for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const float logit = (dot + kap) * inv_sqrt_c;
+        const float mnew = fmaxf(mrun, logit);
+        const float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first source
+        const float pr = expf(logit - mnew);
+        lrun = __builtin_fmaf(lrun, corr, pr);
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) o[k] = __builtin_fmaf(o[k], corr, pr * va[k]);
+        mrun = mnew;
+    };
+    auto finish = [&](long gp, float lrun, const float (&o)[CPL]) {
+        const float invl = 1.f / lrun;
+        float r[CPL];
+        if (!BV_REG) {
+#pragma unroll
+            for (int k = 0; k < CPL; k += 4) {
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(bv + CPL * cl + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bvr[k + j] = b4[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) r[k] = __builtin_fmaf(o[k], invl, bvr[k]);
+        *reinterpret_cast<uintx4*>(out + gp * C + CPL * cl) = TR::pack(r);
+    };
 
+    if constexpr (PIPE) {
+        // Body tiles in TWO passes at a time (round 6; fp32 C = 256, where the tile's 64 KB of x rows hold the CU to two workgroups = two waves per SIMD
+        // and the registers of the other six are free): the sixteen gathers of pass p + 1 are REQUESTED before pass p is folded, so a wave's chain is
+        // no longer (flow -> gathers -> softmax) x 16 one after the other.  The loads of a pass are unconditional (taps outside the image / pixels
+        // outside the tile: out-of-range offsets, zero fill) so that the compiler's vmcnt counts stay exact; a tile WITHOUT any in-image tap (88 % of
+        // them) takes the branch below instead: x in, bv out, statistics - the values the general path computes for it (every logit 0, every value 0).
+        static_assert(NSU == 2 && PW == 1 && (NIT % 2) == 0, "the pipelined form is the ns = 2 frame-batch form");
+        bool mine = false;
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            int yc, xc;
+            const bool live = pixel_of(it, yc, xc);
+            const int ptile = it * PPP + wq * PPW + pg;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float2 t = Tl[s * 64 + ptile];
+                float wt[4];
+                int tx0, ty0;
+                taps_of(t, wt, tx0, ty0);
+                mine |= live && tx0 >= -1 && tx0 < w && ty0 >= -1 && ty0 < h;
+            }
+        }
+        if (__syncthreads_or(mine ? 1 : 0) == 0) {
+#pragma unroll 1
+            for (int it = 0; it < NIT; ++it) {
+                int yc, xc;
+                const bool live = pixel_of(it, yc, xc);
+                float xv[CPL];
+                TR::unpack(x_row(it), xv);
+                if (live) {
+                    if (STATS) stats_add(xv);
+                    float o[CPL];
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) o[k] = 0.f;
+                    finish(((long)b * h + yc) * w + xc, 2.f, o);
+                }
+            }
+        } else {
+            struct Taps { uintx4 kr[2][4], vr[2][4]; float ar[2][4], wt[2][4]; };
+            auto issue = [&](int pass, Taps& g) {
+                int yc, xc;
+                const bool live = pixel_of(pass, yc, xc);
+                const int ptile = pass * PPP + wq * PPW + pg;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    int tx0, ty0;
+                    taps_of(Tl[s * 64 + ptile], g.wt[s], tx0, ty0);
+                    const unsigned pbase = (unsigned)(src_batched ? b * ns + s : s) * (unsigned)hw;
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        const int tyy = ty0 + (tp >> 1), txx = tx0 + (tp & 1);
+                        const bool ok = live && tyy >= 0 && tyy < h && txx >= 0 && txx < w;
+                        const unsigned pix = pbase + (unsigned)(tyy * w + txx);
+                        const unsigned voff = ok ? pix * ROWB + (unsigned)(CPL * cl) * (unsigned)sizeof(ST) : 0xC0000000u;
+                        g.kr[s][tp] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)voff, 0, 0));
+                        g.vr[s][tp] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voff, 0, 0));
+                        g.ar[s][tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, ok ? (int)(pix * 4u) : (int)0xC0000000u, 0, 0));
+                    }
+                }
+            };
+            auto consume = [&](int pass, const Taps& g) {
+                int yc, xc;
+                const bool live = pixel_of(pass, yc, xc);
+                float xv[CPL];
+                TR::unpack(x_row(pass), xv);
+                if (STATS && live) stats_add(xv);
+                float mrun = -INFINITY, lrun = 0.f;
+                float o[CPL];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) o[k] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float ka[CPL], va[CPL], kap = 0.f;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) ka[k] = va[k] = 0.f;
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        float k8[CPL], v8[CPL];
+                        TR::unpack(g.kr[s][tp], k8);
+                        TR::unpack(g.vr[s][tp], v8);
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k) {
+                            ka[k] = __builtin_fmaf(k8[k], g.wt[s][tp], ka[k]);
+                            va[k] = __builtin_fmaf(v8[k], g.wt[s][tp], va[k]);
+                        }
+                        kap = __builtin_fmaf(g.ar[s][tp], g.wt[s][tp], kap);
+                    }
+                    fold(ka, va, kap, xv, mrun, lrun, o);
+                }
+                if (live) finish(((long)b * h + yc) * w + xc, lrun, o);
+            };
+            Taps g0, g1;
+            issue(0, g0);
+#pragma unroll 1
+            for (int it = 0; it < NIT; it += 2) {
+                issue(it + 1, g1);
+                consume(it, g0);
+                issue(it + 2 < NIT ? it + 2 : it + 1, g0);        // (past the end: a harmless re-request of the last pass - no branch, exact vmcnt counts)
+                consume(it + 1, g1);
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int it = 0; it < NIT; ++it) {
         const int pass = it * PW + pl;
@@ -176,29 +330,16 @@ __global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_ker
         const int ptile = pass * PPP + wq * PPW + pg;                             // this lane's pixel of the tile
         float xv[CPL];
         TR::unpack(x_row(pass), xv);
-        if (STATS && live) {
-            ++nlive;
-            if (PW == 1) {
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const float d = xv[k] - shift[k];
-                    s1[k] += d;
-                    s2[k] = __builtin_fmaf(d, d, s2[k]);
-                }
-            }
-        }
+        if (STATS && live) stats_add(xv);
         float mrun = -INFINITY, lrun = 0.f;
         float o[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = 0.f;
 
         auto source = [&](int s, const float2 t) {
-            // grid_sample, align_corners=False: pixel = ((g + 1) * size - 1) / 2
-            const float ix = ((t.x + 1.f) * (float)w - 1.f) * 0.5f, iy = ((t.y + 1.f) * (float)h - 1.f) * 0.5f;
-            const float fx0 = floorf(ix), fy0 = floorf(iy);
-            const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
-            // clamp before the int conversion so wild flows cannot overflow; out-of-range taps read zeros
-            const int tx0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f), ty0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+            float wt[4];
+            int tx0, ty0;
+            taps_of(t, wt, tx0, ty0);
             const bool any_tap = live && tx0 >= -1 && tx0 < w && ty0 >= -1 && ty0 < h;
             float ka[CPL], va[CPL], kap = 0.f;
 #pragma unroll
@@ -220,31 +361,18 @@ __global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_ker
                 }
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) {
-                    const float wt = ((tp >> 1) ? wy1 : wy0) * ((tp & 1) ? wx1 : wx0);
                     float k8[CPL], v8[CPL];
                     TR::unpack(kr[tp], k8);
                     TR::unpack(vr[tp], v8);
 #pragma unroll
                     for (int k = 0; k < CPL; ++k) {
-                        ka[k] = __builtin_fmaf(k8[k], wt, ka[k]);
-                        va[k] = __builtin_fmaf(v8[k], wt, va[k]);
+                        ka[k] = __builtin_fmaf(k8[k], wt[tp], ka[k]);
+                        va[k] = __builtin_fmaf(v8[k], wt[tp], va[k]);
                     }
-                    kap = __builtin_fmaf(ar[tp], wt, kap);
+                    kap = __builtin_fmaf(ar[tp], wt[tp], kap);
                 }
             }
-            float dot = 0.f;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) dot = __builtin_fmaf(ka[k], xv[k], dot);
-#pragma unroll
-            for (int off = LPP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-            const float logit = (dot + kap) * inv_sqrt_c;
-            const float mnew = fmaxf(mrun, logit);
-            const float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first source
-            const float pr = expf(logit - mnew);
-            lrun = __builtin_fmaf(lrun, corr, pr);
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) o[k] = __builtin_fmaf(o[k], corr, pr * va[k]);
-            mrun = mnew;
+            fold(ka, va, kap, xv, mrun, lrun, o);
         };
         if (NSU > 0) {
 #pragma unroll
@@ -253,21 +381,8 @@ __global__ __launch_bounds__(256 * PW, PW == 1 ? OCC : 1) void lwg_lwb_attnx_ker
 #pragma unroll 1
             for (int s = 0; s < ns; ++s) source(s, Tl[s * 64 + ptile]);
         }
-        if (live) {
-            const float invl = 1.f / lrun;
-            float r[CPL];
-            if (!BV_REG) {
-#pragma unroll
-                for (int k = 0; k < CPL; k += 4) {
-                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(bv + CPL * cl + k);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bvr[k + j] = b4[j];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) r[k] = __builtin_fmaf(o[k], invl, bvr[k]);
-            *reinterpret_cast<uintx4*>(out + gp * C + CPL * cl) = TR::pack(r);
-        }
+        if (live) finish(gp, lrun, o);
+    }
     }
 
     if (STATS) {
@@ -374,7 +489,9 @@ static int lwg_attnx_launch(const ST* x, const ST* Kq, const float* kappa, const
     const bool wide = LWG_ATTNX_WIDE && tiles * B < 512 && npass >= 4;
 #define LWG_ATTNX_GO(LPP, ST_, NSU, PW)                                                                                              \
     {                                                                                                                                \
-        auto kern = lwg_lwb_attnx_kernel<ST, LPP, ST_, NSU, PW, (CPL == 4 ? LWG_ATTNX_OCC : LWG_ATTNX_OCC16)>;                         \
+        /* fp32 C = 256, ns = 2, frame batches: the pipelined body form (two workgroups per CU by LDS: 256 registers per wave) */     \
+        constexpr bool pipe = LWG_ATTNX_PIPE && CPL == 4 && (LPP) == 64 && (NSU) == 2 && (PW) == 1;                                  \
+        auto kern = lwg_lwb_attnx_kernel<ST, LPP, ST_, NSU, PW, (pipe ? 2 : CPL == 4 ? LWG_ATTNX_OCC : LWG_ATTNX_OCC16), pipe>;        \
         const size_t lds = (size_t)((LPP) / 4) * 4096 + (size_t)ns * 512;        /* x rows of the tile + its flows */                 \
         static unsigned long long lds_ok = 0;                                                                                        \
         if (lds > 65536) {                                                                                                           \

@@ -62,6 +62,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef LWG_ATTNX_NSU2
 #define LWG_ATTNX_NSU2 1           // lwb_attn_x.hip: ns == 2 launches on the form with prefetched flows and an unrolled source loop (0: the generic form)
 #endif
+#ifndef LWG_ATTNX_PIPE
+#define LWG_ATTNX_PIPE 0           // lwb_attn_x.hip: 1 = fp32 C = 256 frame batches on the form with two passes of gathers in flight + a tile-level background
+                                   // shortcut (round 6 lab: bit-identical, 125 vs 114 us per 32 x 64^2 x 256 launch - SLOWER: a body tile is not a per-wave latency
+                                   // chain; profiles/r06_o_attnlab_pipe.txt)
+#endif
 #ifndef LWG_ATTNX_WIDE
 #define LWG_ATTNX_WIDE 1            // lwb_attn_x.hip: launches of a few frames run sixteen waves (four passes at a time) per tile (0: always four)
 #endif
