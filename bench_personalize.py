@@ -276,6 +276,7 @@ def main(argv=None):
                     help="split: forward / data-gradient convs on the bf16x6 kernel (fp32-level accuracy), weight gradients fp32 MFMA; winograd: the 3x3 / "
                          "stride 1 forward and data-gradient convs as F(2x2,3x3) Winograd convolutions (fp32 MFMA), weight gradients direct")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager launches instead of the captured step")
+    ap.add_argument("--two-pass-loss", action="store_true", help="lab: the frozen loss networks in two passes (target under no_grad) instead of one [fake | target] batch")
     ap.add_argument("--no-panel-cache", dest="panel_cache", action="store_false", help="one pack launch per weight panel (round-1 behaviour)")
     ap.add_argument("--no-branch-streams", dest="branch_streams", action="store_false",
                     help="the background network and the source decoder on the main stream (round-2 default: a second stream)")
@@ -294,6 +295,9 @@ def main(argv=None):
                     help="cpu: plumbing dry run for the CPU test-suite ONLY (tests/test_bench_launch.py installs the emulated C ABI around "
                          "main(); without it every op raises on CPU tensors - there is no CPU product path)")
     args = ap.parse_args(argv)
+    if args.two_pass_loss:
+        from ipercore_amd import trainers as _tr
+        _tr.LOSS_NETS_ONE_PASS = False
     self_launch_if_needed(sys.argv[1:] if argv is None else argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

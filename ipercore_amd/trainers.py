@@ -477,6 +477,11 @@ class VGG19Features(nn.Module):
         return outs
 
 
+# The frozen loss networks (VGG19, Sphere20a) see [fake | target] as ONE batch (True: half the launches, but the data gradients then run over the
+# target rows too - zeros) or as two passes with the target under no_grad (False).  Measured in bench_personalize.py --two-pass-loss.
+LOSS_NETS_ONE_PASS = True
+
+
 class VGGLoss(nn.Module):
     """criterions/vggloss.py:261-292: sum_i w_i * L1(vgg_i(x), vgg_i(y).detach()), inputs resized to 224x224 (bilinear,
     align_corners=True) as the trainers do (lwg_trainer.py:153-155, resize=True)."""
@@ -493,6 +498,11 @@ class VGGLoss(nn.Module):
         # one pass over [x | y] (the network is frozen and has no batch statistics: the same features as two passes, half the launches - a
         # one-sample launch leaves most of the chip idle); the target half is cut out of the graph
         n = x.shape[0]
+        if not LOSS_NETS_ONE_PASS:          # two passes: the target half under no_grad (no activations saved, no data gradients over its rows)
+            fx = self.vgg(x)
+            with torch.no_grad():
+                fy = self.vgg(y)
+            return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, fx, fy))
         f = self.vgg(torch.cat([x, y.detach()], dim=0))
         return sum(w * F.l1_loss(a[:n], a[n:].detach()) for w, a in zip(self.WEIGHTS, f))
 
@@ -607,8 +617,13 @@ class FaceLoss(nn.Module):
         else:
             h2 = F.interpolate(imgs2, size=(self.HEIGHT, self.WIDTH), mode="bilinear", align_corners=True)
         n = h1.shape[0]
-        f = self.net(torch.cat([h1, h2.detach()], dim=0))          # one pass over [fake | target] heads (see VGGLoss.forward)
-        f1, f2 = [a[:n] for a in f], [a[n:].detach() for a in f]
+        if not LOSS_NETS_ONE_PASS:
+            f1 = self.net(h1)
+            with torch.no_grad():
+                f2 = self.net(h2)
+        else:
+            f = self.net(torch.cat([h1, h2.detach()], dim=0))      # one pass over [fake | target] heads (see VGGLoss.forward)
+            f1, f2 = [a[:n] for a in f], [a[n:].detach() for a in f]
         if valid is None:
             return sum(w * F.l1_loss(a, b) for w, a, b in zip(self.WEIGHTS, f1, f2))
         nv = valid.sum().clamp_min(1.0)                      # no valid head at all: every term is zero (the reference returns 0)
