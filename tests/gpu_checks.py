@@ -2045,8 +2045,9 @@ def _generator_training_grads(S, nf, nres, bgf, real_flows=False, ref64=False, p
         #     the bound the small case meets outright);
         #   * element-wise (one flipped kink lands on a few weight elements: a heavy-tailed quantity) the same 3x bound holds for >= 90 % of the
         #     parameters and 6e-2 for all of them - measured in round 5: 211 of 221 within 3x; the ten above it are all in the background network's
-        #     residual / output layers (7e-3 .. 4e-2 against 1.3e-3 .. 2.3e-3 for torch-fp32, their L2 errors 2.2 - 2.5x torch's): recorded as an
-        #     open item in DESIGN.md 4, not hidden by the bound;
+        #     residual / output layers (7e-3 .. 4e-2 against 1.3e-3 .. 2.3e-3 for torch-fp32, their L2 errors 2.2 - 2.5x torch's).  Bisected in
+        #     round 6 (tools/diag_bg_grads.py): no kernel carries them - the fp64 oracle with its input perturbed by 1e-7 shows the same
+        #     element-wise outliers (2.1e-2), every weight-gradient kernel alone is 7e-8 .. 4e-7 from fp64, torch-ROCm fp32 reaches 1.4e-2;
         #   * plus the global L2 bound (a wiring error moves that to O(1)).
         m["torch_fp32_autograd_s"] = t_fp32
         over, over_l2, ratio_worst, t32_worst = [], [], (0.0, None), 0.0
