@@ -49,9 +49,11 @@ __device__ __forceinline__ float lwg_bf16_hi(unsigned u) { return __builtin_bit_
 // pixel (ty0 + r / 16, tx0 + r % 16) and rows outside the image are dead.
 // EA: the activation as a compile-time constant (>= 0) or a.act at run time (-1) - lwg_bf16_epilogue below resolves it once per workgroup
 // (lwg_common.h, LwgActC: a runtime code inside the innermost loops costs a uniform branch ladder per group of outputs).
+// pre (halo-tile kernels only; nullptr: read from global memory here): the workgroup's epilogue operands parked in LDS by the kernel's prologue -
+// [0, BN): bias of columns n_base ..; SPADE: [BN, BN + BN/2) mean, [BN + BN/2, 2 BN) rstd of image tb, channels n_base / 2 ..
 template <int TM, int TN, int EPI, int SPATIAL, int EA>
 __device__ __forceinline__ void lwg_bf16_epilogue_a(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
-                                                    int lane, int tb, int ty0, int tx0) {
+                                                    int lane, int tb, int ty0, int tx0, const float* pre = nullptr, int pre_bn = 0) {
     const int khalf = lane >> 5;
     const int HW = a.OH * a.OW;
     // ---- epilogue: D^T tiles -> bf16 NHWC.  acc[i][j][4*g + c] = pixel (lane & 31) of row tile i, channel 8*g + 4*khalf + c of
@@ -95,6 +97,114 @@ __device__ __forceinline__ void lwg_bf16_epilogue_a(const LwgConvArgs& a, floatx
             *reinterpret_cast<uintx4*>(p16 + 16 * khalf + 8) = st[1];
         }
     };
+    if constexpr (TN == 1 && SPATIAL != 0) {
+        // The halo-tile kernels (one 32-column tile per wave, a workgroup inside ONE image): EVERY load of the epilogue - the bias quads (once, not once
+        // per row tile), the residual / xn rows of all TM row tiles, SPADE's statistics - is issued BEFORE the first store.  The memory counter retires
+        // in order: with the loads of row tile i + 1 behind the stores of row tile i (rounds 2-5) every row tile waited for the previous one's stores
+        // to be acknowledged AND for an L2 round trip of its own - the tile time that did not scale with K.
+        bool live[TM];
+        size_t opix[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * TM * 32 + i * 32 + (lane & 31);
+            const int oy = ty0 + (SPATIAL == 2 ? wm * 2 * TM + i + TM * ((lane >> 4) & 1) : (r >> 4)), ox = tx0 + (r & 15);
+            live[i] = oy < a.OH && ox < a.OW;
+            opix[i] = live[i] ? ((size_t)tb * a.YH + (oy * a.omul + a.ooy)) * a.YW + (ox * a.omul + a.oox) : 0;
+        }
+        const int ncol = n_base + wn * 32;
+        if constexpr (EPI == LWG_EPI_SPADE) {
+            const int chb = ncol >> 1;                              // first of the wave's 16 output channels (gamma | beta interleaved in blocks of 16)
+            uintx2 xv[TM][2];
+            floatx4 mu[2], rs[2], bg4[2], bb4[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int ch = chb + 8 * g + 4 * khalf;
+                if (pre) {
+                    mu[g] = *reinterpret_cast<const floatx4*>(pre + pre_bn + wn * 16 + 8 * g + 4 * khalf);
+                    rs[g] = *reinterpret_cast<const floatx4*>(pre + pre_bn + (pre_bn >> 1) + wn * 16 + 8 * g + 4 * khalf);
+                    bg4[g] = *reinterpret_cast<const floatx4*>(pre + wn * 32 + 8 * g + 4 * khalf);
+                    bb4[g] = *reinterpret_cast<const floatx4*>(pre + wn * 32 + 16 + 8 * g + 4 * khalf);
+                } else {
+                    mu[g] = *reinterpret_cast<const floatx4*>(a.mean + (size_t)tb * a.YC + ch);
+                    rs[g] = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)tb * a.YC + ch);
+                    bg4[g] = *reinterpret_cast<const floatx4*>(a.bias + ncol + 8 * g + 4 * khalf);
+                    bb4[g] = *reinterpret_cast<const floatx4*>(a.bias + ncol + 16 + 8 * g + 4 * khalf);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                xv[i][0] = xv[i][1] = uintx2{0u, 0u};
+                if (live[i]) {
+                    xv[i][0] = *reinterpret_cast<const uintx2*>(xnb + opix[i] * a.YC + chb + 4 * khalf);
+                    xv[i][1] = *reinterpret_cast<const uintx2*>(xnb + opix[i] * a.YC + chb + 8 + 4 * khalf);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float xf[4] = {lwg_bf16_lo(xv[i][g][0]), lwg_bf16_hi(xv[i][g][0]), lwg_bf16_lo(xv[i][g][1]), lwg_bf16_hi(xv[i][g][1])};
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float gm = acc[i][0][4 * g + c] + bg4[g][c];
+                        const float bt = acc[i][0][4 * (g + 2) + c] + bb4[g][c];
+                        o[c] = lwg_act_c<EA>((xf[c] - mu[g][c]) * rs[g][c] * (1.f + gm) + bt, a.act);
+                    }
+                    if (live[i]) {
+                        uintx2 pk;
+                        pk[0] = lwg_pack_bf16x2(o[0], o[1]);
+                        pk[1] = lwg_pack_bf16x2(o[2], o[3]);
+                        *reinterpret_cast<uintx2*>(yb + opix[i] * a.YC + chb + 8 * g + 4 * khalf) = pk;
+                    }
+                }
+        } else {
+            floatx4 b4[4];
+            if (pre) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const floatx4*>(pre + wn * 32 + 8 * g + 4 * khalf);
+            } else if (a.bias) {                                    // (ONE branch around the four loads: four quads in flight, one wait)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const floatx4*>(a.bias + ncol + 8 * g + 4 * khalf);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b4[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            uintx4 L[TM][2];
+            if constexpr (EPI == LWG_EPI_RESIDUAL) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    L[i][0] = L[i][1] = uintx4{0u, 0u, 0u, 0u};
+                    if (live[i]) {
+                        const __bf16* p16 = resb + opix[i] * a.YC + a.ycoff + ncol;
+                        L[i][0] = *reinterpret_cast<const uintx4*>(p16 + 16 * khalf);
+                        L[i][1] = *reinterpret_cast<const uintx4*>(p16 + 16 * khalf + 8);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float r4[4][4], o[4][4];
+                if constexpr (EPI == LWG_EPI_RESIDUAL) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto sres = __builtin_amdgcn_permlane32_swap(L[i][h][d], L[i][h][2 + d], false, false);
+                            r4[h][2 * d] = lwg_bf16_lo(sres[0]); r4[h][2 * d + 1] = lwg_bf16_hi(sres[0]);
+                            r4[2 + h][2 * d] = lwg_bf16_lo(sres[1]); r4[2 + h][2 * d + 1] = lwg_bf16_hi(sres[1]);
+                        }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        o[g][c] = lwg_act_c<EA>(acc[i][0][4 * g + c] + b4[g][c] + (EPI == LWG_EPI_RESIDUAL ? r4[g][c] : 0.f), a.act);
+                store_dt(yb + opix[i] * a.YC + a.ycoff + ncol, live[i], o);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         bool live;
@@ -196,10 +306,10 @@ __device__ __forceinline__ void lwg_bf16_epilogue_a(const LwgConvArgs& a, floatx
 
 template <int TM, int TN, int EPI, int SPATIAL = 0>
 __device__ __forceinline__ void lwg_bf16_epilogue(const LwgConvArgs& a, floatx16 (&acc)[TM][TN], int m_base, int n_base, int wm, int wn,
-                                                  int lane, int tb = 0, int ty0 = 0, int tx0 = 0) {
-    if (a.act == LWG_ACT_RELU) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_RELU>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
-    else if (a.act == LWG_ACT_NONE) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_NONE>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
-    else lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, -1>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0);
+                                                  int lane, int tb = 0, int ty0 = 0, int tx0 = 0, const float* pre = nullptr, int pre_bn = 0) {
+    if (a.act == LWG_ACT_RELU) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_RELU>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0, pre, pre_bn);
+    else if (a.act == LWG_ACT_NONE) lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, LWG_ACT_NONE>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0, pre, pre_bn);
+    else lwg_bf16_epilogue_a<TM, TN, EPI, SPATIAL, -1>(a, acc, m_base, n_base, wm, wn, lane, tb, ty0, tx0, pre, pre_bn);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool DMA_A>
@@ -512,6 +622,14 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
 #pragma unroll
     for (int q = 0; q < R; ++q)
         if (q < nfrags) load_w(0, q, q);
+    // the epilogue's operands (bias; SPADE: mean / rstd of this image) parked in LDS behind the halo buffers: read from global memory in the epilogue
+    // they were an L2 round trip between the last MFMA and the first store of every tile
+    float* const pre = reinterpret_cast<float*>(smem_r2 + 2 * LWG_HALO_BYTES);
+    if (tid < BN) pre[tid] = a.bias ? a.bias[n_base + tid] : 0.f;
+    if (EPI == LWG_EPI_SPADE && tid < BN) {
+        const int c = (n_base >> 1) + (tid & (BN / 2 - 1));
+        pre[BN + tid] = tid < BN / 2 ? a.mean[(size_t)tb * a.YC + c] : a.rstd[(size_t)tb * a.YC + c];
+    }
     store_halo(0);
     __syncthreads();
 
@@ -554,12 +672,12 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
             __syncthreads();
         }
     }
-    lwg_bf16_epilogue<TM, 1, EPI, 2>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0);
+    lwg_bf16_epilogue<TM, 1, EPI, 2>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0, pre, BN);
 }
 
 template <int NDY, int NDX, int EPI, int WAVES_M>
 static hipError_t launch_cfg_bf16_hr2(const LwgConvArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES;
+    constexpr size_t lds = (size_t)2 * LWG_HALO_BYTES + 2 * 128 * sizeof(float);   // two halo buffers + the parked epilogue operands (2 BN floats)
     auto kern = lwg_conv_bf16_hr2_kernel<NDY, NDX, EPI, WAVES_M>;
     const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 15) / 16) * (a.N / (128 / WAVES_M));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, a);
