@@ -523,6 +523,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
 //     ascending NDY x NDX grid (the host sorts them).
 // The two earlier forms (halo tile with LDS-DMA weights; one fragment per MFMA) are in the history of this file, DESIGN.md 3.11 has
 // their measurements.
+// lab instrumentation (compiled out of the product): tools/hr2ts.py on a -DLWG_HR2_TS variant library - wave 0 of every workgroup stamps kernel entry, the
+// first barrier passed, K-loop exit and the end of its epilogue into args->res (LWG_EPI_NONE launches; eight 64-bit slots per workgroup)
+#ifdef LWG_HR2_TS
+#define HTS(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<void*>(static_cast<const void*>(a.res)))[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HTS(i) do { } while (0)
+#endif
 #define LWG_HALO_W 18
 #define LWG_HALO_PIX 180
 #define LWG_HALO_PIECES 23                 // 8 pixels per DMA piece; the 23rd is half used
@@ -541,6 +548,7 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
 
     extern __shared__ __attribute__((aligned(16))) char smem_r2[];
     char* Ah = smem_r2;                                      // [2][LWG_HALO_BYTES]
+    HTS(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -632,6 +640,7 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
     }
     store_halo(0);
     __syncthreads();
+    HTS(1);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const char* Acur = Ah + (chunk & 1) * LWG_HALO_BYTES;
@@ -672,7 +681,9 @@ __global__ __launch_bounds__(256, (WAVES_M == 1 || NDY * NDX == 9) ? 2 : 3) void
             __syncthreads();
         }
     }
+    HTS(2);
     lwg_bf16_epilogue<TM, 1, EPI, 2>(a, acc, 0, n_base, wm, wn, lane, tb, y0, x0, pre, BN);
+    HTS(3);
 }
 
 template <int NDY, int NDX, int EPI, int WAVES_M>
