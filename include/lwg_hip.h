@@ -26,9 +26,9 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 8: lwg_conv2d_winograd_plan, lwg_up4_head_compose_bf16; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 9: lwg_conv2d_winograd4_f32, lwg_winograd4_panel_f32 (F(4x4, 3x3); round 6); 8: lwg_conv2d_winograd_plan, lwg_up4_head_compose_bf16; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 8
+#define LWG_ABI_VERSION 9
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -136,6 +136,16 @@ typedef struct LwgWinoDesc {
     int tap9[9];
 } LwgWinoDesc;
 int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, int total_blocks, lwg_stream_t stream);
+/* The same layers as a fused F(4x4, 3x3) Winograd convolution (csrc/conv_winograd4.hip; round 6): 36 multiplies per 4 x 4 outputs = 2.25 per output
+ * (F(2x2, 3x3): 4, direct: 9).  lwg_conv2d_winograd_f32's launch description and contract (one or two inputs, LWG_EPI_NONE / _RESIDUAL / _SPADE, any
+ * activation incl. LWG_ACTIVATION_RELU_MASK with LWG_EPI_RESIDUAL, any batch size in one launch) EXCEPT args->w = the fragment panel
+ * Upk[4][Cin/8][4][2][N][12] (192 Cin N bytes): element (q, s, kk, kh, n, j) of input channel c = 8 s + 2 kk + kh (concatenated order) and output column n =
+ * (G w G^T)[xi][nu] with (xi, nu) = (q, j) for j < 6, (4 + q / 2, 3 (q % 2) + j - 6) for j = 6..8 (j = 9..11: zero padding), G = [[1/4,0,0],[-1/6,-1/6,-1/6],
+ * [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] (points 0, +-1, +-2, inf).  fp32-grade results (relative L2 error against fp64 ~15x the direct
+ * kernel's, 3e-6), neither the direct nor the F(2x2, 3x3) kernel's bits; a frame's result does not depend on the batch it is launched in. */
+int lwg_conv2d_winograd4_f32(const LwgConvArgs* args, lwg_stream_t stream);
+/* That panel from the fp32 GEMM panel of the same convolution (arguments as lwg_winograd_panel_f32): U = G w G^T in fp64, rounded once. */
+int lwg_winograd4_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream);
 /* The same convolution for the 3x3 (9 taps) and 2x2 (4 taps, transposed-conv parity) stride-1 launches, as the
  * halo-tile kernel with register-streamed weights: args->w = the bf16 panel [ntaps*Cin/64][4][N][16] - element
  * [step][ks][n][e] = weight of GEMM column n at k = step*64 + ks*16 + e (k order as above) - and, for LWG_EPI_SPADE, columns

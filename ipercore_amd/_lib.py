@@ -65,6 +65,8 @@ _SIGS = {
                                        ctypes.POINTER(c_i)]),
     "lwg_winograd_panel_f32": (c_i, [c_f, c_f, c_i, c_i, ctypes.POINTER(c_i), c_f]),
     "lwg_winograd_panels_f32": (c_i, [c_f, c_i, c_i, c_f]),
+    "lwg_conv2d_winograd4_f32": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
+    "lwg_winograd4_panel_f32": (c_i, [c_f, c_f, c_i, c_i, ctypes.POINTER(c_i), c_f]),
     "lwg_conv2d_nhwc_bf16_hr": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv2d_nhwc_c8_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
     "lwg_conv_transpose4_nhwc_bf16": (c_i, [ctypes.POINTER(LwgConvArgs), c_f]),
@@ -161,7 +163,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 8:
+        if handle.lwg_abi_version() != 9:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -1,0 +1,619 @@
+// Fused F(4x4, 3x3) Winograd form of the 3x3 / stride 1 / pad 1 fp32 convolution on v_mfma_f32_32x32x2_f32 (round 6; the sibling of conv_winograd.hip's
+// F(2x2, 3x3) kernel for the layers whose K loop is long enough to pay for the larger transforms - DESIGN.md 3.12d; attlwb_spade_resunet.py:14-25,62-93,316-357).
+//   y = act(bias + sum x * w [+ res]) computed as U = G w G^T (6 x 6 per channel pair; the fragment panel built by lwg_winograd4_panel_f32 below), V = B^T d B per
+//   6 x 6 input patch d (patches overlap by two pixels), M_{xi,nu} = V_{xi,nu} U_{xi,nu} - thirty-six GEMMs over Cin -, Y = A^T M A (4 x 4 outputs per patch):
+//   36 multiplies per 16 outputs = 2.25 per output instead of 9 (F(2x2, 3x3): 4).  Points 0, +-1, +-2, inf (Lavin & Gray):
+//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Workgroup: 512 threads = 8 waves; block = 8 x 4 patches (32 x 16 output pixels) x 64 output channels.  Wave w = (q = w % 4, channel tile ct = w / 4) owns NINE
+// products for the block's 32 patches x 32 channels (9 accumulator tiles of 32 x 32 = 144 VGPRs, rows = output channels - the transposed kernel's shape):
+// the whole row xi = q of the transformed patch (nu = 0..5) and three products of row 4 + q / 2 (nu = 3 (q % 2) .. + 2).  The nu half of A^T M A is then
+// register-local for rows 0..3 and half-local for rows 4, 5: 28 planes of (patch, channel) values cross LDS in the epilogue.
+// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the panel
+// Upk[4][Cin/8][4][2][N][12] (two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS, each one right behind the MFMA that
+// used its register for the previous k-pair.  The raw 34 x 18 x 8 halo goes global -> registers -> raw[s % 2] (channel-major planes, rows of 36 floats);
+// the 256 (patch, channel) transforms of the next stage are shared by the 512 threads: waves 0-3 form rows 0..2 of B^T d B, waves 4-7 rows 3..5 (72 vector
+// instructions per thread and stage), one barrier per stage in front of k-pair 3.
+// Rounding: relative L2 error against fp64 ~14-20x the direct fp32 convolution's (3e-6; tools/winograd_study.py --f43): fp32-grade, NOT the direct kernel's
+// and not the F(2x2, 3x3) kernel's bits.  A frame's result does not depend on the batch it is launched in (per-image work in a fixed order).
+#include <hip/hip_runtime.h>
+#include "lwg_common.h"
+#include "lwg_conv_args.h"
+
+#define W4_THREADS 512
+#define W4_PBX 8             // patches per block row: 32 output pixels
+#define W4_PBY 4             // patch rows per block: 16 output pixels
+#define W4_NB 64             // output channels per block
+#define W4_KS 8              // input channels per stage
+#define W4_HW 34             // halo pixels per row
+#define W4_HH 18             // halo rows
+#define W4_RS 36             // floats per halo row in LDS (16-byte aligned rows)
+#define W4_PLANE 652         // floats per channel plane: 18 x 36 + 4 (4 PLANE = 16 mod 32: the two channel quads of a pixel fall into different banks)
+#define W4_RAW (W4_KS * W4_PLANE)
+#define W4_VS (36 * W4_KS * 32)                  // [product 6 xi + nu][k][patch]
+#define W4_NEL (W4_HW * W4_HH * 2)               // (pixel, channel quad) elements of a stage's halo
+#define W4_NQ 3                                  // ... per thread (the third round: threads < W4_NEL - 1024 only)
+#define W4_DUMP_OFF (2 * W4_RAW + 2 * W4_VS)     // where the threads without a halo element store their zeros (dead LDS)
+#define W4_DUMP (W4_THREADS + 3 * W4_PLANE)
+#define W4_LOOP (W4_DUMP_OFF + W4_DUMP)
+#define W4_MSR 68                                // floats per (plane, patch) row of the epilogue's exchange buffer: 64 channels + 4
+#define W4_NPL 28                                // planes: rows 0..3 x 4 output columns, rows 4 / 5: 2 halves x 3 partial sums
+#define W4_MS (W4_NPL * 16 * W4_MSR)             // one pass = 16 patches
+#define W4_OOB 0xC0000000u
+#define W4SB() __builtin_amdgcn_sched_barrier(0)
+
+// lab instrumentation (compiled out of the product): tools/wino4lab.py --ts on a -DLWG_W4_TS variant library; wave 0 stamps into args->res (LWG_EPI_NONE)
+#ifdef LWG_W4_TS
+#define W4TS(i) do { if (tid == 0 && lab_bi == 1) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4TS(i) do { } while (0)
+#endif
+
+template <int V> struct W4Int { static constexpr int value = V; };
+
+__device__ __forceinline__ floatx4 w4_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// the 1-D input transform B^T (.) of six values
+__device__ __forceinline__ void w4_bt6(const float (&r)[6], float (&v)[6]) {
+    const float a = __builtin_fmaf(-4.f, r[2], r[4]), b = __builtin_fmaf(-4.f, r[1], r[3]);
+    const float c = r[4] - r[2], e = r[3] - r[1];
+    v[0] = __builtin_fmaf(-5.f, r[2], __builtin_fmaf(4.f, r[0], r[4]));
+    v[1] = a + b;
+    v[2] = a - b;
+    v[3] = __builtin_fmaf(2.f, e, c);
+    v[4] = __builtin_fmaf(-2.f, e, c);
+    v[5] = __builtin_fmaf(-5.f, r[3], __builtin_fmaf(4.f, r[1], r[5]));
+}
+
+template <int EPI, bool TWO>
+__global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const LwgConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* __restrict__ bias = a.bias;
+    const int H = a.H, W = a.W, Cin = a.C0 + a.C1, N = a.N;
+    float* __restrict__ y = a.y;
+    float* const raw0 = smem;                                // [2][RAW], then [2][VS]
+    float* const Ms = smem;                                  // the epilogue's exchange buffer (after the K loop)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bx = (W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (H + 4 * W4_PBY - 1) / (4 * W4_PBY);
+    // persistent workgroups (as conv_winograd.hip): min(blocks, CUs) workgroups walk the block ids blockIdx.x + k gridDim.x (id = column block * tiles + tile)
+    const int tiles = bx * by * a.B;
+    const int total = tiles * (N / W4_NB);
+    int blk = blockIdx.x;
+    const int nst = Cin / W4_KS;                             // even (host: Cin % 16 == 0)
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
+    const int q = wid & 3, ct = wid >> 2;                    // this wave's product set and 32-channel tile
+    const int half = wid >> 2;                               // ... and its half of the input transform (rows 3 half .. 3 half + 2 of B^T d B)
+    floatx16 acc[9];                                         // products 0..5: (xi = q, nu); 6..8: (xi = 4 + q / 2, nu = 3 (q % 2) + 0..2)
+    int b, x0, y0, n0;
+    __amdgpu_buffer_rsrc_t rx0, rx1;
+    unsigned voff0[W4_NQ], voff1[W4_NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
+    unsigned uvoff;                                          // this lane's column of the fragment panel
+    auto setup = [&](int id) {
+        const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
+        int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        b = __builtin_amdgcn_readfirstlane(t / (bx * by));
+        t -= b * bx * by;
+        x0 = (t % bx) * 4 * W4_PBX;
+        y0 = (t / bx) * 4 * W4_PBY;
+        n0 = cb * W4_NB;
+        rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
+        if constexpr (TWO) rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * H * W * a.C1), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < W4_NQ; ++k) {                    // padding pixels / threads without an element: an out-of-range offset (the hardware returns zeros)
+            const int i = tid + W4_THREADS * k;
+            const int pix = i >> 1, hq = i & 1, hy = pix / W4_HW, hx = pix - hy * W4_HW;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool in = i < W4_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            voff0[k] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * hq) * 4u : W4_OOB;
+            if constexpr (TWO) voff1[k] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * hq) * 4u : W4_OOB;
+        }
+        uvoff = (unsigned)((((lane >> 5) * N + n0 + ct * 32 + (lane & 31)) * 12) * 4);
+    };
+    setup(blk);
+    int wst[W4_NQ];                                          // the halo elements' LDS slot
+#pragma unroll
+    for (int k = 0; k < W4_NQ; ++k) {
+        const int i = tid + W4_THREADS * k;
+        const int pix = i >> 1, hq = i & 1, hy = pix / W4_HW, hx = pix - hy * W4_HW;
+        wst[k] = i < W4_NEL ? 4 * hq * W4_PLANE + hy * W4_RS + hx : W4_DUMP_OFF + tid;
+    }
+    floatx4 rreg[W4_NQ];
+    auto rld1 = [&](int st, int k) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
+        const int c = st * W4_KS;
+        if constexpr (!TWO) {
+            return w4_buf_load(rx0, voff0[k], (unsigned)c * 4u);
+        } else {
+            const bool first = c < a.C0;
+            const __amdgpu_buffer_rsrc_t r = first ? rx0 : rx1;
+            const unsigned v = first ? voff0[k] : voff1[k];
+            return w4_buf_load(r, v, (unsigned)(first ? c : c - a.C0) * 4u);
+        }
+    };
+    auto rst1 = [&](int buf, int k, floatx4 v) {
+        float* dst = raw0 + buf * W4_RAW + wst[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c * W4_PLANE] = v[c];
+    };
+    // weights: lane = (k-half lane / 32, channel lane % 32); element (q, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
+    floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 + padding]: loaded TWO k-pairs ahead
+    const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
+    const unsigned uq = (unsigned)q * (unsigned)nst * 4u * ukk;
+    auto uld1 = [&](int st, int kk, int j) -> floatx4 { return w4_buf_load(ru, uvoff + 16u * j, uq + (unsigned)(st * 4 + kk) * ukk); };
+    // the input transform's thread: patch tid % 32, channel (tid / 32) % 8, rows 3 half .. 3 half + 2
+    const int patch = tid & 31, tc = (tid >> 5) & 7;
+    const int pty = patch >> 3, ptx = patch & 7;
+    unsigned dbs = (unsigned)(tc * W4_PLANE + (4 * pty) * W4_RS + 4 * ptx) >> 2;      // its 6 x 6 input patch inside raw[0] (float index; 16-byte aligned)
+    asm volatile("" : "+v"(dbs));
+    dbs <<= 2;
+    unsigned vbs[2];                                         // its 18 transformed values inside Vs[u]
+    unsigned fbs[2];                                         // this lane's fragments: products 0..5 | 6..8, inside Vs[0]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        vbs[u] = (unsigned)(2 * W4_RAW + u * W4_VS + (18 * half) * W4_KS * 32 + tc * 32 + patch);
+        asm volatile("" : "+v"(vbs[u]));
+    }
+    fbs[0] = (unsigned)(2 * W4_RAW + (6 * q) * W4_KS * 32 + lane);
+    fbs[1] = (unsigned)(2 * W4_RAW + (6 * (4 + (q >> 1)) + 3 * (q & 1)) * W4_KS * 32 + lane);
+    asm volatile("" : "+v"(fbs[0]));
+    asm volatile("" : "+v"(fbs[1]));
+    float fb[9];                                             // the current k-pair's nine fragments (each refilled right behind its MFMA)
+    auto frag1 = [&](int buf, int kk, int j) -> float {
+        return smem[fbs[j < 6 ? 0 : 1] + buf * W4_VS + ((j < 6 ? j : j - 6) * W4_KS + 2 * kk) * 32];
+    };
+    auto rd6 = [&](int buf, int r, float (&d)[6]) {          // row r of this thread's patch in raw[buf]
+        const floatx4 v4 = *reinterpret_cast<const floatx4*>(smem + dbs + buf * W4_RAW + r * W4_RS);
+        const float2 v2 = *reinterpret_cast<const float2*>(smem + dbs + buf * W4_RAW + r * W4_RS + 4);
+        d[0] = v4[0]; d[1] = v4[1]; d[2] = v4[2]; d[3] = v4[3]; d[4] = v2.x; d[5] = v2.y;
+    };
+    auto vst6 = [&](int buf, int i, const float (&v)[6]) {   // row i (of this thread's three) of V -> Vs[buf]
+        float* dst = smem + vbs[buf] + (6 * i) * W4_KS * 32;
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) dst[nu * W4_KS * 32] = v[nu];
+    };
+    // column pass of the transform, in two steps (rows read in two sets: 24 registers at the peak).  HALF 0: T rows 0..2 from d0..d4; HALF 1: T rows 3..5 from d1..d5
+    // step A: rows (0, 2, 4) | (1, 3, 5) -> X = 4 dA0 - 5 dA1 + dA2 (= t0 | t5), Y = dA2 - 4 dA1 (half 0) | dA1 - dA0 (half 1)
+    // step B: rows (1, 3) | (2, 4)      -> Z = dB1 - 4 dB0 (half 0) | dB1 - dB0 (half 1); half 0: t1 = Y + Z, t2 = Y - Z; half 1: t3 = Z + 2 Y, t4 = Z - 2 Y
+    auto transform_full = [&](int buf) {                     // prologue only
+        float TT[3][6], Y[6], v[6];                          // TT: this thread's three rows of B^T d (half 0: t0 t1 t2, half 1: t3 t4 t5)
+        const int ix = half ? 2 : 0, i1 = half ? 0 : 1, i2 = half ? 1 : 2;
+        {
+            float dR[3][6];
+            rd6(buf, half, dR[0]); rd6(buf, 2 + half, dR[1]); rd6(buf, 4 + half, dR[2]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                TT[ix][j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
+                Y[j] = half ? dR[1][j] - dR[0][j] : __builtin_fmaf(-4.f, dR[1][j], dR[2][j]);
+            }
+        }
+        {
+            float dR[2][6];
+            rd6(buf, 1 + half, dR[0]); rd6(buf, 3 + half, dR[1]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (half) {
+                    const float Z = dR[1][j] - dR[0][j];
+                    TT[i1][j] = __builtin_fmaf(2.f, Y[j], Z);
+                    TT[i2][j] = __builtin_fmaf(-2.f, Y[j], Z);
+                } else {
+                    const float Z = __builtin_fmaf(-4.f, dR[0][j], dR[1][j]);
+                    TT[i1][j] = Y[j] + Z;
+                    TT[i2][j] = Y[j] - Z;
+                }
+            }
+        }
+        if (half) {                                          // (a wave-uniform branch around constant indices: no scratch)
+            w4_bt6(TT[0], v); vst6(buf, 0, v);
+            w4_bt6(TT[1], v); vst6(buf, 1, v);
+            w4_bt6(TT[2], v); vst6(buf, 2, v);
+        } else {
+            w4_bt6(TT[0], v); vst6(buf, 0, v);
+            w4_bt6(TT[1], v); vst6(buf, 1, v);
+            w4_bt6(TT[2], v); vst6(buf, 2, v);
+        }
+    };
+    auto iteration = [&](int s, auto SET, auto NXT, auto HALFC) {
+        constexpr int set = decltype(SET)::value;            // s % 2
+        constexpr bool nxt = decltype(NXT)::value != 0;      // the last stage has no next one to prepare (peeled: no branches in the loop)
+        constexpr int HF = decltype(HALFC)::value;           // this wave's half of the transform (the K loop exists once per half: no branches inside)
+        const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
+        constexpr int IX = HF ? 2 : 0, I1 = HF ? 0 : 1, I2 = HF ? 1 : 2;      // rows of TT: t0 t1 t2 | t3 t4 t5
+        float TT[3][6], Y[6], dR[3][6];
+        auto mf = [&](int kk, int j, bool refill) {          // product j of k-pair kk; then its register takes the fragment of the next k-pair
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk][j >> 2][j & 3], fb[j], acc[j], 0, 0, 0);
+            if (refill) fb[j] = kk < 3 ? frag1(set, kk + 1, j) : frag1(set ^ 1, 0, j);
+            W4SB();
+        };
+        auto uldn = [&](int kk) {                            // the weights of the k-pair after the next (kk + 2 of this stage, or kk - 2 of the next)
+            if (kk < 2) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ufr[kk + 2][j] = uld1(s, kk + 2, j);
+            } else if (nxt) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ufr[kk - 2][j] = uld1(s + 1, kk - 2, j);
+            }
+            W4SB();
+        };
+        auto halo = [&](int k) {                             // the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3
+            if (nxt) { rst1(set, k, rreg[k]); rreg[k] = rld1(s3, k); }
+            W4SB();
+        };
+        auto rdA = [&](int i) {
+            if (nxt) rd6(set ^ 1, 2 * i + HF, dR[i]);
+            W4SB();
+        };
+        auto colA = [&](int j0) {
+            if (nxt) {
+#pragma unroll
+                for (int j = j0; j < j0 + 3; ++j) {
+                    TT[IX][j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
+                    Y[j] = HF ? dR[1][j] - dR[0][j] : __builtin_fmaf(-4.f, dR[1][j], dR[2][j]);
+                }
+            }
+            W4SB();
+        };
+        auto rdB = [&](int i) {                              // (the registers of step A's rows)
+            if (nxt) rd6(set ^ 1, 2 * i + 1 + HF, dR[i]);
+            W4SB();
+        };
+        auto colB = [&](int j0) {
+            if (nxt) {
+#pragma unroll
+                for (int j = j0; j < j0 + 3; ++j) {
+                    if (HF) {
+                        const float Z = dR[1][j] - dR[0][j];
+                        TT[I1][j] = __builtin_fmaf(2.f, Y[j], Z);
+                        TT[I2][j] = __builtin_fmaf(-2.f, Y[j], Z);
+                    } else {
+                        const float Z = __builtin_fmaf(-4.f, dR[0][j], dR[1][j]);
+                        TT[I1][j] = Y[j] + Z;
+                        TT[I2][j] = Y[j] - Z;
+                    }
+                }
+            }
+            W4SB();
+        };
+        auto rowp = [&](int i) {                             // row i of this thread's three: B^T (.) over the columns, six V stores
+            if (nxt) {
+                float v[6];
+                w4_bt6(TT[i], v);
+                vst6(set ^ 1, i, v);
+            }
+            W4SB();
+        };
+        // k-pair 0: the halo of stage s + 2 -> raw, the loads of stage s + 3; the first rows of the next stage's patch
+        uldn(0);
+        mf(0, 0, true); halo(0);
+        mf(0, 1, true); halo(1);
+        mf(0, 2, true); halo(2);
+        mf(0, 3, true); rdA(0);
+        mf(0, 4, true); rdA(1);
+        mf(0, 5, true); rdA(2);
+        mf(0, 6, true);
+        mf(0, 7, true); colA(0);
+        mf(0, 8, true); colA(3);
+        // k-pair 1: the rest of the column pass, the row pass
+        uldn(1);
+        mf(1, 0, true); rdB(0);
+        mf(1, 1, true); rdB(1);
+        mf(1, 2, true);
+        mf(1, 3, true); colB(0);
+        mf(1, 4, true); colB(3);
+        mf(1, 5, true); rowp(0);
+        mf(1, 6, true);
+        mf(1, 7, true); rowp(1);
+        mf(1, 8, true);
+        // k-pair 2
+        uldn(2);
+        mf(2, 0, true); rowp(2);
+        mf(2, 1, true); mf(2, 2, true); mf(2, 3, true); mf(2, 4, true); mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
+        // k-pair 3: behind the stage's barrier (the refills read the NEXT stage's fragments)
+        uldn(3);
+        __syncthreads();
+        W4SB();
+        mf(3, 0, nxt); mf(3, 1, nxt); mf(3, 2, nxt); mf(3, 3, nxt); mf(3, 4, nxt); mf(3, 5, nxt); mf(3, 6, nxt); mf(3, 7, nxt); mf(3, 8, nxt);
+    };
+
+    // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested here for
+    // the workgroup's first block, for every later one from inside the previous block's epilogue
+    floatx4 r0[W4_NQ], r1[W4_NQ];
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int k = 0; k < W4_NQ; ++k) {
+            r0[k] = rld1(0, k);
+            r1[k] = rld1(1, k);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            ufr[0][j] = uld1(0, 0, j);
+            ufr[1][j] = uld1(0, 1, j);
+        }
+#pragma unroll
+        for (int k = 0; k < W4_NQ; ++k) rreg[k] = rld1(nst > 2 ? 2 : 1, k);
+    };
+    issue_loads();
+#ifdef LWG_W4_TS
+    int lab_bi = 0;
+#endif
+    for (;;) {
+    W4TS(0);
+#pragma unroll
+    for (int k = 0; k < W4_NQ; ++k) {
+        rst1(0, k, r0[k]);
+        rst1(1, k, r1[k]);
+    }
+    __syncthreads();
+    transform_full(0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; ++j) fb[j] = frag1(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    W4TS(1);
+    if (half == 0) {
+        int s = 0;
+        for (; s + 2 < nst; s += 2) {
+            iteration(s, W4Int<0>(), W4Int<1>(), W4Int<0>());
+            iteration(s + 1, W4Int<1>(), W4Int<1>(), W4Int<0>());
+        }
+        iteration(s, W4Int<0>(), W4Int<1>(), W4Int<0>());
+        iteration(s + 1, W4Int<1>(), W4Int<0>(), W4Int<0>());
+    } else {
+        int s = 0;
+        for (; s + 2 < nst; s += 2) {
+            iteration(s, W4Int<0>(), W4Int<1>(), W4Int<1>());
+            iteration(s + 1, W4Int<1>(), W4Int<1>(), W4Int<1>());
+        }
+        iteration(s, W4Int<0>(), W4Int<1>(), W4Int<1>());
+        iteration(s + 1, W4Int<1>(), W4Int<0>(), W4Int<1>());
+    }
+    W4TS(2);
+    const int eb = b, ex0 = x0, ey0 = y0, en0 = n0;          // this block's coordinates (the state moves on to the next block below)
+    // epilogue.  (1) M A in registers: row q -> F[b] (b = 0..3, into acc[0..3]); the half row -> three partial sums (into acc[6..8]):
+    //   nu 0..2: a0 = m0 + m1 + m2, a1 = m1 - m2, a2 = m1 + m2;  nu 3..5: b0 = m3 + m4, b1 = m3 - m4, b2 = m5
+    //   (F[0] = a0 + b0, F[1] = a1 + 2 b1, F[2] = a2 + 4 b0, F[3] = a1 + 8 b1 + b2: finished by the reader)
+    // (2) two passes of 16 patches: the 28 planes cross LDS ([plane][patch][64 channels + 4]: 16-byte stores and loads, conflict-free both ways); a reader
+    // thread owns one output column b of one patch x the channel quads n4.. and 32 + n4..: A^T (.) over xi, bias, (residual | SPADE modulation), activation,
+    // 16-byte NHWC stores.  LWG_EPI_SPADE: the block's 64 columns are gamma | beta of the SAME 32 channels (as conv_winograd.hip).
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        acc[0][r] = (m0 + s12) + s34;
+        acc[1][r] = __builtin_fmaf(2.f, d34, d12);
+        acc[2][r] = __builtin_fmaf(4.f, s34, s12);
+        acc[3][r] = __builtin_fmaf(8.f, d34, d12) + m5;
+        const float h0 = acc[6][r], h1 = acc[7][r], h2 = acc[8][r];
+        if (q & 1) {
+            acc[6][r] = h0 + h1;
+            acc[7][r] = h0 - h1;
+        } else {
+            acc[6][r] = (h0 + h1) + h2;
+            acc[7][r] = h1 - h2;
+            acc[8][r] = h1 + h2;
+        }
+    }
+    int tide = tid;                                          // (through an empty asm per block: the epilogue's address arithmetic must not be hoisted out
+    asm volatile("" : "+v"(tide));                           //  of the block loop - it would sit in registers through the K loop)
+    const int lanee = tide & 63;
+    const int rb = wid & 3;                                  // reader: output column inside a patch (wave-uniform)
+    const int p16 = (wid >> 2) * 8 + (lanee >> 3);           // ... patch inside the pass
+    const int n4 = (lanee & 7) * 4;                          // ... channel quad (and 32 + n4)
+    floatx4 bv[2], mu, rs;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + en0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == LWG_EPI_SPADE) {
+        mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + (en0 >> 1) + n4);
+        rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)eb * a.YC + (en0 >> 1) + n4);
+    }
+    bool more = false;
+    int nblk = blk;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        __syncthreads();                                     // the loop's last fragment reads / the previous pass's readers are done
+        if (((lanee >> 4) & 1) == ph) {
+            float* dst = Ms + (lanee & 15) * W4_MSR + ct * 32 + 4 * (lanee >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+                    *reinterpret_cast<floatx4*>(dst + (4 * q + bb) * 16 * W4_MSR + 8 * g) = floatx4{acc[bb][4 * g], acc[bb][4 * g + 1], acc[bb][4 * g + 2], acc[bb][4 * g + 3]};
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    *reinterpret_cast<floatx4*>(dst + (16 + 3 * q + i) * 16 * W4_MSR + 8 * g) = floatx4{acc[6 + i][4 * g], acc[6 + i][4 * g + 1], acc[6 + i][4 * g + 2], acc[6 + i][4 * g + 3]};
+            }
+        }
+        if (ph == 1) {
+            // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
+            // (unconditional: the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
+            nblk = blk + (int)gridDim.x;
+            more = nblk < total;
+            setup(more ? nblk : blk);
+            issue_loads();
+        }
+        __syncthreads();
+        const int p = ph * 16 + p16;
+        const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
+        lwg_act_dispatch(a.act, [&](auto ACTC) {
+        constexpr int EA = decltype(ACTC)::value;
+        floatx4 gam[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* base = Ms + p16 * W4_MSR + h * 32 + n4;
+            floatx4 F[6];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) F[xi] = *reinterpret_cast<const floatx4*>(base + (4 * xi + rb) * 16 * W4_MSR);
+            const int ia = rb == 0 ? 0 : rb == 2 ? 2 : 1, ib = (rb & 1) ? 4 : 3;
+            const float cb = (float)(1 << rb);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float* hb = base + (16 + 6 * r) * 16 * W4_MSR;
+                const floatx4 pa = *reinterpret_cast<const floatx4*>(hb + ia * 16 * W4_MSR);
+                const floatx4 pb = *reinterpret_cast<const floatx4*>(hb + ib * 16 * W4_MSR);
+                floatx4 f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f[c] = __builtin_fmaf(cb, pb[c], pa[c]);
+                if (rb == 3) f += *reinterpret_cast<const floatx4*>(hb + 5 * 16 * W4_MSR);
+                F[4 + r] = f;
+            }
+            floatx4 Y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float s12 = F[1][c] + F[2][c], d12 = F[1][c] - F[2][c], s34 = F[3][c] + F[4][c], d34 = F[3][c] - F[4][c];
+                Y[0][c] = (F[0][c] + s12) + s34;
+                Y[1][c] = __builtin_fmaf(2.f, d34, d12);
+                Y[2][c] = __builtin_fmaf(4.f, s34, s12);
+                Y[3][c] = __builtin_fmaf(8.f, d34, d12) + F[5][c];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oy = oyb + i;
+                floatx4 v = Y[i] + bv[h];
+                const bool in = oy < H && ox < W;
+                if (EPI == LWG_EPI_SPADE) {
+                    if (h == 0) {
+                        gam[i] = v;                          // gamma
+                    } else if (in) {
+                        const floatx4 xn = *reinterpret_cast<const floatx4*>(a.xn + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4);
+                        floatx4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>((xn[c] - mu[c]) * rs[c] * (1.f + gam[i][c]) + v[c], a.act);
+                        *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4) = o;
+                    }
+                } else if (in) {
+                    const size_t off = (((size_t)eb * H + oy) * W + ox) * a.YC + a.ycoff + en0 + h * 32 + n4;
+                    floatx4 o;
+                    if (EPI == LWG_EPI_RESIDUAL) {
+                        const floatx4 e = *reinterpret_cast<const floatx4*>(a.res + off);
+                        if (lwg_act_is_mask<EA>(a.act)) {    // data gradient behind a ReLU: res = the forward input, the mask source
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = e[c] > 0.f ? v[c] : 0.f;
+                        } else {
+                            v += e;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>(v[c], a.act);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>(v[c], a.act);
+                    }
+                    *reinterpret_cast<floatx4*>(y + off) = o;
+                }
+            }
+        }
+        });
+    }
+    W4TS(3);
+#ifdef LWG_W4_TS
+    ++lab_bi;
+#endif
+    if (!more) break;
+    blk = nblk;
+    __syncthreads();                                         // every reader is done with the exchange buffer: raw[0] / raw[1] (the same LDS) may be written
+    }
+}
+
+
+// The fragment panel from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w: [9 Cin / 4][N][4], k = ((c / 32) 9 + tap) 32 + c % 32):
+// U = G w G^T (6 x 6) per (input channel, output column) in fp64, rounded once, written as Upk[4][Cin/8][4][2][N][12]: element (q, s, kk, kh, n, j) of input
+// channel c = 8 s + 2 kk + kh: j < 6: U[q][j]; j = 6..8: U[4 + q / 2][3 (q % 2) + j - 6]; j = 9..11: padding (zero).  tap9[3 r + s] = the tap index of kernel
+// position (dy, dx) = (r - 1, s - 1) in the GEMM panel.  One thread per (c, n).
+struct LwgWino4Taps { int t[9]; };
+
+__global__ __launch_bounds__(256) void lwg_winograd4_panel_kernel(const float* __restrict__ wp, float* __restrict__ U, int Cin, int N, LwgWino4Taps taps) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n >= N || c >= Cin) return;
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = ((c >> 5) * 9 + taps.t[3 * r + s]) * 32 + (c & 31);
+            g[r][s] = (double)wp[((size_t)(k >> 2) * N + n) * 4 + (k & 3)];
+        }
+    const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double t[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t[i][s] = G[i][0] * g[0][s] + G[i][1] * g[1][s] + G[i][2] * g[2][s];
+    const int s8 = c >> 3, kk = (c & 7) >> 1, kh = c & 1;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        float* dst = U + (((((size_t)qq * (Cin >> 3) + s8) * 4 + kk) * 2 + kh) * N + n) * 12;
+        float o[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int xi = j < 6 ? qq : 4 + (qq >> 1), nu = j < 6 ? j : 3 * (qq & 1) + (j - 6);
+            o[j] = j < 9 ? (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<floatx4*>(dst + 4 * j) = floatx4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+    }
+}
+
+extern "C" int lwg_winograd4_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream_) {
+    if (!wpanel || !upk || !tap9 || Cin <= 0 || (Cin % 32) != 0 || N <= 0) return (int)hipErrorInvalidValue;
+    LwgWino4Taps taps;
+    for (int i = 0; i < 9; ++i) {
+        if (tap9[i] < 0 || tap9[i] > 8) return (int)hipErrorInvalidValue;
+        taps.t[i] = tap9[i];
+    }
+    hipLaunchKernelGGL(lwg_winograd4_panel_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((Cin + 3) / 4)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), wpanel, upk, Cin, N, taps);
+    return (int)hipGetLastError();
+}
+
+// args: lwg_conv2d_winograd_f32's launch description (3 x 3 / stride 1 / pad 1, one or two inputs with C0 % 8 == 0, C1 % 8 == 0, (C0 + C1) % 16 == 0, N % 64 == 0,
+// YC % 4 == 0; LWG_EPI_NONE, LWG_EPI_RESIDUAL or LWG_EPI_SPADE; any activation of lwg_act) EXCEPT args->w = the F(4x4, 3x3) fragment panel of
+// lwg_winograd4_panel_f32, 192 Cin N bytes.
+static bool lwg_wino4_contract(const LwgConvArgs& a) {
+    if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C0 <= 0 || (a.C0 % W4_KS) != 0 || a.C1 < 0 ||
+        (a.C1 % W4_KS) != 0 || ((a.C0 + a.C1) % (2 * W4_KS)) != 0 || (a.C1 > 0 && !a.x1) || a.N <= 0 || (a.N % W4_NB) != 0 || a.OH != a.H || a.OW != a.W ||
+        a.YH != a.H || a.YW != a.W || a.xdt != LWG_DT_F32 || a.ydt != LWG_DT_F32 || a.M != a.B * a.H * a.W || a.ycoff < 0 || (a.ycoff % 4) != 0 ||
+        (a.YC % 4) != 0 || (a.act == LWG_ACT_RELU_MASK && a.epi != LWG_EPI_RESIDUAL))
+        return false;
+    if (a.epi == LWG_EPI_SPADE) {
+        if (!a.xn || !a.mean || !a.rstd || !a.bias || a.YC * 2 != a.N || a.ycoff != 0) return false;
+    } else {
+        if (a.ycoff + a.N > a.YC) return false;
+        if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return false;
+    }
+    const unsigned long long cmax = (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1);
+    if ((unsigned long long)a.H * a.W * cmax * 4ull >= (unsigned long long)W4_OOB || 192ull * (a.C0 + a.C1) * a.N >= 0xffffffffull) return false;
+    return true;
+}
+
+extern "C" int lwg_conv2d_winograd4_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!pa || !lwg_wino4_contract(*pa)) return (int)hipErrorInvalidValue;
+    const LwgConvArgs& a = *pa;
+    const size_t lds = (size_t)(W4_LOOP > W4_MS ? W4_LOOP : W4_MS) * 4;
+    const int bx = (a.W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (a.H + 4 * W4_PBY - 1) / (4 * W4_PBY);
+    const int cus = lwg_device_cus();
+    const long total = (long)bx * by * a.B * (a.N / W4_NB);
+    const dim3 grid((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total));
+    static unsigned long long done[6] = {0, 0, 0, 0, 0, 0};
+    const bool two = a.C1 > 0;
+#define LWG_W4_GO2(E, T, SLOT)                                                                                                          \
+    {                                                                                                                                   \
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd4_kernel<E, T>), lds, done[SLOT]); e != hipSuccess) \
+            return (int)e;                                                                                                              \
+        hipLaunchKernelGGL((lwg_conv_winograd4_kernel<E, T>), grid, dim3(W4_THREADS), lds, stream, a);                                  \
+    }
+#define LWG_W4_GO(E, SLOT)                                                                                                              \
+    {                                                                                                                                   \
+        if (two) LWG_W4_GO2(E, true, SLOT + 3) else LWG_W4_GO2(E, false, SLOT)                                                          \
+    }
+    if (a.epi == LWG_EPI_SPADE) LWG_W4_GO(LWG_EPI_SPADE, 2)
+    else if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GO(LWG_EPI_RESIDUAL, 1)
+    else LWG_W4_GO(LWG_EPI_NONE, 0)
+#undef LWG_W4_GO
+#undef LWG_W4_GO2
+    return (int)hipGetLastError();
+}

@@ -63,7 +63,7 @@ def _stream():
 
 class ConvSpec:
     """Host description of one packed convolution (weights already in the kernel's layout)."""
-    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up", "_wwino", "_wwino_t")
+    __slots__ = ("w", "bias", "N", "Cin", "ntaps", "dy", "dx", "stride", "cshift", "omul", "ooy", "oox", "algo_kn", "_w16v2", "_w16hr", "_w16x3", "_w16c8", "_w16up", "_w32up", "_wwino", "_wwino_t", "_wwino4")
 
     def __init__(self, w, bias, N, Cin, taps, stride=1, omul=1, ooy=0, oox=0, algo_kn=None):
         self.w, self.bias, self.N, self.Cin = w, bias, int(N), int(Cin)
@@ -81,6 +81,7 @@ class ConvSpec:
         self._w32up = None
         self._wwino = None
         self._wwino_t = None
+        self._wwino4 = None
         self.cshift = 0
         if self.Cin % 32 != 0:
             q = self.Cin // 4
@@ -251,6 +252,35 @@ def _wwino(spec):
     return spec._wwino
 
 
+WINO4 = True            # lab switch: in the "winograd" mode the synthesis path's eligible launches with Cin >= WINO4_MIN_CIN run the F(4x4, 3x3) kernel
+WINO4_MIN_CIN = 128     # below it the F(2x2, 3x3) kernel stays (a block's K loop must pay for the 28-plane exchange of the F(4x4, 3x3) epilogue)
+
+
+def _wino4_use(spec, splitk):
+    """Which launches of the "winograd" mode run lwg_conv2d_winograd4_f32 (F(4x4, 3x3): 2.25 multiplies per output instead of 4): a rule on the LAYER
+    (its Cin), never on the batch - a frame's result must not depend on how many frames share its launch.  Training launches (splitk=True) keep the
+    F(2x2, 3x3) kernel and its split plan."""
+    return WINO4 and not splitk and spec.Cin >= WINO4_MIN_CIN
+
+
+def _wwino4(spec):
+    """The fragment panel of lwg_conv2d_winograd4_f32, built once per spec from the fp32 GEMM panel by ONE launch (lwg_winograd4_panel_f32):
+    U = G w G^T (6 x 6) per (input, output) channel pair in fp64, rounded once, stored [4][Cin/8][4][2][N][12]."""
+    if spec._wwino4 is None or spec._wwino4.device != spec.w.device:
+        K4, N, _ = spec.w.shape
+        cin, nt = spec.Cin, spec.ntaps
+        assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin, (cin, nt, K4)
+        if not spec.w.is_cuda:
+            raise RuntimeError("ipercore_amd ops need CUDA (HIP) tensors: the MI355X path has no CPU fallback")
+        tap9 = (ctypes.c_int * 9)()
+        for t in range(nt):
+            tap9[3 * (spec.dy[t] + 1) + spec.dx[t] + 1] = t
+        U = torch.empty(4, cin // 8, 4, 2, N, 12, device=spec.w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().lwg_winograd4_panel_f32(_ptr(spec.w), _ptr(U), cin, N, tap9, _stream()), "lwg_winograd4_panel_f32")
+        spec._wwino4 = U
+    return spec._wwino4
+
+
 def conv_args(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, mean=None, rstd=None,
               out_hw=None, ycoff=0, q4=False):
     """Fill the C-ABI argument block of one conv launch (see ``conv2d``).  q4: y is (B, YC/4, YH, YW, 4) - channel-quad planes
@@ -330,12 +360,17 @@ def conv2d(x0, spec, y, x1=None, epi=EPI_NONE, act=ACT_NONE, res=None, xn=None, 
             _lib.check(_lib.lib().lwg_conv2d_nhwc_f32(a, _stream()), "lwg_conv2d_nhwc_f32")
     elif CONV_PRECISION == "winograd" and _wino_eligible(spec, x0, y, x1, epi, act, out_hw, q4, ycoff) and \
             (nws := _wino_plan(a, spec, y, splitk)) is not None:
-        a.w = _ptr(_wwino(spec))
         kind, sliced = "winograd", False            # per-image buffer descriptors: one launch at any batch size
-        if nws:
+        if _wino4_use(spec, splitk):
+            a.w = _ptr(_wwino4(spec))
+            kind = "winograd4"
+            _lib.check(_lib.lib().lwg_conv2d_winograd4_f32(a, _stream()), "lwg_conv2d_winograd4_f32")
+        elif nws:
+            a.w = _ptr(_wwino(spec))
             ws, extra = torch.empty(nws, device=x0.device, dtype=torch.float32), 1
             _lib.check(_lib.lib().lwg_conv2d_winograd_f32_ws(a, _ptr(ws), _stream()), "lwg_conv2d_winograd_f32_ws")
         else:
+            a.w = _ptr(_wwino(spec))
             _lib.check(_lib.lib().lwg_conv2d_winograd_f32(a, _stream()), "lwg_conv2d_winograd_f32")
     elif CONV_PRECISION == "split" and spec.Cin % 32 == 0:
         a.w = _ptr(_w16x3(spec), torch.bfloat16)
