@@ -40,6 +40,7 @@
 #define W4_MSR 68                                // floats per (plane, patch) row of the epilogue's exchange buffer: 64 channels + 4
 #define W4_NPL 28                                // planes: rows 0..3 x 4 output columns, rows 4 / 5: 2 halves x 3 partial sums
 #define W4_MS (W4_NPL * 16 * W4_MSR)             // one pass = 16 patches
+#define W4_BIAS_OFF (W4_LOOP > W4_MS ? W4_LOOP : W4_MS)          // the block's 64 bias values, behind both uses of the LDS
 #define W4_OOB 0xC0000000u
 #define W4SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -102,9 +103,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         n0 = cb * W4_NB;
         rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
         if constexpr (TWO) rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * H * W * a.C1), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
+        int tids = tid;                                      // (through an empty asm: the halo geometry is recomputed per block - hoisted out of the block
+        asm volatile("" : "+v"(tids));                       //  loop it would sit in registers through the K loop)
 #pragma unroll
         for (int k = 0; k < W4_NQ; ++k) {                    // padding pixels / threads without an element: an out-of-range offset (the hardware returns zeros)
-            const int i = tid + W4_THREADS * k;
+            const int i = tids + W4_THREADS * k;
             const int pix = i >> 1, hq = i & 1, hy = pix / W4_HW, hx = pix - hy * W4_HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool in = i < W4_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -149,13 +152,16 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     unsigned dbs = (unsigned)(tc * W4_PLANE + (4 * pty) * W4_RS + 4 * ptx) >> 2;      // its 6 x 6 input patch inside raw[0] (float index; 16-byte aligned)
     asm volatile("" : "+v"(dbs));
     dbs <<= 2;
-    unsigned vbs[2];                                         // its 18 transformed values inside Vs[u]
+    unsigned dbx = (unsigned)(tc * W4_PLANE + (4 * pty + half) * W4_RS + 4 * ptx) >> 2;   // ... from row `half`: the rows of X (half, half + 2, half + 4)
+    asm volatile("" : "+v"(dbx));
+    dbx <<= 2;
+    // its 18 transformed values inside Vs[0]: row X (xi = 0 | 5) and rows T+, T- (xi = 1, 2 | 3, 4)
+    unsigned vbx = (unsigned)(2 * W4_RAW + (half ? 30 : 0) * W4_KS * 32 + tc * 32 + patch);
+    unsigned vbt = (unsigned)(2 * W4_RAW + (half ? 18 : 6) * W4_KS * 32 + tc * 32 + patch);
+    asm volatile("" : "+v"(vbx));
+    asm volatile("" : "+v"(vbt));
+    const float alpha = half ? -1.f : -4.f, beta = half ? 2.f : 1.f, nbeta = -beta;       // (wave-uniform: scalar operands)
     unsigned fbs[2];                                         // this lane's fragments: products 0..5 | 6..8, inside Vs[0]
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        vbs[u] = (unsigned)(2 * W4_RAW + u * W4_VS + (18 * half) * W4_KS * 32 + tc * 32 + patch);
-        asm volatile("" : "+v"(vbs[u]));
-    }
     fbs[0] = (unsigned)(2 * W4_RAW + (6 * q) * W4_KS * 32 + lane);
     fbs[1] = (unsigned)(2 * W4_RAW + (6 * (4 + (q >> 1)) + 3 * (q & 1)) * W4_KS * 32 + lane);
     asm volatile("" : "+v"(fbs[0]));
@@ -164,64 +170,50 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     auto frag1 = [&](int buf, int kk, int j) -> float {
         return smem[fbs[j < 6 ? 0 : 1] + buf * W4_VS + ((j < 6 ? j : j - 6) * W4_KS + 2 * kk) * 32];
     };
-    auto rd6 = [&](int buf, int r, float (&d)[6]) {          // row r of this thread's patch in raw[buf]
-        const floatx4 v4 = *reinterpret_cast<const floatx4*>(smem + dbs + buf * W4_RAW + r * W4_RS);
-        const float2 v2 = *reinterpret_cast<const float2*>(smem + dbs + buf * W4_RAW + r * W4_RS + 4);
+    auto rd6 = [&](unsigned base, int buf, int r, float (&d)[6]) {     // row r (from the base's row) of this thread's patch in raw[buf]
+        const floatx4 v4 = *reinterpret_cast<const floatx4*>(smem + base + buf * W4_RAW + r * W4_RS);
+        const float2 v2 = *reinterpret_cast<const float2*>(smem + base + buf * W4_RAW + r * W4_RS + 4);
         d[0] = v4[0]; d[1] = v4[1]; d[2] = v4[2]; d[3] = v4[3]; d[4] = v2.x; d[5] = v2.y;
     };
-    auto vst6 = [&](int buf, int i, const float (&v)[6]) {   // row i (of this thread's three) of V -> Vs[buf]
-        float* dst = smem + vbs[buf] + (6 * i) * W4_KS * 32;
+    auto vst6 = [&](unsigned base, int buf, int i, const float (&v)[6]) {   // six values of a row of V -> Vs[buf], row i behind the base's
+        float* dst = smem + base + buf * W4_VS + (6 * i) * W4_KS * 32;
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu) dst[nu * W4_KS * 32] = v[nu];
     };
-    // column pass of the transform, in two steps (rows read in two sets: 24 registers at the peak).  HALF 0: T rows 0..2 from d0..d4; HALF 1: T rows 3..5 from d1..d5
-    // step A: rows (0, 2, 4) | (1, 3, 5) -> X = 4 dA0 - 5 dA1 + dA2 (= t0 | t5), Y = dA2 - 4 dA1 (half 0) | dA1 - dA0 (half 1)
-    // step B: rows (1, 3) | (2, 4)      -> Z = dB1 - 4 dB0 (half 0) | dB1 - dB0 (half 1); half 0: t1 = Y + Z, t2 = Y - Z; half 1: t3 = Z + 2 Y, t4 = Z - 2 Y
+    // column pass of the transform, the SAME instructions in both halves (no branches, one copy of the K loop):
+    //   X  = 4 dx0 - 5 dx1 + dx2 over the rows (half, half + 2, half + 4)           = t0 | t5
+    //   P  = d4 + alpha d2, Q = d3 + alpha d1 (alpha = -4 | -1); T+ = P + beta Q, T- = P - beta Q (beta = 1 | 2)   = t1, t2 | t3, t4
     auto transform_full = [&](int buf) {                     // prologue only
-        float TT[3][6], Y[6], v[6];                          // TT: this thread's three rows of B^T d (half 0: t0 t1 t2, half 1: t3 t4 t5)
-        const int ix = half ? 2 : 0, i1 = half ? 0 : 1, i2 = half ? 1 : 2;
+        float X[6], P[6], Q[6], v[6];
         {
             float dR[3][6];
-            rd6(buf, half, dR[0]); rd6(buf, 2 + half, dR[1]); rd6(buf, 4 + half, dR[2]);
+            rd6(dbx, buf, 0, dR[0]); rd6(dbx, buf, 2, dR[1]); rd6(dbx, buf, 4, dR[2]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                TT[ix][j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
-                Y[j] = half ? dR[1][j] - dR[0][j] : __builtin_fmaf(-4.f, dR[1][j], dR[2][j]);
-            }
+            for (int j = 0; j < 6; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
         }
         {
             float dR[2][6];
-            rd6(buf, 1 + half, dR[0]); rd6(buf, 3 + half, dR[1]);
+            rd6(dbs, buf, 2, dR[0]); rd6(dbs, buf, 4, dR[1]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                if (half) {
-                    const float Z = dR[1][j] - dR[0][j];
-                    TT[i1][j] = __builtin_fmaf(2.f, Y[j], Z);
-                    TT[i2][j] = __builtin_fmaf(-2.f, Y[j], Z);
-                } else {
-                    const float Z = __builtin_fmaf(-4.f, dR[0][j], dR[1][j]);
-                    TT[i1][j] = Y[j] + Z;
-                    TT[i2][j] = Y[j] - Z;
-                }
-            }
+            for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
+            rd6(dbs, buf, 1, dR[0]); rd6(dbs, buf, 3, dR[1]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
         }
-        if (half) {                                          // (a wave-uniform branch around constant indices: no scratch)
-            w4_bt6(TT[0], v); vst6(buf, 0, v);
-            w4_bt6(TT[1], v); vst6(buf, 1, v);
-            w4_bt6(TT[2], v); vst6(buf, 2, v);
-        } else {
-            w4_bt6(TT[0], v); vst6(buf, 0, v);
-            w4_bt6(TT[1], v); vst6(buf, 1, v);
-            w4_bt6(TT[2], v); vst6(buf, 2, v);
-        }
+        w4_bt6(X, v); vst6(vbx, buf, 0, v);
+        float T[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(beta, Q[j], P[j]);
+        w4_bt6(T, v); vst6(vbt, buf, 0, v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(nbeta, Q[j], P[j]);
+        w4_bt6(T, v); vst6(vbt, buf, 1, v);
     };
-    auto iteration = [&](int s, auto SET, auto NXT, auto HALFC) {
+    auto iteration = [&](int s, auto SET, auto NXT) {
         constexpr int set = decltype(SET)::value;            // s % 2
         constexpr bool nxt = decltype(NXT)::value != 0;      // the last stage has no next one to prepare (peeled: no branches in the loop)
-        constexpr int HF = decltype(HALFC)::value;           // this wave's half of the transform (the K loop exists once per half: no branches inside)
         const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
-        constexpr int IX = HF ? 2 : 0, I1 = HF ? 0 : 1, I2 = HF ? 1 : 2;      // rows of TT: t0 t1 t2 | t3 t4 t5
-        float TT[3][6], Y[6], dR[3][6];
+        float X[6], P[6], Q[6], dR[3][6];
         auto mf = [&](int kk, int j, bool refill) {          // product j of k-pair kk; then its register takes the fragment of the next k-pair
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk][j >> 2][j & 3], fb[j], acc[j], 0, 0, 0);
             if (refill) fb[j] = kk < 3 ? frag1(set, kk + 1, j) : frag1(set ^ 1, 0, j);
@@ -241,74 +233,82 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             if (nxt) { rst1(set, k, rreg[k]); rreg[k] = rld1(s3, k); }
             W4SB();
         };
-        auto rdA = [&](int i) {
-            if (nxt) rd6(set ^ 1, 2 * i + HF, dR[i]);
+        auto rdX = [&](int i) {                              // the rows of X
+            if (nxt) rd6(dbx, set ^ 1, 2 * i, dR[i]);
             W4SB();
         };
-        auto colA = [&](int j0) {
+        auto colX = [&](int j0) {
             if (nxt) {
 #pragma unroll
-                for (int j = j0; j < j0 + 3; ++j) {
-                    TT[IX][j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
-                    Y[j] = HF ? dR[1][j] - dR[0][j] : __builtin_fmaf(-4.f, dR[1][j], dR[2][j]);
-                }
+                for (int j = j0; j < j0 + 3; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
             }
             W4SB();
         };
-        auto rdB = [&](int i) {                              // (the registers of step A's rows)
-            if (nxt) rd6(set ^ 1, 2 * i + 1 + HF, dR[i]);
+        auto rdP = [&](int i) {                              // rows 2, 4 (-> P), then rows 1, 3 (-> Q)
+            if (nxt) rd6(dbs, set ^ 1, 2 * i + 2, dR[i]);
             W4SB();
         };
-        auto colB = [&](int j0) {
+        auto rdQ = [&](int i) {
+            if (nxt) rd6(dbs, set ^ 1, 2 * i + 1, dR[i]);
+            W4SB();
+        };
+        auto colP = [&]() {
             if (nxt) {
 #pragma unroll
-                for (int j = j0; j < j0 + 3; ++j) {
-                    if (HF) {
-                        const float Z = dR[1][j] - dR[0][j];
-                        TT[I1][j] = __builtin_fmaf(2.f, Y[j], Z);
-                        TT[I2][j] = __builtin_fmaf(-2.f, Y[j], Z);
-                    } else {
-                        const float Z = __builtin_fmaf(-4.f, dR[0][j], dR[1][j]);
-                        TT[I1][j] = Y[j] + Z;
-                        TT[I2][j] = Y[j] - Z;
-                    }
-                }
+                for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
             }
             W4SB();
         };
-        auto rowp = [&](int i) {                             // row i of this thread's three: B^T (.) over the columns, six V stores
+        auto colQ = [&]() {
+            if (nxt) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
+            }
+            W4SB();
+        };
+        auto rowX = [&]() {                                  // B^T (.) over the columns of a row, six V stores
             if (nxt) {
                 float v[6];
-                w4_bt6(TT[i], v);
-                vst6(set ^ 1, i, v);
+                w4_bt6(X, v);
+                vst6(vbx, set ^ 1, 0, v);
             }
             W4SB();
         };
-        // k-pair 0: the halo of stage s + 2 -> raw, the loads of stage s + 3; the first rows of the next stage's patch
+        auto rowT = [&](int i) {
+            if (nxt) {
+                float T[6], v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(i ? nbeta : beta, Q[j], P[j]);
+                w4_bt6(T, v);
+                vst6(vbt, set ^ 1, i, v);
+            }
+            W4SB();
+        };
+        // k-pair 0: the halo of stage s + 2 -> raw, the loads of stage s + 3; the rows of X of the next stage's patch
         uldn(0);
         mf(0, 0, true); halo(0);
         mf(0, 1, true); halo(1);
         mf(0, 2, true); halo(2);
-        mf(0, 3, true); rdA(0);
-        mf(0, 4, true); rdA(1);
-        mf(0, 5, true); rdA(2);
+        mf(0, 3, true); rdX(0);
+        mf(0, 4, true); rdX(1);
+        mf(0, 5, true); rdX(2);
         mf(0, 6, true);
-        mf(0, 7, true); colA(0);
-        mf(0, 8, true); colA(3);
+        mf(0, 7, true); colX(0);
+        mf(0, 8, true); colX(3);
         // k-pair 1: the rest of the column pass, the row pass
         uldn(1);
-        mf(1, 0, true); rdB(0);
-        mf(1, 1, true); rdB(1);
-        mf(1, 2, true);
-        mf(1, 3, true); colB(0);
-        mf(1, 4, true); colB(3);
-        mf(1, 5, true); rowp(0);
-        mf(1, 6, true);
-        mf(1, 7, true); rowp(1);
+        mf(1, 0, true); rdP(0);
+        mf(1, 1, true); rdP(1);
+        mf(1, 2, true); rowX();
+        mf(1, 3, true); colP(); rdQ(0);
+        mf(1, 4, true); rdQ(1);
+        mf(1, 5, true);
+        mf(1, 6, true); colQ();
+        mf(1, 7, true); rowT(0);
         mf(1, 8, true);
         // k-pair 2
         uldn(2);
-        mf(2, 0, true); rowp(2);
+        mf(2, 0, true); rowT(1);
         mf(2, 1, true); mf(2, 2, true); mf(2, 3, true); mf(2, 4, true); mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
         // k-pair 3: behind the stage's barrier (the refills read the NEXT stage's fragments)
         uldn(3);
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested here for
     // the workgroup's first block, for every later one from inside the previous block's epilogue
     floatx4 r0[W4_NQ], r1[W4_NQ];
+    float bq;                                                // the block's bias, one value per lane of wave 0: requested with the first loads, parked in LDS by the prologue
     auto issue_loads = [&]() {
+        bq = bias ? bias[n0 + (tid & 63)] : 0.f;
 #pragma unroll
         for (int k = 0; k < W4_NQ; ++k) {
             r0[k] = rld1(0, k);
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         rst1(0, k, r0[k]);
         rst1(1, k, r1[k]);
     }
+    if (tid < 64) smem[W4_BIAS_OFF + tid] = bq;
     __syncthreads();
     transform_full(0);
     __syncthreads();
@@ -354,23 +357,25 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     for (int j = 0; j < 9; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // the bias for free: A^T m = (1, 1, 1, 1) for m = (0, 1, 0, 0, 0, 0), so a constant c added to product (xi, nu) = (1, 1) of every patch adds c to all
+    // sixteen outputs - the accumulator of that product starts at the bias of its channel (rows = channels) instead of zero
+    if (q == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(smem + W4_BIAS_OFF + ct * 32 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[1][4 * g + k] = b4[k];
+        }
+    }
     W4TS(1);
-    if (half == 0) {
+    {
         int s = 0;
         for (; s + 2 < nst; s += 2) {
-            iteration(s, W4Int<0>(), W4Int<1>(), W4Int<0>());
-            iteration(s + 1, W4Int<1>(), W4Int<1>(), W4Int<0>());
+            iteration(s, W4Int<0>(), W4Int<1>());
+            iteration(s + 1, W4Int<1>(), W4Int<1>());
         }
-        iteration(s, W4Int<0>(), W4Int<1>(), W4Int<0>());
-        iteration(s + 1, W4Int<1>(), W4Int<0>(), W4Int<0>());
-    } else {
-        int s = 0;
-        for (; s + 2 < nst; s += 2) {
-            iteration(s, W4Int<0>(), W4Int<1>(), W4Int<1>());
-            iteration(s + 1, W4Int<1>(), W4Int<1>(), W4Int<1>());
-        }
-        iteration(s, W4Int<0>(), W4Int<1>(), W4Int<1>());
-        iteration(s + 1, W4Int<1>(), W4Int<0>(), W4Int<1>());
+        iteration(s, W4Int<0>(), W4Int<1>());
+        iteration(s + 1, W4Int<1>(), W4Int<0>());
     }
     W4TS(2);
     const int eb = b, ex0 = x0, ey0 = y0, en0 = n0;          // this block's coordinates (the state moves on to the next block below)
@@ -388,29 +393,43 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         acc[1][r] = __builtin_fmaf(2.f, d34, d12);
         acc[2][r] = __builtin_fmaf(4.f, s34, s12);
         acc[3][r] = __builtin_fmaf(8.f, d34, d12) + m5;
-        const float h0 = acc[6][r], h1 = acc[7][r], h2 = acc[8][r];
-        if (q & 1) {
+    }
+    if (q & 1) {                                             // (ONE wave-uniform branch around the whole loop)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = acc[6][r], h1 = acc[7][r];
             acc[6][r] = h0 + h1;
             acc[7][r] = h0 - h1;
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = acc[6][r], h1 = acc[7][r], h2 = acc[8][r];
             acc[6][r] = (h0 + h1) + h2;
             acc[7][r] = h1 - h2;
             acc[8][r] = h1 + h2;
         }
     }
+    W4TS(4);
     int tide = tid;                                          // (through an empty asm per block: the epilogue's address arithmetic must not be hoisted out
     asm volatile("" : "+v"(tide));                           //  of the block loop - it would sit in registers through the K loop)
     const int lanee = tide & 63;
     const int rb = wid & 3;                                  // reader: output column inside a patch (wave-uniform)
     const int p16 = (wid >> 2) * 8 + (lanee >> 3);           // ... patch inside the pass
     const int n4 = (lanee & 7) * 4;                          // ... channel quad (and 32 + n4)
-    floatx4 bv[2], mu, rs;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) bv[h] = bias ? *reinterpret_cast<const floatx4*>(bias + en0 + h * 32 + n4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 mu, rs;
     if (EPI == LWG_EPI_SPADE) {
         mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + (en0 >> 1) + n4);
         rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)eb * a.YC + (en0 >> 1) + n4);
     }
+    // image eb of the output (and of res / xn: the output's layout) as ONE buffer: a reader thread's four pixels are 32-bit offsets inside it (out of
+    // range: right of / below the image - the hardware drops the store and returns zeros for the load), the second channel group an immediate
+    typedef unsigned int w4_u4 __attribute__((ext_vector_type(4)));
+    const unsigned img_bytes = (unsigned)(H * W) * (unsigned)a.YC * 4u;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)eb * H * W * a.YC, 0, (int)img_bytes, 0x00020000);
+    const float* const esrc = EPI == LWG_EPI_SPADE ? a.xn : EPI == LWG_EPI_RESIDUAL ? a.res : a.y;
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(esrc) + (size_t)eb * H * W * a.YC, 0, (int)img_bytes, 0x00020000);
+    const int chan = EPI == LWG_EPI_SPADE ? (en0 >> 1) + n4 : a.ycoff + en0 + n4;
     bool more = false;
     int nblk = blk;
 #pragma unroll
@@ -428,6 +447,20 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
                     *reinterpret_cast<floatx4*>(dst + (16 + 3 * q + i) * 16 * W4_MSR + 8 * g) = floatx4{acc[6 + i][4 * g], acc[6 + i][4 * g + 1], acc[6 + i][4 * g + 2], acc[6 + i][4 * g + 3]};
             }
         }
+        // this pass's pixels: patch p, output column rb, rows 0..3
+        const int p = ph * 16 + p16;
+        const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
+        unsigned vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            vo[i] = ox < W && oyb + i < H ? (unsigned)(((oyb + i) * W + ox) * a.YC + chan) * 4u : W4_OOB;
+        floatx4 ext[2][4];                                   // residual (both channel groups) | xn (group 0)
+        if (EPI != LWG_EPI_NONE) {
+#pragma unroll
+            for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : 2); ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[i] + 128u * h, 0u);
+        }
         if (ph == 1) {
             // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
             // (unconditional: the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
@@ -437,10 +470,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             issue_loads();
         }
         __syncthreads();
-        const int p = ph * 16 + p16;
-        const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
-        lwg_act_dispatch(a.act, [&](auto ACTC) {
-        constexpr int EA = decltype(ACTC)::value;
+        if (ph == 0) W4TS(5); else W4TS(7);
         floatx4 gam[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -461,52 +491,50 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
                 if (rb == 3) f += *reinterpret_cast<const floatx4*>(hb + 5 * 16 * W4_MSR);
                 F[4 + r] = f;
             }
-            floatx4 Y[4];
+            floatx4 o[4];                                    // the four rows of this thread's output column (bias included: see the accumulators' start)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float s12 = F[1][c] + F[2][c], d12 = F[1][c] - F[2][c], s34 = F[3][c] + F[4][c], d34 = F[3][c] - F[4][c];
-                Y[0][c] = (F[0][c] + s12) + s34;
-                Y[1][c] = __builtin_fmaf(2.f, d34, d12);
-                Y[2][c] = __builtin_fmaf(4.f, s34, s12);
-                Y[3][c] = __builtin_fmaf(8.f, d34, d12) + F[5][c];
+                o[0][c] = (F[0][c] + s12) + s34;
+                o[1][c] = __builtin_fmaf(2.f, d34, d12);
+                o[2][c] = __builtin_fmaf(4.f, s34, s12);
+                o[3][c] = __builtin_fmaf(8.f, d34, d12) + F[5][c];
             }
+            if (EPI == LWG_EPI_SPADE) {
+                if (h == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int oy = oyb + i;
-                floatx4 v = Y[i] + bv[h];
-                const bool in = oy < H && ox < W;
-                if (EPI == LWG_EPI_SPADE) {
-                    if (h == 0) {
-                        gam[i] = v;                          // gamma
-                    } else if (in) {
-                        const floatx4 xn = *reinterpret_cast<const floatx4*>(a.xn + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4);
-                        floatx4 o;
+                    for (int i = 0; i < 4; ++i) gam[i] = o[i];   // gamma
+                    continue;
+                }
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>((xn[c] - mu[c]) * rs[c] * (1.f + gam[i][c]) + v[c], a.act);
-                        *reinterpret_cast<floatx4*>(y + (((size_t)eb * H + oy) * W + ox) * a.YC + (en0 >> 1) + n4) = o;
-                    }
-                } else if (in) {
-                    const size_t off = (((size_t)eb * H + oy) * W + ox) * a.YC + a.ycoff + en0 + h * 32 + n4;
-                    floatx4 o;
-                    if (EPI == LWG_EPI_RESIDUAL) {
-                        const floatx4 e = *reinterpret_cast<const floatx4*>(a.res + off);
-                        if (lwg_act_is_mask<EA>(a.act)) {    // data gradient behind a ReLU: res = the forward input, the mask source
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = e[c] > 0.f ? v[c] : 0.f;
-                        } else {
-                            v += e;
+                    for (int c = 0; c < 4; ++c) o[i][c] = (ext[0][i][c] - mu[c]) * rs[c] * (1.f + gam[i][c]) + o[i][c];
+            } else if (EPI == LWG_EPI_RESIDUAL) {
+                if (a.act == LWG_ACT_RELU_MASK) {            // data gradient behind a ReLU: res = the forward input, the mask source
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>(v[c], a.act);
-                        }
-                    } else {
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = lwg_act_c<EA>(v[c], a.act);
-                    }
-                    *reinterpret_cast<floatx4*>(y + off) = o;
+                        for (int c = 0; c < 4; ++c) o[i][c] = ext[h][i][c] > 0.f ? o[i][c] : 0.f;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] += ext[h][i];
                 }
             }
+            // (the activation resolved once per sixteen values - lwg_common.h; around the whole output pass the four copies of the pass cost registers:
+            // 40-90 spilled, their reloads between the stores each waiting for every store before them)
+            lwg_act_dispatch(a.act, [&](auto ACTC) {
+                constexpr int EA = decltype(ACTC)::value;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[i][c] = lwg_act_c<EA>(o[i][c], a.act);
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[i] + (EPI == LWG_EPI_SPADE ? 0u : 128u * h)), 0, 0);
         }
-        });
+        if (ph == 0) W4TS(6);
     }
     W4TS(3);
 #ifdef LWG_W4_TS
@@ -586,6 +614,7 @@ static bool lwg_wino4_contract(const LwgConvArgs& a) {
     }
     const unsigned long long cmax = (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1);
     if ((unsigned long long)a.H * a.W * cmax * 4ull >= (unsigned long long)W4_OOB || 192ull * (a.C0 + a.C1) * a.N >= 0xffffffffull) return false;
+    if ((unsigned long long)a.H * a.W * a.YC * 4ull + 256ull >= (unsigned long long)W4_OOB) return false;      // (an output image is one buffer of the store path)
     return true;
 }
 
@@ -593,7 +622,7 @@ extern "C" int lwg_conv2d_winograd4_f32(const LwgConvArgs* pa, lwg_stream_t stre
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa || !lwg_wino4_contract(*pa)) return (int)hipErrorInvalidValue;
     const LwgConvArgs& a = *pa;
-    const size_t lds = (size_t)(W4_LOOP > W4_MS ? W4_LOOP : W4_MS) * 4;
+    const size_t lds = (size_t)(W4_BIAS_OFF + 64) * 4;
     const int bx = (a.W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (a.H + 4 * W4_PBY - 1) / (4 * W4_PBY);
     const int cus = lwg_device_cus();
     const long total = (long)bx * by * a.B * (a.N / W4_NB);

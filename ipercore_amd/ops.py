@@ -253,7 +253,7 @@ def _wwino(spec):
 
 
 WINO4 = True            # lab switch: in the "winograd" mode the synthesis path's eligible launches with Cin >= WINO4_MIN_CIN run the F(4x4, 3x3) kernel
-WINO4_MIN_CIN = 128     # below it the F(2x2, 3x3) kernel stays (a block's K loop must pay for the 28-plane exchange of the F(4x4, 3x3) epilogue)
+WINO4_MIN_CIN = 64      # below it the F(2x2, 3x3) kernel stays (a block's K loop must pay for the 28-plane exchange of the F(4x4, 3x3) epilogue)
 
 
 def _wino4_use(spec, splitk):

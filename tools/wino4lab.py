@@ -39,8 +39,9 @@ if args.parity:
     SHAPES = [("tiny 8x8 32->64", 2, 8, 8, 32, 0, 64, "none"),
               ("ragged 19x45 32->64 res", 3, 19, 45, 32, 0, 64, "res"),
               ("1-row 1x70 64->64", 2, 1, 70, 64, 0, 64, "none"),
-              ("ragged 33x17 40+24->128", 2, 33, 17, 40, 24, 128, "none"),
+              ("ragged 33x17 32+32->128", 2, 33, 17, 32, 32, 128, "none"),
               ("two-input 50x34 64+32->64 res", 2, 50, 34, 64, 32, 64, "res"),
+              ("two-input 37x41 96+32->128 spade", 2, 37, 41, 96, 32, 64, "spade"),
               ("spade 21x37 32->2x64", 2, 21, 37, 32, 0, 64, "spade"),
               ("spade 64^2 128->2x96 tanh", 2, 64, 64, 128, 0, 96, "spade"),
               ("res 40x40 160->192 mask", 2, 40, 40, 160, 0, 192, "mask"),
@@ -123,6 +124,9 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
         nst = Cin // 8
         print(f"[ts] {tag} B={B}: {int(ok.sum())} workgroups with a second block; medians (cycles): prologue {float((u[:, 1] - u[:, 0]).median()):.0f}  K loop {float((u[:, 2] - u[:, 1]).median()):.0f}"
               f" ({float((u[:, 2] - u[:, 1]).median()) / nst:.0f} per stage; ideal 4608)  epilogue {float((u[:, 3] - u[:, 2]).median()):.0f}")
+        md = lambda i1, i0: float((u[:, i1] - u[:, i0]).median())
+        print(f"     steady-state stage (stamps at s = 2 and s = 6): {md(10, 9) / 4:.0f} cycles; epilogue: fold {md(4, 2):.0f}, pass 0 writes + barriers {md(5, 4):.0f}, pass 0 output {md(6, 5):.0f}, "
+              f"pass 1 writes + next block's loads + barriers {md(7, 6):.0f}, pass 1 output {md(3, 7):.0f}")
         continue
 
     def run(kind):
