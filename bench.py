@@ -85,9 +85,10 @@ class ConvTimer:
             info = info or {"kernels": 1, "kind": "direct"}
             self.kernels += info["kernels"]                  # a call whose input exceeds the 32-bit buffer range runs as batch slices
             self.flops += 2.0 * M * spec.algo_kn
-            # EXECUTED matrix-pipe flops: the F(2x2, 3x3) Winograd kernel forms 16 products per 2 x 2 outputs where the direct form has 36
+            # EXECUTED matrix-pipe flops: the F(2x2, 3x3) Winograd kernel forms 16 products per 2 x 2 outputs where the direct form has 36, the
+            # F(4x4, 3x3) kernel 36 per 4 x 4 outputs where the direct form has 144,
             # ... and the F(2x2, 2x2) form of a transposed convolution 36 per 4 x 4 input patch where the direct form has 64
-            ex = 2.0 * M * spec.algo_kn * {"winograd": 4.0 / 9.0, "winograd_up4": 9.0 / 16.0}.get(info["kind"], 1.0)
+            ex = 2.0 * M * spec.algo_kn * {"winograd": 4.0 / 9.0, "winograd4": 2.25 / 9.0, "winograd_up4": 9.0 / 16.0}.get(info["kind"], 1.0)
             self.exec_flops += ex
             k = self.kinds.setdefault(info["kind"], [0, 0.0, 0.0, [], 0.0, 0])     # calls, algorithmic flops, executed flops, event pairs, bytes, kernels
             k[0] += 1
@@ -736,6 +737,7 @@ def main(argv=None):
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     ap.add_argument("--tiny-arch", action="store_true", help="reduced-width generator (plumbing tests only; never a reported number)")
     ap.add_argument("--no-self-check", dest="self_check", action="store_false")
+    ap.add_argument("--lab-no-wino4", action="store_true", help="lab A/B: the F(4x4,3x3) kernel off (every eligible 3x3 layer on the F(2x2,3x3) kernel, rounds 5-6's engine)")
     ap.add_argument("--no-sizes-extra", dest="sizes_extra", action="store_false")
     ap.add_argument("--no-exchange-u8", dest="exchange_u8", action="store_false", help="N > 1 with the f32 exchange: skip the extra uint8-exchange loop")
     args = ap.parse_args(argv)
@@ -769,6 +771,8 @@ def main(argv=None):
         args.gather_dtype = "f32"
 
     from ipercore_amd import ops, sharding, synthetic as pu      # product path only; the oracle is imported in cpu_baseline()
+    if args.lab_no_wino4:
+        ops.WINO4 = False
 
     S = args.size
     # frames per launch batch (FB_512 above): N = 1 - the whole clip as one batch; N > 1 - 32 at 512x512 fp32 (the 64x64-feature layers have
@@ -944,7 +948,7 @@ def main(argv=None):
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands + bf16 activation storage, f32 accumulation",
                       "split": "f32 in/out/accumulate, products as 6 bf16 MFMAs over an exact 3-way split",
                       "winograd": "f32"}[args.precision],
-            "conv_engine": {"winograd": "fp32 MFMA: 3x3 / stride 1 layers as fused F(2x2,3x3) Winograd convolutions (lwg_conv_winograd_kernel), the transposed "
+            "conv_engine": {"winograd": "fp32 MFMA: 3x3 / stride 1 layers as fused F(4x4,3x3) Winograd convolutions (lwg_conv_winograd4_kernel; Cin < 64: F(2x2,3x3), lwg_conv_winograd_kernel), the transposed "
                                         "convolutions as fused F(2x2,2x2) Winograd convolutions (lwg_convt_winograd_kernel), the strided / first layers as direct "
                                         "implicit GEMMs (lwg_conv_igemm_kernel)",
                             "fp32": "fp32 MFMA: every layer as a direct implicit GEMM (lwg_conv_igemm_kernel)",
@@ -995,7 +999,8 @@ def main(argv=None):
                         cfg.get("precision", "fp32") == args.precision:   # same launches
                     traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
                     # like for like (round 6): the counters per KERNEL FAMILY against that family's own algorithmic bytes per kernel launch
-                    fam = {"lwg_conv_winograd_kernel": "winograd", "lwg_convt_winograd_kernel": "winograd_up4", "lwg_conv_igemm_kernel": "direct"}
+                    fam = {"lwg_conv_winograd_kernel": "winograd", "lwg_conv_winograd4_kernel": "winograd4", "lwg_convt_winograd_kernel": "winograd_up4",
+                           "lwg_conv_igemm_kernel": "direct"}
                     traffic_by_kernel = {}
                     for kname, rec in (tj.get("by_kernel") or {}).items():
                         bk = conv_by_kind.get(fam.get(kname, kname)) or {}
@@ -1018,8 +1023,8 @@ def main(argv=None):
                                            "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "
                                                     "MFMA work actually executed) + fp32 first layers",
-                                           "winograd": "lwg_conv_winograd_kernel (F(2x2,3x3) on the fp32 MFMA pipe: achieved counts the EXECUTED flops, "
-                                                       "2 M 4 Cin N on those launches) + lwg_convt_winograd_kernel (F(2x2,2x2) form of the transposed convolutions: "
+                                           "winograd": "lwg_conv_winograd4_kernel (F(4x4,3x3) on the fp32 MFMA pipe: achieved counts the EXECUTED flops, "
+                                                       "2 M 2.25 Cin N on those launches; F(2x2,3x3) launches: 2 M 4 Cin N) + lwg_convt_winograd_kernel (F(2x2,2x2) form of the transposed convolutions: "
                                                        "2 M 9 Cin N per input pixel instead of 16) + lwg_conv_igemm_kernel for the strided / first layers"}[args.precision],
                                 "launches": n_launch, "avg_launch_us": round(mean_launch_ms * 1e3, 2), "streams": args.streams,
                                 "algorithmic_gflop_per_frame": round(conv_flops * world / frames / 1e9, 2),
@@ -1031,6 +1036,8 @@ def main(argv=None):
                 line["roofline"]["by_kernel"] = conv_by_kind
                 if wk.get("executed_tflops"):
                     line["roofline"]["winograd_kernel_frac"] = round(wk["executed_tflops"] / peak, 4)
+                if (conv_by_kind.get("winograd4") or {}).get("executed_tflops"):
+                    line["roofline"]["winograd4_kernel_frac"] = round(conv_by_kind["winograd4"]["executed_tflops"] / peak, 4)
                 if (conv_by_kind.get("winograd_up4") or {}).get("executed_tflops"):
                     line["roofline"]["winograd_up4_kernel_frac"] = round(conv_by_kind["winograd_up4"]["executed_tflops"] / peak, 4)
             if args.precision == "bf16":

@@ -490,6 +490,78 @@ def winograd_panel(spec):
     return U.view(16, cin // 8, 4, 2, N).permute(0, 1, 3, 4, 2).contiguous().float()
 
 
+W4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
+W4_BT = [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]]
+W4_AT = [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]
+
+
+def winograd4_product(q, j):
+    """(xi, nu) of product j (0..8) of wave set q (0..3) of csrc/conv_winograd4.hip: the row xi = q, then three products of row 4 + q // 2."""
+    return (q, j) if j < 6 else (4 + q // 2, 3 * (q % 2) + j - 6)
+
+
+def winograd4_panel(spec):
+    """lwg_winograd4_panel_f32's contract in torch (fp64, rounded once): Upk[4][Cin/8][4][2][N][12] from the fp32 GEMM panel of a 3x3 ConvSpec."""
+    K4, N, _ = spec.w.shape
+    cin, nt = spec.Cin, spec.ntaps
+    assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin
+    wk = spec.w.permute(0, 2, 1).reshape(K4 * 4, N)
+    w = wk.view(cin // 32, nt, 32, N).permute(1, 0, 2, 3).reshape(nt, cin, N).double()     # [tap][c][n]
+    g = w.new_zeros(3, 3, cin, N)
+    for t in range(nt):
+        g[spec.dy[t] + 1, spec.dx[t] + 1] = w[t]
+    G = torch.tensor(W4_G, dtype=torch.float64)
+    U = torch.einsum("ij,jkcn,lk->ilcn", G, g, G)                                        # [xi][nu][c][n]
+    out = torch.zeros(4, cin // 8, 4, 2, N, 12, dtype=torch.float64)
+    for q in range(4):
+        for j in range(9):
+            xi, nu = winograd4_product(q, j)
+            out[q, :, :, :, :, j] = U[xi, nu].view(cin // 8, 4, 2, N)                        # c = 8 s + 2 kk + kh
+    return out.float()
+
+
+def winograd4_conv(x, panel, bias=None):
+    """The F(4x4, 3x3) algorithm of csrc/conv_winograd4.hip restated around the panel (NHWC fp32 in, NHWC out; fp64 arithmetic): V = B^T d B per 6 x 6 patch
+    (stride 4, halo origin -1), 36 channel contractions with the panel's products, the nu fold per wave set (whole rows 0..3, half rows 4 / 5 as three
+    partial sums each), the reader's reconstruction of rows 4 / 5 and the xi fold - the bias enters as the start value of product (1, 1)."""
+    B, H, W, C = x.shape
+    _, _, _, _, N, _ = panel.shape
+    U = panel.double().permute(0, 5, 1, 2, 3, 4).reshape(4, 12, C, N)                       # [q][j][c][n]
+    BT, AT = torch.tensor(W4_BT, dtype=torch.float64), torch.tensor(W4_AT, dtype=torch.float64)
+    ph, pw = -(-H // 4), -(-W // 4)
+    xp = F.pad(x.double().permute(0, 3, 1, 2), [1, 4 * pw - W + 1, 1, 4 * ph - H + 1])
+    d = xp.unfold(2, 6, 4).unfold(3, 6, 4)                                                 # (B, C, ph, pw, 6, 6)
+    V = torch.einsum("ij,bcyxjk,lk->bcyxil", BT, d, BT)
+    M = x.new_zeros(6, 6, B, ph, pw, N, dtype=torch.float64)
+    for q in range(4):
+        for j in range(9):
+            xi, nu = winograd4_product(q, j)
+            M[xi, nu] = torch.einsum("bcyx,cn->byxn", V[..., xi, nu], U[q, j])
+    if bias is not None:
+        M[1, 1] += bias.double()
+    planes = {}
+    for q in range(4):
+        m = M[q]
+        s12, d12, s34, d34 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+        for b_, f in enumerate(((m[0] + s12) + s34, 2 * d34 + d12, 4 * s34 + s12, 8 * d34 + d12 + m[5])):
+            planes[4 * q + b_] = f
+        h = M[4 + q // 2][3 * (q % 2):3 * (q % 2) + 3]
+        P = (h[0] + h[1], h[0] - h[1], h[2]) if q % 2 else ((h[0] + h[1]) + h[2], h[1] - h[2], h[1] + h[2])
+        for i in range(3):
+            planes[16 + 3 * q + i] = P[i]
+    Y = x.new_zeros(4, 4, B, ph, pw, N, dtype=torch.float64)
+    for rb in range(4):
+        Fs = [planes[4 * xi + rb] for xi in range(4)]
+        ia, ib, cb = (0 if rb == 0 else 2 if rb == 2 else 1), (4 if rb & 1 else 3), float(1 << rb)
+        for r in range(2):
+            f = planes[16 + 6 * r + ia] + cb * planes[16 + 6 * r + ib]
+            Fs.append(f + planes[16 + 6 * r + 5] if rb == 3 else f)
+        s12, d12, s34, d34 = Fs[1] + Fs[2], Fs[1] - Fs[2], Fs[3] + Fs[4], Fs[3] - Fs[4]
+        for a_, yv in enumerate(((Fs[0] + s12) + s34, 2 * d34 + d12, 4 * s34 + s12, 8 * d34 + d12 + Fs[5])):
+            Y[a_, rb] = yv
+    return Y.permute(2, 3, 0, 4, 1, 5).reshape(B, 4 * ph, 4 * pw, N)[:, :H, :W]
+
+
 def _crop_ref(x, box, out_hw):
     """lwg_crop_resize_bilinear_f32's contract in the reference's own formulation (faceloss.py:384-406): per-sample slice + F.interpolate."""
     N = x.shape[0]

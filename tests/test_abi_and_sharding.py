@@ -63,6 +63,8 @@ def test_invalid_arguments_are_rejected_on_the_host():
     assert L.lwg_prelu_f32(None, None, None, 4, 64, None, None) == 1 and L.lwg_prelu_f32(bad, bad, None, 4, 6, bad, None) == 1      # C % 4
     assert L.lwg_prelu_bwd_f32(bad, bad, None, 4, 64, bad, None) == 1                                                               # no dy
     assert L.lwg_conv_slice_count(None) == 0
+    assert L.lwg_conv2d_winograd4_f32(None, None) == 1 and L.lwg_conv2d_winograd4_f32(ctypes.byref(a), None) == 1
+    assert L.lwg_winograd4_panel_f32(None, None, 64, 64, None, None) == 1 and L.lwg_winograd4_panel_f32(bad, bad, 48, 64, (ctypes.c_int * 9)(), None) == 1     # Cin % 32
     assert L.lwg_conv2d_winograd_ws_floats(None) == 0 and L.lwg_conv2d_winograd_f32_ws(None, None, None) == 1
     assert L.lwg_conv2d_nhwc_f32(None, None) == 1
     assert L.lwg_conv2d_nhwc_f32(a, None) == 1                                   # NULL tensors

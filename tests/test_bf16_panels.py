@@ -357,3 +357,44 @@ def test_winograd_panel_and_eligibility():
     sp2 = packing.pack_conv(torch.randn(N, 96, 3, 3, generator=g), b, stride=1, pad=1)
     assert ok(spec=sp2, x0=torch.zeros(1, 8, 8, 64), x1=torch.zeros(1, 8, 8, 32))
     assert ok(spec=spec, y=torch.zeros(1, 8, 8, N // 2), epi=ops.EPI_SPADE) and not ok(spec=spec, epi=ops.EPI_SPADE)
+
+
+def test_winograd4_panel_algorithm_and_rule():
+    """csrc/conv_winograd4.hip (F(4x4, 3x3)) on the CPU: the fragment panel's contract (tests/emu_ops.winograd4_panel: U = G w G^T, products dealt to the four
+    wave sets as (row q) + (three products of row 4 + q // 2), twelve floats per element with three of padding), the algorithm restated around that panel
+    exactly as the kernel folds it (whole rows, half rows as three partial sums, the bias as the start value of product (1, 1)) equals the convolution on
+    ragged sizes, and ops._wino4_use is a rule on the LAYER only (never on the batch: batch invariance)."""
+    import torch.nn.functional as F
+    from ipercore_amd import ops
+    from ipercore_amd.networks import packing
+    from tests import emu_ops
+    g = torch.Generator().manual_seed(5)
+    N, Cin = 64, 32
+    w, b = torch.randn(N, Cin, 3, 3, generator=g) * 0.1, torch.randn(N, generator=g)
+    spec = packing.pack_conv(w, b, stride=1, pad=1)
+    Upk = emu_ops.winograd4_panel(spec)
+    assert tuple(Upk.shape) == (4, Cin // 8, 4, 2, N, 12) and Upk.dtype == torch.float32
+    assert float(Upk[..., 9:].abs().max()) == 0.0
+    G = torch.tensor(emu_ops.W4_G, dtype=torch.float64)
+    U = torch.einsum("ij,ncjk,lk->ilcn", G, w.double(), G)                    # [xi][nu][c][n]
+    seen = set()
+    for q in range(4):
+        for j in range(9):
+            xi, nu = emu_ops.winograd4_product(q, j)
+            seen.add((xi, nu))
+            got = Upk[q, :, :, :, :, j].reshape(Cin, N)                          # c = 8 s + 2 kk + kh
+            assert torch.allclose(got.double(), U[xi, nu], atol=1e-7), (q, j)
+    assert len(seen) == 36                                                    # every product of the 6 x 6 patch exactly once
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._wwino4(spec)
+    for (B, H, W) in ((1, 10, 14), (2, 5, 33), (1, 1, 7)):
+        x = torch.randn(B, H, W, Cin, generator=g)
+        y = emu_ops.winograd4_conv(x, Upk, b)
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        assert tuple(y.shape) == tuple(want.shape)
+        assert float((y - want).abs().max()) <= 2e-5, float((y - want).abs().max())      # (the panel is rounded to fp32 once)
+    # the rule: the layer's Cin, never the batch; training launches (splitk) keep the F(2x2, 3x3) kernel and its split plan
+    assert ops.WINO4 and ops._wino4_use(packing.pack_conv(torch.zeros(64, ops.WINO4_MIN_CIN, 3, 3), None, stride=1, pad=1), False)
+    assert not ops._wino4_use(spec, True)
+    if ops.WINO4_MIN_CIN > 32:
+        assert not ops._wino4_use(spec, False)

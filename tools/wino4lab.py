@@ -131,8 +131,11 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
 
     def run(kind):
         if kind == "d":
-            with ops.conv_precision("fp32"):
-                ops.conv2d(x0, spec, yd, x1=x1, **kw)
+            try:
+                with ops.conv_precision("fp32"):
+                    ops.conv2d(x0, spec, yd, x1=x1, **kw)
+            except RuntimeError:                             # (shapes the direct kernel's contract does not take: SPADE with N % 128, C0 % 32 of two inputs)
+                pass
         else:
             ops.WINO4, ops.WINO4_MIN_CIN = kind == "w4", 0
             with ops.conv_precision("winograd"):
