@@ -451,6 +451,46 @@ def b1_latency(im, tgt, timer, n_frames=64):
                     out[f"bitwise_{k}_streams_vs_1"] = bool(torch.equal(fr, ref))
         finally:
             im.streams, im._side_streams = prev_streams, None
+        # the latency engine (generator.conv_precision = "winograd2x2": the F(4x4,3x3) kernel off): a one-frame F(4x4,3x3) launch of a 64 x 64 layer is 32
+        # workgroups of 2.25 K stages' worth each; the F(2x2,3x3) kernel's small-launch form gives the same layer 128.  Each engine is batch-invariant in
+        # itself (checked here: frames of one-frame launches = the same frames in a batch of 8); the two engines' frames differ at the 1e-5 level.
+        prev_prec = im.generator.conv_precision
+        if prev_prec == "winograd":
+            try:
+                ref1 = im.synthesize(tgt[:8], "smooth")
+                im.generator.conv_precision = "winograd2x2"
+                im.synthesize(tgt[:8], "smooth")
+                idle2 = []
+                for i in range(10):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    im.synthesize(tgt[i:i + 1], "smooth", t0=i)
+                    torch.cuda.synchronize()
+                    idle2.append((time.perf_counter() - t0) * 1e3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fr2 = im.synthesize(tgt[:n], "smooth")
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                im.frame_batch = 8
+                b8 = im.synthesize(tgt[:8], "smooth")
+                im.frame_batch = 1
+                im.streams, im._side_streams = 2, None
+                im.synthesize(tgt[:8], "smooth")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                im.synthesize(tgt[:n], "smooth")
+                torch.cuda.synchronize()
+                dt2s = time.perf_counter() - t0
+                out["latency_engine"] = {"conv_precision": "winograd2x2", "what": "every eligible 3x3 layer on the F(2x2,3x3) kernel (the F(4x4,3x3) kernel off)",
+                                         "ms_per_frame_back_to_back": round(dt2 / n * 1e3, 3), "ms_one_frame_from_idle_median": round(float(np.median(idle2)), 3),
+                                         "ms_per_frame_back_to_back_2_streams": round(dt2s / n * 1e3, 3),
+                                         "bitwise_frame_batch_1_vs_8": bool(torch.equal(fr2[:8], b8)),
+                                         "max_abs_diff_vs_default_engine": round((fr2[:8] - ref1).abs().max().item(), 8)}
+            finally:
+                im.generator.conv_precision = prev_prec
+                im.streams, im._side_streams = prev_streams, None
+                im.frame_batch = 1
         timer.reset()
         timer.enabled, ops.CONV_HOOK = True, timer
         torch.cuda.synchronize()
@@ -737,6 +777,7 @@ def main(argv=None):
     ap.add_argument("--conv-breakdown", action="store_true", help="write gpurun_out/conv_breakdown.json")
     ap.add_argument("--tiny-arch", action="store_true", help="reduced-width generator (plumbing tests only; never a reported number)")
     ap.add_argument("--no-self-check", dest="self_check", action="store_false")
+    ap.add_argument("--only-extras", default="", help="lab: comma-separated names of the separately reported measurements to run (default: all)")
     ap.add_argument("--lab-no-wino4", action="store_true", help="lab A/B: the F(4x4,3x3) kernel off (every eligible 3x3 layer on the F(2x2,3x3) kernel, rounds 5-6's engine)")
     ap.add_argument("--no-sizes-extra", dest="sizes_extra", action="store_false")
     ap.add_argument("--no-exchange-u8", dest="exchange_u8", action="store_false", help="N > 1 with the f32 exchange: skip the extra uint8-exchange loop")
@@ -1052,36 +1093,44 @@ def main(argv=None):
         timer.reset()
         if args.extras and world == 1 and args.streams == 1 and clip:
             Ke = max(2, K // 5)
+            only = set(filter(None, args.only_extras.split(",")))
+
+            def want(name):
+                return not only or name in only
 
             def render():
                 return im.synthesize(tgt, "smooth")
-            if args.pipelined_streams > 1:
+            if args.pipelined_streams > 1 and want("pipelined"):
                 line["pipelined"] = _extra(pipelined, im, render, n_clip, 1, Ke, args.pipelined_streams, tgt if args.self_check else None)
-            if args.split_extra and is_f32:
+            if args.split_extra and is_f32 and want("split_products"):
                 line["split_products"] = _extra(split_products, im, render, n_clip, 1, Ke, last)
                 if headline:
                     line["direct_products"] = _extra(direct_products, im, render, n_clip, 1, Ke, last)
                 else:
                     line["winograd_products"] = _extra(winograd_products, im, render, n_clip, 1, Ke, last)
-            if args.output_frames > 0:
+            if args.output_frames > 0 and want("with_output"):
                 # finer batches for the output pipeline: D2H / PNG encoding of batch t overlaps the synthesis of batch t+1, and a 160-frame
                 # measurement at 32 frames per batch is mostly pipeline fill and drain (408 vs 430 frames/s at 16)
                 line["with_output"] = _extra(with_output, im, tgt, min(FB, 16), args.output_frames, 0)
-            if headline and S == 512 and args.sizes_extra:
+            if headline and S == 512 and args.sizes_extra and want("sizes"):
                 line["sizes"] = {str(S2): size_extra(dev, timer, S2) for S2 in (256, 1024)}
-            if headline and S == 512 and clip:
+            if headline and S == 512 and clip and want("shard_of_8"):
                 line["shard_of_8"] = _extra(shard_of_8, im, tgt, n_clip)
             if headline and S == 512:
-                line["b1_latency"] = _extra(b1_latency, im, tgt, timer)
+                if want("b1_latency"):
+                    line["b1_latency"] = _extra(b1_latency, im, tgt, timer)
                 ops.CONV_HOOK = hook
-                try:
-                    line["novel_view_1024_bf16"] = novel_view_1024_bf16(dev, timer, 1, 3)
-                except Exception as e:
-                    line["novel_view_1024_bf16"] = {"error": f"{type(e).__name__}: {e}"}
-                line["personalize_step"] = personalize_step_extra()
+                if want("novel_view_1024_bf16"):
+                    try:
+                        line["novel_view_1024_bf16"] = novel_view_1024_bf16(dev, timer, 1, 3)
+                    except Exception as e:
+                        line["novel_view_1024_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+                if want("personalize_step"):
+                    line["personalize_step"] = personalize_step_extra()
                 # the reference's DEFAULT loss set (VGG19 perceptual + SphereFace on seeded weights: the licensed checkpoints are not
                 # available offline; same cost per step).  The face crop reads its box on the host, so this step runs eager launches.
-                line["personalize_step_vgg_face"] = personalize_step_extra(steps=6, warmup=3, extra_args=("--use-vgg", "--use-face"))
+                if want("personalize_step_vgg_face"):
+                    line["personalize_step_vgg_face"] = personalize_step_extra(steps=6, warmup=3, extra_args=("--use-vgg", "--use-face"))
         if args.cpu_frames > 0 and world == 1:          # the CPU baseline is an N = 1 measurement (rank 0 only)
             small = pu.build_case(image_size=S, n_frames=args.cpu_frames, ns=2)
             line["cpu_baseline"] = _extra(cpu_baseline, small, args.cpu_frames)

@@ -139,10 +139,11 @@ int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, int total_b
 /* The same layers as a fused F(4x4, 3x3) Winograd convolution (csrc/conv_winograd4.hip; round 6): 36 multiplies per 4 x 4 outputs = 2.25 per output
  * (F(2x2, 3x3): 4, direct: 9).  lwg_conv2d_winograd_f32's launch description and contract (one or two inputs, LWG_EPI_NONE / _RESIDUAL / _SPADE, any
  * activation incl. LWG_ACTIVATION_RELU_MASK with LWG_EPI_RESIDUAL, any batch size in one launch) EXCEPT args->w = the fragment panel
- * Upk[4][Cin/8][4][2][N][12] (192 Cin N bytes): element (q, s, kk, kh, n, j) of input channel c = 8 s + 2 kk + kh (concatenated order) and output column n =
- * (G w G^T)[xi][nu] with (xi, nu) = (q, j) for j < 6, (4 + q / 2, 3 (q % 2) + j - 6) for j = 6..8 (j = 9..11: zero padding), G = [[1/4,0,0],[-1/6,-1/6,-1/6],
- * [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] (points 0, +-1, +-2, inf).  fp32-grade results (relative L2 error against fp64 ~15x the direct
- * kernel's, 3e-6), neither the direct nor the F(2x2, 3x3) kernel's bits; a frame's result does not depend on the batch it is launched in. */
+ * Upk[4][Cin/8][4][2][9 N] (144 Cin N bytes): block (q, s, kk, kh) of input channel c = 8 s + 2 kk + kh (concatenated order) holds, for output column n and
+ * product j, (G w G^T)[xi][nu] at [n][j] (j = 0..3), 4 N + [n][j - 4] (j = 4..7), 8 N + [n] (j = 8), with (xi, nu) = (q, j) for j < 6 and
+ * (4 + q / 2, 3 (q % 2) + j - 6) for j = 6..8; G = [[1/4,0,0],[-1/6,-1/6,-1/6],
+ * [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] (points 0, +-1, +-2, inf).  fp32-grade results (relative L2 error against fp64 1-4e-6:
+ * 0.4-4.3x the direct kernel's on the adversarial operands of tests/gpu_checks.py), neither the direct nor the F(2x2, 3x3) kernel's bits; a frame's result does not depend on the batch it is launched in. */
 int lwg_conv2d_winograd4_f32(const LwgConvArgs* args, lwg_stream_t stream);
 /* That panel from the fp32 GEMM panel of the same convolution (arguments as lwg_winograd_panel_f32): U = G w G^T in fp64, rounded once. */
 int lwg_winograd4_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream);

@@ -10,8 +10,8 @@
 // products for the block's 32 patches x 32 channels (9 accumulator tiles of 32 x 32 = 144 VGPRs, rows = output channels - the transposed kernel's shape):
 // the whole row xi = q of the transformed patch (nu = 0..5) and three products of row 4 + q / 2 (nu = 3 (q % 2) .. + 2).  The nu half of A^T M A is then
 // register-local for rows 0..3 and half-local for rows 4, 5: 28 planes of (patch, channel) values cross LDS in the epilogue.
-// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the panel
-// Upk[4][Cin/8][4][2][N][12] (two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS, each one right behind the MFMA that
+// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights as two 16-byte and one 4-byte buffer loads from the panel
+// Upk[4][Cin/8][4][2][9 N] (every instruction reads contiguous memory; two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS, each one right behind the MFMA that
 // used its register for the previous k-pair.  The raw 34 x 18 x 8 halo goes global -> registers -> raw[s % 2] (channel-major planes, rows of 36 floats);
 // the 256 (patch, channel) transforms of the next stage are shared by the 512 threads: waves 0-3 form rows 0..2 of B^T d B, waves 4-7 rows 3..5 (72 vector
 // instructions per thread and stage), one barrier per stage in front of k-pair 3.
@@ -47,14 +47,22 @@
 // lab instrumentation (compiled out of the product): tools/wino4lab.py --ts on a -DLWG_W4_TS variant library; wave 0 stamps into args->res (LWG_EPI_NONE)
 #ifdef LWG_W4_TS
 #define W4TS(i) do { if (tid == 0 && lab_bi == 1) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define W4TSA(i) do { if (tid == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W4TS(i) do { } while (0)
+#define W4TSA(i) do { } while (0)
 #endif
 
 template <int V> struct W4Int { static constexpr int value = V; };
 
 __device__ __forceinline__ floatx4 w4_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#ifndef W4_NT
+#define W4_NT 0              // cache policy of the activation traffic (halo loads, output stores): 0 = default; 2 = non-temporal: measured 20 % SLOWER (profiles/r06_w_*)
+#endif
+__device__ __forceinline__ floatx4 w4_buf_load_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, W4_NT));
 }
 
 // the 1-D input transform B^T (.) of six values
@@ -85,14 +93,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     const int total = tiles * (N / W4_NB);
     int blk = blockIdx.x;
     const int nst = Cin / W4_KS;                             // even (host: Cin % 16 == 0)
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(144u * (unsigned)Cin * (unsigned)N), 0x00020000);
     const int q = wid & 3, ct = wid >> 2;                    // this wave's product set and 32-channel tile
     const int half = wid >> 2;                               // ... and its half of the input transform (rows 3 half .. 3 half + 2 of B^T d B)
     floatx16 acc[9];                                         // products 0..5: (xi = q, nu); 6..8: (xi = 4 + q / 2, nu = 3 (q % 2) + 0..2)
     int b, x0, y0, n0;
     __amdgpu_buffer_rsrc_t rx0, rx1;
     unsigned voff0[W4_NQ], voff1[W4_NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
-    unsigned uvoff;                                          // this lane's column of the fragment panel
+    unsigned uvoff, uvoffc;                                  // this lane's column of the fragment panel: the 16-byte parts, the ninth product
     auto setup = [&](int id) {
         const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
         int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
@@ -114,7 +122,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             voff0[k] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * hq) * 4u : W4_OOB;
             if constexpr (TWO) voff1[k] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * hq) * 4u : W4_OOB;
         }
-        uvoff = (unsigned)((((lane >> 5) * N + n0 + ct * 32 + (lane & 31)) * 12) * 4);
+        uvoff = (unsigned)(((lane >> 5) * 9 * N + 4 * (n0 + ct * 32 + (lane & 31))) * 4);
+        uvoffc = (unsigned)(((lane >> 5) * 9 * N + 8 * N + n0 + ct * 32 + (lane & 31)) * 4);
     };
     setup(blk);
     int wst[W4_NQ];                                          // the halo elements' LDS slot
@@ -126,14 +135,18 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     }
     floatx4 rreg[W4_NQ];
     auto rld1 = [&](int st, int k) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
+#ifdef W4_LAB_HFIX            // lab: every halo load reads stage 0
+        const int c = 0 * st;
+#else
         const int c = st * W4_KS;
+#endif
         if constexpr (!TWO) {
-            return w4_buf_load(rx0, voff0[k], (unsigned)c * 4u);
+            return w4_buf_load_nt(rx0, voff0[k], (unsigned)c * 4u);
         } else {
             const bool first = c < a.C0;
             const __amdgpu_buffer_rsrc_t r = first ? rx0 : rx1;
             const unsigned v = first ? voff0[k] : voff1[k];
-            return w4_buf_load(r, v, (unsigned)(first ? c : c - a.C0) * 4u);
+            return w4_buf_load_nt(r, v, (unsigned)(first ? c : c - a.C0) * 4u);
         }
     };
     auto rst1 = [&](int buf, int k, floatx4 v) {
@@ -142,10 +155,33 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         for (int c = 0; c < 4; ++c) dst[c * W4_PLANE] = v[c];
     };
     // weights: lane = (k-half lane / 32, channel lane % 32); element (q, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
-    floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 + padding]: loaded TWO k-pairs ahead
-    const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
+    // weights: lane = (k-half lane / 32, channel lane % 32); element (q, stage, k-pair, k-half) = 9 N floats: [N][4] products 0-3, [N][4] products 4-7, [N] product 8 -
+    // every load instruction reads contiguous memory (32 lanes x 16 bytes), nothing is padding
+    floatx4 ufa[4], ufb[4];                                  // [register set = k-pair]: loaded TWO k-pairs ahead
+    float ufc[4];
+    const unsigned ukk = (unsigned)N * 72u;                  // bytes between two k-pairs: [2][9 N] floats
     const unsigned uq = (unsigned)q * (unsigned)nst * 4u * ukk;
-    auto uld1 = [&](int st, int kk, int j) -> floatx4 { return w4_buf_load(ru, uvoff + 16u * j, uq + (unsigned)(st * 4 + kk) * ukk); };
+    const unsigned ubo = (unsigned)N * 16u;                  // bytes from part A to part B
+    auto uldpart = [&](int set, int st, int kk, int part) {  // part 0 | 1 | 2: products 0-3 | 4-7 | 8
+#ifdef W4_LAB_UFIX
+        const unsigned so = uq + 0u * (unsigned)(st + kk);
+#else
+        const unsigned so = uq + (unsigned)(st * 4 + kk) * ukk;
+#endif
+        if (part == 0) ufa[set] = w4_buf_load(ru, uvoff, so);
+        else if (part == 1) ufb[set] = w4_buf_load(ru, uvoff, so + ubo);
+        else ufc[set] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (int)uvoffc, (int)so, 0));
+    };
+    auto uldset = [&](int set, int st, int kk) {
+#ifdef W4_LAB_UFIX            // lab: every weight load reads k-pair 0 of stage 0 (cache-hot: the loads' issue / wait mechanics without the memory system behind them)
+        const unsigned so = uq + 0u * (unsigned)(st + kk);
+#else
+        const unsigned so = uq + (unsigned)(st * 4 + kk) * ukk;
+#endif
+        ufa[set] = w4_buf_load(ru, uvoff, so);
+        ufb[set] = w4_buf_load(ru, uvoff, so + ubo);
+        ufc[set] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (int)uvoffc, (int)so, 0));
+    };
     // the input transform's thread: patch tid % 32, channel (tid / 32) % 8, rows 3 half .. 3 half + 2
     const int patch = tid & 31, tc = (tid >> 5) & 7;
     const int pty = patch >> 3, ptx = patch & 7;
@@ -215,59 +251,66 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         const int s3 = s + 3 < nst ? s + 3 : nst - 1;        // past the end: a harmless re-load of the last stage (its halo store lands in a dead buffer)
         float X[6], P[6], Q[6], dR[3][6];
         auto mf = [&](int kk, int j, bool refill) {          // product j of k-pair kk; then its register takes the fragment of the next k-pair
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[kk][j >> 2][j & 3], fb[j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < 4 ? ufa[kk][j & 3] : j < 8 ? ufb[kk][j & 3] : ufc[kk], fb[j], acc[j], 0, 0, 0);
+#ifndef W4_KO_FRAG
             if (refill) fb[j] = kk < 3 ? frag1(set, kk + 1, j) : frag1(set ^ 1, 0, j);
+#endif
             W4SB();
         };
-        auto uldn = [&](int kk) {                            // the weights of the k-pair after the next (kk + 2 of this stage, or kk - 2 of the next)
-            if (kk < 2) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ufr[kk + 2][j] = uld1(s, kk + 2, j);
-            } else if (nxt) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ufr[kk - 2][j] = uld1(s + 1, kk - 2, j);
-            }
+        auto ul = [&](int kk, int part) {                    // ONE load of them
+#ifndef W4_KO_ULD
+            if (kk < 2) uldpart(kk + 2, s, kk + 2, part);
+            else if (nxt) uldpart(kk - 2, s + 1, kk - 2, part);
+#endif
             W4SB();
         };
         auto halo = [&](int k) {                             // the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3
+#ifdef W4_KO_HALO
+            return;
+#endif
             if (nxt) { rst1(set, k, rreg[k]); rreg[k] = rld1(s3, k); }
             W4SB();
         };
+#ifdef W4_KO_TR
+        constexpr bool trn = false;
+#else
+        constexpr bool trn = nxt;
+#endif
         auto rdX = [&](int i) {                              // the rows of X
-            if (nxt) rd6(dbx, set ^ 1, 2 * i, dR[i]);
+            if (trn) rd6(dbx, set ^ 1, 2 * i, dR[i]);
             W4SB();
         };
         auto colX = [&](int j0) {
-            if (nxt) {
+            if (trn) {
 #pragma unroll
                 for (int j = j0; j < j0 + 3; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
             }
             W4SB();
         };
         auto rdP = [&](int i) {                              // rows 2, 4 (-> P), then rows 1, 3 (-> Q)
-            if (nxt) rd6(dbs, set ^ 1, 2 * i + 2, dR[i]);
+            if (trn) rd6(dbs, set ^ 1, 2 * i + 2, dR[i]);
             W4SB();
         };
         auto rdQ = [&](int i) {
-            if (nxt) rd6(dbs, set ^ 1, 2 * i + 1, dR[i]);
+            if (trn) rd6(dbs, set ^ 1, 2 * i + 1, dR[i]);
             W4SB();
         };
         auto colP = [&]() {
-            if (nxt) {
+            if (trn) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
             }
             W4SB();
         };
         auto colQ = [&]() {
-            if (nxt) {
+            if (trn) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
             }
             W4SB();
         };
         auto rowX = [&]() {                                  // B^T (.) over the columns of a row, six V stores
-            if (nxt) {
+            if (trn) {
                 float v[6];
                 w4_bt6(X, v);
                 vst6(vbx, set ^ 1, 0, v);
@@ -275,7 +318,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             W4SB();
         };
         auto rowT = [&](int i) {
-            if (nxt) {
+            if (trn) {
                 float T[6], v[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(i ? nbeta : beta, Q[j], P[j]);
@@ -284,37 +327,45 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             }
             W4SB();
         };
-        // k-pair 0: the halo of stage s + 2 -> raw, the loads of stage s + 3; the rows of X of the next stage's patch
-        uldn(0);
-        mf(0, 0, true); halo(0);
-        mf(0, 1, true); halo(1);
-        mf(0, 2, true); halo(2);
-        mf(0, 3, true); rdX(0);
-        mf(0, 4, true); rdX(1);
-        mf(0, 5, true); rdX(2);
-        mf(0, 6, true);
-        mf(0, 7, true); colX(0);
-        mf(0, 8, true); colX(3);
+        // Slot plan: the stage's fifteen loads (twelve weight parts two k-pairs ahead, three halo pieces a stage ahead) ONE per MFMA slot - requested in
+        // bursts (six weight loads at the top of a k-pair, by eight waves at once) the memory pipeline's queue fills and the wave stalls in front of its
+        // next MFMA (profiles/r06_z_*: with every load cache-hot the K loop still lost 20 % to its fillers; the transform and the fragment reads cost 1 % each)
+        // k-pair 0: the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3; the rows of X of the next stage's patch
+        mf(0, 0, true); ul(0, 0);
+        mf(0, 1, true); halo(0);
+        mf(0, 2, true); ul(0, 1); rdX(0);
+        mf(0, 3, true); halo(1); rdX(1);
+        mf(0, 4, true); ul(0, 2); rdX(2);
+        mf(0, 5, true); halo(2);
+        mf(0, 6, true); colX(0);
+        mf(0, 7, true); colX(3);
+        mf(0, 8, true); rdP(0);
         // k-pair 1: the rest of the column pass, the row pass
-        uldn(1);
-        mf(1, 0, true); rdP(0);
-        mf(1, 1, true); rdP(1);
-        mf(1, 2, true); rowX();
-        mf(1, 3, true); colP(); rdQ(0);
-        mf(1, 4, true); rdQ(1);
-        mf(1, 5, true);
-        mf(1, 6, true); colQ();
-        mf(1, 7, true); rowT(0);
-        mf(1, 8, true);
+        mf(1, 0, true); ul(1, 0); rdP(1);
+        mf(1, 1, true); rowX();
+        mf(1, 2, true); ul(1, 1); colP(); rdQ(0);
+        mf(1, 3, true); rdQ(1);
+        mf(1, 4, true); ul(1, 2);
+        mf(1, 5, true); colQ();
+        mf(1, 6, true); rowT(0);
+        mf(1, 7, true);
+        mf(1, 8, true); rowT(1);
         // k-pair 2
-        uldn(2);
-        mf(2, 0, true); rowT(1);
-        mf(2, 1, true); mf(2, 2, true); mf(2, 3, true); mf(2, 4, true); mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
+        mf(2, 0, true); ul(2, 0);
+        mf(2, 1, true);
+        mf(2, 2, true); ul(2, 1);
+        mf(2, 3, true);
+        mf(2, 4, true); ul(2, 2);
+        mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
         // k-pair 3: behind the stage's barrier (the refills read the NEXT stage's fragments)
-        uldn(3);
         __syncthreads();
         W4SB();
-        mf(3, 0, nxt); mf(3, 1, nxt); mf(3, 2, nxt); mf(3, 3, nxt); mf(3, 4, nxt); mf(3, 5, nxt); mf(3, 6, nxt); mf(3, 7, nxt); mf(3, 8, nxt);
+        mf(3, 0, nxt); ul(3, 0);
+        mf(3, 1, nxt);
+        mf(3, 2, nxt); ul(3, 1);
+        mf(3, 3, nxt);
+        mf(3, 4, nxt); ul(3, 2);
+        mf(3, 5, nxt); mf(3, 6, nxt); mf(3, 7, nxt); mf(3, 8, nxt);
     };
 
     // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested here for
@@ -328,11 +379,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             r0[k] = rld1(0, k);
             r1[k] = rld1(1, k);
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ufr[0][j] = uld1(0, 0, j);
-            ufr[1][j] = uld1(0, 1, j);
-        }
+        uldset(0, 0, 0);
+        uldset(1, 0, 1);
 #pragma unroll
         for (int k = 0; k < W4_NQ; ++k) rreg[k] = rld1(nst > 2 ? 2 : 1, k);
     };
@@ -340,6 +388,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
 #ifdef LWG_W4_TS
     int lab_bi = 0;
 #endif
+    W4TSA(11);
     for (;;) {
     W4TS(0);
 #pragma unroll
@@ -532,7 +581,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             });
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[i] + (EPI == LWG_EPI_SPADE ? 0u : 128u * h)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[i] + (EPI == LWG_EPI_SPADE ? 0u : 128u * h)), 0, W4_NT);
         }
         if (ph == 0) W4TS(6);
     }
@@ -544,12 +593,16 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     blk = nblk;
     __syncthreads();                                         // every reader is done with the exchange buffer: raw[0] / raw[1] (the same LDS) may be written
     }
+    W4TSA(12);
+#ifdef LWG_W4_TS
+    if (tid == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res))[(size_t)blockIdx.x * 16 + 13] = (unsigned long long)lab_bi;
+#endif
 }
 
 
 // The fragment panel from the fp32 GEMM panel of the same convolution (lwg_conv2d_nhwc_f32's w: [9 Cin / 4][N][4], k = ((c / 32) 9 + tap) 32 + c % 32):
-// U = G w G^T (6 x 6) per (input channel, output column) in fp64, rounded once, written as Upk[4][Cin/8][4][2][N][12]: element (q, s, kk, kh, n, j) of input
-// channel c = 8 s + 2 kk + kh: j < 6: U[q][j]; j = 6..8: U[4 + q / 2][3 (q % 2) + j - 6]; j = 9..11: padding (zero).  tap9[3 r + s] = the tap index of kernel
+// U = G w G^T (6 x 6) per (input channel, output column) in fp64, rounded once, written as Upk[4][Cin/8][4][2][9 N]: block (q, s, kk, kh) of input channel
+// c = 8 s + 2 kk + kh holds product j of column n at [n][j] (j = 0..3), 4 N + [n][j - 4] (j = 4..7), 8 N + [n] (j = 8); j < 6: U[q][j]; j = 6..8: U[4 + q / 2][3 (q % 2) + j - 6].  tap9[3 r + s] = the tap index of kernel
 // position (dy, dx) = (r - 1, s - 1) in the GEMM panel.  One thread per (c, n).
 struct LwgWino4Taps { int t[9]; };
 
@@ -573,15 +626,16 @@ __global__ __launch_bounds__(256) void lwg_winograd4_panel_kernel(const float* _
     const int s8 = c >> 3, kk = (c & 7) >> 1, kh = c & 1;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-        float* dst = U + (((((size_t)qq * (Cin >> 3) + s8) * 4 + kk) * 2 + kh) * N + n) * 12;
-        float o[12];
+        float* dst = U + ((((size_t)qq * (Cin >> 3) + s8) * 4 + kk) * 2 + kh) * 9 * (size_t)N;
+        float o[9];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
+        for (int j = 0; j < 9; ++j) {
             const int xi = j < 6 ? qq : 4 + (qq >> 1), nu = j < 6 ? j : 3 * (qq & 1) + (j - 6);
-            o[j] = j < 9 ? (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]) : 0.f;
+            o[j] = (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]);
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<floatx4*>(dst + 4 * j) = floatx4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+        *reinterpret_cast<floatx4*>(dst + 4 * n) = floatx4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<floatx4*>(dst + 4 * (size_t)N + 4 * n) = floatx4{o[4], o[5], o[6], o[7]};
+        dst[8 * (size_t)N + n] = o[8];
     }
 }
 
@@ -599,7 +653,7 @@ extern "C" int lwg_winograd4_panel_f32(const float* wpanel, float* upk, int Cin,
 
 // args: lwg_conv2d_winograd_f32's launch description (3 x 3 / stride 1 / pad 1, one or two inputs with C0 % 8 == 0, C1 % 8 == 0, (C0 + C1) % 16 == 0, N % 64 == 0,
 // YC % 4 == 0; LWG_EPI_NONE, LWG_EPI_RESIDUAL or LWG_EPI_SPADE; any activation of lwg_act) EXCEPT args->w = the F(4x4, 3x3) fragment panel of
-// lwg_winograd4_panel_f32, 192 Cin N bytes.
+// lwg_winograd4_panel_f32, 144 Cin N bytes.
 static bool lwg_wino4_contract(const LwgConvArgs& a) {
     if (!a.x0 || !a.w || !a.y || a.M <= 0 || a.ntaps != 9 || a.stride != 1 || a.omul != 1 || a.C0 <= 0 || (a.C0 % W4_KS) != 0 || a.C1 < 0 ||
         (a.C1 % W4_KS) != 0 || ((a.C0 + a.C1) % (2 * W4_KS)) != 0 || (a.C1 > 0 && !a.x1) || a.N <= 0 || (a.N % W4_NB) != 0 || a.OH != a.H || a.OW != a.W ||
@@ -613,7 +667,7 @@ static bool lwg_wino4_contract(const LwgConvArgs& a) {
         if (a.epi != LWG_EPI_NONE && (a.epi != LWG_EPI_RESIDUAL || !a.res)) return false;
     }
     const unsigned long long cmax = (unsigned long long)(a.C0 > a.C1 ? a.C0 : a.C1);
-    if ((unsigned long long)a.H * a.W * cmax * 4ull >= (unsigned long long)W4_OOB || 192ull * (a.C0 + a.C1) * a.N >= 0xffffffffull) return false;
+    if ((unsigned long long)a.H * a.W * cmax * 4ull >= (unsigned long long)W4_OOB || 144ull * (a.C0 + a.C1) * a.N >= 0xffffffffull) return false;
     if ((unsigned long long)a.H * a.W * a.YC * 4ull + 256ull >= (unsigned long long)W4_OOB) return false;      // (an output image is one buffer of the store path)
     return true;
 }

@@ -225,8 +225,11 @@ class AttentionLWBGenerator(nn.Module):
         self._packed = None
         # How the engine's convolutions run (ops.conv_precision):
         # "winograd" (default since round 5; BASELINE configs[1] / [2]: "AttLWB generator fp32"): fp32 tensors and fp32 MFMA arithmetic throughout;
-        #   the 3x3 / stride 1 layers (SPADE, residual blocks, skip convolutions: 81 % of the flops) as fused F(2x2,3x3) Winograd convolutions
-        #   (csrc/conv_winograd.hip: 16 products per 2 x 2 outputs instead of 36), everything else on the direct implicit-GEMM kernel;
+        #   the 3x3 / stride 1 layers (SPADE, residual blocks, skip convolutions: 81 % of the flops) as fused Winograd convolutions - F(4x4,3x3)
+        #   (csrc/conv_winograd4.hip, round 6: 36 products per 4 x 4 outputs instead of 144) for Cin >= 64, F(2x2,3x3) (csrc/conv_winograd.hip: 16 per
+        #   2 x 2 instead of 36) below -, the transposed convolutions as F(2x2,2x2), everything else on the direct implicit-GEMM kernel;
+        # "winograd2x2": the same with the F(4x4,3x3) kernel off (rounds 5 / 6's engine) - the latency engine of callers that render ONE frame per
+        #   call (2.4 against 3.6 ms per frame at frame batch 1: a one-frame F(4x4,3x3) launch is 32 workgroups on a 64^2 layer), 20 % slower on batches;
         # "fp32": every layer on the direct kernel (the rounds 1-4 default; frames differ from "winograd" by ~3e-6);
         # "bf16": BASELINE configs[3] - every activation tensor of the engine is stored as bf16, the convs run on the bf16 MFMA kernel
         #   (fp32 accumulation), InstanceNorm statistics / attention / head read bf16; the first conv of a stream takes the fp32 input;
@@ -355,7 +358,7 @@ class AttentionLWBGenerator(nn.Module):
             site += 1
         # fp32 MFMA path ("fp32": direct transposed convolutions; "winograd": lwg_conv_transpose4_winograd_f32, incl. this last layer): the last
         # up-sampling layer writes channel-quad planes, the layout the fp32 head stages whole lines from
-        q4 = adt == torch.float32 and self.conv_precision in ("fp32", "winograd")
+        q4 = adt == torch.float32 and self.conv_precision in ("fp32", "winograd", "winograd2x2")
         for i in range(n_down):
             if i == n_down - 1 and pk.head16 is not None and ops.up4_head_eligible(x, pk.upconvs[i], ops.ACT_RELU):
                 # bf16 engine (BASELINE configs[3]): the last up-sampling layer, the 5x5 regressors and the compositing as ONE launch - the

@@ -36,19 +36,25 @@ CONV_PRECISION = "fp32"
 
 
 class conv_precision(object):
-    """Context manager: ``with ops.conv_precision("bf16"): ...``."""
+    """Context manager: ``with ops.conv_precision("bf16"): ...``.  "winograd2x2" = "winograd" with the F(4x4, 3x3) kernel off (every eligible layer on
+    the F(2x2, 3x3) kernel - rounds 5 / 6's engine): the latency engine of single-frame callers (a one-frame launch of the F(4x4, 3x3) kernel is 32
+    workgroups on a 64^2 layer: 3.6 against 2.4 ms per frame at frame batch 1), 20 % slower on frame batches.  Each engine is batch-invariant in itself."""
 
     def __init__(self, mode):
-        assert mode in ("fp32", "bf16", "split", "winograd")
+        assert mode in ("fp32", "bf16", "split", "winograd", "winograd2x2")
         self.mode = mode
 
     def __enter__(self):
-        global CONV_PRECISION
-        self.prev, CONV_PRECISION = CONV_PRECISION, self.mode
+        global CONV_PRECISION, WINO4
+        self.prev = CONV_PRECISION, WINO4
+        if self.mode == "winograd2x2":
+            CONV_PRECISION, WINO4 = "winograd", False
+        else:
+            CONV_PRECISION = self.mode
 
     def __exit__(self, *exc):
-        global CONV_PRECISION
-        CONV_PRECISION = self.prev
+        global CONV_PRECISION, WINO4
+        CONV_PRECISION, WINO4 = self.prev
 
 
 # bench.py installs a callable(begin, M, spec, epi, info) to bracket conv entry-point calls with HIP events; info (the closing call only, else
@@ -265,7 +271,7 @@ def _wino4_use(spec, splitk):
 
 def _wwino4(spec):
     """The fragment panel of lwg_conv2d_winograd4_f32, built once per spec from the fp32 GEMM panel by ONE launch (lwg_winograd4_panel_f32):
-    U = G w G^T (6 x 6) per (input, output) channel pair in fp64, rounded once, stored [4][Cin/8][4][2][N][12]."""
+    U = G w G^T (6 x 6) per (input, output) channel pair in fp64, rounded once, stored [4][Cin/8][4][2][9 N] (include/lwg_hip.h)."""
     if spec._wwino4 is None or spec._wwino4.device != spec.w.device:
         K4, N, _ = spec.w.shape
         cin, nt = spec.Cin, spec.ntaps
@@ -275,7 +281,7 @@ def _wwino4(spec):
         tap9 = (ctypes.c_int * 9)()
         for t in range(nt):
             tap9[3 * (spec.dy[t] + 1) + spec.dx[t] + 1] = t
-        U = torch.empty(4, cin // 8, 4, 2, N, 12, device=spec.w.device, dtype=torch.float32)
+        U = torch.empty(4, cin // 8, 4, 2, 9 * N, device=spec.w.device, dtype=torch.float32)
         _lib.check(_lib.lib().lwg_winograd4_panel_f32(_ptr(spec.w), _ptr(U), cin, N, tap9, _stream()), "lwg_winograd4_panel_f32")
         spec._wwino4 = U
     return spec._wwino4

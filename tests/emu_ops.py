@@ -501,7 +501,8 @@ def winograd4_product(q, j):
 
 
 def winograd4_panel(spec):
-    """lwg_winograd4_panel_f32's contract in torch (fp64, rounded once): Upk[4][Cin/8][4][2][N][12] from the fp32 GEMM panel of a 3x3 ConvSpec."""
+    """lwg_winograd4_panel_f32's contract in torch (fp64, rounded once): Upk[4][Cin/8][4][2][9 N] from the fp32 GEMM panel of a 3x3 ConvSpec - per block
+    (q, s, kk, kh): [N][4] products 0-3, [N][4] products 4-7, [N] product 8."""
     K4, N, _ = spec.w.shape
     cin, nt = spec.Cin, spec.ntaps
     assert nt == 9 and cin % 32 == 0 and K4 * 4 == nt * cin
@@ -512,12 +513,25 @@ def winograd4_panel(spec):
         g[spec.dy[t] + 1, spec.dx[t] + 1] = w[t]
     G = torch.tensor(W4_G, dtype=torch.float64)
     U = torch.einsum("ij,jkcn,lk->ilcn", G, g, G)                                        # [xi][nu][c][n]
-    out = torch.zeros(4, cin // 8, 4, 2, N, 12, dtype=torch.float64)
+    out = torch.zeros(4, cin // 8, 4, 2, 9 * N, dtype=torch.float64)
     for q in range(4):
         for j in range(9):
             xi, nu = winograd4_product(q, j)
-            out[q, :, :, :, :, j] = U[xi, nu].view(cin // 8, 4, 2, N)                        # c = 8 s + 2 kk + kh
+            u = U[xi, nu].view(cin // 8, 4, 2, N)                                          # c = 8 s + 2 kk + kh
+            if j < 8:
+                out[q, :, :, :, (j // 4) * 4 * N + (j % 4):(j // 4 + 1) * 4 * N:4] = u
+            else:
+                out[q, :, :, :, 8 * N:] = u
     return out.float()
+
+
+def winograd4_panel_products(panel):
+    """[q][j][c][n] view of a panel (c = 8 s + 2 kk + kh)."""
+    _, ns, _, _, n9 = panel.shape
+    N = n9 // 9
+    ab = panel[..., :8 * N].reshape(4, ns, 4, 2, 2, N, 4).permute(0, 4, 6, 1, 2, 3, 5).reshape(4, 8, ns * 8, N)
+    c8 = panel[..., 8 * N:].reshape(4, 1, ns * 8, N)
+    return torch.cat([ab, c8], 1)
 
 
 def winograd4_conv(x, panel, bias=None):
@@ -525,8 +539,8 @@ def winograd4_conv(x, panel, bias=None):
     (stride 4, halo origin -1), 36 channel contractions with the panel's products, the nu fold per wave set (whole rows 0..3, half rows 4 / 5 as three
     partial sums each), the reader's reconstruction of rows 4 / 5 and the xi fold - the bias enters as the start value of product (1, 1)."""
     B, H, W, C = x.shape
-    _, _, _, _, N, _ = panel.shape
-    U = panel.double().permute(0, 5, 1, 2, 3, 4).reshape(4, 12, C, N)                       # [q][j][c][n]
+    U = winograd4_panel_products(panel.double())                                           # [q][j][c][n]
+    N = U.shape[3]
     BT, AT = torch.tensor(W4_BT, dtype=torch.float64), torch.tensor(W4_AT, dtype=torch.float64)
     ph, pw = -(-H // 4), -(-W // 4)
     xp = F.pad(x.double().permute(0, 3, 1, 2), [1, 4 * pw - W + 1, 1, 4 * ph - H + 1])

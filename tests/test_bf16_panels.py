@@ -361,7 +361,7 @@ def test_winograd_panel_and_eligibility():
 
 def test_winograd4_panel_algorithm_and_rule():
     """csrc/conv_winograd4.hip (F(4x4, 3x3)) on the CPU: the fragment panel's contract (tests/emu_ops.winograd4_panel: U = G w G^T, products dealt to the four
-    wave sets as (row q) + (three products of row 4 + q // 2), twelve floats per element with three of padding), the algorithm restated around that panel
+    wave sets as (row q) + (three products of row 4 + q // 2), nine floats per (column, block) in three contiguous parts), the algorithm restated around that panel
     exactly as the kernel folds it (whole rows, half rows as three partial sums, the bias as the start value of product (1, 1)) equals the convolution on
     ragged sizes, and ops._wino4_use is a rule on the LAYER only (never on the batch: batch invariance)."""
     import torch.nn.functional as F
@@ -373,8 +373,8 @@ def test_winograd4_panel_algorithm_and_rule():
     w, b = torch.randn(N, Cin, 3, 3, generator=g) * 0.1, torch.randn(N, generator=g)
     spec = packing.pack_conv(w, b, stride=1, pad=1)
     Upk = emu_ops.winograd4_panel(spec)
-    assert tuple(Upk.shape) == (4, Cin // 8, 4, 2, N, 12) and Upk.dtype == torch.float32
-    assert float(Upk[..., 9:].abs().max()) == 0.0
+    assert tuple(Upk.shape) == (4, Cin // 8, 4, 2, 9 * N) and Upk.dtype == torch.float32
+    prod = emu_ops.winograd4_panel_products(Upk)                               # [q][j][c][n]
     G = torch.tensor(emu_ops.W4_G, dtype=torch.float64)
     U = torch.einsum("ij,ncjk,lk->ilcn", G, w.double(), G)                    # [xi][nu][c][n]
     seen = set()
@@ -382,8 +382,10 @@ def test_winograd4_panel_algorithm_and_rule():
         for j in range(9):
             xi, nu = emu_ops.winograd4_product(q, j)
             seen.add((xi, nu))
-            got = Upk[q, :, :, :, :, j].reshape(Cin, N)                          # c = 8 s + 2 kk + kh
-            assert torch.allclose(got.double(), U[xi, nu], atol=1e-7), (q, j)
+            assert torch.allclose(prod[q, j].double(), U[xi, nu], atol=1e-7), (q, j)
+            blk = Upk[q, 1, 2, 1]                                                 # the block of input channel c = 8 + 4 + 1: [N][4] | [N][4] | [N]
+            where = blk[(j // 4) * 4 * N + (j % 4):(j // 4 + 1) * 4 * N:4] if j < 8 else blk[8 * N:]
+            assert torch.equal(where, prod[q, j, 13]), (q, j)
     assert len(seen) == 36                                                    # every product of the 6 x 6 patch exactly once
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops._wwino4(spec)

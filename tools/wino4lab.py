@@ -12,6 +12,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--w4only", action="store_true", help="time the F(4x4,3x3) kernel only (knock-out variant libraries: their results are wrong by construction)")
 ap.add_argument("--parity", action="store_true", help="small / ragged / odd shapes: correctness only")
 ap.add_argument("--ts", action="store_true", help="-DLWG_W4_TS build: per-block stamps of wave 0 (second block of every workgroup; plain epilogue)")
 args = ap.parse_args()
@@ -118,7 +119,17 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
             for _ in range(2):
                 ops.conv2d(x0, spec, y4, x1=x1, act=ops.ACT_RELU, res=stamps)
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        with ops.conv_precision("winograd"):
+            ops.conv2d(x0, spec, y4, x1=x1, act=ops.ACT_RELU, res=stamps)
+        e1.record()
+        torch.cuda.synchronize()
         t = stamps.view(torch.int64).view(nwg, 16).cpu()
+        tot_c, nb = (t[:, 12] - t[:, 11]).double(), t[:, 13].double()
+        ms = e0.elapsed_time(e1)
+        print(f"[ts] launch {ms * 1e3:.1f} us; per workgroup: {float(nb.mean()):.2f} blocks, {float(tot_c.median()):.0f} cycles entry -> exit (max {float(tot_c.max()):.0f}) = "
+              f"{float(tot_c.median()) / max(float(nb.median()), 1):.0f} per block; counter rate {float(tot_c.max()) / ms / 1e3:.0f} MHz if the slowest workgroup spans the launch")
         ok = t[:, 3] > 0
         u = t[ok].double()
         nst = Cin // 8
@@ -141,6 +152,12 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
             with ops.conv_precision("winograd"):
                 ops.conv2d(x0, spec, y4 if kind == "w4" else y2, x1=x1, **kw)
 
+    if args.w4only:
+        t4 = timeit(lambda: run("w4"), args.reps)
+        ex = 2.0 * B * H * W * 2.25 * Cin * N
+        tot["w4"] += t4
+        print(f"{idx} {tag:36s} B={B:3d}: F(4,3) {t4 * 1e3:8.1f} us executed {ex / t4 / 1e9 / 157.3:.3f} of the pipe", flush=True)
+        continue
     for k in ("w4", "w2", "d"):
         run(k)
     torch.cuda.synchronize()
@@ -158,7 +175,7 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
         line += (f" | F(4,3) {t['w4'] * 1e3:8.1f} us executed {ex / t['w4'] / 1e9 / 157.3:.3f} of the pipe, algorithmic {al / t['w4'] / 1e9:6.1f} TF/s"
                  f" | F(2,3) {t['w2'] * 1e3:8.1f} us (x{t['w2'] / t['w4']:.2f}) | direct {t['d'] * 1e3:8.1f} us (x{t['d'] / t['w4']:.2f})")
     print(line, flush=True)
-if tot["w4"] and args.only < 0:
+if tot["w4"] and args.only < 0 and not args.w4only:
     print(f"sum: F(4,3) {tot['w4'] * 1e3:.1f} us, F(2,3) {tot['w2'] * 1e3:.1f} us (x{tot['w2'] / tot['w4']:.2f}), direct {tot['d'] * 1e3:.1f} us (x{tot['d'] / tot['w4']:.2f})")
 print(f"worst max error of F(4,3) relative to max(1, |ref|): {worst:.2e}")
 if args.parity:
