@@ -30,6 +30,8 @@
 #define W4_HH 18             // halo rows
 #define W4_RS 36             // floats per halo row in LDS (16-byte aligned rows)
 #define W4_PLANE 652         // floats per channel plane: 18 x 36 + 4 (4 PLANE = 16 mod 32: the two channel quads of a pixel fall into different banks)
+                             // (lab: consecutive lanes = consecutive pixels of one quad + planes of 704 floats, i.e. ds_write2st64_b32 halo stores: 6-12 % SLOWER -
+                             //  a lane pair no longer reads 32 contiguous bytes; profiles/r06_y3_*)
 #define W4_RAW (W4_KS * W4_PLANE)
 #define W4_VS (36 * W4_KS * 32)                  // [product 6 xi + nu][k][patch]
 #define W4_NEL (W4_HW * W4_HH * 2)               // (pixel, channel quad) elements of a stage's halo
@@ -253,7 +255,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         auto mf = [&](int kk, int j, bool refill) {          // product j of k-pair kk; then its register takes the fragment of the next k-pair
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < 4 ? ufa[kk][j & 3] : j < 8 ? ufb[kk][j & 3] : ufc[kk], fb[j], acc[j], 0, 0, 0);
 #ifndef W4_KO_FRAG
-            if (refill) fb[j] = kk < 3 ? frag1(set, kk + 1, j) : frag1(set ^ 1, 0, j);
+            // (two fragments per LDS instruction: products j - 1 and j lie 1 KB apart - ds_read2st64_b32 -, refilled behind the second one's MFMA)
+            if (refill && (j & 1)) {
+                fb[j - 1] = kk < 3 ? frag1(set, kk + 1, j - 1) : frag1(set ^ 1, 0, j - 1);
+                fb[j] = kk < 3 ? frag1(set, kk + 1, j) : frag1(set ^ 1, 0, j);
+            } else if (refill && j == 8) {
+                fb[8] = kk < 3 ? frag1(set, kk + 1, 8) : frag1(set ^ 1, 0, 8);
+            }
 #endif
             W4SB();
         };
@@ -483,7 +491,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     int nblk = blk;
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-        __syncthreads();                                     // the loop's last fragment reads / the previous pass's readers are done
+        // (pass 0 needs no barrier in front of its writes: the last LDS reads of the K loop - the fragments of its last k-pair - were issued in front of
+        // the last stage's barrier; pass 1 waits for the readers of pass 0)
+        if (ph == 1) __syncthreads();
         if (((lanee >> 4) & 1) == ph) {
             float* dst = Ms + (lanee & 15) * W4_MSR + ct * 32 + 4 * (lanee >> 5);
 #pragma unroll
@@ -513,10 +523,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         if (ph == 1) {
             // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
             // (unconditional: the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
+            W4TS(8);
             nblk = blk + (int)gridDim.x;
             more = nblk < total;
             setup(more ? nblk : blk);
+            W4TS(9);
             issue_loads();
+            W4TS(10);
         }
         __syncthreads();
         if (ph == 0) W4TS(5); else W4TS(7);

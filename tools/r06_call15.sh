@@ -2,7 +2,7 @@
 # Round-6 call 15: F(4x4,3x3) kernel, weights in pairs + halo loads at k-pair 2 (tree) vs the first order (nt0 library)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r06_y2_wino4_spread.txt; : > $O
+O=gpurun_out/r06_y4_wino4_paired_frags.txt; : > $O
 timeout 200 python tools/wino4lab.py --parity 2>&1 | tail -2 >> $O
 for rep in 1 2; do
 for v in tree nt0; do

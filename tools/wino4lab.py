@@ -136,8 +136,8 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
         print(f"[ts] {tag} B={B}: {int(ok.sum())} workgroups with a second block; medians (cycles): prologue {float((u[:, 1] - u[:, 0]).median()):.0f}  K loop {float((u[:, 2] - u[:, 1]).median()):.0f}"
               f" ({float((u[:, 2] - u[:, 1]).median()) / nst:.0f} per stage; ideal 4608)  epilogue {float((u[:, 3] - u[:, 2]).median()):.0f}")
         md = lambda i1, i0: float((u[:, i1] - u[:, i0]).median())
-        print(f"     steady-state stage (stamps at s = 2 and s = 6): {md(10, 9) / 4:.0f} cycles; epilogue: fold {md(4, 2):.0f}, pass 0 writes + barriers {md(5, 4):.0f}, pass 0 output {md(6, 5):.0f}, "
-              f"pass 1 writes + next block's loads + barriers {md(7, 6):.0f}, pass 1 output {md(3, 7):.0f}")
+        print(f"     epilogue: fold {md(4, 2):.0f}, pass 0 writes + barriers {md(5, 4):.0f}, pass 0 output {md(6, 5):.0f}, "
+              f"pass 1: barrier + writes + offsets {md(8, 6):.0f}, next block's set-up {md(9, 8):.0f}, its loads issued {md(10, 9):.0f}, barrier {md(7, 10):.0f}, output {md(3, 7):.0f}")
         continue
 
     def run(kind):
