@@ -1029,7 +1029,7 @@ def main(argv=None):
         if self_check:
             line["self_check_detail"] = self_check
         if n_launch:
-            traffic, traffic_src, traffic_by_kernel = None, None, None
+            traffic, traffic_src, traffic_by_kernel, tj = None, None, None, {}
             tname = {"winograd": "pmc_traffic.json", "fp32": "pmc_traffic_direct.json", "bf16": "pmc_traffic_bf16.json"}.get(args.precision)
             tpath = os.path.join(ROOT, "profiles", tname) if tname else None       # written by tools/pmc_round.sh (separate --pmc passes)
             if tpath and S == (512 if is_f32 else 1024) and args.streams == 1 and os.path.exists(tpath):
@@ -1060,6 +1060,10 @@ def main(argv=None):
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(timer.bytes / n_launch, 1),
                                 "traffic_by_kernel": traffic_by_kernel,
+                                # like for like for the DOMINANT kernel (the one `traffic` is the counter figure of): its own algorithmic bytes per launch
+                                "traffic_kernel": tj.get("kernel") if traffic is not None else None,
+                                "traffic_over_algorithmic": ((traffic_by_kernel or {}).get(tj.get("kernel")) or {}).get("traffic_over_algorithmic")
+                                if traffic is not None else None,
                                 "kernel": {"fp32": "lwg_conv_igemm_kernel (fp32 MFMA implicit GEMM)",
                                            "bf16": "lwg_conv_igemm_bf16_kernel (bf16 MFMA implicit GEMM, bf16 activations) + fp32-input first layers",
                                            "split": "lwg_conv_igemm_split_kernel (bf16x6: achieved = 6 x algorithmic flops, the bf16 "

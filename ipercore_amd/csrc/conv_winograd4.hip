@@ -44,6 +44,9 @@
 #define W4_MS (W4_NPL * 16 * W4_MSR)             // one pass = 16 patches
 #define W4_BIAS_OFF (W4_LOOP > W4_MS ? W4_LOOP : W4_MS)          // the block's 64 bias values, behind both uses of the LDS
 #define W4_OOB 0xC0000000u
+#ifndef LWG_W4_SMALL
+#define LWG_W4_SMALL 1       // the 4-wave form for small launches (lab: 0 = off)
+#endif
 #define W4SB() __builtin_amdgcn_sched_barrier(0)
 
 // lab instrumentation (compiled out of the product): tools/wino4lab.py --ts on a -DLWG_W4_TS variant library; wave 0 stamps into args->res (LWG_EPI_NONE)
@@ -79,8 +82,19 @@ __device__ __forceinline__ void w4_bt6(const float (&r)[6], float (&v)[6]) {
     v[5] = __builtin_fmaf(-5.f, r[3], __builtin_fmaf(4.f, r[1], r[5]));
 }
 
-template <int EPI, bool TWO>
-__global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const LwgConvArgs a) {
+// SM (small launches - a frame or two -, plain / residual epilogues): 256 threads = the four waves q = 0..3 of ONE 32-channel tile - block = the same 32 patches x
+// 32 channels: twice the workgroups (one wave per SIMD: the 36 MFMAs of a wave and stage run unshared), every thread forms BOTH halves of its (patch, channel)
+// transform and stages five halo pieces.  Every output element is accumulated over the stages and k-pairs in the same order and finished by the same
+// expressions in both forms (the transform, the folds and the reader are explicit fma / add sequences): bitwise the same result - a frame does not depend on
+// its batch (check_winograd4: frame n of a 40-frame launch = the frame alone, across the forms).
+template <int EPI, bool TWO, bool SM = false>
+__global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_kernel(const LwgConvArgs a) {
+    static_assert(!(SM && EPI == LWG_EPI_SPADE), "the SPADE epilogue needs gamma | beta in one block");
+    constexpr int NTH = SM ? 256 : W4_THREADS;               // threads per workgroup
+    constexpr int NQ = SM ? 5 : W4_NQ;                       // halo pieces per thread and stage
+    constexpr int NBV = SM ? 32 : W4_NB;                     // output channels per block
+    constexpr int MSR = SM ? 36 : W4_MSR;                    // floats per (plane, patch) row of the exchange buffer
+    constexpr int NHF = SM ? 2 : 1;                          // halves of the input transform per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ bias = a.bias;
@@ -92,16 +106,16 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     const int bx = (W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (H + 4 * W4_PBY - 1) / (4 * W4_PBY);
     // persistent workgroups (as conv_winograd.hip): min(blocks, CUs) workgroups walk the block ids blockIdx.x + k gridDim.x (id = column block * tiles + tile)
     const int tiles = bx * by * a.B;
-    const int total = tiles * (N / W4_NB);
+    const int total = tiles * (N / NBV);
     int blk = blockIdx.x;
     const int nst = Cin / W4_KS;                             // even (host: Cin % 16 == 0)
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(144u * (unsigned)Cin * (unsigned)N), 0x00020000);
-    const int q = wid & 3, ct = wid >> 2;                    // this wave's product set and 32-channel tile
-    const int half = wid >> 2;                               // ... and its half of the input transform (rows 3 half .. 3 half + 2 of B^T d B)
+    const int q = wid & 3, ct = SM ? 0 : wid >> 2;           // this wave's product set and 32-channel tile
+    const int half = SM ? 0 : wid >> 2;                      // ... and its half of the input transform (rows 3 half .. 3 half + 2 of B^T d B; SM: both)
     floatx16 acc[9];                                         // products 0..5: (xi = q, nu); 6..8: (xi = 4 + q / 2, nu = 3 (q % 2) + 0..2)
     int b, x0, y0, n0;
     __amdgpu_buffer_rsrc_t rx0, rx1;
-    unsigned voff0[W4_NQ], voff1[W4_NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
+    unsigned voff0[NQ], voff1[NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
     unsigned uvoff, uvoffc;                                  // this lane's column of the fragment panel: the 16-byte parts, the ninth product
     auto setup = [&](int id) {
         const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
@@ -110,14 +124,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         t -= b * bx * by;
         x0 = (t % bx) * 4 * W4_PBX;
         y0 = (t / bx) * 4 * W4_PBY;
-        n0 = cb * W4_NB;
+        n0 = cb * NBV;
         rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
         if constexpr (TWO) rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * H * W * a.C1), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
         int tids = tid;                                      // (through an empty asm: the halo geometry is recomputed per block - hoisted out of the block
         asm volatile("" : "+v"(tids));                       //  loop it would sit in registers through the K loop)
 #pragma unroll
-        for (int k = 0; k < W4_NQ; ++k) {                    // padding pixels / threads without an element: an out-of-range offset (the hardware returns zeros)
-            const int i = tids + W4_THREADS * k;
+        for (int k = 0; k < NQ; ++k) {                       // padding pixels / threads without an element: an out-of-range offset (the hardware returns zeros)
+            const int i = tids + NTH * k;
             const int pix = i >> 1, hq = i & 1, hy = pix / W4_HW, hx = pix - hy * W4_HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool in = i < W4_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -128,14 +142,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         uvoffc = (unsigned)(((lane >> 5) * 9 * N + 8 * N + n0 + ct * 32 + (lane & 31)) * 4);
     };
     setup(blk);
-    int wst[W4_NQ];                                          // the halo elements' LDS slot
+    int wst[NQ];                                             // the halo elements' LDS slot
 #pragma unroll
-    for (int k = 0; k < W4_NQ; ++k) {
-        const int i = tid + W4_THREADS * k;
+    for (int k = 0; k < NQ; ++k) {
+        const int i = tid + NTH * k;
         const int pix = i >> 1, hq = i & 1, hy = pix / W4_HW, hx = pix - hy * W4_HW;
         wst[k] = i < W4_NEL ? 4 * hq * W4_PLANE + hy * W4_RS + hx : W4_DUMP_OFF + tid;
     }
-    floatx4 rreg[W4_NQ];
+    floatx4 rreg[NQ];
     auto rld1 = [&](int st, int k) -> floatx4 {              // a stage's 8 channels lie in ONE input (C0 % 8 == 0)
 #ifdef W4_LAB_HFIX            // lab: every halo load reads stage 0
         const int c = 0 * st;
@@ -190,15 +204,24 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     unsigned dbs = (unsigned)(tc * W4_PLANE + (4 * pty) * W4_RS + 4 * ptx) >> 2;      // its 6 x 6 input patch inside raw[0] (float index; 16-byte aligned)
     asm volatile("" : "+v"(dbs));
     dbs <<= 2;
-    unsigned dbx = (unsigned)(tc * W4_PLANE + (4 * pty + half) * W4_RS + 4 * ptx) >> 2;   // ... from row `half`: the rows of X (half, half + 2, half + 4)
-    asm volatile("" : "+v"(dbx));
-    dbx <<= 2;
-    // its 18 transformed values inside Vs[0]: row X (xi = 0 | 5) and rows T+, T- (xi = 1, 2 | 3, 4)
-    unsigned vbx = (unsigned)(2 * W4_RAW + (half ? 30 : 0) * W4_KS * 32 + tc * 32 + patch);
-    unsigned vbt = (unsigned)(2 * W4_RAW + (half ? 18 : 6) * W4_KS * 32 + tc * 32 + patch);
-    asm volatile("" : "+v"(vbx));
-    asm volatile("" : "+v"(vbt));
-    const float alpha = half ? -1.f : -4.f, beta = half ? 2.f : 1.f, nbeta = -beta;       // (wave-uniform: scalar operands)
+    // per half hf of the transform (this thread's one - index 0 - or, SM, both): the rows of X start at row hf; its 18 transformed values inside Vs[0]:
+    // row X (xi = 0 | 5) and rows T+, T- (xi = 1, 2 | 3, 4); alpha, beta (wave-uniform: scalar operands)
+    unsigned dbx[NHF], vbx[NHF], vbt[NHF];
+    float alpha[NHF], beta[NHF], nbeta[NHF];
+#pragma unroll
+    for (int hi = 0; hi < NHF; ++hi) {
+        const int hf = SM ? hi : half;
+        dbx[hi] = (unsigned)(tc * W4_PLANE + (4 * pty + hf) * W4_RS + 4 * ptx) >> 2;
+        asm volatile("" : "+v"(dbx[hi]));
+        dbx[hi] <<= 2;
+        vbx[hi] = (unsigned)(2 * W4_RAW + (hf ? 30 : 0) * W4_KS * 32 + tc * 32 + patch);
+        vbt[hi] = (unsigned)(2 * W4_RAW + (hf ? 18 : 6) * W4_KS * 32 + tc * 32 + patch);
+        asm volatile("" : "+v"(vbx[hi]));
+        asm volatile("" : "+v"(vbt[hi]));
+        alpha[hi] = hf ? -1.f : -4.f;
+        beta[hi] = hf ? 2.f : 1.f;
+        nbeta[hi] = -beta[hi];
+    }
     unsigned fbs[2];                                         // this lane's fragments: products 0..5 | 6..8, inside Vs[0]
     fbs[0] = (unsigned)(2 * W4_RAW + (6 * q) * W4_KS * 32 + lane);
     fbs[1] = (unsigned)(2 * W4_RAW + (6 * (4 + (q >> 1)) + 3 * (q & 1)) * W4_KS * 32 + lane);
@@ -222,30 +245,33 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     //   X  = 4 dx0 - 5 dx1 + dx2 over the rows (half, half + 2, half + 4)           = t0 | t5
     //   P  = d4 + alpha d2, Q = d3 + alpha d1 (alpha = -4 | -1); T+ = P + beta Q, T- = P - beta Q (beta = 1 | 2)   = t1, t2 | t3, t4
     auto transform_full = [&](int buf) {                     // prologue only
-        float X[6], P[6], Q[6], v[6];
-        {
-            float dR[3][6];
-            rd6(dbx, buf, 0, dR[0]); rd6(dbx, buf, 2, dR[1]); rd6(dbx, buf, 4, dR[2]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
+        for (int hi = 0; hi < NHF; ++hi) {
+            float X[6], P[6], Q[6], v[6];
+            {
+                float dR[3][6];
+                rd6(dbx[hi], buf, 0, dR[0]); rd6(dbx[hi], buf, 2, dR[1]); rd6(dbx[hi], buf, 4, dR[2]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
+            }
+            {
+                float dR[2][6];
+                rd6(dbs, buf, 2, dR[0]); rd6(dbs, buf, 4, dR[1]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha[hi], dR[0][j], dR[1][j]);
+                rd6(dbs, buf, 1, dR[0]); rd6(dbs, buf, 3, dR[1]);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha[hi], dR[0][j], dR[1][j]);
+            }
+            w4_bt6(X, v); vst6(vbx[hi], buf, 0, v);
+            float T[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(beta[hi], Q[j], P[j]);
+            w4_bt6(T, v); vst6(vbt[hi], buf, 0, v);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(nbeta[hi], Q[j], P[j]);
+            w4_bt6(T, v); vst6(vbt[hi], buf, 1, v);
         }
-        {
-            float dR[2][6];
-            rd6(dbs, buf, 2, dR[0]); rd6(dbs, buf, 4, dR[1]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
-            rd6(dbs, buf, 1, dR[0]); rd6(dbs, buf, 3, dR[1]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
-        }
-        w4_bt6(X, v); vst6(vbx, buf, 0, v);
-        float T[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(beta, Q[j], P[j]);
-        w4_bt6(T, v); vst6(vbt, buf, 0, v);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(nbeta, Q[j], P[j]);
-        w4_bt6(T, v); vst6(vbt, buf, 1, v);
     };
     auto iteration = [&](int s, auto SET, auto NXT) {
         constexpr int set = decltype(SET)::value;            // s % 2
@@ -284,87 +310,96 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
 #else
         constexpr bool trn = nxt;
 #endif
-        auto rdX = [&](int i) {                              // the rows of X
-            if (trn) rd6(dbx, set ^ 1, 2 * i, dR[i]);
-            W4SB();
-        };
-        auto colX = [&](int j0) {
+        // the next stage's transform in fourteen steps per half: 0-2 the rows of X, 3-4 X, 5-6 rows 2 / 4, 7 X's row of V, 8 P, 9-10 rows 1 / 3, 11 Q, 12-13 the rows T+ / T-
+        auto tr = [&](int hi, int step) {
             if (trn) {
+                if (step < 3) rd6(dbx[hi], set ^ 1, 2 * step, dR[step]);
+                else if (step < 5) {
 #pragma unroll
-                for (int j = j0; j < j0 + 3; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
-            }
-            W4SB();
-        };
-        auto rdP = [&](int i) {                              // rows 2, 4 (-> P), then rows 1, 3 (-> Q)
-            if (trn) rd6(dbs, set ^ 1, 2 * i + 2, dR[i]);
-            W4SB();
-        };
-        auto rdQ = [&](int i) {
-            if (trn) rd6(dbs, set ^ 1, 2 * i + 1, dR[i]);
-            W4SB();
-        };
-        auto colP = [&]() {
-            if (trn) {
+                    for (int j = 3 * (step - 3); j < 3 * (step - 3) + 3; ++j) X[j] = __builtin_fmaf(-5.f, dR[1][j], __builtin_fmaf(4.f, dR[0][j], dR[2][j]));
+                } else if (step < 7) rd6(dbs, set ^ 1, 2 * (step - 5) + 2, dR[step - 5]);
+                else if (step == 7) {
+                    float v[6];
+                    w4_bt6(X, v);
+                    vst6(vbx[hi], set ^ 1, 0, v);
+                } else if (step == 8) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
-            }
-            W4SB();
-        };
-        auto colQ = [&]() {
-            if (trn) {
+                    for (int j = 0; j < 6; ++j) P[j] = __builtin_fmaf(alpha[hi], dR[0][j], dR[1][j]);
+                } else if (step < 11) rd6(dbs, set ^ 1, 2 * (step - 9) + 1, dR[step - 9]);
+                else if (step == 11) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha, dR[0][j], dR[1][j]);
-            }
-            W4SB();
-        };
-        auto rowX = [&]() {                                  // B^T (.) over the columns of a row, six V stores
-            if (trn) {
-                float v[6];
-                w4_bt6(X, v);
-                vst6(vbx, set ^ 1, 0, v);
-            }
-            W4SB();
-        };
-        auto rowT = [&](int i) {
-            if (trn) {
-                float T[6], v[6];
+                    for (int j = 0; j < 6; ++j) Q[j] = __builtin_fmaf(alpha[hi], dR[0][j], dR[1][j]);
+                } else {
+                    float T[6], v[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(i ? nbeta : beta, Q[j], P[j]);
-                w4_bt6(T, v);
-                vst6(vbt, set ^ 1, i, v);
+                    for (int j = 0; j < 6; ++j) T[j] = __builtin_fmaf(step == 12 ? beta[hi] : nbeta[hi], Q[j], P[j]);
+                    w4_bt6(T, v);
+                    vst6(vbt[hi], set ^ 1, step - 12, v);
+                }
             }
             W4SB();
         };
         // Slot plan: the stage's fifteen loads (twelve weight parts two k-pairs ahead, three halo pieces a stage ahead) ONE per MFMA slot - requested in
         // bursts (six weight loads at the top of a k-pair, by eight waves at once) the memory pipeline's queue fills and the wave stalls in front of its
         // next MFMA (profiles/r06_z_*: with every load cache-hot the K loop still lost 20 % to its fillers; the transform and the fragment reads cost 1 % each)
-        // k-pair 0: the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3; the rows of X of the next stage's patch
-        mf(0, 0, true); ul(0, 0);
-        mf(0, 1, true); halo(0);
-        mf(0, 2, true); ul(0, 1); rdX(0);
-        mf(0, 3, true); halo(1); rdX(1);
-        mf(0, 4, true); ul(0, 2); rdX(2);
-        mf(0, 5, true); halo(2);
-        mf(0, 6, true); colX(0);
-        mf(0, 7, true); colX(3);
-        mf(0, 8, true); rdP(0);
-        // k-pair 1: the rest of the column pass, the row pass
-        mf(1, 0, true); ul(1, 0); rdP(1);
-        mf(1, 1, true); rowX();
-        mf(1, 2, true); ul(1, 1); colP(); rdQ(0);
-        mf(1, 3, true); rdQ(1);
-        mf(1, 4, true); ul(1, 2);
-        mf(1, 5, true); colQ();
-        mf(1, 6, true); rowT(0);
-        mf(1, 7, true);
-        mf(1, 8, true); rowT(1);
-        // k-pair 2
-        mf(2, 0, true); ul(2, 0);
-        mf(2, 1, true);
-        mf(2, 2, true); ul(2, 1);
-        mf(2, 3, true);
-        mf(2, 4, true); ul(2, 2);
-        mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
+        if constexpr (!SM) {
+            // k-pair 0: the halo of stage s + 2 -> raw[s % 2], the loads of stage s + 3; the rows of X of the next stage's patch
+            mf(0, 0, true); ul(0, 0);
+            mf(0, 1, true); halo(0);
+            mf(0, 2, true); ul(0, 1); tr(0, 0);
+            mf(0, 3, true); halo(1); tr(0, 1);
+            mf(0, 4, true); ul(0, 2); tr(0, 2);
+            mf(0, 5, true); halo(2);
+            mf(0, 6, true); tr(0, 3);
+            mf(0, 7, true); tr(0, 4);
+            mf(0, 8, true); tr(0, 5);
+            // k-pair 1: the rest of the column pass, the row pass
+            mf(1, 0, true); ul(1, 0); tr(0, 6);
+            mf(1, 1, true); tr(0, 7);
+            mf(1, 2, true); ul(1, 1); tr(0, 8); tr(0, 9);
+            mf(1, 3, true); tr(0, 10);
+            mf(1, 4, true); ul(1, 2);
+            mf(1, 5, true); tr(0, 11);
+            mf(1, 6, true); tr(0, 12);
+            mf(1, 7, true);
+            mf(1, 8, true); tr(0, 13);
+            // k-pair 2
+            mf(2, 0, true); ul(2, 0);
+            mf(2, 1, true);
+            mf(2, 2, true); ul(2, 1);
+            mf(2, 3, true);
+            mf(2, 4, true); ul(2, 2);
+            mf(2, 5, true); mf(2, 6, true); mf(2, 7, true); mf(2, 8, true);
+        } else {
+            // the small form: five halo pieces and both halves of the transform per thread in front of the barrier
+            mf(0, 0, true); ul(0, 0); halo(0);
+            mf(0, 1, true); tr(0, 0);
+            mf(0, 2, true); ul(0, 1); tr(0, 1);
+            mf(0, 3, true); halo(1); tr(0, 2);
+            mf(0, 4, true); ul(0, 2); tr(0, 3);
+            mf(0, 5, true); halo(2); tr(0, 4);
+            mf(0, 6, true); tr(0, 5);
+            mf(0, 7, true); halo(3); tr(0, 6);
+            mf(0, 8, true); tr(0, 7);
+            mf(1, 0, true); ul(1, 0); tr(0, 8); tr(0, 9);
+            mf(1, 1, true); halo(4); tr(0, 10);
+            mf(1, 2, true); ul(1, 1); tr(0, 11);
+            mf(1, 3, true); tr(0, 12);
+            mf(1, 4, true); ul(1, 2); tr(0, 13);
+            mf(1, 5, true); tr(1, 0);
+            mf(1, 6, true); tr(1, 1);
+            mf(1, 7, true); tr(1, 2);
+            mf(1, 8, true); tr(1, 3);
+            mf(2, 0, true); ul(2, 0); tr(1, 4);
+            mf(2, 1, true); tr(1, 5);
+            mf(2, 2, true); ul(2, 1); tr(1, 6);
+            mf(2, 3, true); tr(1, 7);
+            mf(2, 4, true); ul(2, 2); tr(1, 8); tr(1, 9);
+            mf(2, 5, true); tr(1, 10);
+            mf(2, 6, true); tr(1, 11);
+            mf(2, 7, true); tr(1, 12);
+            mf(2, 8, true); tr(1, 13);
+        }
         // k-pair 3: behind the stage's barrier (the refills read the NEXT stage's fragments)
         __syncthreads();
         W4SB();
@@ -378,19 +413,19 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
 
     // prologue loads of a block: stages 0 and 1 (-> raw[0], raw[1]), stage 2's halo (kept in registers), the first two k-pairs' weights - requested here for
     // the workgroup's first block, for every later one from inside the previous block's epilogue
-    floatx4 r0[W4_NQ], r1[W4_NQ];
+    floatx4 r0[NQ], r1[NQ];
     float bq;                                                // the block's bias, one value per lane of wave 0: requested with the first loads, parked in LDS by the prologue
     auto issue_loads = [&]() {
-        bq = bias ? bias[n0 + (tid & 63)] : 0.f;
+        bq = bias ? bias[n0 + (tid & (NBV - 1))] : 0.f;
 #pragma unroll
-        for (int k = 0; k < W4_NQ; ++k) {
+        for (int k = 0; k < NQ; ++k) {
             r0[k] = rld1(0, k);
             r1[k] = rld1(1, k);
         }
         uldset(0, 0, 0);
         uldset(1, 0, 1);
 #pragma unroll
-        for (int k = 0; k < W4_NQ; ++k) rreg[k] = rld1(nst > 2 ? 2 : 1, k);
+        for (int k = 0; k < NQ; ++k) rreg[k] = rld1(nst > 2 ? 2 : 1, k);
     };
     issue_loads();
 #ifdef LWG_W4_TS
@@ -400,11 +435,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     for (;;) {
     W4TS(0);
 #pragma unroll
-    for (int k = 0; k < W4_NQ; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         rst1(0, k, r0[k]);
         rst1(1, k, r1[k]);
     }
-    if (tid < 64) smem[W4_BIAS_OFF + tid] = bq;
+    if (tid < NBV) smem[W4_BIAS_OFF + tid] = bq;
     __syncthreads();
     transform_full(0);
     __syncthreads();
@@ -472,8 +507,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
     asm volatile("" : "+v"(tide));                           //  of the block loop - it would sit in registers through the K loop)
     const int lanee = tide & 63;
     const int rb = wid & 3;                                  // reader: output column inside a patch (wave-uniform)
-    const int p16 = (wid >> 2) * 8 + (lanee >> 3);           // ... patch inside the pass
-    const int n4 = (lanee & 7) * 4;                          // ... channel quad (and 32 + n4)
+    const int p16 = (wid >> 2) * 8 + (lanee >> 3);           // ... patch inside the pass (SM: lanee >> 3 and 8 + lanee >> 3)
+    const int n4 = (lanee & 7) * 4;                          // ... channel quad (and 32 + n4; SM: the block's only 32 channels)
     floatx4 mu, rs;
     if (EPI == LWG_EPI_SPADE) {
         mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + (en0 >> 1) + n4);
@@ -495,30 +530,33 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         // the last stage's barrier; pass 1 waits for the readers of pass 0)
         if (ph == 1) __syncthreads();
         if (((lanee >> 4) & 1) == ph) {
-            float* dst = Ms + (lanee & 15) * W4_MSR + ct * 32 + 4 * (lanee >> 5);
+            float* dst = Ms + (lanee & 15) * MSR + ct * 32 + 4 * (lanee >> 5);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb)
-                    *reinterpret_cast<floatx4*>(dst + (4 * q + bb) * 16 * W4_MSR + 8 * g) = floatx4{acc[bb][4 * g], acc[bb][4 * g + 1], acc[bb][4 * g + 2], acc[bb][4 * g + 3]};
+                    *reinterpret_cast<floatx4*>(dst + (4 * q + bb) * 16 * MSR + 8 * g) = floatx4{acc[bb][4 * g], acc[bb][4 * g + 1], acc[bb][4 * g + 2], acc[bb][4 * g + 3]};
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    *reinterpret_cast<floatx4*>(dst + (16 + 3 * q + i) * 16 * W4_MSR + 8 * g) = floatx4{acc[6 + i][4 * g], acc[6 + i][4 * g + 1], acc[6 + i][4 * g + 2], acc[6 + i][4 * g + 3]};
+                    *reinterpret_cast<floatx4*>(dst + (16 + 3 * q + i) * 16 * MSR + 8 * g) = floatx4{acc[6 + i][4 * g], acc[6 + i][4 * g + 1], acc[6 + i][4 * g + 2], acc[6 + i][4 * g + 3]};
             }
         }
-        // this pass's pixels: patch p, output column rb, rows 0..3
-        const int p = ph * 16 + p16;
-        const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
-        unsigned vo[4];
+        // this pass's pixels: patch p, output column rb, rows 0..3 (SM: two patches, one channel group)
+        unsigned vo[SM ? 2 : 1][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            vo[i] = ox < W && oyb + i < H ? (unsigned)(((oyb + i) * W + ox) * a.YC + chan) * 4u : W4_OOB;
-        floatx4 ext[2][4];                                   // residual (both channel groups) | xn (group 0)
+        for (int hp = 0; hp < (SM ? 2 : 1); ++hp) {
+            const int p = ph * 16 + (SM ? 8 * hp + (lanee >> 3) : p16);
+            const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                vo[hp][i] = ox < W && oyb + i < H ? (unsigned)(((oyb + i) * W + ox) * a.YC + chan) * 4u : W4_OOB;
+        }
+        floatx4 ext[2][4];                                   // residual (both channel groups | SM: both patches) | xn (group 0)
         if (EPI != LWG_EPI_NONE) {
 #pragma unroll
             for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : 2); ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[i] + 128u * h, 0u);
+                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[SM ? h : 0][i] + (SM ? 0u : 128u * h), 0u);
         }
         if (ph == 1) {
             // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
@@ -536,21 +574,21 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
         floatx4 gam[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float* base = Ms + p16 * W4_MSR + h * 32 + n4;
+            const float* base = Ms + (SM ? 8 * h + (lanee >> 3) : p16) * MSR + (SM ? 0 : h * 32) + n4;
             floatx4 F[6];
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi) F[xi] = *reinterpret_cast<const floatx4*>(base + (4 * xi + rb) * 16 * W4_MSR);
+            for (int xi = 0; xi < 4; ++xi) F[xi] = *reinterpret_cast<const floatx4*>(base + (4 * xi + rb) * 16 * MSR);
             const int ia = rb == 0 ? 0 : rb == 2 ? 2 : 1, ib = (rb & 1) ? 4 : 3;
             const float cb = (float)(1 << rb);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float* hb = base + (16 + 6 * r) * 16 * W4_MSR;
-                const floatx4 pa = *reinterpret_cast<const floatx4*>(hb + ia * 16 * W4_MSR);
-                const floatx4 pb = *reinterpret_cast<const floatx4*>(hb + ib * 16 * W4_MSR);
+                const float* hb = base + (16 + 6 * r) * 16 * MSR;
+                const floatx4 pa = *reinterpret_cast<const floatx4*>(hb + ia * 16 * MSR);
+                const floatx4 pb = *reinterpret_cast<const floatx4*>(hb + ib * 16 * MSR);
                 floatx4 f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) f[c] = __builtin_fmaf(cb, pb[c], pa[c]);
-                if (rb == 3) f += *reinterpret_cast<const floatx4*>(hb + 5 * 16 * W4_MSR);
+                if (rb == 3) f += *reinterpret_cast<const floatx4*>(hb + 5 * 16 * MSR);
                 F[4 + r] = f;
             }
             floatx4 o[4];                                    // the four rows of this thread's output column (bias included: see the accumulators' start)
@@ -594,7 +632,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void lwg_conv_winograd4_kernel(const
             });
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[i] + (EPI == LWG_EPI_SPADE ? 0u : 128u * h)), 0, W4_NT);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[SM ? h : 0][i] + (EPI == LWG_EPI_SPADE || SM ? 0u : 128u * h)), 0, W4_NT);
         }
         if (ph == 0) W4TS(6);
     }
@@ -692,23 +730,35 @@ extern "C" int lwg_conv2d_winograd4_f32(const LwgConvArgs* pa, lwg_stream_t stre
     const size_t lds = (size_t)(W4_BIAS_OFF + 64) * 4;
     const int bx = (a.W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (a.H + 4 * W4_PBY - 1) / (4 * W4_PBY);
     const int cus = lwg_device_cus();
-    const long total = (long)bx * by * a.B * (a.N / W4_NB);
+    long total = (long)bx * by * a.B * (a.N / W4_NB);
+    // small launches (the 8-wave blocks would leave half the chip or more without a workgroup): the 4-wave form, 32 channels per block - bitwise the same
+    // result (see the kernel), so the choice may depend on the batch.  The SPADE epilogue needs gamma | beta of a channel in one block: 8-wave form always
+    const bool sm = LWG_W4_SMALL && a.epi != LWG_EPI_SPADE && 2 * total <= cus;
+    if (sm) total *= 2;
     const dim3 grid((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total));
-    static unsigned long long done[6] = {0, 0, 0, 0, 0, 0};
+    static unsigned long long done[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool two = a.C1 > 0;
-#define LWG_W4_GO2(E, T, SLOT)                                                                                                          \
+#define LWG_W4_GO2(E, T, S, SLOT)                                                                                                       \
     {                                                                                                                                   \
-        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd4_kernel<E, T>), lds, done[SLOT]); e != hipSuccess) \
+        if (hipError_t e = lwg_allow_dynamic_lds(reinterpret_cast<const void*>(lwg_conv_winograd4_kernel<E, T, S>), lds, done[SLOT]); e != hipSuccess) \
             return (int)e;                                                                                                              \
-        hipLaunchKernelGGL((lwg_conv_winograd4_kernel<E, T>), grid, dim3(W4_THREADS), lds, stream, a);                                  \
+        hipLaunchKernelGGL((lwg_conv_winograd4_kernel<E, T, S>), grid, dim3(S ? 256 : W4_THREADS), lds, stream, a);                     \
     }
 #define LWG_W4_GO(E, SLOT)                                                                                                              \
     {                                                                                                                                   \
-        if (two) LWG_W4_GO2(E, true, SLOT + 3) else LWG_W4_GO2(E, false, SLOT)                                                          \
+        if (two) LWG_W4_GO2(E, true, false, SLOT + 3) else LWG_W4_GO2(E, false, false, SLOT)                                            \
     }
-    if (a.epi == LWG_EPI_SPADE) LWG_W4_GO(LWG_EPI_SPADE, 2)
+#define LWG_W4_GOS(E, SLOT)                                                                                                             \
+    {                                                                                                                                   \
+        if (two) LWG_W4_GO2(E, true, true, SLOT + 2) else LWG_W4_GO2(E, false, true, SLOT)                                              \
+    }
+    if (sm) {
+        if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GOS(LWG_EPI_RESIDUAL, 7)
+        else LWG_W4_GOS(LWG_EPI_NONE, 6)
+    } else if (a.epi == LWG_EPI_SPADE) LWG_W4_GO(LWG_EPI_SPADE, 2)
     else if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GO(LWG_EPI_RESIDUAL, 1)
     else LWG_W4_GO(LWG_EPI_NONE, 0)
+#undef LWG_W4_GOS
 #undef LWG_W4_GO
 #undef LWG_W4_GO2
     return (int)hipGetLastError();

@@ -9,7 +9,7 @@ R="$PWD"
 # KERNEL: name substring of the kernel family whose per-launch traffic goes to gpurun_out/pmc_traffic$TAG.json
 CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-conv-events --no-extras --no-self-check ${BENCH_ARGS:-}"
 TAG="${TAG:-}"
-KERNEL="${KERNEL:-lwg_conv_winograd_kernel}"
+KERNEL="${KERNEL:-lwg_conv_winograd4_kernel}"
 export LWG_PMC_CMD="bench.py --steps 2 --warmup 1 --no-extras --no-self-check ${BENCH_ARGS:-}"
 run() { # name counters...
   local name=$1; shift

@@ -63,7 +63,7 @@ def traffic_json(fetch_dir, write_dir, out_path, kernel_substr="lwg_conv_igemm_k
     fk, nf = mean_kb(fetch_dir, "FETCH_SIZE")
     wk, nw = mean_kb(write_dir, "WRITE_SIZE")
     by_kernel = {}
-    for sub in ("lwg_conv_winograd_kernel", "lwg_convt_winograd_kernel", "lwg_conv_igemm_kernel", "lwg_conv_bf16_hr2_kernel", "lwg_lwb_attn_x"):
+    for sub in ("lwg_conv_winograd4_kernel", "lwg_conv_winograd_kernel", "lwg_convt_winograd_kernel", "lwg_conv_igemm_kernel", "lwg_conv_bf16_hr2_kernel", "lwg_lwb_attn_x"):
         f1, n1 = mean_kb_of(fetch_dir, "FETCH_SIZE", sub)
         w1, n2 = mean_kb_of(write_dir, "WRITE_SIZE", sub)
         if n1 and n2:
