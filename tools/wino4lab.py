@@ -14,6 +14,7 @@ ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--w4only", action="store_true", help="time the F(4x4,3x3) kernel only (knock-out variant libraries: their results are wrong by construction)")
 ap.add_argument("--parity", action="store_true", help="small / ragged / odd shapes: correctness only")
+ap.add_argument("--half", action="store_true", help="--ts on a -DLWG_W4_SMALL=2 build: the half-block form's grid (2 workgroups per CU, 32 channels per block, 4-channel stages)")
 ap.add_argument("--ts", action="store_true", help="-DLWG_W4_TS build: per-block stamps of wave 0 (second block of every workgroup; plain epilogue)")
 args = ap.parse_args()
 import torch
@@ -112,7 +113,7 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
     y4, y2, yd = (torch.full((B, H, W, Co), float("nan"), device=dev) for _ in range(3))
     if args.ts:
         assert epi == "none"
-        nwg = min(256, ((W + 31) // 32) * ((H + 15) // 16) * B * (N // 64))
+        nwg = min(512, ((W + 31) // 32) * ((H + 15) // 16) * B * (N // 32)) if args.half else min(256, ((W + 31) // 32) * ((H + 15) // 16) * B * (N // 64))
         stamps = torch.zeros(nwg * 32, device=dev)
         ops.WINO4, ops.WINO4_MIN_CIN = True, 0
         with ops.conv_precision("winograd"):
@@ -132,7 +133,7 @@ for idx, (tag, B, H, W, C0, C1, Co, epi) in enumerate(SHAPES):
               f"{float(tot_c.median()) / max(float(nb.median()), 1):.0f} per block; counter rate {float(tot_c.max()) / ms / 1e3:.0f} MHz if the slowest workgroup spans the launch")
         ok = t[:, 3] > 0
         u = t[ok].double()
-        nst = Cin // 8
+        nst = Cin // (4 if args.half else 8)
         print(f"[ts] {tag} B={B}: {int(ok.sum())} workgroups with a second block; medians (cycles): prologue {float((u[:, 1] - u[:, 0]).median()):.0f}  K loop {float((u[:, 2] - u[:, 1]).median()):.0f}"
               f" ({float((u[:, 2] - u[:, 1]).median()) / nst:.0f} per stage; ideal 4608)  epilogue {float((u[:, 3] - u[:, 2]).median()):.0f}")
         md = lambda i1, i0: float((u[:, i1] - u[:, i0]).median())
