@@ -44,6 +44,9 @@
 #define W4_MS (W4_NPL * 16 * W4_MSR)             // one pass = 16 patches
 #define W4_BIAS_OFF (W4_LOOP > W4_MS ? W4_LOOP : W4_MS)          // the block's 64 bias values, behind both uses of the LDS
 #define W4_OOB 0xC0000000u
+#ifndef LWG_W4_CHUNK
+#define LWG_W4_CHUNK 1       // block order: 1 = chunks of gridDim.x tiles through every column block where the panel fits L2, 2 = always, 0 = never (lab)
+#endif
 #ifndef LWG_W4_SMALL
 #define LWG_W4_SMALL 1       // the 4-wave form for small launches (lab: 0 = off)
 #endif
@@ -118,8 +121,23 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
     unsigned voff0[NQ], voff1[NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
     unsigned uvoff, uvoffc;                                  // this lane's column of the fragment panel: the 16-byte parts, the ninth product
     auto setup = [&](int id) {
-        const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
-        int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        // block id -> (column block, tile).  Chunked order (layers whose WHOLE fragment panel stays in an XCD's 4 MB L2 - in the generator N = 128): the
+        // grid's G persistent workgroups walk a chunk of G tiles through ALL column blocks before the next chunk (workgroup w: tile ch G + w in N / 64
+        // consecutive blocks) - a tile's halo is re-read one round after its first read instead of a whole pass over the batch apart.  Measured inside the
+        // 300-frame step (profiles/r06_ag_*): 2-3.4 % faster per launch for N = 128, 2-5 % SLOWER for N >= 256 (every round then pulls another column
+        // block's panel through L2): those keep the column-block-major order
+        int cb, t;
+        if (LWG_W4_CHUNK == 2 || (LWG_W4_CHUNK == 1 && 144u * (unsigned)Cin * (unsigned)N <= (5u << 20))) {
+            const int G = (int)gridDim.x, per = G * (N / NBV);
+            const int ch = __builtin_amdgcn_readfirstlane(id / per);
+            const int r = id - ch * per, base = ch * G;
+            const int nt = tiles - base < G ? tiles - base : G;
+            cb = __builtin_amdgcn_readfirstlane(r / nt);
+            t = __builtin_amdgcn_readfirstlane(base + r - cb * nt);
+        } else {
+            cb = __builtin_amdgcn_readfirstlane(id / tiles);
+            t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        }
         b = __builtin_amdgcn_readfirstlane(t / (bx * by));
         t -= b * bx * by;
         x0 = (t % bx) * 4 * W4_PBX;
