@@ -85,14 +85,17 @@ __device__ __forceinline__ void w4_bt6(const float (&r)[6], float (&v)[6]) {
     v[5] = __builtin_fmaf(-5.f, r[3], __builtin_fmaf(4.f, r[1], r[5]));
 }
 
-// SM (small launches - a frame or two -, plain / residual epilogues): 256 threads = the four waves q = 0..3 of ONE 32-channel tile - block = the same 32 patches x
+// SM (small launches - a frame or two -, every epilogue): 256 threads = the four waves q = 0..3 of ONE 32-channel tile - block = the same 32 patches x
 // 32 channels: twice the workgroups (one wave per SIMD: the 36 MFMAs of a wave and stage run unshared), every thread forms BOTH halves of its (patch, channel)
 // transform and stages five halo pieces.  Every output element is accumulated over the stages and k-pairs in the same order and finished by the same
 // expressions in both forms (the transform, the folds and the reader are explicit fma / add sequences): bitwise the same result - a frame does not depend on
 // its batch (check_winograd4: frame n of a 40-frame launch = the frame alone, across the forms).
 template <int EPI, bool TWO, bool SM = false>
 __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_kernel(const LwgConvArgs a) {
-    static_assert(!(SM && EPI == LWG_EPI_SPADE), "the SPADE epilogue needs gamma | beta in one block");
+    // (SM with the SPADE epilogue: the block's 32 accumulator rows are gamma | beta of the SAME 16 channels - columns n0 .. + 15 and n0 + 32 .. + 47 of the
+    // stacked panel, n0 = 64 (block / 2) + 16 (block % 2) - so the modulation still finds both in one block)
+    constexpr bool SMS = SM && EPI == LWG_EPI_SPADE;
+    constexpr int NVP = SM && !SMS ? 2 : 1;                  // patches per reader thread and pass
     constexpr int NTH = SM ? 256 : W4_THREADS;               // threads per workgroup
     constexpr int NQ = SM ? 5 : W4_NQ;                       // halo pieces per thread and stage
     constexpr int NBV = SM ? 32 : W4_NB;                     // output channels per block
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
         t -= b * bx * by;
         x0 = (t % bx) * 4 * W4_PBX;
         y0 = (t / bx) * 4 * W4_PBY;
-        n0 = cb * NBV;
+        n0 = SMS ? (cb >> 1) * 64 + (cb & 1) * 16 : cb * NBV;
         rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0 + (size_t)b * H * W * a.C0), 0, (int)((unsigned)(H * W) * (unsigned)a.C0 * 4u), 0x00020000);
         if constexpr (TWO) rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * H * W * a.C1), 0, (int)((unsigned)(H * W) * (unsigned)a.C1 * 4u), 0x00020000);
         int tids = tid;                                      // (through an empty asm: the halo geometry is recomputed per block - hoisted out of the block
@@ -156,8 +159,9 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
             voff0[k] = in ? (unsigned)((gy * W + gx) * a.C0 + 4 * hq) * 4u : W4_OOB;
             if constexpr (TWO) voff1[k] = in ? (unsigned)((gy * W + gx) * a.C1 + 4 * hq) * 4u : W4_OOB;
         }
-        uvoff = (unsigned)(((lane >> 5) * 9 * N + 4 * (n0 + ct * 32 + (lane & 31))) * 4);
-        uvoffc = (unsigned)(((lane >> 5) * 9 * N + 8 * N + n0 + ct * 32 + (lane & 31)) * 4);
+        const int col = SMS ? n0 + (((lane & 31) >> 4) << 5) + (lane & 15) : n0 + ct * 32 + (lane & 31);      // this lane's accumulator row = panel column
+        uvoff = (unsigned)(((lane >> 5) * 9 * N + 4 * col) * 4);
+        uvoffc = (unsigned)(((lane >> 5) * 9 * N + 8 * N + col) * 4);
     };
     setup(blk);
     int wst[NQ];                                             // the halo elements' LDS slot
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
     floatx4 r0[NQ], r1[NQ];
     float bq;                                                // the block's bias, one value per lane of wave 0: requested with the first loads, parked in LDS by the prologue
     auto issue_loads = [&]() {
-        bq = bias ? bias[n0 + (tid & (NBV - 1))] : 0.f;
+        bq = bias ? bias[SMS ? n0 + (((tid & 31) >> 4) << 5) + (tid & 15) : n0 + (tid & (NBV - 1))] : 0.f;
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             r0[k] = rld1(0, k);
@@ -526,11 +530,12 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
     const int lanee = tide & 63;
     const int rb = wid & 3;                                  // reader: output column inside a patch (wave-uniform)
     const int p16 = (wid >> 2) * 8 + (lanee >> 3);           // ... patch inside the pass (SM: lanee >> 3 and 8 + lanee >> 3)
-    const int n4 = (lanee & 7) * 4;                          // ... channel quad (and 32 + n4; SM: the block's only 32 channels)
+    const int n4 = SMS ? (lanee & 3) * 4 : (lanee & 7) * 4;  // ... channel quad (and 32 + n4; SM: the block's only 32 channels; SM + SPADE: gamma | beta rows n4 and 16 + n4)
+    const int cbase = SMS ? (en0 >> 6) * 32 + ((en0 >> 4) & 1) * 16 : en0 >> 1;       // SPADE: the block's first output channel
     floatx4 mu, rs;
     if (EPI == LWG_EPI_SPADE) {
-        mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + (en0 >> 1) + n4);
-        rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)eb * a.YC + (en0 >> 1) + n4);
+        mu = *reinterpret_cast<const floatx4*>(a.mean + (size_t)eb * a.YC + cbase + n4);
+        rs = *reinterpret_cast<const floatx4*>(a.rstd + (size_t)eb * a.YC + cbase + n4);
     }
     // image eb of the output (and of res / xn: the output's layout) as ONE buffer: a reader thread's four pixels are 32-bit offsets inside it (out of
     // range: right of / below the image - the hardware drops the store and returns zeros for the load), the second channel group an immediate
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)eb * H * W * a.YC, 0, (int)img_bytes, 0x00020000);
     const float* const esrc = EPI == LWG_EPI_SPADE ? a.xn : EPI == LWG_EPI_RESIDUAL ? a.res : a.y;
     const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(esrc) + (size_t)eb * H * W * a.YC, 0, (int)img_bytes, 0x00020000);
-    const int chan = EPI == LWG_EPI_SPADE ? (en0 >> 1) + n4 : a.ycoff + en0 + n4;
+    const int chan = EPI == LWG_EPI_SPADE ? cbase + n4 : a.ycoff + en0 + n4;
     bool more = false;
     int nblk = blk;
 #pragma unroll
@@ -560,10 +565,10 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
             }
         }
         // this pass's pixels: patch p, output column rb, rows 0..3 (SM: two patches, one channel group)
-        unsigned vo[SM ? 2 : 1][4];
+        unsigned vo[NVP][4];
 #pragma unroll
-        for (int hp = 0; hp < (SM ? 2 : 1); ++hp) {
-            const int p = ph * 16 + (SM ? 8 * hp + (lanee >> 3) : p16);
+        for (int hp = 0; hp < NVP; ++hp) {
+            const int p = ph * 16 + (SMS ? lanee >> 2 : SM ? 8 * hp + (lanee >> 3) : p16);
             const int ox = ex0 + 4 * (p & 7) + rb, oyb = ey0 + 4 * (p >> 3);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
 #pragma unroll
             for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : 2); ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[SM ? h : 0][i] + (SM ? 0u : 128u * h), 0u);
+                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[NVP == 2 ? h : 0][i] + (SM ? 0u : 128u * h), 0u);
         }
         if (ph == 1) {
             // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
         floatx4 gam[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float* base = Ms + (SM ? 8 * h + (lanee >> 3) : p16) * MSR + (SM ? 0 : h * 32) + n4;
+            const float* base = Ms + (SMS ? lanee >> 2 : SM ? 8 * h + (lanee >> 3) : p16) * MSR + (SMS ? h * 16 : SM ? 0 : h * 32) + n4;
             floatx4 F[6];
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) F[xi] = *reinterpret_cast<const floatx4*>(base + (4 * xi + rb) * 16 * MSR);
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
             });
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[SM ? h : 0][i] + (EPI == LWG_EPI_SPADE || SM ? 0u : 128u * h)), 0, W4_NT);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[NVP == 2 ? h : 0][i] + (EPI == LWG_EPI_SPADE || SM ? 0u : 128u * h)), 0, W4_NT);
         }
         if (ph == 0) W4TS(6);
     }
@@ -749,12 +754,12 @@ extern "C" int lwg_conv2d_winograd4_f32(const LwgConvArgs* pa, lwg_stream_t stre
     const int bx = (a.W + 4 * W4_PBX - 1) / (4 * W4_PBX), by = (a.H + 4 * W4_PBY - 1) / (4 * W4_PBY);
     const int cus = lwg_device_cus();
     long total = (long)bx * by * a.B * (a.N / W4_NB);
-    // small launches (the 8-wave blocks would leave half the chip or more without a workgroup): the 4-wave form, 32 channels per block - bitwise the same
-    // result (see the kernel), so the choice may depend on the batch.  The SPADE epilogue needs gamma | beta of a channel in one block: 8-wave form always
-    const bool sm = LWG_W4_SMALL && a.epi != LWG_EPI_SPADE && 2 * total <= cus;
+    // small launches (the 8-wave blocks would leave half the chip or more without a workgroup): the 4-wave form, 32 channels per block (SPADE: gamma | beta
+    // of 16 channels) - bitwise the same result (see the kernel), so the choice may depend on the batch
+    const bool sm = LWG_W4_SMALL && 2 * total <= cus;
     if (sm) total *= 2;
     const dim3 grid((unsigned)(LWG_WINO_PERSIST && total > cus ? cus : total));
-    static unsigned long long done[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static unsigned long long done[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool two = a.C1 > 0;
 #define LWG_W4_GO2(E, T, S, SLOT)                                                                                                       \
     {                                                                                                                                   \
@@ -771,7 +776,9 @@ extern "C" int lwg_conv2d_winograd4_f32(const LwgConvArgs* pa, lwg_stream_t stre
         if (two) LWG_W4_GO2(E, true, true, SLOT + 2) else LWG_W4_GO2(E, false, true, SLOT)                                              \
     }
     if (sm) {
-        if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GOS(LWG_EPI_RESIDUAL, 7)
+        if (a.epi == LWG_EPI_SPADE) {
+            if (two) LWG_W4_GO2(LWG_EPI_SPADE, true, true, 11) else LWG_W4_GO2(LWG_EPI_SPADE, false, true, 10)
+        } else if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GOS(LWG_EPI_RESIDUAL, 7)
         else LWG_W4_GOS(LWG_EPI_NONE, 6)
     } else if (a.epi == LWG_EPI_SPADE) LWG_W4_GO(LWG_EPI_SPADE, 2)
     else if (a.epi == LWG_EPI_RESIDUAL) LWG_W4_GO(LWG_EPI_RESIDUAL, 1)
