@@ -12,7 +12,7 @@
 // register-local for rows 0..3 and half-local for rows 4, 5: 28 planes of (patch, channel) values cross LDS in the epilogue.
 // A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights as two 16-byte and one 4-byte buffer loads from the panel
 // Upk[4][Cin/8][4][2][9 N] (every instruction reads contiguous memory; two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS, each one right behind the MFMA that
-// used its register for the previous k-pair.  The raw 34 x 18 x 8 halo goes global -> registers -> raw[s % 2] (channel-major planes, rows of 36 floats);
+// used its register for the previous k-pair.  The raw 34 x 18 x 8 halo goes global -> registers -> raw[s % 2] (channel-major planes, rows of 40 floats);
 // the 256 (patch, channel) transforms of the next stage are shared by the 512 threads: waves 0-3 form rows 0..2 of B^T d B, waves 4-7 rows 3..5 (72 vector
 // instructions per thread and stage), one barrier per stage in front of k-pair 3.
 // Rounding: relative L2 error against fp64 ~14-20x the direct fp32 convolution's (3e-6; tools/winograd_study.py --f43): fp32-grade, NOT the direct kernel's
@@ -28,8 +28,12 @@
 #define W4_KS 8              // input channels per stage
 #define W4_HW 34             // halo pixels per row
 #define W4_HH 18             // halo rows
-#define W4_RS 36             // floats per halo row in LDS (16-byte aligned rows)
-#define W4_PLANE 652         // floats per channel plane: 18 x 36 + 4 (4 PLANE = 16 mod 32: the two channel quads of a pixel fall into different banks)
+#ifndef W4_RS
+#define W4_RS 40             // floats per halo row in LDS (16-byte aligned rows).  40: a patch row (four halo rows) is 160 = 32 mod 64 floats, so the 16 lanes of a
+                             // ds_read_b128 lane group - patches (pty, ptx 0-3 | 4-7) of four patch rows - read sixteen distinct bank quads in the transform
+                             // (36: 144 = 16 mod 64, two-way conflicts on every patch-row read; PMC r06_ah / r06_ak)
+#endif
+#define W4_PLANE (18 * W4_RS + 4)   // floats per channel plane: 18 rows + 4 (4 PLANE = 16 mod 32: the two channel quads of a pixel fall into different banks)
                              // (lab: consecutive lanes = consecutive pixels of one quad + planes of 704 floats, i.e. ds_write2st64_b32 halo stores: 6-12 % SLOWER -
                              //  a lane pair no longer reads 32 contiguous bytes; profiles/r06_y3_*)
 #define W4_RAW (W4_KS * W4_PLANE)
