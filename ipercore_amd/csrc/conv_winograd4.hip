@@ -48,6 +48,9 @@
 #define W4_MS (W4_NPL * 16 * W4_MSR)             // one pass = 16 patches
 #define W4_BIAS_OFF (W4_LOOP > W4_MS ? W4_LOOP : W4_MS)          // the block's 64 bias values, behind both uses of the LDS
 #define W4_OOB 0xC0000000u
+#ifndef LWG_W4_XCD
+#define LWG_W4_XCD 1         // XCD-aware block order (see the kernel): 0 = off (lab)
+#endif
 #ifndef LWG_W4_CHUNK
 #define LWG_W4_CHUNK 1       // block order: 1 = chunks of gridDim.x tiles through every column block where the panel fits L2, 2 = always, 0 = never (lab)
 #endif
@@ -130,6 +133,20 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
     __amdgpu_buffer_rsrc_t rx0, rx1;
     unsigned voff0[NQ], voff1[NQ];                     // this thread's halo elements (pixel, channel quad): byte offsets inside either input
     unsigned uvoff, uvoffc;                                  // this lane's column of the fragment panel: the 16-byte parts, the ninth product
+    // XCD-aware block order (8-wave form, persistent grids of a multiple of 8 workgroups, N / 64 = 2, 4 or 8 column blocks): workgroup w runs on XCD w % 8
+    // (round-robin dispatch) and keeps ONE column block, (w % 8) % ncb, for the whole launch - an XCD's 4 MB L2 holds that column block's panel only and
+    // never turns it over -, while the ncb workgroups (w % 8) / ncb, w / 8 of adjacent XCDs walk the SAME tile sequence in step: a tile's halo is fetched
+    // by ncb XCDs at about the same time - once from HBM, the rest out of the memory-side cache - instead of ncb times a whole pass over the batch apart
+    const int ncb = N / NBV;
+    // Measured inside the 300-frame step (profiles/r06_am_*): 2-7 % per launch for N >= 256 and for N = 128 with Cin >= 192; the N = 128 layers with
+    // Cin <= 128 keep the chunked order below (1-4 % faster there)
+    const bool xcd = LWG_W4_XCD && !SM && (gridDim.x & 7u) == 0 && (ncb == 4 || ncb == 8 || (ncb == 2 && (Cin >= 192 || LWG_W4_XCD == 2))) &&
+                     (int)gridDim.x < total && tiles >= (int)gridDim.x / ncb;
+    const int xg = (int)gridDim.x / ncb;                     // workgroups per column block = tiles per round
+    const int xr = (int)(((blockIdx.x & 7u) / (unsigned)ncb) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // this workgroup's place among them
+    auto has_block = [&](int id) -> bool {                   // (id = blockIdx.x + k gridDim.x)
+        return xcd ? (id / (int)gridDim.x) * xg + xr < tiles : id < total;
+    };
     auto setup = [&](int id) {
         // block id -> (column block, tile).  Chunked order (layers whose WHOLE fragment panel stays in an XCD's 4 MB L2 - in the generator N = 128): the
         // grid's G persistent workgroups walk a chunk of G tiles through ALL column blocks before the next chunk (workgroup w: tile ch G + w in N / 64
@@ -137,7 +154,10 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
         // 300-frame step (profiles/r06_ag_*): 2-3.4 % faster per launch for N = 128, 2-5 % SLOWER for N >= 256 (every round then pulls another column
         // block's panel through L2): those keep the column-block-major order
         int cb, t;
-        if (LWG_W4_CHUNK == 2 || (LWG_W4_CHUNK == 1 && 144u * (unsigned)Cin * (unsigned)N <= (5u << 20))) {
+        if (xcd) {
+            cb = (int)(blockIdx.x & 7u) & (ncb - 1);
+            t = __builtin_amdgcn_readfirstlane((id / (int)gridDim.x) * xg + xr);
+        } else if (LWG_W4_CHUNK == 2 || (LWG_W4_CHUNK == 1 && 144u * (unsigned)Cin * (unsigned)N <= (5u << 20))) {
             const int G = (int)gridDim.x, per = G * (N / NBV);
             const int ch = __builtin_amdgcn_readfirstlane(id / per);
             const int r = id - ch * per, base = ch * G;
@@ -600,7 +620,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
             // (unconditional: the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
             W4TS(8);
             nblk = blk + (int)gridDim.x;
-            more = nblk < total;
+            more = has_block(nblk);
             setup(more ? nblk : blk);
             W4TS(9);
             issue_loads();

@@ -21,6 +21,9 @@
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
+#ifndef LWG_CTW_XCD
+#define LWG_CTW_XCD 1        // XCD-aware block order (see the kernel): 0 = column-block-major (lab)
+#endif
 #define WG_THREADS 512
 #define TPB 8            // patches per block edge: 8 x 8 patches = 16 x 16 input pixels
 #define NPATCH 64
@@ -95,9 +98,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     __amdgpu_buffer_rsrc_t rx0;
     unsigned voff0[2];
     unsigned uvoff;
+    // XCD-aware block order (as conv_winograd4.hip; persistent grids of a multiple of 8 workgroups, N / 32 = 2, 4 or 8 column blocks): workgroup w runs on
+    // XCD w % 8 and keeps ONE column block, (w % 8) % ncb, for the whole launch (an XCD's L2 holds that column block's panel only), while the ncb
+    // workgroups (w % 8) / ncb, w / 8 of adjacent XCDs walk the same tile sequence in step: a tile's halo comes from HBM once instead of ncb times
+    const int ncb = N / NBT;
+    const bool xcd = LWG_CTW_XCD && (gridDim.x & 7u) == 0 && (ncb == 2 || ncb == 4 || ncb == 8) && (int)gridDim.x < total && tiles >= (int)gridDim.x / ncb;
+    const int xg = (int)gridDim.x / ncb;                     // workgroups per column block = tiles per round
+    const int xr = (int)(((blockIdx.x & 7u) / (unsigned)ncb) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // this workgroup's place among them
+    auto has_block = [&](int id) -> bool {                   // (id = blockIdx.x + k gridDim.x)
+        return xcd ? (id / (int)gridDim.x) * xg + xr < tiles : id < total;
+    };
     auto setup = [&](int id) {
-        const int cb = __builtin_amdgcn_readfirstlane(id / tiles);
-        int t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        int cb, t;
+        if (xcd) {
+            cb = (int)(blockIdx.x & 7u) & (ncb - 1);
+            t = __builtin_amdgcn_readfirstlane((id / (int)gridDim.x) * xg + xr);
+        } else {
+            cb = __builtin_amdgcn_readfirstlane(id / tiles);
+            t = __builtin_amdgcn_readfirstlane(id - cb * tiles);
+        }
         b = __builtin_amdgcn_readfirstlane(t / (bx * by));
         t -= b * bx * by;
         x0 = (t % bx) * 2 * TPB;
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     // the last block re-requests its own first stages, nobody waits for them; see conv_winograd.hip)
     CTSB(1, 7);
     const int nblk = blk + (int)gridDim.x;
-    const bool more = nblk < total;
+    const bool more = has_block(nblk);
     setup(more ? nblk : blk);
     issue_loads();
     CTSB(1, 8);
