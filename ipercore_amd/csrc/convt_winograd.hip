@@ -70,6 +70,21 @@ template <int V> struct IntT { static constexpr int value = V; };
 #define CTS_COUNT() do { } while (0)
 #endif
 
+// Where pixel column lx of a row of the epilogue's exchange buffer lies (rows of 32 pixel slots x 36 floats).  A write instruction's eight consecutive
+// lanes are the patches etx = 0..7 of one patch row - pixels 4 etx + r, r = 2 ib + px fixed: in column order their 16-byte pieces lie 144 floats apart,
+// i.e. on TWO of the eight bank quads of a ds_write_b128 (four-way conflicts on every write; PMC: 22 % of the kernel's LDS-array cycles).  Slot
+// 8 r + (etx + 2 r) % 8 puts the eight lanes on eight bank quads, and the sixteen lanes of either ds_read_b128 lane group of the channel-quad-plane reader
+// (32 consecutive pixels: lanes {0-3, 12-15, 20-27} | {4-11, 16-19, 28-31}) on sixteen distinct slots mod 16 (36 floats = 9 quads per slot: the bank quad
+// of a slot is 9 slot % 16, a bijection) - checked by enumeration in tests/test_bf16_panels.py::test_convt_exchange_slots.
+__device__ __forceinline__ int ctw_slot(int lx) {
+#ifdef CTW_LAB_LINEAR_SLOTS
+    return lx;
+#else
+    const int r = lx & 3;
+    return 8 * r + (((lx >> 2) + 2 * r) & 7);
+#endif
+}
+
 __device__ __forceinline__ floatx4 ctw_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
                     o[k] = lwg_act_c<EA>(v + bv[k], a.act);
                 }
                 const int ly = 2 * (2 * ety + ia) + py, lx = 2 * (2 * etx + ib) + px;      // the pixel inside the block's 32 x 32 outputs
-                *reinterpret_cast<floatx4*>(smem + (ly * 32 + lx) * OROW + 8 * g + chl) = o;
+                *reinterpret_cast<floatx4*>(smem + (ly * 32 + ctw_slot(lx)) * OROW + 8 * g + chl) = o;
             }
     }
     });
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     const int oy0 = 2 * ey0, ox0 = 2 * ex0;
     const size_t plane = (size_t)a.YH * a.YW;
     // The block's 32 x 32 x 32 outputs leave as BUFFER stores (round 6): image eb is one buffer, a thread's offset inside it is computed once, the
-    // sixteen passes differ by a SCALAR offset - no per-pass 64-bit address arithmetic, no per-pass bounds branch (profiles/r06_m_*: the store phase was
+    // sixteen passes differ by one 32-bit add - no per-pass 64-bit address arithmetic, no per-pass bounds branch (profiles/r06_m_*: the store phase was
     // 4.2-5.4 k cycles of instruction issue per block).  Pixels right of the image: an out-of-range thread offset (the store is dropped); rows below it:
     // beyond the buffer's end in the NHWC layout (rows are its slowest dimension), an out-of-range scalar offset for the pass in the plane layout.
     typedef unsigned int ctw_u4 __attribute__((ext_vector_type(4)));
@@ -435,24 +450,27 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)eb * (size_t)(a.YC >> 2) * plane * 4, 0,
                                                                             (int)((unsigned)(a.YC >> 2) * (unsigned)plane * 16u), 0x00020000);
         const unsigned yv = ox0 + lx < a.YW ? (unsigned)(((((a.ycoff + en0) >> 2) + cq) * (int)plane + (oy0 + lyh) * a.YW + ox0 + lx) * 16) : WINO_OOB;
-        const float* src = smem + (lyh * 32 + lx) * OROW + 4 * cq;
+        const float* src = smem + (lyh * 32 + ctw_slot(lx)) * OROW + 4 * cq;
         const unsigned rowpair = (unsigned)a.YW * 32u;           // bytes between the rows of two passes (two rows of 16-byte pixels)
 #pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
             const ctw_u4 v = *reinterpret_cast<const ctw_u4*>(src + pass * 64 * OROW);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yv, (int)(oy0 + 2 * pass < a.YH ? (unsigned)pass * rowpair : WINO_OOB), 0);
+            // (the pass offset goes into the VECTOR offset, the scalar offset stays the constant 0: with a register in the scalar-offset field the compiler
+            //  plans no wait state between a 16-byte store and a VALU write of its data registers - and the next pass's address add landed in the first
+            //  data register right behind the store: intermittently corrupted first channels, found by tools/determinism_stress.py; r06_ar)
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(oy0 + 2 * pass < a.YH ? yv + (unsigned)pass * rowpair : WINO_OOB), 0, 0);
         }
     } else {
         // NHWC: 8 lanes = the block's 32 channels of one pixel, 128 contiguous bytes
         const int cq = tide & 7, lx = (tide >> 3) & 31, lyh = tide >> 8;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)eb * plane * a.YC, 0, (int)((unsigned)plane * (unsigned)a.YC * 4u), 0x00020000);
         const unsigned yv = ox0 + lx < a.YW ? (unsigned)((((oy0 + lyh) * a.YW + ox0 + lx) * a.YC + a.ycoff + en0 + 4 * cq) * 4) : WINO_OOB;
-        const float* src = smem + (tide >> 3) * OROW + 4 * cq;
+        const float* src = smem + (lyh * 32 + ctw_slot(lx)) * OROW + 4 * cq;
         const unsigned rowpair = (unsigned)a.YW * (unsigned)a.YC * 8u;
 #pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
             const ctw_u4 v = *reinterpret_cast<const ctw_u4*>(src + pass * 64 * OROW);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yv, (int)((unsigned)pass * rowpair), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(yv + (unsigned)pass * rowpair), 0, 0);        // (vector offset: see above)
         }
     }
     CTSB(1, 13);

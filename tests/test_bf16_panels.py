@@ -400,3 +400,37 @@ def test_winograd4_panel_algorithm_and_rule():
     assert not ops._wino4_use(spec, True)
     if ops.WINO4_MIN_CIN > 32:
         assert not ops._wino4_use(spec, False)
+
+
+def test_convt_exchange_slots():
+    """csrc/convt_winograd.hip ctw_slot: the pixel-slot permutation of the transposed Winograd kernel's exchange buffer (rows of 32 slots x 36 floats) is a
+    bijection; the eight consecutive lanes of a ds_write_b128 (patches etx = 0..7, pixel 4 etx + r) hit eight distinct bank quads (banks mod 32), and the
+    sixteen lanes of either ds_read_b128 lane group of the channel-quad-plane reader (32 consecutive pixels, banks mod 64; MI355X_MICROARCH.md, LDS)
+    sixteen distinct ones.  The same enumeration for the epilogue reader map of csrc/conv_winograd4.hip (LWG_W4_RDMAP: rows of 68 floats)."""
+    slot = lambda lx: 8 * (lx & 3) + (((lx >> 2) + 2 * (lx & 3)) & 7)      # noqa: E731
+    assert sorted(slot(lx) for lx in range(32)) == list(range(32))
+    orow = 36
+    for r in range(4):
+        for qd in range(8):                                   # a lane's 16-byte piece: channel quad qd of its pixel
+            quads = {((slot(4 * etx + r) * orow + 4 * qd) // 4) % 8 for etx in range(8)}
+            assert len(quads) == 8, (r, qd, quads)
+            lin = {(((4 * etx + r) * orow + 4 * qd) // 4) % 8 for etx in range(8)}
+            assert len(lin) == 2                              # what the linear order did: four-way conflicts
+    groups = ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31])
+    for grp in groups:
+        for cq in range(8):
+            quads = {((slot(lx) * orow + 4 * cq) // 4) % 16 for lx in grp}
+            assert len(quads) == 16, (cq, quads)
+    # conv_winograd4.hip: reader lane -> (patch, quad) through the lane groups; a slot of the 68-float rows lies in bank quad (17 patch + quad) % 16
+    amask = 0x0FF0F00F
+    for half in range(2):
+        for first in (True, False):
+            lanes = [l for l in range(32) if bool((amask >> l) & 1) == first]
+            seen = set()
+            for l5 in lanes:
+                gm = amask if first else (~amask & 0xFFFFFFFF)
+                gidx = bin(gm & ((1 << l5) - 1)).count("1")
+                patch = 2 * half + (0 if first else 1) + 8 * (gidx >> 3)
+                quad = gidx & 7
+                seen.add((17 * patch + quad) % 16)
+            assert len(seen) == 16, (half, first, seen)
