@@ -583,12 +583,14 @@ def novel_view_1024_bf16(dev, timer, W, K):
         timer.reset()
 
 
-def size_extra(dev, timer, S, W=1, K=2):
+def size_extra(dev, timer, S, W=2, K=2):
     """the metric is quoted "at 256 / 512 / 1024" - the same fp32 per-frame path at another image size in a short loop
     (W warm-up + K timed clips), with the conv kernel's roofline fraction from HIP events.  Reported beside the headline, never as it."""
     from ipercore_amd import ops, synthetic as syn
     n = {256: 300, 1024: 96}.get(S, 96)
     FB = default_frame_batch("fp32", S)
+    torch.cuda.empty_cache()                     # (the 1024 x 1024 clip needs ~100 GB of new blocks: start from an empty pool - on a fragmented one the timed
+                                                 #  clips of round 6's evidence run spent 80 % of their wall time in the allocator: 66 instead of 245-288 frames/s)
     case = syn.build_case(image_size=S, n_frames=n, ns=2)
     im = syn.make_imitator(case, frame_batch=FB, device=dev)
     tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
