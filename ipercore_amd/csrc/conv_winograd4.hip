@@ -15,6 +15,7 @@
 // used its register for the previous k-pair.  The raw 34 x 18 x 8 halo goes global -> registers -> raw[s % 2] (channel-major planes, rows of 40 floats);
 // the 256 (patch, channel) transforms of the next stage are shared by the 512 threads: waves 0-3 form rows 0..2 of B^T d B, waves 4-7 rows 3..5 (72 vector
 // instructions per thread and stage), one barrier per stage in front of k-pair 3.
+// Persistent workgroups in an XCD-aware block order (one column block per XCD for the whole launch; see the kernel), a 4-wave form for small launches.
 // Rounding: relative L2 error against fp64 ~14-20x the direct fp32 convolution's (3e-6; tools/winograd_study.py --f43): fp32-grade, NOT the direct kernel's
 // and not the F(2x2, 3x3) kernel's bits.  A frame's result does not depend on the batch it is launched in (per-image work in a fixed order).
 #include <hip/hip_runtime.h>
