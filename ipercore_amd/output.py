@@ -57,7 +57,7 @@ class FrameWriter(object):
         self.output_dir, self.prefix = output_dir, prefix
         os.makedirs(output_dir, exist_ok=True)
         self.compress_level = compress_level
-        self.workers = int(workers or min(32, max(2, (os.cpu_count() or 4) // 2)))
+        self.workers = int(workers or min(64, max(2, (os.cpu_count() or 4) // 2)))     # (the PNGs of the LAST batch trail the GPU: the more threads the shorter that tail)
         self.ring = ring
         self._free = queue.Queue()         # pinned host buffers whose frames are all encoded
         self._nbuf = 0
