@@ -57,7 +57,7 @@ class FrameWriter(object):
         self.output_dir, self.prefix = output_dir, prefix
         os.makedirs(output_dir, exist_ok=True)
         self.compress_level = compress_level
-        self.workers = int(workers or min(64, max(2, (os.cpu_count() or 4) // 2)))     # (the PNGs of the LAST batch trail the GPU: the more threads the shorter that tail)
+        self.workers = int(workers or min(32, max(2, (os.cpu_count() or 4) // 2)))     # (64 measured: the launching thread loses the GIL more often - 869 against 1 090 frames/s on the GPU side, 802 against 865 end to end)
         self.ring = ring
         self._free = queue.Queue()         # pinned host buffers whose frames are all encoded
         self._nbuf = 0
