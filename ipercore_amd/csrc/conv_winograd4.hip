@@ -80,8 +80,16 @@ __device__ __forceinline__ floatx4 w4_buf_load(__amdgpu_buffer_rsrc_t r, unsigne
 #ifndef W4_NT
 #define W4_NT 0              // cache policy of the activation traffic (halo loads, output stores): 0 = default; 2 = non-temporal: measured 20 % SLOWER (profiles/r06_w_*)
 #endif
+#ifndef W4_NT_LD
+#define W4_NT_LD W4_NT       // ... of the halo loads alone
+#endif
+#ifndef W4_NT_ST
+#define W4_NT_ST 2           // ... of the output stores alone: NON-TEMPORAL - the block's 128 KB of outputs are not read again by this launch and otherwise push
+                             // panel and halo lines out of the XCD's L2: +0.4-0.6 % in the step (A/B/A/B and five policies, profiles/r06_ay_*; the halo LOADS
+                             // non-temporal were the 20 % loss of r06_w)
+#endif
 __device__ __forceinline__ floatx4 w4_buf_load_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, W4_NT));
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, W4_NT_LD));
 }
 
 // the 1-D input transform B^T (.) of six values
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
             });
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[NVP == 2 ? h : 0][i] + (EPI == LWG_EPI_SPADE || SM ? 0u : 128u * h)), 0, W4_NT);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, o[i]), ry, (int)(vo[NVP == 2 ? h : 0][i] + (EPI == LWG_EPI_SPADE || SM ? 0u : 128u * h)), 0, W4_NT_ST);
         }
         if (ph == 0) W4TS(6);
     }

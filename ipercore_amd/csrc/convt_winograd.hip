@@ -21,6 +21,9 @@
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
 
+#ifndef CTW_NT_ST
+#define CTW_NT_ST 0          // cache policy of the output stores: 0 = default; 2 = non-temporal - worth 0.5 % in conv_winograd4.hip, measured neutral here (profiles/r06_az_*)
+#endif
 #ifndef LWG_CTW_XCD
 #define LWG_CTW_XCD 1        // XCD-aware block order (see the kernel): 0 = column-block-major (lab)
 #endif
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
             // (the pass offset goes into the VECTOR offset, the scalar offset stays the constant 0: with a register in the scalar-offset field the compiler
             //  plans no wait state between a 16-byte store and a VALU write of its data registers - and the next pass's address add landed in the first
             //  data register right behind the store: intermittently corrupted first channels, found by tools/determinism_stress.py; r06_ar)
-            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(oy0 + 2 * pass < a.YH ? yv + (unsigned)pass * rowpair : WINO_OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(oy0 + 2 * pass < a.YH ? yv + (unsigned)pass * rowpair : WINO_OOB), 0, CTW_NT_ST);
         }
     } else {
         // NHWC: 8 lanes = the block's 32 channels of one pixel, 128 contiguous bytes
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
 #pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
             const ctw_u4 v = *reinterpret_cast<const ctw_u4*>(src + pass * 64 * OROW);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(yv + (unsigned)pass * rowpair), 0, 0);        // (vector offset: see above)
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)(yv + (unsigned)pass * rowpair), 0, CTW_NT_ST);        // (vector offset: see above)
         }
     }
     CTSB(1, 13);
