@@ -83,6 +83,9 @@ __device__ __forceinline__ floatx4 w4_buf_load(__amdgpu_buffer_rsrc_t r, unsigne
 #ifndef W4_NT_LD
 #define W4_NT_LD W4_NT       // ... of the halo loads alone
 #endif
+#ifndef W4_NT_RES
+#define W4_NT_RES 0          // ... of the epilogue's residual / xn loads (read once per launch)
+#endif
 #ifndef W4_NT_ST
 #define W4_NT_ST 2           // ... of the output stores alone: NON-TEMPORAL - the block's 128 KB of outputs are not read again by this launch and otherwise push
                              // panel and halo lines out of the XCD's L2: +0.4-0.6 % in the step (A/B/A/B and five policies, profiles/r06_ay_*; the halo LOADS
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(SM ? 256 : W4_THREADS, 1) void lwg_conv_winograd4_k
 #pragma unroll
             for (int h = 0; h < (EPI == LWG_EPI_SPADE ? 1 : 2); ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ext[h][i] = w4_buf_load(re, vo[NVP == 2 ? h : 0][i] + (SM ? 0u : 128u * h), 0u);
+                for (int i = 0; i < 4; ++i) ext[h][i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(re, (int)(vo[NVP == 2 ? h : 0][i] + (SM ? 0u : 128u * h)), 0, W4_NT_RES));
         }
         if (ph == 1) {
             // the next block of this workgroup: its first loads go out here - the accumulators are dead - and land under the second pass's output
