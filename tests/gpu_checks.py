@@ -1143,6 +1143,25 @@ def check_winograd_determinism():
     return out
 
 
+def check_pipeline_determinism():
+    """Every kernel of the per-frame path at once: the same 24 frames at 512 x 512 rendered three times as ONE batch in each engine (the default
+    "winograd" engine, the direct fp32 engine, bf16, the bf16x6 split products) must agree bit for bit run to run.  (Round 6: a store-data hazard in one
+    kernel corrupted a few channels now and then - DESIGN.md 3.12c; single-shot parity checks against the oracle pass most of the time in that situation.)"""
+    m = {}
+    case = pu.build_case(image_size=512, num_filters=FULL[0], n_res=FULL[1], bg_filters=FULL[2], n_frames=24, ns=2)
+    im = pu.make_imitator(case, frame_batch=24)
+    tgt = im.prepare_sequence(case.tgt_smpls, "smooth")
+    for mode in ("winograd", "fp32", "bf16", "split"):
+        im.generator.conv_precision = mode
+        im.set_source(case.src_smpl, case.uv_img, case.bg_img, src_img=case.src_img)
+        runs = [im.synthesize(tgt, "smooth").clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        m[mode + "_repeats_differing"] = sum(0 if torch.equal(runs[0], r) else 1 for r in runs[1:])
+        assert torch.isfinite(runs[0]).all() and m[mode + "_repeats_differing"] == 0, m
+        del runs
+    return m
+
+
 def check_winograd_adversarial():
     """both Winograd kernels (F(2x2,3x3) csrc/conv_winograd.hip, F(2x2,2x2) csrc/convt_winograd.hip; the reference layers are
     attlwb_spade_resunet.py:14-25,62-93,316-357) on ADVERSARIAL distributions - inputs with a DC offset of 10 and 100 (post-ReLU-like), per-channel
@@ -3051,7 +3070,7 @@ def check_panel_cache_refresh():
     return out
 
 
-ALL = [check_winograd4, check_winograd_up4, check_winograd_determinism, check_winograd_adversarial, check_bf16_up4_head, check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
+ALL = [check_winograd4, check_winograd_up4, check_winograd_determinism, check_pipeline_determinism, check_winograd_adversarial, check_bf16_up4_head, check_panel_cache_refresh, check_conv_variants, check_conv_transpose, check_spade_epilogue, check_instnorm, check_lwb_attention, check_lwb_attention_x,
        check_head_and_layout, check_lbs, check_raster, check_flows, check_identity_warp_512, check_generator_golden, check_generator_golden_256,
        check_pipeline_tiny_64, check_pipeline_full_256, check_pipeline_full_512, check_novel_view_256, check_num_source_1_and_8,
        check_pipeline_full_1024, check_bf16_conv_kernels, check_bf16_vs_oracle, check_benched_shapes_512, check_benched_shapes_1024_bf16, check_batch_slicing_1024, check_whole_clip_batches, check_winograd_mode,
