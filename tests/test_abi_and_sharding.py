@@ -475,3 +475,31 @@ def test_segmented_dp_schedule_gloo_world2(tmp_path):
     ranks with different samples: same losses and weights as the hook-driven eager step, ranks stay identical.  Reference behaviour
     being matched: DistributedDataParallel's overlapped all-reduce, iPERCore/services/train.py:89-95."""
     _run_gloo(tmp_path, _DP_SCHEDULE_WORKER, 2)
+
+
+def test_no_wide_buffer_store_with_register_soffset():
+    """gfx950 (round 6): a 12- / 16-byte buffer store with a REGISTER in its scalar-offset field followed at once by a VALU write of its
+    first data register stored corrupted data now and then - the compiler plans the wait state between the two only for a constant scalar offset.  Every
+    kernel source that issues raw buffer stores is compiled to ISA here and must not contain such a store (pass offsets belong in the vector offset)."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ipercore_amd", "csrc")
+    srcs = [f for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) if "raw_buffer_store" in open(f).read()]
+    assert srcs, "the Winograd kernels store through buffer instructions"
+    pat = re.compile(r"buffer_store_(dwordx[34]|format_xyzw?)\s+v\[[0-9:]+\],\s*[^,]+,\s*s\[[0-9:]+\],\s*s[0-9]+\b")
+    with tempfile.TemporaryDirectory() as d:
+        for f in srcs:
+            out = os.path.join(d, os.path.basename(f) + ".s")
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + csrc, "-I" + os.path.join(root, "include"),
+                                   "-S", "--cuda-device-only", "-o", out, f], stderr=subprocess.DEVNULL)
+            text = open(out).read()
+            assert "buffer_store_dwordx4" in text, f
+            bad = [ln.strip() for ln in text.splitlines() if pat.search(ln)]
+            assert not bad, (os.path.basename(f), bad[:3])
