@@ -143,7 +143,9 @@ int lwg_winograd_panels_f32(const LwgWinoDesc* descs_dev, int ndesc, int total_b
  * product j, (G w G^T)[xi][nu] at [n][j] (j = 0..3), 4 N + [n][j - 4] (j = 4..7), 8 N + [n] (j = 8), with (xi, nu) = (q, j) for j < 6 and
  * (4 + q / 2, 3 (q % 2) + j - 6) for j = 6..8; G = [[1/4,0,0],[-1/6,-1/6,-1/6],
  * [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] (points 0, +-1, +-2, inf).  fp32-grade results (relative L2 error against fp64 1-4e-6:
- * 0.4-4.3x the direct kernel's on the adversarial operands of tests/gpu_checks.py), neither the direct nor the F(2x2, 3x3) kernel's bits; a frame's result does not depend on the batch it is launched in. */
+ * 0.4-4.3x the direct kernel's on the adversarial operands of tests/gpu_checks.py), neither the direct nor the F(2x2, 3x3) kernel's bits; a frame's result does not depend on the batch it is launched in
+ * NOR on the form the entry point chooses for the launch (an 8-wave block of 64 output channels in persistent workgroups - block order by column block
+ * per XCD, see the kernel - or, for launches that would leave half the chip without a workgroup, a 4-wave block of 32: bitwise the same values). */
 int lwg_conv2d_winograd4_f32(const LwgConvArgs* args, lwg_stream_t stream);
 /* That panel from the fp32 GEMM panel of the same convolution (arguments as lwg_winograd_panel_f32): U = G w G^T in fp64, rounded once. */
 int lwg_winograd4_panel_f32(const float* wpanel, float* upk, int Cin, int N, const int* tap9, lwg_stream_t stream);
