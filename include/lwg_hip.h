@@ -26,9 +26,9 @@ extern "C" {
 
 typedef void* lwg_stream_t; /* hipStream_t */
 
-/* 9: lwg_conv2d_winograd4_f32, lwg_winograd4_panel_f32 (F(4x4, 3x3); round 6); 8: lwg_conv2d_winograd_plan, lwg_up4_head_compose_bf16; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
+/* 10: the panel of lwg_conv_transpose4_winograd_f32 is [4][Cin/8][4][2][9 N] (contiguous per load; round 6, end); 9: lwg_conv2d_winograd4_f32, lwg_winograd4_panel_f32 (F(4x4, 3x3); round 6); 8: lwg_conv2d_winograd_plan, lwg_up4_head_compose_bf16; the Winograd kernels run as persistent workgroups (round 6); 7: lwg_conv_slice_count, lwg_winograd_panel(s)_f32, lwg_crop_resize_bilinear(_bwd)_f32, lwg_conv2d_winograd_f32 contract (Cin % 16, 16-byte output alignment) (round 5); 6: lwg_conv2d_winograd_f32 (round 4); 5: LWG_DT_F32_Q4 output storage of the fp32 convolutions + lwg_head_compose_q4_f32 (round 4); 4: lwg_lwb_attention_x_*, lwg_instnorm_finalize_*;
  * 3: lwg_conv2d_wgrad_unpacked_f32 gained db, lwg_norm_fwd / lwg_norm_bwd gained gstride (round 3); 2: LwgConvArgs.xdt / ydt */
-#define LWG_ABI_VERSION 9
+#define LWG_ABI_VERSION 10
 int lwg_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -181,9 +181,10 @@ int lwg_conv_transpose4_is_one_grid(const LwgConvArgs* args);
  * ConvTranspose2d(4, 2, 1) is a 2 x 2-tap convolution - 9 multiplies per 2 x 2 outputs of a parity instead of 16.  args = the parity-(0,0) launch
  * description as above (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2H, YW = 2W, LWG_EPI_NONE, one input) with Cin % 16 == 0, N % 32 == 0,
  * the image < 3 GiB, ydt = LWG_DT_F32 or LWG_DT_F32_Q4, any activation of the forward path; args->w = the transformed-weight panel
- * Upk[4][Cin/8][4][2][N][12]: element (parity 2 py + px, s, kk, kh, n, 3 xi + nu) = sgn (G g G^T)[xi][nu] for input channel 8 s + 2 kk + kh and output
+ * Upk[4][Cin/8][4][2][9 N] (144 Cin N bytes; ABI 10) - per (parity 2 py + px, s, kk, kh) [N][4] products 0-3, [N][4] products 4-7, [N] product 8: every load of
+ * the kernel reads contiguous memory -, product 3 xi + nu of column n = sgn (G g G^T)[xi][nu] for input channel 8 s + 2 kk + kh and output
  * column n, g[r][q] = w[c][n][3 - py - 2 r][3 - px - 2 q] (the parity's 2 x 2 sub-kernel), G = [[1,0],[1,1],[0,1]], sgn = (py == 1 && xi == 0 ? -1 : 1)
- * (px == 1 && nu == 0 ? -1 : 1); elements 9 .. 11 are padding.  fp32-grade results, not the bits of the call above: part of the "winograd" precision
+ * (px == 1 && nu == 0 ? -1 : 1).  fp32-grade results, not the bits of the call above: part of the "winograd" precision
  * mode of ipercore_amd.ops; a frame's result does not depend on the batch it is launched in. */
 int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* args, lwg_stream_t stream);
 

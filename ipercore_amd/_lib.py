@@ -163,7 +163,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.lwg_abi_version() != 9:
+        if handle.lwg_abi_version() != 10:
             raise RuntimeError("liblwg_hip.so ABI version mismatch")
         _lib = handle
     return _lib

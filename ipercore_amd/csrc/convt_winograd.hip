@@ -11,8 +11,8 @@
 // products of parity w % 4 for the 32 patches of tile w / 4 (9 accumulator tiles of 32 x 32 = 144 VGPRs, rows = output channels): the output
 // transform A^T M A is register-local; the block's outputs then cross LDS once so that the global stores are whole 128-byte (NHWC) / 512-byte
 // (channel-quad planes) runs.
-// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights (padded to twelve) as three 16-byte buffer loads from the
-// panel Upk[4][Cin/8][4][2][N][12] (two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
+// A K stage is 8 input channels = four k-pairs; per k-pair a lane loads its nine weights as two 16-byte and one 4-byte buffer loads from the
+// panel Upk[4][Cin/8][4][2][9 N] (contiguous per load instruction; two k-pairs ahead, four register sets) and reads nine V fragments (4 bytes each) from LDS.  The raw 18 x 18 x 8
 // halo goes global -> registers (three stages ahead) -> raw[s % 2]; every thread transforms ONE (patch, channel) 4 x 4 -> 25 values (27 subtractions)
 // from raw[(s + 1) % 2] into Vs[(s + 1) % 2] beside the MFMAs of k-pairs 0 and 1; one barrier per stage, in the middle of k-pair 3.
 // Rounding: the transforms only add / subtract (no 1/2 factors as in F(2x2, 3x3)); panel entries are sums of up to four weights formed in fp64
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     int blk = blockIdx.x;
     const int nst = Cin / KS;                                // even (host: Cin % 16 == 0)
     CTS(0);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(192u * (unsigned)Cin * (unsigned)N), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)(144u * (unsigned)Cin * (unsigned)N), 0x00020000);
     const int par = wid & 3, py = par >> 1, px = par & 1;    // this wave's output parity
     const int pt = wid >> 2;                                  // ... and its 32-patch tile
     floatx16 acc[9];                                         // [product 3 xi + nu]
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
     int b, x0, y0, n0;
     __amdgpu_buffer_rsrc_t rx0;
     unsigned voff0[2];
-    unsigned uvoff;
+    unsigned uvoff, uvoffc;                                  // this lane's column of the panel: the 16-byte parts, the ninth product
     // XCD-aware block order (as conv_winograd4.hip; persistent grids of a multiple of 8 workgroups, N / 32 = 2, 4 or 8 column blocks): workgroup w runs on
     // XCD w % 8 and keeps ONE column block, (w % 8) % ncb, for the whole launch (an XCD's L2 holds that column block's panel only), while the ncb
     // workgroups (w % 8) / ncb, w / 8 of adjacent XCDs walk the same tile sequence in step: a tile's halo comes from HBM once instead of ncb times
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
             const bool in = i < PLANE * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
             voff0[q] = in ? (unsigned)((gy * W + gx) * Cin + 4 * half) * 4u : WINO_OOB;
         }
-        uvoff = (unsigned)((((lane >> 5) * N + n0 + (lane & 31)) * 12) * 4);
+        uvoff = (unsigned)(((lane >> 5) * 9 * N + 4 * (n0 + (lane & 31))) * 4);
+        uvoffc = (unsigned)(((lane >> 5) * 9 * N + 8 * N + n0 + (lane & 31)) * 4);
     };
     setup(blk);
     int wst[2];                                              // the halo elements' LDS slot (threads without one store their zeros into dead LDS)
@@ -165,11 +166,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[k * PLANE] = v[k];
     };
-    // weights: lane = (k-half lane / 32, channel lane % 32); element (parity, stage, k-pair, k-half, n) = twelve floats (nine products + padding)
-    floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 + padding]: loaded TWO k-pairs ahead
-    const unsigned ukk = (unsigned)N * 96u;                  // bytes between two k-pairs: [2][N][12] floats
+    // weights: lane = (k-half lane / 32, channel lane % 32); element (parity, stage, k-pair, k-half) = 9 N floats: [N][4] products 0-3, [N][4] products 4-7,
+    // [N] product 8 - every load instruction reads contiguous memory (as conv_winograd4.hip; the first layout, [N][12] with three of padding, made a
+    // half-wave's 16-byte load span 1.5 KB for 512 useful bytes)
+    floatx4 ufr[4][3];                                       // [register set = k-pair][products 0-3 | 4-7 | 8 (element 0)]: loaded TWO k-pairs ahead
+    const unsigned ukk = (unsigned)N * 72u;                  // bytes between two k-pairs: [2][9 N] floats
     const unsigned upar = (unsigned)par * (unsigned)nst * 4u * ukk;
-    auto uld1 = [&](int st, int kk, int j) -> floatx4 { return ctw_buf_load(ru, uvoff + 16u * j, upar + (unsigned)(st * 4 + kk) * ukk); };
+    const unsigned ubo = (unsigned)N * 16u;                  // bytes from part A to part B
+    auto uld1 = [&](int st, int kk, int j) -> floatx4 {
+        const unsigned so = upar + (unsigned)(st * 4 + kk) * ukk;
+        if (j < 2) return ctw_buf_load(ru, uvoff, so + (j ? ubo : 0u));
+        floatx4 r;
+        r[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (int)uvoffc, (int)so, 0));
+        r[1] = r[2] = r[3] = 0.f;
+        return r;
+    };
     const int patch = tid & 63, tc = tid >> 6;
     const int pty = patch >> 3, ptx = patch & 7;
     unsigned dbs[2];                                         // this thread's 4 x 4 input patch inside raw[u] (float index into smem)
@@ -487,9 +498,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void lwg_convt_winograd_kernel(const
 
 // args: the parity-(0, 0) launch description of lwg_conv_transpose4_nhwc_f32 (ntaps = 4, stride = 1, omul = 2, OH = H, OW = W, YH = 2 H, YW = 2 W,
 // LWG_EPI_NONE, one input) with Cin % 16 == 0, N % 32 == 0, ydt LWG_DT_F32 or LWG_DT_F32_Q4, EXCEPT args->w = the Winograd panel
-// Upk[4][Cin/8][4][2][N][12]: element (parity 2 py + px, stage s, k-pair kk, k-half kh, column n, product 3 xi + nu) =
+// Upk[4][Cin/8][4][2][9 N] ([N][4] products 0-3, [N][4] products 4-7, [N] product 8 per (parity 2 py + px, stage s, k-pair kk, k-half kh)): product 3 xi + nu of column n =
 // sgn * (G g G^T)[xi][nu] with g[r][q] = w[c][n][3 - py - 2 r][3 - px - 2 q] the parity's 2 x 2 sub-kernel of input channel c = 8 s + 2 kk + kh,
-// G = [[1,0],[1,1],[0,1]] and sgn = (py == 1 && xi == 0 ? -1 : 1) * (px == 1 && nu == 0 ? -1 : 1); products 9 .. 11 are padding (zero).
+// G = [[1,0],[1,1],[0,1]] and sgn = (py == 1 && xi == 0 ? -1 : 1) * (px == 1 && nu == 0 ? -1 : 1).
 extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!pa) return (int)hipErrorInvalidValue;
@@ -499,7 +510,7 @@ extern "C" int lwg_conv_transpose4_winograd_f32(const LwgConvArgs* pa, lwg_strea
         (a.ydt != LWG_DT_F32 && a.ydt != LWG_DT_F32_Q4) || a.M != a.B * a.H * a.W || a.epi != LWG_EPI_NONE || a.act == LWG_ACT_RELU_MASK ||
         a.ycoff < 0 || (a.ycoff % 4) != 0 || (a.YC % 4) != 0 || a.ycoff + a.N > a.YC)
         return (int)hipErrorInvalidValue;
-    if ((unsigned long long)a.H * a.W * a.C0 * 4ull >= (unsigned long long)WINO_OOB || 192ull * a.C0 * a.N >= 0xffffffffull) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)a.H * a.W * a.C0 * 4ull >= (unsigned long long)WINO_OOB || 144ull * a.C0 * a.N >= 0xffffffffull) return (int)hipErrorInvalidValue;
     // (an output image is one buffer of the store path: byte offsets + the sixteen row-pair offsets of a block stay below the out-of-range marker)
     if ((unsigned long long)a.YH * a.YW * a.YC * 4ull + 32ull * a.YW * a.YC * 4ull >= (unsigned long long)WINO_OOB) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(BIAS_OFF + 32) * 4;

@@ -408,7 +408,7 @@ def _parity_specs_ok(specs):
 
 def _wwino_t(specs):
     """The transformed-weight panel of lwg_conv_transpose4_winograd_f32 from the four parity GEMM panels, built once per layer (a weight transform at
-    load time, like the packing itself): Upk[4][Cin/8][4][2][N][12], element (2 py + px, s, kk, kh, n, 3 xi + nu) = sgn (G g G^T)[xi][nu] for input
+    load time, like the packing itself): Upk[4][Cin/8][4][2][9 N] - per (parity 2 py + px, s, kk, kh) [N][4] products 0-3, [N][4] products 4-7, [N] product 8 -, product 3 xi + nu of column n = sgn (G g G^T)[xi][nu] for input
     channel 8 s + 2 kk + kh - g the parity's 2 x 2 sub-kernel in input-offset order, G = [[1,0],[1,1],[0,1]], formed in fp64 and rounded once; the
     sign (-1 where a parity-1 row / column takes the form the parity-0 one already holds negated) is documented in include/lwg_hip.h."""
     s0 = specs[0]
@@ -431,10 +431,10 @@ def _wwino_t(specs):
         if px:
             u[:, 0] = -u[:, 0]
         parts.append(u.reshape(9, Cin, N))
-    U9 = torch.stack(parts)                                                      # (4, 9, Cin, N)
-    U = torch.zeros(4, Cin, N, 12, dtype=torch.float32, device=s0.w.device)
-    U[..., :9] = U9.permute(0, 2, 3, 1).float()
-    U = U.view(4, Cin // 8, 4, 2, N, 12).contiguous()                            # c = 8 s + 2 kk + kh
+    U9 = torch.stack(parts).float()                                              # (4, 9, Cin, N)
+    # per (parity, input channel): 9 N floats - [N][4] products 0-3, [N][4] products 4-7, [N] product 8 (every load of the kernel reads contiguous memory)
+    U = torch.cat([U9[:, 0:4].permute(0, 2, 3, 1).reshape(4, Cin, 4 * N), U9[:, 4:8].permute(0, 2, 3, 1).reshape(4, Cin, 4 * N), U9[:, 8]], dim=2)
+    U = U.view(4, Cin // 8, 4, 2, 9 * N).contiguous()                            # c = 8 s + 2 kk + kh
     s0._wwino_t = U
     return U
 

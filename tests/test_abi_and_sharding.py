@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/lwg_hip.h but not exported"
     assert set(_lib._SIGS) == set(names)
-    assert _lib.lib().lwg_abi_version() == 9
+    assert _lib.lib().lwg_abi_version() == 10
     assert _lib.lib().lwg_rasterize_ws_bytes(2, 13776, 512) == 2 * 13776 * 88 + 2 * 256 * 4 + 2 * 256 * 13776 * 4   # records + boxes, then 16 x 16 bins of 32 pixels: cursors + worst-case lists
 
 

@@ -238,7 +238,7 @@ def test_winograd_transpose_panel_and_algorithm_cpu():
     (ops._wwino_t, from the four parity GEMM panels): 25 transformed values per 4 x 4 input patch and channel (row / column forms r0-r1, r1, r2-r1, r2,
     r3-r2), product (xi, nu) of parity (py, px) = form (2 py + xi, 2 px + nu) x panel element 3 xi + nu (the sign of a shared form lives in the panel),
     Y[a][b] = the sum of the four products around (a, b) - equal to torch's transposed convolution on a ragged size; panel layout
-    [4][Cin/8][4][2][N][12] with the padding entries zero."""
+    [4][Cin/8][4][2][9 N] ([N][4] products 0-3, [N][4] products 4-7, [N] product 8: every load of the kernel reads contiguous memory)."""
     torch.manual_seed(0)
     B, H, W, Cin, N = 1, 6, 5, 32, 64
     w, b, x = torch.randn(Cin, N, 4, 4) * 0.1, torch.randn(N) * 0.1, torch.randn(B, H, W, Cin)
@@ -246,8 +246,10 @@ def test_winograd_transpose_panel_and_algorithm_cpu():
     specs = packing.pack_conv_transpose(w, b)
     assert ops._parity_specs_ok(specs) and not ops._parity_specs_ok(specs[::-1])
     U = ops._wwino_t(specs)
-    assert U.shape == (4, Cin // 8, 4, 2, N, 12) and U.dtype == torch.float32 and float(U[..., 9:].abs().max()) == 0.0 and ops._wwino_t(specs) is U
-    Uc = U.double().permute(0, 1, 2, 3, 5, 4).reshape(4, Cin, 12, N)                       # [parity][c = 8 s + 2 kk + kh][product][n]
+    assert U.shape == (4, Cin // 8, 4, 2, 9 * N) and U.dtype == torch.float32 and ops._wwino_t(specs) is U
+    Uf = U.double().reshape(4, Cin, 9 * N)                                                  # [parity][c = 8 s + 2 kk + kh][ [N][4] | [N][4] | [N] ]
+    Uc = torch.cat([Uf[..., :4 * N].reshape(4, Cin, N, 4).permute(0, 1, 3, 2), Uf[..., 4 * N:8 * N].reshape(4, Cin, N, 4).permute(0, 1, 3, 2),
+                    Uf[..., 8 * N:].reshape(4, Cin, 1, N)], dim=2)                          # [parity][c][product 0..8][n]
     xp = torch.zeros(H + 4, W + 4, Cin, dtype=torch.float64)
     xp[1:H + 1, 1:W + 1] = x[0].double()                                                    # xp[r] = x[r - 1]: the patch of input rows i - 1 .. i + 2 is xp[i : i + 4]
     y = torch.zeros(2 * H, 2 * W, N, dtype=torch.float64)
