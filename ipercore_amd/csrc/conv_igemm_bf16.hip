@@ -23,6 +23,9 @@
 // Epilogues: bias, ReLU / tanh / sigmoid, residual add, SPADE's IN(x) * (1 + gamma) + beta - all read / written as bf16.
 #include "lwg_common.h"
 #include "lwg_conv_args.h"
+#ifndef LWG_BF16_NT_ST
+#define LWG_BF16_NT_ST 0     // lab: the epilogue's 16-byte output stores non-temporal (worth 0.5 % in conv_winograd4.hip)
+#endif
 #include "lwg_conv_slices.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -93,8 +96,13 @@ __device__ __forceinline__ void lwg_bf16_epilogue_a(const LwgConvArgs& a, floatx
                 st[h][2 + d] = sres[1];
             }
         if (live) {
+#if LWG_BF16_NT_ST
+            __builtin_nontemporal_store(st[0], reinterpret_cast<uintx4*>(p16 + 16 * khalf));
+            __builtin_nontemporal_store(st[1], reinterpret_cast<uintx4*>(p16 + 16 * khalf + 8));
+#else
             *reinterpret_cast<uintx4*>(p16 + 16 * khalf) = st[0];
             *reinterpret_cast<uintx4*>(p16 + 16 * khalf + 8) = st[1];
+#endif
         }
     };
     if constexpr (TN == 1 && SPATIAL != 0) {
